@@ -1,0 +1,86 @@
+"""ctypes binding of ``lib/libgptst_hip.so`` — prototypes are parsed from ``include/gptst_hip.h`` so the header
+is the single source of truth.  There is NO fallback: a missing library raises ``ImportError`` (the product
+path must fail loudly without its HIP extension).  ``import torch`` must come first so the library binds to the
+HIP runtime torch already loaded (one runtime per process)."""
+import ctypes
+import os
+import re
+
+import torch  # noqa: F401  (loads libamdhip64 first)
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(HERE, "lib", "libgptst_hip.so")
+HEADER = os.path.join(os.path.dirname(HERE), "include", "gptst_hip.h")
+
+_CT = {"int": ctypes.c_int, "long": ctypes.c_long, "float": ctypes.c_float, "double": ctypes.c_double,
+       "int64_t": ctypes.c_int64, "uint64_t": ctypes.c_uint64, "size_t": ctypes.c_size_t}
+
+
+def parse_header(path=HEADER):
+    """-> {name: [ctype per argument]} for every ``int gptst_*(...);`` declaration."""
+    txt = open(path).read()
+    txt = re.sub(r"/\*.*?\*/", "", txt, flags=re.S)
+    txt = re.sub(r"//[^\n]*", "", txt)
+    protos = {}
+    for m in re.finditer(r"\bint\s+(gptst_\w+)\s*\(([^)]*)\)\s*;", txt):
+        name, args = m.group(1), m.group(2).strip()
+        types = []
+        if args and args != "void":
+            for a in args.split(","):
+                a = a.strip()
+                if "*" in a:
+                    types.append(ctypes.c_void_p)
+                else:
+                    base = a.replace("const", "").split()
+                    types.append(_CT[base[0]])
+        protos[name] = types
+    return protos
+
+
+class GptstError(RuntimeError):
+    pass
+
+
+class _Lib:
+    def __init__(self):
+        if not os.path.exists(LIB_PATH):
+            raise ImportError("gpt-st_amd: %s not built — run `python -m gptst_amd.build` (no CPU fallback exists)" % LIB_PATH)
+        self._dll = ctypes.CDLL(LIB_PATH)
+        self.protos = parse_header()
+        for name, types in self.protos.items():
+            fn = getattr(self._dll, name)          # AttributeError if the header declares a missing symbol
+            fn.argtypes = types
+            fn.restype = ctypes.c_int
+            setattr(self, "_raw_" + name, fn)
+        if self._raw_gptst_abi_version() != 1:
+            raise ImportError("gpt-st_amd: ABI version mismatch")
+
+    def call(self, name, *args):
+        rc = getattr(self, "_raw_" + name)(*args)
+        if rc != 0:
+            raise GptstError("%s failed with code %d" % (name, rc))
+
+    def value(self, name, *args):
+        return getattr(self, "_raw_" + name)(*args)
+
+
+_lib = None
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        _lib = _Lib()
+    return _lib
+
+
+def ptr(t):
+    """Device pointer of a contiguous fp32/int tensor (None -> NULL)."""
+    if t is None:
+        return None
+    assert t.is_contiguous(), "gpt-st_amd kernels need contiguous tensors"
+    return t.data_ptr()
+
+
+def stream():
+    return torch.cuda.current_stream().cuda_stream

@@ -1,0 +1,229 @@
+// "Customised parameter" contractions of GPT-ST on fp32 MFMA (gfx950).
+//
+//   apply :  out[g,m,:] = epi( pro(A)[g,m,:] @ W[g] (+ bias[g]) (+ resid[g,m,:]) )
+//   wgrad :  dW[g]      = sum_m A[g,m,:]^T  pro(D)[g,m,:]
+//
+// replacing the reference's  einsum('btni,btio->btno') / einsum('btni,nio->btno')  + bias + residual + LeakyReLU
+// (GPTST.py:26-27,31-32,139-141,162-163), nn.Linear C->C (GPTST.py:102) and their autograd backward.
+// Activations are (B*T*N, C) row-major.  A "group" g shares one C x C weight:
+//   mode 0 (TIME)   g = (b,t), rows m = n      : row = g*N + m          (time-conditioned weights, hyperTem / MLP_RL)
+//   mode 1 (NODE)   g = n,     rows m = (b,t)  : row = m*N + g          (node-conditioned weights, cap / MLP_RL)
+//   mode 2 (SHARED) one group, rows = all                                (nn.Linear)
+#include "mfma_tile.h"
+
+enum { PRO_NONE = 0, PRO_DPRE = 1 };          // PRO_DPRE: a = A * lrelu'(A2)   (A = dOut, A2 = layer output)
+enum { EPI_PLAIN = 0, EPI_RES_LRELU = 1 };     // EPI_RES_LRELU: lrelu(acc + bias + resid)
+
+struct RowMap {
+    int G, M;
+    long rs_g, rs_m;
+};
+
+__host__ __device__ inline RowMap make_rowmap(int mode, int BT, int N) {
+    RowMap r;
+    if (mode == 0) { r.G = BT; r.M = N; r.rs_g = N; r.rs_m = 1; }
+    else if (mode == 1) { r.G = N; r.M = BT; r.rs_g = 1; r.rs_m = N; }
+    else { r.G = 1; r.M = BT * N; r.rs_g = 0; r.rs_m = 1; }
+    return r;
+}
+
+template <int C, int PRO, int EPI>
+__global__ __launch_bounds__(256) void apply_kernel(const float* __restrict__ A, const float* __restrict__ A2,
+                                                    const float* __restrict__ W, long w_gstride, int transw,
+                                                    const float* __restrict__ bias, const float* __restrict__ resid,
+                                                    float* __restrict__ out, float* __restrict__ colsum, RowMap rm) {
+    using T = Tile<C>;
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    float* Wl = smem;                                   // C*C
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    float* tile = smem + C * C + wave * T::TILE_FLOATS;
+    const int g = blockIdx.x;
+    load_w_lds<C>(Wl, W + (size_t)g * w_gstride, transw, tid, 256);
+    __syncthreads();
+
+    const int ntiles = (rm.M + 31) / 32;
+    float cs[C / 64];
+#pragma unroll
+    for (int u = 0; u < C / 64; ++u) cs[u] = 0.f;
+
+    for (int t = blockIdx.y * 4 + wave; t < ntiles; t += gridDim.y * 4) {
+        const int m0 = t * 32;
+        // ---- stage A tile (coalesced float4 rows) ----
+#pragma unroll
+        for (int it = 0; it < T::F4_PER_LANE; ++it) {
+            const int f = it * 64 + lane;
+            const int r = f / T::F4_PER_ROW, c4 = f % T::F4_PER_ROW;
+            float4 v = f4zero();
+            if (m0 + r < rm.M) {
+                const size_t off = ((size_t)g * rm.rs_g + (size_t)(m0 + r) * rm.rs_m) * C + 4 * c4;
+                v = ld4(A + off);
+                if (PRO == PRO_DPRE) {
+                    const float4 o = ld4(A2 + off);
+                    v.x *= lrelu_grad_from_out(o.x); v.y *= lrelu_grad_from_out(o.y);
+                    v.z *= lrelu_grad_from_out(o.z); v.w *= lrelu_grad_from_out(o.w);
+                }
+            }
+            st4(tile + r * T::PITCH + 4 * c4, v);
+        }
+        if (colsum != nullptr) {      // column sums of the staged tile (bias gradient)
+#pragma unroll
+            for (int u = 0; u < C / 64; ++u) {
+                float s = 0.f;
+#pragma unroll 8
+                for (int r = 0; r < 32; ++r) s += tile[r * T::PITCH + u * 64 + lane];
+                cs[u] += s;
+            }
+        }
+        f32x16 acc[T::NCT];
+        mfma_tile<C>(tile, Wl, acc, lane);
+        acc_to_tile<C>(tile, acc, lane);
+        // ---- epilogue: row-major float4 ----
+#pragma unroll
+        for (int it = 0; it < T::F4_PER_LANE; ++it) {
+            const int f = it * 64 + lane;
+            const int r = f / T::F4_PER_ROW, c4 = f % T::F4_PER_ROW;
+            if (m0 + r < rm.M) {
+                const size_t off = ((size_t)g * rm.rs_g + (size_t)(m0 + r) * rm.rs_m) * C + 4 * c4;
+                float4 y = ld4(tile + r * T::PITCH + 4 * c4);
+                if (bias != nullptr) y = f4add(y, ld4(bias + (size_t)g * C + 4 * c4));
+                if (EPI == EPI_RES_LRELU) {
+                    y = f4add(y, ld4(resid + off));
+                    y.x = lrelu(y.x); y.y = lrelu(y.y); y.z = lrelu(y.z); y.w = lrelu(y.w);
+                }
+                st4(out + off, y);
+            }
+        }
+    }
+    if (colsum != nullptr) {
+#pragma unroll
+        for (int u = 0; u < C / 64; ++u) atomicAdd(colsum + (size_t)g * C + u * 64 + lane, cs[u]);
+    }
+}
+
+// dW[g] (C x C, [i][o]) = sum_m A[row(g,m)][i] * D[row(g,m)][o];  both operands come straight from global memory:
+// for MFMA step s the half-wave h reads row m = 2s+h, 32 consecutive floats (128 B) of each operand.
+template <int C, int PRO>
+__global__ __launch_bounds__(256) void wgrad_kernel(const float* __restrict__ A, const float* __restrict__ D,
+                                                    const float* __restrict__ D2, float* __restrict__ dW,
+                                                    RowMap rm, int rows_per_split) {
+    constexpr int NCT = C / 32;
+    constexpr int TPW = NCT * NCT / 4;                 // output tiles per wave (C=64: 1, C=128: 4)
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int j = lane & 31, h = lane >> 5;
+    const int g = blockIdx.x, sp = blockIdx.y;
+    const int mbeg = sp * rows_per_split;
+    const int mend = min(rm.M, mbeg + rows_per_split);
+    const int it = (wave * TPW) / NCT;                 // A column tile (input channel block) of this wave
+    f32x16 acc[TPW];
+#pragma unroll
+    for (int u = 0; u < TPW; ++u)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[u][r] = 0.f;
+
+    for (int m = mbeg + h; m < mend + h; m += 2) {     // both halves run the same trip count
+        float a = 0.f;
+        float d[TPW];
+#pragma unroll
+        for (int u = 0; u < TPW; ++u) d[u] = 0.f;
+        if (m < mend) {
+            const size_t off = ((size_t)g * rm.rs_g + (size_t)m * rm.rs_m) * C;
+            a = A[off + it * 32 + j];
+#pragma unroll
+            for (int u = 0; u < TPW; ++u) {
+                const int jt = (wave * TPW + u) % NCT;
+                float dv = D[off + jt * 32 + j];
+                if (PRO == PRO_DPRE) dv *= lrelu_grad_from_out(D2[off + jt * 32 + j]);
+                d[u] = dv;
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < TPW; ++u) acc[u] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, d[u], acc[u], 0, 0, 0);
+    }
+    float* o = dW + ((size_t)sp * rm.G + g) * C * C;
+#pragma unroll
+    for (int u = 0; u < TPW; ++u) {
+        const int jt = (wave * TPW + u) % NCT;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int row = (r & 3) + 8 * (r >> 2) + 4 * h;
+            o[(size_t)(it * 32 + row) * C + jt * 32 + j] = acc[u][r];
+        }
+    }
+}
+
+template <int C>
+static int launch_apply(const float* A, const float* A2, const float* W, long w_gstride, int transw, const float* bias,
+                        const float* resid, float* out, float* colsum, RowMap rm, int pro, int epi, hipStream_t st) {
+    const int ntiles = (rm.M + 31) / 32;
+    int gy = (ntiles + 3) / 4;
+    if (rm.G == 1) gy = min(gy, 1024);                 // shared weight: many row chunks, W staged once per block
+    else gy = min(gy, 2);
+    if (gy < 1) gy = 1;
+    dim3 grid(rm.G, gy), block(256);
+    const size_t smem = (size_t)(C * C + 4 * Tile<C>::TILE_FLOATS) * sizeof(float);
+#define LAUNCH(P, E)                                                                                              \
+    hipLaunchKernelGGL((apply_kernel<C, P, E>), grid, block, smem, st, A, A2, W, w_gstride, transw, bias, resid, \
+                       out, colsum, rm)
+    if (pro == PRO_NONE && epi == EPI_PLAIN) LAUNCH(PRO_NONE, EPI_PLAIN);
+    else if (pro == PRO_NONE && epi == EPI_RES_LRELU) LAUNCH(PRO_NONE, EPI_RES_LRELU);
+    else if (pro == PRO_DPRE && epi == EPI_PLAIN) LAUNCH(PRO_DPRE, EPI_PLAIN);
+    else return GPTST_EARG;
+#undef LAUNCH
+    GPTST_CHECK_LAUNCH();
+    return GPTST_OK;
+}
+
+static int g_smem_attr_done = 0;
+template <int C>
+static void raise_smem_limits() {
+    const int smem = (int)((C * C + 4 * Tile<C>::TILE_FLOATS) * sizeof(float));
+    hipFuncSetAttribute((const void*)apply_kernel<C, PRO_NONE, EPI_PLAIN>, hipFuncAttributeMaxDynamicSharedMemorySize, smem);
+    hipFuncSetAttribute((const void*)apply_kernel<C, PRO_NONE, EPI_RES_LRELU>, hipFuncAttributeMaxDynamicSharedMemorySize, smem);
+    hipFuncSetAttribute((const void*)apply_kernel<C, PRO_DPRE, EPI_PLAIN>, hipFuncAttributeMaxDynamicSharedMemorySize, smem);
+}
+
+extern "C" int gptst_apply(const float* A, const float* A2, const float* W, int w_per_group, int transw,
+                           const float* bias, const float* resid, float* out, float* colsum, int mode, int pro,
+                           int epi, int BT, int N, int C, void* stream) {
+    if (!A || !W || !out || BT <= 0 || N <= 0) return GPTST_EARG;
+    if (pro == PRO_DPRE && !A2) return GPTST_EARG;
+    if (epi == EPI_RES_LRELU && !resid) return GPTST_EARG;
+    if (!g_smem_attr_done) { raise_smem_limits<64>(); raise_smem_limits<128>(); g_smem_attr_done = 1; }
+    RowMap rm = make_rowmap(mode, BT, N);
+    const long gs = w_per_group ? (long)C * C : 0;
+    hipStream_t st = (hipStream_t)stream;
+    if (C == 64) return launch_apply<64>(A, A2, W, gs, transw, bias, resid, out, colsum, rm, pro, epi, st);
+    if (C == 128) return launch_apply<128>(A, A2, W, gs, transw, bias, resid, out, colsum, rm, pro, epi, st);
+    return GPTST_ESHAPE;
+}
+
+// dW has room for nsplit * G matrices; returns nsplit through *nsplit_out (consumers sum the splits).
+extern "C" int gptst_wgrad_nsplit(int mode, int BT, int N) {
+    RowMap rm = make_rowmap(mode, BT, N);
+    if (mode == 2) return (rm.M + 255) / 256;          // shared weight: 256-row chunks
+    if (rm.G >= 256) return 1;
+    int want = (512 + rm.G - 1) / rm.G;                // aim for >= 512 workgroups
+    int maxs = (rm.M + 63) / 64;
+    return want < maxs ? want : maxs;
+}
+
+extern "C" int gptst_wgrad(const float* A, const float* D, const float* D2, float* dW, int mode, int pro, int BT, int N,
+                           int C, void* stream) {
+    if (!A || !D || !dW) return GPTST_EARG;
+    if (pro == PRO_DPRE && !D2) return GPTST_EARG;
+    RowMap rm = make_rowmap(mode, BT, N);
+    const int ns = gptst_wgrad_nsplit(mode, BT, N);
+    int rps = (rm.M + ns - 1) / ns;
+    rps = (rps + 1) & ~1;                               // even, so a k-step never straddles a split
+    dim3 grid(rm.G, ns), block(256);
+    hipStream_t st = (hipStream_t)stream;
+    if (C == 64) {
+        if (pro == PRO_DPRE) hipLaunchKernelGGL((wgrad_kernel<64, PRO_DPRE>), grid, block, 0, st, A, D, D2, dW, rm, rps);
+        else hipLaunchKernelGGL((wgrad_kernel<64, PRO_NONE>), grid, block, 0, st, A, D, D2, dW, rm, rps);
+    } else if (C == 128) {
+        if (pro == PRO_DPRE) hipLaunchKernelGGL((wgrad_kernel<128, PRO_DPRE>), grid, block, 0, st, A, D, D2, dW, rm, rps);
+        else hipLaunchKernelGGL((wgrad_kernel<128, PRO_NONE>), grid, block, 0, st, A, D, D2, dW, rm, rps);
+    } else return GPTST_ESHAPE;
+    GPTST_CHECK_LAUNCH();
+    return GPTST_OK;
+}

@@ -1,0 +1,51 @@
+// Shared device helpers for the gfx950 (CDNA4, wave64) kernels of the GPT-ST pretraining path.
+// Everything here is fp32: the reference computes in fp32 and parity is 1e-4 rel.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#define GPTST_OK 0
+#define GPTST_EARG (-1)      // bad argument (shape / null pointer)
+#define GPTST_ESHAPE (-2)    // shape not supported by the compiled kernels
+#define GPTST_EWS (-3)       // workspace too small
+
+#define LRELU_SLOPE 0.01f
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+#define GPTST_CHECK_LAUNCH()                                  \
+    do {                                                      \
+        hipError_t e__ = hipGetLastError();                   \
+        if (e__ != hipSuccess) return (int)e__;               \
+    } while (0)
+
+__device__ __forceinline__ float lrelu(float x) { return x > 0.f ? x : LRELU_SLOPE * x; }
+// derivative selected by the sign of the OUTPUT (slope > 0 keeps the sign; x == 0 -> slope, as ATen).
+__device__ __forceinline__ float lrelu_grad_from_out(float out) { return out > 0.f ? 1.f : LRELU_SLOPE; }
+
+__device__ __forceinline__ float4 ld4(const float* p) { return *reinterpret_cast<const float4*>(p); }
+__device__ __forceinline__ void st4(float* p, float4 v) { *reinterpret_cast<float4*>(p) = v; }
+__device__ __forceinline__ float4 f4zero() { return make_float4(0.f, 0.f, 0.f, 0.f); }
+__device__ __forceinline__ float4 f4add(float4 a, float4 b) { return make_float4(a.x + b.x, a.y + b.y, a.z + b.z, a.w + b.w); }
+__device__ __forceinline__ float4 f4fma(float s, float4 a, float4 c) {
+    return make_float4(fmaf(s, a.x, c.x), fmaf(s, a.y, c.y), fmaf(s, a.z, c.z), fmaf(s, a.w, c.w));
+}
+__device__ __forceinline__ float f4dot(float4 a, float4 b) { return fmaf(a.x, b.x, fmaf(a.y, b.y, fmaf(a.z, b.z, a.w * b.w))); }
+
+// xor-butterfly sum over groups of W consecutive lanes (W power of two <= 64); every lane gets the total.
+template <int W>
+__device__ __forceinline__ float group_sum(float v) {
+#pragma unroll
+    for (int o = W / 2; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+template <int W>
+__device__ __forceinline__ float group_max(float v) {
+#pragma unroll
+    for (int o = W / 2; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+    return v;
+}
+
+// squash scale for a vector with squared norm sq:  y = x * sq / ((1+sq) * (sqrt(sq)+1e-8))   (reference GPTST.py:36-39)
+__device__ __forceinline__ float squash_scale(float sq) { return (sq / (1.f + sq)) / (sqrtf(sq) + 1e-8f); }

@@ -1,0 +1,82 @@
+// fp32 MFMA tile primitives (v_mfma_f32_32x32x2_f32) for the C x C "customised parameter" contractions.
+//
+// One wave computes a 32-row x C-col output tile  D = A(32 x C) * W(C x C):
+//   * the A tile lives in a wave-private LDS region, row-major with pitch C+4 floats (conflict-free
+//     ds_read_b128 for the operand fetch, 16-byte aligned rows for coalesced float4 staging);
+//   * W lives in LDS as [k][C] (shared by the workgroup's waves);
+//   * K is walked in a permuted order so that each lane fetches its A operands as one float4 per four
+//     MFMAs: MFMA step s = 4q+jj uses k = 8q + 4h + jj for lane-half h = lane>>5 (A and B agree).
+// Operand / result maps (cdna_hip_programming.md §3):  A: lane l holds A[i=l&31][k=l>>5];
+//   B: lane l holds B[k=l>>5][j=l&31];  D reg r: col j = l&31, row i = (r&3) + 8*(r>>2) + 4*(l>>5).
+#pragma once
+#include "common.h"
+
+template <int C>
+struct Tile {
+    static constexpr int PITCH = C + 4;
+    static constexpr int NCT = C / 32;           // 32-wide column tiles
+    static constexpr int F4_PER_ROW = C / 4;
+    static constexpr int TILE_FLOATS = 32 * PITCH;
+    static constexpr int F4_PER_LANE = 32 * F4_PER_ROW / 64;   // float4 slots each lane stages
+};
+
+// D(32 x C) = tile(32 x C) * Wl(C x C); acc[ct] holds column tile ct.
+template <int C>
+__device__ __forceinline__ void mfma_tile(const float* __restrict__ tile, const float* __restrict__ Wl,
+                                          f32x16 (&acc)[Tile<C>::NCT], int lane) {
+    constexpr int P = Tile<C>::PITCH;
+    constexpr int NCT = Tile<C>::NCT;
+    const int i = lane & 31, h = lane >> 5;
+#pragma unroll
+    for (int ct = 0; ct < NCT; ++ct)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[ct][r] = 0.f;
+    const float* arow = tile + i * P + 4 * h;
+    const float* wcol = Wl + 4 * h * C + i;
+#pragma unroll 2
+    for (int q = 0; q < C / 8; ++q) {
+        const float4 a4 = ld4(arow + 8 * q);
+        const float av[4] = {a4.x, a4.y, a4.z, a4.w};
+#pragma unroll
+        for (int jj = 0; jj < 4; ++jj) {
+            const float* wk = wcol + (8 * q + jj) * C;
+#pragma unroll
+            for (int ct = 0; ct < NCT; ++ct)
+                acc[ct] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[jj], wk[ct * 32], acc[ct], 0, 0, 0);
+        }
+    }
+}
+
+// write the accumulators back into the (wave-private) tile region as row-major [32][PITCH]
+template <int C>
+__device__ __forceinline__ void acc_to_tile(float* __restrict__ tile, const f32x16 (&acc)[Tile<C>::NCT], int lane) {
+    constexpr int P = Tile<C>::PITCH;
+    const int j = lane & 31, h = lane >> 5;
+#pragma unroll
+    for (int ct = 0; ct < Tile<C>::NCT; ++ct)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int row = (r & 3) + 8 * (r >> 2) + 4 * h;
+            tile[row * P + ct * 32 + j] = acc[ct][r];
+        }
+}
+
+// Cooperative load of a C x C matrix into LDS as Wl[k][j].
+//   trans == 0: source is [k][j] row-major;  trans == 1: source is [j][k] (nn.Linear weight, or W^T for backward).
+template <int C>
+__device__ __forceinline__ void load_w_lds(float* __restrict__ Wl, const float* __restrict__ W, int trans,
+                                           int tid, int nthreads) {
+    constexpr int NF4 = C * C / 4;
+    if (!trans) {
+        for (int f = tid; f < NF4; f += nthreads) st4(Wl + 4 * f, ld4(W + 4 * f));
+    } else {
+        for (int f = tid; f < NF4; f += nthreads) {
+            const int k4 = f / C, j = f % C;              // lanes walk j: conflict-free LDS writes
+            const float4 v = ld4(W + (size_t)j * C + 4 * k4);
+            Wl[(4 * k4 + 0) * C + j] = v.x;
+            Wl[(4 * k4 + 1) * C + j] = v.y;
+            Wl[(4 * k4 + 2) * C + j] = v.z;
+            Wl[(4 * k4 + 3) * C + j] = v.w;
+        }
+    }
+}

@@ -1,0 +1,159 @@
+// Per-node adaptive temporal hypergraph of hyperTem (reference GPTST.py:156-158):
+//     hyper = einsum('htn,btnd->bhnd', A, X);   ret = einsum('thn,bhnd->btnd', A^T, hyper)
+// There is no nonlinearity between the gather (T -> Hm hyperedges) and the scatter (Hm -> T), so per node
+//     ret[b,:,n,:] = G_n  X[b,:,n,:],     G_n = A_n^T A_n   (T x T, symmetric),  A_n = (E_node . adj)[n]  (Hm x T)
+// Kernels:  gram_fwd  (A -> G),  tmix (G (*) X, also the data-gradient because G is symmetric),
+//           tmix_dgraph (dG_n = sum_b dR[b,:,n,:] X[b,:,n,:]^T on fp32 MFMA 16x16x4),  gram_bwd (dG -> dA).
+// T is fixed at 12 by the reference (GPTST.py:97,208-209).
+#include "common.h"
+
+#define TT 12
+#define TT2 144
+
+// ---- G[n] = A[n]^T A[n];  A: (N, Hm, T) ---------------------------------------------------------------------
+__global__ __launch_bounds__(256) void gram_fwd_kernel(const float* __restrict__ A, float* __restrict__ G, int N, int Hm) {
+    const int idx = blockIdx.x * 256 + threadIdx.x;
+    if (idx >= N * TT2) return;
+    const int n = idx / TT2, t = (idx % TT2) / TT, u = idx % TT;
+    const float* a = A + (size_t)n * Hm * TT;
+    float s = 0.f;
+    for (int h = 0; h < Hm; ++h) s = fmaf(a[h * TT + t], a[h * TT + u], s);
+    G[idx] = s;
+}
+
+// ---- dA[n,h,t] = sum_u A[n,h,u] (dG[n,t,u] + dG[n,u,t]) -----------------------------------------------------
+__global__ __launch_bounds__(256) void gram_bwd_kernel(const float* __restrict__ A, const float* __restrict__ dG,
+                                                       float* __restrict__ dA, int N, int Hm) {
+    const int idx = blockIdx.x * 256 + threadIdx.x;
+    if (idx >= N * Hm * TT) return;
+    const int n = idx / (Hm * TT), h = (idx / TT) % Hm, t = idx % TT;
+    const float* a = A + ((size_t)n * Hm + h) * TT;
+    const float* g = dG + (size_t)n * TT2;
+    float s = 0.f;
+#pragma unroll
+    for (int u = 0; u < TT; ++u) s = fmaf(a[u], g[t * TT + u] + g[u * TT + t], s);
+    dA[idx] = s;
+}
+
+// ---- out[b,t,n,:] = sum_u G[n,t,u] X[b,u,n,:]  (+ dOut * lrelu'(Y) when ADD_DPRE: the residual branch of backward) --
+// block = (256 / (C/4)) nodes x (C/4) float4 lanes, one batch sample; every thread keeps its 12 x float4 column in registers.
+template <int C, bool ADD_DPRE>
+__global__ __launch_bounds__(256) void tmix_kernel(const float* __restrict__ X, const float* __restrict__ G,
+                                                   const float* __restrict__ dOut, const float* __restrict__ Y,
+                                                   float* __restrict__ out, int N) {
+    constexpr int LPR = C / 4;              // lanes per row
+    constexpr int NPB = 256 / LPR;          // nodes per block
+    __shared__ float Gs[NPB][TT2];
+    const int b = blockIdx.y, n0 = blockIdx.x * NPB;
+    for (int i = threadIdx.x; i < NPB * TT2; i += 256) {
+        const int nl = i / TT2;
+        Gs[nl][i % TT2] = (n0 + nl < N) ? G[(size_t)(n0 + nl) * TT2 + i % TT2] : 0.f;
+    }
+    __syncthreads();
+    const int nl = threadIdx.x / LPR, c4 = threadIdx.x % LPR;
+    const int n = n0 + nl;
+    if (n >= N) return;
+    const size_t base = ((size_t)b * TT * N + n) * C + 4 * c4;     // element (b, 0, n, 4*c4)
+    const size_t tstride = (size_t)N * C;
+    float4 x[TT];
+#pragma unroll
+    for (int u = 0; u < TT; ++u) x[u] = ld4(X + base + u * tstride);
+#pragma unroll
+    for (int t = 0; t < TT; ++t) {
+        float4 acc = f4zero();
+        if (ADD_DPRE) {
+            const float4 d = ld4(dOut + base + t * tstride), y = ld4(Y + base + t * tstride);
+            acc = make_float4(d.x * lrelu_grad_from_out(y.x), d.y * lrelu_grad_from_out(y.y),
+                              d.z * lrelu_grad_from_out(y.z), d.w * lrelu_grad_from_out(y.w));
+        }
+#pragma unroll
+        for (int u = 0; u < TT; ++u) acc = f4fma(Gs[nl][t * TT + u], x[u], acc);
+        st4(out + base + t * tstride, acc);
+    }
+}
+
+// ---- dG[n,t,u] = sum_{b,c} dR[b,t,n,c] X[b,u,n,c] --------------------------------------------------------------
+// MFMA 16x16x4 f32: A-op lane l holds A[i=l&15][k=l>>4], B-op B[k=l>>4][j=l&15]; D reg r: row (l>>4)*4+r, col l&15.
+// i = t, j = u (12 of 16 used), k walks the channels: lane group kk = l>>4 loads float4 c = 16q + 4kk .. +3 and feeds
+// MFMA steps 4q..4q+3 (the same k-permutation on both operands).  One block per node, waves split the batch.
+template <int C>
+__global__ __launch_bounds__(256) void tmix_dgraph_kernel(const float* __restrict__ dR, const float* __restrict__ X,
+                                                          float* __restrict__ dG, int B, int N) {
+    __shared__ float red[4][TT2];
+    const int n = blockIdx.x, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int i = lane & 15, kk = lane >> 4;
+    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+    const size_t tstride = (size_t)N * C;
+    for (int b = wave; b < B; b += 4) {
+        const size_t base = ((size_t)b * TT * N + n) * C + 4 * kk;
+        float4 a[C / 16], x[C / 16];
+#pragma unroll
+        for (int q = 0; q < C / 16; ++q) {
+            a[q] = f4zero(); x[q] = f4zero();
+            if (i < TT) {
+                a[q] = ld4(dR + base + i * tstride + 16 * q);
+                x[q] = ld4(X + base + i * tstride + 16 * q);
+            }
+        }
+#pragma unroll
+        for (int q = 0; q < C / 16; ++q) {
+            acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a[q].x, x[q].x, acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a[q].y, x[q].y, acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a[q].z, x[q].z, acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a[q].w, x[q].w, acc, 0, 0, 0);
+        }
+    }
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        const int t = kk * 4 + r, u = i;
+        if (t < TT && u < TT) red[wave][t * TT + u] = acc[r];
+    }
+    __syncthreads();
+    if (threadIdx.x < TT2) {
+        const int e = threadIdx.x;
+        dG[(size_t)n * TT2 + e] = red[0][e] + red[1][e] + red[2][e] + red[3][e];
+    }
+}
+
+extern "C" int gptst_gram_fwd(const float* A, float* G, int N, int Hm, void* stream) {
+    if (!A || !G) return GPTST_EARG;
+    hipLaunchKernelGGL(gram_fwd_kernel, dim3((N * TT2 + 255) / 256), dim3(256), 0, (hipStream_t)stream, A, G, N, Hm);
+    GPTST_CHECK_LAUNCH();
+    return GPTST_OK;
+}
+
+extern "C" int gptst_gram_bwd(const float* A, const float* dG, float* dA, int N, int Hm, void* stream) {
+    if (!A || !dG || !dA) return GPTST_EARG;
+    hipLaunchKernelGGL(gram_bwd_kernel, dim3((N * Hm * TT + 255) / 256), dim3(256), 0, (hipStream_t)stream, A, dG, dA, N, Hm);
+    GPTST_CHECK_LAUNCH();
+    return GPTST_OK;
+}
+
+// out = G (*) X  [+ dOut * lrelu'(Y) if dOut != NULL]
+extern "C" int gptst_tmix(const float* X, const float* G, const float* dOut, const float* Y, float* out, int B, int T, int N,
+                          int C, void* stream) {
+    if (!X || !G || !out || T != TT) return GPTST_EARG;
+    if (dOut && !Y) return GPTST_EARG;
+    hipStream_t st = (hipStream_t)stream;
+    if (C == 64) {
+        dim3 grid((N + 15) / 16, B);
+        if (dOut) hipLaunchKernelGGL((tmix_kernel<64, true>), grid, dim3(256), 0, st, X, G, dOut, Y, out, N);
+        else hipLaunchKernelGGL((tmix_kernel<64, false>), grid, dim3(256), 0, st, X, G, dOut, Y, out, N);
+    } else if (C == 128) {
+        dim3 grid((N + 7) / 8, B);
+        if (dOut) hipLaunchKernelGGL((tmix_kernel<128, true>), grid, dim3(256), 0, st, X, G, dOut, Y, out, N);
+        else hipLaunchKernelGGL((tmix_kernel<128, false>), grid, dim3(256), 0, st, X, G, dOut, Y, out, N);
+    } else return GPTST_ESHAPE;
+    GPTST_CHECK_LAUNCH();
+    return GPTST_OK;
+}
+
+extern "C" int gptst_tmix_dgraph(const float* dR, const float* X, float* dG, int B, int T, int N, int C, void* stream) {
+    if (!dR || !X || !dG || T != TT) return GPTST_EARG;
+    hipStream_t st = (hipStream_t)stream;
+    if (C == 64) hipLaunchKernelGGL((tmix_dgraph_kernel<64>), dim3(N), dim3(256), 0, st, dR, X, dG, B, N);
+    else if (C == 128) hipLaunchKernelGGL((tmix_dgraph_kernel<128>), dim3(N), dim3(256), 0, st, dR, X, dG, B, N);
+    else return GPTST_ESHAPE;
+    GPTST_CHECK_LAUNCH();
+    return GPTST_OK;
+}

@@ -1,0 +1,115 @@
+"""Thin Python wrappers over the C ABI (include/gptst_hip.h): one function per kernel entry point.
+
+All tensors are contiguous fp32 CUDA tensors; calls enqueue on torch's current stream and never synchronise,
+so they are hipGraph-capturable.  No CPU path exists here by design.
+"""
+import torch
+
+from . import _C
+
+MODE_TIME, MODE_NODE, MODE_SHARED = 0, 1, 2
+PRO_NONE, PRO_DPRE = 0, 1
+EPI_PLAIN, EPI_RES_LRELU = 0, 1
+
+_p = _C.ptr
+
+
+def _call(name, *args):
+    _C.lib().call(name, *args, _C.stream())
+
+
+def _chk(*ts):
+    for t in ts:
+        if t is not None:
+            assert t.is_cuda and t.dtype == torch.float32 and t.is_contiguous(), (t.device, t.dtype, t.is_contiguous())
+
+
+# ---- poolgen -------------------------------------------------------------------------------------------------
+def poolgen(emb, pool, pool2=None):
+    """emb (R,K); pool (K, ...) -> out (R, ...) [and out2 for pool2]."""
+    _chk(emb, pool, pool2)
+    R, K = emb.shape
+    cols = pool.numel() // K
+    out = torch.empty((R,) + tuple(pool.shape[1:]), device=emb.device, dtype=torch.float32)
+    out2, cols2 = None, 0
+    if pool2 is not None:
+        cols2 = pool2.numel() // K
+        out2 = torch.empty((R,) + tuple(pool2.shape[1:]), device=emb.device, dtype=torch.float32)
+    _call("gptst_poolgen_fwd", _p(emb), _p(pool), _p(out), cols, _p(pool2), _p(out2), cols2, R, K)
+    return (out, out2) if pool2 is not None else out
+
+
+def poolgen_bwd_pool(emb, dW, dpool, dW2=None, dpool2=None, nsplit=1):
+    """dpool += emb^T dW (summing wgrad splits); dpool2 += emb^T dW2."""
+    _chk(emb, dW, dpool, dW2, dpool2)
+    R, K = emb.shape
+    cols = dpool.numel() // K
+    cols2 = dpool2.numel() // K if dpool2 is not None else 0
+    _call("gptst_poolgen_bwd_pool", _p(emb), _p(dW), _p(dpool), cols, _p(dW2), _p(dpool2), cols2, R, nsplit, K)
+
+
+def poolgen_bwd_emb(dW, pool, demb, dW2=None, pool2=None, nsplit=1):
+    """demb += dW pool^T (+ dW2 pool2^T)."""
+    _chk(dW, pool, demb, dW2, pool2)
+    R, K = demb.shape
+    cols = pool.numel() // K
+    cols2 = pool2.numel() // K if pool2 is not None else 0
+    _call("gptst_poolgen_bwd_emb", _p(dW), _p(pool), cols, _p(dW2), _p(pool2), cols2, _p(demb), R, nsplit, K)
+
+
+# ---- MFMA contractions ---------------------------------------------------------------------------------------
+def apply(A, W, mode, BT, N, bias=None, resid=None, A2=None, transw=False, pro=PRO_NONE, epi=EPI_PLAIN, colsum=None,
+          out=None):
+    _chk(A, W, bias, resid, A2, colsum)
+    C = A.shape[-1]
+    if out is None:
+        out = torch.empty_like(A)
+    _call("gptst_apply", _p(A), _p(A2), _p(W), int(W.dim() == 3), int(transw), _p(bias), _p(resid), _p(out), _p(colsum),
+          mode, pro, epi, BT, N, C)
+    return out
+
+
+def wgrad_nsplit(mode, BT, N):
+    return _C.lib().value("gptst_wgrad_nsplit", mode, BT, N)
+
+
+def wgrad(A, D, mode, BT, N, D2=None, pro=PRO_NONE):
+    """-> (dW (nsplit*G, C, C), nsplit)."""
+    _chk(A, D, D2)
+    C = A.shape[-1]
+    ns = wgrad_nsplit(mode, BT, N)
+    G = BT if mode == MODE_TIME else (N if mode == MODE_NODE else 1)
+    dW = torch.empty(ns * G, C, C, device=A.device, dtype=torch.float32)
+    _call("gptst_wgrad", _p(A), _p(D), _p(D2), _p(dW), mode, pro, BT, N, C)
+    return dW, ns
+
+
+# ---- temporal hypergraph -------------------------------------------------------------------------------------
+def gram_fwd(A):
+    N, Hm, T = A.shape
+    G = torch.empty(N, T, T, device=A.device, dtype=torch.float32)
+    _call("gptst_gram_fwd", _p(A), _p(G), N, Hm)
+    return G
+
+
+def gram_bwd(A, dG):
+    N, Hm, T = A.shape
+    dA = torch.empty_like(A)
+    _call("gptst_gram_bwd", _p(A), _p(dG), _p(dA), N, Hm)
+    return dA
+
+
+def tmix(X, G, dOut=None, Y=None):
+    _chk(X, G, dOut, Y)
+    B, T, N, C = X.shape
+    out = torch.empty_like(X)
+    _call("gptst_tmix", _p(X), _p(G), _p(dOut), _p(Y), _p(out), B, T, N, C)
+    return out
+
+
+def tmix_dgraph(dR, X):
+    _chk(dR, X)
+    B, T, N, C = X.shape
+    dG = torch.empty(N, T, T, device=X.device, dtype=torch.float32)
+    _call("gptst_tmix_dgraph", _p(dR), _p(X), _p(dG), B, T, N, C)
+    return dG

@@ -1,0 +1,70 @@
+/* gptst_hip.h — C ABI of the MI355X (gfx950) GPT-ST pretraining kernels.
+ *
+ * Drop-in boundary: the reference has no FFI — its hot path sits behind the Python nn.Module
+ * GPTST_Model (model/Pretrain_model/GPTST.py:459-493).  gpt-st_amd/model.py mirrors that interface and
+ * calls these entry points through ctypes; each entry replaces the chain of ATen ops cited with it.
+ *
+ * Conventions (all entry points):
+ *   - every pointer is a DEVICE pointer into caller-owned memory (a torch tensor) that stays valid until
+ *     the stream has executed the call; fp32 unless the name says otherwise; tensors are dense row-major;
+ *   - activations are (B, T, N, C) = (B*T*N rows, C); T is 12 (reference GPTST.py:97,208-209);
+ *   - `stream` is a hipStream_t (torch.cuda.current_stream().cuda_stream); calls only enqueue — no
+ *     allocation, no synchronisation, no host reads — so a whole step can be captured in a hipGraph;
+ *   - return 0 on success, a negative GPTST_E* code for bad arguments / unsupported shapes, or a positive
+ *     hipError_t from the launch.  Never throws, never exits.
+ *   - "+=" in a description means the kernel ACCUMULATES into the output (caller zeroes it once per step).
+ */
+#ifndef GPTST_HIP_H
+#define GPTST_HIP_H
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define GPTST_ABI_VERSION 1
+int gptst_abi_version(void);
+
+/* ---- embedding-conditioned parameter generation (poolgen.hip) -----------------------------------------
+ * out[r,:] = sum_k emb[r,k] * pool[k,:]   r < R, k < K <= 16.  Optional second problem (pool2/out2/cols2) shares emb.
+ * Replaces einsum('btd,dio->btio'), einsum('nd,dio->nio'), matmul(emb, bias_pool) (GPTST.py:24-25,29-30,137-138,
+ * 160-161), einsum('btd,dhn->bthn') (:104), einsum('bd,dhk->bhk') (:129), einsum('nk,kht->nht') (:156). */
+int gptst_poolgen_fwd(const float* emb, const float* pool, float* out, int cols, const float* pool2, float* out2,
+                      int cols2, int R, int K, void* stream);
+/* dpool[k,:] += sum_rr emb[rr % R, k] * dW[rr,:],  rr < R*nsplit (problem 1) / R (problem 2). */
+int gptst_poolgen_bwd_pool(const float* emb, const float* dW, float* dpool, int cols, const float* dW2, float* dpool2,
+                           int cols2, int R, int nsplit, int K, void* stream);
+/* demb[r,k] += sum_s sum_c dW[s*R + r, c] pool[k,c]  (+ problem 2 without splits). */
+int gptst_poolgen_bwd_emb(const float* dW, const float* pool, int cols, const float* dW2, const float* pool2, int cols2,
+                          float* demb, int R, int nsplit, int K, void* stream);
+
+/* ---- C x C contractions on fp32 MFMA (apply.hip) ------------------------------------------------------
+ * out[g,m,:] = epi( pro(A)[g,m,:] @ W[g] (+bias[g]) (+resid) ).   mode: 0 TIME (g=(b,t), rows n), 1 NODE (g=n, rows
+ * (b,t)), 2 SHARED (one weight).  w_per_group: W is (G,C,C) else (C,C).  transw: W[g] stored [out][in].
+ * pro: 0 none, 1 A*lrelu'(A2) (A=dOut, A2=layer output).  epi: 0 plain, 1 lrelu(acc+bias+resid).
+ * colsum (optional, += via atomics): colsum[g,:] += sum_m pro(A)[g,m,:]  (bias gradient).
+ * Replaces einsum('btni,btio->btno') / einsum('btni,nio->btno') + bias + residual + LeakyReLU
+ * (GPTST.py:26-27,31-32,139-141,162-163), nn.Linear C->C (:102) and their backward w.r.t. the data. */
+int gptst_apply(const float* A, const float* A2, const float* W, int w_per_group, int transw, const float* bias,
+                const float* resid, float* out, float* colsum, int mode, int pro, int epi, int BT, int N, int C,
+                void* stream);
+/* dW[s*G + g] = sum_{m in split s} A[g,m,:]^T pro(D)[g,m,:];  nsplit = gptst_wgrad_nsplit(mode,BT,N) partial sums
+ * that the consumer (gptst_poolgen_bwd_*) adds up.  dW must hold nsplit*G*C*C floats. */
+int gptst_wgrad_nsplit(int mode, int BT, int N);
+int gptst_wgrad(const float* A, const float* D, const float* D2, float* dW, int mode, int pro, int BT, int N, int C,
+                void* stream);
+
+/* ---- per-node temporal hypergraph of hyperTem (tmix.hip), GPTST.py:156-158 -----------------------------
+ * A (N,Hm,T) = node_emb . adj (via poolgen);  G[n] = A[n]^T A[n] (T x T);  ret[b,:,n,:] = G[n] X[b,:,n,:]. */
+int gptst_gram_fwd(const float* A, float* G, int N, int Hm, void* stream);
+int gptst_gram_bwd(const float* A, const float* dG, float* dA, int N, int Hm, void* stream);
+/* out = G (*) X  [+ dOut*lrelu'(Y) when dOut != NULL: fuses the residual branch of hyperTem's backward]. */
+int gptst_tmix(const float* X, const float* G, const float* dOut, const float* Y, float* out, int B, int T, int N, int C,
+               void* stream);
+/* dG[n,t,u] = sum_{b,c} dR[b,t,n,c] X[b,u,n,c]   (fp32 MFMA 16x16x4). */
+int gptst_tmix_dgraph(const float* dR, const float* X, float* dG, int B, int T, int N, int C, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* GPTST_HIP_H */
