@@ -12,7 +12,7 @@
 #include "mfma_tile.h"
 
 enum { PRO_NONE = 0, PRO_DPRE = 1 };          // PRO_DPRE: a = A * lrelu'(A2)   (A = dOut, A2 = layer output)
-enum { EPI_PLAIN = 0, EPI_RES_LRELU = 1 };     // EPI_RES_LRELU: lrelu(acc + bias + resid)
+enum { EPI_PLAIN = 0, EPI_RES_LRELU = 1, EPI_ADD_DPRE = 2 };   // 1: lrelu(acc + bias + resid)   2: acc + resid * lrelu'(resid2)
 
 struct RowMap {
     int G, M;
@@ -31,7 +31,7 @@ template <int C, int PRO, int EPI>
 __global__ __launch_bounds__(256) void apply_kernel(const float* __restrict__ A, const float* __restrict__ A2,
                                                     const float* __restrict__ W, long w_gstride, int transw,
                                                     const float* __restrict__ bias, const float* __restrict__ resid,
-                                                    float* __restrict__ out, float* __restrict__ colsum, RowMap rm) {
+                                                    const float* __restrict__ resid2, float* __restrict__ out, float* __restrict__ colsum, RowMap rm) {
     using T = Tile<C>;
     extern __shared__ __attribute__((aligned(16))) float smem[];
     float* Wl = smem;                                   // C*C
@@ -89,6 +89,11 @@ __global__ __launch_bounds__(256) void apply_kernel(const float* __restrict__ A,
                 if (EPI == EPI_RES_LRELU) {
                     y = f4add(y, ld4(resid + off));
                     y.x = lrelu(y.x); y.y = lrelu(y.y); y.z = lrelu(y.z); y.w = lrelu(y.w);
+                }
+                if (EPI == EPI_ADD_DPRE) {
+                    const float4 d = ld4(resid + off), o = ld4(resid2 + off);
+                    y.x = fmaf(d.x, lrelu_grad_from_out(o.x), y.x); y.y = fmaf(d.y, lrelu_grad_from_out(o.y), y.y);
+                    y.z = fmaf(d.z, lrelu_grad_from_out(o.z), y.z); y.w = fmaf(d.w, lrelu_grad_from_out(o.w), y.w);
                 }
                 st4(out + off, y);
             }
@@ -153,7 +158,7 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const float* __restrict__ A,
 
 template <int C>
 static int launch_apply(const float* A, const float* A2, const float* W, long w_gstride, int transw, const float* bias,
-                        const float* resid, float* out, float* colsum, RowMap rm, int pro, int epi, hipStream_t st) {
+                        const float* resid, const float* resid2, float* out, float* colsum, RowMap rm, int pro, int epi, hipStream_t st) {
     const int ntiles = (rm.M + 31) / 32;
     int gy = (ntiles + 3) / 4;
     if (rm.G == 1) gy = min(gy, 1024);                 // shared weight: many row chunks, W staged once per block
@@ -163,10 +168,11 @@ static int launch_apply(const float* A, const float* A2, const float* W, long w_
     const size_t smem = (size_t)(C * C + 4 * Tile<C>::TILE_FLOATS) * sizeof(float);
 #define LAUNCH(P, E)                                                                                              \
     hipLaunchKernelGGL((apply_kernel<C, P, E>), grid, block, smem, st, A, A2, W, w_gstride, transw, bias, resid, \
-                       out, colsum, rm)
+                       resid2, out, colsum, rm)
     if (pro == PRO_NONE && epi == EPI_PLAIN) LAUNCH(PRO_NONE, EPI_PLAIN);
     else if (pro == PRO_NONE && epi == EPI_RES_LRELU) LAUNCH(PRO_NONE, EPI_RES_LRELU);
     else if (pro == PRO_DPRE && epi == EPI_PLAIN) LAUNCH(PRO_DPRE, EPI_PLAIN);
+    else if (pro == PRO_NONE && epi == EPI_ADD_DPRE) LAUNCH(PRO_NONE, EPI_ADD_DPRE);
     else return GPTST_EARG;
 #undef LAUNCH
     GPTST_CHECK_LAUNCH();
@@ -180,20 +186,22 @@ static void raise_smem_limits() {
     hipFuncSetAttribute((const void*)apply_kernel<C, PRO_NONE, EPI_PLAIN>, hipFuncAttributeMaxDynamicSharedMemorySize, smem);
     hipFuncSetAttribute((const void*)apply_kernel<C, PRO_NONE, EPI_RES_LRELU>, hipFuncAttributeMaxDynamicSharedMemorySize, smem);
     hipFuncSetAttribute((const void*)apply_kernel<C, PRO_DPRE, EPI_PLAIN>, hipFuncAttributeMaxDynamicSharedMemorySize, smem);
+    hipFuncSetAttribute((const void*)apply_kernel<C, PRO_NONE, EPI_ADD_DPRE>, hipFuncAttributeMaxDynamicSharedMemorySize, smem);
 }
 
 extern "C" int gptst_apply(const float* A, const float* A2, const float* W, int w_per_group, int transw,
-                           const float* bias, const float* resid, float* out, float* colsum, int mode, int pro,
-                           int epi, int BT, int N, int C, void* stream) {
+                           const float* bias, const float* resid, const float* resid2, float* out, float* colsum,
+                           int mode, int pro, int epi, int BT, int N, int C, void* stream) {
     if (!A || !W || !out || BT <= 0 || N <= 0) return GPTST_EARG;
     if (pro == PRO_DPRE && !A2) return GPTST_EARG;
     if (epi == EPI_RES_LRELU && !resid) return GPTST_EARG;
+    if (epi == EPI_ADD_DPRE && (!resid || !resid2)) return GPTST_EARG;
     if (!g_smem_attr_done) { raise_smem_limits<64>(); raise_smem_limits<128>(); g_smem_attr_done = 1; }
     RowMap rm = make_rowmap(mode, BT, N);
     const long gs = w_per_group ? (long)C * C : 0;
     hipStream_t st = (hipStream_t)stream;
-    if (C == 64) return launch_apply<64>(A, A2, W, gs, transw, bias, resid, out, colsum, rm, pro, epi, st);
-    if (C == 128) return launch_apply<128>(A, A2, W, gs, transw, bias, resid, out, colsum, rm, pro, epi, st);
+    if (C == 64) return launch_apply<64>(A, A2, W, gs, transw, bias, resid, resid2, out, colsum, rm, pro, epi, st);
+    if (C == 128) return launch_apply<128>(A, A2, W, gs, transw, bias, resid, resid2, out, colsum, rm, pro, epi, st);
     return GPTST_ESHAPE;
 }
 

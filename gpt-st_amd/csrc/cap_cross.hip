@@ -1,0 +1,173 @@
+// cap, inter-cluster / cross-time hyperedges on the T*HS cluster tokens of one sample (reference GPTST.py:125-134):
+//     Z   = s + (t+1)/12                                   (B, KK = T*HS, C)
+//     Ht  = LReLU(dyn Z)        dyn = time_eb_spg . t_adj  (B, HT, KK), produced by poolgen
+//     Rt  = LReLU(dyn^T Ht)
+//     v   = squash(Rt + s)
+// Tiny (0.5 MFLOP per sample) and latency bound: one workgroup per sample, everything LDS-resident, VALU only.
+#include "common.h"
+
+template <int C>
+struct CrossCfg {
+    static constexpr int LPR = C / 4;
+    static constexpr int PITCH = C + 4;
+};
+
+template <int C>
+__global__ __launch_bounds__(256) void cap_cross_fwd_kernel(const float* __restrict__ s, const float* __restrict__ dyn,
+                                                            const float* __restrict__ tmpl, float* __restrict__ v,
+                                                            float* __restrict__ Ht_out, float* __restrict__ Rt_out, int T, int HS,
+                                                            int HT) {
+    using K = CrossCfg<C>;
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    const int KK = T * HS;
+    float* Zs = smem;                         // KK * PITCH
+    float* Hs = Zs + KK * K::PITCH;           // HT * C
+    float* dyns = Hs + HT * C;                // HT * KK
+    const int b = blockIdx.x, tid = threadIdx.x;
+    for (int i = tid; i < KK * K::LPR; i += 256) {
+        const int k = i / K::LPR, c4 = i % K::LPR;
+        const float tm = tmpl[k / HS];
+        const float4 x = ld4(s + ((size_t)b * KK + k) * C + 4 * c4);
+        st4(Zs + k * K::PITCH + 4 * c4, make_float4(x.x + tm, x.y + tm, x.z + tm, x.w + tm));
+    }
+    for (int i = tid; i < HT * KK; i += 256) dyns[i] = dyn[(size_t)b * HT * KK + i];
+    __syncthreads();
+    for (int i = tid; i < HT * K::LPR; i += 256) {
+        const int j = i / K::LPR, c4 = i % K::LPR;
+        float4 acc = f4zero();
+        for (int k = 0; k < KK; ++k) acc = f4fma(dyns[j * KK + k], ld4(Zs + k * K::PITCH + 4 * c4), acc);
+        acc = make_float4(lrelu(acc.x), lrelu(acc.y), lrelu(acc.z), lrelu(acc.w));
+        st4(Hs + j * C + 4 * c4, acc);
+        st4(Ht_out + ((size_t)b * HT + j) * C + 4 * c4, acc);
+    }
+    __syncthreads();
+    for (int base = 0; base < KK * K::LPR; base += 256) {
+        const int i = base + tid;
+        const bool valid = i < KK * K::LPR;
+        const int k = valid ? i / K::LPR : 0, c4 = i % K::LPR;
+        float4 acc = f4zero();
+        for (int j = 0; j < HT; ++j) acc = f4fma(dyns[j * KK + k], ld4(Hs + j * C + 4 * c4), acc);
+        const float4 rt = make_float4(lrelu(acc.x), lrelu(acc.y), lrelu(acc.z), lrelu(acc.w));
+        const float tm = tmpl[k / HS];
+        const float4 z = ld4(Zs + k * K::PITCH + 4 * c4);
+        const float4 u = make_float4(rt.x + (z.x - tm), rt.y + (z.y - tm), rt.z + (z.z - tm), rt.w + (z.w - tm));
+        const float sc = squash_scale(group_sum<K::LPR>(f4dot(u, u)));
+        if (valid) {
+            st4(Rt_out + ((size_t)b * KK + k) * C + 4 * c4, rt);
+            st4(v + ((size_t)b * KK + k) * C + 4 * c4, make_float4(u.x * sc, u.y * sc, u.z * sc, u.w * sc));
+        }
+    }
+}
+
+// backward: dS (total grad of s) and ddyn from dv
+template <int C>
+__global__ __launch_bounds__(256) void cap_cross_bwd_kernel(const float* __restrict__ dv, const float* __restrict__ s,
+                                                            const float* __restrict__ Rt, const float* __restrict__ Ht,
+                                                            const float* __restrict__ dyn, const float* __restrict__ tmpl,
+                                                            float* __restrict__ dS, float* __restrict__ ddyn, int T, int HS, int HT) {
+    using K = CrossCfg<C>;
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    const int KK = T * HS;
+    float* Zs = smem;                         // KK * PITCH
+    float* Gs = Zs + KK * K::PITCH;           // KK * PITCH   dRpre
+    float* Hs = Gs + KK * K::PITCH;           // HT * PITCH   Ht
+    float* dHs = Hs + HT * K::PITCH;          // HT * PITCH   dHpre
+    float* dyns = dHs + HT * K::PITCH;        // HT * KK
+    const int b = blockIdx.x, tid = threadIdx.x;
+    for (int i = tid; i < HT * KK; i += 256) dyns[i] = dyn[(size_t)b * HT * KK + i];
+    for (int i = tid; i < HT * K::LPR; i += 256)
+        st4(Hs + (i / K::LPR) * K::PITCH + 4 * (i % K::LPR), ld4(Ht + ((size_t)b * HT) * C + 4 * i));
+    // rows k: u = Rt + s;  du = squash_bwd(u, dv);  dRpre = du * lrelu'(Rt)
+    for (int base = 0; base < KK * K::LPR; base += 256) {
+        const int i = base + tid;
+        const bool valid = i < KK * K::LPR;
+        const int k = valid ? i / K::LPR : 0, c4 = i % K::LPR;
+        const size_t off = ((size_t)b * KK + k) * C + 4 * c4;
+        float4 sv = f4zero(), rt = f4zero(), g = f4zero();
+        if (valid) { sv = ld4(s + off); rt = ld4(Rt + off); g = ld4(dv + off); }
+        const float4 u = f4add(rt, sv);
+        const float q = group_sum<K::LPR>(f4dot(u, u));
+        const float udg = group_sum<K::LPR>(f4dot(u, g));
+        const float r = sqrtf(q), den = (1.f + q) * (r + 1e-8f);
+        const float gq = q / den;
+        float gp = 0.f;
+        if (r > 0.f) gp = (den - q * ((r + 1e-8f) + (1.f + q) * 0.5f / r)) / (den * den);
+        const float k2 = 2.f * gp * udg;
+        const float4 du = make_float4(fmaf(k2, u.x, gq * g.x), fmaf(k2, u.y, gq * g.y), fmaf(k2, u.z, gq * g.z), fmaf(k2, u.w, gq * g.w));
+        if (valid) {
+            const float tm = tmpl[k / HS];
+            st4(dS + off, du);
+            st4(Zs + k * K::PITCH + 4 * c4, make_float4(sv.x + tm, sv.y + tm, sv.z + tm, sv.w + tm));
+            st4(Gs + k * K::PITCH + 4 * c4, make_float4(du.x * lrelu_grad_from_out(rt.x), du.y * lrelu_grad_from_out(rt.y),
+                                                        du.z * lrelu_grad_from_out(rt.z), du.w * lrelu_grad_from_out(rt.w)));
+        }
+    }
+    __syncthreads();
+    // dHpre[j] = lrelu'(Ht[j]) * sum_k dyn[j][k] dRpre[k]
+    for (int i = tid; i < HT * K::LPR; i += 256) {
+        const int j = i / K::LPR, c4 = i % K::LPR;
+        float4 acc = f4zero();
+        for (int k = 0; k < KK; ++k) acc = f4fma(dyns[j * KK + k], ld4(Gs + k * K::PITCH + 4 * c4), acc);
+        const float4 h = ld4(Hs + j * K::PITCH + 4 * c4);
+        st4(dHs + j * K::PITCH + 4 * c4, make_float4(acc.x * lrelu_grad_from_out(h.x), acc.y * lrelu_grad_from_out(h.y),
+                                                     acc.z * lrelu_grad_from_out(h.z), acc.w * lrelu_grad_from_out(h.w)));
+    }
+    __syncthreads();
+    // ddyn[j][k] = Ht[j].dRpre[k] + dHpre[j].Z[k]
+    for (int i = tid; i < HT * KK; i += 256) {
+        const int j = i / KK, k = i % KK;
+        float acc = 0.f;
+#pragma unroll 4
+        for (int c4 = 0; c4 < K::LPR; ++c4) {
+            acc += f4dot(ld4(Hs + j * K::PITCH + 4 * c4), ld4(Gs + k * K::PITCH + 4 * c4));
+            acc += f4dot(ld4(dHs + j * K::PITCH + 4 * c4), ld4(Zs + k * K::PITCH + 4 * c4));
+        }
+        ddyn[(size_t)b * HT * KK + i] = acc;
+    }
+    // dS[k] += sum_j dyn[j][k] dHpre[j]
+    for (int i = tid; i < KK * K::LPR; i += 256) {
+        const int k = i / K::LPR, c4 = i % K::LPR;
+        float4 acc = f4zero();
+        for (int j = 0; j < HT; ++j) acc = f4fma(dyns[j * KK + k], ld4(dHs + j * K::PITCH + 4 * c4), acc);
+        const size_t off = ((size_t)b * KK + k) * C + 4 * c4;
+        st4(dS + off, f4add(ld4(dS + off), acc));
+    }
+}
+
+template <int C>
+static int launch_cross(bool fwd, const float* a0, const float* a1, const float* a2, const float* a3, const float* a4, const float* a5,
+                        float* o0, float* o1, float* o2, int B, int T, int HS, int HT, hipStream_t st) {
+    const int KK = T * HS;
+    using K = CrossCfg<C>;
+    if (fwd) {
+        const size_t smem = ((size_t)KK * K::PITCH + (size_t)HT * C + (size_t)HT * KK) * sizeof(float);
+        if (smem > 160 * 1024) return GPTST_ESHAPE;
+        static size_t cur = 0;
+        if (smem > cur) { hipFuncSetAttribute((const void*)cap_cross_fwd_kernel<C>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem); cur = smem; }
+        hipLaunchKernelGGL((cap_cross_fwd_kernel<C>), dim3(B), dim3(256), smem, st, a0, a1, a2, o0, o1, o2, T, HS, HT);
+    } else {
+        const size_t smem = ((size_t)2 * KK * K::PITCH + (size_t)2 * HT * K::PITCH + (size_t)HT * KK) * sizeof(float);
+        if (smem > 160 * 1024) return GPTST_ESHAPE;
+        static size_t cur = 0;
+        if (smem > cur) { hipFuncSetAttribute((const void*)cap_cross_bwd_kernel<C>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem); cur = smem; }
+        hipLaunchKernelGGL((cap_cross_bwd_kernel<C>), dim3(B), dim3(256), smem, st, a0, a1, a2, a3, a4, a5, o0, o1, T, HS, HT);
+    }
+    GPTST_CHECK_LAUNCH();
+    return GPTST_OK;
+}
+
+extern "C" int gptst_cap_cross_fwd(const float* s, const float* dyn, const float* tmpl, float* v, float* Ht, float* Rt, int B, int T,
+                                   int C, int HS, int HT, void* stream) {
+    if (!s || !dyn || !tmpl || !v || !Ht || !Rt) return GPTST_EARG;
+    if (C == 64) return launch_cross<64>(true, s, dyn, tmpl, 0, 0, 0, v, Ht, Rt, B, T, HS, HT, (hipStream_t)stream);
+    if (C == 128) return launch_cross<128>(true, s, dyn, tmpl, 0, 0, 0, v, Ht, Rt, B, T, HS, HT, (hipStream_t)stream);
+    return GPTST_ESHAPE;
+}
+
+extern "C" int gptst_cap_cross_bwd(const float* dv, const float* s, const float* Rt, const float* Ht, const float* dyn,
+                                   const float* tmpl, float* dS, float* ddyn, int B, int T, int C, int HS, int HT, void* stream) {
+    if (!dv || !s || !Rt || !Ht || !dyn || !tmpl || !dS || !ddyn) return GPTST_EARG;
+    if (C == 64) return launch_cross<64>(false, dv, s, Rt, Ht, dyn, tmpl, dS, ddyn, 0, B, T, HS, HT, (hipStream_t)stream);
+    if (C == 128) return launch_cross<128>(false, dv, s, Rt, Ht, dyn, tmpl, dS, ddyn, 0, B, T, HS, HT, (hipStream_t)stream);
+    return GPTST_ESHAPE;
+}

@@ -47,3 +47,65 @@ class HyperTemFn(torch.autograd.Function):
 
 def hypertem(x, node_emb, time_eb, adj, wpool, bpool):
     return HyperTemFn.apply(x, node_emb, time_eb, adj, wpool, bpool)
+
+
+class CapFn(torch.autograd.Function):
+    """cap.forward (reference GPTST.py:100-141).  Returns (out, c (B,T,HS,N) detached, dyn (B,HT,T*HS) detached)."""
+
+    @staticmethod
+    def forward(ctx, x, node_emb, time_eb_spg, teb, t_adj, adj, wspa, bspa, lnp_w, lnp_b, tmpl, num_route):
+        B, T, N, C = x.shape
+        ds, HS = adj.shape[0], adj.shape[1]
+        HT = t_adj.shape[1]
+        BT = B * T
+        x = x.contiguous()
+        teb2 = teb.reshape(BT, ds).contiguous()
+        tes = time_eb_spg.contiguous()
+        ne = node_emb.contiguous()
+        c, s = ops.cap_route_fwd(x, lnp_w, lnp_b, teb2, adj, num_route)                    # :102-123
+        dyn = ops.poolgen(tes, t_adj.reshape(ds, HT * T * HS)).view(B, HT, T * HS)         # :129
+        v, Ht, Rt = ops.cap_cross_fwd(s, dyn, tmpl, B, T, HS, HT)                          # :125-134
+        rec = ops.cap_rec_fwd(c, v, N, C)                                                  # :135
+        Wn, bn = ops.poolgen(ne, wspa, bspa)                                               # :137-138
+        out = ops.apply(rec, Wn, MODE_NODE, BT, N, bias=bn, resid=x.view(-1, C), epi=EPI_RES_LRELU).view(B, T, N, C)   # :139-141
+        ctx.save_for_backward(x, out, rec, c, s, v, Ht, Rt, dyn, Wn, teb2, tes, ne, t_adj, adj, wspa, bspa, lnp_w, lnp_b, tmpl)
+        ctx.mark_non_differentiable(c, dyn)
+        return out, c.view(B, T, HS, N), dyn
+
+    @staticmethod
+    def backward(ctx, dout, _dc, _ddyn):
+        (x, out, rec, c, s, v, Ht, Rt, dyn, Wn, teb2, tes, ne, t_adj, adj, wspa, bspa, lnp_w, lnp_b, tmpl) = ctx.saved_tensors
+        B, T, N, C = x.shape
+        ds, HS = adj.shape[0], adj.shape[1]
+        HT = t_adj.shape[1]
+        BT = B * T
+        dev = x.device
+        dout = dout.contiguous().view(-1, C)
+        out2, x2 = out.view(-1, C), x.view(-1, C)
+        # node-conditioned apply
+        dbn = torch.zeros(N, C, device=dev)
+        drec = ops.apply(dout, Wn, MODE_NODE, BT, N, A2=out2, transw=True, pro=PRO_DPRE, colsum=dbn)
+        dWn, ns = ops.wgrad(rec, dout, MODE_NODE, BT, N, D2=out2, pro=PRO_DPRE)
+        dwspa, dbspa, dne = torch.zeros_like(wspa), torch.zeros_like(bspa), torch.zeros_like(ne)
+        ops.poolgen_bwd_pool(ne, dWn, dwspa, dbn, dbspa, nsplit=ns)
+        ops.poolgen_bwd_emb(dWn, wspa, dne, dbn, bspa, nsplit=ns)
+        # scatter, cross-time, soft assignment
+        dc1, dv = ops.cap_rec_bwd(drec, c, v)
+        dS, ddyn = ops.cap_cross_bwd(dv, s, Rt, Ht, dyn, tmpl, B, T, HS, HT)
+        dt_adj, dtes = torch.zeros_like(t_adj), torch.zeros_like(tes)
+        ops.poolgen_bwd_pool(tes, ddyn, dt_adj)
+        ops.poolgen_bwd_emb(ddyn, t_adj, dtes)
+        dY, dlogit = ops.cap_route_bwd(x, lnp_w, lnp_b, c, dc1, dS)
+        dadj, dteb = torch.zeros_like(adj), torch.zeros_like(teb2)
+        ops.poolgen_bwd_pool(teb2, dlogit, dadj)
+        ops.poolgen_bwd_emb(dlogit, adj, dteb)
+        # Linear ln_p: Y = X Wp^T + bp
+        dbp = torch.zeros(1, C, device=dev)
+        dx = ops.apply(dY, lnp_w, MODE_SHARED, BT, N, resid=dout, resid2=out2, epi=ops.EPI_ADD_DPRE, colsum=dbp)
+        dWp, ns2 = ops.wgrad(dY, x2, MODE_SHARED, BT, N)
+        dlnp_w = dWp.view(ns2, C, C).sum(0)
+        return (dx.view(B, T, N, C), dne, dtes, dteb.view(B, T, ds), dt_adj, dadj, dwspa, dbspa, dlnp_w, dbp.view(C), None, None)
+
+
+def cap(x, node_emb, time_eb_spg, teb, t_adj, adj, wspa, bspa, lnp_w, lnp_b, tmpl, num_route):
+    return CapFn.apply(x, node_emb, time_eb_spg, teb, t_adj, adj, wspa, bspa, lnp_w, lnp_b, tmpl, num_route)

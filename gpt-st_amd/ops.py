@@ -9,7 +9,7 @@ from . import _C
 
 MODE_TIME, MODE_NODE, MODE_SHARED = 0, 1, 2
 PRO_NONE, PRO_DPRE = 0, 1
-EPI_PLAIN, EPI_RES_LRELU = 0, 1
+EPI_PLAIN, EPI_RES_LRELU, EPI_ADD_DPRE = 0, 1, 2
 
 _p = _C.ptr
 
@@ -59,12 +59,12 @@ def poolgen_bwd_emb(dW, pool, demb, dW2=None, pool2=None, nsplit=1):
 
 # ---- MFMA contractions ---------------------------------------------------------------------------------------
 def apply(A, W, mode, BT, N, bias=None, resid=None, A2=None, transw=False, pro=PRO_NONE, epi=EPI_PLAIN, colsum=None,
-          out=None):
-    _chk(A, W, bias, resid, A2, colsum)
+          out=None, resid2=None):
+    _chk(A, W, bias, resid, A2, colsum, resid2)
     C = A.shape[-1]
     if out is None:
         out = torch.empty_like(A)
-    _call("gptst_apply", _p(A), _p(A2), _p(W), int(W.dim() == 3), int(transw), _p(bias), _p(resid), _p(out), _p(colsum),
+    _call("gptst_apply", _p(A), _p(A2), _p(W), int(W.dim() == 3), int(transw), _p(bias), _p(resid), _p(resid2), _p(out), _p(colsum),
           mode, pro, epi, BT, N, C)
     return out
 
@@ -113,3 +113,62 @@ def tmix_dgraph(dR, X):
     dG = torch.empty(N, T, T, device=X.device, dtype=torch.float32)
     _call("gptst_tmix_dgraph", _p(dR), _p(X), _p(dG), B, T, N, C)
     return dG
+
+
+# ---- cap -----------------------------------------------------------------------------------------------------
+def cap_route_fwd(X, Wp, bp, teb, adj, R):
+    """X (B,T,N,C); Wp (C,C) ln_p.weight; teb (BT,ds); adj (ds,HS,N) -> c (BT,HS,N), s (BT,HS,C)."""
+    _chk(X, Wp, bp, teb, adj)
+    B, T, N, C = X.shape
+    ds, HS = adj.shape[0], adj.shape[1]
+    c = torch.empty(B * T, HS, N, device=X.device, dtype=torch.float32)
+    s = torch.empty(B * T, HS, C, device=X.device, dtype=torch.float32)
+    _call("gptst_cap_route_fwd", _p(X), _p(Wp), _p(bp), _p(teb), _p(adj), _p(c), _p(s), B * T, N, C, HS, ds, R)
+    return c, s
+
+
+def cap_cross_fwd(s, dyn, tmpl, B, T, HS, HT):
+    _chk(s, dyn, tmpl)
+    C = s.shape[-1]
+    v = torch.empty_like(s)
+    Ht = torch.empty(B, HT, C, device=s.device, dtype=torch.float32)
+    Rt = torch.empty_like(s)
+    _call("gptst_cap_cross_fwd", _p(s), _p(dyn), _p(tmpl), _p(v), _p(Ht), _p(Rt), B, T, C, HS, HT)
+    return v, Ht, Rt
+
+
+def cap_cross_bwd(dv, s, Rt, Ht, dyn, tmpl, B, T, HS, HT):
+    _chk(dv, s, Rt, Ht, dyn, tmpl)
+    C = s.shape[-1]
+    dS = torch.empty_like(s)
+    ddyn = torch.empty_like(dyn)
+    _call("gptst_cap_cross_bwd", _p(dv), _p(s), _p(Rt), _p(Ht), _p(dyn), _p(tmpl), _p(dS), _p(ddyn), B, T, C, HS, HT)
+    return dS, ddyn
+
+
+def cap_rec_fwd(c, v, N, C):
+    _chk(c, v)
+    BT, HS = c.shape[0], c.shape[1]
+    rec = torch.empty(BT * N, C, device=c.device, dtype=torch.float32)
+    _call("gptst_cap_rec_fwd", _p(c), _p(v), _p(rec), BT, N, C, HS)
+    return rec
+
+
+def cap_rec_bwd(drec, c, v):
+    _chk(drec, c, v)
+    BT, HS, N = c.shape
+    C = v.shape[-1]
+    dc1 = torch.empty_like(c)
+    dv = torch.empty_like(v)
+    _call("gptst_cap_rec_bwd", _p(drec), _p(c), _p(v), _p(dc1), _p(dv), BT, N, C, HS)
+    return dc1, dv
+
+
+def cap_route_bwd(X, Wp, bp, c, dc1, dS):
+    _chk(X, Wp, bp, c, dc1, dS)
+    B, T, N, C = X.shape
+    HS = c.shape[1]
+    dY = torch.empty(B * T * N, C, device=X.device, dtype=torch.float32)
+    dlogit = torch.empty_like(c)
+    _call("gptst_cap_route_bwd", _p(X), _p(Wp), _p(bp), _p(c), _p(dc1), _p(dS), _p(dY), _p(dlogit), B * T, N, C, HS)
+    return dY, dlogit

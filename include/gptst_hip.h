@@ -41,13 +41,14 @@ int gptst_poolgen_bwd_emb(const float* dW, const float* pool, int cols, const fl
 /* ---- C x C contractions on fp32 MFMA (apply.hip) ------------------------------------------------------
  * out[g,m,:] = epi( pro(A)[g,m,:] @ W[g] (+bias[g]) (+resid) ).   mode: 0 TIME (g=(b,t), rows n), 1 NODE (g=n, rows
  * (b,t)), 2 SHARED (one weight).  w_per_group: W is (G,C,C) else (C,C).  transw: W[g] stored [out][in].
- * pro: 0 none, 1 A*lrelu'(A2) (A=dOut, A2=layer output).  epi: 0 plain, 1 lrelu(acc+bias+resid).
+ * pro: 0 none, 1 A*lrelu'(A2) (A=dOut, A2=layer output).  epi: 0 plain, 1 lrelu(acc+bias+resid),
+ * 2 acc + resid*lrelu'(resid2) (adds the residual branch of a layer's backward).
  * colsum (optional, += via atomics): colsum[g,:] += sum_m pro(A)[g,m,:]  (bias gradient).
  * Replaces einsum('btni,btio->btno') / einsum('btni,nio->btno') + bias + residual + LeakyReLU
  * (GPTST.py:26-27,31-32,139-141,162-163), nn.Linear C->C (:102) and their backward w.r.t. the data. */
 int gptst_apply(const float* A, const float* A2, const float* W, int w_per_group, int transw, const float* bias,
-                const float* resid, float* out, float* colsum, int mode, int pro, int epi, int BT, int N, int C,
-                void* stream);
+                const float* resid, const float* resid2, float* out, float* colsum, int mode, int pro, int epi, int BT,
+                int N, int C, void* stream);
 /* dW[s*G + g] = sum_{m in split s} A[g,m,:]^T pro(D)[g,m,:];  nsplit = gptst_wgrad_nsplit(mode,BT,N) partial sums
  * that the consumer (gptst_poolgen_bwd_*) adds up.  dW must hold nsplit*G*C*C floats. */
 int gptst_wgrad_nsplit(int mode, int BT, int N);
@@ -63,6 +64,27 @@ int gptst_tmix(const float* X, const float* G, const float* dOut, const float* Y
                void* stream);
 /* dG[n,t,u] = sum_{b,c} dR[b,t,n,c] X[b,u,n,c]   (fp32 MFMA 16x16x4). */
 int gptst_tmix_dgraph(const float* dR, const float* X, float* dG, int B, int T, int N, int C, void* stream);
+
+/* ---- cap: node x cluster soft assignment + routing + aggregation (cap.hip, cap_cross.hip), GPTST.py:100-141 ----
+ * route_fwd, one workgroup per (b,t):  P = squash(X Wp^T + bp) by MFMA into LDS; dadj = teb.adj; v0 = squash(softmax_h(dadj) P);
+ *   R x { c = softmax_h(b); v = squash(v0 (.) c P); b += v P^T };  c = softmax_h(b + dadj) -> c_out (BT,HS,N);  s = c P -> (BT,HS,C).
+ * Wp/bp = ln_p.weight ([out][in]) / bias; teb (BT,ds); adj (ds,HS,N). */
+int gptst_cap_route_fwd(const float* X, const float* Wp, const float* bp, const float* teb, const float* adj, float* c_out,
+                        float* s_out, int BT, int N, int C, int HS, int ds, int R, void* stream);
+/* cross-time hyperedges per sample (GPTST.py:125-134): v = squash(LReLU(dyn^T LReLU(dyn (s + (t+1)/12))) + s);
+ * dyn (B,HT,T*HS) = time_eb_spg . t_adj (poolgen); saves Ht (B,HT,C), Rt (B,T*HS,C) for backward. */
+int gptst_cap_cross_fwd(const float* s, const float* dyn, const float* tmpl, float* v, float* Ht, float* Rt, int B, int T, int C,
+                        int HS, int HT, void* stream);
+int gptst_cap_cross_bwd(const float* dv, const float* s, const float* Rt, const float* Ht, const float* dyn, const float* tmpl,
+                        float* dS, float* ddyn, int B, int T, int C, int HS, int HT, void* stream);
+/* cluster -> node scatter (GPTST.py:135): rec[bt,n,:] = sum_h c[bt,h,n] v[bt,h,:]; and its backward (dc1, dv). */
+int gptst_cap_rec_fwd(const float* c, const float* v, float* rec, int BT, int N, int C, int HS, void* stream);
+int gptst_cap_rec_bwd(const float* drec, const float* c, const float* v, float* dc1, float* dv, int BT, int N, int C, int HS,
+                      void* stream);
+/* backward through s = c P, c = softmax_h(b + dadj) (routing logits b are detached, GPTST.py:108-109) and the squash:
+ * dY (BT*N,C) = grad of X Wp^T + bp;  dlogit (BT,HS,N) = grad of dadj. */
+int gptst_cap_route_bwd(const float* X, const float* Wp, const float* bp, const float* c, const float* dc1, const float* dS,
+                        float* dY, float* dlogit, int BT, int N, int C, int HS, void* stream);
 
 #ifdef __cplusplus
 }

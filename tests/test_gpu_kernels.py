@@ -149,3 +149,38 @@ def test_hypertem_layer(B, N, d, Hm):
     close(out, ref, what="hypertem out")
     for nm, a, b in zip(["x", "node_emb", "time_eb", "adj", "wpool", "bpool"], gpu, cpu):
         close(a.grad, b.grad, tol=2e-4, what="hypertem d" + nm)
+
+
+def _cap_case(B, N, C, d, ds, HS, HT, seed):
+    g = torch.Generator().manual_seed(seed)
+    T = 12
+    x = rnd(B, T, N, C, g=g, scale=0.5); ne = rnd(N, d, g=g); tes = rnd(B, ds, g=g); teb = rnd(B, T, ds, g=g)
+    t_adj = rnd(ds, HT, T * HS, g=g, scale=0.2); adj = rnd(ds, HS, N, g=g, scale=0.5)
+    wspa = rnd(d, C, C, g=g, scale=0.1); bspa = rnd(d, C, g=g, scale=0.3)
+    lw = rnd(C, C, g=g, scale=0.15); lb = rnd(C, g=g, scale=0.3)
+    go = rnd(B, T, N, C, g=g)
+    return [x, ne, tes, teb, t_adj, adj, wspa, bspa, lw, lb], go
+
+
+@pytest.mark.parametrize("B,N,d,ds,HS,HT,R", [(2, 20, 8, 4, 5, 6, 3), (2, 170, 16, 4, 10, 16, 2), (1, 33, 4, 3, 16, 5, 0),
+                                              (1, 41, 4, 4, 20, 8, 2)])
+def test_cap_layer(B, N, d, ds, HS, HT, R):
+    from gptst_amd import layers
+    dev = _dev()
+    C, T = 64, 12
+    ts, go = _cap_case(B, N, C, d, ds, HS, HT, 21)
+    tmpl = torch.linspace(1, T, steps=T) / 12.0
+    cpu = [t.clone().requires_grad_() for t in ts]
+    sd = {"c.t_adj": cpu[4], "c.adj": cpu[5], "c.weights_spa": cpu[6], "c.bias_spa": cpu[7], "c.ln_p.weight": cpu[8],
+          "c.ln_p.bias": cpu[9], "c.mask_template": tmpl}
+    ref, cref, dynref, aux = O.cap(sd, "c.", cpu[0], cpu[1], cpu[2], cpu[3], R, materialize_5d=(N <= 64), return_aux=True)
+    (ref * go).sum().backward()
+    gpu = [t.to(dev).requires_grad_() for t in ts]
+    out, c, dyn = layers.cap(*gpu, tmpl.to(dev), R)
+    (out * go.to(dev)).sum().backward()
+    close(c, cref.squeeze(-1), what="cap c")
+    close(dyn, dynref, what="cap dyn")
+    close(out, ref, what="cap out")
+    names = ["x", "node_emb", "time_eb_spg", "teb", "t_adj", "adj", "wspa", "bspa", "lnp_w", "lnp_b"]
+    for nm, a, b in zip(names, gpu, cpu):
+        close(a.grad, b.grad, tol=3e-4, what="cap d" + nm)
