@@ -12,7 +12,7 @@
 #include "mfma_tile.h"
 
 enum { PRO_NONE = 0, PRO_DPRE = 1 };          // PRO_DPRE: a = A * lrelu'(A2)   (A = dOut, A2 = layer output)
-enum { EPI_PLAIN = 0, EPI_RES_LRELU = 1, EPI_ADD_DPRE = 2 };   // 1: lrelu(acc + bias + resid)   2: acc + resid * lrelu'(resid2)
+enum { EPI_PLAIN = 0, EPI_RES_LRELU = 1, EPI_ADD_DPRE = 2, EPI_LRELU = 3 };   // 1: lrelu(acc+bias+resid)  2: acc + resid*lrelu'(resid2)  3: lrelu(acc+bias)
 
 struct RowMap {
     int G, M;
@@ -90,6 +90,7 @@ __global__ __launch_bounds__(256) void apply_kernel(const float* __restrict__ A,
                     y = f4add(y, ld4(resid + off));
                     y.x = lrelu(y.x); y.y = lrelu(y.y); y.z = lrelu(y.z); y.w = lrelu(y.w);
                 }
+                if (EPI == EPI_LRELU) { y.x = lrelu(y.x); y.y = lrelu(y.y); y.z = lrelu(y.z); y.w = lrelu(y.w); }
                 if (EPI == EPI_ADD_DPRE) {
                     const float4 d = ld4(resid + off), o = ld4(resid2 + off);
                     y.x = fmaf(d.x, lrelu_grad_from_out(o.x), y.x); y.y = fmaf(d.y, lrelu_grad_from_out(o.y), y.y);
@@ -173,6 +174,7 @@ static int launch_apply(const float* A, const float* A2, const float* W, long w_
     else if (pro == PRO_NONE && epi == EPI_RES_LRELU) LAUNCH(PRO_NONE, EPI_RES_LRELU);
     else if (pro == PRO_DPRE && epi == EPI_PLAIN) LAUNCH(PRO_DPRE, EPI_PLAIN);
     else if (pro == PRO_NONE && epi == EPI_ADD_DPRE) LAUNCH(PRO_NONE, EPI_ADD_DPRE);
+    else if (pro == PRO_NONE && epi == EPI_LRELU) LAUNCH(PRO_NONE, EPI_LRELU);
     else return GPTST_EARG;
 #undef LAUNCH
     GPTST_CHECK_LAUNCH();
@@ -187,6 +189,7 @@ static void raise_smem_limits() {
     hipFuncSetAttribute((const void*)apply_kernel<C, PRO_NONE, EPI_RES_LRELU>, hipFuncAttributeMaxDynamicSharedMemorySize, smem);
     hipFuncSetAttribute((const void*)apply_kernel<C, PRO_DPRE, EPI_PLAIN>, hipFuncAttributeMaxDynamicSharedMemorySize, smem);
     hipFuncSetAttribute((const void*)apply_kernel<C, PRO_NONE, EPI_ADD_DPRE>, hipFuncAttributeMaxDynamicSharedMemorySize, smem);
+    hipFuncSetAttribute((const void*)apply_kernel<C, PRO_NONE, EPI_LRELU>, hipFuncAttributeMaxDynamicSharedMemorySize, smem);
 }
 
 extern "C" int gptst_apply(const float* A, const float* A2, const float* W, int w_per_group, int transw,

@@ -1,0 +1,162 @@
+// Loss and optimiser tail of the pretraining step.
+//   mae   : scaler_mae_loss (reference Run.py:92-100) + MAE_torch (lib/metrics.py:11-18) + inverse_transform
+//           (lib/normalization.py:23-27):  p=(out*s+m)*M, y=(label*s+m)*M, keep = y > thresh, loss = mean_keep |y-p|
+//   kl    : 0.1 * KLDivLoss(sum)(log prob, eb) (Run.py:132, BasicTrainer.py:85) fused with the softmax backward of MLP_RL
+//   adam  : clip_grad_norm_(5) + Adam (BasicTrainer.py:95-97, Run.py:134) as ONE pass over a flat parameter buffer
+// stats (device float[8]): [0] sum |y-p| over kept cells, [1] kept count, [2] sum eb*(log eb - log prob), [3] sum g^2 (scaled)
+// Everything stays on the device: the reference syncs on loss.item() and masked_select every step.
+#include "common.h"
+
+// mask: 1 = visible, 0 = masked (reconstruction target);  the reference multiplies with (1 - mask)
+__global__ __launch_bounds__(256) void mae_fwd_kernel(const float* __restrict__ out, const float* __restrict__ src, int lda,
+                                                      const float* __restrict__ mask, float sigma, float mu, float thresh, int rows,
+                                                      int J, float* __restrict__ stats) {
+    __shared__ float red[2][4];
+    float ls = 0.f, cnt = 0.f;
+    for (size_t e = (size_t)blockIdx.x * 256 + threadIdx.x; e < (size_t)rows * J; e += (size_t)gridDim.x * 256) {
+        const size_t i = e / J; const int j = (int)(e % J);
+        const float M = 1.f - mask[e];
+        const float p = (out[e] * sigma + mu) * M;
+        const float y = (src[i * lda + j] * sigma + mu) * M;
+        if (y > thresh) { ls += fabsf(y - p); cnt += 1.f; }
+    }
+    ls = group_sum<64>(ls); cnt = group_sum<64>(cnt);
+    if ((threadIdx.x & 63) == 0) { red[0][threadIdx.x >> 6] = ls; red[1][threadIdx.x >> 6] = cnt; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        atomicAdd(stats + 0, red[0][0] + red[0][1] + red[0][2] + red[0][3]);
+        atomicAdd(stats + 1, red[1][0] + red[1][1] + red[1][2] + red[1][3]);
+    }
+}
+
+// dOut = d loss / d out;  normalize: divide by the kept count in stats[1] (single GPU);  otherwise gradient of the SUM
+// (data-parallel: the count is all-reduced with the gradients and applied in the optimiser)
+__global__ __launch_bounds__(256) void mae_bwd_kernel(const float* __restrict__ out, const float* __restrict__ src, int lda,
+                                                      const float* __restrict__ mask, float sigma, float mu, float thresh, int rows,
+                                                      int J, const float* __restrict__ stats, int normalize, float* __restrict__ dOut) {
+    const float inv = normalize ? 1.f / fmaxf(stats[1], 1.f) : 1.f;
+    for (size_t e = (size_t)blockIdx.x * 256 + threadIdx.x; e < (size_t)rows * J; e += (size_t)gridDim.x * 256) {
+        const size_t i = e / J; const int j = (int)(e % J);
+        const float M = 1.f - mask[e];
+        const float p = (out[e] * sigma + mu) * M;
+        const float y = (src[i * lda + j] * sigma + mu) * M;
+        float g = 0.f;
+        if (y > thresh) {
+            const float d = p - y;
+            g = (d > 0.f ? 1.f : (d < 0.f ? -1.f : 0.f)) * M * sigma * inv;
+        }
+        dOut[e] = g;
+    }
+}
+
+// prob (rows, HS) row-major;  eb = cap1 soft assignment c laid out (BT, HS, N): eb[i=(bt,n)][h] = c[(bt*HS + h)*N + n].
+// stats[2] += sum eb*(log eb - log prob);   dlogit[i][h] = w * (prob[i][h] * sum_h eb - eb[i][h])   (softmax + KL backward)
+__global__ __launch_bounds__(256) void kl_kernel(const float* __restrict__ prob, const float* __restrict__ c, int rows, int N, int HS,
+                                                 float w, float* __restrict__ dlogit, float* __restrict__ stats) {
+    __shared__ float red[4];
+    float kl = 0.f;
+    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (i < (size_t)rows) {
+        const size_t bt = i / N, n = i % N;
+        const float* cp = c + bt * HS * N + n;
+        float se = 0.f;
+        for (int h = 0; h < HS; ++h) {
+            const float e = cp[(size_t)h * N], p = prob[i * HS + h];
+            se += e;
+            if (e > 0.f) kl += e * (logf(e) - logf(p));
+        }
+        if (dlogit != nullptr)
+            for (int h = 0; h < HS; ++h) dlogit[i * HS + h] = w * (prob[i * HS + h] * se - cp[(size_t)h * N]);
+    }
+    kl = group_sum<64>(kl);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = kl;
+    __syncthreads();
+    if (threadIdx.x == 0) atomicAdd(stats + 2, red[0] + red[1] + red[2] + red[3]);
+}
+
+// hyper (device float[16]), refreshed by the host before every step:
+//  [0] step_size_A = lr/(1-b1^tA)  [1] bc2sqrt_A = sqrt(1-b2^tA)  [2] step_size_B  [3] bc2sqrt_B  [4] beta1  [5] beta2  [6] eps
+//  [7] max_norm (<=0: no clipping)  [8] active_B (0/1)  [9] gscale_A mode: 0 -> 1, 1 -> 1/max(stats[1],1)   [10] gscale_B
+// segment A = parameters on the reconstruction-loss path, B = MLP_RL / teb4mask / neb4mask (KL path; no gradient - hence no
+// Adam state, as in torch - until epoch > change_epoch);  parameters after nA+nB never receive gradients.
+__device__ __forceinline__ float seg_scale(const float* hyper, const float* stats, bool segA) {
+    if (segA) return hyper[9] != 0.f ? 1.f / fmaxf(stats[1], 1.f) : 1.f;
+    return hyper[10];
+}
+
+__global__ __launch_bounds__(256) void gradnorm_kernel(const float* __restrict__ g, long nA, long nB, const float* __restrict__ hyper,
+                                                       float* __restrict__ stats) {
+    __shared__ float red[4];
+    const bool actB = hyper[8] != 0.f;
+    const float sa = seg_scale(hyper, stats, true), sb = seg_scale(hyper, stats, false);
+    const long n = nA + (actB ? nB : 0);
+    float s = 0.f;
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256) {
+        const float v = g[i] * (i < nA ? sa : sb);
+        s = fmaf(v, v, s);
+    }
+    s = group_sum<64>(s);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
+    __syncthreads();
+    if (threadIdx.x == 0) atomicAdd(stats + 3, red[0] + red[1] + red[2] + red[3]);
+}
+
+__global__ __launch_bounds__(256) void adam_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m,
+                                                   float* __restrict__ v, long nA, long nB, const float* __restrict__ hyper,
+                                                   const float* __restrict__ stats) {
+    const bool actB = hyper[8] != 0.f;
+    const long n = nA + (actB ? nB : 0);
+    const float b1 = hyper[4], b2 = hyper[5], eps = hyper[6], maxn = hyper[7];
+    float clip = 1.f;
+    if (maxn > 0.f) clip = fminf(1.f, maxn / (sqrtf(stats[3]) + 1e-6f));          // clip_grad_norm_
+    const float sa = seg_scale(hyper, stats, true) * clip, sb = seg_scale(hyper, stats, false) * clip;
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256) {
+        const bool A = i < nA;
+        const float gr = g[i] * (A ? sa : sb);
+        const float step = A ? hyper[0] : hyper[2], bc2 = A ? hyper[1] : hyper[3];
+        float mi = m[i], vi = v[i];
+        mi = mi + (gr - mi) * (1.f - b1);                      // exp_avg.lerp_(grad, 1-beta1)
+        vi = vi * b2 + (1.f - b2) * gr * gr;                   // exp_avg_sq.mul_(beta2).addcmul_(grad, grad, 1-beta2)
+        const float denom = sqrtf(vi) / bc2 + eps;
+        p[i] = p[i] - step * (mi / denom);                     // param.addcdiv_(exp_avg, denom, -step_size)
+        m[i] = mi; v[i] = vi;
+    }
+}
+
+extern "C" int gptst_mae_fwd(const float* out, const float* src, int lda, const float* mask, float sigma, float mu, float thresh,
+                             int rows, int J, float* stats, void* stream) {
+    if (!out || !src || !mask || !stats) return GPTST_EARG;
+    int nb = (int)(((size_t)rows * J + 255) / 256); if (nb > 512) nb = 512;
+    hipLaunchKernelGGL(mae_fwd_kernel, dim3(nb), dim3(256), 0, (hipStream_t)stream, out, src, lda, mask, sigma, mu, thresh, rows, J, stats);
+    GPTST_CHECK_LAUNCH();
+    return GPTST_OK;
+}
+
+extern "C" int gptst_mae_bwd(const float* out, const float* src, int lda, const float* mask, float sigma, float mu, float thresh,
+                             int rows, int J, const float* stats, int normalize, float* dOut, void* stream) {
+    if (!out || !src || !mask || !stats || !dOut) return GPTST_EARG;
+    int nb = (int)(((size_t)rows * J + 255) / 256); if (nb > 1024) nb = 1024;
+    hipLaunchKernelGGL(mae_bwd_kernel, dim3(nb), dim3(256), 0, (hipStream_t)stream, out, src, lda, mask, sigma, mu, thresh, rows, J, stats,
+                       normalize, dOut);
+    GPTST_CHECK_LAUNCH();
+    return GPTST_OK;
+}
+
+extern "C" int gptst_kl(const float* prob, const float* c, int rows, int N, int HS, float w, float* dlogit, float* stats, void* stream) {
+    if (!prob || !c || !stats) return GPTST_EARG;
+    hipLaunchKernelGGL(kl_kernel, dim3((rows + 255) / 256), dim3(256), 0, (hipStream_t)stream, prob, c, rows, N, HS, w, dlogit, stats);
+    GPTST_CHECK_LAUNCH();
+    return GPTST_OK;
+}
+
+// stats[3] must be zero on entry (the caller zeroes the stats block once per step)
+extern "C" int gptst_clip_adam(float* p, const float* g, float* m, float* v, long nA, long nB, const float* hyper, float* stats,
+                               void* stream) {
+    if (!p || !g || !m || !v || !hyper || !stats) return GPTST_EARG;
+    long n = nA + nB;
+    int nb = (int)((n + 255) / 256); if (nb > 1024) nb = 1024;
+    hipLaunchKernelGGL(gradnorm_kernel, dim3(nb), dim3(256), 0, (hipStream_t)stream, g, nA, nB, hyper, stats);
+    hipLaunchKernelGGL(adam_kernel, dim3(nb), dim3(256), 0, (hipStream_t)stream, p, g, m, v, nA, nB, hyper, stats);
+    GPTST_CHECK_LAUNCH();
+    return GPTST_OK;
+}

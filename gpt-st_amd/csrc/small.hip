@@ -1,0 +1,175 @@
+// Thin projections at the edges of the network — all HBM bound, VALU only, float4 rows:
+//   lin_in   : Y[i,:]  = sum_{j<J} a[i,j] W(:,j) + b      J = input_base_dim (1..2) or HS; optional masking of a
+//              (dim_in_flow with mask / scaler_zeros, GPTST.py:416-418; MLP_RL.ln1 :22; data-gradients of the C->J Linears)
+//   rowdot   : Z[i,j]  = X[i,:] . W[j,:] + b[j], optional softmax over j
+//              (dim_flow_out :455; MLP_RL.ln3 + softmax :33,:332/:343)
+//   rowouter : out(j,c) += sum_i a[i,j] X[i,c]  (+ column sums)          weight / bias gradients of the above
+#include "common.h"
+
+#define SM_MAXJ 64
+
+// a'[i,j] = mask ? (mask[i*J+j] != 0 ? a : fill) : a          a has row stride lda
+__device__ __forceinline__ float masked_a(const float* __restrict__ a, const float* __restrict__ mask, float fill, size_t i, int j,
+                                          int lda, int J) {
+    const float v = a[i * lda + j];
+    if (mask == nullptr) return v;
+    return mask[i * J + j] != 0.f ? v : fill;
+}
+
+// grid: ceil(rows / (256/(C/4))), block 256.  wlayout 0: W[c*J + j] (nn.Linear weight (C,J));  1: W[j*C + c].
+template <int C>
+__global__ __launch_bounds__(256) void lin_in_kernel(const float* __restrict__ a, int lda, const float* __restrict__ mask, float fill,
+                                                     const float* __restrict__ W, int wlayout, const float* __restrict__ b,
+                                                     float* __restrict__ Y, int rows, int J) {
+    constexpr int LPR = C / 4, RPB = 256 / LPR;
+    __shared__ float Ws[SM_MAXJ * C];           // stored [j][c]
+    for (int i = threadIdx.x; i < J * C; i += 256) {
+        const int j = i / C, c = i % C;
+        Ws[i] = wlayout ? W[i] : W[c * J + j];
+    }
+    __syncthreads();
+    const int c4 = threadIdx.x % LPR;
+    const size_t i = (size_t)blockIdx.x * RPB + threadIdx.x / LPR;
+    if (i >= (size_t)rows) return;
+    float4 acc = b ? ld4(b + 4 * c4) : f4zero();
+    for (int j = 0; j < J; ++j) acc = f4fma(masked_a(a, mask, fill, i, j, lda, J), ld4(Ws + j * C + 4 * c4), acc);
+    st4(Y + i * C + 4 * c4, acc);
+}
+
+// Z[i,j] = X[i,:].W[j,:] + b[j];  softmax over j when do_softmax.  C/4 lanes per row, butterfly reduce.
+template <int C>
+__global__ __launch_bounds__(256) void rowdot_kernel(const float* __restrict__ X, const float* __restrict__ W, const float* __restrict__ b,
+                                                     float* __restrict__ Z, int rows, int J, int do_softmax) {
+    constexpr int LPR = C / 4, RPB = 256 / LPR;
+    __shared__ float Ws[SM_MAXJ * C];
+    for (int i = threadIdx.x; i < J * C / 4; i += 256) st4(Ws + 4 * i, ld4(W + 4 * i));
+    __syncthreads();
+    const int c4 = threadIdx.x % LPR;
+    const size_t i = (size_t)blockIdx.x * RPB + threadIdx.x / LPR;
+    const bool valid = i < (size_t)rows;
+    const float4 x = valid ? ld4(X + i * C + 4 * c4) : f4zero();
+    float mine[(SM_MAXJ + LPR - 1) / LPR];      // logits owned by this lane: j = c4 + q*LPR
+    float m = -3.0e38f;
+#pragma unroll
+    for (int q = 0; q < (SM_MAXJ + LPR - 1) / LPR; ++q) {
+        mine[q] = 0.f;
+        for (int jj = 0; jj < LPR; ++jj) {
+            const int j = q * LPR + jj;
+            if (j < J) {                                       // uniform
+                const float u = group_sum<LPR>(f4dot(x, ld4(Ws + j * C + 4 * c4))) + (b ? b[j] : 0.f);
+                if (jj == c4) mine[q] = u;
+            }
+        }
+        if (q * LPR + c4 < J) m = fmaxf(m, mine[q]);
+    }
+    if (do_softmax) {
+        m = group_max<LPR>(m);
+        float s = 0.f;
+#pragma unroll
+        for (int q = 0; q < (SM_MAXJ + LPR - 1) / LPR; ++q)
+            if (q * LPR + c4 < J) { mine[q] = expf(mine[q] - m); s += mine[q]; }
+        s = group_sum<LPR>(s);
+        const float inv = 1.f / s;
+#pragma unroll
+        for (int q = 0; q < (SM_MAXJ + LPR - 1) / LPR; ++q) mine[q] *= inv;
+    }
+    if (valid) {
+#pragma unroll
+        for (int q = 0; q < (SM_MAXJ + LPR - 1) / LPR; ++q)
+            if (q * LPR + c4 < J) Z[i * J + q * LPR + c4] = mine[q];
+    }
+}
+
+// out(j,c) += sum_i a'[i,j] X[i,c]   (olayout 0: out[c*J+j], 1: out[j*C+c]);  csum[c] += sum_i X[i,c];  asum[j] += sum_i a'[i,j]
+// grid: nblocks row chunks; J processed in register blocks of 8.
+template <int C>
+__global__ __launch_bounds__(256) void rowouter_kernel(const float* __restrict__ a, int lda, const float* __restrict__ mask, float fill,
+                                                       const float* __restrict__ X, float* __restrict__ out, int olayout,
+                                                       float* __restrict__ csum, float* __restrict__ asum, int rows, int J,
+                                                       int rows_per_block) {
+    constexpr int LPR = C / 4, RPB = 256 / LPR;
+    __shared__ float4 red[RPB][LPR];
+    const int c4 = threadIdx.x % LPR, slot = threadIdx.x / LPR;
+    const size_t r0 = (size_t)blockIdx.x * rows_per_block;
+    const size_t r1 = min((size_t)rows, r0 + rows_per_block);
+    for (int jb = 0; jb < J || (jb == 0 && J == 0); jb += 8) {
+        float4 acc[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) acc[u] = f4zero();
+        float4 cacc = f4zero();
+        for (size_t i = r0 + slot; i < r1; i += RPB) {
+            const float4 x = ld4(X + i * C + 4 * c4);
+            if (jb == 0) cacc = f4add(cacc, x);
+#pragma unroll
+            for (int u = 0; u < 8; ++u)
+                if (jb + u < J) acc[u] = f4fma(masked_a(a, mask, fill, i, jb + u, lda, J), x, acc[u]);
+        }
+        // reduce the RPB row slots through LDS, then one atomic per (j, c)
+#pragma unroll
+        for (int u = 0; u < 9; ++u) {
+            const bool is_c = (u == 8);
+            if (is_c ? (jb != 0 || csum == nullptr) : (jb + u >= J)) continue;       // uniform
+            red[slot][c4] = is_c ? cacc : acc[u < 8 ? u : 0];
+            __syncthreads();
+            if (slot == 0) {
+                float4 s = red[0][c4];
+                for (int q = 1; q < RPB; ++q) s = f4add(s, red[q][c4]);
+                if (is_c) {
+                    float* o = csum + 4 * c4;
+                    atomicAdd(o, s.x); atomicAdd(o + 1, s.y); atomicAdd(o + 2, s.z); atomicAdd(o + 3, s.w);
+                } else if (olayout) {
+                    float* o = out + (size_t)(jb + u) * C + 4 * c4;
+                    atomicAdd(o, s.x); atomicAdd(o + 1, s.y); atomicAdd(o + 2, s.z); atomicAdd(o + 3, s.w);
+                } else {
+                    float* o = out + (size_t)(4 * c4) * J + jb + u;
+                    atomicAdd(o, s.x); atomicAdd(o + J, s.y); atomicAdd(o + 2 * J, s.z); atomicAdd(o + 3 * J, s.w);
+                }
+            }
+            __syncthreads();
+        }
+    }
+    if (asum != nullptr) {          // column sums of a' over this block's rows
+        for (int j = 0; j < J; ++j) {
+            float s = 0.f;
+            for (size_t i = r0 + threadIdx.x; i < r1; i += 256) s += masked_a(a, mask, fill, i, j, lda, J);
+            s = group_sum<64>(s);
+            if ((threadIdx.x & 63) == 0) atomicAdd(asum + j, s);
+        }
+    }
+}
+
+extern "C" int gptst_lin_in(const float* a, int lda, const float* mask, float fill, const float* W, int wlayout, const float* b,
+                            float* Y, int rows, int J, int C, void* stream) {
+    if (!a || !W || !Y || J <= 0 || J > SM_MAXJ) return GPTST_EARG;
+    hipStream_t st = (hipStream_t)stream;
+    if (C == 64) hipLaunchKernelGGL((lin_in_kernel<64>), dim3((rows + 15) / 16), dim3(256), 0, st, a, lda, mask, fill, W, wlayout, b, Y, rows, J);
+    else if (C == 128) hipLaunchKernelGGL((lin_in_kernel<128>), dim3((rows + 7) / 8), dim3(256), 0, st, a, lda, mask, fill, W, wlayout, b, Y, rows, J);
+    else return GPTST_ESHAPE;
+    GPTST_CHECK_LAUNCH();
+    return GPTST_OK;
+}
+
+extern "C" int gptst_rowdot(const float* X, const float* W, const float* b, float* Z, int rows, int J, int C, int do_softmax,
+                            void* stream) {
+    if (!X || !W || !Z || J <= 0 || J > SM_MAXJ) return GPTST_EARG;
+    hipStream_t st = (hipStream_t)stream;
+    if (C == 64) hipLaunchKernelGGL((rowdot_kernel<64>), dim3((rows + 15) / 16), dim3(256), 0, st, X, W, b, Z, rows, J, do_softmax);
+    else if (C == 128) hipLaunchKernelGGL((rowdot_kernel<128>), dim3((rows + 7) / 8), dim3(256), 0, st, X, W, b, Z, rows, J, do_softmax);
+    else return GPTST_ESHAPE;
+    GPTST_CHECK_LAUNCH();
+    return GPTST_OK;
+}
+
+extern "C" int gptst_rowouter(const float* a, int lda, const float* mask, float fill, const float* X, float* out, int olayout,
+                              float* csum, float* asum, int rows, int J, int C, void* stream) {
+    if (!X || J < 0 || J > SM_MAXJ || (J > 0 && (!a || !out))) return GPTST_EARG;
+    int nb = 512;
+    int rpb = (rows + nb - 1) / nb; if (rpb < 16) rpb = 16;
+    nb = (rows + rpb - 1) / rpb;
+    hipStream_t st = (hipStream_t)stream;
+    if (C == 64) hipLaunchKernelGGL((rowouter_kernel<64>), dim3(nb), dim3(256), 0, st, a, lda, mask, fill, X, out, olayout, csum, asum, rows, J, rpb);
+    else if (C == 128) hipLaunchKernelGGL((rowouter_kernel<128>), dim3(nb), dim3(256), 0, st, a, lda, mask, fill, X, out, olayout, csum, asum, rows, J, rpb);
+    else return GPTST_ESHAPE;
+    GPTST_CHECK_LAUNCH();
+    return GPTST_OK;
+}

@@ -109,3 +109,38 @@ class CapFn(torch.autograd.Function):
 
 def cap(x, node_emb, time_eb_spg, teb, t_adj, adj, wspa, bspa, lnp_w, lnp_b, tmpl, num_route):
     return CapFn.apply(x, node_emb, time_eb_spg, teb, t_adj, adj, wspa, bspa, lnp_w, lnp_b, tmpl, num_route)
+
+
+class CondLinearFn(torch.autograd.Function):
+    """LReLU(x @ W_g + b_g) with embedding-generated weights, no residual (MLP_RL, reference GPTST.py:24-32).
+    mode MODE_NODE: g = n, emb (N,d);  mode MODE_TIME: g = (b,t), emb (B*T,d)."""
+
+    @staticmethod
+    def forward(ctx, x, emb, wpool, bpool, mode):
+        B, T, N, C = x.shape
+        x = x.contiguous()
+        emb2 = emb.reshape(-1, emb.shape[-1]).contiguous()
+        Wg, bg = ops.poolgen(emb2, wpool, bpool)
+        out = ops.apply(x.view(-1, C), Wg, mode, B * T, N, bias=bg, epi=ops.EPI_LRELU).view(B, T, N, C)
+        ctx.save_for_backward(x, out, Wg, emb2, wpool, bpool)
+        ctx.mode, ctx.emb_shape = mode, emb.shape
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        x, out, Wg, emb2, wpool, bpool = ctx.saved_tensors
+        B, T, N, C = x.shape
+        BT, mode = B * T, ctx.mode
+        G = emb2.shape[0]
+        dout = dout.contiguous().view(-1, C)
+        db = torch.zeros(G, C, device=x.device)
+        dx = ops.apply(dout, Wg, mode, BT, N, A2=out.view(-1, C), transw=True, pro=PRO_DPRE, colsum=db)
+        dW, ns = ops.wgrad(x.view(-1, C), dout, mode, BT, N, D2=out.view(-1, C), pro=PRO_DPRE)
+        dwpool, dbpool, demb = torch.zeros_like(wpool), torch.zeros_like(bpool), torch.zeros_like(emb2)
+        ops.poolgen_bwd_pool(emb2, dW, dwpool, db, dbpool, nsplit=ns)
+        ops.poolgen_bwd_emb(dW, wpool, demb, db, bpool, nsplit=ns)
+        return dx.view(B, T, N, C), demb.view(ctx.emb_shape), dwpool, dbpool, None
+
+
+def cond_linear(x, emb, wpool, bpool, mode):
+    return CondLinearFn.apply(x, emb, wpool, bpool, mode)

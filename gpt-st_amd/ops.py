@@ -9,7 +9,7 @@ from . import _C
 
 MODE_TIME, MODE_NODE, MODE_SHARED = 0, 1, 2
 PRO_NONE, PRO_DPRE = 0, 1
-EPI_PLAIN, EPI_RES_LRELU, EPI_ADD_DPRE = 0, 1, 2
+EPI_PLAIN, EPI_RES_LRELU, EPI_ADD_DPRE, EPI_LRELU = 0, 1, 2, 3
 
 _p = _C.ptr
 
@@ -172,3 +172,90 @@ def cap_route_bwd(X, Wp, bp, c, dc1, dS):
     dlogit = torch.empty_like(c)
     _call("gptst_cap_route_bwd", _p(X), _p(Wp), _p(bp), _p(c), _p(dc1), _p(dS), _p(dY), _p(dlogit), B * T, N, C, HS)
     return dY, dlogit
+
+
+# ---- mask generation (integer path) -----------------------------------------------------------------------------
+def mask_random(noise, k):
+    _chk(noise)
+    mask = torch.empty_like(noise)
+    _call("gptst_mask_random", _p(noise), noise.numel(), int(k), _p(mask))
+    return mask
+
+
+def mask_labels(prob):
+    """prob (rows, HS) -> label int32 (rows), counts int32 (HS)."""
+    _chk(prob)
+    rows, HS = prob.shape
+    label = torch.empty(rows, device=prob.device, dtype=torch.int32)
+    counts = torch.empty(HS, device=prob.device, dtype=torch.int32)
+    _call("gptst_mask_labels", _p(prob), rows, HS, _p(label), _p(counts))
+    return label, counts
+
+
+def mask_adaptive(label, counts, list_c, nums, noise_a, noise_r, ada_all, base):
+    """-> (m_ada (M), m_rnd (M), mask (M*base)) fp32 {0,1}."""
+    M, HS = label.numel(), counts.numel()
+    m_ada = torch.empty(M, device=label.device, dtype=torch.float32)
+    m_rnd = torch.empty_like(m_ada)
+    mask = torch.empty(M * base, device=label.device, dtype=torch.float32)
+    _call("gptst_mask_adaptive", _p(label), _p(counts), _p(list_c), _p(nums), _p(noise_a), _p(noise_r), int(ada_all), M, HS, base,
+          _p(m_ada), _p(m_rnd), _p(mask))
+    return m_ada, m_rnd, mask
+
+
+# ---- thin projections -------------------------------------------------------------------------------------------
+def lin_in(a, lda, J, W, b, C, mask=None, fill=0.0, wlayout=0, rows=None):
+    rows = rows if rows is not None else a.numel() // lda
+    Y = torch.empty(rows, C, device=a.device, dtype=torch.float32)
+    _call("gptst_lin_in", _p(a), lda, _p(mask), float(fill), _p(W), wlayout, _p(b), _p(Y), rows, J, C)
+    return Y
+
+
+def rowdot(X, W, b, softmax=False):
+    rows, C = X.shape
+    J = W.shape[0]
+    Z = torch.empty(rows, J, device=X.device, dtype=torch.float32)
+    _call("gptst_rowdot", _p(X), _p(W), _p(b), _p(Z), rows, J, C, int(softmax))
+    return Z
+
+
+def rowouter(a, lda, J, X, out, olayout, csum=None, asum=None, mask=None, fill=0.0):
+    rows, C = X.shape
+    _call("gptst_rowouter", _p(a), lda, _p(mask), float(fill), _p(X), _p(out), olayout, _p(csum), _p(asum), rows, J, C)
+
+
+# ---- time features ----------------------------------------------------------------------------------------------
+def timefeat_fwd(params, tidx, rows, K):
+    """params: the 10 nn.Linear tensors in module order; tidx (B,T,2) contiguous."""
+    E = params[1].numel()
+    out = torch.empty(rows, E, device=tidx.device, dtype=torch.float32)
+    _call("gptst_timefeat_fwd", *[_p(t) for t in params], _p(tidx), _p(out), rows, K, E)
+    return out
+
+
+def timefeat_bwd(params, grads, tidx, dout, rows, K):
+    E = params[1].numel()
+    _call("gptst_timefeat_bwd", *[_p(t) for t in params], *[_p(t) for t in grads], _p(tidx), _p(dout), rows, K, E)
+
+
+# ---- loss / optimiser -------------------------------------------------------------------------------------------
+def mae_fwd(out, src, lda, mask, sigma, mu, thresh, rows, J, stats):
+    _call("gptst_mae_fwd", _p(out), _p(src), lda, _p(mask), float(sigma), float(mu), float(thresh), rows, J, _p(stats))
+
+
+def mae_bwd(out, src, lda, mask, sigma, mu, thresh, rows, J, stats, normalize=True):
+    dOut = torch.empty_like(out)
+    _call("gptst_mae_bwd", _p(out), _p(src), lda, _p(mask), float(sigma), float(mu), float(thresh), rows, J, _p(stats), int(normalize),
+          _p(dOut))
+    return dOut
+
+
+def kl(prob, c, N, w, stats, want_grad=True):
+    rows, HS = prob.shape
+    dlogit = torch.empty_like(prob) if want_grad else None
+    _call("gptst_kl", _p(prob), _p(c), rows, N, HS, float(w), _p(dlogit), _p(stats))
+    return dlogit
+
+
+def clip_adam(p, g, m, v, nA, nB, hyper, stats):
+    _call("gptst_clip_adam", _p(p), _p(g), _p(m), _p(v), int(nA), int(nB), _p(hyper), _p(stats))

@@ -42,7 +42,7 @@ int gptst_poolgen_bwd_emb(const float* dW, const float* pool, int cols, const fl
  * out[g,m,:] = epi( pro(A)[g,m,:] @ W[g] (+bias[g]) (+resid) ).   mode: 0 TIME (g=(b,t), rows n), 1 NODE (g=n, rows
  * (b,t)), 2 SHARED (one weight).  w_per_group: W is (G,C,C) else (C,C).  transw: W[g] stored [out][in].
  * pro: 0 none, 1 A*lrelu'(A2) (A=dOut, A2=layer output).  epi: 0 plain, 1 lrelu(acc+bias+resid),
- * 2 acc + resid*lrelu'(resid2) (adds the residual branch of a layer's backward).
+ * 2 acc + resid*lrelu'(resid2) (adds the residual branch of a layer's backward), 3 lrelu(acc+bias).
  * colsum (optional, += via atomics): colsum[g,:] += sum_m pro(A)[g,m,:]  (bias gradient).
  * Replaces einsum('btni,btio->btno') / einsum('btni,nio->btno') + bias + residual + LeakyReLU
  * (GPTST.py:26-27,31-32,139-141,162-163), nn.Linear C->C (:102) and their backward w.r.t. the data. */
@@ -85,6 +85,53 @@ int gptst_cap_rec_bwd(const float* drec, const float* c, const float* v, float* 
  * dY (BT*N,C) = grad of X Wp^T + bp;  dlogit (BT,HS,N) = grad of dadj. */
 int gptst_cap_route_bwd(const float* X, const float* Wp, const float* bp, const float* c, const float* dc1, const float* dS,
                         float* dY, float* dlogit, int BT, int N, int C, int HS, void* stream);
+
+/* ---- mask generation, integer work, bit-exact given noise/labels/class order (maskgen.hip), GPTST.py:314-323,344-413 ----
+ * Masks are fp32 {0,1} arrays, 1 = visible, 0 = masked.  Top-k = radix select (ties at rank k -> lowest index). */
+int gptst_mask_random(const float* noise, int M, int k, float* mask, void* stream);
+/* label[i] = argmax_h prob[i,h] (int32), counts[h] (int32, zeroed here) — replaces sort(..)[..., 0] (:344-345). */
+int gptst_mask_labels(const float* prob, int rows, int HS, int* label, int* counts, void* stream);
+/* adaptive phase: device-side class selection (:356-384) + two selections (:386-407) + product (:410-413).
+ * list_c: shuffled class order (int32[HS]); nums: {adaptive_mask_num, random_mask_num} int32[2] on the device;
+ * m_ada / m_rnd (M) are the partial masks, mask (M*base) the final one. */
+int gptst_mask_adaptive(const int* label, const int* counts, const int* list_c, const int* nums, const float* noise_a,
+                        const float* noise_r, int ada_all, int M, int HS, int base, float* m_ada, float* m_rnd, float* mask,
+                        void* stream);
+
+/* ---- thin projections (small.hip) ------------------------------------------------------------------------
+ * lin_in: Y[i,:] = sum_j a'[i,j] W(:,j) + b, a' = mask ? (mask[i,j] ? a[i*lda+j] : fill) : a;  wlayout 0: W[c*J+j], 1: W[j*C+c].
+ *   (dim_in_flow on the masked source, GPTST.py:416-418; MLP_RL.ln1 :22; data-gradients of rowdot)
+ * rowdot: Z[i,j] = X[i,:].W[j,:] + b[j] (+ softmax over j)   (dim_flow_out :455; MLP_RL.ln3 + softmax :33,:332)
+ * rowouter: out(j,c) += sum_i a'[i,j] X[i,c] (olayout 0: out[c*J+j], 1: out[j*C+c]); csum[c] += sum_i X[i,c];
+ *   asum[j] += sum_i a'[i,j]    (weight / bias gradients of both) */
+int gptst_lin_in(const float* a, int lda, const float* mask, float fill, const float* W, int wlayout, const float* b, float* Y,
+                 int rows, int J, int C, void* stream);
+int gptst_rowdot(const float* X, const float* W, const float* b, float* Z, int rows, int J, int C, int do_softmax, void* stream);
+int gptst_rowouter(const float* a, int lda, const float* mask, float fill, const float* X, float* out, int olayout, float* csum,
+                   float* asum, int rows, int J, int C, void* stream);
+
+/* ---- time-index embeddings (timefeat.hip), GPTST.py:187-219 ------------------------------------------------
+ * rows x K day/week features (K=1: time_feature, rows=B*T; K=12: time_feature_spg, rows=B) -> (rows, E).
+ * The ten tensors are ln_day.{weight,bias}, ln_week.{..}, ln1.{..}, ln2.{..}, ln.{..}; bwd ACCUMULATES into g*. */
+int gptst_timefeat_fwd(const float* wd, const float* bd, const float* ww, const float* bw, const float* w1, const float* b1,
+                       const float* w2, const float* b2, const float* w3, const float* b3, const float* tidx, float* out, int rows,
+                       int K, int E, void* stream);
+int gptst_timefeat_bwd(const float* wd, const float* bd, const float* ww, const float* bw, const float* w1, const float* b1,
+                       const float* w2, const float* b2, const float* w3, const float* b3, float* gwd, float* gbd, float* gww,
+                       float* gbw, float* gw1, float* gb1, float* gw2, float* gb2, float* gw3, float* gb3, const float* tidx,
+                       const float* dout, int rows, int K, int E, void* stream);
+
+/* ---- loss + optimiser (loss_adam.hip) ---------------------------------------------------------------------
+ * stats: device float[8] zeroed once per step: [0] sum|y-p| [1] kept count [2] KL sum [3] sum g^2.
+ * mae: Run.py:92-100 + lib/metrics.py:11-18 + lib/normalization.py:23-27;  kl: Run.py:132 + BasicTrainer.py:85 (w = 0.1),
+ * also emits the gradient w.r.t. the MLP_RL logits;  clip_adam: BasicTrainer.py:95-97 + Run.py:134 over flat buffers
+ * (hyper layout documented in loss_adam.hip). */
+int gptst_mae_fwd(const float* out, const float* src, int lda, const float* mask, float sigma, float mu, float thresh, int rows,
+                  int J, float* stats, void* stream);
+int gptst_mae_bwd(const float* out, const float* src, int lda, const float* mask, float sigma, float mu, float thresh, int rows,
+                  int J, const float* stats, int normalize, float* dOut, void* stream);
+int gptst_kl(const float* prob, const float* c, int rows, int N, int HS, float w, float* dlogit, float* stats, void* stream);
+int gptst_clip_adam(float* p, const float* g, float* m, float* v, long nA, long nB, const float* hyper, float* stats, void* stream);
 
 #ifdef __cplusplus
 }

@@ -184,3 +184,186 @@ def test_cap_layer(B, N, d, ds, HS, HT, R):
     names = ["x", "node_emb", "time_eb_spg", "teb", "t_adj", "adj", "wspa", "bspa", "lnp_w", "lnp_b"]
     for nm, a, b in zip(names, gpu, cpu):
         close(a.grad, b.grad, tol=3e-4, what="cap d" + nm)
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# integer path: mask generation, bit-exact vs the oracle's sort/scatter restatement
+# ---------------------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("M,ratio,seed", [(65280, 0.25, 1), (5000, 0.25, 2), (1234, 0.9, 3), (777, 0.0, 4), (300, 1.0, 5)])
+def test_mask_random_bit_exact(M, ratio, seed):
+    from gptst_amd import ops, synth
+    dev = _dev()
+    noise = synth.make_noise(M, seed)
+    ref = O.random_mask(noise, ratio)
+    got = ops.mask_random(noise.to(dev), int(M * ratio))
+    assert torch.equal(got.cpu().to(torch.int64), ref)
+
+
+def test_mask_random_ties_lowest_index():
+    """Duplicated values straddling rank k: exactly k cells are dropped, larger values first, ties -> lowest index."""
+    from gptst_amd import ops
+    dev = _dev()
+    noise = torch.tensor([0.5, 0.25, 0.5, 0.75, 0.5, 0.1, 0.5, 0.0] * 40)
+    for k in (0, 40, 41, 100, 199, 200, 201, 320):
+        got = ops.mask_random(noise.to(dev), k).cpu()
+        assert int((got == 0).sum()) == k
+        order = sorted(range(noise.numel()), key=lambda i: (-float(noise[i]), i))
+        ref = torch.ones(noise.numel())
+        ref[order[:k]] = 0
+        assert torch.equal(got, ref), k
+
+
+@pytest.mark.parametrize("ada_all", [1, 0])
+@pytest.mark.parametrize("B,N,HS,frac", [(32, 170, 10, 0.5), (4, 20, 5, 0.9), (3, 17, 10, 0.01), (2, 33, 16, 0.0)])
+def test_mask_adaptive_bit_exact(ada_all, B, N, HS, frac):
+    from gptst_amd import ops, synth
+    dev = _dev()
+    T = 12
+    M = B * T * N
+    g = torch.Generator().manual_seed(B * 100 + HS)
+    prob = torch.softmax(torch.randn(M, HS, generator=g) * 2, -1)
+    label_ref = torch.sort(prob, dim=-1, descending=True)[1][..., 0]
+    label, counts = ops.mask_labels(prob.to(dev))
+    assert torch.equal(label.cpu().long(), label_ref)
+    assert torch.equal(counts.cpu().long(), torch.bincount(label_ref, minlength=HS))
+    total = int(M * 0.25)
+    ada = int(total * frac)
+    rnd_n = total - ada
+    list_c = synth.class_order(HS, 5)
+    na, nr = synth.make_noise(M, 11), synth.make_noise(M, 12)
+    m_ada_r, m_rnd_r, fin_r = O.adaptive_mask(label_ref.view(B, T, N), list_c, na, nr, ada, rnd_n, "all" if ada_all else "half")
+    for base in (1, 2):
+        m_ada, m_rnd, mask = ops.mask_adaptive(label, counts, torch.tensor(list_c, dtype=torch.int32, device=dev),
+                                               torch.tensor([ada, rnd_n], dtype=torch.int32, device=dev), na.to(dev), nr.to(dev),
+                                               ada_all, base)
+        assert torch.equal(m_ada.cpu().long(), m_ada_r)
+        assert torch.equal(m_rnd.cpu().long(), m_rnd_r)
+        assert torch.equal(mask.cpu().long().view(M, base), fin_r.view(M, 1).repeat(1, base))
+        assert int((mask.view(M, base)[:, 0] == 0).sum()) == total
+
+
+# ---------------------------------------------------------------------------------------------------------------
+def test_small_projections():
+    from gptst_amd import ops
+    dev = _dev()
+    g = torch.Generator().manual_seed(5)
+    rows, C = 1000, 64
+    for J, lda in ((1, 3), (2, 4), (10, 10), (40, 40)):
+        a = rnd(rows, lda, g=g); W = rnd(C, J, g=g); b = rnd(C, g=g)
+        mask = (torch.rand(rows, J, generator=g) > 0.3).float()
+        Y = ops.lin_in(a.to(dev), lda, J, W.to(dev), b.to(dev), C)
+        close(Y, a[:, :J] @ W.t() + b, what="lin_in")
+        am = torch.where(mask != 0, a[:, :J], torch.full_like(a[:, :J], -1.5))
+        Y = ops.lin_in(a.to(dev), lda, J, W.to(dev), b.to(dev), C, mask=mask.to(dev), fill=-1.5)
+        close(Y, am @ W.t() + b, what="lin_in masked")
+        Wt = W.t().contiguous()
+        Y = ops.lin_in(a.to(dev), lda, J, Wt.to(dev), None, C, wlayout=1)
+        close(Y, a[:, :J] @ W.t(), what="lin_in wlayout1")
+        X = rnd(rows, C, g=g); W2 = rnd(J, C, g=g); b2 = rnd(J, g=g)
+        close(ops.rowdot(X.to(dev), W2.to(dev), b2.to(dev)), X @ W2.t() + b2, what="rowdot")
+        close(ops.rowdot(X.to(dev), W2.to(dev), b2.to(dev), softmax=True), torch.softmax(X @ W2.t() + b2, -1), what="rowdot softmax")
+        out0 = torch.zeros(C, J, device=dev); out1 = torch.zeros(J, C, device=dev)
+        cs = torch.zeros(C, device=dev); asum = torch.zeros(J, device=dev)
+        ops.rowouter(a.to(dev), lda, J, X.to(dev), out0, 0, csum=cs, asum=asum, mask=mask.to(dev), fill=-1.5)
+        ops.rowouter(a.to(dev), lda, J, X.to(dev), out1, 1)
+        close(out0, X.t() @ am, what="rowouter layout0 masked")
+        close(out1, a[:, :J].t() @ X, what="rowouter layout1")
+        close(cs, X.sum(0), what="csum"); close(asum, am.sum(0), what="asum")
+    cs = torch.zeros(C, device=dev)
+    ops.rowouter(None, 0, 0, X.to(dev), None, 0, csum=cs)
+    close(cs, X.sum(0), what="csum only")
+
+
+@pytest.mark.parametrize("E,K,rows", [(16, 1, 384), (4, 1, 24), (4, 12, 32), (8, 1, 130), (4, 12, 2)])
+def test_timefeat(E, K, rows):
+    from gptst_amd import ops
+    dev = _dev()
+    g = torch.Generator().manual_seed(E + K)
+    names = ["ln_day", "ln_week", "ln1", "ln2", "ln"]
+    sd = {}
+    for n in names:
+        i = K if n in ("ln_day", "ln_week") else E
+        sd["t.%s.weight" % n] = rnd(E, i, g=g, scale=0.5).requires_grad_()
+        sd["t.%s.bias" % n] = rnd(E, g=g, scale=0.5).requires_grad_()
+    if K == 1:
+        tidx = rnd(rows // 12 if rows % 12 == 0 else rows, 12 if rows % 12 == 0 else 1, 2, g=g)
+        ref = O.time_feature(sd, "t.", tidx).reshape(rows, E)
+    else:
+        tidx = rnd(rows, 12, 2, g=g)
+        ref = O.time_feature_spg(sd, "t.", tidx)
+    go = rnd(rows, E, g=g)
+    (ref * go).sum().backward()
+    params = []
+    for n in names:
+        params += [sd["t.%s.weight" % n].detach().to(dev).contiguous(), sd["t.%s.bias" % n].detach().to(dev).contiguous()]
+    out = ops.timefeat_fwd(params, tidx.to(dev).contiguous(), rows, K)
+    close(out, ref, what="timefeat out")
+    grads = [torch.zeros_like(p) for p in params]
+    ops.timefeat_bwd(params, grads, tidx.to(dev).contiguous(), go.to(dev), rows, K)
+    i = 0
+    for n in names:
+        close(grads[i], sd["t.%s.weight" % n].grad, tol=2e-4, what="timefeat d%s.w" % n)
+        close(grads[i + 1], sd["t.%s.bias" % n].grad, tol=2e-4, what="timefeat d%s.b" % n)
+        i += 2
+
+
+def test_loss_and_kl():
+    from gptst_amd import ops, synth
+    dev = _dev()
+    g = torch.Generator().manual_seed(9)
+    B, T, N, HS = 3, 12, 20, 5
+    for base, thresh in ((1, 0.0), (2, 0.001)):
+        rows = B * T * N
+        src = synth.make_batch(B, T, N, base, seed=3)
+        out = rnd(B, T, N, base, g=g).requires_grad_()
+        vis = (torch.rand(B, T, N, base, generator=g) > 0.25).float()          # 1 = visible
+        loss = O.mae_loss(out, src[..., :base], (1 - vis).long(), synth.SCALER_MEAN, synth.SCALER_STD, thresh)
+        loss.backward()
+        stats = torch.zeros(8, device=dev)
+        o, s, m = out.detach().to(dev).contiguous(), src.to(dev).contiguous(), vis.to(dev).contiguous()
+        ops.mae_fwd(o, s, base + 2, m, synth.SCALER_STD, synth.SCALER_MEAN, thresh, rows, base, stats)
+        st = stats.cpu()
+        assert abs(float(st[0] / st[1]) - float(loss)) < 1e-4 * float(loss)
+        dO = ops.mae_bwd(o, s, base + 2, m, synth.SCALER_STD, synth.SCALER_MEAN, thresh, rows, base, stats)
+        close(dO, out.grad, what="mae bwd")
+    logits = rnd(rows, HS, g=g).requires_grad_()
+    prob = torch.softmax(logits, -1)
+    c = torch.softmax(rnd(B * T, HS, N, g=g), 1)                                # (BT, HS, N)
+    eb = c.view(B, T, HS, N).transpose(-1, -2).reshape(rows, HS)
+    ls = torch.nn.functional.kl_div(prob.log(), eb, reduction="sum") * 0.1
+    ls.backward()
+    stats = torch.zeros(8, device=dev)
+    dl = ops.kl(prob.detach().to(dev).contiguous(), c.to(dev).contiguous(), N, 0.1, stats)
+    assert abs(float(stats[2].cpu()) * 0.1 - float(ls)) < 1e-4 * abs(float(ls))
+    close(dl, logits.grad, what="kl dlogit")
+
+
+def test_clip_adam_matches_torch():
+    from gptst_amd import ops
+    dev = _dev()
+    g = torch.Generator().manual_seed(2)
+    nA, nB, nC = 5000, 700, 100
+    n = nA + nB + nC
+    p0 = rnd(n, g=g)
+    pa = p0[:nA].clone().requires_grad_(); pb = p0[nA:nA + nB].clone().requires_grad_()
+    opt = torch.optim.Adam([pa, pb], lr=0.003, eps=1e-8)
+    p = p0.to(dev).clone(); m = torch.zeros(n, device=dev); v = torch.zeros(n, device=dev)
+    tA = tB = 0
+    for step in range(6):
+        actB = step >= 3
+        gr = rnd(n, g=g, scale=3.0 if step % 2 else 0.01)
+        pa.grad = gr[:nA].clone()
+        pb.grad = gr[nA:nA + nB].clone() if actB else None
+        torch.nn.utils.clip_grad_norm_([pa, pb], 5)
+        opt.step()
+        tA += 1
+        tB += 1 if actB else 0
+        hy = torch.zeros(16)
+        hy[0] = 0.003 / (1 - 0.9 ** tA); hy[1] = (1 - 0.999 ** tA) ** 0.5
+        if tB:
+            hy[2] = 0.003 / (1 - 0.9 ** tB); hy[3] = (1 - 0.999 ** tB) ** 0.5
+        hy[4], hy[5], hy[6], hy[7], hy[8], hy[9], hy[10] = 0.9, 0.999, 1e-8, 5.0, float(actB), 0.0, 1.0
+        stats = torch.zeros(8, device=dev)
+        ops.clip_adam(p, gr.to(dev), m, v, nA, nB, hy.to(dev), stats)
+        ref = torch.cat([pa.detach(), pb.detach(), p0[nA + nB:]])
+        close(p, ref, tol=2e-6, what="adam step %d" % step)
