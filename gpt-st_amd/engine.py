@@ -1,0 +1,219 @@
+"""Hand-written forward / backward of the GPT-ST pretraining network on the HIP kernels (no torch autograd inside).
+
+Every ``*_fwd`` returns ``(outputs..., saved)`` and every ``*_bwd`` ACCUMULATES parameter gradients into the tensors of a
+gradient dict ``g`` (views into one flat buffer) and returns the input gradients.  ``p`` / ``g`` map the reference's
+state_dict keys to tensors.  Citations: reference model/Pretrain_model/GPTST.py.
+"""
+import torch
+
+from . import ops
+from .ops import (EPI_ADD_DPRE, EPI_LRELU, EPI_PLAIN, EPI_RES_LRELU, MODE_NODE, MODE_SHARED, MODE_TIME, PRO_DPRE, PRO_NONE)
+
+TF_NAMES = ("ln_day", "ln_week", "ln1", "ln2", "ln")
+
+
+def _tf_tensors(d, pfx):
+    out = []
+    for n in TF_NAMES:
+        out += [d[pfx + n + ".weight"], d[pfx + n + ".bias"]]
+    return out
+
+
+# ---- time features (GPTST.py:187-219) -----------------------------------------------------------------------------
+def timefeat_fwd(p, pfx, tidx, spg=False):
+    B, T = tidx.shape[0], tidx.shape[1]
+    rows, K = (B, T) if spg else (B * T, 1)
+    return ops.timefeat_fwd(_tf_tensors(p, pfx), tidx, rows, K)
+
+
+def timefeat_bwd(p, g, pfx, tidx, dout, spg=False):
+    B, T = tidx.shape[0], tidx.shape[1]
+    rows, K = (B, T) if spg else (B * T, 1)
+    ops.timefeat_bwd(_tf_tensors(p, pfx), _tf_tensors(g, pfx), tidx, dout, rows, K)
+
+
+# ---- hyperTem (GPTST.py:154-163) -----------------------------------------------------------------------------------
+def hypertem_fwd(p, pfx, x, node_emb, time_eb, dims):
+    """x (BTN, C) rows; node_emb (N,d); time_eb (BT,d) -> out (BTN, C)."""
+    B, T, N, C = dims
+    adj, wpool, bpool = p[pfx + "adj"], p[pfx + "weights_pool"], p[pfx + "bias_pool"]
+    d, Hm = adj.shape[0], adj.shape[1]
+    A = ops.poolgen(node_emb, adj.view(d, Hm * T)).view(N, Hm, T)                       # :156
+    G = ops.gram_fwd(A)
+    R = ops.tmix(x.view(B, T, N, C), G).view(-1, C)                                     # :157-158
+    Wbt, bbt = ops.poolgen(time_eb, wpool, bpool)                                       # :160-161
+    out = ops.apply(R, Wbt, MODE_TIME, B * T, N, bias=bbt, resid=x, epi=EPI_RES_LRELU)  # :162-163
+    return out, (x, R, out, A, G, Wbt)
+
+
+def hypertem_bwd(p, g, pfx, saved, dout, node_emb, time_eb, d_node_emb, d_time_eb, dims):
+    B, T, N, C = dims
+    x, R, out, A, G, Wbt = saved
+    adj, wpool, bpool = p[pfx + "adj"], p[pfx + "weights_pool"], p[pfx + "bias_pool"]
+    d, Hm = adj.shape[0], adj.shape[1]
+    BT = B * T
+    dbias = torch.zeros(BT, C, device=x.device)
+    dR = ops.apply(dout, Wbt, MODE_TIME, BT, N, A2=out, transw=True, pro=PRO_DPRE, colsum=dbias)
+    dWbt, ns = ops.wgrad(R, dout, MODE_TIME, BT, N, D2=out, pro=PRO_DPRE)
+    ops.poolgen_bwd_pool(time_eb, dWbt, g[pfx + "weights_pool"], dbias, g[pfx + "bias_pool"], nsplit=ns)
+    ops.poolgen_bwd_emb(dWbt, wpool, d_time_eb, dbias, bpool, nsplit=ns)
+    dx = ops.tmix(dR.view(B, T, N, C), G, dOut=dout.view(B, T, N, C), Y=out.view(B, T, N, C)).view(-1, C)
+    dG = ops.tmix_dgraph(dR.view(B, T, N, C), x.view(B, T, N, C))
+    dA = ops.gram_bwd(A, dG)
+    ops.poolgen_bwd_pool(node_emb, dA, g[pfx + "adj"])
+    ops.poolgen_bwd_emb(dA, adj, d_node_emb)
+    return dx
+
+
+# ---- cap (GPTST.py:100-141) ----------------------------------------------------------------------------------------
+def cap_fwd(p, pfx, x, node_emb, tes, teb, dims, num_route):
+    """x (BTN,C); node_emb (N,d); tes (B,ds); teb (BT,ds) -> out (BTN,C), c (BT,HS,N), dyn (B,HT,T*HS)."""
+    B, T, N, C = dims
+    adj, t_adj = p[pfx + "adj"], p[pfx + "t_adj"]
+    ds, HS, HT = adj.shape[0], adj.shape[1], t_adj.shape[1]
+    c, s = ops.cap_route_fwd(x.view(B, T, N, C), p[pfx + "ln_p.weight"], p[pfx + "ln_p.bias"], teb, adj, num_route)   # :102-123
+    dyn = ops.poolgen(tes, t_adj.view(ds, HT * T * HS)).view(B, HT, T * HS)                                          # :129
+    v, Ht, Rt = ops.cap_cross_fwd(s, dyn, p[pfx + "mask_template"], B, T, HS, HT)                                     # :125-134
+    rec = ops.cap_rec_fwd(c, v, N, C)                                                                                 # :135
+    Wn, bn = ops.poolgen(node_emb, p[pfx + "weights_spa"], p[pfx + "bias_spa"])                                       # :137-138
+    out = ops.apply(rec, Wn, MODE_NODE, B * T, N, bias=bn, resid=x, epi=EPI_RES_LRELU)                                # :139-141
+    return out, c, dyn, (x, out, rec, c, s, v, Ht, Rt, dyn, Wn)
+
+
+def cap_bwd(p, g, pfx, saved, dout, node_emb, tes, teb, d_node_emb, d_tes, d_teb, dims):
+    B, T, N, C = dims
+    x, out, rec, c, s, v, Ht, Rt, dyn, Wn = saved
+    adj, t_adj = p[pfx + "adj"], p[pfx + "t_adj"]
+    ds, HS, HT = adj.shape[0], adj.shape[1], t_adj.shape[1]
+    BT, dev = B * T, x.device
+    dbn = torch.zeros(N, C, device=dev)
+    drec = ops.apply(dout, Wn, MODE_NODE, BT, N, A2=out, transw=True, pro=PRO_DPRE, colsum=dbn)
+    dWn, ns = ops.wgrad(rec, dout, MODE_NODE, BT, N, D2=out, pro=PRO_DPRE)
+    ops.poolgen_bwd_pool(node_emb, dWn, g[pfx + "weights_spa"], dbn, g[pfx + "bias_spa"], nsplit=ns)
+    ops.poolgen_bwd_emb(dWn, p[pfx + "weights_spa"], d_node_emb, dbn, p[pfx + "bias_spa"], nsplit=ns)
+    dc1, dv = ops.cap_rec_bwd(drec, c, v)
+    dS, ddyn = ops.cap_cross_bwd(dv, s, Rt, Ht, dyn, p[pfx + "mask_template"], B, T, HS, HT)
+    ops.poolgen_bwd_pool(tes, ddyn, g[pfx + "t_adj"])
+    ops.poolgen_bwd_emb(ddyn, t_adj, d_tes)
+    dY, dlogit = ops.cap_route_bwd(x.view(B, T, N, C), p[pfx + "ln_p.weight"], p[pfx + "ln_p.bias"], c, dc1, dS)
+    ops.poolgen_bwd_pool(teb, dlogit, g[pfx + "adj"])
+    ops.poolgen_bwd_emb(dlogit, adj, d_teb)
+    dx = ops.apply(dY, p[pfx + "ln_p.weight"], MODE_SHARED, BT, N, resid=dout, resid2=out, epi=EPI_ADD_DPRE,
+                   colsum=g[pfx + "ln_p.bias"].view(1, C))
+    dWp, ns2 = ops.wgrad(dY, x, MODE_SHARED, BT, N)
+    ones = torch.ones(1, 1, device=dev)
+    ops.poolgen_bwd_pool(ones, dWp, g[pfx + "ln_p.weight"].view(1, C * C), nsplit=ns2)
+    return dx
+
+
+# ---- LReLU(x W_g + b_g) with generated weights, no residual (MLP_RL, GPTST.py:24-32) --------------------------------
+def condlin_fwd(x, emb, wpool, bpool, mode, dims):
+    B, T, N, C = dims
+    Wg, bg = ops.poolgen(emb, wpool, bpool)
+    out = ops.apply(x, Wg, mode, B * T, N, bias=bg, epi=EPI_LRELU)
+    return out, (x, out, Wg)
+
+
+def condlin_bwd(saved, dout, emb, wpool, bpool, g_wpool, g_bpool, d_emb, mode, dims):
+    B, T, N, C = dims
+    x, out, Wg = saved
+    db = torch.zeros(emb.shape[0], C, device=x.device)
+    dx = ops.apply(dout, Wg, mode, B * T, N, A2=out, transw=True, pro=PRO_DPRE, colsum=db)
+    dW, ns = ops.wgrad(x, dout, mode, B * T, N, D2=out, pro=PRO_DPRE)
+    ops.poolgen_bwd_pool(emb, dW, g_wpool, db, g_bpool, nsplit=ns)
+    ops.poolgen_bwd_emb(dW, wpool, d_emb, db, bpool, nsplit=ns)
+    return dx
+
+
+# ---- STHCN (GPTST.py:253-273) --------------------------------------------------------------------------------------
+def sthcn_fwd(p, pfx, tidx, x, dims, num_route):
+    B, T, N, C = dims
+    time_eb = timefeat_fwd(p, pfx + "time_feature1.", tidx)                       # (BT,d)   :259
+    teb = timefeat_fwd(p, pfx + "time_feature1_.", tidx)                          # (BT,ds)  :260
+    tes = timefeat_fwd(p, pfx + "time_feature2.", tidx, spg=True)                 # (B,ds)   :261
+    ne, nes = p[pfx + "node_embeddings"], p[pfx + "node_embeddings_spg"]
+    sv = {}
+    x, sv["h1"] = hypertem_fwd(p, pfx + "hyperTem1.", x, ne, time_eb, dims)
+    x, c1, _, sv["c1"] = cap_fwd(p, pfx + "cap1.", x, nes, tes, teb, dims, num_route)
+    x, sv["h2"] = hypertem_fwd(p, pfx + "hyperTem2.", x, ne, time_eb, dims)
+    x, sv["h3"] = hypertem_fwd(p, pfx + "hyperTem3.", x, ne, time_eb, dims)
+    x, _, _, sv["c2"] = cap_fwd(p, pfx + "cap2.", x, nes, tes, teb, dims, num_route)
+    x, sv["h4"] = hypertem_fwd(p, pfx + "hyperTem4.", x, ne, time_eb, dims)
+    sv["emb"] = (time_eb, teb, tes)
+    return x, c1, sv
+
+
+def sthcn_bwd(p, g, pfx, tidx, sv, dout, dims):
+    time_eb, teb, tes = sv["emb"]
+    ne, nes = p[pfx + "node_embeddings"], p[pfx + "node_embeddings_spg"]
+    dne, dnes = g[pfx + "node_embeddings"], g[pfx + "node_embeddings_spg"]
+    d_te, d_teb, d_tes = torch.zeros_like(time_eb), torch.zeros_like(teb), torch.zeros_like(tes)
+    d = hypertem_bwd(p, g, pfx + "hyperTem4.", sv["h4"], dout, ne, time_eb, dne, d_te, dims)
+    d = cap_bwd(p, g, pfx + "cap2.", sv["c2"], d, nes, tes, teb, dnes, d_tes, d_teb, dims)
+    d = hypertem_bwd(p, g, pfx + "hyperTem3.", sv["h3"], d, ne, time_eb, dne, d_te, dims)
+    d = hypertem_bwd(p, g, pfx + "hyperTem2.", sv["h2"], d, ne, time_eb, dne, d_te, dims)
+    d = cap_bwd(p, g, pfx + "cap1.", sv["c1"], d, nes, tes, teb, dnes, d_tes, d_teb, dims)
+    d = hypertem_bwd(p, g, pfx + "hyperTem1.", sv["h1"], d, ne, time_eb, dne, d_te, dims)
+    timefeat_bwd(p, g, pfx + "time_feature1.", tidx, d_te)
+    timefeat_bwd(p, g, pfx + "time_feature1_.", tidx, d_teb)
+    timefeat_bwd(p, g, pfx + "time_feature2.", tidx, d_tes, spg=True)
+    return d
+
+
+# ---- whole model ---------------------------------------------------------------------------------------------------
+def guide_fwd(p, source, tidx, dims, base):
+    """softmax(MLP_RL(raw flow, teb4mask(t), neb4mask)) — GPTST.py:326-332 / 337-343.  -> prob (BTN,HS), saved."""
+    B, T, N, C = dims
+    t4m = timefeat_fwd(p, "encoder.teb4mask.", tidx)
+    m = "encoder.MLP_RL."
+    h0 = ops.lin_in(source, base + 2, base, p[m + "ln1.weight"], p[m + "ln1.bias"], C)                    # :22
+    h1, s1 = condlin_fwd(h0, p["encoder.neb4mask"], p[m + "weights_pool_spa"], p[m + "bias_pool_spa"], MODE_NODE, dims)   # :24-27
+    h2, s2 = condlin_fwd(h1, t4m, p[m + "weights_pool_tem"], p[m + "bias_pool_tem"], MODE_TIME, dims)     # :29-32
+    prob = ops.rowdot(h2, p[m + "ln3.weight"], p[m + "ln3.bias"], softmax=True)                           # :33, :332
+    return prob, (t4m, s1, s2, h2)
+
+
+def guide_bwd(p, g, source, tidx, saved, dlogit, dims, base):
+    B, T, N, C = dims
+    t4m, s1, s2, h2 = saved
+    m = "encoder.MLP_RL."
+    HS = dlogit.shape[1]
+    dh2 = ops.lin_in(dlogit, HS, HS, p[m + "ln3.weight"], None, C, wlayout=1)
+    ops.rowouter(dlogit, HS, HS, h2, g[m + "ln3.weight"], 1, asum=g[m + "ln3.bias"])
+    d_t4m = torch.zeros_like(t4m)
+    dh1 = condlin_bwd(s2, dh2, t4m, p[m + "weights_pool_tem"], p[m + "bias_pool_tem"], g[m + "weights_pool_tem"],
+                      g[m + "bias_pool_tem"], d_t4m, MODE_TIME, dims)
+    dh0 = condlin_bwd(s1, dh1, p["encoder.neb4mask"], p[m + "weights_pool_spa"], p[m + "bias_pool_spa"],
+                      g[m + "weights_pool_spa"], g[m + "bias_pool_spa"], g["encoder.neb4mask"], MODE_NODE, dims)
+    ops.rowouter(source, base + 2, base, dh0, g[m + "ln1.weight"], 0, csum=g[m + "ln1.bias"])
+    timefeat_bwd(p, g, "encoder.teb4mask.", tidx, d_t4m)
+
+
+def model_fwd(p, source, mask, dims, base, num_route, scaler_zeros):
+    """Masked-autoencoder body — GPTST.py:415-421 + 453-456.  mask (BTN*base) fp32, 1 = visible; None -> no masking (eval)."""
+    B, T, N, C = dims
+    tidx = source[:, :, 0, base:base + 2].contiguous()
+    x0 = ops.lin_in(source, base + 2, base, p["encoder.dim_in_flow.weight"], p["encoder.dim_in_flow.bias"], C,
+                    mask=mask, fill=scaler_zeros)                                                          # :416-418
+    emb, c1, sv_e = sthcn_fwd(p, "encoder.STHCN_encode.", tidx, x0, dims, num_route)                        # :421
+    return emb, c1, tidx, sv_e
+
+
+def decoder_fwd(p, tidx, emb, dims, num_route):
+    dec, _, sv_d = sthcn_fwd(p, "decoder.STHCN_decode.", tidx, emb, dims, num_route)                        # :454
+    out = ops.rowdot(dec, p["decoder.dim_flow_out.weight"], p["decoder.dim_flow_out.bias"])                 # :455
+    return out, dec, sv_d
+
+
+def model_bwd(p, g, source, mask, tidx, sv_e, sv_d, dec, d_out, d_dec, dims, base, scaler_zeros):
+    """Backward of decoder_fwd . model_fwd given d_out (BTN, base) [and optional d_dec (BTN, C)]."""
+    B, T, N, C = dims
+    wo = "decoder.dim_flow_out."
+    dd = ops.lin_in(d_out, base, base, p[wo + "weight"], None, C, wlayout=1)
+    if d_dec is not None:
+        dd = dd + d_dec
+    ops.rowouter(d_out, base, base, dec, g[wo + "weight"], 1, asum=g[wo + "bias"])
+    d_emb = sthcn_bwd(p, g, "decoder.STHCN_decode.", tidx, sv_d, dd, dims)
+    d_x0 = sthcn_bwd(p, g, "encoder.STHCN_encode.", tidx, sv_e, d_emb, dims)
+    ops.rowouter(source, base + 2, base, d_x0, g["encoder.dim_in_flow.weight"], 0, csum=g["encoder.dim_in_flow.bias"],
+                 mask=mask, fill=scaler_zeros)

@@ -1,0 +1,106 @@
+"""GPU parity of the drop-in GPTST_Model against (a) the golden vectors produced by the reference itself and (b) the
+pinned oracle, through the same forward()/backward() API the reference trainer uses (BasicTrainer.py:82-92).
+fp32 tolerance 1e-4 relative to the tensor scale (north-star); masks bit-exact."""
+import numpy as np
+import pytest
+import torch
+
+from golden_util import cfg_args, check, load, t
+from gptst_amd import synth
+from gptst_amd.config import make_args
+from oracle import gptst_oracle as O
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+
+
+def _rel(a, b):
+    a, b = a.detach().cpu().double(), b.detach().cpu().double()
+    return float((a - b).abs().max() / b.abs().max().clamp_min(1e-6))
+
+
+def _build(args, sd):
+    from gptst_amd.model import GPTST_Model
+    m = GPTST_Model(args)
+    m.load_state_dict(sd)
+    return m.to(DEV)
+
+
+def _inject(model, fx, tag, epoch, args):
+    if epoch <= args.change_epoch:
+        model.set_mask_inputs(noise=t(fx, tag + ".noise0"))
+    else:
+        model.set_mask_inputs(noise_a=t(fx, tag + ".noise0"), noise_r=t(fx, tag + ".noise1"),
+                              list_c=[int(i) for i in fx[tag + ".list_c"]])
+
+
+def _loss(outs, src, args, epoch):
+    """The reference trainer's loss assembly in torch ops on the device (BasicTrainer.py:83-88, Run.py:92-100)."""
+    out, _, mask, prob, hs1 = outs
+    base = args.output_dim
+    p = (out * synth.SCALER_STD + synth.SCALER_MEAN) * mask
+    y = (src[..., :base] * synth.SCALER_STD + synth.SCALER_MEAN) * mask
+    keep = y > args.mape_thresh
+    lf = torch.abs(torch.masked_select(y, keep) - torch.masked_select(p, keep)).mean()
+    if epoch > args.change_epoch:
+        ls = torch.nn.functional.kl_div(prob.log(), hs1, reduction="sum") * 0.1
+        return lf + ls, lf, ls
+    return lf, lf, torch.zeros((), device=out.device)
+
+
+@pytest.mark.parametrize("tag", ["s_rand", "s_ada_all", "s_ada_half", "s_ada_full", "s_base2"])
+def test_model_vs_reference_golden(tag):
+    fx = load("forward_small.npz")
+    args = cfg_args(fx, tag, make_args, scaler_zeros=synth.scaler_zeros())
+    epoch = int(fx[tag + ".epoch"])
+    sd = O.init_state_dict(args, int(fx[tag + ".sd_seed"]))
+    model = _build(args, sd)
+    src = t(fx, tag + ".src").to(DEV)
+    _inject(model, fx, tag, epoch, args)
+    outs = model(src, src, None, epoch)
+    out, dec, mask, prob, hs1 = outs
+    assert mask.dtype == torch.int64 and hs1.shape == prob.shape
+    assert torch.equal(mask.cpu().to(torch.int8), t(fx, tag + ".mask")), "mask must be bit-exact"
+    check(fx, tag + ".out", out, 1e-4, 1e-4 * float(t(fx, tag + ".out").abs().max()))
+    check(fx, tag + ".prob", prob, 1e-4, 1e-5)
+    check(fx, tag + ".hs1", hs1.contiguous(), 1e-4, 1e-5)
+    loss, lf, ls = _loss(outs, src, args, epoch)
+    np.testing.assert_allclose([float(loss), float(lf), float(ls)], fx[tag + ".loss"], rtol=2e-4)
+    loss.backward()
+    worst = 0.0
+    for k, p in model.named_parameters():
+        key = "%s.grad.%s" % (tag, k)
+        if key in fx.files and t(fx, key).numel() == 0:
+            assert p.grad is None or float(p.grad.abs().max()) == 0.0, k
+            continue
+        g = p.grad
+        assert g is not None, k
+        if key in fx.files:
+            ref, val = t(fx, key).reshape(-1), g.detach().cpu().reshape(-1)
+        else:
+            ref, val = t(fx, key + "::sub"), g.detach().cpu().reshape(-1)[::13]
+        scale = float(ref.abs().max())
+        err = float((val - ref).abs().max()) / max(scale, 1e-6)
+        worst = max(worst, err)
+        assert err < 2e-3, (k, err, scale)          # gradients through ~40 fp32 layers
+    print(tag, "worst grad rel err", worst)
+
+
+def test_model_full_pems08_forward():
+    fx = load("forward_full.npz")
+    args = make_args("PEMS08", scaler_zeros=synth.scaler_zeros())
+    model = _build(args, O.init_state_dict(args, 12))
+    src = t(fx, "src").to(DEV)
+    for epoch in (1, 11, 200, 300):
+        tag = "e%d" % epoch
+        _inject(model, fx, tag, epoch, args)
+        with torch.no_grad():
+            out, dec, mask, prob, hs1 = model(src, src, None, epoch)
+        assert torch.equal(mask.cpu().to(torch.int8), t(fx, tag + ".mask")), epoch
+        assert _rel(out, t(fx, tag + ".out")) < 1e-4
+        assert _rel(prob, t(fx, tag + ".prob")) < 1e-4
+        assert _rel(hs1, t(fx, tag + ".hs1")) < 1e-4
+        assert _rel(dec[:, :, ::7, ::5], t(fx, tag + ".dec_sub")) < 1e-4
+    emodel = _build(make_args("PEMS08", scaler_zeros=synth.scaler_zeros(), mode="eval"), O.init_state_dict(args, 12))
+    emb = emodel(src, None)[0]
+    assert _rel(emb[:, :, ::7, ::5], t(fx, "eval.emb_sub")) < 1e-4
