@@ -1,0 +1,172 @@
+"""One fused pretraining step = the body of reference BasicTrainer.train_epoch (model/BasicTrainer.py:72-103):
+zero_grad -> forward (mask generation included) -> masked-MAE (+0.1 KL) -> backward -> clip_grad_norm_(5) -> Adam,
+entirely as HIP kernels enqueued on one stream and captured in a hipGraph (two graphs: random-mask phase and
+adaptive-mask + KL phase).  Nothing in the step synchronises with the host: loss scalars are read from a device
+statistics block whenever the caller asks.  Data-parallel: one process per GPU, one RCCL all-reduce (sum) of
+[flat gradient | loss statistics] between backward and the optimiser (dist.py).
+"""
+import math
+import random
+
+import torch
+
+from . import engine, ops
+
+
+class PretrainStep:
+    def __init__(self, model, args, scaler_mean, scaler_std, batch_size, use_graph=True, dp=None, seed=0):
+        self.model, self.args = model, args
+        self.mean, self.std = float(scaler_mean), float(scaler_std)
+        self.B, self.T, self.N = batch_size, args.lag, args.num_nodes
+        self.C, self.base, self.HS = args.hidden_dim, args.input_base_dim, args.HS
+        self.dims = (self.B, self.T, self.N, self.C)
+        self.dev = model.flat.device
+        assert self.dev.type == "cuda", "PretrainStep needs the model on an MI355X (no CPU fallback)"
+        self.use_graph, self.dp = use_graph, dp
+        n = model.flat.numel()
+        self.gbuf = torch.zeros(n + 8, device=self.dev)             # [flat gradient | stats] -> one collective
+        self.gflat, self.stats = self.gbuf[:n], self.gbuf[n:]
+        self.g = model.views_of(self.gflat)
+        self.m, self.v = torch.zeros(n, device=self.dev), torch.zeros(n, device=self.dev)
+        M = self.B * self.T * self.N
+        self.src = torch.zeros(self.B, self.T, self.N, self.base + 2, device=self.dev)
+        self.noise = torch.zeros(M * self.base, device=self.dev)
+        self.noise_a, self.noise_r = torch.zeros(M, device=self.dev), torch.zeros(M, device=self.dev)
+        self.ctrl = torch.zeros(self.HS + 2, dtype=torch.int32, device=self.dev)    # [list_c | adaptive_num, random_num]
+        self.ctrl_host = torch.zeros(self.HS + 2, dtype=torch.int32).pin_memory()
+        self.hyper = torch.zeros(16, device=self.dev)
+        self.hyper_host = torch.zeros(16).pin_memory()
+        self.stats_out = torch.zeros(8, device=self.dev)            # snapshot of stats after the step (graph output)
+        self.mask_buf = torch.ones(M * self.base, device=self.dev)   # teacher-forced mask (parity runs)
+        self.last_mask = None
+        self.force_mask = False
+        self.tA = self.tB = 0
+        self.lr = args.lr_init
+        self.rng = random.Random(seed)
+        self.graphs = {}
+        self.inject_noise = False
+
+    # ---- the enqueued work ---------------------------------------------------------------------------------------
+    def _fwd_bwd(self, phase):
+        mdl, p, g, dims, base = self.model, self.model.param_views(), self.g, self.dims, self.base
+        a = self.args
+        M = self.B * self.T * self.N
+        self.gbuf.zero_()
+        src = self.src
+        tidx = src[:, :, 0, base:base + 2].contiguous()
+        prob, sv_g = engine.guide_fwd(p, src, tidx, dims, base)
+        if not self.inject_noise:
+            if phase == 0:
+                self.noise.uniform_()
+            else:
+                self.noise_a.uniform_(); self.noise_r.uniform_()
+        if self.force_mask:
+            mask = self.mask_buf
+        elif phase == 0:
+            mask = ops.mask_random(self.noise, int(M * base * a.mask_ratio))
+        else:
+            label, counts = ops.mask_labels(prob)
+            mask = ops.mask_adaptive(label, counts, self.ctrl[:self.HS], self.ctrl[self.HS:], self.noise_a, self.noise_r,
+                                     a.ada_type == "all", base)[2]
+        self.last_mask = mask
+        emb, c1, tidx, sv_e = engine.model_fwd(p, src, mask, dims, base, mdl.num_route, mdl.scaler_zeros)
+        out, dec, sv_d = engine.decoder_fwd(p, tidx, emb, dims, mdl.num_route)
+        ops.mae_fwd(out, src, base + 2, mask, self.std, self.mean, a.mape_thresh, M, base, self.stats)
+        d_out = ops.mae_bwd(out, src, base + 2, mask, self.std, self.mean, a.mape_thresh, M, base, self.stats,
+                            normalize=self.dp is None)
+        engine.model_bwd(p, g, src, mask, tidx, sv_e, sv_d, dec, d_out, None, dims, base, mdl.scaler_zeros)
+        if phase == 1:
+            dlogit = ops.kl(prob, c1, self.N, 0.1, self.stats)
+            engine.guide_bwd(p, g, src, tidx, sv_g, dlogit, dims, base)
+
+    def _optim(self):
+        ops.clip_adam(self.model.flat, self.gflat, self.m, self.v, self.model.nA, self.model.nB, self.hyper, self.stats)
+        self.stats_out.copy_(self.stats)
+
+    def _body(self, phase):
+        self._fwd_bwd(phase)
+        if self.dp is None:
+            self._optim()
+
+    # ---- host side of one step -------------------------------------------------------------------------------------
+    def _host_prepare(self, phase, epoch, list_c):
+        a = self.args
+        self.tA += 1
+        if phase == 1:
+            self.tB += 1
+        b1, b2 = 0.9, 0.999
+        h = self.hyper_host
+        h[0] = self.lr / (1 - b1 ** self.tA); h[1] = math.sqrt(1 - b2 ** self.tA)
+        h[2] = self.lr / (1 - b1 ** self.tB) if self.tB else 0.0
+        h[3] = math.sqrt(1 - b2 ** self.tB) if self.tB else 1.0
+        h[4], h[5], h[6] = b1, b2, 1e-8
+        h[7] = float(a.max_grad_norm) if a.grad_norm else 0.0
+        h[8] = 1.0 if phase == 1 else 0.0
+        h[9] = 0.0 if self.dp is None else 1.0
+        h[10] = 1.0
+        self.hyper.copy_(h, non_blocking=True)
+        if phase == 1:
+            if list_c is None:
+                list_c = list(range(self.HS))
+                self.rng.shuffle(list_c)                                   # GPTST.py:357-358
+            ada, rnd = self.model.adaptive_counts(self.B * self.T * self.N, epoch)
+            c = self.ctrl_host
+            for i, v in enumerate(list_c):
+                c[i] = int(v)
+            c[self.HS], c[self.HS + 1] = ada, rnd
+            self.ctrl.copy_(c, non_blocking=True)
+
+    def step(self, source, epoch, noise=None, noise_a=None, noise_r=None, list_c=None, forced_mask=None):
+        """Enqueue one optimisation step on ``source`` (B,T,N,base+2).  Never synchronises.
+        ``forced_mask`` (fp32, 1 = visible) teacher-forces the mask: used by loss-curve parity runs in the adaptive phase,
+        where an fp32-level argmax flip of the cluster classifier would otherwise change which cells are masked."""
+        phase = 0 if epoch <= self.args.change_epoch else 1
+        if source is not self.src:
+            self.src.copy_(source, non_blocking=True)
+        inject = noise is not None or noise_a is not None
+        if inject:
+            if phase == 0:
+                self.noise.copy_(noise.reshape(-1), non_blocking=True)
+            else:
+                self.noise_a.copy_(noise_a.reshape(-1), non_blocking=True)
+                self.noise_r.copy_(noise_r.reshape(-1), non_blocking=True)
+        if forced_mask is not None:
+            self.mask_buf.copy_(forced_mask.reshape(-1), non_blocking=True)
+        self._host_prepare(phase, epoch, list_c)
+        key = (phase, inject, forced_mask is not None)
+        if not self.use_graph:
+            self.inject_noise, self.force_mask = inject, forced_mask is not None
+            self._body(phase)
+        else:
+            if key not in self.graphs:
+                self._capture(key)
+            self.graphs[key].replay()
+        if self.dp is not None:
+            self.dp.allreduce_(self.gbuf)
+            self._optim()
+
+    def _capture(self, key):
+        phase, inject, forced = key
+        self.inject_noise, self.force_mask = inject, forced
+        keep = (self.model.flat.clone(), self.m.clone(), self.v.clone())
+        s = torch.cuda.Stream()
+        s.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(s):                      # warm-up on a side stream (allocator, lazy kernel attributes)
+            for _ in range(2):
+                self._body(phase)
+        torch.cuda.current_stream().wait_stream(s)
+        torch.cuda.synchronize()
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g):
+            self._body(phase)
+        self.graphs[key] = g
+        self.model.flat.copy_(keep[0]); self.m.copy_(keep[1]); self.v.copy_(keep[2])   # undo the warm-up updates
+        torch.cuda.synchronize()
+
+    # ---- results ---------------------------------------------------------------------------------------------------
+    def losses(self):
+        """(loss, loss_flow, loss_s) of the last step — synchronises (reference BasicTrainer.py:98-103 does so every step)."""
+        st = self.stats_out.cpu()
+        lf = float(st[0] / max(float(st[1]), 1.0))
+        ls = float(st[2]) * 0.1 if self.tB and self.hyper_host[8] != 0 else 0.0
+        return lf + ls, lf, ls
