@@ -1,0 +1,214 @@
+#!/usr/bin/env python
+"""Headline benchmark: GPT-ST pretraining steps/s on PEMS08-shaped synthetic input (B=32, T=12, N=170, C=64) on MI355X.
+
+    python bench.py --gpus 1 --steps 200 --warmup 20
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py --gpus N ...
+
+One step = zero_grad -> forward (mask generation included) -> masked-MAE + 0.1 KL -> backward -> clip -> Adam
+(reference BasicTrainer.py:72-103) at epoch 200 of 300 (adaptive masking + KL: the phase 290 of the 300 epochs run in).
+Prints ONE JSON line on rank 0 (contract in the task statement) with `roofline` (dominant kernel, measured with
+HIP events inside this run) and `cpu_baseline` (the oracle's op-for-op PyTorch-CPU restatement on the host cores).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+import torch  # noqa: E402
+
+HBM_PEAK = 8.0e12          # B/s   (MI355X_MICROARCH.md: 8 TB/s spec)
+MFMA_F32_PEAK = 157.3e12   # FLOP/s fp32 matrix (same file)
+
+
+def kernel_flops(name, tag, d):
+    """Algorithmic FLOPs per launch of the heavy kernels (SURVEY.md §8d formulas)."""
+    B, T, N, C, HS, R = d["B"], d["T"], d["N"], d["C"], d["HS"], d["R"]
+    rows = B * T * N
+    if name in ("gptst_apply", "gptst_wgrad"):
+        return 2.0 * rows * C * C
+    if name in ("gptst_tmix", "gptst_tmix_dgraph"):
+        return 2.0 * rows * C * T
+    if name == "gptst_cap_route_fwd":
+        return 2.0 * rows * C * C + (2 * R + 2) * 2.0 * B * T * HS * N * C
+    if name == "gptst_cap_route_bwd":
+        return 2.0 * rows * C * C + 2 * 2.0 * B * T * HS * N * C
+    if name in ("gptst_cap_rec_fwd",):
+        return 2.0 * B * T * HS * N * C
+    if name in ("gptst_cap_rec_bwd",):
+        return 4.0 * B * T * HS * N * C
+    return 0.0
+
+
+def time_kernels(stepper, epoch, nsteps=3):
+    """Eager (non-graph) steps with a HIP event pair around every kernel launch on the launch stream."""
+    from gptst_amd import ops
+    stepper.use_graph = False
+    stepper.step(stepper.src, epoch)                # warm
+    torch.cuda.synchronize()
+    ops.TIMER = []
+    for _ in range(nsteps):
+        stepper.step(stepper.src, epoch)
+    torch.cuda.synchronize()
+    rec, ops.TIMER = ops.TIMER, None
+    agg = {}
+    for name, tag, e0, e1, nb in rec:
+        k = (name, tag)
+        a = agg.setdefault(k, [0.0, 0, nb])
+        a[0] += e0.elapsed_time(e1) * 1e-3
+        a[1] += 1
+    return {k: dict(total_s=v[0] / nsteps, launches=v[1] // nsteps, avg_s=v[0] / v[1], bytes=v[2]) for k, v in agg.items()}
+
+
+def cpu_baseline(args, B, budget_s=12.0):
+    """The oracle (op-for-op CPU restatement of the reference step) timed on the host cores — reported, never the target."""
+    from gptst_amd import synth
+    from oracle import gptst_oracle as O
+    cores = os.cpu_count() or 1
+    torch.set_num_threads(cores)
+    sd = O.init_state_dict(args, 12)
+    st = O.Stepper(sd, args, synth.SCALER_MEAN, synth.SCALER_STD)
+    src = synth.make_batch(B, 12, args.num_nodes, args.input_base_dim, seed=2024)
+    M = B * 12 * args.num_nodes
+    inj = dict(noise_a=synth.make_noise(M, 7), noise_r=synth.make_noise(M, 8), list_c=synth.class_order(args.HS, 7))
+    st.step(src, 200, **inj)                         # warm-up
+    n, t0 = 0, time.perf_counter()
+    while True:
+        st.step(src, 200, **inj)
+        n += 1
+        el = time.perf_counter() - t0
+        if el > budget_s or n >= 40:
+            break
+    return dict(value=n / el, unit="steps/s", cores=cores, kind="port",
+                sample="%d full steps (B=%d, epoch 200: adaptive mask + KL) of the same workload in %.1f s, torch %s CPU, %d threads"
+                       % (n, B, el, torch.__version__, cores))
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--batch", type=int, default=32)
+    ap.add_argument("--dataset", default="PEMS08")
+    ap.add_argument("--epoch", type=int, default=200, help="epoch whose masking schedule is benchmarked (of 300)")
+    ap.add_argument("--no-graph", action="store_true")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-kernel-timing", action="store_true")
+    a = ap.parse_args()
+
+    from gptst_amd import synth
+    from gptst_amd.config import make_args
+    from gptst_amd.model import GPTST_Model, init_seed, xavier_init_
+    from gptst_amd.step import PretrainStep
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != a.gpus and world > 1:
+        raise SystemExit("--gpus %d but WORLD_SIZE=%d" % (a.gpus, world))
+    if a.gpus > 1 and world == 1:
+        raise SystemExit("launch with torch.distributed.run for --gpus > 1")
+    torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
+    dp = None
+    if world > 1:
+        from gptst_amd.dist import DataParallel
+        dp = DataParallel("nccl")
+
+    args = make_args(a.dataset, scaler_zeros=synth.scaler_zeros(), device=str(dev))
+    init_seed(args.seed)
+    model = xavier_init_(GPTST_Model(args)).to(dev)
+    B, T, N, C = a.batch, 12, args.num_nodes, args.hidden_dim
+    stepper = PretrainStep(model, args, synth.SCALER_MEAN, synth.SCALER_STD, batch_size=B, use_graph=not a.no_graph, dp=dp,
+                           seed=7 + rank)
+    src = synth.make_batch(B, T, N, args.input_base_dim, interval=args.interval, seed=2024 + rank, start_slot=1000 * rank).to(dev)
+    stepper.src.copy_(src)                           # inputs resident in HBM before the timed region
+
+    for _ in range(max(a.warmup, 1)):
+        stepper.step(stepper.src, a.epoch)
+    torch.cuda.synchronize()
+    if dp is not None:
+        dp.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(a.steps):
+        stepper.step(stepper.src, a.epoch)
+    torch.cuda.synchronize()
+    if dp is not None:
+        dp.barrier()
+    torch.cuda.synchronize()
+    el = time.perf_counter() - t0
+    if dp is not None:
+        el = dp.max_over_ranks(el)
+    loss = stepper.losses()
+
+    # random-mask phase (epochs 1..change_epoch) rate, informative
+    rnd_rate = None
+    if world == 1:
+        for _ in range(5):
+            stepper.step(stepper.src, 1)
+        torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        for _ in range(max(a.steps // 4, 10)):
+            stepper.step(stepper.src, 1)
+        torch.cuda.synchronize()
+        rnd_rate = max(a.steps // 4, 10) / (time.perf_counter() - t1)
+
+    if rank != 0:
+        return
+    steps_s = a.steps / el
+    dims = dict(B=B, T=T, N=N, C=C, HS=args.HS, R=args.num_route)
+    out = {
+        "metric": "pretrain steps/sec at (B=32,T=12,N=170,C=64)", "value": steps_s * 1.0, "unit": "steps/s",
+        "n_gpus": a.gpus, "steps": a.steps, "warmup": a.warmup, "ms_per_step": 1e3 * el / a.steps,
+        "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+        "config": {"workload": "BASELINE configs[1]: PEMS08-shape synthetic pretrain step, per-GPU B=%d T=%d N=%d C=%d, epoch %d/300 "
+                               "(adaptive mask + KL), fwd+loss+bwd+clip+Adam, hipGraph=%s" % (B, T, N, C, a.epoch, not a.no_graph),
+                   "global_batch": B * a.gpus, "parallelism": "dp%d" % a.gpus},
+        "samples_per_s": steps_s * B * a.gpus,
+        "steps_per_s_random_mask_phase": rnd_rate,
+        "last_loss": loss[0],
+    }
+    # whole-step roofline (64A + side + optimiser bytes; 3 x forward FLOPs)
+    A_bytes = 4.0 * B * T * N * C
+    bytes_alg = 64 * A_bytes + 4.0 * B * T * N * (8 * args.HS + 4 * (args.input_base_dim + args.HS)) + 28.0 * sum(p.numel() for p in model.parameters())
+    d_, ds_, HT, Hm, HS, R = args.embed_dim, args.embed_dim_spa, args.HT, args.HT_Tem, args.HS, args.num_route
+    BTN = B * T * N
+    F_ht = 2 * BTN * C * C + 4 * B * Hm * T * N * C + 2 * B * T * d_ * C * C + 2 * N * d_ * Hm * T
+    F_cap = 4 * BTN * C * C + (2 * R + 3) * 2 * B * T * HS * N * C + 2 * N * d_ * C * C + 4 * B * HT * T * HS * C + 2 * B * T * ds_ * HS * N
+    F_mlp = 4 * BTN * C * C + 2 * N * d_ * C * C + 2 * B * T * d_ * C * C + 2 * BTN * C * (args.input_base_dim + HS)
+    flops_alg = 3.0 * (8 * F_ht + 4 * F_cap + F_mlp + 4 * BTN * args.input_base_dim * C)
+    t_step = el / a.steps
+    out["step_roofline"] = {"bytes_alg": bytes_alg, "flops_alg": flops_alg, "t_hbm_us": 1e6 * bytes_alg / HBM_PEAK,
+                            "t_mfma_us": 1e6 * flops_alg / MFMA_F32_PEAK, "hbm_frac": (bytes_alg / HBM_PEAK) / t_step,
+                            "mfma_frac": (flops_alg / MFMA_F32_PEAK) / t_step}
+
+    if not a.no_kernel_timing and world == 1:
+        kt = time_kernels(stepper, a.epoch)
+        tot = sum(v["total_s"] for v in kt.values())
+        (dn, dt), dv = max(kt.items(), key=lambda kv: kv[1]["total_s"])
+        fl = kernel_flops(dn, dt, dims)
+        t_h, t_m = dv["bytes"] / HBM_PEAK, fl / MFMA_F32_PEAK
+        if t_h >= t_m:
+            rf = dict(bound="hbm", achieved=dv["bytes"] / dv["avg_s"] / 1e9, peak=HBM_PEAK / 1e9, unit="GB/s")
+        else:
+            rf = dict(bound="mfma", achieved=fl / dv["avg_s"] / 1e12, peak=MFMA_F32_PEAK / 1e12, unit="TFLOP/s")
+        rf["frac"] = rf["achieved"] / rf["peak"]
+        rf["traffic"] = None
+        rf.update(kernel="%s[%s]" % (dn, dt), avg_us=1e6 * dv["avg_s"], launches_per_step=dv["launches"],
+                  alg_bytes_per_launch=dv["bytes"], alg_flops_per_launch=fl, share_of_step_kernel_time=dv["total_s"] / tot)
+        out["roofline"] = rf
+        top = sorted(kt.items(), key=lambda kv: -kv[1]["total_s"])[:12]
+        out["kernel_breakdown_us_per_step"] = {"%s[%s]" % k: round(1e6 * v["total_s"], 1) for k, v in top}
+        out["kernel_time_sum_us_per_step_eager"] = round(1e6 * tot, 1)
+    if not a.no_cpu_baseline and world == 1:
+        out["cpu_baseline"] = cpu_baseline(args, B)
+    print(json.dumps(out))
+
+
+if __name__ == "__main__":
+    main()

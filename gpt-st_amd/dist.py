@@ -1,0 +1,53 @@
+"""Data-parallel pretraining: one process per GPU, ``torch.distributed`` (backend "nccl" = RCCL over xGMI on ROCm,
+"gloo" in CPU tests).  The reference has no distributed code; semantics here = the reference run on the
+GLOBAL batch: every rank back-propagates the SUM-loss gradient of its local batch, then ONE all-reduce (sum) of the
+buffer [flat gradient | loss statistics (sum|y-p|, kept count, KL sum, -)] makes both the gradient and the global
+kept-count available everywhere; the optimiser kernel divides the reconstruction-path gradient by the global count
+(masked-MAE is a mean over kept cells of the whole batch, lib/metrics.py:18) and leaves the KL path (a sum) unscaled.
+Masks are generated per rank on the rank's local batch with the reference's ratio (documented deviation from a single
+global top-k; the masked fraction is identical).
+"""
+import os
+
+import torch
+import torch.distributed as dist
+
+
+class DataParallel:
+    def __init__(self, backend=None):
+        self.rank = int(os.environ.get("RANK", "0"))
+        self.world = int(os.environ.get("WORLD_SIZE", "1"))
+        self.local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+        if backend is None:
+            backend = "nccl" if torch.cuda.is_available() else "gloo"
+        if not dist.is_initialized():
+            os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+            os.environ.setdefault("MASTER_PORT", "29511")
+            dist.init_process_group(backend=backend, rank=self.rank, world_size=self.world)
+
+    def allreduce_(self, buf):
+        """In-place sum over ranks of the packed [gradient | statistics] buffer (one collective per step)."""
+        dist.all_reduce(buf, op=dist.ReduceOp.SUM)
+        return buf
+
+    def broadcast_(self, t, src=0):
+        dist.broadcast(t, src=src)
+        return t
+
+    def barrier(self):
+        dist.barrier()
+
+    def max_over_ranks(self, x):
+        t = torch.tensor([float(x)], dtype=torch.float64, device="cuda" if torch.cuda.is_available() and dist.get_backend() == "nccl" else "cpu")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        return float(t[0])
+
+
+def combine_local_gradients(local_bufs, nA, nB):
+    """Reference semantics of the packed-buffer reduction, written out for tests: given each rank's
+    [sum-loss gradient | stats] buffer, return the global-mean gradient the optimiser applies."""
+    total = torch.stack(local_bufs).sum(0)
+    n = total.numel() - 8
+    g, stats = total[:n].clone(), total[n:]
+    g[:nA] /= max(float(stats[1]), 1.0)
+    return g, stats

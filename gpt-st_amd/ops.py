@@ -14,8 +14,23 @@ EPI_PLAIN, EPI_RES_LRELU, EPI_ADD_DPRE, EPI_LRELU = 0, 1, 2, 3
 _p = _C.ptr
 
 
-def _call(name, *args):
+TIMER = None      # bench.py sets this to a list to collect (name, tag, start_event, end_event, bytes) per launch
+
+
+def _call(name, *args, tag="", nbytes=0):
+    if TIMER is None:
+        _C.lib().call(name, *args, _C.stream())
+        return
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
     _C.lib().call(name, *args, _C.stream())
+    e1.record()
+    TIMER.append((name, tag, e0, e1, nbytes))
+
+
+def _nb(*ts):
+    """Algorithmic bytes of a launch: every tensor operand read or written once."""
+    return sum(t.numel() * t.element_size() for t in ts if t is not None)
 
 
 def _chk(*ts):
@@ -35,7 +50,7 @@ def poolgen(emb, pool, pool2=None):
     if pool2 is not None:
         cols2 = pool2.numel() // K
         out2 = torch.empty((R,) + tuple(pool2.shape[1:]), device=emb.device, dtype=torch.float32)
-    _call("gptst_poolgen_fwd", _p(emb), _p(pool), _p(out), cols, _p(pool2), _p(out2), cols2, R, K)
+    _call("gptst_poolgen_fwd", _p(emb), _p(pool), _p(out), cols, _p(pool2), _p(out2), cols2, R, K, nbytes=_nb(emb, pool, out, pool2, out2))
     return (out, out2) if pool2 is not None else out
 
 
@@ -45,7 +60,8 @@ def poolgen_bwd_pool(emb, dW, dpool, dW2=None, dpool2=None, nsplit=1):
     R, K = emb.shape
     cols = dpool.numel() // K
     cols2 = dpool2.numel() // K if dpool2 is not None else 0
-    _call("gptst_poolgen_bwd_pool", _p(emb), _p(dW), _p(dpool), cols, _p(dW2), _p(dpool2), cols2, R, nsplit, K)
+    _call("gptst_poolgen_bwd_pool", _p(emb), _p(dW), _p(dpool), cols, _p(dW2), _p(dpool2), cols2, R, nsplit, K,
+          nbytes=_nb(emb, dW, dpool, dW2, dpool2))
 
 
 def poolgen_bwd_emb(dW, pool, demb, dW2=None, pool2=None, nsplit=1):
@@ -54,7 +70,8 @@ def poolgen_bwd_emb(dW, pool, demb, dW2=None, pool2=None, nsplit=1):
     R, K = demb.shape
     cols = pool.numel() // K
     cols2 = pool2.numel() // K if pool2 is not None else 0
-    _call("gptst_poolgen_bwd_emb", _p(dW), _p(pool), cols, _p(dW2), _p(pool2), cols2, _p(demb), R, nsplit, K)
+    _call("gptst_poolgen_bwd_emb", _p(dW), _p(pool), cols, _p(dW2), _p(pool2), cols2, _p(demb), R, nsplit, K,
+          nbytes=_nb(dW, pool, dW2, pool2, demb))
 
 
 # ---- MFMA contractions ---------------------------------------------------------------------------------------
@@ -65,7 +82,7 @@ def apply(A, W, mode, BT, N, bias=None, resid=None, A2=None, transw=False, pro=P
     if out is None:
         out = torch.empty_like(A)
     _call("gptst_apply", _p(A), _p(A2), _p(W), int(W.dim() == 3), int(transw), _p(bias), _p(resid), _p(resid2), _p(out), _p(colsum),
-          mode, pro, epi, BT, N, C)
+          mode, pro, epi, BT, N, C, tag="mode%d pro%d epi%d" % (mode, pro, epi), nbytes=_nb(A, A2, W, bias, resid, resid2, out))
     return out
 
 
@@ -80,7 +97,7 @@ def wgrad(A, D, mode, BT, N, D2=None, pro=PRO_NONE):
     ns = wgrad_nsplit(mode, BT, N)
     G = BT if mode == MODE_TIME else (N if mode == MODE_NODE else 1)
     dW = torch.empty(ns * G, C, C, device=A.device, dtype=torch.float32)
-    _call("gptst_wgrad", _p(A), _p(D), _p(D2), _p(dW), mode, pro, BT, N, C)
+    _call("gptst_wgrad", _p(A), _p(D), _p(D2), _p(dW), mode, pro, BT, N, C, tag="mode%d pro%d" % (mode, pro), nbytes=_nb(A, D, D2, dW))
     return dW, ns
 
 
@@ -103,7 +120,8 @@ def tmix(X, G, dOut=None, Y=None):
     _chk(X, G, dOut, Y)
     B, T, N, C = X.shape
     out = torch.empty_like(X)
-    _call("gptst_tmix", _p(X), _p(G), _p(dOut), _p(Y), _p(out), B, T, N, C)
+    _call("gptst_tmix", _p(X), _p(G), _p(dOut), _p(Y), _p(out), B, T, N, C, tag="bwd" if dOut is not None else "fwd",
+          nbytes=_nb(X, G, dOut, Y, out))
     return out
 
 
@@ -111,7 +129,7 @@ def tmix_dgraph(dR, X):
     _chk(dR, X)
     B, T, N, C = X.shape
     dG = torch.empty(N, T, T, device=X.device, dtype=torch.float32)
-    _call("gptst_tmix_dgraph", _p(dR), _p(X), _p(dG), B, T, N, C)
+    _call("gptst_tmix_dgraph", _p(dR), _p(X), _p(dG), B, T, N, C, nbytes=_nb(dR, X, dG))
     return dG
 
 
@@ -123,7 +141,8 @@ def cap_route_fwd(X, Wp, bp, teb, adj, R):
     ds, HS = adj.shape[0], adj.shape[1]
     c = torch.empty(B * T, HS, N, device=X.device, dtype=torch.float32)
     s = torch.empty(B * T, HS, C, device=X.device, dtype=torch.float32)
-    _call("gptst_cap_route_fwd", _p(X), _p(Wp), _p(bp), _p(teb), _p(adj), _p(c), _p(s), B * T, N, C, HS, ds, R)
+    _call("gptst_cap_route_fwd", _p(X), _p(Wp), _p(bp), _p(teb), _p(adj), _p(c), _p(s), B * T, N, C, HS, ds, R,
+          nbytes=_nb(X, Wp, bp, teb, adj, c, s))
     return c, s
 
 
@@ -150,7 +169,7 @@ def cap_rec_fwd(c, v, N, C):
     _chk(c, v)
     BT, HS = c.shape[0], c.shape[1]
     rec = torch.empty(BT * N, C, device=c.device, dtype=torch.float32)
-    _call("gptst_cap_rec_fwd", _p(c), _p(v), _p(rec), BT, N, C, HS)
+    _call("gptst_cap_rec_fwd", _p(c), _p(v), _p(rec), BT, N, C, HS, nbytes=_nb(c, v, rec))
     return rec
 
 
@@ -160,7 +179,7 @@ def cap_rec_bwd(drec, c, v):
     C = v.shape[-1]
     dc1 = torch.empty_like(c)
     dv = torch.empty_like(v)
-    _call("gptst_cap_rec_bwd", _p(drec), _p(c), _p(v), _p(dc1), _p(dv), BT, N, C, HS)
+    _call("gptst_cap_rec_bwd", _p(drec), _p(c), _p(v), _p(dc1), _p(dv), BT, N, C, HS, nbytes=_nb(drec, c, v, dc1, dv))
     return dc1, dv
 
 
@@ -170,7 +189,8 @@ def cap_route_bwd(X, Wp, bp, c, dc1, dS):
     HS = c.shape[1]
     dY = torch.empty(B * T * N, C, device=X.device, dtype=torch.float32)
     dlogit = torch.empty_like(c)
-    _call("gptst_cap_route_bwd", _p(X), _p(Wp), _p(bp), _p(c), _p(dc1), _p(dS), _p(dY), _p(dlogit), B * T, N, C, HS)
+    _call("gptst_cap_route_bwd", _p(X), _p(Wp), _p(bp), _p(c), _p(dc1), _p(dS), _p(dY), _p(dlogit), B * T, N, C, HS,
+          nbytes=_nb(X, Wp, bp, c, dc1, dS, dY, dlogit))
     return dY, dlogit
 
 
@@ -207,7 +227,7 @@ def mask_adaptive(label, counts, list_c, nums, noise_a, noise_r, ada_all, base):
 def lin_in(a, lda, J, W, b, C, mask=None, fill=0.0, wlayout=0, rows=None):
     rows = rows if rows is not None else a.numel() // lda
     Y = torch.empty(rows, C, device=a.device, dtype=torch.float32)
-    _call("gptst_lin_in", _p(a), lda, _p(mask), float(fill), _p(W), wlayout, _p(b), _p(Y), rows, J, C)
+    _call("gptst_lin_in", _p(a), lda, _p(mask), float(fill), _p(W), wlayout, _p(b), _p(Y), rows, J, C, nbytes=_nb(a, mask, W, b, Y))
     return Y
 
 
@@ -215,13 +235,14 @@ def rowdot(X, W, b, softmax=False):
     rows, C = X.shape
     J = W.shape[0]
     Z = torch.empty(rows, J, device=X.device, dtype=torch.float32)
-    _call("gptst_rowdot", _p(X), _p(W), _p(b), _p(Z), rows, J, C, int(softmax))
+    _call("gptst_rowdot", _p(X), _p(W), _p(b), _p(Z), rows, J, C, int(softmax), nbytes=_nb(X, W, b, Z))
     return Z
 
 
 def rowouter(a, lda, J, X, out, olayout, csum=None, asum=None, mask=None, fill=0.0):
     rows, C = X.shape
-    _call("gptst_rowouter", _p(a), lda, _p(mask), float(fill), _p(X), _p(out), olayout, _p(csum), _p(asum), rows, J, C)
+    _call("gptst_rowouter", _p(a), lda, _p(mask), float(fill), _p(X), _p(out), olayout, _p(csum), _p(asum), rows, J, C,
+          nbytes=_nb(a, mask, X, out))
 
 
 # ---- time features ----------------------------------------------------------------------------------------------
