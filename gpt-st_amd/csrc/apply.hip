@@ -100,9 +100,83 @@ __global__ __launch_bounds__(256) void apply_kernel(const float* __restrict__ A,
             }
         }
     }
-    if (colsum != nullptr) {
+    if (colsum != nullptr) {          // fold the 4 waves in LDS first: one atomic per column and workgroup
+        __syncthreads();
 #pragma unroll
-        for (int u = 0; u < C / 64; ++u) atomicAdd(colsum + (size_t)g * C + u * 64 + lane, cs[u]);
+        for (int u = 0; u < C / 64; ++u) tile[u * 64 + lane] = cs[u];
+        __syncthreads();
+        if (wave == 0) {
+#pragma unroll
+            for (int u = 0; u < C / 64; ++u) {
+                float s = 0.f;
+#pragma unroll
+                for (int w = 0; w < 4; ++w) s += smem[C * C + w * T::TILE_FLOATS + u * 64 + lane];
+                atomicAdd(colsum + (size_t)g * C + u * 64 + lane, s);
+            }
+        }
+    }
+}
+
+// C = 64 weight gradient with the row range split over the 4 waves: every wave accumulates all four 32x32 output tiles
+// over its quarter of the rows (4 operand loads per 4 MFMAs, k-loop unrolled so ~16 loads are in flight), then the waves
+// are folded through LDS and the 64x64 result is stored with coalesced float4 rows.
+template <int PRO>
+__global__ __launch_bounds__(256) void wgrad64_kernel(const float* __restrict__ A, const float* __restrict__ D,
+                                                      const float* __restrict__ D2, float* __restrict__ dW, RowMap rm,
+                                                      int rows_per_split) {
+    constexpr int C = 64;
+    __shared__ float red[4][C * C];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int j = lane & 31, h = lane >> 5;
+    const int g = blockIdx.x, sp = blockIdx.y;
+    const int mbeg0 = sp * rows_per_split;
+    const int mend0 = min(rm.M, mbeg0 + rows_per_split);
+    int q = (mend0 - mbeg0 + 3) / 4;
+    q = (q + 1) & ~1;
+    const int mbeg = mbeg0 + wave * q, mend = min(mend0, mbeg + q);
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int b = 0; b < 2; ++b)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
+    constexpr int U = 4;
+    for (int m0 = mbeg; m0 < mend; m0 += 2 * U) {
+        float a0[U], a1[U], d0[U], d1[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const int m = m0 + 2 * u + h;
+            a0[u] = a1[u] = d0[u] = d1[u] = 0.f;
+            if (m < mend) {
+                const size_t off = ((size_t)g * rm.rs_g + (size_t)m * rm.rs_m) * C;
+                a0[u] = A[off + j]; a1[u] = A[off + 32 + j];
+                d0[u] = D[off + j]; d1[u] = D[off + 32 + j];
+                if (PRO == PRO_DPRE) { d0[u] *= lrelu_grad_from_out(D2[off + j]); d1[u] *= lrelu_grad_from_out(D2[off + 32 + j]); }
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0[u], d0[u], acc[0][0], 0, 0, 0);
+            acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0[u], d1[u], acc[0][1], 0, 0, 0);
+            acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1[u], d0[u], acc[1][0], 0, 0, 0);
+            acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1[u], d1[u], acc[1][1], 0, 0, 0);
+        }
+    }
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int b = 0; b < 2; ++b)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int row = (r & 3) + 8 * (r >> 2) + 4 * h;
+                red[wave][(a * 32 + row) * C + b * 32 + j] = acc[a][b][r];
+            }
+    __syncthreads();
+    float* o = dW + ((size_t)sp * rm.G + g) * C * C;
+    for (int f = threadIdx.x; f < C * C / 4; f += 256) {
+        const float4 s = f4add(f4add(ld4(&red[0][4 * f]), ld4(&red[1][4 * f])), f4add(ld4(&red[2][4 * f]), ld4(&red[3][4 * f])));
+        st4(o + 4 * f, s);
     }
 }
 
@@ -162,7 +236,7 @@ static int launch_apply(const float* A, const float* A2, const float* W, long w_
                         const float* resid, const float* resid2, float* out, float* colsum, RowMap rm, int pro, int epi, hipStream_t st) {
     const int ntiles = (rm.M + 31) / 32;
     int gy = (ntiles + 3) / 4;
-    if (rm.G == 1) gy = min(gy, 1024);                 // shared weight: many row chunks, W staged once per block
+    if (rm.G == 1) gy = min(gy, 128);                  // shared weight: persistent row chunks (W staged once, few colsum atomics)
     else gy = min(gy, 2);
     if (gy < 1) gy = 1;
     dim3 grid(rm.G, gy), block(256);
@@ -229,8 +303,8 @@ extern "C" int gptst_wgrad(const float* A, const float* D, const float* D2, floa
     dim3 grid(rm.G, ns), block(256);
     hipStream_t st = (hipStream_t)stream;
     if (C == 64) {
-        if (pro == PRO_DPRE) hipLaunchKernelGGL((wgrad_kernel<64, PRO_DPRE>), grid, block, 0, st, A, D, D2, dW, rm, rps);
-        else hipLaunchKernelGGL((wgrad_kernel<64, PRO_NONE>), grid, block, 0, st, A, D, D2, dW, rm, rps);
+        if (pro == PRO_DPRE) hipLaunchKernelGGL((wgrad64_kernel<PRO_DPRE>), grid, block, 0, st, A, D, D2, dW, rm, rps);
+        else hipLaunchKernelGGL((wgrad64_kernel<PRO_NONE>), grid, block, 0, st, A, D, D2, dW, rm, rps);
     } else if (C == 128) {
         if (pro == PRO_DPRE) hipLaunchKernelGGL((wgrad_kernel<128, PRO_DPRE>), grid, block, 0, st, A, D, D2, dW, rm, rps);
         else hipLaunchKernelGGL((wgrad_kernel<128, PRO_NONE>), grid, block, 0, st, A, D, D2, dW, rm, rps);

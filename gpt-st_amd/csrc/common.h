@@ -33,17 +33,33 @@ __device__ __forceinline__ float4 f4fma(float s, float4 a, float4 c) {
 }
 __device__ __forceinline__ float f4dot(float4 a, float4 b) { return fmaf(a.x, b.x, fmaf(a.y, b.y, fmaf(a.z, b.z, a.w * b.w))); }
 
-// xor-butterfly sum over groups of W consecutive lanes (W power of two <= 64); every lane gets the total.
+// ---- wave-level segmented reductions -------------------------------------------------------------------------------
+// Groups of W consecutive lanes (W power of two <= 64); every lane of a group ends with the group's total.
+// Up to 16 lanes (one DPP row) the exchange is done with DPP modifiers (VALU latency, no LDS crossbar):
+// quad_perm[1,0,3,2] (0xB1), quad_perm[2,3,0,1] (0x4E), row_half_mirror (0x141), row_mirror (0x140); beyond a row
+// it falls back to ds_bpermute (__shfl_xor).
+template <int CTRL>
+__device__ __forceinline__ float dpp_mov(float v) {
+    return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, 0xF, 0xF, true));
+}
 template <int W>
 __device__ __forceinline__ float group_sum(float v) {
-#pragma unroll
-    for (int o = W / 2; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    if (W >= 2) v += dpp_mov<0xB1>(v);
+    if (W >= 4) v += dpp_mov<0x4E>(v);
+    if (W >= 8) v += dpp_mov<0x141>(v);
+    if (W >= 16) v += dpp_mov<0x140>(v);
+    if (W >= 32) v += __shfl_xor(v, 16, 64);
+    if (W >= 64) v += __shfl_xor(v, 32, 64);
     return v;
 }
 template <int W>
 __device__ __forceinline__ float group_max(float v) {
-#pragma unroll
-    for (int o = W / 2; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+    if (W >= 2) v = fmaxf(v, dpp_mov<0xB1>(v));
+    if (W >= 4) v = fmaxf(v, dpp_mov<0x4E>(v));
+    if (W >= 8) v = fmaxf(v, dpp_mov<0x141>(v));
+    if (W >= 16) v = fmaxf(v, dpp_mov<0x140>(v));
+    if (W >= 32) v = fmaxf(v, __shfl_xor(v, 16, 64));
+    if (W >= 64) v = fmaxf(v, __shfl_xor(v, 32, 64));
     return v;
 }
 

@@ -1,0 +1,238 @@
+// Mask generation of the masked autoencoder (reference GPTST.py:314-323 random phase, :344-413 adaptive phase).
+//
+// The reference zeroes the k largest noise values with  sort(descending) -> idx[:k] -> scatter_(0)  (one global sort per
+// selection) and picks whole cluster classes in a host `while` loop with a device->host sync per iteration (:366-369).
+// Here every selection is a multi-workgroup radix SELECT on the exact float bits (3 digits of 11/11/10 bits): each digit
+// pass is one launch in which every workgroup histograms its slice in LDS and merges into a global histogram; the next
+// launch re-derives the running prefix from the finished histograms (256-2048 bins, redundantly per workgroup — cheaper
+// than a grid barrier), and a final launch writes the mask.  The result is the same SET as the sort-based one whenever
+// the k-th and (k+1)-th values differ; ties straddling rank k go to the lowest indices (torch's sort is unstable there,
+// SURVEY.md §7).  Class selection runs on the device from a per-class histogram.  Nothing on this path reads back to
+// the host, so it is hipGraph-capturable.  Noise is non-negative (uniform [0,1)): uint32 bit order == float order.
+// Masks are fp32 {0,1} arrays (1 = visible, 0 = masked) of B*T*N*base cells — the consumers multiply with them.
+#include "common.h"
+
+#define MS_BLOCKS 64
+#define MS_THREADS 256
+#define MS_BINS 2048
+// digit d covers bits [SH(d), SH(d)+W(d)):  d0 = 31..21, d1 = 20..10, d2 = 9..0
+__device__ __forceinline__ int ms_shift(int d) { return d == 0 ? 21 : (d == 1 ? 10 : 0); }
+__device__ __forceinline__ int ms_bins(int d) { return d == 2 ? 1024 : 2048; }
+
+// workspace layout (uint32): hist[3][2048] for selection A/R or the random selection, followed by nothing else.
+struct MsPlan {            // what a selection works on
+    const int* label;      // adaptive: cluster label per cell (else null)
+    const int* counts;     // adaptive: cells per class
+    const int* list_c;     // adaptive: shuffled class order
+    const int* nums;       // adaptive: {adaptive_mask_num, random_mask_num}
+    const float* noise;    // noise of THIS selection
+    const float* gate;     // selection R: m_ada (cells with gate == 0 are not eligible); else null
+    int mode;              // 0 random phase, 1 adaptive selection A (class gated), 2 adaptive selection R (m_ada gated)
+    int ada_all, HS, M, k_const;
+};
+
+struct MsClass {           // class roles of the adaptive phase, derived per workgroup (cheap: <= HS steps)
+    unsigned char d[256], f[256];
+    int ka;
+};
+
+__device__ void ms_classes(const MsPlan& p, MsClass& c) {       // GPTST.py:357-384,393
+    for (int h = threadIdx.x; h < 256; h += MS_THREADS) { c.d[h] = 0; c.f[h] = 0; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const int ada_num = p.nums[0];
+        int num = 0, i = 0;
+        while (num < ada_num && i < p.HS) { num += p.counts[p.list_c[i]]; ++i; }      // :366-369 / :379-382
+        int dnum = 0;
+        if (p.ada_all && i >= 2) {                                                     // :370-374
+            for (int k = 0; k < i - 1; ++k) { c.d[p.list_c[k]] = 1; dnum += p.counts[p.list_c[k]]; }
+            c.f[p.list_c[i - 1]] = 1;
+        } else {                                                                       // :375-377 / :383-384
+            for (int k = 0; k < i; ++k) c.f[p.list_c[k]] = 1;
+        }
+        c.ka = ada_num - dnum;                                                         // :393
+    }
+    __syncthreads();
+}
+
+__device__ __forceinline__ unsigned ms_key(const MsPlan& p, const MsClass& c, int i) {
+    if (p.mode == 1) return c.f[p.label[i]] ? __float_as_uint(p.noise[i]) : 0u;          // :390
+    if (p.mode == 2) return p.gate[i] != 0.f ? __float_as_uint(p.noise[i]) : 0u;         // :401
+    return __float_as_uint(p.noise[i]);                                                  // :316-317
+}
+
+__device__ __forceinline__ int ms_rank(const MsPlan& p, const MsClass& c) {
+    return p.mode == 0 ? p.k_const : (p.mode == 1 ? c.ka : p.nums[1]);
+}
+
+// Re-derive (prefix, remaining, cnt_eq) from the finished histograms of digits 0..ndig-1.  Thread-0 serial scan is
+// replaced by a block-parallel suffix scan because 2048 bins x 64 workgroups adds up.
+__device__ void ms_prefix(const unsigned* __restrict__ hist, int ndig, int k, unsigned* sh /* >= MS_BINS+8 */, unsigned& prefix,
+                          unsigned& remaining, unsigned& cnt_eq) {
+    prefix = 0u; remaining = (unsigned)k; cnt_eq = 0u;
+    for (int d = 0; d < ndig; ++d) {
+        const int nb = ms_bins(d);
+        const unsigned* h = hist + d * MS_BINS;
+        // each thread owns nb/256 consecutive bins (descending order = ascending "rank from the top")
+        const int per = nb / MS_THREADS;
+        unsigned loc = 0u;
+        for (int j = 0; j < per; ++j) loc += h[nb - 1 - (threadIdx.x * per + j)];
+        sh[threadIdx.x] = loc;
+        __syncthreads();
+        for (int off = 1; off < MS_THREADS; off <<= 1) {
+            const unsigned v = threadIdx.x >= off ? sh[threadIdx.x - off] : 0u;
+            __syncthreads();
+            sh[threadIdx.x] += v;
+            __syncthreads();
+        }
+        const unsigned before = sh[threadIdx.x] - loc;           // keys in bins above this thread's range
+        if (before < remaining && before + loc >= remaining) {   // the threshold bin is in this thread's range (exactly one thread)
+            unsigned cum = before;
+            for (int j = 0; j < per; ++j) {
+                const int b = nb - 1 - (threadIdx.x * per + j);
+                if (cum + h[b] >= remaining) { sh[MS_THREADS] = (unsigned)b; sh[MS_THREADS + 1] = remaining - cum; sh[MS_THREADS + 2] = h[b]; break; }
+                cum += h[b];
+            }
+        }
+        __syncthreads();
+        prefix |= sh[MS_THREADS] << ms_shift(d);
+        remaining = sh[MS_THREADS + 1];
+        cnt_eq = sh[MS_THREADS + 2];
+        __syncthreads();
+    }
+}
+
+// one digit pass: histogram of digit `dig` over the keys that match the prefix of the earlier digits
+__global__ __launch_bounds__(MS_THREADS) void ms_hist_kernel(MsPlan p, unsigned* __restrict__ hist, int dig) {
+    __shared__ unsigned lh[MS_BINS];
+    __shared__ unsigned sc[MS_THREADS + 8];
+    __shared__ MsClass cls;
+    if (p.mode == 1) ms_classes(p, cls);
+    const int k = ms_rank(p, cls);
+    if (k <= 0) return;                                          // uniform: nothing to select
+    unsigned prefix, remaining, cnt_eq;
+    ms_prefix(hist, dig, k, sc, prefix, remaining, cnt_eq);
+    for (int b = threadIdx.x; b < MS_BINS; b += MS_THREADS) lh[b] = 0u;
+    __syncthreads();
+    const int sh = ms_shift(dig), nb = ms_bins(dig);
+    const unsigned hi_mask = dig == 0 ? 0u : (0xFFFFFFFFu << (sh + (dig == 1 ? 11 : 10)));
+    for (int i = blockIdx.x * MS_THREADS + threadIdx.x; i < p.M; i += MS_BLOCKS * MS_THREADS) {
+        const unsigned key = ms_key(p, cls, i);
+        if ((key & hi_mask) == (prefix & hi_mask)) atomicAdd(&lh[(key >> sh) & (unsigned)(nb - 1)], 1u);
+    }
+    __syncthreads();
+    unsigned* gh = hist + dig * MS_BINS;
+    for (int b = threadIdx.x; b < nb; b += MS_THREADS) if (lh[b]) atomicAdd(gh + b, lh[b]);
+}
+
+// final launch of a selection: write the {0,1} mask of this selection (and the combined mask for selection R)
+//   mode 0: out = mask (M = B*T*N*base cells)
+//   mode 1: out = m_ada  (also zeroes the fully masked classes, :397)
+//   mode 2: out = m_rnd, final[i*base + j] = gate[i] * m_rnd[i]   (:411-413)
+__global__ __launch_bounds__(MS_THREADS) void ms_apply_kernel(MsPlan p, const unsigned* __restrict__ hist, float* __restrict__ out,
+                                                              float* __restrict__ final_mask, int base) {
+    __shared__ unsigned sc[MS_THREADS + 8];
+    __shared__ MsClass cls;
+    __shared__ unsigned s_base;
+    if (p.mode == 1) ms_classes(p, cls);
+    const int k = ms_rank(p, cls);
+    unsigned thr = 0xFFFFFFFFu, need = 0u, cnt_eq = 0u;
+    if (k > 0) ms_prefix(hist, 3, k, sc, thr, need, cnt_eq);
+    const bool ties = k > 0 && need != cnt_eq;                   // uniform
+    for (int i = blockIdx.x * MS_THREADS + threadIdx.x; i < p.M; i += MS_BLOCKS * MS_THREADS) {
+        const unsigned key = ms_key(p, cls, i);
+        float vis = 1.f;
+        if (k > 0 && (key > thr || (key == thr && !ties))) vis = 0.f;
+        if (p.mode == 1 && cls.d[p.label[i]]) vis = 0.f;
+        out[i] = vis;
+        if (p.mode == 2) { const float f = p.gate[i] * vis; for (int j = 0; j < base; ++j) final_mask[(size_t)i * base + j] = f; }
+    }
+    if (!ties || blockIdx.x != 0) return;
+    // rare: a tie straddles rank k.  Workgroup 0 hands the `need` threshold-equal slots out in index order.
+    // (the other workgroups left threshold-equal cells visible; cells are revisited here only to clear them)
+    if (threadIdx.x == 0) s_base = 0u;
+    __syncthreads();
+    for (int i0 = 0; i0 < p.M; i0 += MS_THREADS) {
+        const int i = i0 + threadIdx.x;
+        const bool eq = i < p.M && ms_key(p, cls, i) == thr;
+        sc[threadIdx.x] = eq ? 1u : 0u;
+        __syncthreads();
+        for (int off = 1; off < MS_THREADS; off <<= 1) {
+            const unsigned v = threadIdx.x >= off ? sc[threadIdx.x - off] : 0u;
+            __syncthreads();
+            sc[threadIdx.x] += v;
+            __syncthreads();
+        }
+        const unsigned rank = s_base + sc[threadIdx.x] - (eq ? 1u : 0u);
+        if (eq && rank < need) {
+            out[i] = 0.f;
+            if (p.mode == 2) for (int j = 0; j < base; ++j) final_mask[(size_t)i * base + j] = 0.f;
+        }
+        __syncthreads();
+        if (threadIdx.x == MS_THREADS - 1) s_base += sc[threadIdx.x];
+        __syncthreads();
+        if (s_base >= need) break;                                // uniform
+    }
+}
+
+// label[i] = argmax_h prob[i, h] (first maximum), counts[h] += 1      (GPTST.py:344-345)
+// counts: per-workgroup LDS histogram, then one global atomic per class and workgroup (same-address global atomics serialise).
+__global__ __launch_bounds__(256) void mask_labels_kernel(const float* __restrict__ prob, int rows, int HS,
+                                                          int* __restrict__ label, int* __restrict__ counts) {
+    __shared__ int hist[256];
+    for (int h = threadIdx.x; h < HS; h += 256) hist[h] = 0;
+    __syncthreads();
+    for (int i = blockIdx.x * 256 + threadIdx.x; i < rows; i += gridDim.x * 256) {
+        const float* p = prob + (size_t)i * HS;
+        float best = p[0];
+        int bi = 0;
+        for (int h = 1; h < HS; ++h) { const float v = p[h]; if (v > best) { best = v; bi = h; } }
+        label[i] = bi;
+        atomicAdd(&hist[bi], 1);
+    }
+    __syncthreads();
+    for (int h = threadIdx.x; h < HS; h += 256) if (hist[h]) atomicAdd(counts + h, hist[h]);
+}
+
+// zeroing by kernel rather than hipMemsetAsync: memset nodes captured in a hipGraph were observed not to re-execute
+// reliably on replay (ROCm 7.0 runtime bundled with torch), which silently doubled the histograms.
+__global__ __launch_bounds__(256) void ms_zero_kernel(unsigned* __restrict__ p, int n) {
+    for (int i = blockIdx.x * 256 + threadIdx.x; i < n; i += gridDim.x * 256) p[i] = 0u;
+}
+
+static int ms_select(const MsPlan& p, unsigned* hist, float* out, float* final_mask, int base, hipStream_t st) {
+    hipLaunchKernelGGL(ms_zero_kernel, dim3(6), dim3(256), 0, st, hist, 3 * MS_BINS);
+    for (int d = 0; d < 3; ++d) hipLaunchKernelGGL(ms_hist_kernel, dim3(MS_BLOCKS), dim3(MS_THREADS), 0, st, p, hist, d);
+    hipLaunchKernelGGL(ms_apply_kernel, dim3(MS_BLOCKS), dim3(MS_THREADS), 0, st, p, (const unsigned*)hist, out, final_mask, base);
+    GPTST_CHECK_LAUNCH();
+    return GPTST_OK;
+}
+
+// ws: device scratch of gptst_mask_ws_bytes() bytes
+extern "C" int gptst_mask_ws_bytes(void) { return (int)(sizeof(unsigned) * 3 * MS_BINS); }
+
+extern "C" int gptst_mask_random(const float* noise, int M, int k, float* mask, void* ws, void* stream) {
+    if (!noise || !mask || !ws || M <= 0 || k < 0 || k > M) return GPTST_EARG;
+    MsPlan p{nullptr, nullptr, nullptr, nullptr, noise, nullptr, 0, 0, 0, M, k};
+    return ms_select(p, (unsigned*)ws, mask, nullptr, 1, (hipStream_t)stream);
+}
+
+extern "C" int gptst_mask_labels(const float* prob, int rows, int HS, int* label, int* counts, void* stream) {
+    if (!prob || !label || !counts || HS <= 0 || HS > 256) return GPTST_EARG;
+    hipLaunchKernelGGL(ms_zero_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, (unsigned*)counts, HS);
+    int nb = (rows + 255) / 256; if (nb > 64) nb = 64;
+    hipLaunchKernelGGL(mask_labels_kernel, dim3(nb), dim3(256), 0, (hipStream_t)stream, prob, rows, HS, label, counts);
+    GPTST_CHECK_LAUNCH();
+    return GPTST_OK;
+}
+
+extern "C" int gptst_mask_adaptive(const int* label, const int* counts, const int* list_c, const int* nums, const float* noise_a,
+                                   const float* noise_r, int ada_all, int M, int HS, int base, float* m_ada, float* m_rnd,
+                                   float* mask, void* ws, void* stream) {
+    if (!label || !counts || !list_c || !nums || !noise_a || !noise_r || !m_ada || !m_rnd || !mask || !ws || HS > 256) return GPTST_EARG;
+    MsPlan a{label, counts, list_c, nums, noise_a, nullptr, 1, ada_all, HS, M, 0};
+    int rc = ms_select(a, (unsigned*)ws, m_ada, nullptr, base, (hipStream_t)stream);                       // :386-397
+    if (rc) return rc;
+    MsPlan r{label, counts, list_c, nums, noise_r, m_ada, 2, ada_all, HS, M, 0};
+    return ms_select(r, (unsigned*)ws, m_rnd, mask, base, (hipStream_t)stream);                            // :399-413
+}

@@ -163,7 +163,7 @@ extern "C" int gptst_rowdot(const float* X, const float* W, const float* b, floa
 extern "C" int gptst_rowouter(const float* a, int lda, const float* mask, float fill, const float* X, float* out, int olayout,
                               float* csum, float* asum, int rows, int J, int C, void* stream) {
     if (!X || J < 0 || J > SM_MAXJ || (J > 0 && (!a || !out))) return GPTST_EARG;
-    int nb = 512;
+    int nb = 96;                                    // few workgroups: every output address receives one atomic per workgroup
     int rpb = (rows + nb - 1) / nb; if (rpb < 16) rpb = 16;
     nb = (rows + rpb - 1) / rpb;
     hipStream_t st = (hipStream_t)stream;

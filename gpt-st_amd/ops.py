@@ -195,10 +195,20 @@ def cap_route_bwd(X, Wp, bp, c, dc1, dS):
 
 
 # ---- mask generation (integer path) -----------------------------------------------------------------------------
+_MASK_WS = {}
+
+
+def _mask_ws(dev):
+    """Persistent scratch for the radix-select histograms (stream-ordered reuse; allocated once per device)."""
+    if dev not in _MASK_WS:
+        _MASK_WS[dev] = torch.zeros(_C.lib().value("gptst_mask_ws_bytes") // 4, dtype=torch.int32, device=dev)
+    return _MASK_WS[dev]
+
+
 def mask_random(noise, k):
     _chk(noise)
     mask = torch.empty_like(noise)
-    _call("gptst_mask_random", _p(noise), noise.numel(), int(k), _p(mask))
+    _call("gptst_mask_random", _p(noise), noise.numel(), int(k), _p(mask), _p(_mask_ws(noise.device)))
     return mask
 
 
@@ -219,7 +229,7 @@ def mask_adaptive(label, counts, list_c, nums, noise_a, noise_r, ada_all, base):
     m_rnd = torch.empty_like(m_ada)
     mask = torch.empty(M * base, device=label.device, dtype=torch.float32)
     _call("gptst_mask_adaptive", _p(label), _p(counts), _p(list_c), _p(nums), _p(noise_a), _p(noise_r), int(ada_all), M, HS, base,
-          _p(m_ada), _p(m_rnd), _p(mask))
+          _p(m_ada), _p(m_rnd), _p(mask), _p(_mask_ws(label.device)))
     return m_ada, m_rnd, mask
 
 

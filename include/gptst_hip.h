@@ -24,6 +24,8 @@ extern "C" {
 
 #define GPTST_ABI_VERSION 1
 int gptst_abi_version(void);
+/* launch-geometry knobs for benchmarking (id 1: row chunks = atomics per output of poolgen_bwd_pool); not needed for correctness */
+int gptst_tune(int id, int value);
 
 /* ---- embedding-conditioned parameter generation (poolgen.hip) -----------------------------------------
  * out[r,:] = sum_k emb[r,k] * pool[k,:]   r < R, k < K <= 16.  Optional second problem (pool2/out2/cols2) shares emb.
@@ -87,8 +89,10 @@ int gptst_cap_route_bwd(const float* X, const float* Wp, const float* bp, const 
                         float* dY, float* dlogit, int BT, int N, int C, int HS, void* stream);
 
 /* ---- mask generation, integer work, bit-exact given noise/labels/class order (maskgen.hip), GPTST.py:314-323,344-413 ----
- * Masks are fp32 {0,1} arrays, 1 = visible, 0 = masked.  Top-k = radix select (ties at rank k -> lowest index). */
-int gptst_mask_random(const float* noise, int M, int k, float* mask, void* stream);
+ * Masks are fp32 {0,1} arrays, 1 = visible, 0 = masked.  Top-k = multi-workgroup radix select on the float bits, one launch per
+ * 11/11/10-bit digit + one to write the mask (ties at rank k -> lowest index). */
+int gptst_mask_ws_bytes(void);   /* device scratch (ws) needed by the two selections below */
+int gptst_mask_random(const float* noise, int M, int k, float* mask, void* ws, void* stream);
 /* label[i] = argmax_h prob[i,h] (int32), counts[h] (int32, zeroed here) — replaces sort(..)[..., 0] (:344-345). */
 int gptst_mask_labels(const float* prob, int rows, int HS, int* label, int* counts, void* stream);
 /* adaptive phase: device-side class selection (:356-384) + two selections (:386-407) + product (:410-413).
@@ -96,7 +100,7 @@ int gptst_mask_labels(const float* prob, int rows, int HS, int* label, int* coun
  * m_ada / m_rnd (M) are the partial masks, mask (M*base) the final one. */
 int gptst_mask_adaptive(const int* label, const int* counts, const int* list_c, const int* nums, const float* noise_a,
                         const float* noise_r, int ada_all, int M, int HS, int base, float* m_ada, float* m_rnd, float* mask,
-                        void* stream);
+                        void* ws, void* stream);
 
 /* ---- thin projections (small.hip) ------------------------------------------------------------------------
  * lin_in: Y[i,:] = sum_j a'[i,j] W(:,j) + b, a' = mask ? (mask[i,j] ? a[i*lda+j] : fill) : a;  wlayout 0: W[c*J+j], 1: W[j*C+c].
