@@ -1,0 +1,100 @@
+"""Pretraining loop with the reference's behaviour (model/BasicTrainer.py:125-197 train, :67-123 train_epoch, pretrain
+branches only): per-epoch MultiStepLR, best-on-train-flow-loss tracking with the up_epoch resets, the loss>1e6 abort, the
+log line formats, and the final ``torch.save(best_state_dict, SAVE/<dataset>/<save_pretrain_path>)``.
+The step itself is the fused HIP step (step.py); the host only reads the loss statistics when it has to log."""
+import copy
+import logging
+import os
+import time
+
+import torch
+
+from .step import PretrainStep
+
+
+def get_logger(log_dir, name="GPTST", debug=True):
+    logger = logging.getLogger(name)
+    logger.setLevel(logging.DEBUG)
+    if not logger.handlers:
+        fmt = logging.Formatter("%(asctime)s: %(message)s", "%Y-%m-%d %H:%M")
+        ch = logging.StreamHandler()
+        ch.setLevel(logging.DEBUG if debug else logging.INFO)
+        ch.setFormatter(fmt)
+        logger.addHandler(ch)
+        if not debug:                                   # reference lib/logger.py:18-32: file only when debug=False
+            fh = logging.FileHandler(os.path.join(log_dir, "run.log"), mode="w")
+            fh.setFormatter(fmt)
+            logger.addHandler(fh)
+    return logger
+
+
+class Trainer:
+    def __init__(self, model, args, batches, scaler_mean, scaler_std, batch_size, dp=None, use_graph=True):
+        """batches: a callable epoch -> iterable of (B,T,N,base+2) device tensors (ragged last batch allowed)."""
+        self.model, self.args, self.batches = model, args, batches
+        self.dp = dp
+        self.step = PretrainStep(model, args, scaler_mean, scaler_std, batch_size, use_graph=use_graph, dp=dp, seed=args.seed)
+        self.ragged = {}
+        self.scaler = (scaler_mean, scaler_std)
+        self.use_graph = use_graph
+        os.makedirs(args.log_dir, exist_ok=True)
+        self.logger = get_logger(args.log_dir, name=str(args.model), debug=args.debug)
+        self.best_path = os.path.join(args.log_dir, args.save_pretrain_path)
+        self.lr_steps = [int(i) for i in str(args.lr_decay_step).split(",")] if args.lr_decay else []
+        self.up_epoch = [int(i) for i in str(args.up_epoch).split(",")]
+
+    def _stepper_for(self, B):
+        if B == self.step.B:
+            return self.step
+        if B not in self.ragged:                         # drop_last=False in the reference: the last batch is smaller
+            s = PretrainStep(self.model, self.args, self.scaler[0], self.scaler[1], B, use_graph=False, dp=self.dp, seed=self.args.seed)
+            s.m, s.v = self.step.m, self.step.v          # one optimiser state
+            self.ragged[B] = s
+        s = self.ragged[B]
+        s.tA, s.tB, s.lr = self.step.tA, self.step.tB, self.step.lr
+        return s
+
+    def train_epoch(self, epoch):
+        a = self.args
+        tot = tot_f = tot_s = 0.0
+        nb = 0
+        data = list(self.batches(epoch))
+        for bi, src in enumerate(data):
+            st = self._stepper_for(src.shape[0])
+            st.step(src, epoch)
+            if st is not self.step:
+                self.step.tA, self.step.tB = st.tA, st.tB
+            loss, lf, ls = st.losses()                   # the reference syncs every step too (BasicTrainer.py:98-103)
+            tot += loss; tot_f += lf; tot_s += ls; nb += 1
+            if bi % a.log_step == 0:
+                self.logger.info("Train Epoch {}: {}/{} Loss: {:.6f}".format(epoch, bi, len(data), loss))
+        self.logger.info("**********Train Epoch {}: averaged Loss: {:.6f} averaged Loss_s: {:.6f}".format(epoch, tot_f / nb, tot_s / nb))
+        if a.lr_decay and epoch in self.lr_steps:        # MultiStepLR (Run.py:141), stepped per epoch (BasicTrainer.py:117-118)
+            self.step.lr *= a.lr_decay_rate
+        return tot_f / nb
+
+    def train(self):
+        a = self.args
+        best_loss, best_state, not_improved = float("inf"), None, 0
+        t0 = time.time()
+        for epoch in range(1, a.epochs + 1):
+            loss = self.train_epoch(epoch)
+            if epoch in self.up_epoch:                   # BasicTrainer.py:138-139
+                best_loss = float("inf")
+            if loss > 1e6:                               # :166-168
+                self.logger.warning("Gradient explosion detected. Ending...")
+                break
+            if loss < best_loss:
+                best_loss, not_improved = loss, 0
+                best_state = copy.deepcopy(self.model.state_dict())       # :177-180
+                self.logger.info("*********************************Current best model saved!")
+            else:
+                not_improved += 1
+            if a.early_stop and not_improved == a.early_stop_patience:    # :171-175
+                self.logger.info("Validation performance didn't improve for {} epochs. Training stops.".format(a.early_stop_patience))
+                break
+        self.logger.info("Total training time: {:.4f}min, best loss: {:.6f}".format((time.time() - t0) / 60, best_loss))
+        if a.debug and best_state is not None and (self.dp is None or self.dp.rank == 0):   # :187-189 (flag is inverted in the reference too)
+            torch.save(best_state, self.best_path)
+            self.logger.info("Saving current best model to " + self.best_path)
+        return best_state

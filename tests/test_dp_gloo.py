@@ -1,0 +1,94 @@
+"""world_size-2 data-parallel reduction on CPU (gloo): the packed [sum-loss gradient | statistics] all-reduce of dist.py plus the
+optimiser-side scaling reproduces the gradient of the global-batch loss.  Local gradients come from the oracle (the checker) —
+no HIP compute happens here; the same DataParallel class runs over RCCL on the GPUs."""
+import os
+import sys
+
+import pytest
+import torch
+import torch.multiprocessing as mp
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _local_buffer(rank, world, args, sd, src_all, masks_all, keys, nA_keys):
+    """[sum-loss gradient (path-A params first) | stats] of this rank's slice, from the oracle."""
+    from gptst_amd import synth
+    from oracle import gptst_oracle as O
+    B = src_all.shape[0] // world
+    src, mask = src_all[rank * B:(rank + 1) * B], masks_all[rank * B:(rank + 1) * B]
+    st = O.Stepper(sd, args, synth.SCALER_MEAN, synth.SCALER_STD)
+    outs, _ = O.forward_pretrain(st.sd, args, src, 1, forced_mask=mask)
+    out, m = outs[0], outs[2]
+    p = (out * synth.SCALER_STD + synth.SCALER_MEAN) * m
+    y = (src[..., :1] * synth.SCALER_STD + synth.SCALER_MEAN) * m
+    keep = y > args.mape_thresh
+    lsum = (torch.abs(y - p) * keep).sum()
+    lsum.backward()
+    g = torch.cat([(st.sd[k].grad if st.sd[k].grad is not None else torch.zeros_like(st.sd[k])).reshape(-1) for k in keys])
+    stats = torch.zeros(8)
+    stats[0], stats[1] = float(lsum), float(keep.sum())
+    return torch.cat([g, stats])
+
+
+def _worker(rank, world, port, q):
+    sys.path.insert(0, ROOT)
+    os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    torch.set_num_threads(2)
+    from gptst_amd import synth
+    from gptst_amd.config import make_args
+    from gptst_amd.dist import DataParallel
+    from oracle import gptst_oracle as O
+    args = make_args("PEMS08", num_nodes=12, embed_dim=4, HS=4, HT=4, scaler_zeros=synth.scaler_zeros())
+    sd = O.init_state_dict(args, 2)
+    keys = [k for k in sd if not k.endswith("mask_template")]
+    src_all = synth.make_batch(4, 12, 12, 1, seed=3)
+    masks_all = (torch.rand(4, 12, 12, 1, generator=torch.Generator().manual_seed(5)) > 0.25).long()
+    buf = _local_buffer(rank, world, args, sd, src_all, masks_all, keys, None)
+    dp = DataParallel("gloo")
+    dp.allreduce_(buf)
+    n = buf.numel() - 8
+    g = buf[:n] / max(float(buf[n + 1]), 1.0)
+    if rank == 0:
+        q.put((g, float(buf[n] / buf[n + 1])))
+    dp.barrier()
+
+
+def test_dp_allreduce_equals_global_batch_gradient():
+    sys.path.insert(0, ROOT)
+    from gptst_amd import synth
+    from gptst_amd.config import make_args
+    from oracle import gptst_oracle as O
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 29600 + os.getpid() % 300
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    g, loss = q.get(timeout=180)
+    for p in procs:
+        p.join(60)
+        assert p.exitcode == 0
+    # single-process reference: global batch of 4 with the mean loss
+    args = make_args("PEMS08", num_nodes=12, embed_dim=4, HS=4, HT=4, scaler_zeros=synth.scaler_zeros())
+    sd = O.init_state_dict(args, 2)
+    keys = [k for k in sd if not k.endswith("mask_template")]
+    src_all = synth.make_batch(4, 12, 12, 1, seed=3)
+    masks_all = (torch.rand(4, 12, 12, 1, generator=torch.Generator().manual_seed(5)) > 0.25).long()
+    st = O.Stepper(sd, args, synth.SCALER_MEAN, synth.SCALER_STD)
+    outs, _ = O.forward_pretrain(st.sd, args, src_all, 1, forced_mask=masks_all)
+    lf = O.mae_loss(outs[0], src_all[..., :1], outs[2], synth.SCALER_MEAN, synth.SCALER_STD, args.mape_thresh)
+    lf.backward()
+    ref = torch.cat([(st.sd[k].grad if st.sd[k].grad is not None else torch.zeros_like(st.sd[k])).reshape(-1) for k in keys])
+    assert abs(loss - float(lf)) < 1e-5 * abs(float(lf))
+    torch.testing.assert_close(g, ref, rtol=2e-4, atol=1e-6)
+
+
+def test_combine_local_gradients_matches_formula():
+    from gptst_amd.dist import combine_local_gradients
+    a = torch.arange(20, dtype=torch.float32); b = torch.ones(20)
+    a[-8:] = torch.tensor([10., 4., 1., 0, 0, 0, 0, 0]); b[-8:] = torch.tensor([6., 2., 3., 0, 0, 0, 0, 0])
+    g, stats = combine_local_gradients([a, b], nA=8, nB=4)
+    assert float(stats[1]) == 6.0 and float(stats[0]) == 16.0
+    torch.testing.assert_close(g[:8], (a[:8] + b[:8]) / 6.0)
+    torch.testing.assert_close(g[8:], a[8:12] + b[8:12])
