@@ -119,9 +119,9 @@ __device__ __forceinline__ void cap_linear_to_lds(const float* __restrict__ Xbt,
 // forward: c (BT,HS,N) final soft assignment, s (BT,HS,C) intra-cluster aggregate  (GPTST.py:102-123)
 template <int C>
 __global__ __launch_bounds__(256) void cap_route_fwd_kernel(const float* __restrict__ X, const float* __restrict__ Wp,
-                                                            const float* __restrict__ bp, const float* __restrict__ teb,
-                                                            const float* __restrict__ adj, float* __restrict__ c_out,
-                                                            float* __restrict__ s_out, int N, int HS, int ds, int R, int region2) {
+                                                            const float* __restrict__ bp, const float* __restrict__ dadj,
+                                                            float* __restrict__ c_out,
+                                                            float* __restrict__ s_out, int N, int HS, int R, int region2) {
     using K = CapCfg<C>;
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const int NPAD = cap_npad(N), NP = cap_np(N);
@@ -150,8 +150,7 @@ __global__ __launch_bounds__(256) void cap_route_fwd_kernel(const float* __restr
         }
         for (int i = tid; i < HS * N; i += 256) {
             const int h = i / N, n = i % N;
-            float l = 0.f;
-            for (int k = 0; k < ds; ++k) l = fmaf(teb[(size_t)bt * ds + k], adj[(size_t)k * HS * N + i], l);
+            const float l = dadj[(size_t)bt * HS * N + i];
             L0[h * NP + n] = l;
             bl[h * NP + n] = 0.f;
         }
@@ -296,23 +295,24 @@ static size_t cap_region2(int C, int N, int HS) {
 }
 
 template <int C>
-static int launch_route_fwd(const float* X, const float* Wp, const float* bp, const float* teb, const float* adj, float* c_out,
-                            float* s_out, int BT, int N, int HS, int ds, int R, hipStream_t st) {
+static int launch_route_fwd(const float* X, const float* Wp, const float* bp, const float* dadj, float* c_out, float* s_out, int BT,
+                            int N, int HS, int R, hipStream_t st) {
     const size_t r2 = cap_region2(C, N, HS);
     const size_t smem = ((size_t)cap_npad(N) * CapCfg<C>::PITCH + r2 + 2 * (size_t)HS * C) * sizeof(float);
     if (smem > 160 * 1024) return GPTST_ESHAPE;
     static size_t cur = 0;
     if (smem > cur) { hipFuncSetAttribute((const void*)cap_route_fwd_kernel<C>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem); cur = smem; }
-    hipLaunchKernelGGL((cap_route_fwd_kernel<C>), dim3(BT), dim3(256), smem, st, X, Wp, bp, teb, adj, c_out, s_out, N, HS, ds, R, (int)r2);
+    hipLaunchKernelGGL((cap_route_fwd_kernel<C>), dim3(BT), dim3(256), smem, st, X, Wp, bp, dadj, c_out, s_out, N, HS, R, (int)r2);
     GPTST_CHECK_LAUNCH();
     return GPTST_OK;
 }
 
-extern "C" int gptst_cap_route_fwd(const float* X, const float* Wp, const float* bp, const float* teb, const float* adj,
-                                   float* c_out, float* s_out, int BT, int N, int C, int HS, int ds, int R, void* stream) {
-    if (!X || !Wp || !bp || !teb || !adj || !c_out || !s_out || HS <= 0 || R < 0) return GPTST_EARG;
-    if (C == 64) return launch_route_fwd<64>(X, Wp, bp, teb, adj, c_out, s_out, BT, N, HS, ds, R, (hipStream_t)stream);
-    if (C == 128) return launch_route_fwd<128>(X, Wp, bp, teb, adj, c_out, s_out, BT, N, HS, ds, R, (hipStream_t)stream);
+// first-generation (VALU contractions) forward: kept as the fallback for shapes the MFMA version rejects (HS > 64)
+extern "C" int gptst_cap_route_fwd_v1(const float* X, const float* Wp, const float* bp, const float* dadj, float* c_out, float* s_out,
+                                      int BT, int N, int C, int HS, int R, void* stream) {
+    if (!X || !Wp || !bp || !dadj || !c_out || !s_out || HS <= 0 || R < 0) return GPTST_EARG;
+    if (C == 64) return launch_route_fwd<64>(X, Wp, bp, dadj, c_out, s_out, BT, N, HS, R, (hipStream_t)stream);
+    if (C == 128) return launch_route_fwd<128>(X, Wp, bp, dadj, c_out, s_out, BT, N, HS, R, (hipStream_t)stream);
     return GPTST_ESHAPE;
 }
 

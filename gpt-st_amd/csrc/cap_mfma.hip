@@ -1,0 +1,301 @@
+// cap soft assignment + routing, forward (reference GPTST.py:102-123) — one workgroup (512 threads = 8 waves) per (b,t).
+// The N x C capsule matrix P = squash(X Wp^T + bp) is produced by fp32 MFMA 32x32x2 straight into LDS and stays there; the
+// (B,T,HS,N,C) tensor of the reference (:106-107) is never formed:  s[h,:] = v0[h,:] (.) sum_n c[h,n] P[n,:].
+// The two dense node-embedding x cluster-centroid contractions run on fp32 MFMA 16x16x4 (clusters padded to tiles of 16):
+//   type 1   S[h, c]  = sum_n cs[h, n] P[n, c]    wave w owns 16 columns (c = 16w..16w+15) for ALL nodes: no cross-wave fold
+//   type 2   bl[h, n] += sum_c V[h, c] P[n, c]    waves take 16-node tiles
+// and the softmax over clusters uses a quad of lanes per node (2 DPP steps).
+// History (profiles/r01b, in-kernel s_memtime stamps): the VALU version and a first MFMA version with LDS float atomics
+// both took ~90 us: every phase was a serial latency chain (ds_add_f32 with 8-way bank conflicts, one thread per node doing
+// 30 dependent LDS round trips, 2 waves per SIMD).  LDS at N=170, HS=10, C=64: 78.7 KB -> two workgroups per CU.
+#include "mfma_tile.h"
+__device__ long long g_cap_ts[64];     // debug: per-phase s_memtime stamps of workgroup 5 (enabled by gptst_tune2(99))
+int g_cap_dbg = 0;
+extern "C" int gptst_tune2(int v) { g_cap_dbg = v; return 0; }
+extern "C" int gptst_cap_ts(long long* out) { return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_cap_ts), sizeof(long long) * 64); }
+
+#define CM_NT 512
+#define CM_NW (CM_NT / 64)
+
+__host__ __device__ inline int cm_rows(int N) { return (N + 15) / 16 * 16; }          // stored capsule rows
+__host__ __device__ inline int cm_np(int N) { return ((N + 3) / 4 * 4) | 1; }         // pitch of the [h][n] arrays (>= N+3, odd)
+__host__ __device__ inline int cm_hsp(int HS) { return (HS + 15) / 16 * 16; }
+
+// type 1: S[h][c] = sum_n cs[h][n] P[n][c].  A = cs[h][n] (lane i=h, kk=n offset), B = P[n][16*ct + j].
+template <int C>
+__device__ __forceinline__ void cm_type1(const float* __restrict__ Ps, const float* __restrict__ cs, float* __restrict__ S, int N,
+                                         int NP, int HSP) {
+    constexpr int P = Tile<C>::PITCH;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int j = lane & 15, kk = lane >> 4;
+    const int nsteps = (N + 3) / 4;
+    for (int job = wave; job < (HSP / 16) * (C / 16); job += CM_NW) {
+        const int ht = job / (C / 16), ct = job % (C / 16);
+        const float* arow = cs + (ht * 16 + j) * NP + kk;
+        const float* brow = Ps + kk * P + ct * 16 + j;
+        f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
+        int s = 0;
+        for (; s + 3 < nsteps; s += 4) {                          // 8 LDS reads in flight, two accumulator chains
+            const float a0 = arow[4 * s], a1 = arow[4 * s + 4], a2 = arow[4 * s + 8], a3 = arow[4 * s + 12];
+            const float b0 = brow[4 * s * P], b1 = brow[(4 * s + 4) * P], b2 = brow[(4 * s + 8) * P], b3 = brow[(4 * s + 12) * P];
+            acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a0, b0, acc0, 0, 0, 0);
+            acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a1, b1, acc1, 0, 0, 0);
+            acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a2, b2, acc0, 0, 0, 0);
+            acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a3, b3, acc1, 0, 0, 0);
+        }
+        for (; s < nsteps; ++s) acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(arow[4 * s], brow[4 * s * P], acc0, 0, 0, 0);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) S[(ht * 16 + kk * 4 + r) * C + ct * 16 + j] = acc0[r] + acc1[r];
+    }
+}
+
+// type 2: bl[h][n] += sum_c V[h][c] P[n][c]
+template <int C>
+__device__ __forceinline__ void cm_type2(const float* __restrict__ Ps, const float* __restrict__ Vs, float* __restrict__ bl, int N,
+                                         int NP, int HS, int HSP) {
+    constexpr int P = Tile<C>::PITCH;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int j = lane & 15, kk = lane >> 4;
+    const int ntiles = (N + 15) / 16;
+    for (int job = wave; job < (HSP / 16) * ntiles; job += CM_NW) {
+        const int ht = job / ntiles, nt = job % ntiles;
+        const float* arow = Vs + (ht * 16 + j) * P + 4 * kk;
+        const float* brow = Ps + (nt * 16 + j) * P + 4 * kk;
+        float4 a[C / 16], b[C / 16];
+#pragma unroll
+        for (int q = 0; q < C / 16; ++q) { a[q] = ld4(arow + 16 * q); b[q] = ld4(brow + 16 * q); }
+        f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int q = 0; q < C / 16; ++q) {
+            acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a[q].x, b[q].x, acc0, 0, 0, 0);
+            acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a[q].y, b[q].y, acc1, 0, 0, 0);
+            acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a[q].z, b[q].z, acc0, 0, 0, 0);
+            acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a[q].w, b[q].w, acc1, 0, 0, 0);
+        }
+        const int n = nt * 16 + j;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int h = ht * 16 + kk * 4 + r;
+            if (h < HS && n < N) bl[h * NP + n] += acc0[r] + acc1[r];
+        }
+    }
+}
+
+// cs[h][n] = softmax_h( use_bl*bl + use_l0*(teb . adj) ): a quad of lanes per node, lane q takes h = q, q+4, ...;
+// optional copy to global c_out[h*N + n].  HS <= 64 (16 logits per lane).
+__device__ __forceinline__ void cm_softmax(const float* __restrict__ bl, float* __restrict__ cs, const float* __restrict__ l0g,
+                                           float* __restrict__ c_out, int N, int NP, int HS, bool use_bl, bool use_l0) {
+    const int q = threadIdx.x & 3;
+    for (int n0 = 0; n0 < N; n0 += CM_NT / 4) {
+        const int n = n0 + (threadIdx.x >> 2);
+        const bool valid = n < N;
+        float l[16];
+        float m = -3.0e38f;
+#pragma unroll
+        for (int u = 0; u < 16; ++u) {
+            l[u] = -3.0e38f;
+            if (4 * u < HS) {                                    // uniform
+                const int h = q + 4 * u;
+                if (h < HS && valid) {
+                    float v = use_bl ? bl[h * NP + n] : 0.f;
+                    if (use_l0) v += l0g[(size_t)h * N + n];
+                    l[u] = v;
+                    m = fmaxf(m, v);
+                }
+            }
+        }
+        m = group_max<4>(m);
+        float sum = 0.f;
+#pragma unroll
+        for (int u = 0; u < 16; ++u) {
+            const int h = q + 4 * u;
+            if (4 * u < HS && h < HS && valid) { l[u] = __expf(l[u] - m); sum += l[u]; }     // v_exp_f32 path: rel. error ~2e-6 for |x| < 50
+        }
+        sum = group_sum<4>(sum);
+        const float inv = 1.f / sum;
+#pragma unroll
+        for (int u = 0; u < 16; ++u) {
+            const int h = q + 4 * u;
+            if (4 * u < HS && h < HS && valid) {
+                const float c = l[u] * inv;
+                cs[h * NP + n] = c;
+                if (c_out != nullptr) c_out[(size_t)h * N + n] = c;
+            }
+        }
+    }
+}
+
+// consume S: post 0 -> dst_global[h*C+c] = S;  1 -> Vdst = squash(S);  2 -> Vdst = squash(V0 (.) S)
+template <int C>
+__device__ __forceinline__ void cm_post(const float* __restrict__ S, const float* __restrict__ V0s, float* __restrict__ Vdst,
+                                        float* __restrict__ gdst, int HS, int post) {
+    constexpr int P = Tile<C>::PITCH, LPR = C / 4;
+    for (int base = 0; base < HS * LPR; base += CM_NT) {
+        const int pair = base + threadIdx.x;
+        const bool valid = pair < HS * LPR;
+        const int h = valid ? pair / LPR : 0, c4 = pair % LPR;
+        float4 v = f4zero();
+        if (valid) {
+            v = ld4(S + h * C + 4 * c4);
+            if (post == 2) { const float4 m = ld4(V0s + h * P + 4 * c4); v = make_float4(v.x * m.x, v.y * m.y, v.z * m.z, v.w * m.w); }
+        }
+        if (post != 0) {
+            const float sc = squash_scale(group_sum<LPR>(f4dot(v, v)));
+            v = make_float4(v.x * sc, v.y * sc, v.z * sc, v.w * sc);
+        }
+        if (valid) {
+            if (post == 0) st4(gdst + h * C + 4 * c4, v);
+            else st4(Vdst + h * P + 4 * c4, v);
+        }
+    }
+}
+
+template <int C>
+__global__ __launch_bounds__(CM_NT, 4) void cap_route_fwd2_kernel(const float* __restrict__ X, const float* __restrict__ Wp,
+                                                               const float* __restrict__ bp, const float* __restrict__ dadj,
+                                                               float* __restrict__ c_out,
+                                                               float* __restrict__ s_out, int N, int HS, int R, int region2, int dbg) {
+    using T = Tile<C>;
+    constexpr int P = T::PITCH, LPR = C / 4, RPP = CM_NT / LPR;
+    int tsi = 0;
+#define TS() do { if (dbg == 99 && blockIdx.x == 5 && threadIdx.x == 0) g_cap_ts[tsi] = clock64(); ++tsi; } while (0)
+    TS();
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    const int NR = cm_rows(N), NP = cm_np(N), HSP = cm_hsp(HS);
+    float* Ps = smem;                       // NR * P
+    float* Wl = Ps + NR * P;                // region2 = max(C*C, HS*NP + HSP*NP)
+    float* bl = Wl;                         // HS * NP
+    float* cs = bl + HS * NP;               // HSP * NP
+    float* Vs = Wl + region2;               // HSP * P
+    float* V0s = Vs + HSP * P;              // HSP * P
+    float* S = V0s + HSP * P;               // HSP * C
+    const int bt = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const float* Xbt = X + (size_t)bt * N * C;
+
+    load_w_lds<C>(Wl, Wp, 1, tid, CM_NT);
+    for (int i = tid; i < 2 * HSP * P + HSP * C; i += CM_NT) Vs[i] = 0.f;      // Vs, V0s, S
+    __syncthreads(); TS();
+    // ---- Y = X Wp^T by 32-row MFMA tiles (one per wave); rows beyond the stored range are dropped ----------------
+    for (int t = wave; t < (NR + 31) / 32; t += CM_NW) {
+        float* tile = Ps + t * 32 * P;
+        const int rows_here = min(32, NR - t * 32);
+#pragma unroll
+        for (int it = 0; it < T::F4_PER_LANE; ++it) {
+            const int f = it * 64 + lane;
+            const int r = f / T::F4_PER_ROW, c4 = f % T::F4_PER_ROW;
+            const int n = t * 32 + r;
+            if (r < rows_here) st4(tile + r * P + 4 * c4, n < N ? ld4(Xbt + (size_t)n * C + 4 * c4) : f4zero());
+        }
+        f32x16 acc[T::NCT];
+        if (rows_here == 32) {
+            mfma_tile<C>(tile, Wl, acc, lane);
+            acc_to_tile<C>(tile, acc, lane);
+        } else {                                        // 16-row tail: operand rows 16..31 alias rows 0..15 (results discarded)
+            const int i = lane & 31, h = lane >> 5;
+#pragma unroll
+            for (int ct = 0; ct < T::NCT; ++ct)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[ct][r] = 0.f;
+            const float* arow = tile + (i & 15) * P + 4 * h;
+            const float* wcol = Wl + 4 * h * C + i;
+#pragma unroll 2
+            for (int q = 0; q < C / 8; ++q) {
+                const float4 a4 = ld4(arow + 8 * q);
+                const float av[4] = {a4.x, a4.y, a4.z, a4.w};
+#pragma unroll
+                for (int jj = 0; jj < 4; ++jj)
+#pragma unroll
+                    for (int ct = 0; ct < T::NCT; ++ct)
+                        acc[ct] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[jj], wcol[(8 * q + jj) * C + ct * 32], acc[ct], 0, 0, 0);
+            }
+#pragma unroll
+            for (int ct = 0; ct < T::NCT; ++ct)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int row = (r & 3) + 8 * (r >> 2) + 4 * h;
+                    if (row < 16) tile[row * P + ct * 32 + i] = acc[ct][r];
+                }
+        }
+    }
+    __syncthreads(); TS();
+    // ---- P = squash(Y + bp) in place;  bl = 0, cs = 0 (incl. padding rows / columns) ---------------------------
+    {
+        const int slot = tid / LPR, jj = tid % LPR;
+        const float4 b4 = ld4(bp + 4 * jj);
+        for (int n0 = 0; n0 < NR; n0 += RPP) {
+            const int n = n0 + slot;
+            float4 y = f4zero();
+            if (n < N) y = f4add(ld4(Ps + n * P + 4 * jj), b4);
+            const float sc = squash_scale(group_sum<LPR>(f4dot(y, y)));
+            if (n < NR) st4(Ps + n * P + 4 * jj, make_float4(y.x * sc, y.y * sc, y.z * sc, y.w * sc));
+        }
+        for (int i = tid; i < (HS + HSP) * NP; i += CM_NT) bl[i] = 0.f;
+    }
+    __syncthreads(); TS();
+    const float* l0g = dadj + (size_t)bt * HS * N;
+    cm_softmax(bl, cs, l0g, nullptr, N, NP, HS, false, true);               // c0 = softmax_h(dadj)      :105
+    __syncthreads(); TS();
+    cm_type1<C>(Ps, cs, S, N, NP, HSP);
+    __syncthreads(); TS();
+    cm_post<C>(S, nullptr, V0s, nullptr, HS, 1);                                        // v0 = squash(c0 . P)       :105-106
+    __syncthreads(); TS();
+    for (int r = 0; r < R; ++r) {                                                       // routing (no grad)          :113-118
+        if (r > 0) { cm_type2<C>(Ps, Vs, bl, N, NP, HS, HSP); __syncthreads(); TS(); }        // b += v . P^T
+        cm_softmax(bl, cs, l0g, nullptr, N, NP, HS, true, false);           // c = softmax_h(b)
+        __syncthreads(); TS();
+        cm_type1<C>(Ps, cs, S, N, NP, HSP);
+        __syncthreads(); TS();
+        cm_post<C>(S, V0s, Vs, nullptr, HS, 2);                                         // v = squash(v0 (.) c.P)
+        __syncthreads(); TS();
+    }
+    if (R > 0) { cm_type2<C>(Ps, Vs, bl, N, NP, HS, HSP); __syncthreads(); TS(); }
+    cm_softmax(bl, cs, l0g, c_out + (size_t)bt * HS * N, N, NP, HS, true, true);   // c = softmax_h(b + dadj)  :120
+    __syncthreads(); TS();
+    cm_type1<C>(Ps, cs, S, N, NP, HSP);
+    __syncthreads(); TS();
+    cm_post<C>(S, nullptr, nullptr, s_out + (size_t)bt * HS * C, HS, 0);                // s = c . P                 :123
+}
+
+template <int C>
+static int launch_route_fwd2(const float* X, const float* Wp, const float* bp, const float* dadj, float* c_out,
+                             float* s_out, int BT, int N, int HS, int R, hipStream_t st) {
+    if (HS > 64) return GPTST_ESHAPE;
+    const int NR = cm_rows(N), NP = cm_np(N), HSP = cm_hsp(HS);
+    size_t r2 = (size_t)C * C, need = (size_t)(HS + HSP) * NP;
+    if (need > r2) r2 = need;
+    r2 = (r2 + 3) & ~(size_t)3;
+    const size_t smem = ((size_t)NR * Tile<C>::PITCH + r2 + 2 * (size_t)HSP * Tile<C>::PITCH + (size_t)HSP * C) * sizeof(float);
+    if (smem > 160 * 1024) return GPTST_ESHAPE;
+    static size_t cur = 0;
+    if (smem > cur) { hipFuncSetAttribute((const void*)cap_route_fwd2_kernel<C>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem); cur = smem; }
+    hipLaunchKernelGGL((cap_route_fwd2_kernel<C>), dim3(BT), dim3(CM_NT), smem, st, X, Wp, bp, dadj, c_out, s_out, N, HS, R, (int)r2, g_cap_dbg);
+    GPTST_CHECK_LAUNCH();
+    return GPTST_OK;
+}
+
+extern "C" int gptst_cap_route_fwd_v1(const float* X, const float* Wp, const float* bp, const float* dadj, float* c_out, float* s_out,
+                                      int BT, int N, int C, int HS, int R, void* stream);
+
+extern "C" int gptst_cap_route_fwd(const float* X, const float* Wp, const float* bp, const float* dadj, float* c_out, float* s_out,
+                                   int BT, int N, int C, int HS, int R, void* stream) {
+    if (!X || !Wp || !bp || !dadj || !c_out || !s_out || HS <= 0 || R < 0) return GPTST_EARG;
+    int rc = GPTST_ESHAPE;
+    if (C == 64) rc = launch_route_fwd2<64>(X, Wp, bp, dadj, c_out, s_out, BT, N, HS, R, (hipStream_t)stream);
+    else if (C == 128) rc = launch_route_fwd2<128>(X, Wp, bp, dadj, c_out, s_out, BT, N, HS, R, (hipStream_t)stream);
+    if (rc == GPTST_ESHAPE) return gptst_cap_route_fwd_v1(X, Wp, bp, dadj, c_out, s_out, BT, N, C, HS, R, stream);
+    return rc;
+}
+
+// debug: resident workgroups per CU of the forward kernel at a given shape
+extern "C" int gptst_cap_occupancy(int N, int HS) {
+    constexpr int C = 64;
+    const int NR = cm_rows(N), NP = cm_np(N), HSP = cm_hsp(HS);
+    size_t r2 = (size_t)C * C, need = (size_t)(HS + HSP) * NP;
+    if (need > r2) r2 = need;
+    r2 = (r2 + 3) & ~(size_t)3;
+    const size_t smem = ((size_t)NR * Tile<C>::PITCH + r2 + 2 * (size_t)HSP * Tile<C>::PITCH + (size_t)HSP * C) * sizeof(float);
+    int n = -1;
+    hipFuncSetAttribute((const void*)cap_route_fwd2_kernel<C>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+    hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, (const void*)cap_route_fwd2_kernel<C>, CM_NT, smem);
+    return n * 1000000 + (int)smem;
+}

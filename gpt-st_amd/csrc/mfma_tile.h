@@ -33,16 +33,37 @@ __device__ __forceinline__ void mfma_tile(const float* __restrict__ tile, const 
         for (int r = 0; r < 16; ++r) acc[ct][r] = 0.f;
     const float* arow = tile + i * P + 4 * h;
     const float* wcol = Wl + 4 * h * C + i;
-#pragma unroll 2
-    for (int q = 0; q < C / 8; ++q) {
-        const float4 a4 = ld4(arow + 8 * q);
-        const float av[4] = {a4.x, a4.y, a4.z, a4.w};
+    // Software pipeline: the operands of step q+1 are fetched from LDS before the MFMAs of step q issue — the first
+    // version (read -> s_waitcnt -> mfma per step) was LDS-latency bound at ~3.5x the MFMA time (profiles/r01b).
+    float4 a_cur = ld4(arow);
+    float b_cur[4][NCT];
 #pragma unroll
-        for (int jj = 0; jj < 4; ++jj) {
-            const float* wk = wcol + (8 * q + jj) * C;
+    for (int jj = 0; jj < 4; ++jj)
+#pragma unroll
+        for (int ct = 0; ct < NCT; ++ct) b_cur[jj][ct] = wcol[jj * C + ct * 32];
+#pragma unroll
+    for (int q = 0; q < C / 8; ++q) {
+        float4 a_nxt = a_cur;
+        float b_nxt[4][NCT];
+        if (q + 1 < C / 8) {
+            a_nxt = ld4(arow + 8 * (q + 1));
+#pragma unroll
+            for (int jj = 0; jj < 4; ++jj)
+#pragma unroll
+                for (int ct = 0; ct < NCT; ++ct) b_nxt[jj][ct] = wcol[(8 * (q + 1) + jj) * C + ct * 32];
+        }
+        const float av[4] = {a_cur.x, a_cur.y, a_cur.z, a_cur.w};
+#pragma unroll
+        for (int jj = 0; jj < 4; ++jj)
 #pragma unroll
             for (int ct = 0; ct < NCT; ++ct)
-                acc[ct] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[jj], wk[ct * 32], acc[ct], 0, 0, 0);
+                acc[ct] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[jj], b_cur[jj][ct], acc[ct], 0, 0, 0);
+        if (q + 1 < C / 8) {
+            a_cur = a_nxt;
+#pragma unroll
+            for (int jj = 0; jj < 4; ++jj)
+#pragma unroll
+                for (int ct = 0; ct < NCT; ++ct) b_cur[jj][ct] = b_nxt[jj][ct];
         }
     }
 }

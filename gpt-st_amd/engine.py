@@ -71,7 +71,8 @@ def cap_fwd(p, pfx, x, node_emb, tes, teb, dims, num_route):
     B, T, N, C = dims
     adj, t_adj = p[pfx + "adj"], p[pfx + "t_adj"]
     ds, HS, HT = adj.shape[0], adj.shape[1], t_adj.shape[1]
-    c, s = ops.cap_route_fwd(x.view(B, T, N, C), p[pfx + "ln_p.weight"], p[pfx + "ln_p.bias"], teb, adj, num_route)   # :102-123
+    dadj = ops.poolgen(teb, adj.view(ds, HS * N))                                                                        # :104
+    c, s = ops.cap_route_fwd(x.view(B, T, N, C), p[pfx + "ln_p.weight"], p[pfx + "ln_p.bias"], dadj, HS, num_route)         # :102-123
     dyn = ops.poolgen(tes, t_adj.view(ds, HT * T * HS)).view(B, HT, T * HS)                                          # :129
     v, Ht, Rt = ops.cap_cross_fwd(s, dyn, p[pfx + "mask_template"], B, T, HS, HT)                                     # :125-134
     rec = ops.cap_rec_fwd(c, v, N, C)                                                                                 # :135

@@ -62,7 +62,8 @@ class CapFn(torch.autograd.Function):
         teb2 = teb.reshape(BT, ds).contiguous()
         tes = time_eb_spg.contiguous()
         ne = node_emb.contiguous()
-        c, s = ops.cap_route_fwd(x, lnp_w, lnp_b, teb2, adj, num_route)                    # :102-123
+        dadj = ops.poolgen(teb2, adj.reshape(ds, HS * N))                                  # :104
+        c, s = ops.cap_route_fwd(x, lnp_w, lnp_b, dadj, HS, num_route)                     # :102-123
         dyn = ops.poolgen(tes, t_adj.reshape(ds, HT * T * HS)).view(B, HT, T * HS)         # :129
         v, Ht, Rt = ops.cap_cross_fwd(s, dyn, tmpl, B, T, HS, HT)                          # :125-134
         rec = ops.cap_rec_fwd(c, v, N, C)                                                  # :135

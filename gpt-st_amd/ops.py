@@ -134,15 +134,13 @@ def tmix_dgraph(dR, X):
 
 
 # ---- cap -----------------------------------------------------------------------------------------------------
-def cap_route_fwd(X, Wp, bp, teb, adj, R):
-    """X (B,T,N,C); Wp (C,C) ln_p.weight; teb (BT,ds); adj (ds,HS,N) -> c (BT,HS,N), s (BT,HS,C)."""
-    _chk(X, Wp, bp, teb, adj)
+def cap_route_fwd(X, Wp, bp, dadj, HS, R):
+    """X (B,T,N,C); Wp (C,C) ln_p.weight; dadj (BT, HS*N) logits = teb . adj -> c (BT,HS,N), s (BT,HS,C)."""
+    _chk(X, Wp, bp, dadj)
     B, T, N, C = X.shape
-    ds, HS = adj.shape[0], adj.shape[1]
     c = torch.empty(B * T, HS, N, device=X.device, dtype=torch.float32)
     s = torch.empty(B * T, HS, C, device=X.device, dtype=torch.float32)
-    _call("gptst_cap_route_fwd", _p(X), _p(Wp), _p(bp), _p(teb), _p(adj), _p(c), _p(s), B * T, N, C, HS, ds, R,
-          nbytes=_nb(X, Wp, bp, teb, adj, c, s))
+    _call("gptst_cap_route_fwd", _p(X), _p(Wp), _p(bp), _p(dadj), _p(c), _p(s), B * T, N, C, HS, R, nbytes=_nb(X, Wp, bp, dadj, c, s))
     return c, s
 
 

@@ -68,11 +68,11 @@ int gptst_tmix(const float* X, const float* G, const float* dOut, const float* Y
 int gptst_tmix_dgraph(const float* dR, const float* X, float* dG, int B, int T, int N, int C, void* stream);
 
 /* ---- cap: node x cluster soft assignment + routing + aggregation (cap.hip, cap_cross.hip), GPTST.py:100-141 ----
- * route_fwd, one workgroup per (b,t):  P = squash(X Wp^T + bp) by MFMA into LDS; dadj = teb.adj; v0 = squash(softmax_h(dadj) P);
- *   R x { c = softmax_h(b); v = squash(v0 (.) c P); b += v P^T };  c = softmax_h(b + dadj) -> c_out (BT,HS,N);  s = c P -> (BT,HS,C).
- * Wp/bp = ln_p.weight ([out][in]) / bias; teb (BT,ds); adj (ds,HS,N). */
-int gptst_cap_route_fwd(const float* X, const float* Wp, const float* bp, const float* teb, const float* adj, float* c_out,
-                        float* s_out, int BT, int N, int C, int HS, int ds, int R, void* stream);
+ * route_fwd, one workgroup per (b,t):  P = squash(X Wp^T + bp) by MFMA into LDS; dadj (BT,HS,N) = teb.adj (from gptst_poolgen_fwd);
+ *   v0 = squash(softmax_h(dadj) P);  R x { c = softmax_h(b); v = squash(v0 (.) c P); b += v P^T }  (both contractions on MFMA 16x16x4);
+ *   c = softmax_h(b + dadj) -> c_out (BT,HS,N);  s = c P -> (BT,HS,C).   Wp/bp = ln_p.weight ([out][in]) / bias. */
+int gptst_cap_route_fwd(const float* X, const float* Wp, const float* bp, const float* dadj, float* c_out, float* s_out, int BT, int N,
+                        int C, int HS, int R, void* stream);
 /* cross-time hyperedges per sample (GPTST.py:125-134): v = squash(LReLU(dyn^T LReLU(dyn (s + (t+1)/12))) + s);
  * dyn (B,HT,T*HS) = time_eb_spg . t_adj (poolgen); saves Ht (B,HT,C), Rt (B,T*HS,C) for backward. */
 int gptst_cap_cross_fwd(const float* s, const float* dyn, const float* tmpl, float* v, float* Ht, float* Rt, int B, int T, int C,
