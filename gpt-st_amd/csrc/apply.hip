@@ -123,9 +123,11 @@ __global__ __launch_bounds__(256) void apply_kernel(const float* __restrict__ A,
 template <int PRO>
 __global__ __launch_bounds__(256) void wgrad64_kernel(const float* __restrict__ A, const float* __restrict__ D,
                                                       const float* __restrict__ D2, float* __restrict__ dW, RowMap rm,
-                                                      int rows_per_split) {
+                                                      int rows_per_split, int ostride, int csa) {
     constexpr int C = 64;
     __shared__ float red[4][C * C];
+    __shared__ float csred[4][C];
+    float sa0 = 0.f, sa1 = 0.f;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int j = lane & 31, h = lane >> 5;
     const int g = blockIdx.x, sp = blockIdx.y;
@@ -154,6 +156,7 @@ __global__ __launch_bounds__(256) void wgrad64_kernel(const float* __restrict__ 
                 d0[u] = D[off + j]; d1[u] = D[off + 32 + j];
                 if (PRO == PRO_DPRE) { d0[u] *= lrelu_grad_from_out(D2[off + j]); d1[u] *= lrelu_grad_from_out(D2[off + 32 + j]); }
             }
+            sa0 += a0[u]; sa1 += a1[u];
         }
 #pragma unroll
         for (int u = 0; u < U; ++u) {
@@ -172,8 +175,13 @@ __global__ __launch_bounds__(256) void wgrad64_kernel(const float* __restrict__ 
                 const int row = (r & 3) + 8 * (r >> 2) + 4 * h;
                 red[wave][(a * 32 + row) * C + b * 32 + j] = acc[a][b][r];
             }
+    if (csa) {                                   // column sums of A (bias gradient of a shared Linear), folded over halves and waves
+        sa0 += __shfl_xor(sa0, 32, 64); sa1 += __shfl_xor(sa1, 32, 64);
+        if (h == 0) { csred[wave][j] = sa0; csred[wave][32 + j] = sa1; }
+    }
     __syncthreads();
-    float* o = dW + ((size_t)sp * rm.G + g) * C * C;
+    float* o = dW + ((size_t)sp * rm.G + g) * (size_t)ostride;
+    if (csa && threadIdx.x < C) o[C * C + threadIdx.x] = csred[0][threadIdx.x] + csred[1][threadIdx.x] + csred[2][threadIdx.x] + csred[3][threadIdx.x];
     for (int f = threadIdx.x; f < C * C / 4; f += 256) {
         const float4 s = f4add(f4add(ld4(&red[0][4 * f]), ld4(&red[1][4 * f])), f4add(ld4(&red[2][4 * f]), ld4(&red[3][4 * f])));
         st4(o + 4 * f, s);
@@ -236,7 +244,7 @@ static int launch_apply(const float* A, const float* A2, const float* W, long w_
                         const float* resid, const float* resid2, float* out, float* colsum, RowMap rm, int pro, int epi, hipStream_t st) {
     const int ntiles = (rm.M + 31) / 32;
     int gy = (ntiles + 3) / 4;
-    if (rm.G == 1) gy = min(gy, 128);                  // shared weight: persistent row chunks (W staged once, few colsum atomics)
+    if (rm.G == 1) gy = min(gy, colsum ? 128 : 1024);  // shared weight: with colsum keep the atomics per address low
     else gy = min(gy, 2);
     if (gy < 1) gy = 1;
     dim3 grid(rm.G, gy), block(256);
@@ -292,8 +300,23 @@ extern "C" int gptst_wgrad_nsplit(int mode, int BT, int N) {
     return want < maxs ? want : maxs;
 }
 
+static int wgrad_impl(const float* A, const float* D, const float* D2, float* dW, int mode, int pro, int BT, int N, int C, int csa,
+                      void* stream);
+
 extern "C" int gptst_wgrad(const float* A, const float* D, const float* D2, float* dW, int mode, int pro, int BT, int N,
                            int C, void* stream) {
+    return wgrad_impl(A, D, D2, dW, mode, pro, BT, N, C, 0, stream);
+}
+
+// as gptst_wgrad, plus the column sums of A appended to every split: dW rows are C*C + C floats ([dW | sum_m A[m,:]])
+extern "C" int gptst_wgrad_colsum(const float* A, const float* D, const float* D2, float* dW, int mode, int pro, int BT, int N,
+                                  int C, void* stream) {
+    if (C != 64) return GPTST_ESHAPE;
+    return wgrad_impl(A, D, D2, dW, mode, pro, BT, N, C, 1, stream);
+}
+
+static int wgrad_impl(const float* A, const float* D, const float* D2, float* dW, int mode, int pro, int BT, int N, int C, int csa,
+                      void* stream) {
     if (!A || !D || !dW) return GPTST_EARG;
     if (pro == PRO_DPRE && !D2) return GPTST_EARG;
     RowMap rm = make_rowmap(mode, BT, N);
@@ -303,8 +326,8 @@ extern "C" int gptst_wgrad(const float* A, const float* D, const float* D2, floa
     dim3 grid(rm.G, ns), block(256);
     hipStream_t st = (hipStream_t)stream;
     if (C == 64) {
-        if (pro == PRO_DPRE) hipLaunchKernelGGL((wgrad64_kernel<PRO_DPRE>), grid, block, 0, st, A, D, D2, dW, rm, rps);
-        else hipLaunchKernelGGL((wgrad64_kernel<PRO_NONE>), grid, block, 0, st, A, D, D2, dW, rm, rps);
+        if (pro == PRO_DPRE) hipLaunchKernelGGL((wgrad64_kernel<PRO_DPRE>), grid, block, 0, st, A, D, D2, dW, rm, rps, csa ? C * C + C : C * C, csa);
+        else hipLaunchKernelGGL((wgrad64_kernel<PRO_NONE>), grid, block, 0, st, A, D, D2, dW, rm, rps, csa ? C * C + C : C * C, csa);
     } else if (C == 128) {
         if (pro == PRO_DPRE) hipLaunchKernelGGL((wgrad_kernel<128, PRO_DPRE>), grid, block, 0, st, A, D, D2, dW, rm, rps);
         else hipLaunchKernelGGL((wgrad_kernel<128, PRO_NONE>), grid, block, 0, st, A, D, D2, dW, rm, rps);

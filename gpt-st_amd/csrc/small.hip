@@ -97,12 +97,23 @@ __global__ __launch_bounds__(256) void rowouter_kernel(const float* __restrict__
 #pragma unroll
         for (int u = 0; u < 8; ++u) acc[u] = f4zero();
         float4 cacc = f4zero();
-        for (size_t i = r0 + slot; i < r1; i += RPB) {
-            const float4 x = ld4(X + i * C + 4 * c4);
-            if (jb == 0) cacc = f4add(cacc, x);
+        for (size_t i0 = r0 + slot; i0 < r1; i0 += 4 * RPB) {            // 4 independent rows in flight per thread
+            float4 x[4];
+            float av[4][8];
 #pragma unroll
-            for (int u = 0; u < 8; ++u)
-                if (jb + u < J) acc[u] = f4fma(masked_a(a, mask, fill, i, jb + u, lda, J), x, acc[u]);
+            for (int q = 0; q < 4; ++q) {
+                const size_t i = i0 + (size_t)q * RPB;
+                x[q] = i < r1 ? ld4(X + i * C + 4 * c4) : f4zero();
+#pragma unroll
+                for (int u = 0; u < 8; ++u) av[q][u] = (jb + u < J && i < r1) ? masked_a(a, mask, fill, i, jb + u, lda, J) : 0.f;
+            }
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                if (jb == 0) cacc = f4add(cacc, x[q]);
+#pragma unroll
+                for (int u = 0; u < 8; ++u)
+                    if (jb + u < J) acc[u] = f4fma(av[q][u], x[q], acc[u]);
+            }
         }
         // reduce the RPB row slots through LDS, then one atomic per (j, c)
 #pragma unroll
@@ -163,7 +174,7 @@ extern "C" int gptst_rowdot(const float* X, const float* W, const float* b, floa
 extern "C" int gptst_rowouter(const float* a, int lda, const float* mask, float fill, const float* X, float* out, int olayout,
                               float* csum, float* asum, int rows, int J, int C, void* stream) {
     if (!X || J < 0 || J > SM_MAXJ || (J > 0 && (!a || !out))) return GPTST_EARG;
-    int nb = 96;                                    // few workgroups: every output address receives one atomic per workgroup
+    int nb = 160;                                   // few workgroups: every output address receives one atomic per workgroup
     int rpb = (rows + nb - 1) / nb; if (rpb < 16) rpb = 16;
     nb = (rows + rpb - 1) / rpb;
     hipStream_t st = (hipStream_t)stream;

@@ -4,7 +4,7 @@
 // weight gradients cooperatively (+= into the gradient buffers).  Feature k of row r is tidx[(r*K + k)*2 + {0: day, 1: week}].
 #include "common.h"
 
-#define TF_ROWS 128
+#define TF_ROWS 64      // rows per workgroup: the backward is a serial chain per workgroup, so use many small ones
 
 struct TfParams {      // nn.Linear tensors: weight (out,in) row-major, bias (out)
     const float *wd, *bd, *ww, *bw, *w1, *b1, *w2, *b2, *w3, *b3;

@@ -12,6 +12,42 @@ from .ops import (EPI_ADD_DPRE, EPI_LRELU, EPI_PLAIN, EPI_RES_LRELU, MODE_NODE, 
 TF_NAMES = ("ln_day", "ln_week", "ln1", "ln2", "ln")
 
 
+class ZeroArena:
+    """All zero-initialised scratch of one step (bias-gradient accumulators, embedding gradients) comes from ONE buffer that
+    is cleared with ONE memset per step instead of ~30 torch.zeros launches.  The first (sizing) pass falls back to torch.zeros."""
+
+    def __init__(self, device):
+        self.device, self.buf, self.off, self.need = device, None, 0, 0
+
+    def begin(self):
+        if self.buf is None or self.buf.numel() < self.need:
+            self.buf = torch.zeros(max(self.need, 1), device=self.device) if self.need else None
+        elif self.buf is not None:
+            self.buf.zero_()
+        self.off, self.need = 0, 0
+
+    def zeros(self, *shape):
+        n = 1
+        for d in shape:
+            n *= d
+        n4 = (n + 3) // 4 * 4
+        self.need += n4
+        if self.buf is None or self.off + n4 > self.buf.numel():
+            return torch.zeros(*shape, device=self.device)
+        t = self.buf[self.off:self.off + n].view(*shape)
+        self.off += n4
+        return t
+
+
+ARENA = None      # set by PretrainStep; None -> plain torch.zeros
+
+
+def _zeros(ref, *shape):
+    if ARENA is not None:
+        return ARENA.zeros(*shape)
+    return torch.zeros(*shape, device=ref.device)
+
+
 def _tf_tensors(d, pfx):
     out = []
     for n in TF_NAMES:
@@ -52,7 +88,7 @@ def hypertem_bwd(p, g, pfx, saved, dout, node_emb, time_eb, d_node_emb, d_time_e
     adj, wpool, bpool = p[pfx + "adj"], p[pfx + "weights_pool"], p[pfx + "bias_pool"]
     d, Hm = adj.shape[0], adj.shape[1]
     BT = B * T
-    dbias = torch.zeros(BT, C, device=x.device)
+    dbias = _zeros(x, BT, C)
     dR = ops.apply(dout, Wbt, MODE_TIME, BT, N, A2=out, transw=True, pro=PRO_DPRE, colsum=dbias)
     dWbt, ns = ops.wgrad(R, dout, MODE_TIME, BT, N, D2=out, pro=PRO_DPRE)
     ops.poolgen_bwd_pool(time_eb, dWbt, g[pfx + "weights_pool"], dbias, g[pfx + "bias_pool"], nsplit=ns)
@@ -87,7 +123,7 @@ def cap_bwd(p, g, pfx, saved, dout, node_emb, tes, teb, d_node_emb, d_tes, d_teb
     adj, t_adj = p[pfx + "adj"], p[pfx + "t_adj"]
     ds, HS, HT = adj.shape[0], adj.shape[1], t_adj.shape[1]
     BT, dev = B * T, x.device
-    dbn = torch.zeros(N, C, device=dev)
+    dbn = _zeros(x, N, C)
     drec = ops.apply(dout, Wn, MODE_NODE, BT, N, A2=out, transw=True, pro=PRO_DPRE, colsum=dbn)
     dWn, ns = ops.wgrad(rec, dout, MODE_NODE, BT, N, D2=out, pro=PRO_DPRE)
     ops.poolgen_bwd_pool(node_emb, dWn, g[pfx + "weights_spa"], dbn, g[pfx + "bias_spa"], nsplit=ns)
@@ -99,12 +135,28 @@ def cap_bwd(p, g, pfx, saved, dout, node_emb, tes, teb, d_node_emb, d_tes, d_teb
     dY, dlogit = ops.cap_route_bwd(x.view(B, T, N, C), p[pfx + "ln_p.weight"], p[pfx + "ln_p.bias"], c, dc1, dS)
     ops.poolgen_bwd_pool(teb, dlogit, g[pfx + "adj"])
     ops.poolgen_bwd_emb(dlogit, adj, d_teb)
-    dx = ops.apply(dY, p[pfx + "ln_p.weight"], MODE_SHARED, BT, N, resid=dout, resid2=out, epi=EPI_ADD_DPRE,
-                   colsum=g[pfx + "ln_p.bias"].view(1, C))
-    dWp, ns2 = ops.wgrad(dY, x, MODE_SHARED, BT, N)
-    ones = torch.ones(1, 1, device=dev)
-    ops.poolgen_bwd_pool(ones, dWp, g[pfx + "ln_p.weight"].view(1, C * C), nsplit=ns2)
+    dx = ops.apply(dY, p[pfx + "ln_p.weight"], MODE_SHARED, BT, N, resid=dout, resid2=out, epi=EPI_ADD_DPRE)
+    gw, gb = g[pfx + "ln_p.weight"], g[pfx + "ln_p.bias"]
+    if C == 64 and gb.data_ptr() == gw.data_ptr() + 4 * C * C:
+        # weight and bias gradients of ln_p in one reduction: wgrad appends colsum(dY) to every split, and the two gradient
+        # tensors are adjacent in the flat buffer ([ln_p.weight | ln_p.bias])
+        dWp, ns2 = ops.wgrad(dY, x, MODE_SHARED, BT, N, colsum_a=True)
+        gwb = torch.as_strided(gw, (1, C * C + C), (C * C + C, 1))
+        ops.poolgen_bwd_pool(_ones(dev), dWp, gwb, nsplit=ns2)
+    else:
+        dWp, ns2 = ops.wgrad(dY, x, MODE_SHARED, BT, N)
+        ops.poolgen_bwd_pool(_ones(dev), dWp, gw.view(1, C * C), nsplit=ns2)
+        ops.rowouter(None, 0, 0, dY, None, 0, csum=gb)
     return dx
+
+
+_ONES = {}
+
+
+def _ones(dev):
+    if dev not in _ONES:
+        _ONES[dev] = torch.ones(1, 1, device=dev)
+    return _ONES[dev]
 
 
 # ---- LReLU(x W_g + b_g) with generated weights, no residual (MLP_RL, GPTST.py:24-32) --------------------------------
@@ -118,7 +170,7 @@ def condlin_fwd(x, emb, wpool, bpool, mode, dims):
 def condlin_bwd(saved, dout, emb, wpool, bpool, g_wpool, g_bpool, d_emb, mode, dims):
     B, T, N, C = dims
     x, out, Wg = saved
-    db = torch.zeros(emb.shape[0], C, device=x.device)
+    db = _zeros(x, emb.shape[0], C)
     dx = ops.apply(dout, Wg, mode, B * T, N, A2=out, transw=True, pro=PRO_DPRE, colsum=db)
     dW, ns = ops.wgrad(x, dout, mode, B * T, N, D2=out, pro=PRO_DPRE)
     ops.poolgen_bwd_pool(emb, dW, g_wpool, db, g_bpool, nsplit=ns)
@@ -148,7 +200,7 @@ def sthcn_bwd(p, g, pfx, tidx, sv, dout, dims):
     time_eb, teb, tes = sv["emb"]
     ne, nes = p[pfx + "node_embeddings"], p[pfx + "node_embeddings_spg"]
     dne, dnes = g[pfx + "node_embeddings"], g[pfx + "node_embeddings_spg"]
-    d_te, d_teb, d_tes = torch.zeros_like(time_eb), torch.zeros_like(teb), torch.zeros_like(tes)
+    d_te, d_teb, d_tes = _zeros(time_eb, *time_eb.shape), _zeros(teb, *teb.shape), _zeros(tes, *tes.shape)
     d = hypertem_bwd(p, g, pfx + "hyperTem4.", sv["h4"], dout, ne, time_eb, dne, d_te, dims)
     d = cap_bwd(p, g, pfx + "cap2.", sv["c2"], d, nes, tes, teb, dnes, d_tes, d_teb, dims)
     d = hypertem_bwd(p, g, pfx + "hyperTem3.", sv["h3"], d, ne, time_eb, dne, d_te, dims)
@@ -181,7 +233,7 @@ def guide_bwd(p, g, source, tidx, saved, dlogit, dims, base):
     HS = dlogit.shape[1]
     dh2 = ops.lin_in(dlogit, HS, HS, p[m + "ln3.weight"], None, C, wlayout=1)
     ops.rowouter(dlogit, HS, HS, h2, g[m + "ln3.weight"], 1, asum=g[m + "ln3.bias"])
-    d_t4m = torch.zeros_like(t4m)
+    d_t4m = _zeros(t4m, *t4m.shape)
     dh1 = condlin_bwd(s2, dh2, t4m, p[m + "weights_pool_tem"], p[m + "bias_pool_tem"], g[m + "weights_pool_tem"],
                       g[m + "bias_pool_tem"], d_t4m, MODE_TIME, dims)
     dh0 = condlin_bwd(s1, dh1, p["encoder.neb4mask"], p[m + "weights_pool_spa"], p[m + "bias_pool_spa"],

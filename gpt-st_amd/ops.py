@@ -90,14 +90,18 @@ def wgrad_nsplit(mode, BT, N):
     return _C.lib().value("gptst_wgrad_nsplit", mode, BT, N)
 
 
-def wgrad(A, D, mode, BT, N, D2=None, pro=PRO_NONE):
-    """-> (dW (nsplit*G, C, C), nsplit)."""
+def wgrad(A, D, mode, BT, N, D2=None, pro=PRO_NONE, colsum_a=False):
+    """-> (dW (nsplit*G, C, C), nsplit);  colsum_a: rows become [dW (C*C) | column sums of A (C)]."""
     _chk(A, D, D2)
     C = A.shape[-1]
     ns = wgrad_nsplit(mode, BT, N)
     G = BT if mode == MODE_TIME else (N if mode == MODE_NODE else 1)
-    dW = torch.empty(ns * G, C, C, device=A.device, dtype=torch.float32)
-    _call("gptst_wgrad", _p(A), _p(D), _p(D2), _p(dW), mode, pro, BT, N, C, tag="mode%d pro%d" % (mode, pro), nbytes=_nb(A, D, D2, dW))
+    if colsum_a:
+        dW = torch.empty(ns * G, C * C + C, device=A.device, dtype=torch.float32)
+        _call("gptst_wgrad_colsum", _p(A), _p(D), _p(D2), _p(dW), mode, pro, BT, N, C, tag="mode%d pro%d cs" % (mode, pro), nbytes=_nb(A, D, D2, dW))
+    else:
+        dW = torch.empty(ns * G, C, C, device=A.device, dtype=torch.float32)
+        _call("gptst_wgrad", _p(A), _p(D), _p(D2), _p(dW), mode, pro, BT, N, C, tag="mode%d pro%d" % (mode, pro), nbytes=_nb(A, D, D2, dW))
     return dW, ns
 
 

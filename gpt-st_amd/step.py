@@ -45,6 +45,7 @@ class PretrainStep:
         self.rng = random.Random(seed)
         self.graphs = {}
         self.inject_noise = False
+        self.arena = engine.ZeroArena(self.dev)
 
     # ---- the enqueued work ---------------------------------------------------------------------------------------
     def _fwd_bwd(self, phase):
@@ -52,6 +53,8 @@ class PretrainStep:
         a = self.args
         M = self.B * self.T * self.N
         self.gbuf.zero_()
+        engine.ARENA = self.arena
+        self.arena.begin()
         src = self.src
         tidx = src[:, :, 0, base:base + 2].contiguous()
         prob, sv_g = engine.guide_fwd(p, src, tidx, dims, base)
@@ -78,6 +81,7 @@ class PretrainStep:
         if phase == 1:
             dlogit = ops.kl(prob, c1, self.N, 0.1, self.stats)
             engine.guide_bwd(p, g, src, tidx, sv_g, dlogit, dims, base)
+        engine.ARENA = None
 
     def _optim(self):
         ops.clip_adam(self.model.flat, self.gflat, self.m, self.v, self.model.nA, self.model.nB, self.hyper, self.stats)

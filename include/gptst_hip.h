@@ -56,6 +56,9 @@ int gptst_apply(const float* A, const float* A2, const float* W, int w_per_group
 int gptst_wgrad_nsplit(int mode, int BT, int N);
 int gptst_wgrad(const float* A, const float* D, const float* D2, float* dW, int mode, int pro, int BT, int N, int C,
                 void* stream);
+/* same, with the column sums of A appended to every split (rows of C*C + C floats): weight AND bias gradient of a shared Linear */
+int gptst_wgrad_colsum(const float* A, const float* D, const float* D2, float* dW, int mode, int pro, int BT, int N, int C,
+                       void* stream);
 
 /* ---- per-node temporal hypergraph of hyperTem (tmix.hip), GPTST.py:156-158 -----------------------------
  * A (N,Hm,T) = node_emb . adj (via poolgen);  G[n] = A[n]^T A[n] (T x T);  ret[b,:,n,:] = G[n] X[b,:,n,:]. */
