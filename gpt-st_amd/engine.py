@@ -76,9 +76,13 @@ def hypertem_fwd(p, pfx, x, node_emb, time_eb, dims):
     d, Hm = adj.shape[0], adj.shape[1]
     A = ops.poolgen(node_emb, adj.view(d, Hm * T)).view(N, Hm, T)                       # :156
     G = ops.gram_fwd(A)
-    R = ops.tmix(x.view(B, T, N, C), G).view(-1, C)                                     # :157-158
     Wbt, bbt = ops.poolgen(time_eb, wpool, bpool)                                       # :160-161
-    out = ops.apply(R, Wbt, MODE_TIME, B * T, N, bias=bbt, resid=x, epi=EPI_RES_LRELU)  # :162-163
+    if C == 64:
+        R, out = ops.hypertem_fwd(x.view(B, T, N, C), G, Wbt, bbt)                      # :157-158 + :162-163 fused
+        R, out = R.view(-1, C), out.view(-1, C)
+    else:
+        R = ops.tmix(x.view(B, T, N, C), G).view(-1, C)                                 # :157-158
+        out = ops.apply(R, Wbt, MODE_TIME, B * T, N, bias=bbt, resid=x, epi=EPI_RES_LRELU)  # :162-163
     return out, (x, R, out, A, G, Wbt)
 
 

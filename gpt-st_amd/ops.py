@@ -129,6 +129,16 @@ def tmix(X, G, dOut=None, Y=None):
     return out
 
 
+def hypertem_fwd(X, G, Wbt, bbt):
+    """Fused hyperTem forward -> (R, out), both (B,T,N,C)."""
+    _chk(X, G, Wbt, bbt)
+    B, T, N, C = X.shape
+    R = torch.empty_like(X)
+    out = torch.empty_like(X)
+    _call("gptst_hypertem_fwd", _p(X), _p(G), _p(Wbt), _p(bbt), _p(R), _p(out), B, T, N, C, nbytes=_nb(X, G, Wbt, bbt, R, out))
+    return R, out
+
+
 def tmix_dgraph(dR, X):
     _chk(dR, X)
     B, T, N, C = X.shape

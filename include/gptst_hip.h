@@ -70,6 +70,11 @@ int gptst_tmix(const float* X, const float* G, const float* dOut, const float* Y
 /* dG[n,t,u] = sum_{b,c} dR[b,t,n,c] X[b,u,n,c]   (fp32 MFMA 16x16x4). */
 int gptst_tmix_dgraph(const float* dR, const float* X, float* dG, int B, int T, int N, int C, void* stream);
 
+/* fused hyperTem forward (hypertem.hip): R = G (*) X (saved for the weight gradient), out = LReLU(R W_bt + b_bt + X);
+ * one workgroup per (sample, 16 nodes), MFMA 16x16x4 with W_bt read from L2.  C = 64. */
+int gptst_hypertem_fwd(const float* X, const float* G, const float* Wbt, const float* bbt, float* R_out, float* out, int B, int T,
+                       int N, int C, void* stream);
+
 /* ---- cap: node x cluster soft assignment + routing + aggregation (cap.hip, cap_cross.hip), GPTST.py:100-141 ----
  * route_fwd, one workgroup per (b,t):  P = squash(X Wp^T + bp) by MFMA into LDS; dadj (BT,HS,N) = teb.adj (from gptst_poolgen_fwd);
  *   v0 = squash(softmax_h(dadj) P);  R x { c = softmax_h(b); v = squash(v0 (.) c P); b += v P^T }  (both contractions on MFMA 16x16x4);
