@@ -125,7 +125,7 @@ def main():
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     dp = None
-    if world > 1:
+    if world > 1 or os.environ.get("GPTST_FORCE_DP") == "1":      # FORCE_DP: exercise the RCCL path with one rank
         from gptst_amd.dist import DataParallel
         dp = DataParallel("nccl")
 

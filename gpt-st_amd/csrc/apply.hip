@@ -143,7 +143,7 @@ __global__ __launch_bounds__(256) void wgrad64_kernel(const float* __restrict__ 
         for (int b = 0; b < 2; ++b)
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
-    constexpr int U = 4;
+    constexpr int U = 8;                               // 8 k-steps = 48 operand loads in flight per wave (memory-latency bound otherwise)
     for (int m0 = mbeg; m0 < mend; m0 += 2 * U) {
         float a0[U], a1[U], d0[U], d1[U];
 #pragma unroll

@@ -4,7 +4,8 @@
 // (GPTST.py:24-25,29-30,137-138,160-161), einsum('btd,dhn->bthn') (:104), einsum('bd,dhk->bhk') (:129) and
 // einsum('nk,kht->nht') (:156): a skinny GEMM (R rows <= a few hundred, K <= 16, up to C*C columns).  It is HBM/L2
 // bound on the R x cols operand, so it runs on the VALU with coalesced float4 columns; the two gradient reductions are here
-// too.  Every kernel takes an optional second (pool2, cols2) problem sharing emb (weights_pool + bias_pool in one launch).
+// too.  Every kernel takes up to PG_MAXP problems that share emb (weights_pool + bias_pool of several layers in ONE launch:
+// each launch has a ~4-5 us latency floor on this GPU, so per-layer launches are batched per STHCN).
 //
 // Gradient kernels are written around ONE rule learnt from the first profile (profiles/r01a): global atomics are only cheap
 // when few land on the same address (a same-address atomic serialises at ~80 ns) and when there are few of them overall —
@@ -20,44 +21,57 @@ template <> __device__ __forceinline__ float4 ldv<1>(const float* p) { return ma
 template <int V> __device__ __forceinline__ void stv(float* p, float4 v) { st4(p, v); }
 template <> __device__ __forceinline__ void stv<1>(float* p, float4 v) { *p = v.x; }
 
-// grid: (ceil(cols/V/256) + ceil(cols2/V/256), ceil(R/PG_ROWS))
-template <int V>
-__global__ __launch_bounds__(256) void poolgen_fwd_kernel(const float* __restrict__ emb, const float* __restrict__ pool,
-                                                          float* __restrict__ out, int cols, const float* __restrict__ pool2,
-                                                          float* __restrict__ out2, int cols2, int R, int K, int nblk1) {
-    int bx = blockIdx.x;
-    if (bx >= nblk1) { bx -= nblk1; pool = pool2; out = out2; cols = cols2; }
-    const int c4 = bx * 256 + threadIdx.x;
-    if (V * c4 >= cols) return;
-    float4 p[PG_MAXK];
+#define PG_MAXP 8
+struct PgFwd { const float* pool[PG_MAXP]; float* out[PG_MAXP]; int cols[PG_MAXP]; int blk0[PG_MAXP + 1]; int n; };
+struct PgBwd {
+    const float* dW[PG_MAXP]; const float* pool[PG_MAXP]; float* dpool[PG_MAXP];
+    int cols[PG_MAXP]; int nsplit[PG_MAXP]; int blk0[PG_MAXP + 1]; int n;
+};
+template <class A> __device__ __forceinline__ int pg_find(const A& a, int bx) {
+    int p = 0;
 #pragma unroll
-    for (int k = 0; k < PG_MAXK; ++k) p[k] = (k < K) ? ldv<V>(pool + (size_t)k * cols + V * c4) : f4zero();
+    for (int q = 1; q < PG_MAXP; ++q) if (q < a.n && bx >= a.blk0[q]) p = q;
+    return p;
+}
+
+// out_p[r, :] = sum_k emb[r,k] pool_p[k, :].   grid: (sum_p ceil(cols_p/V/256), ceil(R/PG_ROWS))
+template <int V>
+__global__ __launch_bounds__(256) void poolgen_fwd_kernel(const float* __restrict__ emb, PgFwd a, int R, int K) {
+    const int p = pg_find(a, blockIdx.x);
+    const float* __restrict__ pool = a.pool[p];
+    float* __restrict__ out = a.out[p];
+    const int cols = a.cols[p];
+    const int c4 = (blockIdx.x - a.blk0[p]) * 256 + threadIdx.x;
+    if (V * c4 >= cols) return;
+    float4 pv[PG_MAXK];
+#pragma unroll
+    for (int k = 0; k < PG_MAXK; ++k) pv[k] = (k < K) ? ldv<V>(pool + (size_t)k * cols + V * c4) : f4zero();
     const int r0 = blockIdx.y * PG_ROWS;
 #pragma unroll 1
     for (int r = r0; r < min(R, r0 + PG_ROWS); ++r) {
         float4 acc = f4zero();
 #pragma unroll
         for (int k = 0; k < PG_MAXK; ++k)
-            if (k < K) acc = f4fma(emb[(size_t)r * K + k], p[k], acc);
+            if (k < K) acc = f4fma(emb[(size_t)r * K + k], pv[k], acc);
         stv<V>(out + (size_t)r * cols + V * c4, acc);
     }
 }
 
-// dpool[k, c] += sum_rr emb[rr % R, k] * dW[rr, c]   (rr < R*nsplit for problem 1 — wgrad's K-splits —, rr < R for problem 2)
+// dpool_p[k, c] += sum_rr emb[rr % R, k] * dW_p[rr, c]   (rr < R*nsplit_p: wgrad's K-splits are summed here)
 // on fp32 MFMA 16x16x4:  D[i = k][j] += A[i][kk] B[kk][j],  A = emb[row][k],  B = dW[row][col];  lane (kk = l>>4, j = l&15).
 // V = 4: a lane fetches the float4 dW[row+kk][c0 + 4j ..] (the four lane groups read four consecutive rows, 256 B each) and
 // component e feeds column tile e (columns c0 + 4j + e), so one load drives 4 MFMAs and a wave owns a 64-column slab.
 // The reduction over rows happens inside the MFMA; a workgroup's 4 waves take 4 row chunks of the slab and every output
-// gets g_pg_nchunk atomics in total.   grid: (slabs of problem 1 + slabs of problem 2, ceil(nchunk / 4))
+// gets g_pg_nchunk atomics in total.   grid: (sum_p slabs_p, ceil(nchunk / 4))
 int g_pg_nchunk = 4;
 template <int V>
-__global__ __launch_bounds__(256) void poolgen_bwd_pool_kernel(const float* __restrict__ emb, const float* __restrict__ dW,
-                                                               float* __restrict__ dpool, int cols, const float* __restrict__ dW2,
-                                                               float* __restrict__ dpool2, int cols2, int R, int RR, int K,
-                                                               int nblk1, int nchunk) {
+__global__ __launch_bounds__(256) void poolgen_bwd_pool_kernel(const float* __restrict__ emb, PgBwd a, int R, int K, int nchunk) {
     constexpr int SLAB = 16 * V;
-    int bx = blockIdx.x;
-    if (bx >= nblk1) { bx -= nblk1; dW = dW2; dpool = dpool2; cols = cols2; RR = R; }   // splits apply to problem 1 only
+    const int p = pg_find(a, blockIdx.x);
+    const float* __restrict__ dW = a.dW[p];
+    float* __restrict__ dpool = a.dpool[p];
+    const int cols = a.cols[p], RR = R * a.nsplit[p];
+    const int bx = blockIdx.x - a.blk0[p];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int j = lane & 15, kk = lane >> 4;
     const int chunk = blockIdx.y * 4 + wave;
@@ -71,24 +85,24 @@ __global__ __launch_bounds__(256) void poolgen_bwd_pool_kernel(const float* __re
 #pragma unroll
     for (int e = 0; e < V; ++e) acc[e] = (f32x4){0.f, 0.f, 0.f, 0.f};
     for (int rb = r0; rb < r1; rb += 16) {
-        float a[4];
+        float av[4];
         float4 b[4];
 #pragma unroll
         for (int u = 0; u < 4; ++u) {
             const int row = rb + 4 * u + kk;
-            a[u] = 0.f; b[u] = f4zero();
+            av[u] = 0.f; b[u] = f4zero();
             if (row < r1) {
-                if (j < K) a[u] = emb[(size_t)(row % R) * K + j];
+                if (j < K) av[u] = emb[(size_t)(row % R) * K + j];
                 if (cok) b[u] = ldv<V>(dW + (size_t)row * cols + c);
             }
         }
 #pragma unroll
         for (int u = 0; u < 4; ++u) {
-            acc[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[u], b[u].x, acc[0], 0, 0, 0);
+            acc[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[u], b[u].x, acc[0], 0, 0, 0);
             if (V == 4) {
-                acc[V > 1 ? 1 : 0] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[u], b[u].y, acc[V > 1 ? 1 : 0], 0, 0, 0);
-                acc[V > 2 ? 2 : 0] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[u], b[u].z, acc[V > 2 ? 2 : 0], 0, 0, 0);
-                acc[V > 3 ? 3 : 0] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[u], b[u].w, acc[V > 3 ? 3 : 0], 0, 0, 0);
+                acc[V > 1 ? 1 : 0] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[u], b[u].y, acc[V > 1 ? 1 : 0], 0, 0, 0);
+                acc[V > 2 ? 2 : 0] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[u], b[u].z, acc[V > 2 ? 2 : 0], 0, 0, 0);
+                acc[V > 3 ? 3 : 0] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[u], b[u].w, acc[V > 3 ? 3 : 0], 0, 0, 0);
             }
         }
     }
@@ -103,53 +117,47 @@ __global__ __launch_bounds__(256) void poolgen_bwd_pool_kernel(const float* __re
     }
 }
 
-// demb[r, k] += sum_split sum_c dW[split*R + r, c] * pool[k, c]  (+ second problem, no splits)  on fp32 MFMA 16x16x4:
+// demb[r, k] += sum_p sum_split sum_c dW_p[split*R + r, c] * pool_p[k, c]   on fp32 MFMA 16x16x4:
 // D[i = row][j = k] += A[i][kk] B[kk][j] with A = dW[row0+i][c], B = pool[j][c]; lane (kk = l>>4, i = l&15) fetches
 // float4s at c + 4kk so one load pair feeds four MFMA steps (the usual k-permutation); the MFMA does the reduction over the
-// columns that a VALU version would have to do with cross-lane shuffles.  A wave owns (16-row tile, column chunk).
-// grid: (ceil(R/16), column chunks / 4); 4 waves = 4 column chunks per workgroup.
+// columns that a VALU version would have to do with cross-lane shuffles.  A wave owns (16-row tile, column chunk of one problem).
+// grid: (ceil(R/16), ceil(total chunks / 4)); blk0[] counts chunks here.
 template <int V>
-__global__ __launch_bounds__(256) void poolgen_bwd_emb_kernel(const float* __restrict__ dW, const float* __restrict__ pool, int cols,
-                                                              const float* __restrict__ dW2, const float* __restrict__ pool2,
-                                                              int cols2, float* __restrict__ demb, int R, int nsplit, int K,
-                                                              int chunk_cols) {
+__global__ __launch_bounds__(256) void poolgen_bwd_emb_kernel(PgBwd a, float* __restrict__ demb, int R, int K, int chunk_cols) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int i = lane & 15, kk = lane >> 4;
     const int row = blockIdx.x * 16 + i;
-    const int ch = blockIdx.y * 4 + wave;
+    const int gch = blockIdx.y * 4 + wave;
+    if (gch >= a.blk0[a.n]) return;
+    const int p = pg_find(a, gch);
+    const float* __restrict__ w = a.dW[p];
+    const float* __restrict__ pl = a.pool[p];
+    const int cc = a.cols[p], ns = a.nsplit[p];
+    const int cbeg = (gch - a.blk0[p]) * chunk_cols, cend = min(cc, cbeg + chunk_cols);
     f32x4 acc = {0.f, 0.f, 0.f, 0.f};
-    for (int pb = 0; pb < 2; ++pb) {
-        const float* w = pb ? dW2 : dW;
-        const float* p = pb ? pool2 : pool;
-        const int cc = pb ? cols2 : cols;
-        const int ns = pb ? 1 : nsplit;              // splits apply to problem 1 only
-        if (w == nullptr) continue;                  // uniform
-        const int cbeg = pb ? (ch == 0 ? 0 : cc) : ch * chunk_cols;            // the small second problem goes to chunk 0
-        const int cend = pb ? cc : min(cc, cbeg + chunk_cols);
-        if (V == 4) {
-            for (int c = cbeg + 4 * kk; c < cend + 4 * kk; c += 16) {           // same trip count for the 4 lane groups
-                float4 a = f4zero(), b = f4zero();
-                if (c < cend) {
-                    if (row < R) {
-                        a = ld4(w + (size_t)row * cc + c);
-                        for (int s = 1; s < ns; ++s) a = f4add(a, ld4(w + ((size_t)s * R + row) * cc + c));
-                    }
-                    if (i < K) b = ld4(p + (size_t)i * cc + c);
+    if (V == 4) {
+        for (int c = cbeg + 4 * kk; c < cend + 4 * kk; c += 16) {           // same trip count for the 4 lane groups
+            float4 av = f4zero(), b = f4zero();
+            if (c < cend) {
+                if (row < R) {
+                    av = ld4(w + (size_t)row * cc + c);
+                    for (int s = 1; s < ns; ++s) av = f4add(av, ld4(w + ((size_t)s * R + row) * cc + c));
                 }
-                acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a.x, b.x, acc, 0, 0, 0);
-                acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a.y, b.y, acc, 0, 0, 0);
-                acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a.z, b.z, acc, 0, 0, 0);
-                acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a.w, b.w, acc, 0, 0, 0);
+                if (i < K) b = ld4(pl + (size_t)i * cc + c);
             }
-        } else {
-            for (int c = cbeg + kk; c < cend + kk; c += 4) {
-                float a = 0.f, b = 0.f;
-                if (c < cend) {
-                    if (row < R) for (int s = 0; s < ns; ++s) a += w[((size_t)s * R + row) * cc + c];
-                    if (i < K) b = p[(size_t)i * cc + c];
-                }
-                acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_16x16x4f32(av.x, b.x, acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_16x16x4f32(av.y, b.y, acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_16x16x4f32(av.z, b.z, acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_16x16x4f32(av.w, b.w, acc, 0, 0, 0);
+        }
+    } else {
+        for (int c = cbeg + kk; c < cend + kk; c += 4) {
+            float av = 0.f, b = 0.f;
+            if (c < cend) {
+                if (row < R) for (int s = 0; s < ns; ++s) av += w[((size_t)s * R + row) * cc + c];
+                if (i < K) b = pl[(size_t)i * cc + c];
             }
+            acc = __builtin_amdgcn_mfma_f32_16x16x4f32(av, b, acc, 0, 0, 0);
         }
     }
 #pragma unroll
@@ -159,53 +167,102 @@ __global__ __launch_bounds__(256) void poolgen_bwd_emb_kernel(const float* __res
     }
 }
 
-extern "C" int gptst_poolgen_fwd(const float* emb, const float* pool, float* out, int cols, const float* pool2, float* out2,
-                                 int cols2, int R, int K, void* stream) {
-    if (!emb || !pool || !out || K > PG_MAXK || K <= 0) return GPTST_EARG;
-    if (!pool2) cols2 = 0;
-    const int V = ((cols & 3) || (cols2 & 3)) ? 1 : 4;
-    const int nb1 = ((cols + V - 1) / V + 255) / 256, nb2 = pool2 ? ((cols2 + V - 1) / V + 255) / 256 : 0;
-    dim3 grid(nb1 + nb2, (R + PG_ROWS - 1) / PG_ROWS);
-    if (V == 4) hipLaunchKernelGGL(poolgen_fwd_kernel<4>, grid, dim3(256), 0, (hipStream_t)stream, emb, pool, out, cols, pool2, out2, cols2, R, K, nb1);
-    else hipLaunchKernelGGL(poolgen_fwd_kernel<1>, grid, dim3(256), 0, (hipStream_t)stream, emb, pool, out, cols, pool2, out2, cols2, R, K, nb1);
-    GPTST_CHECK_LAUNCH();
-    return GPTST_OK;
-}
-
 extern "C" int gptst_tune(int id, int value) {
     if (id == 1) g_pg_nchunk = value;
     return GPTST_OK;
 }
 
-extern "C" int gptst_poolgen_bwd_pool(const float* emb, const float* dW, float* dpool, int cols, const float* dW2, float* dpool2,
-                                      int cols2, int R, int nsplit, int K, void* stream) {
-    if (!emb || !dW || !dpool || K > PG_MAXK || K <= 0) return GPTST_EARG;
-    if (!dW2) cols2 = 0;
-    const int V = ((cols & 3) || (cols2 & 3)) ? 1 : 4;
-    const int RR = R * nsplit;
-    const int slab = 16 * V;
-    const int nb1 = (cols + slab - 1) / slab, nb2 = dW2 ? (cols2 + slab - 1) / slab : 0;
-    int nchunk = g_pg_nchunk;                            // row chunks = atomics per output element
-    if (nchunk * 16 > RR) nchunk = (RR + 15) / 16;
-    if (nchunk < 1) nchunk = 1;
-    dim3 grid(nb1 + nb2, (nchunk + 3) / 4);
-    if (V == 4) hipLaunchKernelGGL(poolgen_bwd_pool_kernel<4>, grid, dim3(256), 0, (hipStream_t)stream, emb, dW, dpool, cols, dW2, dpool2, cols2, R, RR, K, nb1, nchunk);
-    else hipLaunchKernelGGL(poolgen_bwd_pool_kernel<1>, grid, dim3(256), 0, (hipStream_t)stream, emb, dW, dpool, cols, dW2, dpool2, cols2, R, RR, K, nb1, nchunk);
+static int pg_vec(int n, const int* cols) {
+    for (int p = 0; p < n; ++p) if (cols[p] & 3) return 1;
+    return 4;
+}
+
+extern "C" int gptst_poolgen_fwd_multi(const float* emb, int nprob, const void* pools, const void* outs, const int* cols, int R, int K,
+                                       void* stream) {
+    if (!emb || !pools || !outs || !cols || nprob <= 0 || nprob > PG_MAXP || K > PG_MAXK || K <= 0) return GPTST_EARG;
+    const int V = pg_vec(nprob, cols);
+    PgFwd a; a.n = nprob; a.blk0[0] = 0;
+    for (int p = 0; p < nprob; ++p) {
+        a.pool[p] = ((const float* const*)pools)[p]; a.out[p] = ((float* const*)outs)[p]; a.cols[p] = cols[p];
+        if (!a.pool[p] || !a.out[p] || cols[p] <= 0) return GPTST_EARG;
+        a.blk0[p + 1] = a.blk0[p] + ((cols[p] + V - 1) / V + 255) / 256;
+    }
+    dim3 grid(a.blk0[nprob], (R + PG_ROWS - 1) / PG_ROWS);
+    if (V == 4) hipLaunchKernelGGL(poolgen_fwd_kernel<4>, grid, dim3(256), 0, (hipStream_t)stream, emb, a, R, K);
+    else hipLaunchKernelGGL(poolgen_fwd_kernel<1>, grid, dim3(256), 0, (hipStream_t)stream, emb, a, R, K);
     GPTST_CHECK_LAUNCH();
     return GPTST_OK;
 }
 
-extern "C" int gptst_poolgen_bwd_emb(const float* dW, const float* pool, int cols, const float* dW2, const float* pool2, int cols2,
-                                     float* demb, int R, int nsplit, int K, void* stream) {
-    if (!dW || !pool || !demb || K > PG_MAXK || K <= 0) return GPTST_EARG;
-    if (!dW2) cols2 = 0;
-    const int V = ((cols & 3) || (cols2 & 3)) ? 1 : 4;
-    int chunk = 256;                                     // columns per wave: 16 MFMA load pairs
-    int nch = (cols + chunk - 1) / chunk;
-    nch = (nch + 3) / 4 * 4;
-    dim3 grid((R + 15) / 16, nch / 4);
-    if (V == 4) hipLaunchKernelGGL(poolgen_bwd_emb_kernel<4>, grid, dim3(256), 0, (hipStream_t)stream, dW, pool, cols, dW2, pool2, cols2, demb, R, nsplit, K, chunk);
-    else hipLaunchKernelGGL(poolgen_bwd_emb_kernel<1>, grid, dim3(256), 0, (hipStream_t)stream, dW, pool, cols, dW2, pool2, cols2, demb, R, nsplit, K, chunk);
+static int pg_fill_bwd(PgBwd& a, int nprob, const void* dWs, const void* pools, const void* dpools, const int* cols, const int* nsplit) {
+    a.n = nprob;
+    for (int p = 0; p < nprob; ++p) {
+        a.dW[p] = ((const float* const*)dWs)[p];
+        a.pool[p] = pools ? ((const float* const*)pools)[p] : nullptr;
+        a.dpool[p] = dpools ? ((float* const*)dpools)[p] : nullptr;
+        a.cols[p] = cols[p]; a.nsplit[p] = nsplit ? nsplit[p] : 1;
+        if (!a.dW[p] || cols[p] <= 0 || a.nsplit[p] <= 0) return GPTST_EARG;
+    }
+    return GPTST_OK;
+}
+
+extern "C" int gptst_poolgen_bwd_pool_multi(const float* emb, int nprob, const void* dWs, const void* dpools, const int* cols,
+                                            const int* nsplit, int R, int K, void* stream) {
+    if (!emb || !dWs || !dpools || !cols || nprob <= 0 || nprob > PG_MAXP || K > PG_MAXK || K <= 0) return GPTST_EARG;
+    const int V = pg_vec(nprob, cols);
+    PgBwd a;
+    if (pg_fill_bwd(a, nprob, dWs, nullptr, dpools, cols, nsplit)) return GPTST_EARG;
+    a.blk0[0] = 0;
+    int minrr = 1 << 30;
+    for (int p = 0; p < nprob; ++p) {
+        if (!a.dpool[p]) return GPTST_EARG;
+        a.blk0[p + 1] = a.blk0[p] + (cols[p] + 16 * V - 1) / (16 * V);
+        if (R * a.nsplit[p] < minrr) minrr = R * a.nsplit[p];
+    }
+    int nchunk = g_pg_nchunk;                            // row chunks = atomics per output element
+    if (nchunk * 16 > minrr) nchunk = (minrr + 15) / 16;
+    if (nchunk < 1) nchunk = 1;
+    dim3 grid(a.blk0[nprob], (nchunk + 3) / 4);
+    if (V == 4) hipLaunchKernelGGL(poolgen_bwd_pool_kernel<4>, grid, dim3(256), 0, (hipStream_t)stream, emb, a, R, K, nchunk);
+    else hipLaunchKernelGGL(poolgen_bwd_pool_kernel<1>, grid, dim3(256), 0, (hipStream_t)stream, emb, a, R, K, nchunk);
     GPTST_CHECK_LAUNCH();
     return GPTST_OK;
+}
+
+extern "C" int gptst_poolgen_bwd_emb_multi(int nprob, const void* dWs, const void* pools, const int* cols, const int* nsplit, float* demb,
+                                           int R, int K, void* stream) {
+    if (!dWs || !pools || !cols || !demb || nprob <= 0 || nprob > PG_MAXP || K > PG_MAXK || K <= 0) return GPTST_EARG;
+    const int V = pg_vec(nprob, cols);
+    PgBwd a;
+    if (pg_fill_bwd(a, nprob, dWs, pools, nullptr, cols, nsplit)) return GPTST_EARG;
+    const int chunk = 256;                               // columns per wave: 16 MFMA load pairs
+    a.blk0[0] = 0;
+    for (int p = 0; p < nprob; ++p) {
+        if (!a.pool[p]) return GPTST_EARG;
+        a.blk0[p + 1] = a.blk0[p] + (cols[p] + chunk - 1) / chunk;
+    }
+    dim3 grid((R + 15) / 16, (a.blk0[nprob] + 3) / 4);
+    if (V == 4) hipLaunchKernelGGL(poolgen_bwd_emb_kernel<4>, grid, dim3(256), 0, (hipStream_t)stream, a, demb, R, K, chunk);
+    else hipLaunchKernelGGL(poolgen_bwd_emb_kernel<1>, grid, dim3(256), 0, (hipStream_t)stream, a, demb, R, K, chunk);
+    GPTST_CHECK_LAUNCH();
+    return GPTST_OK;
+}
+
+// ---- one / two problem convenience forms (thin wrappers) -----------------------------------------------------------
+extern "C" int gptst_poolgen_fwd(const float* emb, const float* pool, float* out, int cols, const float* pool2, float* out2,
+                                 int cols2, int R, int K, void* stream) {
+    const float* pools[2] = {pool, pool2}; float* outs[2] = {out, out2}; int cc[2] = {cols, cols2};
+    return gptst_poolgen_fwd_multi(emb, pool2 ? 2 : 1, pools, outs, cc, R, K, stream);
+}
+
+extern "C" int gptst_poolgen_bwd_pool(const float* emb, const float* dW, float* dpool, int cols, const float* dW2, float* dpool2,
+                                      int cols2, int R, int nsplit, int K, void* stream) {
+    const float* dWs[2] = {dW, dW2}; float* dps[2] = {dpool, dpool2}; int cc[2] = {cols, cols2}; int ns[2] = {nsplit, 1};
+    return gptst_poolgen_bwd_pool_multi(emb, dW2 ? 2 : 1, dWs, dps, cc, ns, R, K, stream);
+}
+
+extern "C" int gptst_poolgen_bwd_emb(const float* dW, const float* pool, int cols, const float* dW2, const float* pool2, int cols2,
+                                     float* demb, int R, int nsplit, int K, void* stream) {
+    const float* dWs[2] = {dW, dW2}; const float* pls[2] = {pool, pool2}; int cc[2] = {cols, cols2}; int ns[2] = {nsplit, 1};
+    return gptst_poolgen_bwd_emb_multi(dW2 ? 2 : 1, dWs, pls, cc, ns, demb, R, K, stream);
 }

@@ -69,76 +69,55 @@ def timefeat_bwd(p, g, pfx, tidx, dout, spg=False):
 
 
 # ---- hyperTem (GPTST.py:154-163) -----------------------------------------------------------------------------------
-def hypertem_fwd(p, pfx, x, node_emb, time_eb, dims):
-    """x (BTN, C) rows; node_emb (N,d); time_eb (BT,d) -> out (BTN, C)."""
+# Parameter generation (A, G, W_bt, b_bt) and the gradient reductions into the pools / embeddings are batched per STHCN
+# (sthcn_fwd / sthcn_bwd below): one launch for all four hyperTem layers instead of one per layer.
+def hypertem_core_fwd(x, G, Wbt, bbt, dims):
+    """x (BTN, C) rows -> out (BTN, C);  G (N,T,T), Wbt (BT,C,C), bbt (BT,C) precomputed."""
     B, T, N, C = dims
-    adj, wpool, bpool = p[pfx + "adj"], p[pfx + "weights_pool"], p[pfx + "bias_pool"]
-    d, Hm = adj.shape[0], adj.shape[1]
-    A = ops.poolgen(node_emb, adj.view(d, Hm * T)).view(N, Hm, T)                       # :156
-    G = ops.gram_fwd(A)
-    Wbt, bbt = ops.poolgen(time_eb, wpool, bpool)                                       # :160-161
     if C == 64:
         R, out = ops.hypertem_fwd(x.view(B, T, N, C), G, Wbt, bbt)                      # :157-158 + :162-163 fused
         R, out = R.view(-1, C), out.view(-1, C)
     else:
         R = ops.tmix(x.view(B, T, N, C), G).view(-1, C)                                 # :157-158
         out = ops.apply(R, Wbt, MODE_TIME, B * T, N, bias=bbt, resid=x, epi=EPI_RES_LRELU)  # :162-163
-    return out, (x, R, out, A, G, Wbt)
+    return out, (x, R, out, G, Wbt)
 
 
-def hypertem_bwd(p, g, pfx, saved, dout, node_emb, time_eb, d_node_emb, d_time_eb, dims):
+def hypertem_core_bwd(saved, dout, dG_out, dims):
+    """-> dx, (dWbt, nsplit, dbias); dG is written into dG_out (N,T,T)."""
     B, T, N, C = dims
-    x, R, out, A, G, Wbt = saved
-    adj, wpool, bpool = p[pfx + "adj"], p[pfx + "weights_pool"], p[pfx + "bias_pool"]
-    d, Hm = adj.shape[0], adj.shape[1]
+    x, R, out, G, Wbt = saved
     BT = B * T
     dbias = _zeros(x, BT, C)
     dR = ops.apply(dout, Wbt, MODE_TIME, BT, N, A2=out, transw=True, pro=PRO_DPRE, colsum=dbias)
     dWbt, ns = ops.wgrad(R, dout, MODE_TIME, BT, N, D2=out, pro=PRO_DPRE)
-    ops.poolgen_bwd_pool(time_eb, dWbt, g[pfx + "weights_pool"], dbias, g[pfx + "bias_pool"], nsplit=ns)
-    ops.poolgen_bwd_emb(dWbt, wpool, d_time_eb, dbias, bpool, nsplit=ns)
     dx = ops.tmix(dR.view(B, T, N, C), G, dOut=dout.view(B, T, N, C), Y=out.view(B, T, N, C)).view(-1, C)
-    dG = ops.tmix_dgraph(dR.view(B, T, N, C), x.view(B, T, N, C))
-    dA = ops.gram_bwd(A, dG)
-    ops.poolgen_bwd_pool(node_emb, dA, g[pfx + "adj"])
-    ops.poolgen_bwd_emb(dA, adj, d_node_emb)
-    return dx
+    ops.tmix_dgraph(dR.view(B, T, N, C), x.view(B, T, N, C), out=dG_out)
+    return dx, (dWbt, ns, dbias)
 
 
 # ---- cap (GPTST.py:100-141) ----------------------------------------------------------------------------------------
-def cap_fwd(p, pfx, x, node_emb, tes, teb, dims, num_route):
-    """x (BTN,C); node_emb (N,d); tes (B,ds); teb (BT,ds) -> out (BTN,C), c (BT,HS,N), dyn (B,HT,T*HS)."""
+def cap_core_fwd(p, pfx, x, dadj, dyn, Wn, bn, dims, num_route, HS, HT):
+    """x (BTN,C); dadj (BT,HS*N), dyn (B,HT,T*HS), Wn (N,C,C), bn (N,C) precomputed -> out, c (BT,HS,N), saved."""
     B, T, N, C = dims
-    adj, t_adj = p[pfx + "adj"], p[pfx + "t_adj"]
-    ds, HS, HT = adj.shape[0], adj.shape[1], t_adj.shape[1]
-    dadj = ops.poolgen(teb, adj.view(ds, HS * N))                                                                        # :104
-    c, s = ops.cap_route_fwd(x.view(B, T, N, C), p[pfx + "ln_p.weight"], p[pfx + "ln_p.bias"], dadj, HS, num_route)         # :102-123
-    dyn = ops.poolgen(tes, t_adj.view(ds, HT * T * HS)).view(B, HT, T * HS)                                          # :129
+    c, s = ops.cap_route_fwd(x.view(B, T, N, C), p[pfx + "ln_p.weight"], p[pfx + "ln_p.bias"], dadj, HS, num_route)   # :102-123
     v, Ht, Rt = ops.cap_cross_fwd(s, dyn, p[pfx + "mask_template"], B, T, HS, HT)                                     # :125-134
     rec = ops.cap_rec_fwd(c, v, N, C)                                                                                 # :135
-    Wn, bn = ops.poolgen(node_emb, p[pfx + "weights_spa"], p[pfx + "bias_spa"])                                       # :137-138
     out = ops.apply(rec, Wn, MODE_NODE, B * T, N, bias=bn, resid=x, epi=EPI_RES_LRELU)                                # :139-141
-    return out, c, dyn, (x, out, rec, c, s, v, Ht, Rt, dyn, Wn)
+    return out, c, (x, out, rec, c, s, v, Ht, Rt, dyn, Wn)
 
 
-def cap_bwd(p, g, pfx, saved, dout, node_emb, tes, teb, d_node_emb, d_tes, d_teb, dims):
+def cap_core_bwd(p, g, pfx, saved, dout, dims, HS, HT):
+    """-> dx and the pieces whose reductions are batched by the caller: (dWn, nsplit, dbn, ddyn, dlogit)."""
     B, T, N, C = dims
     x, out, rec, c, s, v, Ht, Rt, dyn, Wn = saved
-    adj, t_adj = p[pfx + "adj"], p[pfx + "t_adj"]
-    ds, HS, HT = adj.shape[0], adj.shape[1], t_adj.shape[1]
     BT, dev = B * T, x.device
     dbn = _zeros(x, N, C)
     drec = ops.apply(dout, Wn, MODE_NODE, BT, N, A2=out, transw=True, pro=PRO_DPRE, colsum=dbn)
     dWn, ns = ops.wgrad(rec, dout, MODE_NODE, BT, N, D2=out, pro=PRO_DPRE)
-    ops.poolgen_bwd_pool(node_emb, dWn, g[pfx + "weights_spa"], dbn, g[pfx + "bias_spa"], nsplit=ns)
-    ops.poolgen_bwd_emb(dWn, p[pfx + "weights_spa"], d_node_emb, dbn, p[pfx + "bias_spa"], nsplit=ns)
     dc1, dv = ops.cap_rec_bwd(drec, c, v)
     dS, ddyn = ops.cap_cross_bwd(dv, s, Rt, Ht, dyn, p[pfx + "mask_template"], B, T, HS, HT)
-    ops.poolgen_bwd_pool(tes, ddyn, g[pfx + "t_adj"])
-    ops.poolgen_bwd_emb(ddyn, t_adj, d_tes)
     dY, dlogit = ops.cap_route_bwd(x.view(B, T, N, C), p[pfx + "ln_p.weight"], p[pfx + "ln_p.bias"], c, dc1, dS)
-    ops.poolgen_bwd_pool(teb, dlogit, g[pfx + "adj"])
-    ops.poolgen_bwd_emb(dlogit, adj, d_teb)
     dx = ops.apply(dY, p[pfx + "ln_p.weight"], MODE_SHARED, BT, N, resid=dout, resid2=out, epi=EPI_ADD_DPRE)
     gw, gb = g[pfx + "ln_p.weight"], g[pfx + "ln_p.bias"]
     if C == 64 and gb.data_ptr() == gw.data_ptr() + 4 * C * C:
@@ -151,7 +130,7 @@ def cap_bwd(p, g, pfx, saved, dout, node_emb, tes, teb, d_node_emb, d_tes, d_teb
         dWp, ns2 = ops.wgrad(dY, x, MODE_SHARED, BT, N)
         ops.poolgen_bwd_pool(_ones(dev), dWp, gw.view(1, C * C), nsplit=ns2)
         ops.rowouter(None, 0, 0, dY, None, 0, csum=gb)
-    return dx
+    return dx, (dWn, ns, dbn, ddyn, dlogit)
 
 
 _ONES = {}
@@ -189,32 +168,72 @@ def sthcn_fwd(p, pfx, tidx, x, dims, num_route):
     teb = timefeat_fwd(p, pfx + "time_feature1_.", tidx)                          # (BT,ds)  :260
     tes = timefeat_fwd(p, pfx + "time_feature2.", tidx, spg=True)                 # (B,ds)   :261
     ne, nes = p[pfx + "node_embeddings"], p[pfx + "node_embeddings_spg"]
+    hts = [pfx + "hyperTem%d." % i for i in (1, 2, 3, 4)]
+    cps = [pfx + "cap1.", pfx + "cap2."]
+    adj0 = p[hts[0] + "adj"]
+    d, Hm = adj0.shape[0], adj0.shape[1]
+    cadj, tadj = p[cps[0] + "adj"], p[cps[0] + "t_adj"]
+    ds, HS, HT = cadj.shape[0], cadj.shape[1], tadj.shape[1]
+    # ---- all generated parameters of the six layers: 5 launches + 1 gram (was 18) ----
+    A_all = torch.empty(4, N, Hm * T, device=x.device)
+    ops.poolgen_multi(ne, [p[h + "adj"].view(d, Hm * T) for h in hts], outs=[A_all[i] for i in range(4)])       # :156
+    G_all = ops.gram_fwd(A_all.view(4 * N, Hm, T)).view(4, N, T, T)
+    Wb = ops.poolgen_multi(time_eb, [t for h in hts for t in (p[h + "weights_pool"], p[h + "bias_pool"])])       # :160-161
+    Wn = ops.poolgen_multi(nes, [t for c in cps for t in (p[c + "weights_spa"], p[c + "bias_spa"])])             # :137-138
+    dadj = ops.poolgen_multi(teb, [p[c + "adj"].view(ds, HS * N) for c in cps])                                  # :104
+    dyn = [t.view(B, HT, T * HS) for t in ops.poolgen_multi(tes, [p[c + "t_adj"].view(ds, HT * T * HS) for c in cps])]   # :129
     sv = {}
-    x, sv["h1"] = hypertem_fwd(p, pfx + "hyperTem1.", x, ne, time_eb, dims)
-    x, c1, _, sv["c1"] = cap_fwd(p, pfx + "cap1.", x, nes, tes, teb, dims, num_route)
-    x, sv["h2"] = hypertem_fwd(p, pfx + "hyperTem2.", x, ne, time_eb, dims)
-    x, sv["h3"] = hypertem_fwd(p, pfx + "hyperTem3.", x, ne, time_eb, dims)
-    x, _, _, sv["c2"] = cap_fwd(p, pfx + "cap2.", x, nes, tes, teb, dims, num_route)
-    x, sv["h4"] = hypertem_fwd(p, pfx + "hyperTem4.", x, ne, time_eb, dims)
+    x, sv["h1"] = hypertem_core_fwd(x, G_all[0], Wb[0], Wb[1], dims)
+    x, c1, sv["c1"] = cap_core_fwd(p, cps[0], x, dadj[0], dyn[0], Wn[0], Wn[1], dims, num_route, HS, HT)
+    x, sv["h2"] = hypertem_core_fwd(x, G_all[1], Wb[2], Wb[3], dims)
+    x, sv["h3"] = hypertem_core_fwd(x, G_all[2], Wb[4], Wb[5], dims)
+    x, _, sv["c2"] = cap_core_fwd(p, cps[1], x, dadj[1], dyn[1], Wn[2], Wn[3], dims, num_route, HS, HT)
+    x, sv["h4"] = hypertem_core_fwd(x, G_all[3], Wb[6], Wb[7], dims)
     sv["emb"] = (time_eb, teb, tes)
+    sv["gen"] = (A_all, hts, cps, d, Hm, ds, HS, HT)
     return x, c1, sv
 
 
 def sthcn_bwd(p, g, pfx, tidx, sv, dout, dims):
+    B, T, N, C = dims
     time_eb, teb, tes = sv["emb"]
+    A_all, hts, cps, d, Hm, ds, HS, HT = sv["gen"]
     ne, nes = p[pfx + "node_embeddings"], p[pfx + "node_embeddings_spg"]
     dne, dnes = g[pfx + "node_embeddings"], g[pfx + "node_embeddings_spg"]
     d_te, d_teb, d_tes = _zeros(time_eb, *time_eb.shape), _zeros(teb, *teb.shape), _zeros(tes, *tes.shape)
-    d = hypertem_bwd(p, g, pfx + "hyperTem4.", sv["h4"], dout, ne, time_eb, dne, d_te, dims)
-    d = cap_bwd(p, g, pfx + "cap2.", sv["c2"], d, nes, tes, teb, dnes, d_tes, d_teb, dims)
-    d = hypertem_bwd(p, g, pfx + "hyperTem3.", sv["h3"], d, ne, time_eb, dne, d_te, dims)
-    d = hypertem_bwd(p, g, pfx + "hyperTem2.", sv["h2"], d, ne, time_eb, dne, d_te, dims)
-    d = cap_bwd(p, g, pfx + "cap1.", sv["c1"], d, nes, tes, teb, dnes, d_tes, d_teb, dims)
-    d = hypertem_bwd(p, g, pfx + "hyperTem1.", sv["h1"], d, ne, time_eb, dne, d_te, dims)
+    dG_all = torch.empty(4, N, T, T, device=dout.device)
+    dd, hp4 = hypertem_core_bwd(sv["h4"], dout, dG_all[3], dims)
+    dd, cp2 = cap_core_bwd(p, g, cps[1], sv["c2"], dd, dims, HS, HT)
+    dd, hp3 = hypertem_core_bwd(sv["h3"], dd, dG_all[2], dims)
+    dd, hp2 = hypertem_core_bwd(sv["h2"], dd, dG_all[1], dims)
+    dd, cp1 = cap_core_bwd(p, g, cps[0], sv["c1"], dd, dims, HS, HT)
+    dd, hp1 = hypertem_core_bwd(sv["h1"], dd, dG_all[0], dims)
+    # ---- gradient reductions of all generated parameters, batched: 11 launches (was 32) ----
+    hps = (hp1, hp2, hp3, hp4)
+    dWs = [t for hp in hps for t in (hp[0], hp[2])]
+    nss = [v for hp in hps for v in (hp[1], 1)]
+    pools = [t for h in hts for t in (p[h + "weights_pool"], p[h + "bias_pool"])]
+    ops.poolgen_bwd_pool_multi(time_eb, dWs, [t for h in hts for t in (g[h + "weights_pool"], g[h + "bias_pool"])], nss)
+    ops.poolgen_bwd_emb_multi(dWs, pools, d_te, nss)
+    dA_all = ops.gram_bwd(A_all.view(4 * N, Hm, T), dG_all.view(4 * N, T, T)).view(4, N, Hm * T)
+    dAs = [dA_all[i] for i in range(4)]
+    ops.poolgen_bwd_pool_multi(ne, dAs, [g[h + "adj"].view(d, Hm * T) for h in hts])
+    ops.poolgen_bwd_emb_multi(dAs, [p[h + "adj"].view(d, Hm * T) for h in hts], dne)
+    cpp = (cp1, cp2)
+    dWn = [t for cp in cpp for t in (cp[0], cp[2])]
+    nsn = [v for cp in cpp for v in (cp[1], 1)]
+    ops.poolgen_bwd_pool_multi(nes, dWn, [t for c in cps for t in (g[c + "weights_spa"], g[c + "bias_spa"])], nsn)
+    ops.poolgen_bwd_emb_multi(dWn, [t for c in cps for t in (p[c + "weights_spa"], p[c + "bias_spa"])], dnes, nsn)
+    ddyn = [cp[3].view(B, HT * T * HS) for cp in cpp]
+    ops.poolgen_bwd_pool_multi(tes, ddyn, [g[c + "t_adj"].view(ds, HT * T * HS) for c in cps])
+    ops.poolgen_bwd_emb_multi(ddyn, [p[c + "t_adj"].view(ds, HT * T * HS) for c in cps], d_tes)
+    dlg = [cp[4].view(B * T, HS * N) for cp in cpp]
+    ops.poolgen_bwd_pool_multi(teb, dlg, [g[c + "adj"].view(ds, HS * N) for c in cps])
+    ops.poolgen_bwd_emb_multi(dlg, [p[c + "adj"].view(ds, HS * N) for c in cps], d_teb)
     timefeat_bwd(p, g, pfx + "time_feature1.", tidx, d_te)
     timefeat_bwd(p, g, pfx + "time_feature1_.", tidx, d_teb)
     timefeat_bwd(p, g, pfx + "time_feature2.", tidx, d_tes, spg=True)
-    return d
+    return dd
 
 
 # ---- whole model ---------------------------------------------------------------------------------------------------

@@ -74,6 +74,47 @@ def poolgen_bwd_emb(dW, pool, demb, dW2=None, pool2=None, nsplit=1):
           nbytes=_nb(dW, pool, dW2, pool2, demb))
 
 
+def _ptrs(ts):
+    import ctypes
+    return (ctypes.c_void_p * len(ts))(*[t.data_ptr() for t in ts])
+
+
+def _ints(vs):
+    import ctypes
+    return (ctypes.c_int * len(vs))(*[int(v) for v in vs])
+
+
+def poolgen_multi(emb, pools, outs=None):
+    """One launch for up to 8 problems sharing emb: outs[p] (R, ...) = emb @ pools[p] (K, ...)."""
+    _chk(emb, *pools)
+    R, K = emb.shape
+    if outs is None:
+        outs = [torch.empty((R,) + tuple(pl.shape[1:]), device=emb.device, dtype=torch.float32) for pl in pools]
+    cols = [pl.numel() // K for pl in pools]
+    _call("gptst_poolgen_fwd_multi", _p(emb), len(pools), _ptrs(pools), _ptrs(outs), _ints(cols), R, K, nbytes=_nb(emb, *pools, *outs))
+    return outs
+
+
+def poolgen_bwd_pool_multi(emb, dWs, dpools, nsplits=None):
+    """dpools[p] += emb^T dWs[p] (summing nsplits[p] row blocks of R rows)."""
+    _chk(emb, *dWs, *dpools)
+    R, K = emb.shape
+    cols = [dp.numel() // K for dp in dpools]
+    ns = nsplits if nsplits is not None else [1] * len(dWs)
+    _call("gptst_poolgen_bwd_pool_multi", _p(emb), len(dWs), _ptrs(dWs), _ptrs(dpools), _ints(cols), _ints(ns), R, K,
+          nbytes=_nb(emb, *dWs, *dpools))
+
+
+def poolgen_bwd_emb_multi(dWs, pools, demb, nsplits=None):
+    """demb += sum_p dWs[p] pools[p]^T."""
+    _chk(demb, *dWs, *pools)
+    R, K = demb.shape
+    cols = [pl.numel() // K for pl in pools]
+    ns = nsplits if nsplits is not None else [1] * len(dWs)
+    _call("gptst_poolgen_bwd_emb_multi", len(dWs), _ptrs(dWs), _ptrs(pools), _ints(cols), _ints(ns), _p(demb), R, K,
+          nbytes=_nb(demb, *dWs, *pools))
+
+
 # ---- MFMA contractions ---------------------------------------------------------------------------------------
 def apply(A, W, mode, BT, N, bias=None, resid=None, A2=None, transw=False, pro=PRO_NONE, epi=EPI_PLAIN, colsum=None,
           out=None, resid2=None):
@@ -139,10 +180,10 @@ def hypertem_fwd(X, G, Wbt, bbt):
     return R, out
 
 
-def tmix_dgraph(dR, X):
-    _chk(dR, X)
+def tmix_dgraph(dR, X, out=None):
+    _chk(dR, X, out)
     B, T, N, C = X.shape
-    dG = torch.empty(N, T, T, device=X.device, dtype=torch.float32)
+    dG = out if out is not None else torch.empty(N, T, T, device=X.device, dtype=torch.float32)
     _call("gptst_tmix_dgraph", _p(dR), _p(X), _p(dG), B, T, N, C, nbytes=_nb(dR, X, dG))
     return dG
 

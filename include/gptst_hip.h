@@ -40,6 +40,15 @@ int gptst_poolgen_bwd_pool(const float* emb, const float* dW, float* dpool, int 
 int gptst_poolgen_bwd_emb(const float* dW, const float* pool, int cols, const float* dW2, const float* pool2, int cols2,
                           float* demb, int R, int nsplit, int K, void* stream);
 
+/* multi-problem forms (<= 8 problems sharing emb; host arrays of device pointers, read at call time): one launch generates /
+ * reduces the generated parameters of several layers (every launch has a ~4-5 us floor on MI355X). */
+int gptst_poolgen_fwd_multi(const float* emb, int nprob, const void* pools, const void* outs, const int* cols, int R, int K,
+                            void* stream);
+int gptst_poolgen_bwd_pool_multi(const float* emb, int nprob, const void* dWs, const void* dpools, const int* cols, const int* nsplit,
+                                 int R, int K, void* stream);
+int gptst_poolgen_bwd_emb_multi(int nprob, const void* dWs, const void* pools, const int* cols, const int* nsplit, float* demb, int R,
+                                int K, void* stream);
+
 /* ---- C x C contractions on fp32 MFMA (apply.hip) ------------------------------------------------------
  * out[g,m,:] = epi( pro(A)[g,m,:] @ W[g] (+bias[g]) (+resid) ).   mode: 0 TIME (g=(b,t), rows n), 1 NODE (g=n, rows
  * (b,t)), 2 SHARED (one weight).  w_per_group: W is (G,C,C) else (C,C).  transw: W[g] stored [out][in].
