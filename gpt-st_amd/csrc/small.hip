@@ -81,17 +81,20 @@ __global__ __launch_bounds__(256) void rowdot_kernel(const float* __restrict__ X
 }
 
 // out(j,c) += sum_i a'[i,j] X[i,c]   (olayout 0: out[c*J+j], 1: out[j*C+c]);  csum[c] += sum_i X[i,c];  asum[j] += sum_i a'[i,j]
-// grid: nblocks row chunks; J processed in register blocks of 8.
+// Two launches: (1) RO_NB workgroups reduce their row chunk to a partial [J*C | C | J] in scratch (4 independent rows in flight per
+// thread, slots folded through LDS), (2) a fold kernel sums the RO_NB partials per output and accumulates into the gradients.
+// (The single-launch version needed one atomic per output and workgroup: 160..510 same-address atomics = 45..110 us.)
+#define RO_NB 256
 template <int C>
-__global__ __launch_bounds__(256) void rowouter_kernel(const float* __restrict__ a, int lda, const float* __restrict__ mask, float fill,
-                                                       const float* __restrict__ X, float* __restrict__ out, int olayout,
-                                                       float* __restrict__ csum, float* __restrict__ asum, int rows, int J,
-                                                       int rows_per_block) {
+__global__ __launch_bounds__(256) void rowouter_part_kernel(const float* __restrict__ a, int lda, const float* __restrict__ mask, float fill,
+                                                            const float* __restrict__ X, float* __restrict__ part, int rows, int J,
+                                                            int rows_per_block, int want_asum) {
     constexpr int LPR = C / 4, RPB = 256 / LPR;
     __shared__ float4 red[RPB][LPR];
     const int c4 = threadIdx.x % LPR, slot = threadIdx.x / LPR;
     const size_t r0 = (size_t)blockIdx.x * rows_per_block;
     const size_t r1 = min((size_t)rows, r0 + rows_per_block);
+    float* mine = part + (size_t)blockIdx.x * (J * C + C + J);
     for (int jb = 0; jb < J || (jb == 0 && J == 0); jb += 8) {
         float4 acc[8];
 #pragma unroll
@@ -115,39 +118,56 @@ __global__ __launch_bounds__(256) void rowouter_kernel(const float* __restrict__
                     if (jb + u < J) acc[u] = f4fma(av[q][u], x[q], acc[u]);
             }
         }
-        // reduce the RPB row slots through LDS, then one atomic per (j, c)
 #pragma unroll
         for (int u = 0; u < 9; ++u) {
             const bool is_c = (u == 8);
-            if (is_c ? (jb != 0 || csum == nullptr) : (jb + u >= J)) continue;       // uniform
+            if (is_c ? (jb != 0) : (jb + u >= J)) continue;       // uniform
             red[slot][c4] = is_c ? cacc : acc[u < 8 ? u : 0];
             __syncthreads();
             if (slot == 0) {
                 float4 s = red[0][c4];
                 for (int q = 1; q < RPB; ++q) s = f4add(s, red[q][c4]);
-                if (is_c) {
-                    float* o = csum + 4 * c4;
-                    atomicAdd(o, s.x); atomicAdd(o + 1, s.y); atomicAdd(o + 2, s.z); atomicAdd(o + 3, s.w);
-                } else if (olayout) {
-                    float* o = out + (size_t)(jb + u) * C + 4 * c4;
-                    atomicAdd(o, s.x); atomicAdd(o + 1, s.y); atomicAdd(o + 2, s.z); atomicAdd(o + 3, s.w);
-                } else {
-                    float* o = out + (size_t)(4 * c4) * J + jb + u;
-                    atomicAdd(o, s.x); atomicAdd(o + J, s.y); atomicAdd(o + 2 * J, s.z); atomicAdd(o + 3 * J, s.w);
-                }
+                st4(mine + (is_c ? J * C : (jb + u) * C) + 4 * c4, s);
             }
             __syncthreads();
         }
     }
-    if (asum != nullptr) {          // column sums of a' over this block's rows
+    if (want_asum) {
         for (int j = 0; j < J; ++j) {
             float s = 0.f;
             for (size_t i = r0 + threadIdx.x; i < r1; i += 256) s += masked_a(a, mask, fill, i, j, lda, J);
             s = group_sum<64>(s);
-            if ((threadIdx.x & 63) == 0) atomicAdd(asum + j, s);
+            __syncthreads();
+            if ((threadIdx.x & 63) == 0) ((float*)red)[threadIdx.x >> 6] = s;
+            __syncthreads();
+            if (threadIdx.x == 0) mine[J * C + C + j] = ((float*)red)[0] + ((float*)red)[1] + ((float*)red)[2] + ((float*)red)[3];
         }
     }
 }
+
+// 16 lanes per output: each sums nb/16 partials (independent loads), then a 16-lane DPP sum — a serial 256-deep load chain
+// per output took 60 us.
+template <int C>
+__global__ __launch_bounds__(256) void rowouter_fold_kernel(const float* __restrict__ part, int nb, float* __restrict__ out, int olayout,
+                                                            float* __restrict__ csum, float* __restrict__ asum, int J) {
+    const int tot = J * C + C + J;
+    const int e = blockIdx.x * 16 + (threadIdx.x >> 4), q = threadIdx.x & 15;
+    float s = 0.f;
+    if (e < tot)
+        for (int b = q; b < nb; b += 16) s += part[(size_t)b * tot + e];
+    s = group_sum<16>(s);
+    if (e >= tot || q != 0) return;
+    if (e < J * C) {
+        const int j = e / C, c = e % C;
+        out[olayout ? (size_t)j * C + c : (size_t)c * J + j] += s;
+    } else if (e < J * C + C) {
+        if (csum) csum[e - J * C] += s;
+    } else if (asum) {
+        asum[e - J * C - C] += s;
+    }
+}
+
+extern "C" int gptst_rowouter_ws_floats(int J, int C) { return RO_NB * (J * C + C + J); }
 
 extern "C" int gptst_lin_in(const float* a, int lda, const float* mask, float fill, const float* W, int wlayout, const float* b,
                             float* Y, int rows, int J, int C, void* stream) {
@@ -171,16 +191,21 @@ extern "C" int gptst_rowdot(const float* X, const float* W, const float* b, floa
     return GPTST_OK;
 }
 
+// ws: device scratch of gptst_rowouter_ws_floats(J, C) floats
 extern "C" int gptst_rowouter(const float* a, int lda, const float* mask, float fill, const float* X, float* out, int olayout,
-                              float* csum, float* asum, int rows, int J, int C, void* stream) {
-    if (!X || J < 0 || J > SM_MAXJ || (J > 0 && (!a || !out))) return GPTST_EARG;
-    int nb = 160;                                   // few workgroups: every output address receives one atomic per workgroup
-    int rpb = (rows + nb - 1) / nb; if (rpb < 16) rpb = 16;
-    nb = (rows + rpb - 1) / rpb;
+                              float* csum, float* asum, float* ws, int rows, int J, int C, void* stream) {
+    if (!X || !ws || J < 0 || J > SM_MAXJ || (J > 0 && (!a || !out))) return GPTST_EARG;
+    int rpb = (rows + RO_NB - 1) / RO_NB; if (rpb < 16) rpb = 16;
+    const int nb = (rows + rpb - 1) / rpb;
+    const int tot = J * C + C + J;
     hipStream_t st = (hipStream_t)stream;
-    if (C == 64) hipLaunchKernelGGL((rowouter_kernel<64>), dim3(nb), dim3(256), 0, st, a, lda, mask, fill, X, out, olayout, csum, asum, rows, J, rpb);
-    else if (C == 128) hipLaunchKernelGGL((rowouter_kernel<128>), dim3(nb), dim3(256), 0, st, a, lda, mask, fill, X, out, olayout, csum, asum, rows, J, rpb);
-    else return GPTST_ESHAPE;
+    if (C == 64) {
+        hipLaunchKernelGGL((rowouter_part_kernel<64>), dim3(nb), dim3(256), 0, st, a, lda, mask, fill, X, ws, rows, J, rpb, asum != nullptr);
+        hipLaunchKernelGGL((rowouter_fold_kernel<64>), dim3((tot + 15) / 16), dim3(256), 0, st, (const float*)ws, nb, out, olayout, csum, asum, J);
+    } else if (C == 128) {
+        hipLaunchKernelGGL((rowouter_part_kernel<128>), dim3(nb), dim3(256), 0, st, a, lda, mask, fill, X, ws, rows, J, rpb, asum != nullptr);
+        hipLaunchKernelGGL((rowouter_fold_kernel<128>), dim3((tot + 15) / 16), dim3(256), 0, st, (const float*)ws, nb, out, olayout, csum, asum, J);
+    } else return GPTST_ESHAPE;
     GPTST_CHECK_LAUNCH();
     return GPTST_OK;
 }

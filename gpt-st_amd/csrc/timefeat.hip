@@ -60,13 +60,13 @@ __global__ __launch_bounds__(TF_ROWS) void timefeat_fwd_kernel(TfParams p, const
 }
 
 template <int E>
-__global__ __launch_bounds__(TF_ROWS) void timefeat_bwd_kernel(TfParams p, TfGrads g, const float* __restrict__ tidx,
+__global__ __launch_bounds__(256) void timefeat_bwd_kernel(TfParams p, TfGrads g, const float* __restrict__ tidx,
                                                                const float* __restrict__ dout, int rows, int K) {
     // LDS: per-row vectors [row][E+1] (pad) for h0,h1,h2,do,dz2,dz1,dz0
     __shared__ float sh[7][TF_ROWS][E + 1];
     const int tid = threadIdx.x;
     const int r = blockIdx.x * TF_ROWS + tid;
-    const bool valid = r < rows;
+    const bool valid = tid < TF_ROWS && r < rows;        // 256 threads: the first TF_ROWS own a row, all of them reduce
     float h0[E], h1[E], h2[E], o[E], d3[E], z2[E], z1[E], z0[E];
     if (valid) {
         tf_forward_row<E>(p, tidx, r, K, h0, h1, h2, o);
@@ -97,15 +97,17 @@ __global__ __launch_bounds__(TF_ROWS) void timefeat_bwd_kernel(TfParams p, TfGra
 #pragma unroll
         for (int e = 0; e < E; ++e) { h0[e] = h1[e] = h2[e] = d3[e] = z2[e] = z1[e] = z0[e] = 0.f; }
     }
+    if (tid < TF_ROWS) {
 #pragma unroll
     for (int e = 0; e < E; ++e) {
         sh[0][tid][e] = h0[e]; sh[1][tid][e] = h1[e]; sh[2][tid][e] = h2[e]; sh[3][tid][e] = d3[e];
         sh[4][tid][e] = z2[e]; sh[5][tid][e] = z1[e]; sh[6][tid][e] = z0[e];
     }
+    }
     __syncthreads();
     const int nrow = min(TF_ROWS, rows - blockIdx.x * TF_ROWS);
     // weight grads: dW3[e][i] = sum_r d3[e] h2[i]; dW2 = z2 (x) h1; dW1 = z1 (x) h0; biases = column sums of d3, z2, z1, z0
-    for (int idx = tid; idx < 3 * E * E; idx += TF_ROWS) {
+    for (int idx = tid; idx < 3 * E * E; idx += 256) {
         const int which = idx / (E * E), e = (idx / E) % E, i = idx % E;
         const int ga = which == 0 ? 3 : (which == 1 ? 4 : 5), gb = which == 0 ? 2 : (which == 1 ? 1 : 0);
         float s = 0.f;
@@ -113,7 +115,7 @@ __global__ __launch_bounds__(TF_ROWS) void timefeat_bwd_kernel(TfParams p, TfGra
         float* dst = which == 0 ? g.w3 : (which == 1 ? g.w2 : g.w1);
         atomicAdd(dst + e * E + i, s);
     }
-    for (int idx = tid; idx < 4 * E; idx += TF_ROWS) {
+    for (int idx = tid; idx < 4 * E; idx += 256) {
         const int which = idx / E, e = idx % E;
         const int ga = which == 0 ? 3 : (which == 1 ? 4 : (which == 2 ? 5 : 6));
         float s = 0.f;
@@ -124,7 +126,7 @@ __global__ __launch_bounds__(TF_ROWS) void timefeat_bwd_kernel(TfParams p, TfGra
         else { atomicAdd(g.bd + e, s); atomicAdd(g.bw + e, s); }
     }
     // input Linears: dWd[e][k] = sum_r z0[e] * day[r,k]; dWw likewise
-    for (int idx = tid; idx < 2 * E * K; idx += TF_ROWS) {
+    for (int idx = tid; idx < 2 * E * K; idx += 256) {
         const int ch = idx / (E * K), e = (idx / K) % E, k = idx % K;
         float s = 0.f;
         for (int rr = 0; rr < nrow; ++rr)
@@ -164,7 +166,7 @@ extern "C" int gptst_timefeat_bwd(const float* wd, const float* bd, const float*
     TfParams p{wd, bd, ww, bw, w1, b1, w2, b2, w3, b3};
     TfGrads g{gwd, gbd, gww, gbw, gw1, gb1, gw2, gb2, gw3, gb3};
     dim3 grid((rows + TF_ROWS - 1) / TF_ROWS);
-    TF_DISPATCH(E, hipLaunchKernelGGL((timefeat_bwd_kernel<EE>), grid, dim3(TF_ROWS), 0, (hipStream_t)stream, p, g, tidx, dout, rows, K));
+    TF_DISPATCH(E, hipLaunchKernelGGL((timefeat_bwd_kernel<EE>), grid, dim3(256), 0, (hipStream_t)stream, p, g, tidx, dout, rows, K));
     GPTST_CHECK_LAUNCH();
     return GPTST_OK;
 }

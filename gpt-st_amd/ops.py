@@ -304,7 +304,8 @@ def rowdot(X, W, b, softmax=False):
 
 def rowouter(a, lda, J, X, out, olayout, csum=None, asum=None, mask=None, fill=0.0):
     rows, C = X.shape
-    _call("gptst_rowouter", _p(a), lda, _p(mask), float(fill), _p(X), _p(out), olayout, _p(csum), _p(asum), rows, J, C,
+    ws = torch.empty(_C.lib().value("gptst_rowouter_ws_floats", J, C), device=X.device, dtype=torch.float32)
+    _call("gptst_rowouter", _p(a), lda, _p(mask), float(fill), _p(X), _p(out), olayout, _p(csum), _p(asum), _p(ws), rows, J, C,
           nbytes=_nb(a, mask, X, out))
 
 

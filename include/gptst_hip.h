@@ -128,8 +128,9 @@ int gptst_mask_adaptive(const int* label, const int* counts, const int* list_c, 
 int gptst_lin_in(const float* a, int lda, const float* mask, float fill, const float* W, int wlayout, const float* b, float* Y,
                  int rows, int J, int C, void* stream);
 int gptst_rowdot(const float* X, const float* W, const float* b, float* Z, int rows, int J, int C, int do_softmax, void* stream);
+int gptst_rowouter_ws_floats(int J, int C);   /* scratch (ws) size of gptst_rowouter */
 int gptst_rowouter(const float* a, int lda, const float* mask, float fill, const float* X, float* out, int olayout, float* csum,
-                   float* asum, int rows, int J, int C, void* stream);
+                   float* asum, float* ws, int rows, int J, int C, void* stream);
 
 /* ---- time-index embeddings (timefeat.hip), GPTST.py:187-219 ------------------------------------------------
  * rows x K day/week features (K=1: time_feature, rows=B*T; K=12: time_feature_spg, rows=B) -> (rows, E).
