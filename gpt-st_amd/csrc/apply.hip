@@ -10,6 +10,10 @@
 //   mode 1 (NODE)   g = n,     rows m = (b,t)  : row = m*N + g          (node-conditioned weights, cap / MLP_RL)
 //   mode 2 (SHARED) one group, rows = all                                (nn.Linear)
 #include "mfma_tile.h"
+__device__ long long g_ap_ts[64];     // debug: per-phase s_memtime stamps (enabled by gptst_ap_dbg(1))
+int g_ap_dbg = 0;
+extern "C" int gptst_ap_dbg(int v) { g_ap_dbg = v; return 0; }
+extern "C" int gptst_ap_ts(long long* out) { return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_ap_ts), sizeof(long long) * 64); }
 
 enum { PRO_NONE = 0, PRO_DPRE = 1 };          // PRO_DPRE: a = A * lrelu'(A2)   (A = dOut, A2 = layer output)
 enum { EPI_PLAIN = 0, EPI_RES_LRELU = 1, EPI_ADD_DPRE = 2, EPI_LRELU = 3 };   // 1: lrelu(acc+bias+resid)  2: acc + resid*lrelu'(resid2)  3: lrelu(acc+bias)
@@ -31,40 +35,75 @@ template <int C, int PRO, int EPI>
 __global__ __launch_bounds__(256) void apply_kernel(const float* __restrict__ A, const float* __restrict__ A2,
                                                     const float* __restrict__ W, long w_gstride, int transw,
                                                     const float* __restrict__ bias, const float* __restrict__ resid,
-                                                    const float* __restrict__ resid2, float* __restrict__ out, float* __restrict__ colsum, RowMap rm) {
+                                                    const float* __restrict__ resid2, float* __restrict__ out, float* __restrict__ colsum, RowMap rm, int dbg) {
     using T = Tile<C>;
+    int tsi = 0;
+#define TS() do { if (dbg && blockIdx.x == 100 && blockIdx.y == 0 && threadIdx.x == 0) g_ap_ts[tsi] = clock64(); ++tsi; } while (0)
+    TS();
     extern __shared__ __attribute__((aligned(16))) float smem[];
     float* Wl = smem;                                   // C*C
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     float* tile = smem + C * C + wave * T::TILE_FLOATS;
     const int g = blockIdx.x;
-    load_w_lds<C>(Wl, W + (size_t)g * w_gstride, transw, tid, 256);
-    __syncthreads();
-
     const int ntiles = (rm.M + 31) / 32;
     float cs[C / 64];
 #pragma unroll
     for (int u = 0; u < C / 64; ++u) cs[u] = 0.f;
+    const int tstride = gridDim.y * 4;
+    int t = blockIdx.y * 4 + wave;
 
-    for (int t = blockIdx.y * 4 + wave; t < ntiles; t += gridDim.y * 4) {
-        const int m0 = t * 32;
-        // ---- stage A tile (coalesced float4 rows) ----
+    // The A tile of the first (usually only) tile is requested from HBM BEFORE the weight is staged, so the two round trips
+    // overlap; likewise the residual operands of the epilogue are requested before the MFMA phase.
+    float4 av[T::F4_PER_LANE], ov[T::F4_PER_LANE];
+    auto fetch_a = [&](int tt) {
+        const int m0 = tt * 32;
 #pragma unroll
         for (int it = 0; it < T::F4_PER_LANE; ++it) {
             const int f = it * 64 + lane;
             const int r = f / T::F4_PER_ROW, c4 = f % T::F4_PER_ROW;
-            float4 v = f4zero();
-            if (m0 + r < rm.M) {
+            av[it] = f4zero(); ov[it] = make_float4(1.f, 1.f, 1.f, 1.f);
+            if (tt < ntiles && m0 + r < rm.M) {
                 const size_t off = ((size_t)g * rm.rs_g + (size_t)(m0 + r) * rm.rs_m) * C + 4 * c4;
-                v = ld4(A + off);
-                if (PRO == PRO_DPRE) {
-                    const float4 o = ld4(A2 + off);
-                    v.x *= lrelu_grad_from_out(o.x); v.y *= lrelu_grad_from_out(o.y);
-                    v.z *= lrelu_grad_from_out(o.z); v.w *= lrelu_grad_from_out(o.w);
-                }
+                av[it] = ld4(A + off);
+                if (PRO == PRO_DPRE) ov[it] = ld4(A2 + off);
+            }
+        }
+    };
+    fetch_a(t);
+    TS();
+    load_w_lds<C>(Wl, W + (size_t)g * w_gstride, transw, tid, 256);
+    __syncthreads();
+    TS();
+
+    for (; t < ntiles; t += tstride) {
+        const int m0 = t * 32;
+        // ---- stage the prefetched A tile ----
+#pragma unroll
+        for (int it = 0; it < T::F4_PER_LANE; ++it) {
+            const int f = it * 64 + lane;
+            const int r = f / T::F4_PER_ROW, c4 = f % T::F4_PER_ROW;
+            float4 v = av[it];
+            if (PRO == PRO_DPRE) {
+                const float4 o = ov[it];
+                v.x *= lrelu_grad_from_out(o.x); v.y *= lrelu_grad_from_out(o.y);
+                v.z *= lrelu_grad_from_out(o.z); v.w *= lrelu_grad_from_out(o.w);
             }
             st4(tile + r * T::PITCH + 4 * c4, v);
         }
+        // ---- request the epilogue operands now (they land while the MFMAs run) ----
+        float4 rv[T::F4_PER_LANE], rv2[T::F4_PER_LANE];
+#pragma unroll
+        for (int it = 0; it < T::F4_PER_LANE; ++it) {
+            const int f = it * 64 + lane;
+            const int r = f / T::F4_PER_ROW, c4 = f % T::F4_PER_ROW;
+            rv[it] = f4zero(); rv2[it] = f4zero();
+            if ((EPI == EPI_RES_LRELU || EPI == EPI_ADD_DPRE) && m0 + r < rm.M) {
+                const size_t off = ((size_t)g * rm.rs_g + (size_t)(m0 + r) * rm.rs_m) * C + 4 * c4;
+                rv[it] = ld4(resid + off);
+                if (EPI == EPI_ADD_DPRE) rv2[it] = ld4(resid2 + off);
+            }
+        }
+        TS();
         if (colsum != nullptr) {      // column sums of the staged tile (bias gradient)
 #pragma unroll
             for (int u = 0; u < C / 64; ++u) {
@@ -75,8 +114,12 @@ __global__ __launch_bounds__(256) void apply_kernel(const float* __restrict__ A,
             }
         }
         f32x16 acc[T::NCT];
+        TS();
         mfma_tile<C>(tile, Wl, acc, lane);
+        TS();
         acc_to_tile<C>(tile, acc, lane);
+        TS();
+        if (t + tstride < ntiles) fetch_a(t + tstride);      // next tile of a persistent wave
         // ---- epilogue: row-major float4 ----
 #pragma unroll
         for (int it = 0; it < T::F4_PER_LANE; ++it) {
@@ -87,18 +130,19 @@ __global__ __launch_bounds__(256) void apply_kernel(const float* __restrict__ A,
                 float4 y = ld4(tile + r * T::PITCH + 4 * c4);
                 if (bias != nullptr) y = f4add(y, ld4(bias + (size_t)g * C + 4 * c4));
                 if (EPI == EPI_RES_LRELU) {
-                    y = f4add(y, ld4(resid + off));
+                    y = f4add(y, rv[it]);
                     y.x = lrelu(y.x); y.y = lrelu(y.y); y.z = lrelu(y.z); y.w = lrelu(y.w);
                 }
                 if (EPI == EPI_LRELU) { y.x = lrelu(y.x); y.y = lrelu(y.y); y.z = lrelu(y.z); y.w = lrelu(y.w); }
                 if (EPI == EPI_ADD_DPRE) {
-                    const float4 d = ld4(resid + off), o = ld4(resid2 + off);
+                    const float4 d = rv[it], o = rv2[it];
                     y.x = fmaf(d.x, lrelu_grad_from_out(o.x), y.x); y.y = fmaf(d.y, lrelu_grad_from_out(o.y), y.y);
                     y.z = fmaf(d.z, lrelu_grad_from_out(o.z), y.z); y.w = fmaf(d.w, lrelu_grad_from_out(o.w), y.w);
                 }
                 st4(out + off, y);
             }
         }
+        TS();
     }
     if (colsum != nullptr) {          // fold the 4 waves in LDS first: one atomic per column and workgroup
         __syncthreads();
@@ -251,7 +295,7 @@ static int launch_apply(const float* A, const float* A2, const float* W, long w_
     const size_t smem = (size_t)(C * C + 4 * Tile<C>::TILE_FLOATS) * sizeof(float);
 #define LAUNCH(P, E)                                                                                              \
     hipLaunchKernelGGL((apply_kernel<C, P, E>), grid, block, smem, st, A, A2, W, w_gstride, transw, bias, resid, \
-                       resid2, out, colsum, rm)
+                       resid2, out, colsum, rm, g_ap_dbg)
     if (pro == PRO_NONE && epi == EPI_PLAIN) LAUNCH(PRO_NONE, EPI_PLAIN);
     else if (pro == PRO_NONE && epi == EPI_RES_LRELU) LAUNCH(PRO_NONE, EPI_RES_LRELU);
     else if (pro == PRO_DPRE && epi == EPI_PLAIN) LAUNCH(PRO_DPRE, EPI_PLAIN);

@@ -21,6 +21,8 @@ CASES = {
     "hs20": dict(ds="PEMS08", over=dict(HS=20, num_nodes=45), B=2, epoch=100),
     "hs40": dict(ds="NYC_TAXI", over=dict(HS=40, num_nodes=37), B=1, epoch=100),
     "route4": dict(ds="PEMS08", over=dict(num_route=4, num_nodes=33, embed_dim=8), B=2, epoch=100),
+    "c128": dict(ds="PEMS08", over=dict(hidden_dim=128, num_nodes=40, embed_dim=8), B=2, epoch=100),
+    "c128_rand": dict(ds="NYC_TAXI", over=dict(hidden_dim=128, num_nodes=23, embed_dim=4), B=1, epoch=2),
 }
 
 
