@@ -30,6 +30,8 @@ def kernel_flops(name, tag, d):
     rows = B * T * N
     if name in ("gptst_apply", "gptst_wgrad"):
         return 2.0 * rows * C * C
+    if name == "gptst_hypertem_fwd":
+        return 2.0 * rows * C * C + 2.0 * rows * C * T
     if name in ("gptst_tmix", "gptst_tmix_dgraph"):
         return 2.0 * rows * C * T
     if name == "gptst_cap_route_fwd":
@@ -41,6 +43,37 @@ def kernel_flops(name, tag, d):
     if name in ("gptst_cap_rec_bwd",):
         return 4.0 * B * T * HS * N * C
     return 0.0
+
+
+# C-ABI entry point (+ tag) -> kernel symbol prefix in rocprofv3 traces / profiles/pmc_traffic.json
+KERNEL_SYMBOL = {
+    "gptst_cap_route_fwd": "void cap_route_fwd2_kernel<64>", "gptst_cap_route_bwd": "void cap_route_bwd_kernel<64>",
+    "gptst_hypertem_fwd": "void hypertem_fwd_kernel<64>", "gptst_wgrad": "void wgrad64_kernel", "gptst_apply": "void apply_kernel<64",
+    "gptst_tmix": "void tmix_kernel<64", "gptst_tmix_dgraph": "void tmix_dgraph_kernel<64>", "gptst_cap_rec_bwd": "void cap_rec_bwd_kernel<64>",
+    "gptst_cap_cross_bwd": "void cap_cross_bwd_kernel<64>", "gptst_cap_rec_fwd": "void cap_rec_fwd_kernel<64>",
+}
+
+
+def pmc_traffic(name, tag, grid_hint=None):
+    """HBM bytes per launch of the dominant kernel from the committed PMC pass (profiles/pmc_traffic.json), or None."""
+    path = os.path.join(ROOT, "profiles", "pmc_traffic.json")
+    sym = KERNEL_SYMBOL.get(name)
+    if sym is None or not os.path.exists(path):
+        return None, None
+    ks = json.load(open(path))["kernels"]
+    if name == "gptst_apply":
+        m = {"mode0": None, "mode1": None, "mode2": None}
+        pro, epi = tag.split()[1][3:], tag.split()[2][3:]
+        sym = "void apply_kernel<64, %s, %s>" % (pro, epi)
+    if name == "gptst_wgrad":
+        sym = "void wgrad64_kernel<%s>" % tag.split()[1][3:4]
+    cands = [(k, v) for k, v in ks.items() if k.startswith(sym)]
+    if grid_hint is not None:
+        cands = [c for c in cands if grid_hint in c[0]] or cands
+    if not cands:
+        return None, None
+    k, v = max(cands, key=lambda kv: kv[1]["hbm_bytes"])
+    return v["hbm_bytes"], k
 
 
 def time_kernels(stepper, epoch, nsteps=3):
@@ -208,7 +241,8 @@ def main():
         else:
             rf = dict(bound="mfma", achieved=fl / dv["avg_s"] / 1e12, peak=MFMA_F32_PEAK / 1e12, unit="TFLOP/s")
         rf["frac"] = rf["achieved"] / rf["peak"]
-        rf["traffic"] = None
+        hint = {"mode0": "[384,", "mode1": "[170,", "mode2": "[1,"}.get(dt.split()[0]) if dt else None
+        rf["traffic"], rf["traffic_kernel"] = pmc_traffic(dn, dt, hint)
         rf.update(kernel="%s[%s]" % (dn, dt), avg_us=1e6 * dv["avg_s"], launches_per_step=dv["launches"],
                   alg_bytes_per_launch=dv["bytes"], alg_flops_per_launch=fl, share_of_step_kernel_time=dv["total_s"] / tot)
         out["roofline"] = rf
@@ -218,6 +252,9 @@ def main():
     if not a.no_cpu_baseline and world == 1:
         out["cpu_baseline"] = cpu_baseline(args, B)
     print(json.dumps(out))
+    if dp is not None:
+        import torch.distributed as dist
+        dist.destroy_process_group()
 
 
 if __name__ == "__main__":
