@@ -365,7 +365,7 @@ static int launch_route_bwd(const float* X, const float* Wp, const float* bp, co
     return GPTST_OK;
 }
 
-extern "C" int gptst_cap_route_bwd(const float* X, const float* Wp, const float* bp, const float* c, const float* dc1,
+extern "C" int gptst_cap_route_bwd_v1(const float* X, const float* Wp, const float* bp, const float* c, const float* dc1,
                                    const float* dS, float* dY, float* dlogit, int BT, int N, int C, int HS, void* stream) {
     if (!X || !Wp || !bp || !c || !dc1 || !dS || !dY || !dlogit) return GPTST_EARG;
     if (C == 64) return launch_route_bwd<64>(X, Wp, bp, c, dc1, dS, dY, dlogit, BT, N, HS, (hipStream_t)stream);

@@ -299,3 +299,209 @@ extern "C" int gptst_cap_occupancy(int N, int HS) {
     hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, (const void*)cap_route_fwd2_kernel<C>, CM_NT, smem);
     return n * 1000000 + (int)smem;
 }
+
+// =====================================================================================================================
+// backward through s = c.P, c = softmax_h(b + dadj), P = squash(X Wp^T + bp)   (routing logits b are detached, GPTST.py:108-109)
+//   in : X, Wp, bp, c (BT,HS,N), dc1 (BT,HS,N: grad of c from the cluster->node scatter), dS (BT,HS,C: total grad of s)
+//   out: dY (BT*N, C) grad of the pre-squash Linear output, dlogit (BT,HS,N) grad of dadj
+// One 512-thread workgroup per (b,t).  Y = X Wp^T + bp is rebuilt by MFMA into LDS (cheaper than a 16.7 MB round trip); then
+// every wave owns 16-node tiles end to end, with no further workgroup barrier:
+//   U[h,n] = dS[h,:].P[n,:]  (MFMA 16x16x4, P = g(n) Y)  ->  dc = dc1 + U,  dlogit = c (dc - sum_h c dc)
+//   dP[n,:] = sum_h c[h,n] dS[h,:]  (MFMA 16x16x4, K = clusters)  ->  squash backward  dY = g dP + Y (2 g'(q) (Y.dP))
+// =====================================================================================================================
+template <int C>
+__global__ __launch_bounds__(CM_NT, 4) void cap_route_bwd2_kernel(const float* __restrict__ X, const float* __restrict__ Wp,
+                                                                  const float* __restrict__ bp, const float* __restrict__ c,
+                                                                  const float* __restrict__ dc1, const float* __restrict__ dS,
+                                                                  float* __restrict__ dY, float* __restrict__ dlogit, int N, int HS,
+                                                                  int region2) {
+    using T = Tile<C>;
+    constexpr int P = T::PITCH, LPR = C / 4, RPP = CM_NT / LPR;
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    const int NR = cm_rows(N), NP = cm_np(N), HSP = cm_hsp(HS);
+    float* Ys = smem;                       // NR * P     Y = X Wp^T + bp
+    float* Wl = Ys + NR * P;                // region2 = max(C*C, 2*HSP*NP)
+    float* cs = Wl;                         // HSP * NP   (rows >= HS zero)
+    float* dcs = cs + HSP * NP;             // HSP * NP   dc1, then dc
+    float* Vs = Wl + region2;               // HSP * P    dS (rows >= HS zero)
+    float* gq = Vs + HSP * P;               // NR         squash factor g(n)
+    float* qq = gq + NR;                    // NR         squared norm q(n)
+    const int bt = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const float* Xbt = X + (size_t)bt * N * C;
+
+    load_w_lds<C>(Wl, Wp, 1, tid, CM_NT);
+    for (int i = tid; i < HSP * P; i += CM_NT) Vs[i] = 0.f;
+    __syncthreads();
+    for (int t = wave; t < (NR + 31) / 32; t += CM_NW) {           // same tiling as the forward
+        float* tile = Ys + t * 32 * P;
+        const int rows_here = min(32, NR - t * 32);
+#pragma unroll
+        for (int it = 0; it < T::F4_PER_LANE; ++it) {
+            const int f = it * 64 + lane;
+            const int r = f / T::F4_PER_ROW, c4 = f % T::F4_PER_ROW;
+            const int n = t * 32 + r;
+            if (r < rows_here) st4(tile + r * P + 4 * c4, n < N ? ld4(Xbt + (size_t)n * C + 4 * c4) : f4zero());
+        }
+        f32x16 acc[T::NCT];
+        if (rows_here == 32) {
+            mfma_tile<C>(tile, Wl, acc, lane);
+            acc_to_tile<C>(tile, acc, lane);
+        } else {
+            const int i = lane & 31, h = lane >> 5;
+#pragma unroll
+            for (int ct = 0; ct < T::NCT; ++ct)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[ct][r] = 0.f;
+            const float* arow = tile + (i & 15) * P + 4 * h;
+            const float* wcol = Wl + 4 * h * C + i;
+#pragma unroll 2
+            for (int q = 0; q < C / 8; ++q) {
+                const float4 a4 = ld4(arow + 8 * q);
+                const float av[4] = {a4.x, a4.y, a4.z, a4.w};
+#pragma unroll
+                for (int jj = 0; jj < 4; ++jj)
+#pragma unroll
+                    for (int ct = 0; ct < T::NCT; ++ct)
+                        acc[ct] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[jj], wcol[(8 * q + jj) * C + ct * 32], acc[ct], 0, 0, 0);
+            }
+#pragma unroll
+            for (int ct = 0; ct < T::NCT; ++ct)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int row = (r & 3) + 8 * (r >> 2) + 4 * h;
+                    if (row < 16) tile[row * P + ct * 32 + i] = acc[ct][r];
+                }
+        }
+    }
+    __syncthreads();
+    {   // Y += bp, per-row q and g;  stage c, dc1, dS
+        const int slot = tid / LPR, jj = tid % LPR;
+        const float4 b4 = ld4(bp + 4 * jj);
+        for (int n0 = 0; n0 < NR; n0 += RPP) {
+            const int n = n0 + slot;
+            float4 y = f4zero();
+            if (n < N) y = f4add(ld4(Ys + n * P + 4 * jj), b4);
+            const float q = group_sum<LPR>(f4dot(y, y));
+            if (n < NR) {
+                st4(Ys + n * P + 4 * jj, y);
+                if (jj == 0) { qq[n] = q; gq[n] = q / ((1.f + q) * (sqrtf(q) + 1e-8f)); }
+            }
+        }
+        for (int i = tid; i < 2 * HSP * NP; i += CM_NT) cs[i] = 0.f;
+    }
+    __syncthreads();
+    for (int i = tid; i < HS * N; i += CM_NT) {
+        cs[(i / N) * NP + i % N] = c[(size_t)bt * HS * N + i];
+        dcs[(i / N) * NP + i % N] = dc1[(size_t)bt * HS * N + i];
+    }
+    for (int i = tid; i < HS * LPR; i += CM_NT) st4(Vs + (i / LPR) * P + 4 * (i % LPR), ld4(dS + (size_t)bt * HS * C + 4 * i));
+    __syncthreads();
+
+    const int j = lane & 15, kk = lane >> 4;
+    const int ntiles = (N + 15) / 16;
+    for (int nt = wave; nt < ntiles; nt += CM_NW) {
+        const int n = nt * 16 + j;                          // node of this lane as MFMA column (type 2) / row (dP)
+        const float gn = gq[n];
+        // ---- (a) dc = dc1 + dS.P^T on this node tile, wsum[n] = sum_h c dc ----
+        float wsum = 0.f;
+        for (int ht = 0; ht < HSP / 16; ++ht) {
+            f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int q = 0; q < C / 16; ++q) {
+                const float4 a = ld4(Vs + (ht * 16 + j) * P + 16 * q + 4 * kk);
+                const float4 b = ld4(Ys + n * P + 16 * q + 4 * kk);
+                acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a.x, gn * b.x, acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a.y, gn * b.y, acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a.z, gn * b.z, acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a.w, gn * b.w, acc, 0, 0, 0);
+            }
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int h = ht * 16 + kk * 4 + r;           // D reg r: row h, col n
+                if (n < N) {                                  // (n >= N would alias the next row of the [h][NP] arrays)
+                    const float dch = dcs[h * NP + n] + acc[r];
+                    dcs[h * NP + n] = dch;
+                    wsum = fmaf(cs[h * NP + n], dch, wsum);   // c is zero for padded h
+                }
+            }
+        }
+        wsum += __shfl_xor(wsum, 16, 64);
+        wsum += __shfl_xor(wsum, 32, 64);
+        if (n < N)
+            for (int ht = 0; ht < HSP / 16; ++ht)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int h = ht * 16 + kk * 4 + r;
+                    if (h < HS) dlogit[((size_t)bt * HS + h) * N + n] = cs[h * NP + n] * (dcs[h * NP + n] - wsum);
+                }
+        // ---- (b) dP[n,:] = sum_h c[h,n] dS[h,:];  D[i = node][j = column] ----
+        f32x4 dp[C / 16];
+#pragma unroll
+        for (int ct = 0; ct < C / 16; ++ct) dp[ct] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        for (int s = 0; s < HSP / 4; ++s) {
+            const float a = n < N ? cs[(4 * s + kk) * NP + n] : 0.f;
+#pragma unroll
+            for (int ct = 0; ct < C / 16; ++ct)
+                dp[ct] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, Vs[(4 * s + kk) * P + 16 * ct + j], dp[ct], 0, 0, 0);
+        }
+        // squash backward in the D layout: reg r <-> node nt*16 + kk*4 + r, column 16ct + j
+        float yv[C / 16][4], ydp[4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            float s = 0.f;
+#pragma unroll
+            for (int ct = 0; ct < C / 16; ++ct) {
+                yv[ct][r] = Ys[(nt * 16 + kk * 4 + r) * P + 16 * ct + j];
+                s = fmaf(yv[ct][r], dp[ct][r], s);
+            }
+            ydp[r] = group_sum<16>(s);                        // the 16 lanes of a DPP row share kk, i.e. the same 4 nodes
+        }
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int nn = nt * 16 + kk * 4 + r;
+            const float q = qq[nn], g = gq[nn];
+            const float rt = sqrtf(q), den = (1.f + q) * (rt + 1e-8f);
+            float gp = 0.f;
+            if (rt > 0.f) gp = (den - q * ((rt + 1e-8f) + (1.f + q) * 0.5f / rt)) / (den * den);
+            const float k2 = 2.f * gp * ydp[r];
+#pragma unroll
+            for (int ct = 0; ct < C / 16; ++ct) Ys[nn * P + 16 * ct + j] = fmaf(k2, yv[ct][r], g * dp[ct][r]);   // dY over Y (own tile)
+        }
+        // coalesced rows out
+#pragma unroll
+        for (int i = 0; i < 16 * LPR / 64; ++i) {
+            const int f = i * 64 + lane, nl = f / LPR, c4 = f % LPR;
+            const int nn = nt * 16 + nl;
+            if (nn < N) st4(dY + ((size_t)bt * N + nn) * C + 4 * c4, ld4(Ys + nn * P + 4 * c4));
+        }
+    }
+}
+
+template <int C>
+static int launch_route_bwd2(const float* X, const float* Wp, const float* bp, const float* c, const float* dc1, const float* dS,
+                             float* dY, float* dlogit, int BT, int N, int HS, hipStream_t st) {
+    if (HS > 64) return GPTST_ESHAPE;
+    const int NR = cm_rows(N), NP = cm_np(N), HSP = cm_hsp(HS);
+    size_t r2 = (size_t)C * C, need = (size_t)2 * HSP * NP;
+    if (need > r2) r2 = need;
+    r2 = (r2 + 3) & ~(size_t)3;
+    const size_t smem = ((size_t)NR * Tile<C>::PITCH + r2 + (size_t)HSP * Tile<C>::PITCH + 2 * (size_t)NR) * sizeof(float);
+    if (smem > 160 * 1024) return GPTST_ESHAPE;
+    static size_t cur = 0;
+    if (smem > cur) { hipFuncSetAttribute((const void*)cap_route_bwd2_kernel<C>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem); cur = smem; }
+    hipLaunchKernelGGL((cap_route_bwd2_kernel<C>), dim3(BT), dim3(CM_NT), smem, st, X, Wp, bp, c, dc1, dS, dY, dlogit, N, HS, (int)r2);
+    GPTST_CHECK_LAUNCH();
+    return GPTST_OK;
+}
+
+extern "C" int gptst_cap_route_bwd_v1(const float* X, const float* Wp, const float* bp, const float* c, const float* dc1,
+                                      const float* dS, float* dY, float* dlogit, int BT, int N, int C, int HS, void* stream);
+
+extern "C" int gptst_cap_route_bwd(const float* X, const float* Wp, const float* bp, const float* c, const float* dc1,
+                                   const float* dS, float* dY, float* dlogit, int BT, int N, int C, int HS, void* stream) {
+    if (!X || !Wp || !bp || !c || !dc1 || !dS || !dY || !dlogit) return GPTST_EARG;
+    int rc = GPTST_ESHAPE;
+    if (C == 64) rc = launch_route_bwd2<64>(X, Wp, bp, c, dc1, dS, dY, dlogit, BT, N, HS, (hipStream_t)stream);
+    if (rc == GPTST_ESHAPE) return gptst_cap_route_bwd_v1(X, Wp, bp, c, dc1, dS, dY, dlogit, BT, N, C, HS, stream);
+    return rc;
+}
