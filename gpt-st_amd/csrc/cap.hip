@@ -343,7 +343,7 @@ extern "C" int gptst_cap_rec_fwd(const float* c, const float* v, float* rec, int
     return GPTST_ESHAPE;
 }
 
-extern "C" int gptst_cap_rec_bwd(const float* drec, const float* c, const float* v, float* dc1, float* dv, int BT, int N, int C,
+extern "C" int gptst_cap_rec_bwd_v1(const float* drec, const float* c, const float* v, float* dc1, float* dv, int BT, int N, int C,
                                  int HS, void* stream) {
     if (!drec || !c || !v || !dc1 || !dv) return GPTST_EARG;
     if (C == 64) return launch_rec<64>(c, v, nullptr, drec, dc1, dv, BT, N, HS, (hipStream_t)stream);

@@ -6,6 +6,8 @@
 // Tiny (0.5 MFLOP per sample) and latency bound: one workgroup per sample, everything LDS-resident, VALU only.
 #include "common.h"
 
+#define CX_NT 1024     // threads per sample: every phase is a short latency chain, so use all 16 waves of a CU
+
 template <int C>
 struct CrossCfg {
     static constexpr int LPR = C / 4;
@@ -13,7 +15,7 @@ struct CrossCfg {
 };
 
 template <int C>
-__global__ __launch_bounds__(256) void cap_cross_fwd_kernel(const float* __restrict__ s, const float* __restrict__ dyn,
+__global__ __launch_bounds__(CX_NT) void cap_cross_fwd_kernel(const float* __restrict__ s, const float* __restrict__ dyn,
                                                             const float* __restrict__ tmpl, float* __restrict__ v,
                                                             float* __restrict__ Ht_out, float* __restrict__ Rt_out, int T, int HS,
                                                             int HT) {
@@ -24,15 +26,15 @@ __global__ __launch_bounds__(256) void cap_cross_fwd_kernel(const float* __restr
     float* Hs = Zs + KK * K::PITCH;           // HT * C
     float* dyns = Hs + HT * C;                // HT * KK
     const int b = blockIdx.x, tid = threadIdx.x;
-    for (int i = tid; i < KK * K::LPR; i += 256) {
+    for (int i = tid; i < KK * K::LPR; i += CX_NT) {
         const int k = i / K::LPR, c4 = i % K::LPR;
         const float tm = tmpl[k / HS];
         const float4 x = ld4(s + ((size_t)b * KK + k) * C + 4 * c4);
         st4(Zs + k * K::PITCH + 4 * c4, make_float4(x.x + tm, x.y + tm, x.z + tm, x.w + tm));
     }
-    for (int i = tid; i < HT * KK; i += 256) dyns[i] = dyn[(size_t)b * HT * KK + i];
+    for (int i = tid; i < HT * KK; i += CX_NT) dyns[i] = dyn[(size_t)b * HT * KK + i];
     __syncthreads();
-    for (int i = tid; i < HT * K::LPR; i += 256) {
+    for (int i = tid; i < HT * K::LPR; i += CX_NT) {
         const int j = i / K::LPR, c4 = i % K::LPR;
         float4 acc = f4zero();
         for (int k = 0; k < KK; ++k) acc = f4fma(dyns[j * KK + k], ld4(Zs + k * K::PITCH + 4 * c4), acc);
@@ -41,7 +43,7 @@ __global__ __launch_bounds__(256) void cap_cross_fwd_kernel(const float* __restr
         st4(Ht_out + ((size_t)b * HT + j) * C + 4 * c4, acc);
     }
     __syncthreads();
-    for (int base = 0; base < KK * K::LPR; base += 256) {
+    for (int base = 0; base < KK * K::LPR; base += CX_NT) {
         const int i = base + tid;
         const bool valid = i < KK * K::LPR;
         const int k = valid ? i / K::LPR : 0, c4 = i % K::LPR;
@@ -61,7 +63,7 @@ __global__ __launch_bounds__(256) void cap_cross_fwd_kernel(const float* __restr
 
 // backward: dS (total grad of s) and ddyn from dv
 template <int C>
-__global__ __launch_bounds__(256) void cap_cross_bwd_kernel(const float* __restrict__ dv, const float* __restrict__ s,
+__global__ __launch_bounds__(CX_NT) void cap_cross_bwd_kernel(const float* __restrict__ dv, const float* __restrict__ s,
                                                             const float* __restrict__ Rt, const float* __restrict__ Ht,
                                                             const float* __restrict__ dyn, const float* __restrict__ tmpl,
                                                             float* __restrict__ dS, float* __restrict__ ddyn, int T, int HS, int HT) {
@@ -74,11 +76,11 @@ __global__ __launch_bounds__(256) void cap_cross_bwd_kernel(const float* __restr
     float* dHs = Hs + HT * K::PITCH;          // HT * PITCH   dHpre
     float* dyns = dHs + HT * K::PITCH;        // HT * KK
     const int b = blockIdx.x, tid = threadIdx.x;
-    for (int i = tid; i < HT * KK; i += 256) dyns[i] = dyn[(size_t)b * HT * KK + i];
-    for (int i = tid; i < HT * K::LPR; i += 256)
+    for (int i = tid; i < HT * KK; i += CX_NT) dyns[i] = dyn[(size_t)b * HT * KK + i];
+    for (int i = tid; i < HT * K::LPR; i += CX_NT)
         st4(Hs + (i / K::LPR) * K::PITCH + 4 * (i % K::LPR), ld4(Ht + ((size_t)b * HT) * C + 4 * i));
     // rows k: u = Rt + s;  du = squash_bwd(u, dv);  dRpre = du * lrelu'(Rt)
-    for (int base = 0; base < KK * K::LPR; base += 256) {
+    for (int base = 0; base < KK * K::LPR; base += CX_NT) {
         const int i = base + tid;
         const bool valid = i < KK * K::LPR;
         const int k = valid ? i / K::LPR : 0, c4 = i % K::LPR;
@@ -104,7 +106,7 @@ __global__ __launch_bounds__(256) void cap_cross_bwd_kernel(const float* __restr
     }
     __syncthreads();
     // dHpre[j] = lrelu'(Ht[j]) * sum_k dyn[j][k] dRpre[k]
-    for (int i = tid; i < HT * K::LPR; i += 256) {
+    for (int i = tid; i < HT * K::LPR; i += CX_NT) {
         const int j = i / K::LPR, c4 = i % K::LPR;
         float4 acc = f4zero();
         for (int k = 0; k < KK; ++k) acc = f4fma(dyns[j * KK + k], ld4(Gs + k * K::PITCH + 4 * c4), acc);
@@ -114,7 +116,7 @@ __global__ __launch_bounds__(256) void cap_cross_bwd_kernel(const float* __restr
     }
     __syncthreads();
     // ddyn[j][k] = Ht[j].dRpre[k] + dHpre[j].Z[k]
-    for (int i = tid; i < HT * KK; i += 256) {
+    for (int i = tid; i < HT * KK; i += CX_NT) {
         const int j = i / KK, k = i % KK;
         float acc = 0.f;
 #pragma unroll 4
@@ -125,7 +127,7 @@ __global__ __launch_bounds__(256) void cap_cross_bwd_kernel(const float* __restr
         ddyn[(size_t)b * HT * KK + i] = acc;
     }
     // dS[k] += sum_j dyn[j][k] dHpre[j]
-    for (int i = tid; i < KK * K::LPR; i += 256) {
+    for (int i = tid; i < KK * K::LPR; i += CX_NT) {
         const int k = i / K::LPR, c4 = i % K::LPR;
         float4 acc = f4zero();
         for (int j = 0; j < HT; ++j) acc = f4fma(dyns[j * KK + k], ld4(dHs + j * K::PITCH + 4 * c4), acc);
@@ -144,13 +146,13 @@ static int launch_cross(bool fwd, const float* a0, const float* a1, const float*
         if (smem > 160 * 1024) return GPTST_ESHAPE;
         static size_t cur = 0;
         if (smem > cur) { hipFuncSetAttribute((const void*)cap_cross_fwd_kernel<C>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem); cur = smem; }
-        hipLaunchKernelGGL((cap_cross_fwd_kernel<C>), dim3(B), dim3(256), smem, st, a0, a1, a2, o0, o1, o2, T, HS, HT);
+        hipLaunchKernelGGL((cap_cross_fwd_kernel<C>), dim3(B), dim3(CX_NT), smem, st, a0, a1, a2, o0, o1, o2, T, HS, HT);
     } else {
         const size_t smem = ((size_t)2 * KK * K::PITCH + (size_t)2 * HT * K::PITCH + (size_t)HT * KK) * sizeof(float);
         if (smem > 160 * 1024) return GPTST_ESHAPE;
         static size_t cur = 0;
         if (smem > cur) { hipFuncSetAttribute((const void*)cap_cross_bwd_kernel<C>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem); cur = smem; }
-        hipLaunchKernelGGL((cap_cross_bwd_kernel<C>), dim3(B), dim3(256), smem, st, a0, a1, a2, a3, a4, a5, o0, o1, T, HS, HT);
+        hipLaunchKernelGGL((cap_cross_bwd_kernel<C>), dim3(B), dim3(CX_NT), smem, st, a0, a1, a2, a3, a4, a5, o0, o1, T, HS, HT);
     }
     GPTST_CHECK_LAUNCH();
     return GPTST_OK;

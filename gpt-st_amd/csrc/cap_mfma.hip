@@ -505,3 +505,57 @@ extern "C" int gptst_cap_route_bwd(const float* X, const float* Wp, const float*
     if (rc == GPTST_ESHAPE) return gptst_cap_route_bwd_v1(X, Wp, bp, c, dc1, dS, dY, dlogit, BT, N, C, HS, stream);
     return rc;
 }
+
+// =====================================================================================================================
+// backward of the cluster -> node scatter rec[n,:] = sum_h c[h,n] v[h,:]  (GPTST.py:135):
+//   dc1[h,n] = drec[n,:] . v[h,:]   (type 2, "V" = v)        dv[h,:] = sum_n c[h,n] drec[n,:]   (type 1, "P" = drec)
+// drec rows of one (b,t) are staged in LDS once; both contractions on MFMA 16x16x4.
+// =====================================================================================================================
+template <int C>
+__global__ __launch_bounds__(CM_NT, 4) void cap_rec_bwd2_kernel(const float* __restrict__ drec, const float* __restrict__ c,
+                                                                const float* __restrict__ v, float* __restrict__ dc1,
+                                                                float* __restrict__ dv, int N, int HS) {
+    constexpr int P = Tile<C>::PITCH, LPR = C / 4;
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    const int NR = cm_rows(N), NP = cm_np(N), HSP = cm_hsp(HS);
+    float* Ds = smem;                       // NR * P   drec rows (rows >= N zero)
+    float* cs = Ds + NR * P;                // HSP * NP
+    float* bl = cs + HSP * NP;              // HS * NP  dc1 accumulator
+    float* Vs = bl + HS * NP;               // HSP * P  v
+    float* S = Vs + HSP * P;                // HSP * C  dv
+    const int bt = blockIdx.x, tid = threadIdx.x;
+    for (int i = tid; i < NR * LPR; i += CM_NT) {
+        const int n = i / LPR, c4 = i % LPR;
+        st4(Ds + n * P + 4 * c4, n < N ? ld4(drec + ((size_t)bt * N + n) * C + 4 * c4) : f4zero());
+    }
+    for (int i = tid; i < HSP * NP + HS * NP + HSP * P; i += CM_NT) cs[i] = 0.f;      // cs, bl, Vs
+    __syncthreads();
+    for (int i = tid; i < HS * N; i += CM_NT) cs[(i / N) * NP + i % N] = c[(size_t)bt * HS * N + i];
+    for (int i = tid; i < HS * LPR; i += CM_NT) st4(Vs + (i / LPR) * P + 4 * (i % LPR), ld4(v + (size_t)bt * HS * C + 4 * i));
+    __syncthreads();
+    cm_type2<C>(Ds, Vs, bl, N, NP, HS, HSP);
+    cm_type1<C>(Ds, cs, S, N, NP, HSP);
+    __syncthreads();
+    for (int i = tid; i < HS * N; i += CM_NT) dc1[(size_t)bt * HS * N + i] = bl[(i / N) * NP + i % N];
+    for (int i = tid; i < HS * LPR; i += CM_NT) st4(dv + (size_t)bt * HS * C + 4 * i, ld4(S + (i / LPR) * C + 4 * (i % LPR)));
+}
+
+extern "C" int gptst_cap_rec_bwd_v1(const float* drec, const float* c, const float* v, float* dc1, float* dv, int BT, int N, int C,
+                                    int HS, void* stream);
+
+extern "C" int gptst_cap_rec_bwd(const float* drec, const float* c, const float* v, float* dc1, float* dv, int BT, int N, int C, int HS,
+                                 void* stream) {
+    if (!drec || !c || !v || !dc1 || !dv) return GPTST_EARG;
+    if (C == 64 && HS <= 64) {
+        const int NR = cm_rows(N), NP = cm_np(N), HSP = cm_hsp(HS);
+        const size_t smem = ((size_t)NR * Tile<64>::PITCH + (size_t)(HSP + HS) * NP + (size_t)HSP * Tile<64>::PITCH + (size_t)HSP * 64) * sizeof(float);
+        if (smem <= 160 * 1024) {
+            static size_t cur = 0;
+            if (smem > cur) { hipFuncSetAttribute((const void*)cap_rec_bwd2_kernel<64>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem); cur = smem; }
+            hipLaunchKernelGGL((cap_rec_bwd2_kernel<64>), dim3(BT), dim3(CM_NT), smem, (hipStream_t)stream, drec, c, v, dc1, dv, N, HS);
+            GPTST_CHECK_LAUNCH();
+            return GPTST_OK;
+        }
+    }
+    return gptst_cap_rec_bwd_v1(drec, c, v, dc1, dv, BT, N, C, HS, stream);
+}
