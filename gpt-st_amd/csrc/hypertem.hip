@@ -109,3 +109,135 @@ extern "C" int gptst_hypertem_fwd(const float* X, const float* G, const float* W
     GPTST_CHECK_LAUNCH();
     return GPTST_OK;
 }
+
+// =====================================================================================================================
+// hyperTem backward, fused (everything except the weight gradient, which is grouped by (b,t) and stays in wgrad64_kernel):
+//   dPre = dOut * lrelu'(out)                               (LDS slab, 12 x 16 x C per workgroup = (sample, 16 nodes))
+//   dbias[b,t,:] += sum_n dPre                              (column sums of the slab, 11 atomics per address)
+//   dR_t = dPre_t W_bt^T                                    MFMA 16x16x4 as  dR_t^T = W_bt dPre_t^T  so that W_bt (L2) is the
+//                                                           A operand with coalesced float4 rows; result overwrites the slab
+//   dX_u = dPre_u + sum_t G_n[t,u] dR_t                     VALU from the slab (dPre re-read from L2)
+//   dG_n[t,u] += sum_c dR_t[n,c] X_u[n,c]                   MFMA 16x16x4 per node, 32 atomics per address (one per sample)
+// Replaces apply_kernel<TIME, dPre> + tmix_kernel<bwd> + tmix_dgraph_kernel (19 + 14 + 11 us, and the dR round trip).
+// =====================================================================================================================
+template <int C>
+__global__ __launch_bounds__(256, 2) void hypertem_bwd_kernel(const float* __restrict__ dOut, const float* __restrict__ Y,
+                                                              const float* __restrict__ X, const float* __restrict__ G,
+                                                              const float* __restrict__ Wbt, float* __restrict__ dX,
+                                                              float* __restrict__ dbias, float* __restrict__ dG, int N) {
+    constexpr int P = C + 4, LPR = C / 4;
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    float* Ds = smem;                               // [12][16][P]  dPre, then dR
+    float* Gs = Ds + HT_T * 16 * P;                 // [16][144]
+    const int b = blockIdx.y, n0 = blockIdx.x * 16;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    for (int i = tid; i < HT_T * 16 * LPR; i += 256) {
+        const int t = i / (16 * LPR), rem = i % (16 * LPR), nl = rem / LPR, c4 = rem % LPR;
+        const int n = n0 + nl;
+        float4 v = f4zero();
+        if (n < N) {
+            const size_t off = (((size_t)b * HT_T + t) * N + n) * C + 4 * c4;
+            const float4 d = ld4(dOut + off), y = ld4(Y + off);
+            v = make_float4(d.x * lrelu_grad_from_out(y.x), d.y * lrelu_grad_from_out(y.y), d.z * lrelu_grad_from_out(y.z),
+                            d.w * lrelu_grad_from_out(y.w));
+        }
+        st4(Ds + (t * 16 + nl) * P + 4 * c4, v);
+    }
+    for (int i = tid; i < 16 * 144; i += 256) Gs[i] = (n0 + i / 144 < N) ? G[(size_t)n0 * 144 + i] : 0.f;
+    __syncthreads();
+    const int j = lane & 15, kk = lane >> 4;
+    for (int t = wave; t < HT_T; t += 4) {
+        const size_t g = (size_t)b * HT_T + t;
+        float* dt = Ds + t * 16 * P;
+        // bias gradient: column sums of dPre_t over the 16 nodes
+        for (int c = lane; c < C; c += 64) {
+            float s = 0.f;
+#pragma unroll
+            for (int nl = 0; nl < 16; ++nl) s += dt[nl * P + c];
+            atomicAdd(dbias + g * C + c, s);
+        }
+        // dR_t^T (C x 16) = W_bt (C x C) dPre_t^T:  A[i][kk=o] = W[i][o] (global float4 rows), B[kk=o][j=n] = dPre_t[n][o] (LDS)
+        const float* W = Wbt + g * C * C;
+        float4 bq[C / 16];
+#pragma unroll
+        for (int q = 0; q < C / 16; ++q) bq[q] = ld4(dt + j * P + 16 * q + 4 * kk);
+        f32x4 acc[C / 16];
+#pragma unroll
+        for (int it = 0; it < C / 16; ++it) {
+            acc[it] = (f32x4){0.f, 0.f, 0.f, 0.f};
+            float4 aq[C / 16];
+#pragma unroll
+            for (int q = 0; q < C / 16; ++q) aq[q] = ld4(W + (size_t)(it * 16 + j) * C + 16 * q + 4 * kk);
+#pragma unroll
+            for (int q = 0; q < C / 16; ++q) {
+                acc[it] = __builtin_amdgcn_mfma_f32_16x16x4f32(aq[q].x, bq[q].x, acc[it], 0, 0, 0);
+                acc[it] = __builtin_amdgcn_mfma_f32_16x16x4f32(aq[q].y, bq[q].y, acc[it], 0, 0, 0);
+                acc[it] = __builtin_amdgcn_mfma_f32_16x16x4f32(aq[q].z, bq[q].z, acc[it], 0, 0, 0);
+                acc[it] = __builtin_amdgcn_mfma_f32_16x16x4f32(aq[q].w, bq[q].w, acc[it], 0, 0, 0);
+            }
+        }
+        // D reg r: row i = it*16 + kk*4 + r (input channel), col j = node  ->  dR_t[node][channel] over the slab
+#pragma unroll
+        for (int it = 0; it < C / 16; ++it)
+            st4(dt + j * P + it * 16 + kk * 4, make_float4(acc[it][0], acc[it][1], acc[it][2], acc[it][3]));
+    }
+    __syncthreads();
+    // ---- dX_u[n,:] = dPre_u[n,:] + sum_t G_n[t,u] dR_t[n,:] ----
+    {
+        const int c4 = tid % LPR, nb = tid / LPR;              // 256 threads = 16 rows x LPR lanes (C = 64)
+        for (int nl = nb; nl < 16; nl += 256 / LPR) {
+            const int n = n0 + nl;
+            if (n < N) {
+                float4 dr[HT_T];
+#pragma unroll
+                for (int t = 0; t < HT_T; ++t) dr[t] = ld4(Ds + (t * 16 + nl) * P + 4 * c4);
+#pragma unroll
+                for (int u = 0; u < HT_T; ++u) {
+                    const size_t off = (((size_t)b * HT_T + u) * N + n) * C + 4 * c4;
+                    const float4 d = ld4(dOut + off), y = ld4(Y + off);
+                    float4 acc = make_float4(d.x * lrelu_grad_from_out(y.x), d.y * lrelu_grad_from_out(y.y),
+                                             d.z * lrelu_grad_from_out(y.z), d.w * lrelu_grad_from_out(y.w));
+#pragma unroll
+                    for (int t = 0; t < HT_T; ++t) acc = f4fma(Gs[nl * 144 + t * HT_T + u], dr[t], acc);
+                    st4(dX + off, acc);
+                }
+            }
+        }
+    }
+    // ---- dG_n[t,u] += sum_c dR_t[n,c] X_u[n,c]:  A[i=t][kk=c] = dR (LDS), B[kk=c][j=u] = X (global) ----
+    for (int nl = wave; nl < 16; nl += 4) {
+        const int n = n0 + nl;
+        if (n >= N) continue;                                  // wave-uniform
+        f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int q = 0; q < C / 16; ++q) {
+            float4 a = f4zero(), x = f4zero();
+            if (j < HT_T) {
+                a = ld4(Ds + (j * 16 + nl) * P + 16 * q + 4 * kk);
+                x = ld4(X + (((size_t)b * HT_T + j) * N + n) * C + 16 * q + 4 * kk);
+            }
+            acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a.x, x.x, acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a.y, x.y, acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a.z, x.z, acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a.w, x.w, acc, 0, 0, 0);
+        }
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int t = kk * 4 + r, u = j;
+            if (t < HT_T && u < HT_T) atomicAdd(dG + (size_t)n * 144 + t * HT_T + u, acc[r]);
+        }
+    }
+}
+
+// dbias (B*T, C) and dG (N, T, T) are ACCUMULATED (+=): zero them first.
+extern "C" int gptst_hypertem_bwd(const float* dOut, const float* Y, const float* X, const float* G, const float* Wbt, float* dX,
+                                  float* dbias, float* dG, int B, int T, int N, int C, void* stream) {
+    if (!dOut || !Y || !X || !G || !Wbt || !dX || !dbias || !dG || T != HT_T) return GPTST_EARG;
+    if (C != 64) return GPTST_ESHAPE;
+    const size_t smem = ((size_t)HT_T * 16 * (C + 4) + 16 * 144) * sizeof(float);
+    static int done = 0;
+    if (!done) { hipFuncSetAttribute((const void*)hypertem_bwd_kernel<64>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem); done = 1; }
+    hipLaunchKernelGGL((hypertem_bwd_kernel<64>), dim3((N + 15) / 16, B), dim3(256), smem, (hipStream_t)stream, dOut, Y, X, G, Wbt, dX, dbias, dG, N);
+    GPTST_CHECK_LAUNCH();
+    return GPTST_OK;
+}

@@ -89,10 +89,14 @@ def hypertem_core_bwd(saved, dout, dG_out, dims):
     x, R, out, G, Wbt = saved
     BT = B * T
     dbias = _zeros(x, BT, C)
-    dR = ops.apply(dout, Wbt, MODE_TIME, BT, N, A2=out, transw=True, pro=PRO_DPRE, colsum=dbias)
     dWbt, ns = ops.wgrad(R, dout, MODE_TIME, BT, N, D2=out, pro=PRO_DPRE)
-    dx = ops.tmix(dR.view(B, T, N, C), G, dOut=dout.view(B, T, N, C), Y=out.view(B, T, N, C)).view(-1, C)
-    ops.tmix_dgraph(dR.view(B, T, N, C), x.view(B, T, N, C), out=dG_out)
+    if C == 64:
+        dx = ops.hypertem_bwd(dout.view(B, T, N, C), out.view(B, T, N, C), x.view(B, T, N, C), G, Wbt, dbias, dG_out).view(-1, C)
+    else:
+        dR = ops.apply(dout, Wbt, MODE_TIME, BT, N, A2=out, transw=True, pro=PRO_DPRE, colsum=dbias)
+        dx = ops.tmix(dR.view(B, T, N, C), G, dOut=dout.view(B, T, N, C), Y=out.view(B, T, N, C)).view(-1, C)
+        dG_out.zero_()
+        ops.tmix_dgraph(dR.view(B, T, N, C), x.view(B, T, N, C), out=dG_out)
     return dx, (dWbt, ns, dbias)
 
 
@@ -201,7 +205,7 @@ def sthcn_bwd(p, g, pfx, tidx, sv, dout, dims):
     ne, nes = p[pfx + "node_embeddings"], p[pfx + "node_embeddings_spg"]
     dne, dnes = g[pfx + "node_embeddings"], g[pfx + "node_embeddings_spg"]
     d_te, d_teb, d_tes = _zeros(time_eb, *time_eb.shape), _zeros(teb, *teb.shape), _zeros(tes, *tes.shape)
-    dG_all = torch.empty(4, N, T, T, device=dout.device)
+    dG_all = _zeros(dout, 4, N, T, T)
     dd, hp4 = hypertem_core_bwd(sv["h4"], dout, dG_all[3], dims)
     dd, cp2 = cap_core_bwd(p, g, cps[1], sv["c2"], dd, dims, HS, HT)
     dd, hp3 = hypertem_core_bwd(sv["h3"], dd, dG_all[2], dims)

@@ -180,6 +180,16 @@ def hypertem_fwd(X, G, Wbt, bbt):
     return R, out
 
 
+def hypertem_bwd(dOut, Y, X, G, Wbt, dbias, dG):
+    """Fused hyperTem backward: returns dX; accumulates dbias (BT,C) and dG (N,T,T)."""
+    _chk(dOut, Y, X, G, Wbt, dbias, dG)
+    B, T, N, C = X.shape
+    dX = torch.empty_like(X)
+    _call("gptst_hypertem_bwd", _p(dOut), _p(Y), _p(X), _p(G), _p(Wbt), _p(dX), _p(dbias), _p(dG), B, T, N, C,
+          nbytes=_nb(dOut, Y, X, G, Wbt, dX, dbias, dG))
+    return dX
+
+
 def tmix_dgraph(dR, X, out=None):
     _chk(dR, X, out)
     B, T, N, C = X.shape

@@ -84,6 +84,11 @@ int gptst_tmix_dgraph(const float* dR, const float* X, float* dG, int B, int T, 
 int gptst_hypertem_fwd(const float* X, const float* G, const float* Wbt, const float* bbt, float* R_out, float* out, int B, int T,
                        int N, int C, void* stream);
 
+/* fused hyperTem backward w.r.t. data and graph: dX = dPre + G (*) (dPre W_bt^T), dbias[b,t,:] += sum_n dPre, dG[n] += dR X^T,
+ * dPre = dOut*lrelu'(Y).  (The weight gradient stays in gptst_wgrad.)  C = 64. */
+int gptst_hypertem_bwd(const float* dOut, const float* Y, const float* X, const float* G, const float* Wbt, float* dX, float* dbias,
+                       float* dG, int B, int T, int N, int C, void* stream);
+
 /* ---- cap: node x cluster soft assignment + routing + aggregation (cap.hip, cap_cross.hip), GPTST.py:100-141 ----
  * route_fwd, one workgroup per (b,t):  P = squash(X Wp^T + bp) by MFMA into LDS; dadj (BT,HS,N) = teb.adj (from gptst_poolgen_fwd);
  *   v0 = squash(softmax_h(dadj) P);  R x { c = softmax_h(b); v = squash(v0 (.) c P); b += v P^T }  (both contractions on MFMA 16x16x4);
