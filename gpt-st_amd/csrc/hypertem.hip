@@ -13,19 +13,31 @@ int g_ht_dbg = 0;
 extern "C" int gptst_ht_dbg(int v) { g_ht_dbg = v; return 0; }
 extern "C" int gptst_ht_ts(long long* out) { return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_ht_ts), sizeof(long long) * 64); }
 
+// XCD-aware work map: workgroup L runs on XCD L % 8 (observed dispatch order), and all node tiles of one sample should share an
+// XCD so that the sample's twelve W_bt matrices (192 KB) are fetched into ONE L2 instead of eight (PMC: 67 MB -> expected ~23 MB
+// of fabric reads per launch).  L -> xcd = L % 8, slot = L / 8;  sample = xcd + 8 * (slot / ntiles), tile = slot % ntiles.
+__device__ __forceinline__ bool ht_work(int ntiles, int B, int& b, int& tile) {
+    const int L = blockIdx.x, xcd = L & 7, slot = L >> 3;
+    b = xcd + 8 * (slot / ntiles);
+    tile = slot % ntiles;
+    return b < B;
+}
+
 template <int C>
 __global__ __launch_bounds__(256, 2) void hypertem_fwd_kernel(const float* __restrict__ X, const float* __restrict__ G,
                                                               const float* __restrict__ Wbt, const float* __restrict__ bbt,
-                                                              float* __restrict__ R_out, float* __restrict__ out, int N, int dbg) {
+                                                              float* __restrict__ R_out, float* __restrict__ out, int N, int B, int dbg) {
     constexpr int P = C + 4, LPR = C / 4;
     int tsi = 0;
-#define TS() do { if (dbg && blockIdx.x == 3 && blockIdx.y == 7 && threadIdx.x == 0) g_ht_ts[tsi] = clock64(); ++tsi; } while (0)
+#define TS() do { if (dbg && blockIdx.x == 59 && threadIdx.x == 0) g_ht_ts[tsi] = clock64(); ++tsi; } while (0)
     TS();
     extern __shared__ __attribute__((aligned(16))) float smem[];
     float* Xs = smem;                               // [12][16][P]
     float* Gs = Xs + HT_T * 16 * P;                 // [16][144]
     float* Rt = Gs + 16 * 144;                      // [4 waves][16][P]
-    const int b = blockIdx.y, n0 = blockIdx.x * 16;
+    int b, tile;
+    if (!ht_work((N + 15) / 16, B, b, tile)) return;
+    const int n0 = tile * 16;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     for (int i = tid; i < HT_T * 16 * LPR; i += 256) {
         const int t = i / (16 * LPR), rem = i % (16 * LPR), nl = rem / LPR, c4 = rem % LPR;
@@ -105,7 +117,7 @@ extern "C" int gptst_hypertem_fwd(const float* X, const float* G, const float* W
     const size_t smem = ((size_t)HT_T * 16 * (C + 4) + 16 * 144 + 4 * 16 * (C + 4)) * sizeof(float);
     static int done = 0;
     if (!done) { hipFuncSetAttribute((const void*)hypertem_fwd_kernel<64>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem); done = 1; }
-    hipLaunchKernelGGL((hypertem_fwd_kernel<64>), dim3((N + 15) / 16, B), dim3(256), smem, (hipStream_t)stream, X, G, Wbt, bbt, R_out, out, N, g_ht_dbg);
+    hipLaunchKernelGGL((hypertem_fwd_kernel<64>), dim3(8 * ((B + 7) / 8) * ((N + 15) / 16)), dim3(256), smem, (hipStream_t)stream, X, G, Wbt, bbt, R_out, out, N, B, g_ht_dbg);
     GPTST_CHECK_LAUNCH();
     return GPTST_OK;
 }
@@ -124,12 +136,14 @@ template <int C>
 __global__ __launch_bounds__(256, 2) void hypertem_bwd_kernel(const float* __restrict__ dOut, const float* __restrict__ Y,
                                                               const float* __restrict__ X, const float* __restrict__ G,
                                                               const float* __restrict__ Wbt, float* __restrict__ dX,
-                                                              float* __restrict__ dbias, float* __restrict__ dG, int N) {
+                                                              float* __restrict__ dbias, float* __restrict__ dG, int N, int B) {
     constexpr int P = C + 4, LPR = C / 4;
     extern __shared__ __attribute__((aligned(16))) float smem[];
     float* Ds = smem;                               // [12][16][P]  dPre, then dR
     float* Gs = Ds + HT_T * 16 * P;                 // [16][144]
-    const int b = blockIdx.y, n0 = blockIdx.x * 16;
+    int b, tile;
+    if (!ht_work((N + 15) / 16, B, b, tile)) return;
+    const int n0 = tile * 16;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     for (int i = tid; i < HT_T * 16 * LPR; i += 256) {
         const int t = i / (16 * LPR), rem = i % (16 * LPR), nl = rem / LPR, c4 = rem % LPR;
@@ -237,7 +251,7 @@ extern "C" int gptst_hypertem_bwd(const float* dOut, const float* Y, const float
     const size_t smem = ((size_t)HT_T * 16 * (C + 4) + 16 * 144) * sizeof(float);
     static int done = 0;
     if (!done) { hipFuncSetAttribute((const void*)hypertem_bwd_kernel<64>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem); done = 1; }
-    hipLaunchKernelGGL((hypertem_bwd_kernel<64>), dim3((N + 15) / 16, B), dim3(256), smem, (hipStream_t)stream, dOut, Y, X, G, Wbt, dX, dbias, dG, N);
+    hipLaunchKernelGGL((hypertem_bwd_kernel<64>), dim3(8 * ((B + 7) / 8) * ((N + 15) / 16)), dim3(256), smem, (hipStream_t)stream, dOut, Y, X, G, Wbt, dX, dbias, dG, N, B);
     GPTST_CHECK_LAUNCH();
     return GPTST_OK;
 }

@@ -42,6 +42,50 @@ class ZeroArena:
 ARENA = None      # set by PretrainStep; None -> plain torch.zeros
 
 
+class SideStream:
+    """Weight-gradient kernels depend only on saved activations and the incoming gradient, and nothing needs their result
+    until the batched reductions at the end of an STHCN backward — so they run on a second HIP stream, concurrently with the
+    data-gradient chain on the main stream (fork/join with events; works inside hipGraph capture).  Tensors touched on the side
+    stream are kept alive until the join so the caching allocator cannot hand their memory out on the main stream."""
+
+    def __init__(self):
+        self.stream = torch.cuda.Stream()
+        self.pending = []
+        self.active = False
+
+    def fork(self):
+        self.stream.wait_stream(torch.cuda.current_stream())
+        self.active = True
+        return torch.cuda.stream(self.stream)
+
+    def keep(self, *ts):
+        self.pending.extend(ts)
+
+    def join(self):
+        if self.active:
+            torch.cuda.current_stream().wait_stream(self.stream)
+            self.active = False
+        self.pending = []
+
+
+SIDE = None       # set by PretrainStep (None -> everything on one stream)
+
+
+def _wgrad_async(*args, **kw):
+    """ops.wgrad on the side stream when one is installed."""
+    if SIDE is None:
+        return ops.wgrad(*args, **kw)
+    with SIDE.fork():
+        r = ops.wgrad(*args, **kw)
+    SIDE.keep(r[0], *[a for a in args if torch.is_tensor(a)], *[v for v in kw.values() if torch.is_tensor(v)])
+    return r
+
+
+def _join_side():
+    if SIDE is not None:
+        SIDE.join()
+
+
 def _zeros(ref, *shape):
     if ARENA is not None:
         return ARENA.zeros(*shape)
@@ -89,7 +133,7 @@ def hypertem_core_bwd(saved, dout, dG_out, dims):
     x, R, out, G, Wbt = saved
     BT = B * T
     dbias = _zeros(x, BT, C)
-    dWbt, ns = ops.wgrad(R, dout, MODE_TIME, BT, N, D2=out, pro=PRO_DPRE)
+    dWbt, ns = _wgrad_async(R, dout, MODE_TIME, BT, N, D2=out, pro=PRO_DPRE)
     if C == 64:
         dx = ops.hypertem_bwd(dout.view(B, T, N, C), out.view(B, T, N, C), x.view(B, T, N, C), G, Wbt, dbias, dG_out).view(-1, C)
     else:
@@ -118,7 +162,7 @@ def cap_core_bwd(p, g, pfx, saved, dout, dims, HS, HT):
     BT, dev = B * T, x.device
     dbn = _zeros(x, N, C)
     drec = ops.apply(dout, Wn, MODE_NODE, BT, N, A2=out, transw=True, pro=PRO_DPRE, colsum=dbn)
-    dWn, ns = ops.wgrad(rec, dout, MODE_NODE, BT, N, D2=out, pro=PRO_DPRE)
+    dWn, ns = _wgrad_async(rec, dout, MODE_NODE, BT, N, D2=out, pro=PRO_DPRE)
     dc1, dv = ops.cap_rec_bwd(drec, c, v)
     dS, ddyn = ops.cap_cross_bwd(dv, s, Rt, Ht, dyn, p[pfx + "mask_template"], B, T, HS, HT)
     dY, dlogit = ops.cap_route_bwd(x.view(B, T, N, C), p[pfx + "ln_p.weight"], p[pfx + "ln_p.bias"], c, dc1, dS)
@@ -212,6 +256,7 @@ def sthcn_bwd(p, g, pfx, tidx, sv, dout, dims):
     dd, hp2 = hypertem_core_bwd(sv["h2"], dd, dG_all[1], dims)
     dd, cp1 = cap_core_bwd(p, g, cps[0], sv["c1"], dd, dims, HS, HT)
     dd, hp1 = hypertem_core_bwd(sv["h1"], dd, dG_all[0], dims)
+    _join_side()
     # ---- gradient reductions of all generated parameters, batched: 11 launches (was 32) ----
     hps = (hp1, hp2, hp3, hp4)
     dWs = [t for hp in hps for t in (hp[0], hp[2])]
