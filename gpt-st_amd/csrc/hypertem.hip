@@ -11,6 +11,9 @@
 __device__ long long g_ht_ts[64];
 int g_ht_dbg = 0;
 extern "C" int gptst_ht_dbg(int v) { g_ht_dbg = v; return 0; }
+int g_ht_fwd_variant = 0, g_ht_bwd_variant = 0;
+extern int g_ht_nt_override;
+extern "C" int gptst_ht_variant(int fwd, int bwd) { g_ht_nt_override = fwd; g_ht_bwd_variant = bwd; return 0; }
 extern "C" int gptst_ht_ts(long long* out) { return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_ht_ts), sizeof(long long) * 64); }
 
 // XCD-aware work map: workgroup L runs on XCD L % 8 (observed dispatch order), and all node tiles of one sample should share an
@@ -23,101 +26,132 @@ __device__ __forceinline__ bool ht_work(int ntiles, int B, int& b, int& tile) {
     return b < B;
 }
 
-template <int C>
+// NT (rows of the 16-row MFMA tile that are real nodes) is a run-time parameter for experiments: at (B, N) = (32, 170) the time
+// is flat for NT = 11..16 (352..512 workgroups) and 35 % worse for NT <= 10 — the MFMA / fragment work per tile does not shrink.
+int g_ht_nt_override = 0;
+static int ht_pick_nt(int B, int N) {
+    if (g_ht_nt_override >= 4 && g_ht_nt_override <= 16) return g_ht_nt_override;
+    (void)B; (void)N;
+    return 16;     // measured flat for NT = 11..16 at (32, 170): the per-tile MFMA / fragment cost does not shrink with NT
+}
+
 __global__ __launch_bounds__(256, 2) void hypertem_fwd_kernel(const float* __restrict__ X, const float* __restrict__ G,
                                                               const float* __restrict__ Wbt, const float* __restrict__ bbt,
-                                                              float* __restrict__ R_out, float* __restrict__ out, int N, int B, int dbg) {
-    constexpr int P = C + 4, LPR = C / 4;
+                                                              float* __restrict__ R_out, float* __restrict__ out, int N, int B, int NT,
+                                                              int dbg) {
+    constexpr int C = 64, P = C + 4, GP = 145;
     int tsi = 0;
-#define TS() do { if (dbg && blockIdx.x == 59 && threadIdx.x == 0) g_ht_ts[tsi] = clock64(); ++tsi; } while (0)
+#define TS() do { if ((dbg & 1) && blockIdx.x == 59 && threadIdx.x == 0) g_ht_ts[tsi] = clock64(); ++tsi; } while (0)
     TS();
     extern __shared__ __attribute__((aligned(16))) float smem[];
-    float* Xs = smem;                               // [12][16][P]
-    float* Gs = Xs + HT_T * 16 * P;                 // [16][144]
-    float* Rt = Gs + 16 * 144;                      // [4 waves][16][P]
+    float* Xs = smem;                               // [12][NT][P]
+    float* Gs = Xs + HT_T * NT * P;                 // [NT][GP]  (pitch 145: the 16 rows of a mix step hit 16 different banks)
     int b, tile;
-    if (!ht_work((N + 15) / 16, B, b, tile)) return;
-    const int n0 = tile * 16;
+    if (!ht_work((N + NT - 1) / NT, B, b, tile)) return;
+    const int n0 = tile * NT;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    for (int i = tid; i < HT_T * 16 * LPR; i += 256) {
-        const int t = i / (16 * LPR), rem = i % (16 * LPR), nl = rem / LPR, c4 = rem % LPR;
-        const int n = n0 + nl;
-        st4(Xs + (t * 16 + nl) * P + 4 * c4, n < N ? ld4(X + (((size_t)b * HT_T + t) * N + n) * C + 4 * c4) : f4zero());
+    {   // slab + graph staging: ALL global loads are issued before the first LDS store (a plain `for (i = tid; ...) lds[i] = glb[i]`
+        // loop compiles to load -> s_waitcnt vmcnt(0) -> ds_write per trip: 21 serialised L2 round trips, 1/3 of the kernel)
+        const int nl = tid >> 4, c4 = tid & 15;     // thread = (row, float4 column) of every time slice
+        const int n = min(n0 + nl, N - 1);
+        float4 v[HT_T];
+        float gv[9];
+#pragma unroll
+        for (int t = 0; t < HT_T; ++t) v[t] = ld4(X + (((size_t)b * HT_T + t) * N + n) * C + 4 * c4);
+#pragma unroll
+        for (int k = 0; k < 9; ++k) gv[k] = G[min(n0 * 144 + tid + k * 256, N * 144 - 1)];
+        if (nl < NT) {
+#pragma unroll
+            for (int t = 0; t < HT_T; ++t) st4(Xs + (t * NT + nl) * P + 4 * c4, n0 + nl < N ? v[t] : f4zero());
+        }
+#pragma unroll
+        for (int k = 0; k < 9; ++k) {
+            const int i = tid + k * 256;
+            if (i < NT * 144) Gs[(i / 144) * GP + i % 144] = (n0 + i / 144 < N) ? gv[k] : 0.f;
+        }
     }
-    for (int i = tid; i < 16 * 144; i += 256) Gs[i] = (n0 + i / 144 < N) ? G[(size_t)n0 * 144 + i] : 0.f;
     __syncthreads();
     TS();
-    float* rt = Rt + wave * 16 * P;
-    const int c4 = lane % LPR, nb = lane / LPR;              // VALU / epilogue mapping: LPR lanes per row
-    const int j = lane & 15, kk = lane >> 4;                 // MFMA mapping
-    constexpr int ROWS_PER_PASS = 64 / LPR;
+    const int j = lane & 15, kk = lane >> 4;                 // MFMA mapping: A row / D column j, k-slice kk
+    const int ja = j < NT ? j : 0;                           // A-operand row (rows >= NT of the 16-row MFMA tile are don't-care)
+    // B fragments as float4: MFMA column tile ct, column j  <->  output channel 4j + ct, so one 16-byte load per (k) feeds the
+    // four column tiles (the dword version spent ~1000 TA cycles per time step on 64 loads) and the accumulators of a lane are
+    // four CONSECUTIVE channels of a row: the epilogue runs from registers.
+    // The fragments of the NEXT time step are requested right after the MFMAs of the current one, BEFORE its output stores:
+    // vmcnt retires in order on gfx9, so a load issued behind stores waits for their write acknowledgements.
+    float4 bv[C / 16][4];
+    float4 b4;
+#define HT_LOAD_W(tt) do {                                                                                         \
+        const float* W_ = Wbt + ((size_t)b * HT_T + (tt)) * C * C;                                                 \
+        _Pragma("unroll") for (int q = 0; q < C / 16; ++q)                                                         \
+            _Pragma("unroll") for (int e = 0; e < 4; ++e) bv[q][e] = ld4(W_ + (size_t)(16 * q + 4 * kk + e) * C + 4 * j); \
+        b4 = ld4(bbt + ((size_t)b * HT_T + (tt)) * C + 4 * j);                                                     \
+    } while (0)
+    HT_LOAD_W(wave);
     for (int t = wave; t < HT_T; t += 4) {
         const size_t g = (size_t)b * HT_T + t;
-        // W_bt fragments for the whole time step are requested from L2 FIRST so their latency hides behind the temporal mix
-        const float* W = Wbt + g * C * C;
-        float bv[C / 16][4][C / 16];
-#pragma unroll
-        for (int q = 0; q < C / 16; ++q)
-#pragma unroll
-            for (int e = 0; e < 4; ++e)
-#pragma unroll
-                for (int ct = 0; ct < C / 16; ++ct) bv[q][e][ct] = W[(size_t)(16 * q + 4 * kk + e) * C + 16 * ct + j];
         TS();
-        // ---- (1) temporal mix ----
+        // ---- (1) temporal mix, computed directly in the MFMA A-operand layout: lane (j, kk) owns R_t[row j][16q + 4kk .. +3] ----
+        float4 a4[C / 16];
 #pragma unroll
-        for (int i = 0; i < 16 / ROWS_PER_PASS; ++i) {
-            const int nl = nb + ROWS_PER_PASS * i;
-            float4 acc = f4zero();
-            const float* gr = Gs + nl * 144 + t * HT_T;
+        for (int q = 0; q < C / 16; ++q) a4[q] = f4zero();
+        {
+            const float* gr = Gs + ja * GP + t * HT_T;
+            const float* xr = Xs + ja * P + 4 * kk;
 #pragma unroll
-            for (int u = 0; u < HT_T; ++u) acc = f4fma(gr[u], ld4(Xs + (u * 16 + nl) * P + 4 * c4), acc);
-            st4(rt + nl * P + 4 * c4, acc);
-            if (n0 + nl < N) st4(R_out + (g * N + n0 + nl) * C + 4 * c4, acc);
+            for (int u = 0; u < HT_T; ++u) {
+                const float gu = gr[u];
+#pragma unroll
+                for (int q = 0; q < C / 16; ++q) a4[q] = f4fma(gu, ld4(xr + u * NT * P + 16 * q), a4[q]);
+            }
+        }
+        if (j < NT && n0 + j < N) {
+#pragma unroll
+            for (int q = 0; q < C / 16; ++q) st4(R_out + (g * N + n0 + j) * C + 16 * q + 4 * kk, a4[q]);
         }
         TS();
-        // ---- (2) R_t @ W_bt on MFMA 16x16x4: A = R_t (LDS), B = W_bt fragments (registers) ----
+        // ---- (2) R_t @ W_bt on MFMA 16x16x4: A = R_t (registers), B = W_bt fragments (registers) ----
         f32x4 acc[C / 16];
 #pragma unroll
         for (int ct = 0; ct < C / 16; ++ct) acc[ct] = (f32x4){0.f, 0.f, 0.f, 0.f};
-        float4 a4[C / 16];
-#pragma unroll
-        for (int q = 0; q < C / 16; ++q) a4[q] = ld4(rt + j * P + 16 * q + 4 * kk);
 #pragma unroll
         for (int q = 0; q < C / 16; ++q) {
             const float av[4] = {a4[q].x, a4[q].y, a4[q].z, a4[q].w};
 #pragma unroll
-            for (int e = 0; e < 4; ++e)
-#pragma unroll
-                for (int ct = 0; ct < C / 16; ++ct) acc[ct] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[e], bv[q][e][ct], acc[ct], 0, 0, 0);
+            for (int e = 0; e < 4; ++e) {
+                acc[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[e], bv[q][e].x, acc[0], 0, 0, 0);
+                acc[1] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[e], bv[q][e].y, acc[1], 0, 0, 0);
+                acc[2] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[e], bv[q][e].z, acc[2], 0, 0, 0);
+                acc[3] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[e], bv[q][e].w, acc[3], 0, 0, 0);
+            }
         }
         TS();
-        // ---- (3) epilogue through the wave's tile: rows of float4 ----
+        const float4 bias = b4;
+        if (t + 4 < HT_T) HT_LOAD_W(t + 4);
+        // ---- (3) epilogue from registers: lane (j, kk) owns rows kk*4 + r, channels 4j .. 4j+3 ----
 #pragma unroll
-        for (int ct = 0; ct < C / 16; ++ct)
-#pragma unroll
-            for (int r = 0; r < 4; ++r) rt[(kk * 4 + r) * P + 16 * ct + j] = acc[ct][r];
-        const float4 b4 = ld4(bbt + g * C + 4 * c4);
-#pragma unroll
-        for (int i = 0; i < 16 / ROWS_PER_PASS; ++i) {
-            const int nl = nb + ROWS_PER_PASS * i;
-            if (n0 + nl < N) {
-                float4 y = f4add(f4add(ld4(rt + nl * P + 4 * c4), b4), ld4(Xs + (t * 16 + nl) * P + 4 * c4));
+        for (int r = 0; r < 4; ++r) {
+            const int nl = kk * 4 + r;
+            if (nl < NT && n0 + nl < N) {
+                float4 y = f4add(f4add(make_float4(acc[0][r], acc[1][r], acc[2][r], acc[3][r]), bias), ld4(Xs + (t * NT + nl) * P + 4 * j));
                 y.x = lrelu(y.x); y.y = lrelu(y.y); y.z = lrelu(y.z); y.w = lrelu(y.w);
-                st4(out + (g * N + n0 + nl) * C + 4 * c4, y);
+                st4(out + (g * N + n0 + nl) * C + 4 * j, y);
             }
         }
         TS();
     }
 }
 
+static size_t ht_smem(int NT) { return ((size_t)HT_T * NT * 68 + NT * 145) * sizeof(float); }
+
 extern "C" int gptst_hypertem_fwd(const float* X, const float* G, const float* Wbt, const float* bbt, float* R_out, float* out, int B,
                                   int T, int N, int C, void* stream) {
     if (!X || !G || !Wbt || !bbt || !R_out || !out || T != HT_T) return GPTST_EARG;
     if (C != 64) return GPTST_ESHAPE;
-    const size_t smem = ((size_t)HT_T * 16 * (C + 4) + 16 * 144 + 4 * 16 * (C + 4)) * sizeof(float);
     static int done = 0;
-    if (!done) { hipFuncSetAttribute((const void*)hypertem_fwd_kernel<64>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem); done = 1; }
-    hipLaunchKernelGGL((hypertem_fwd_kernel<64>), dim3(8 * ((B + 7) / 8) * ((N + 15) / 16)), dim3(256), smem, (hipStream_t)stream, X, G, Wbt, bbt, R_out, out, N, B, g_ht_dbg);
+    if (!done) { hipFuncSetAttribute((const void*)hypertem_fwd_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ht_smem(16)); done = 1; }
+    const int NT = ht_pick_nt(B, N);
+    hipLaunchKernelGGL(hypertem_fwd_kernel, dim3(8 * ((B + 7) / 8) * ((N + NT - 1) / NT)), dim3(256), ht_smem(NT), (hipStream_t)stream, X, G, Wbt, bbt, R_out, out, N, B, NT, g_ht_dbg);
     GPTST_CHECK_LAUNCH();
     return GPTST_OK;
 }
@@ -132,46 +166,63 @@ extern "C" int gptst_hypertem_fwd(const float* X, const float* G, const float* W
 //   dG_n[t,u] += sum_c dR_t[n,c] X_u[n,c]                   MFMA 16x16x4 per node, 32 atomics per address (one per sample)
 // Replaces apply_kernel<TIME, dPre> + tmix_kernel<bwd> + tmix_dgraph_kernel (19 + 14 + 11 us, and the dR round trip).
 // =====================================================================================================================
-template <int C>
+// Scheduling notes (measured): all global loads of a phase are issued as one batch into registers (a copy loop
+// compiles to one L2 round trip per trip); dPre stays in registers for the dX phase instead of being re-read; W_bt fragments of
+// the next time step and the X operands of the dG phase are requested before the stores / atomics of the current phase.
 __global__ __launch_bounds__(256, 2) void hypertem_bwd_kernel(const float* __restrict__ dOut, const float* __restrict__ Y,
                                                               const float* __restrict__ X, const float* __restrict__ G,
                                                               const float* __restrict__ Wbt, float* __restrict__ dX,
                                                               float* __restrict__ dbias, float* __restrict__ dG, int N, int B) {
-    constexpr int P = C + 4, LPR = C / 4;
+    constexpr int C = 64, P = C + 4, GP = 145, NT = 16;
     extern __shared__ __attribute__((aligned(16))) float smem[];
     float* Ds = smem;                               // [12][16][P]  dPre, then dR
-    float* Gs = Ds + HT_T * 16 * P;                 // [16][144]
+    float* Gs = Ds + HT_T * NT * P;                 // [16][GP]
     int b, tile;
-    if (!ht_work((N + 15) / 16, B, b, tile)) return;
-    const int n0 = tile * 16;
+    if (!ht_work((N + NT - 1) / NT, B, b, tile)) return;
+    const int n0 = tile * NT;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    for (int i = tid; i < HT_T * 16 * LPR; i += 256) {
-        const int t = i / (16 * LPR), rem = i % (16 * LPR), nl = rem / LPR, c4 = rem % LPR;
-        const int n = n0 + nl;
-        float4 v = f4zero();
-        if (n < N) {
-            const size_t off = (((size_t)b * HT_T + t) * N + n) * C + 4 * c4;
-            const float4 d = ld4(dOut + off), y = ld4(Y + off);
-            v = make_float4(d.x * lrelu_grad_from_out(y.x), d.y * lrelu_grad_from_out(y.y), d.z * lrelu_grad_from_out(y.z),
-                            d.w * lrelu_grad_from_out(y.w));
+    const int nl = tid >> 4, c4 = tid & 15;         // thread = (row, float4 column) of every time slice
+    const bool valid = n0 + nl < N;
+    const size_t rowoff = ((size_t)b * HT_T * N + min(n0 + nl, N - 1)) * C + 4 * c4;     // + t * N * C
+    float4 dp[HT_T];
+    {
+        float4 yv[HT_T];
+        float gv[9];
+#pragma unroll
+        for (int t = 0; t < HT_T; ++t) { dp[t] = ld4(dOut + rowoff + (size_t)t * N * C); yv[t] = ld4(Y + rowoff + (size_t)t * N * C); }
+#pragma unroll
+        for (int k = 0; k < 9; ++k) gv[k] = G[min(n0 * 144 + tid + k * 256, N * 144 - 1)];
+#pragma unroll
+        for (int t = 0; t < HT_T; ++t) {
+            float4 v = make_float4(dp[t].x * lrelu_grad_from_out(yv[t].x), dp[t].y * lrelu_grad_from_out(yv[t].y),
+                                   dp[t].z * lrelu_grad_from_out(yv[t].z), dp[t].w * lrelu_grad_from_out(yv[t].w));
+            if (!valid) v = f4zero();
+            dp[t] = v;
+            st4(Ds + (t * NT + nl) * P + 4 * c4, v);
         }
-        st4(Ds + (t * 16 + nl) * P + 4 * c4, v);
+#pragma unroll
+        for (int k = 0; k < 9; ++k) {
+            const int i = tid + k * 256;
+            Gs[(i / 144) * GP + i % 144] = (n0 + i / 144 < N) ? gv[k] : 0.f;
+        }
     }
-    for (int i = tid; i < 16 * 144; i += 256) Gs[i] = (n0 + i / 144 < N) ? G[(size_t)n0 * 144 + i] : 0.f;
     __syncthreads();
     const int j = lane & 15, kk = lane >> 4;
+    // dR_t^T (C x 16) = W_bt (C x C) dPre_t^T:  A[i][kk=o] = W[i][o] (global float4 rows), B[kk=o][j=n] = dPre_t[n][o] (LDS)
+    float4 aq[C / 16][C / 16];
+#define HT_LOAD_WT(tt) do {                                                                                         \
+        const float* W_ = Wbt + ((size_t)b * HT_T + (tt)) * C * C;                                                  \
+        _Pragma("unroll") for (int it = 0; it < C / 16; ++it)                                                       \
+            _Pragma("unroll") for (int q = 0; q < C / 16; ++q) aq[it][q] = ld4(W_ + (size_t)(it * 16 + j) * C + 16 * q + 4 * kk); \
+    } while (0)
+    HT_LOAD_WT(wave);
     for (int t = wave; t < HT_T; t += 4) {
         const size_t g = (size_t)b * HT_T + t;
-        float* dt = Ds + t * 16 * P;
-        // bias gradient: column sums of dPre_t over the 16 nodes
-        for (int c = lane; c < C; c += 64) {
-            float s = 0.f;
+        float* dt = Ds + t * NT * P;
+        // bias gradient: column sums of dPre_t over the 16 nodes (lane = channel)
+        float s = 0.f;
 #pragma unroll
-            for (int nl = 0; nl < 16; ++nl) s += dt[nl * P + c];
-            atomicAdd(dbias + g * C + c, s);
-        }
-        // dR_t^T (C x 16) = W_bt (C x C) dPre_t^T:  A[i][kk=o] = W[i][o] (global float4 rows), B[kk=o][j=n] = dPre_t[n][o] (LDS)
-        const float* W = Wbt + g * C * C;
+        for (int r = 0; r < NT; ++r) s += dt[r * P + lane];
         float4 bq[C / 16];
 #pragma unroll
         for (int q = 0; q < C / 16; ++q) bq[q] = ld4(dt + j * P + 16 * q + 4 * kk);
@@ -179,57 +230,55 @@ __global__ __launch_bounds__(256, 2) void hypertem_bwd_kernel(const float* __res
 #pragma unroll
         for (int it = 0; it < C / 16; ++it) {
             acc[it] = (f32x4){0.f, 0.f, 0.f, 0.f};
-            float4 aq[C / 16];
-#pragma unroll
-            for (int q = 0; q < C / 16; ++q) aq[q] = ld4(W + (size_t)(it * 16 + j) * C + 16 * q + 4 * kk);
 #pragma unroll
             for (int q = 0; q < C / 16; ++q) {
-                acc[it] = __builtin_amdgcn_mfma_f32_16x16x4f32(aq[q].x, bq[q].x, acc[it], 0, 0, 0);
-                acc[it] = __builtin_amdgcn_mfma_f32_16x16x4f32(aq[q].y, bq[q].y, acc[it], 0, 0, 0);
-                acc[it] = __builtin_amdgcn_mfma_f32_16x16x4f32(aq[q].z, bq[q].z, acc[it], 0, 0, 0);
-                acc[it] = __builtin_amdgcn_mfma_f32_16x16x4f32(aq[q].w, bq[q].w, acc[it], 0, 0, 0);
+                acc[it] = __builtin_amdgcn_mfma_f32_16x16x4f32(aq[it][q].x, bq[q].x, acc[it], 0, 0, 0);
+                acc[it] = __builtin_amdgcn_mfma_f32_16x16x4f32(aq[it][q].y, bq[q].y, acc[it], 0, 0, 0);
+                acc[it] = __builtin_amdgcn_mfma_f32_16x16x4f32(aq[it][q].z, bq[q].z, acc[it], 0, 0, 0);
+                acc[it] = __builtin_amdgcn_mfma_f32_16x16x4f32(aq[it][q].w, bq[q].w, acc[it], 0, 0, 0);
             }
         }
+        if (t + 4 < HT_T) HT_LOAD_WT(t + 4);
+        atomicAdd(dbias + g * C + lane, s);
         // D reg r: row i = it*16 + kk*4 + r (input channel), col j = node  ->  dR_t[node][channel] over the slab
 #pragma unroll
         for (int it = 0; it < C / 16; ++it)
             st4(dt + j * P + it * 16 + kk * 4, make_float4(acc[it][0], acc[it][1], acc[it][2], acc[it][3]));
     }
     __syncthreads();
-    // ---- dX_u[n,:] = dPre_u[n,:] + sum_t G_n[t,u] dR_t[n,:] ----
-    {
-        const int c4 = tid % LPR, nb = tid / LPR;              // 256 threads = 16 rows x LPR lanes (C = 64)
-        for (int nl = nb; nl < 16; nl += 256 / LPR) {
-            const int n = n0 + nl;
-            if (n < N) {
-                float4 dr[HT_T];
+    // X operands of the dG phase (nodes wave, wave+4, ...): requested now, consumed after the dX phase
+    float4 xg[NT / 4][C / 16];
 #pragma unroll
-                for (int t = 0; t < HT_T; ++t) dr[t] = ld4(Ds + (t * 16 + nl) * P + 4 * c4);
+    for (int i = 0; i < NT / 4; ++i) {
+        const int n = min(n0 + wave + 4 * i, N - 1);
 #pragma unroll
-                for (int u = 0; u < HT_T; ++u) {
-                    const size_t off = (((size_t)b * HT_T + u) * N + n) * C + 4 * c4;
-                    const float4 d = ld4(dOut + off), y = ld4(Y + off);
-                    float4 acc = make_float4(d.x * lrelu_grad_from_out(y.x), d.y * lrelu_grad_from_out(y.y),
-                                             d.z * lrelu_grad_from_out(y.z), d.w * lrelu_grad_from_out(y.w));
+        for (int q = 0; q < C / 16; ++q)
+            xg[i][q] = j < HT_T ? ld4(X + (((size_t)b * HT_T + j) * N + n) * C + 16 * q + 4 * kk) : f4zero();
+    }
+    // ---- dX_u[n,:] = dPre_u[n,:] + sum_t G_n[t,u] dR_t[n,:]   (thread = (row nl, float4 column c4), dPre still in registers) ----
+    if (valid) {
+        float4 dr[HT_T];
 #pragma unroll
-                    for (int t = 0; t < HT_T; ++t) acc = f4fma(Gs[nl * 144 + t * HT_T + u], dr[t], acc);
-                    st4(dX + off, acc);
-                }
-            }
+        for (int t = 0; t < HT_T; ++t) dr[t] = ld4(Ds + (t * NT + nl) * P + 4 * c4);
+        const float* gr = Gs + nl * GP;
+#pragma unroll
+        for (int u = 0; u < HT_T; ++u) {
+            float4 acc = dp[u];
+#pragma unroll
+            for (int t = 0; t < HT_T; ++t) acc = f4fma(gr[t * HT_T + u], dr[t], acc);
+            st4(dX + rowoff + (size_t)u * N * C, acc);
         }
     }
-    // ---- dG_n[t,u] += sum_c dR_t[n,c] X_u[n,c]:  A[i=t][kk=c] = dR (LDS), B[kk=c][j=u] = X (global) ----
-    for (int nl = wave; nl < 16; nl += 4) {
-        const int n = n0 + nl;
+    // ---- dG_n[t,u] += sum_c dR_t[n,c] X_u[n,c]:  A[i=t][kk=c] = dR (LDS), B[kk=c][j=u] = X (registers) ----
+#pragma unroll
+    for (int i = 0; i < NT / 4; ++i) {
+        const int nn = wave + 4 * i, n = n0 + nn;
         if (n >= N) continue;                                  // wave-uniform
         f32x4 acc = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
         for (int q = 0; q < C / 16; ++q) {
-            float4 a = f4zero(), x = f4zero();
-            if (j < HT_T) {
-                a = ld4(Ds + (j * 16 + nl) * P + 16 * q + 4 * kk);
-                x = ld4(X + (((size_t)b * HT_T + j) * N + n) * C + 16 * q + 4 * kk);
-            }
+            const float4 a = j < HT_T ? ld4(Ds + (j * NT + nn) * P + 16 * q + 4 * kk) : f4zero();
+            const float4 x = xg[i][q];
             acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a.x, x.x, acc, 0, 0, 0);
             acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a.y, x.y, acc, 0, 0, 0);
             acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a.z, x.z, acc, 0, 0, 0);
@@ -248,10 +297,10 @@ extern "C" int gptst_hypertem_bwd(const float* dOut, const float* Y, const float
                                   float* dbias, float* dG, int B, int T, int N, int C, void* stream) {
     if (!dOut || !Y || !X || !G || !Wbt || !dX || !dbias || !dG || T != HT_T) return GPTST_EARG;
     if (C != 64) return GPTST_ESHAPE;
-    const size_t smem = ((size_t)HT_T * 16 * (C + 4) + 16 * 144) * sizeof(float);
+    const size_t smem = ht_smem(16);
     static int done = 0;
-    if (!done) { hipFuncSetAttribute((const void*)hypertem_bwd_kernel<64>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem); done = 1; }
-    hipLaunchKernelGGL((hypertem_bwd_kernel<64>), dim3(8 * ((B + 7) / 8) * ((N + 15) / 16)), dim3(256), smem, (hipStream_t)stream, dOut, Y, X, G, Wbt, dX, dbias, dG, N, B);
+    if (!done) { hipFuncSetAttribute((const void*)hypertem_bwd_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem); done = 1; }
+    hipLaunchKernelGGL(hypertem_bwd_kernel, dim3(8 * ((B + 7) / 8) * ((N + 15) / 16)), dim3(256), smem, (hipStream_t)stream, dOut, Y, X, G, Wbt, dX, dbias, dG, N, B);
     GPTST_CHECK_LAUNCH();
     return GPTST_OK;
 }
