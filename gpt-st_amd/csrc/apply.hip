@@ -71,7 +71,7 @@ __global__ __launch_bounds__(256) void apply_kernel(const float* __restrict__ A,
     };
     fetch_a(t);
     TS();
-    load_w_lds<C>(Wl, W + (size_t)g * w_gstride, transw, tid, 256);
+    load_w_lds<C, 256>(Wl, W + (size_t)g * w_gstride, transw, tid);
     __syncthreads();
     TS();
 
@@ -161,72 +161,75 @@ __global__ __launch_bounds__(256) void apply_kernel(const float* __restrict__ A,
     }
 }
 
-// C = 64 weight gradient with the row range split over the 4 waves: every wave accumulates all four 32x32 output tiles
-// over its quarter of the rows (4 operand loads per 4 MFMAs, k-loop unrolled so ~16 loads are in flight), then the waves
-// are folded through LDS and the 64x64 result is stored with coalesced float4 rows.
-template <int PRO>
-__global__ __launch_bounds__(256) void wgrad64_kernel(const float* __restrict__ A, const float* __restrict__ D,
-                                                      const float* __restrict__ D2, float* __restrict__ dW, RowMap rm,
-                                                      int rows_per_split, int ostride, int csa) {
+// C = 64 weight gradient on fp32 MFMA 16x16x4, operands straight from global memory as float4:
+//   lane (j, kk) of k-step s loads row m = m0 + 4s + kk, channels 4j..4j+3 of A and of D: one instruction covers four whole
+//   256-byte rows (the 32x32x2 version needed dword loads: 4x the load instructions, 128-byte pieces).  Component ca of the
+//   A fragment and cb of the D fragment feed accumulator tile (ca, cb), whose MFMA index i / j stands for channel 4i+ca / 4j+cb:
+//   the permutation is undone for free when the tile is written (a lane owns four CONSECUTIVE output columns of a row).
+// The row range of a group is split over the 4 waves, folded through LDS, and stored as coalesced float4 rows.
+template <int PRO, int U>
+__global__ __launch_bounds__(256, 2) void wgrad64_kernel(const float* __restrict__ A, const float* __restrict__ D,
+                                                         const float* __restrict__ D2, float* __restrict__ dW, RowMap rm,
+                                                         int rows_per_split, int ostride, int csa) {
     constexpr int C = 64;
-    __shared__ float red[4][C * C];
-    __shared__ float csred[4][C];
-    float sa0 = 0.f, sa1 = 0.f;
+    __shared__ __attribute__((aligned(16))) float red[4][C * C];
+    __shared__ __attribute__((aligned(16))) float csred[4][C];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int j = lane & 31, h = lane >> 5;
+    const int j = lane & 15, kk = lane >> 4;
     const int g = blockIdx.x, sp = blockIdx.y;
     const int mbeg0 = sp * rows_per_split;
     const int mend0 = min(rm.M, mbeg0 + rows_per_split);
-    int q = (mend0 - mbeg0 + 3) / 4;
-    q = (q + 1) & ~1;
+    const int q = (mend0 - mbeg0 + 3) / 4;
     const int mbeg = mbeg0 + wave * q, mend = min(mend0, mbeg + q);
-    f32x16 acc[2][2];
+    f32x4 acc[4][4];
 #pragma unroll
-    for (int a = 0; a < 2; ++a)
+    for (int ca = 0; ca < 4; ++ca)
 #pragma unroll
-        for (int b = 0; b < 2; ++b)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
-    constexpr int U = 8;                               // 8 k-steps = 48 operand loads in flight per wave (memory-latency bound otherwise)
-    for (int m0 = mbeg; m0 < mend; m0 += 2 * U) {
-        float a0[U], a1[U], d0[U], d1[U];
+        for (int cb = 0; cb < 4; ++cb) acc[ca][cb] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    float4 sa = f4zero();
+    // U = k-steps (of 4 rows) per batch of loads (2-3 float4 per step in flight per lane); the launcher picks 4 or 6 so that the
+    // wave's step count divides evenly (measured: TIME 11 steps 13.5 us either way, NODE 6 steps 13.7 vs 16.8, SHARED 16 steps 10.5 vs 13.0)
+    for (int m0 = mbeg; m0 < mend; m0 += 4 * U) {
+        float4 a[U], d[U], y[U];
 #pragma unroll
         for (int u = 0; u < U; ++u) {
-            const int m = m0 + 2 * u + h;
-            a0[u] = a1[u] = d0[u] = d1[u] = 0.f;
-            if (m < mend) {
-                const size_t off = ((size_t)g * rm.rs_g + (size_t)m * rm.rs_m) * C;
-                a0[u] = A[off + j]; a1[u] = A[off + 32 + j];
-                d0[u] = D[off + j]; d1[u] = D[off + 32 + j];
-                if (PRO == PRO_DPRE) { d0[u] *= lrelu_grad_from_out(D2[off + j]); d1[u] *= lrelu_grad_from_out(D2[off + 32 + j]); }
-            }
-            sa0 += a0[u]; sa1 += a1[u];
+            const int m = min(m0 + 4 * u + kk, mend - 1);                        // clamped: out-of-range rows are zeroed below
+            const size_t off = ((size_t)g * rm.rs_g + (size_t)m * rm.rs_m) * C + 4 * j;
+            a[u] = ld4(A + off); d[u] = ld4(D + off);
+            if (PRO == PRO_DPRE) y[u] = ld4(D2 + off);
         }
 #pragma unroll
         for (int u = 0; u < U; ++u) {
-            acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0[u], d0[u], acc[0][0], 0, 0, 0);
-            acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0[u], d1[u], acc[0][1], 0, 0, 0);
-            acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1[u], d0[u], acc[1][0], 0, 0, 0);
-            acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1[u], d1[u], acc[1][1], 0, 0, 0);
+            if (m0 + 4 * u + kk >= mend) a[u] = f4zero();
+            if (PRO == PRO_DPRE) {
+                d[u].x *= lrelu_grad_from_out(y[u].x); d[u].y *= lrelu_grad_from_out(y[u].y);
+                d[u].z *= lrelu_grad_from_out(y[u].z); d[u].w *= lrelu_grad_from_out(y[u].w);
+            }
+            sa = f4add(sa, a[u]);
+            const float av[4] = {a[u].x, a[u].y, a[u].z, a[u].w}, dv[4] = {d[u].x, d[u].y, d[u].z, d[u].w};
+#pragma unroll
+            for (int ca = 0; ca < 4; ++ca)
+#pragma unroll
+                for (int cb = 0; cb < 4; ++cb) acc[ca][cb] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[ca], dv[cb], acc[ca][cb], 0, 0, 0);
         }
     }
+    // D reg r of tile (ca, cb): dW row 4*(kk*4 + r) + ca, columns 4j + cb
 #pragma unroll
-    for (int a = 0; a < 2; ++a)
+    for (int ca = 0; ca < 4; ++ca)
 #pragma unroll
-        for (int b = 0; b < 2; ++b)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int row = (r & 3) + 8 * (r >> 2) + 4 * h;
-                red[wave][(a * 32 + row) * C + b * 32 + j] = acc[a][b][r];
-            }
-    if (csa) {                                   // column sums of A (bias gradient of a shared Linear), folded over halves and waves
-        sa0 += __shfl_xor(sa0, 32, 64); sa1 += __shfl_xor(sa1, 32, 64);
-        if (h == 0) { csred[wave][j] = sa0; csred[wave][32 + j] = sa1; }
+        for (int r = 0; r < 4; ++r)
+            st4(&red[wave][(4 * (kk * 4 + r) + ca) * C + 4 * j], make_float4(acc[ca][0][r], acc[ca][1][r], acc[ca][2][r], acc[ca][3][r]));
+    if (csa) {                                   // column sums of A (bias gradient of a shared Linear), folded over row slots and waves
+        sa.x += __shfl_xor(sa.x, 16, 64); sa.y += __shfl_xor(sa.y, 16, 64); sa.z += __shfl_xor(sa.z, 16, 64); sa.w += __shfl_xor(sa.w, 16, 64);
+        sa.x += __shfl_xor(sa.x, 32, 64); sa.y += __shfl_xor(sa.y, 32, 64); sa.z += __shfl_xor(sa.z, 32, 64); sa.w += __shfl_xor(sa.w, 32, 64);
+        if (kk == 0) st4(&csred[wave][4 * j], sa);
     }
     __syncthreads();
     float* o = dW + ((size_t)sp * rm.G + g) * (size_t)ostride;
     if (csa && threadIdx.x < C) o[C * C + threadIdx.x] = csred[0][threadIdx.x] + csred[1][threadIdx.x] + csred[2][threadIdx.x] + csred[3][threadIdx.x];
-    for (int f = threadIdx.x; f < C * C / 4; f += 256) {
+#pragma unroll
+    for (int k = 0; k < C * C / 4 / 256; ++k) {
+        const int f = threadIdx.x + k * 256;
         const float4 s = f4add(f4add(ld4(&red[0][4 * f]), ld4(&red[1][4 * f])), f4add(ld4(&red[2][4 * f]), ld4(&red[3][4 * f])));
         st4(o + 4 * f, s);
     }
@@ -335,11 +338,14 @@ extern "C" int gptst_apply(const float* A, const float* A2, const float* W, int 
 }
 
 // dW has room for nsplit * G matrices; returns nsplit through *nsplit_out (consumers sum the splits).
+int g_wgrad_ns_override = 0;                           // experiments: gptst_tune(2, ns) forces the NODE-mode split
 extern "C" int gptst_wgrad_nsplit(int mode, int BT, int N) {
     RowMap rm = make_rowmap(mode, BT, N);
     if (mode == 2) return (rm.M + 255) / 256;          // shared weight: 256-row chunks
+    if (mode == 1 && g_wgrad_ns_override > 0) return g_wgrad_ns_override;
     if (rm.G >= 256) return 1;
-    int want = (512 + rm.G - 1) / rm.G;                // aim for >= 512 workgroups
+    int want = 512 / rm.G;                             // largest split that still fits ONE round of 2 workgroups per CU
+    if (want < 1) want = 1;                            // (G = 170: 3 x 170 = 510 workgroups 12.8 us; 4 x 170 = 680 -> 16.4 us)
     int maxs = (rm.M + 63) / 64;
     return want < maxs ? want : maxs;
 }
@@ -370,8 +376,13 @@ static int wgrad_impl(const float* A, const float* D, const float* D2, float* dW
     dim3 grid(rm.G, ns), block(256);
     hipStream_t st = (hipStream_t)stream;
     if (C == 64) {
-        if (pro == PRO_DPRE) hipLaunchKernelGGL((wgrad64_kernel<PRO_DPRE>), grid, block, 0, st, A, D, D2, dW, rm, rps, csa ? C * C + C : C * C, csa);
-        else hipLaunchKernelGGL((wgrad64_kernel<PRO_NONE>), grid, block, 0, st, A, D, D2, dW, rm, rps, csa ? C * C + C : C * C, csa);
+        const int rows = rps < rm.M ? rps : rm.M, steps = ((rows + 3) / 4 + 3) / 4;      // k-steps per wave
+        const bool u6 = (steps + 5) / 6 * 6 <= (steps + 3) / 4 * 4;
+        const int os = csa ? C * C + C : C * C;
+#define WG64(P, UU) hipLaunchKernelGGL((wgrad64_kernel<P, UU>), grid, block, 0, st, A, D, D2, dW, rm, rps, os, csa)
+        if (pro == PRO_DPRE) { if (u6) WG64(PRO_DPRE, 6); else WG64(PRO_DPRE, 4); }
+        else { if (u6) WG64(PRO_NONE, 6); else WG64(PRO_NONE, 4); }
+#undef WG64
     } else if (C == 128) {
         if (pro == PRO_DPRE) hipLaunchKernelGGL((wgrad_kernel<128, PRO_DPRE>), grid, block, 0, st, A, D, D2, dW, rm, rps);
         else hipLaunchKernelGGL((wgrad_kernel<128, PRO_NONE>), grid, block, 0, st, A, D, D2, dW, rm, rps);

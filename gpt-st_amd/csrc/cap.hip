@@ -134,7 +134,7 @@ __global__ __launch_bounds__(256) void cap_route_fwd_kernel(const float* __restr
     float* vs = v0s + HS * C;
     const int bt = blockIdx.x, tid = threadIdx.x;
 
-    load_w_lds<C>(Wl, Wp, 1, tid, 256);
+    load_w_lds<C, 256>(Wl, Wp, 1, tid);
     __syncthreads();
     cap_linear_to_lds<C>(X + (size_t)bt * N * C, Wl, Ps, N, NPAD);
     __syncthreads();
@@ -241,7 +241,7 @@ __global__ __launch_bounds__(256) void cap_route_bwd_kernel(const float* __restr
     float* dcs = cs + HS * NP;                 // HS*NP
     float* dss = Wl + region2;                 // HS*C
     const int bt = blockIdx.x, tid = threadIdx.x;
-    load_w_lds<C>(Wl, Wp, 1, tid, 256);
+    load_w_lds<C, 256>(Wl, Wp, 1, tid);
     __syncthreads();
     cap_linear_to_lds<C>(X + (size_t)bt * N * C, Wl, Ys, N, NPAD);
     __syncthreads();

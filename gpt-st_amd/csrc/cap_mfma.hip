@@ -150,6 +150,17 @@ __device__ __forceinline__ void cm_post(const float* __restrict__ S, const float
     }
 }
 
+// one batch of float4 loads for the 32 x C row tile t of a (b,t) slice; rows beyond N are clamped (and zeroed when staged)
+template <int C>
+__device__ __forceinline__ void cm_fetch_x(float4 (&xv)[Tile<C>::F4_PER_LANE], const float* __restrict__ Xbt, int t, int N, int lane) {
+#pragma unroll
+    for (int it = 0; it < Tile<C>::F4_PER_LANE; ++it) {
+        const int f = it * 64 + lane;
+        const int r = f / Tile<C>::F4_PER_ROW, c4 = f % Tile<C>::F4_PER_ROW;
+        xv[it] = ld4(Xbt + (size_t)min(t * 32 + r, N - 1) * C + 4 * c4);
+    }
+}
+
 template <int C>
 __global__ __launch_bounds__(CM_NT, 4) void cap_route_fwd2_kernel(const float* __restrict__ X, const float* __restrict__ Wp,
                                                                const float* __restrict__ bp, const float* __restrict__ dadj,
@@ -172,19 +183,22 @@ __global__ __launch_bounds__(CM_NT, 4) void cap_route_fwd2_kernel(const float* _
     const int bt = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const float* Xbt = X + (size_t)bt * N * C;
 
-    load_w_lds<C>(Wl, Wp, 1, tid, CM_NT);
+    float4 xv[T::F4_PER_LANE];              // this wave's X tile: requested before the weight is staged (one batch, clamped rows)
+    cm_fetch_x<C>(xv, Xbt, wave, N, lane);
+    load_w_lds<C, CM_NT>(Wl, Wp, 1, tid);
     for (int i = tid; i < 2 * HSP * P + HSP * C; i += CM_NT) Vs[i] = 0.f;      // Vs, V0s, S
     __syncthreads(); TS();
     // ---- Y = X Wp^T by 32-row MFMA tiles (one per wave); rows beyond the stored range are dropped ----------------
     for (int t = wave; t < (NR + 31) / 32; t += CM_NW) {
         float* tile = Ps + t * 32 * P;
         const int rows_here = min(32, NR - t * 32);
+        if (t != wave) cm_fetch_x<C>(xv, Xbt, t, N, lane);
 #pragma unroll
         for (int it = 0; it < T::F4_PER_LANE; ++it) {
             const int f = it * 64 + lane;
             const int r = f / T::F4_PER_ROW, c4 = f % T::F4_PER_ROW;
             const int n = t * 32 + r;
-            if (r < rows_here) st4(tile + r * P + 4 * c4, n < N ? ld4(Xbt + (size_t)n * C + 4 * c4) : f4zero());
+            if (r < rows_here) st4(tile + r * P + 4 * c4, n < N ? xv[it] : f4zero());
         }
         f32x16 acc[T::NCT];
         if (rows_here == 32) {
@@ -329,18 +343,21 @@ __global__ __launch_bounds__(CM_NT, 4) void cap_route_bwd2_kernel(const float* _
     const int bt = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const float* Xbt = X + (size_t)bt * N * C;
 
-    load_w_lds<C>(Wl, Wp, 1, tid, CM_NT);
+    float4 xv[T::F4_PER_LANE];
+    cm_fetch_x<C>(xv, Xbt, wave, N, lane);
+    load_w_lds<C, CM_NT>(Wl, Wp, 1, tid);
     for (int i = tid; i < HSP * P; i += CM_NT) Vs[i] = 0.f;
     __syncthreads();
     for (int t = wave; t < (NR + 31) / 32; t += CM_NW) {           // same tiling as the forward
         float* tile = Ys + t * 32 * P;
         const int rows_here = min(32, NR - t * 32);
+        if (t != wave) cm_fetch_x<C>(xv, Xbt, t, N, lane);
 #pragma unroll
         for (int it = 0; it < T::F4_PER_LANE; ++it) {
             const int f = it * 64 + lane;
             const int r = f / T::F4_PER_ROW, c4 = f % T::F4_PER_ROW;
             const int n = t * 32 + r;
-            if (r < rows_here) st4(tile + r * P + 4 * c4, n < N ? ld4(Xbt + (size_t)n * C + 4 * c4) : f4zero());
+            if (r < rows_here) st4(tile + r * P + 4 * c4, n < N ? xv[it] : f4zero());
         }
         f32x16 acc[T::NCT];
         if (rows_here == 32) {
@@ -390,9 +407,18 @@ __global__ __launch_bounds__(CM_NT, 4) void cap_route_bwd2_kernel(const float* _
         for (int i = tid; i < 2 * HSP * NP; i += CM_NT) cs[i] = 0.f;
     }
     __syncthreads();
-    for (int i = tid; i < HS * N; i += CM_NT) {
-        cs[(i / N) * NP + i % N] = c[(size_t)bt * HS * N + i];
-        dcs[(i / N) * NP + i % N] = dc1[(size_t)bt * HS * N + i];
+    for (int i0 = 0; i0 < HS * N; i0 += 4 * CM_NT) {             // c, dc1: batches of 4 + 4 loads per thread
+        float cv[4], dv[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const int i = min(i0 + k * CM_NT + tid, HS * N - 1);
+            cv[k] = c[(size_t)bt * HS * N + i]; dv[k] = dc1[(size_t)bt * HS * N + i];
+        }
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const int i = i0 + k * CM_NT + tid;
+            if (i < HS * N) { cs[(i / N) * NP + i % N] = cv[k]; dcs[(i / N) * NP + i % N] = dv[k]; }
+        }
     }
     for (int i = tid; i < HS * LPR; i += CM_NT) st4(Vs + (i / LPR) * P + 4 * (i % LPR), ld4(dS + (size_t)bt * HS * C + 4 * i));
     __syncthreads();

@@ -84,20 +84,35 @@ __device__ __forceinline__ void acc_to_tile(float* __restrict__ tile, const f32x
 
 // Cooperative load of a C x C matrix into LDS as Wl[k][j].
 //   trans == 0: source is [k][j] row-major;  trans == 1: source is [j][k] (nn.Linear weight, or W^T for backward).
-template <int C>
-__device__ __forceinline__ void load_w_lds(float* __restrict__ Wl, const float* __restrict__ W, int trans,
-                                           int tid, int nthreads) {
+// The float4 loads are issued in batches of up to 8 per thread BEFORE the LDS stores: the obvious copy loop compiles to
+// load -> s_waitcnt vmcnt(0) -> ds_write per trip, i.e. one serialised L2 round trip per 4 KB (measured 4 x ~0.4 us per launch).
+template <int C, int NTH>
+__device__ __forceinline__ void load_w_lds(float* __restrict__ Wl, const float* __restrict__ W, int trans, int tid) {
     constexpr int NF4 = C * C / 4;
-    if (!trans) {
-        for (int f = tid; f < NF4; f += nthreads) st4(Wl + 4 * f, ld4(W + 4 * f));
-    } else {
-        for (int f = tid; f < NF4; f += nthreads) {
-            const int k4 = f / C, j = f % C;              // lanes walk j: conflict-free LDS writes
-            const float4 v = ld4(W + (size_t)j * C + 4 * k4);
-            Wl[(4 * k4 + 0) * C + j] = v.x;
-            Wl[(4 * k4 + 1) * C + j] = v.y;
-            Wl[(4 * k4 + 2) * C + j] = v.z;
-            Wl[(4 * k4 + 3) * C + j] = v.w;
+    static_assert(NF4 % NTH == 0, "weight must divide evenly over the workgroup");
+    constexpr int K = NF4 / NTH, KB = K < 8 ? K : 8;
+#pragma unroll
+    for (int k0 = 0; k0 < K; k0 += KB) {
+        float4 v[KB];
+        if (!trans) {
+#pragma unroll
+            for (int k = 0; k < KB; ++k) v[k] = ld4(W + 4 * (tid + (k0 + k) * NTH));
+#pragma unroll
+            for (int k = 0; k < KB; ++k) st4(Wl + 4 * (tid + (k0 + k) * NTH), v[k]);
+        } else {
+#pragma unroll
+            for (int k = 0; k < KB; ++k) {
+                const int f = tid + (k0 + k) * NTH, k4 = f / C, j = f % C;      // lanes walk j: conflict-free LDS writes
+                v[k] = ld4(W + (size_t)j * C + 4 * k4);
+            }
+#pragma unroll
+            for (int k = 0; k < KB; ++k) {
+                const int f = tid + (k0 + k) * NTH, k4 = f / C, j = f % C;
+                Wl[(4 * k4 + 0) * C + j] = v[k].x;
+                Wl[(4 * k4 + 1) * C + j] = v[k].y;
+                Wl[(4 * k4 + 2) * C + j] = v[k].z;
+                Wl[(4 * k4 + 3) * C + j] = v[k].w;
+            }
         }
     }
 }

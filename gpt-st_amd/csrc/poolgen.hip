@@ -167,8 +167,10 @@ __global__ __launch_bounds__(256) void poolgen_bwd_emb_kernel(PgBwd a, float* __
     }
 }
 
+extern int g_wgrad_ns_override;
 extern "C" int gptst_tune(int id, int value) {
     if (id == 1) g_pg_nchunk = value;
+    if (id == 2) g_wgrad_ns_override = value;
     return GPTST_OK;
 }
 
