@@ -75,45 +75,50 @@ __global__ __launch_bounds__(256) void poolgen_bwd_pool_kernel(const float* __re
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int j = lane & 15, kk = lane >> 4;
     const int chunk = blockIdx.y * 4 + wave;
-    if (chunk >= nchunk) return;
     int per = (RR + nchunk - 1) / nchunk;
     per = (per + 3) & ~3;
-    const int r0 = chunk * per, r1 = min(RR, r0 + per);
+    const int r0 = chunk < nchunk ? chunk * per : RR, r1 = min(RR, r0 + per);       // an idle wave gets an empty row range
     const int c = bx * SLAB + V * j;
     const bool cok = c < cols;
     f32x4 acc[V];
 #pragma unroll
     for (int e = 0; e < V; ++e) acc[e] = (f32x4){0.f, 0.f, 0.f, 0.f};
-    for (int rb = r0; rb < r1; rb += 16) {
-        float av[4];
-        float4 b[4];
+    // NU k-steps (4 rows each) per batch: all dW / emb loads of a batch are issued before the first MFMA (row and column are
+    // clamped instead of predicated; a row beyond the chunk contributes through a zero emb operand).  The per-16-row loop of
+    // the first version paid one memory round trip per 16 rows with 4 waves per CU: 23 us for 25 MB.
+    constexpr int NU = 4;
+    const int cl = cok ? c : 0;
+    for (int rb = r0; rb < r1; rb += 4 * NU) {
+        float av[NU];
+        float4 b[NU];
 #pragma unroll
-        for (int u = 0; u < 4; ++u) {
-            const int row = rb + 4 * u + kk;
-            av[u] = 0.f; b[u] = f4zero();
-            if (row < r1) {
-                if (j < K) av[u] = emb[(size_t)(row % R) * K + j];
-                if (cok) b[u] = ldv<V>(dW + (size_t)row * cols + c);
-            }
+        for (int u = 0; u < NU; ++u) {
+            const int row = min(rb + 4 * u + kk, r1 - 1);
+            av[u] = emb[(size_t)(row % R) * K + min(j, K - 1)];
+            b[u] = ldv<V>(dW + (size_t)row * cols + cl);
         }
 #pragma unroll
-        for (int u = 0; u < 4; ++u) {
-            acc[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[u], b[u].x, acc[0], 0, 0, 0);
+        for (int u = 0; u < NU; ++u) {
+            const float a_ = (rb + 4 * u + kk < r1 && j < K) ? av[u] : 0.f;
+            acc[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(a_, b[u].x, acc[0], 0, 0, 0);
             if (V == 4) {
-                acc[V > 1 ? 1 : 0] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[u], b[u].y, acc[V > 1 ? 1 : 0], 0, 0, 0);
-                acc[V > 2 ? 2 : 0] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[u], b[u].z, acc[V > 2 ? 2 : 0], 0, 0, 0);
-                acc[V > 3 ? 3 : 0] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[u], b[u].w, acc[V > 3 ? 3 : 0], 0, 0, 0);
+                acc[V > 1 ? 1 : 0] = __builtin_amdgcn_mfma_f32_16x16x4f32(a_, b[u].y, acc[V > 1 ? 1 : 0], 0, 0, 0);
+                acc[V > 2 ? 2 : 0] = __builtin_amdgcn_mfma_f32_16x16x4f32(a_, b[u].z, acc[V > 2 ? 2 : 0], 0, 0, 0);
+                acc[V > 3 ? 3 : 0] = __builtin_amdgcn_mfma_f32_16x16x4f32(a_, b[u].w, acc[V > 3 ? 3 : 0], 0, 0, 0);
             }
         }
     }
-    if (cok) {
+    // fold the 4 waves (= 4 row chunks of the same slab) through LDS: one atomic per output and workgroup instead of four
+    // (the atomics, not the loads, bounded this kernel: 4 x 16 x 4160 x 4 problems = 1 M atomics per launch).
+    __shared__ float fold[4][PG_MAXK][SLAB + 1];
 #pragma unroll
-        for (int e = 0; e < V; ++e)
+    for (int e = 0; e < V; ++e)
 #pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const int k = kk * 4 + r;                  // D reg r: row (l>>4)*4 + r = k, col l&15 = j
-                if (k < K) atomicAdd(dpool + (size_t)k * cols + c + e, acc[e][r]);
-            }
+        for (int r = 0; r < 4; ++r) fold[wave][kk * 4 + r][V * j + e] = acc[e][r];      // D reg r: row (l>>4)*4 + r = k, col l&15 = j
+    __syncthreads();
+    for (int o = threadIdx.x; o < PG_MAXK * SLAB; o += 256) {
+        const int k = o / SLAB, cc = o % SLAB, col = bx * SLAB + cc;
+        if (k < K && col < cols) atomicAdd(dpool + (size_t)k * cols + col, fold[0][k][cc] + fold[1][k][cc] + fold[2][k][cc] + fold[3][k][cc]);
     }
 }
 
@@ -136,19 +141,36 @@ __global__ __launch_bounds__(256) void poolgen_bwd_emb_kernel(PgBwd a, float* __
     const int cbeg = (gch - a.blk0[p]) * chunk_cols, cend = min(cc, cbeg + chunk_cols);
     f32x4 acc = {0.f, 0.f, 0.f, 0.f};
     if (V == 4) {
-        for (int c = cbeg + 4 * kk; c < cend + 4 * kk; c += 16) {           // same trip count for the 4 lane groups
-            float4 av = f4zero(), b = f4zero();
-            if (c < cend) {
-                if (row < R) {
-                    av = ld4(w + (size_t)row * cc + c);
-                    for (int s = 1; s < ns; ++s) av = f4add(av, ld4(w + ((size_t)s * R + row) * cc + c));
-                }
-                if (i < K) b = ld4(pl + (size_t)i * cc + c);
+        // UC column steps (16 columns each) per batch, all loads issued before the MFMAs (clamped, not predicated): the
+        // one-step loop paid one L2 round trip per 16 columns (32 per chunk -> 22 us).
+        constexpr int UC = 8;
+        const int rowc = min(row, R - 1), ic = min(i, K - 1);
+        const bool rok = row < R, kok = i < K;
+        for (int c0 = cbeg; c0 < cend; c0 += 16 * UC) {
+            float4 av[UC], b[UC];
+#pragma unroll
+            for (int u = 0; u < UC; ++u) {
+                const int c = min(c0 + 16 * u + 4 * kk, cc - 4);
+                av[u] = ld4(w + (size_t)rowc * cc + c);
+                b[u] = ld4(pl + (size_t)ic * cc + c);
             }
-            acc = __builtin_amdgcn_mfma_f32_16x16x4f32(av.x, b.x, acc, 0, 0, 0);
-            acc = __builtin_amdgcn_mfma_f32_16x16x4f32(av.y, b.y, acc, 0, 0, 0);
-            acc = __builtin_amdgcn_mfma_f32_16x16x4f32(av.z, b.z, acc, 0, 0, 0);
-            acc = __builtin_amdgcn_mfma_f32_16x16x4f32(av.w, b.w, acc, 0, 0, 0);
+            for (int s = 1; s < ns; ++s) {
+#pragma unroll
+                for (int u = 0; u < UC; ++u) {
+                    const int c = min(c0 + 16 * u + 4 * kk, cc - 4);
+                    av[u] = f4add(av[u], ld4(w + ((size_t)s * R + rowc) * cc + c));
+                }
+            }
+#pragma unroll
+            for (int u = 0; u < UC; ++u) {
+                const bool ok = c0 + 16 * u + 4 * kk < cend;
+                const float4 a_ = (ok && rok) ? av[u] : f4zero();
+                const float4 b_ = (ok && kok) ? b[u] : f4zero();
+                acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a_.x, b_.x, acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a_.y, b_.y, acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a_.z, b_.z, acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a_.w, b_.w, acc, 0, 0, 0);
+            }
         }
     } else {
         for (int c = cbeg + kk; c < cend + kk; c += 4) {
