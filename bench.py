@@ -32,6 +32,8 @@ def kernel_flops(name, tag, d):
         return 2.0 * rows * C * C
     if name == "gptst_hypertem_fwd":
         return 2.0 * rows * C * C + 2.0 * rows * C * T
+    if name == "gptst_hypertem_bwd":                      # dR = dPre W^T, dX = G^T dR, dG = dR X^T
+        return 2.0 * rows * C * C + 4.0 * rows * C * T
     if name in ("gptst_tmix", "gptst_tmix_dgraph"):
         return 2.0 * rows * C * T
     if name == "gptst_cap_route_fwd":
@@ -47,10 +49,11 @@ def kernel_flops(name, tag, d):
 
 # C-ABI entry point (+ tag) -> kernel symbol prefix in rocprofv3 traces / profiles/pmc_traffic.json
 KERNEL_SYMBOL = {
-    "gptst_cap_route_fwd": "void cap_route_fwd2_kernel<64>", "gptst_cap_route_bwd": "void cap_route_bwd_kernel<64>",
-    "gptst_hypertem_fwd": "void hypertem_fwd_kernel<64>", "gptst_wgrad": "void wgrad64_kernel", "gptst_apply": "void apply_kernel<64",
-    "gptst_tmix": "void tmix_kernel<64", "gptst_tmix_dgraph": "void tmix_dgraph_kernel<64>", "gptst_cap_rec_bwd": "void cap_rec_bwd_kernel<64>",
-    "gptst_cap_cross_bwd": "void cap_cross_bwd_kernel<64>", "gptst_cap_rec_fwd": "void cap_rec_fwd_kernel<64>",
+    "gptst_cap_route_fwd": "void cap_route_fwd2_kernel<64>", "gptst_cap_route_bwd": "void cap_route_bwd2_kernel<64>",
+    "gptst_hypertem_fwd": "hypertem_fwd_kernel", "gptst_hypertem_bwd": "hypertem_bwd_kernel", "gptst_wgrad": "void wgrad64_kernel",
+    "gptst_apply": "void apply_kernel<64", "gptst_tmix": "void tmix_kernel<64", "gptst_tmix_dgraph": "void tmix_dgraph_kernel<64>",
+    "gptst_cap_rec_bwd": "void cap_rec_bwd2_kernel<64>", "gptst_cap_cross_bwd": "void cap_cross_bwd_kernel<64>",
+    "gptst_cap_rec_fwd": "void cap_rec_fwd_kernel<64>",
 }
 
 
@@ -66,7 +69,7 @@ def pmc_traffic(name, tag, grid_hint=None):
         pro, epi = tag.split()[1][3:], tag.split()[2][3:]
         sym = "void apply_kernel<64, %s, %s>" % (pro, epi)
     if name == "gptst_wgrad":
-        sym = "void wgrad64_kernel<%s>" % tag.split()[1][3:4]
+        sym = "void wgrad64_kernel<%s," % tag.split()[1][3:4]
     cands = [(k, v) for k, v in ks.items() if k.startswith(sym)]
     if grid_hint is not None:
         cands = [c for c in cands if grid_hint in c[0]] or cands
@@ -94,6 +97,29 @@ def time_kernels(stepper, epoch, nsteps=3):
         a[0] += e0.elapsed_time(e1) * 1e-3
         a[1] += 1
     return {k: dict(total_s=v[0] / nsteps, launches=v[1] // nsteps, avg_s=v[0] / v[1], bytes=v[2]) for k, v in agg.items()}
+
+
+def retime_kernel(name, tag, reps=50):
+    """Average duration of ONE launch of (name, tag): its recorded call is enqueued `reps` times back to back on the launch
+    stream, bracketed by one HIP event pair (an event pair around a single launch also counts the ~3-5 us dispatch gap, which
+    matters for a 20-30 us kernel; back to back the queue stays full because a ctypes enqueue is faster than the kernel).
+    The operand buffers of the recorded call are still mapped: nothing releases the caching allocator in between."""
+    from gptst_amd import ops, _C
+    args = ops.LAST_CALL.get((name, tag))
+    if args is None:
+        return None
+    lib = _C.lib()
+    st = _C.stream()
+    for _ in range(5):
+        lib.call(name, *args, st)
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(reps):
+        lib.call(name, *args, st)
+    e1.record()
+    torch.cuda.synchronize()
+    return e0.elapsed_time(e1) * 1e-3 / reps
 
 
 def cpu_baseline(args, B, budget_s=12.0):
@@ -235,6 +261,10 @@ def main():
         tot = sum(v["total_s"] for v in kt.values())
         (dn, dt), dv = max(kt.items(), key=lambda kv: kv[1]["total_s"])
         fl = kernel_flops(dn, dt, dims)
+        eager_avg = dv["avg_s"]
+        precise = retime_kernel(dn, dt)
+        if precise is not None:
+            dv = dict(dv, avg_s=precise)
         t_h, t_m = dv["bytes"] / HBM_PEAK, fl / MFMA_F32_PEAK
         if t_h >= t_m:
             rf = dict(bound="hbm", achieved=dv["bytes"] / dv["avg_s"] / 1e9, peak=HBM_PEAK / 1e9, unit="GB/s")
@@ -243,7 +273,9 @@ def main():
         rf["frac"] = rf["achieved"] / rf["peak"]
         hint = {"mode0": "[384,", "mode1": "[170,", "mode2": "[1,"}.get(dt.split()[0]) if dt else None
         rf["traffic"], rf["traffic_kernel"] = pmc_traffic(dn, dt, hint)
-        rf.update(kernel="%s[%s]" % (dn, dt), avg_us=1e6 * dv["avg_s"], launches_per_step=dv["launches"],
+        rf.update(kernel="%s[%s]" % (dn, dt), avg_us=1e6 * dv["avg_s"], avg_us_single_eager_launch=1e6 * eager_avg,
+                  timing="one HIP event pair around 50 back-to-back launches of the recorded call on the launch stream",
+                  launches_per_step=dv["launches"],
                   alg_bytes_per_launch=dv["bytes"], alg_flops_per_launch=fl, share_of_step_kernel_time=dv["total_s"] / tot)
         out["roofline"] = rf
         top = sorted(kt.items(), key=lambda kv: -kv[1]["total_s"])[:12]

@@ -172,7 +172,7 @@ extern "C" int gptst_hypertem_fwd(const float* X, const float* G, const float* W
 __global__ __launch_bounds__(256, 2) void hypertem_bwd_kernel(const float* __restrict__ dOut, const float* __restrict__ Y,
                                                               const float* __restrict__ X, const float* __restrict__ G,
                                                               const float* __restrict__ Wbt, float* __restrict__ dX,
-                                                              float* __restrict__ dbias, float* __restrict__ dG, int N, int B) {
+                                                              float* __restrict__ dbias, float* __restrict__ dG, int N, int B, int dbg) {
     constexpr int C = 64, P = C + 4, GP = 145, NT = 16;
     extern __shared__ __attribute__((aligned(16))) float smem[];
     float* Ds = smem;                               // [12][16][P]  dPre, then dR
@@ -216,7 +216,7 @@ __global__ __launch_bounds__(256, 2) void hypertem_bwd_kernel(const float* __res
             _Pragma("unroll") for (int q = 0; q < C / 16; ++q) aq[it][q] = ld4(W_ + (size_t)(it * 16 + j) * C + 16 * q + 4 * kk); \
     } while (0)
     HT_LOAD_WT(wave);
-    for (int t = wave; t < HT_T; t += 4) {
+    for (int t = wave; t < HT_T && !(dbg & 32); t += 4) {
         const size_t g = (size_t)b * HT_T + t;
         float* dt = Ds + t * NT * P;
         // bias gradient: column sums of dPre_t over the 16 nodes (lane = channel)
@@ -239,7 +239,7 @@ __global__ __launch_bounds__(256, 2) void hypertem_bwd_kernel(const float* __res
             }
         }
         if (t + 4 < HT_T) HT_LOAD_WT(t + 4);
-        atomicAdd(dbias + g * C + lane, s);
+        if (!(dbg & 4)) atomicAdd(dbias + g * C + lane, s);
         // D reg r: row i = it*16 + kk*4 + r (input channel), col j = node  ->  dR_t[node][channel] over the slab
 #pragma unroll
         for (int it = 0; it < C / 16; ++it)
@@ -256,7 +256,7 @@ __global__ __launch_bounds__(256, 2) void hypertem_bwd_kernel(const float* __res
             xg[i][q] = j < HT_T ? ld4(X + (((size_t)b * HT_T + j) * N + n) * C + 16 * q + 4 * kk) : f4zero();
     }
     // ---- dX_u[n,:] = dPre_u[n,:] + sum_t G_n[t,u] dR_t[n,:]   (thread = (row nl, float4 column c4), dPre still in registers) ----
-    if (valid) {
+    if (valid && !(dbg & 16)) {
         float4 dr[HT_T];
 #pragma unroll
         for (int t = 0; t < HT_T; ++t) dr[t] = ld4(Ds + (t * NT + nl) * P + 4 * c4);
@@ -266,7 +266,7 @@ __global__ __launch_bounds__(256, 2) void hypertem_bwd_kernel(const float* __res
             float4 acc = dp[u];
 #pragma unroll
             for (int t = 0; t < HT_T; ++t) acc = f4fma(gr[t * HT_T + u], dr[t], acc);
-            st4(dX + rowoff + (size_t)u * N * C, acc);
+            if (!(dbg & 8)) st4(dX + rowoff + (size_t)u * N * C, acc);
         }
     }
     // ---- dG_n[t,u] += sum_c dR_t[n,c] X_u[n,c]:  A[i=t][kk=c] = dR (LDS), B[kk=c][j=u] = X (registers) ----
@@ -287,7 +287,7 @@ __global__ __launch_bounds__(256, 2) void hypertem_bwd_kernel(const float* __res
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
             const int t = kk * 4 + r, u = j;
-            if (t < HT_T && u < HT_T) atomicAdd(dG + (size_t)n * 144 + t * HT_T + u, acc[r]);
+            if (t < HT_T && u < HT_T && !(dbg & 2)) atomicAdd(dG + (size_t)n * 144 + t * HT_T + u, acc[r]);
         }
     }
 }
@@ -300,7 +300,7 @@ extern "C" int gptst_hypertem_bwd(const float* dOut, const float* Y, const float
     const size_t smem = ht_smem(16);
     static int done = 0;
     if (!done) { hipFuncSetAttribute((const void*)hypertem_bwd_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem); done = 1; }
-    hipLaunchKernelGGL(hypertem_bwd_kernel, dim3(8 * ((B + 7) / 8) * ((N + 15) / 16)), dim3(256), smem, (hipStream_t)stream, dOut, Y, X, G, Wbt, dX, dbias, dG, N, B);
+    hipLaunchKernelGGL(hypertem_bwd_kernel, dim3(8 * ((B + 7) / 8) * ((N + 15) / 16)), dim3(256), smem, (hipStream_t)stream, dOut, Y, X, G, Wbt, dX, dbias, dG, N, B, g_ht_dbg);
     GPTST_CHECK_LAUNCH();
     return GPTST_OK;
 }

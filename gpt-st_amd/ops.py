@@ -15,6 +15,7 @@ _p = _C.ptr
 
 
 TIMER = None      # bench.py sets this to a list to collect (name, tag, start_event, end_event, bytes) per launch
+LAST_CALL = {}    # (name, tag) -> argument tuple of the most recent timed launch (bench.py replays the dominant kernel)
 
 
 def _call(name, *args, tag="", nbytes=0):
@@ -26,6 +27,7 @@ def _call(name, *args, tag="", nbytes=0):
     _C.lib().call(name, *args, _C.stream())
     e1.record()
     TIMER.append((name, tag, e0, e1, nbytes))
+    LAST_CALL[(name, tag)] = args
 
 
 def _nb(*ts):
