@@ -4,8 +4,11 @@ GLOBAL batch: every rank back-propagates the SUM-loss gradient of its local batc
 buffer [flat gradient | loss statistics (sum|y-p|, kept count, KL sum, -)] makes both the gradient and the global
 kept-count available everywhere; the optimiser kernel divides the reconstruction-path gradient by the global count
 (masked-MAE is a mean over kept cells of the whole batch, lib/metrics.py:18) and leaves the KL path (a sum) unscaled.
-Masks are generated per rank on the rank's local batch with the reference's ratio (documented deviation from a single
-global top-k; the masked fraction is identical).
+Masks follow the reference's GLOBAL-batch semantics (GPTST.py:316-321, 351-404: one top-k / one class selection over
+the whole batch): every rank draws the same global noise (same Philox seed), runs the bit-exact integer selection on the
+global batch and keeps its own rows.  The random phase needs no communication; the adaptive phase all-gathers the
+per-cell cluster labels (int32, 261 KB per 32-sample rank) and sums the per-class counts (HS int32) before the selection.
+``PretrainStep(global_mask=False)`` falls back to per-rank masks (same ratio, no label exchange).
 """
 import os
 
@@ -29,6 +32,26 @@ class DataParallel:
         """In-place sum over ranks of the packed [gradient | statistics] buffer (one collective per step)."""
         dist.all_reduce(buf, op=dist.ReduceOp.SUM)
         return buf
+
+    def gather_labels(self, local, out=None):
+        """Concatenate the ranks' label vectors in rank order (= batch-major order of the global batch)."""
+        if out is None:
+            out = torch.empty(self.world * local.numel(), dtype=local.dtype, device=local.device)
+        if self.world == 1:
+            out.copy_(local)
+            return out
+        dist.all_gather_into_tensor(out, local.contiguous())
+        return out
+
+    def sum_counts_(self, counts):
+        """In-place sum over ranks of the per-class cell counts (int32)."""
+        if self.world > 1:
+            dist.all_reduce(counts, op=dist.ReduceOp.SUM)
+        return counts
+
+    def rows_of(self, flat_global, per_rank):
+        """This rank's contiguous slice of a batch-major global vector."""
+        return flat_global[self.rank * per_rank:(self.rank + 1) * per_rank]
 
     def broadcast_(self, t, src=0):
         dist.broadcast(t, src=src)

@@ -15,7 +15,7 @@ from . import engine, ops
 
 
 class PretrainStep:
-    def __init__(self, model, args, scaler_mean, scaler_std, batch_size, use_graph=True, dp=None, seed=0):
+    def __init__(self, model, args, scaler_mean, scaler_std, batch_size, use_graph=True, dp=None, seed=0, global_mask=True):
         self.model, self.args = model, args
         self.mean, self.std = float(scaler_mean), float(scaler_std)
         self.B, self.T, self.N = batch_size, args.lag, args.num_nodes
@@ -47,6 +47,19 @@ class PretrainStep:
         self.graphs = {}
         self.inject_noise = False
         self.arena = engine.ZeroArena(self.dev)
+        # ---- data parallel: masks over the GLOBAL batch (dist.py) ----
+        self.W = dp.world if dp is not None else 1
+        self.gmask = bool(global_mask) and dp is not None and self.W > 1
+        if self.gmask:
+            torch.cuda.manual_seed(1234567 + seed)              # every rank draws the same global mask noise
+            Mg = M * self.W
+            self.noise_g = torch.zeros(Mg * self.base, device=self.dev)
+            self.noise_a_g, self.noise_r_g = torch.zeros(Mg, device=self.dev), torch.zeros(Mg, device=self.dev)
+            self.label_l = torch.zeros(M, dtype=torch.int32, device=self.dev)
+            self.label_g = torch.zeros(Mg, dtype=torch.int32, device=self.dev)
+            self.counts_g = torch.zeros(self.HS, dtype=torch.int32, device=self.dev)
+            self.arena_l = engine.ZeroArena(self.dev)
+            self.label_graph = None
         # measured: running weight gradients on a second stream slows the step (364 vs 403 steps/s), so opt-in only
         self.side = engine.SideStream() if os.environ.get("GPTST_SIDE_STREAM", "0") == "1" else None
 
@@ -62,19 +75,22 @@ class PretrainStep:
         src = self.src
         tidx = src[:, :, 0, base:base + 2].contiguous()
         prob, sv_g = engine.guide_fwd(p, src, tidx, dims, base)
-        if not self.inject_noise:
-            if phase == 0:
-                self.noise.uniform_()
-            else:
-                self.noise_a.uniform_(); self.noise_r.uniform_()
-        if self.force_mask:
-            mask = self.mask_buf
-        elif phase == 0:
-            mask = ops.mask_random(self.noise, int(M * base * a.mask_ratio))
+        if self.gmask:
+            mask = self._global_mask(phase)
         else:
-            label, counts = ops.mask_labels(prob)
-            mask = ops.mask_adaptive(label, counts, self.ctrl[:self.HS], self.ctrl[self.HS:], self.noise_a, self.noise_r,
-                                     a.ada_type == "all", base)[2]
+            if not self.inject_noise:
+                if phase == 0:
+                    self.noise.uniform_()
+                else:
+                    self.noise_a.uniform_(); self.noise_r.uniform_()
+            if self.force_mask:
+                mask = self.mask_buf
+            elif phase == 0:
+                mask = ops.mask_random(self.noise, int(M * base * a.mask_ratio))
+            else:
+                label, counts = ops.mask_labels(prob)
+                mask = ops.mask_adaptive(label, counts, self.ctrl[:self.HS], self.ctrl[self.HS:], self.noise_a, self.noise_r,
+                                         a.ada_type == "all", base)[2]
         self.last_mask = mask
         emb, c1, tidx, sv_e = engine.model_fwd(p, src, mask, dims, base, mdl.num_route, mdl.scaler_zeros)
         out, dec, sv_d = engine.decoder_fwd(p, tidx, emb, dims, mdl.num_route)
@@ -88,6 +104,57 @@ class PretrainStep:
         engine._join_side()
         engine.ARENA = None
         engine.SIDE = None
+
+    def _global_mask(self, phase):
+        """Mask of this rank's rows cut out of the selection over the global batch (identical on every rank)."""
+        a, base, M = self.args, self.base, self.B * self.T * self.N
+        Mg = M * self.W
+        if self.force_mask:
+            return self.mask_buf
+        if not self.inject_noise:
+            if phase == 0:
+                self.noise_g.uniform_()
+            else:
+                self.noise_a_g.uniform_(); self.noise_r_g.uniform_()
+        if phase == 0:
+            mask_g = ops.mask_random(self.noise_g, int(Mg * base * a.mask_ratio))
+        else:                                              # label_g / counts_g were exchanged by _exchange_labels()
+            mask_g = ops.mask_adaptive(self.label_g, self.counts_g, self.ctrl[:self.HS], self.ctrl[self.HS:], self.noise_a_g,
+                                       self.noise_r_g, a.ada_type == "all", base)[2]
+        self.last_mask_global = mask_g
+        return self.dp.rows_of(mask_g, M * base)
+
+    def _labels_body(self):
+        p, dims, base = self.model.param_views(), self.dims, self.base
+        engine.ARENA = self.arena_l
+        self.arena_l.begin()
+        tidx = self.src[:, :, 0, base:base + 2].contiguous()
+        prob, _ = engine.guide_fwd(p, self.src, tidx, dims, base)
+        label, counts = ops.mask_labels(prob)
+        self.label_l.copy_(label); self.counts_g.copy_(counts)
+        engine.ARENA = None
+
+    def _exchange_labels(self):
+        """Adaptive phase under DP: cluster labels of the local rows (guide forward + argmax, its own small hipGraph), then one
+        all-gather of the labels and one all-reduce of the class counts.  The main graph recomputes the guide forward (it
+        needs its activations for the KL backward): +~60 us per step, and no collective inside a captured graph."""
+        if self.use_graph:
+            if self.label_graph is None:
+                s = torch.cuda.Stream()
+                s.wait_stream(torch.cuda.current_stream())
+                with torch.cuda.stream(s):
+                    self._labels_body()
+                torch.cuda.current_stream().wait_stream(s)
+                torch.cuda.synchronize()
+                g = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(g):
+                    self._labels_body()
+                self.label_graph = g
+            self.label_graph.replay()
+        else:
+            self._labels_body()
+        self.dp.gather_labels(self.label_l, out=self.label_g)
+        self.dp.sum_counts_(self.counts_g)
 
     def _optim(self):
         ops.clip_adam(self.model.flat, self.gflat, self.m, self.v, self.model.nA, self.model.nB, self.hyper, self.stats)
@@ -119,7 +186,7 @@ class PretrainStep:
             if list_c is None:
                 list_c = list(range(self.HS))
                 self.rng.shuffle(list_c)                                   # GPTST.py:357-358
-            ada, rnd = self.model.adaptive_counts(self.B * self.T * self.N, epoch)
+            ada, rnd = self.model.adaptive_counts(self.B * self.T * self.N * (self.W if self.gmask else 1), epoch)
             c = self.ctrl_host
             for i, v in enumerate(list_c):
                 c[i] = int(v)
@@ -134,15 +201,18 @@ class PretrainStep:
         if source is not self.src:
             self.src.copy_(source, non_blocking=True)
         inject = noise is not None or noise_a is not None
-        if inject:
+        if inject:                                      # with global masks the injected noise covers the GLOBAL batch
+            n0, na, nr = (self.noise_g, self.noise_a_g, self.noise_r_g) if self.gmask else (self.noise, self.noise_a, self.noise_r)
             if phase == 0:
-                self.noise.copy_(noise.reshape(-1), non_blocking=True)
+                n0.copy_(noise.reshape(-1), non_blocking=True)
             else:
-                self.noise_a.copy_(noise_a.reshape(-1), non_blocking=True)
-                self.noise_r.copy_(noise_r.reshape(-1), non_blocking=True)
+                na.copy_(noise_a.reshape(-1), non_blocking=True)
+                nr.copy_(noise_r.reshape(-1), non_blocking=True)
         if forced_mask is not None:
             self.mask_buf.copy_(forced_mask.reshape(-1), non_blocking=True)
         self._host_prepare(phase, epoch, list_c)
+        if self.gmask and phase == 1 and forced_mask is None:
+            self._exchange_labels()
         key = (phase, inject, forced_mask is not None)
         if not self.use_graph:
             self.inject_noise, self.force_mask = inject, forced_mask is not None

@@ -92,3 +92,43 @@ def test_combine_local_gradients_matches_formula():
     assert float(stats[1]) == 6.0 and float(stats[0]) == 16.0
     torch.testing.assert_close(g[:8], (a[:8] + b[:8]) / 6.0)
     torch.testing.assert_close(g[8:], a[8:12] + b[8:12])
+
+
+def _worker_labels(rank, world, port, q):
+    sys.path.insert(0, ROOT)
+    os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    torch.set_num_threads(1)
+    from gptst_amd.dist import DataParallel
+    dp = DataParallel("gloo")
+    M = 2 * 12 * 5                                                       # this rank's B*T*N cells
+    g = torch.Generator().manual_seed(100 + rank)
+    label = torch.randint(0, 4, (M,), generator=g, dtype=torch.int32)
+    counts = torch.bincount(label, minlength=4).to(torch.int32)
+    lab_g = dp.gather_labels(label)
+    dp.sum_counts_(counts)
+    mask_g = torch.arange(world * M * 2, dtype=torch.float32)            # any batch-major global vector (base = 2)
+    mine = dp.rows_of(mask_g, M * 2)
+    q.put((rank, lab_g.tolist(), counts.tolist(), mine.tolist()))        # plain lists: the worker may exit before the parent reads
+    dp.barrier()
+
+
+def test_dp_label_exchange_protocol():
+    """Adaptive-mask phase under DP (dist.py): labels are concatenated in rank order (= batch-major order of the global batch),
+    class counts are summed, and a rank's rows of a global vector are its contiguous slice."""
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 29900 + os.getpid() % 90
+    procs = [ctx.Process(target=_worker_labels, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    got = sorted([q.get(timeout=120) for _ in range(2)], key=lambda x: x[0])
+    for p in procs:
+        p.join(60)
+        assert p.exitcode == 0
+    M = 2 * 12 * 5
+    labs = [torch.randint(0, 4, (M,), generator=torch.Generator().manual_seed(100 + r), dtype=torch.int32) for r in range(2)]
+    want_lab = torch.cat(labs)
+    want_cnt = torch.bincount(want_lab, minlength=4).to(torch.int32)
+    for r, lab_g, counts, mine in got:
+        assert lab_g == want_lab.tolist() and counts == want_cnt.tolist()
+        assert mine == torch.arange(2 * M * 2, dtype=torch.float32)[r * M * 2:(r + 1) * M * 2].tolist()

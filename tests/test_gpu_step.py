@@ -98,3 +98,76 @@ def test_graph_replay_equals_eager_and_random_noise_changes():
         masks.append(st.last_mask.clone())
         assert int((masks[-1] == 0).sum()) == int(960 * 0.25)
     assert not torch.equal(masks[0], masks[1]) and not torch.equal(masks[1], masks[2])
+
+
+class _FakeDP:
+    """Stands in for dist.DataParallel on one GPU: the peers' labels / counts are injected, the gradient all-reduce is a no-op."""
+
+    def __init__(self, rank, world, labels, counts):
+        self.rank, self.world, self.labels, self.counts = rank, world, labels, counts
+
+    def gather_labels(self, local, out=None):
+        assert torch.equal(local, self.labels[self.rank])           # the step's own labels = what the peers would receive
+        out.copy_(torch.cat(self.labels))
+        return out
+
+    def sum_counts_(self, counts):
+        counts.copy_(sum(self.counts))
+        return counts
+
+    def rows_of(self, flat, per_rank):
+        return flat[self.rank * per_rank:(self.rank + 1) * per_rank]
+
+    def allreduce_(self, buf):
+        return buf
+
+
+@pytest.mark.parametrize("use_graph", [False, True])
+def test_dp_global_mask_equals_single_process_global_batch(use_graph):
+    """under data parallelism the mask is ONE selection over the global batch (GPTST.py:316-321,351-404).  Two
+    ranks with B=2 each (emulated one after the other on this GPU) must cut exactly their rows out of the mask a single
+    process generates for B=4 — random phase (no exchange) and adaptive phase (label all-gather + count all-reduce) — and
+    the oracle on the global batch agrees bit for bit."""
+    from gptst_amd import engine, ops
+    from gptst_amd.model import GPTST_Model
+    from gptst_amd.step import PretrainStep
+    args = _args()
+    sd = O.init_state_dict(args, 1)
+    W, Bl, Mg = 2, 2, 4 * 12 * 20
+    M = Mg // W
+    src_g = synth.make_batch(4, 12, 20, 1, seed=11).to(DEV)
+    n0, na, nr = (synth.make_noise(Mg, s).to(DEV) for s in (1, 2, 3))
+    list_c = [3, 1, 0, 4, 2]
+
+    def fresh(B, dp=None):
+        model = GPTST_Model(args); model.load_state_dict(sd); model = model.to(DEV)
+        return model, PretrainStep(model, args, synth.SCALER_MEAN, synth.SCALER_STD, batch_size=B, use_graph=use_graph, dp=dp)
+
+    # per-rank labels / counts, as the ranks compute them (guide forward + argmax on their own rows)
+    model, _ = fresh(4)
+    labels, counts = [], []
+    for r in range(W):
+        src = src_g[r * Bl:(r + 1) * Bl].contiguous()
+        engine.ARENA = engine.ZeroArena(torch.device(DEV)); engine.ARENA.begin()
+        prob, _ = engine.guide_fwd(model.param_views(), src, src[:, :, 0, 1:3].contiguous(), (Bl, 12, 20, args.hidden_dim), 1)
+        lab, cnt = ops.mask_labels(prob)
+        engine.ARENA = None
+        labels.append(lab.clone()); counts.append(cnt.clone())
+    for epoch in (1, 20):
+        _, st = fresh(4)
+        st.step(src_g, epoch, noise=n0, noise_a=na, noise_r=nr, list_c=list_c)
+        mask_ref = st.last_mask.clone()
+        # the oracle on the global batch (integer path: bit exact given the labels)
+        if epoch == 1:
+            want = O.random_mask(n0.cpu(), args.mask_ratio)
+        else:
+            ada, rnd = O.adaptive_counts(Mg, args.mask_ratio, epoch, args.change_epoch, args.epochs, args.ada_mask_ratio)
+            want = O.adaptive_mask(torch.cat(labels).cpu().long(), list_c, na.cpu(), nr.cpu(), ada, rnd, args.ada_type)[2]
+        assert torch.equal(mask_ref.cpu().long(), want.reshape(-1).long())
+        for r in range(W):
+            _, sr = fresh(Bl, dp=_FakeDP(r, W, labels, counts))
+            assert sr.gmask
+            for _ in range(2 if epoch == 1 else 1):              # (the optimiser moves the guide, so labels are compared once)
+                sr.step(src_g[r * Bl:(r + 1) * Bl].contiguous(), epoch, noise=n0, noise_a=na, noise_r=nr, list_c=list_c)
+                torch.cuda.synchronize()
+                assert torch.equal(sr.last_mask, mask_ref[r * M:(r + 1) * M]), (epoch, r)
