@@ -69,6 +69,24 @@ class SideStream:
 
 
 SIDE = None       # set by PretrainStep (None -> everything on one stream)
+TAIL = None       # second stream for the small, latency-bound kernels off the critical path: parameter generation of the decoder
+                  # (depends only on the time index) and the pool / embedding gradient reductions at the end of an STHCN backward
+
+
+def _off_critical_path(fn, keep=()):
+    """Run fn() on the TAIL stream (after everything enqueued so far on the main stream); tensors in `keep` stay referenced until
+    the join so the caching allocator cannot recycle them under the side kernels."""
+    if TAIL is None:
+        return fn()
+    with TAIL.fork():
+        r = fn()
+    TAIL.keep(r, *keep)
+    return r
+
+
+def _join_tail():
+    if TAIL is not None:
+        TAIL.join()
 
 
 def _wgrad_async(*args, **kw):
@@ -210,7 +228,9 @@ def condlin_bwd(saved, dout, emb, wpool, bpool, g_wpool, g_bpool, d_emb, mode, d
 
 
 # ---- STHCN (GPTST.py:253-273) --------------------------------------------------------------------------------------
-def sthcn_fwd(p, pfx, tidx, x, dims, num_route):
+def sthcn_gen(p, pfx, tidx, dims):
+    """Everything of an STHCN forward that depends only on the time index and the parameters: the three time embeddings and all
+    generated parameters of the six layers (5 launches + 1 gram; was 18)."""
     B, T, N, C = dims
     time_eb = timefeat_fwd(p, pfx + "time_feature1.", tidx)                       # (BT,d)   :259
     teb = timefeat_fwd(p, pfx + "time_feature1_.", tidx)                          # (BT,ds)  :260
@@ -222,14 +242,21 @@ def sthcn_fwd(p, pfx, tidx, x, dims, num_route):
     d, Hm = adj0.shape[0], adj0.shape[1]
     cadj, tadj = p[cps[0] + "adj"], p[cps[0] + "t_adj"]
     ds, HS, HT = cadj.shape[0], cadj.shape[1], tadj.shape[1]
-    # ---- all generated parameters of the six layers: 5 launches + 1 gram (was 18) ----
-    A_all = torch.empty(4, N, Hm * T, device=x.device)
+    A_all = torch.empty(4, N, Hm * T, device=tidx.device)
     ops.poolgen_multi(ne, [p[h + "adj"].view(d, Hm * T) for h in hts], outs=[A_all[i] for i in range(4)])       # :156
     G_all = ops.gram_fwd(A_all.view(4 * N, Hm, T)).view(4, N, T, T)
     Wb = ops.poolgen_multi(time_eb, [t for h in hts for t in (p[h + "weights_pool"], p[h + "bias_pool"])])       # :160-161
     Wn = ops.poolgen_multi(nes, [t for c in cps for t in (p[c + "weights_spa"], p[c + "bias_spa"])])             # :137-138
     dadj = ops.poolgen_multi(teb, [p[c + "adj"].view(ds, HS * N) for c in cps])                                  # :104
     dyn = [t.view(B, HT, T * HS) for t in ops.poolgen_multi(tes, [p[c + "t_adj"].view(ds, HT * T * HS) for c in cps])]   # :129
+    return dict(emb=(time_eb, teb, tes), gen=(A_all, hts, cps, d, Hm, ds, HS, HT), G_all=G_all, Wb=Wb, Wn=Wn, dadj=dadj, dyn=dyn)
+
+
+def sthcn_fwd(p, pfx, tidx, x, dims, num_route, gen=None):
+    if gen is None:
+        gen = sthcn_gen(p, pfx, tidx, dims)
+    A_all, hts, cps, d, Hm, ds, HS, HT = gen["gen"]
+    G_all, Wb, Wn, dadj, dyn = gen["G_all"], gen["Wb"], gen["Wn"], gen["dadj"], gen["dyn"]
     sv = {}
     x, sv["h1"] = hypertem_core_fwd(x, G_all[0], Wb[0], Wb[1], dims)
     x, c1, sv["c1"] = cap_core_fwd(p, cps[0], x, dadj[0], dyn[0], Wn[0], Wn[1], dims, num_route, HS, HT)
@@ -237,8 +264,8 @@ def sthcn_fwd(p, pfx, tidx, x, dims, num_route):
     x, sv["h3"] = hypertem_core_fwd(x, G_all[2], Wb[4], Wb[5], dims)
     x, _, sv["c2"] = cap_core_fwd(p, cps[1], x, dadj[1], dyn[1], Wn[2], Wn[3], dims, num_route, HS, HT)
     x, sv["h4"] = hypertem_core_fwd(x, G_all[3], Wb[6], Wb[7], dims)
-    sv["emb"] = (time_eb, teb, tes)
-    sv["gen"] = (A_all, hts, cps, d, Hm, ds, HS, HT)
+    sv["emb"] = gen["emb"]
+    sv["gen"] = gen["gen"]
     return x, c1, sv
 
 
@@ -257,31 +284,36 @@ def sthcn_bwd(p, g, pfx, tidx, sv, dout, dims):
     dd, cp1 = cap_core_bwd(p, g, cps[0], sv["c1"], dd, dims, HS, HT)
     dd, hp1 = hypertem_core_bwd(sv["h1"], dd, dG_all[0], dims)
     _join_side()
-    # ---- gradient reductions of all generated parameters, batched: 11 launches (was 32) ----
-    hps = (hp1, hp2, hp3, hp4)
-    dWs = [t for hp in hps for t in (hp[0], hp[2])]
-    nss = [v for hp in hps for v in (hp[1], 1)]
-    pools = [t for h in hts for t in (p[h + "weights_pool"], p[h + "bias_pool"])]
-    ops.poolgen_bwd_pool_multi(time_eb, dWs, [t for h in hts for t in (g[h + "weights_pool"], g[h + "bias_pool"])], nss)
-    ops.poolgen_bwd_emb_multi(dWs, pools, d_te, nss)
-    dA_all = ops.gram_bwd(A_all.view(4 * N, Hm, T), dG_all.view(4 * N, T, T)).view(4, N, Hm * T)
-    dAs = [dA_all[i] for i in range(4)]
-    ops.poolgen_bwd_pool_multi(ne, dAs, [g[h + "adj"].view(d, Hm * T) for h in hts])
-    ops.poolgen_bwd_emb_multi(dAs, [p[h + "adj"].view(d, Hm * T) for h in hts], dne)
-    cpp = (cp1, cp2)
-    dWn = [t for cp in cpp for t in (cp[0], cp[2])]
-    nsn = [v for cp in cpp for v in (cp[1], 1)]
-    ops.poolgen_bwd_pool_multi(nes, dWn, [t for c in cps for t in (g[c + "weights_spa"], g[c + "bias_spa"])], nsn)
-    ops.poolgen_bwd_emb_multi(dWn, [t for c in cps for t in (p[c + "weights_spa"], p[c + "bias_spa"])], dnes, nsn)
-    ddyn = [cp[3].view(B, HT * T * HS) for cp in cpp]
-    ops.poolgen_bwd_pool_multi(tes, ddyn, [g[c + "t_adj"].view(ds, HT * T * HS) for c in cps])
-    ops.poolgen_bwd_emb_multi(ddyn, [p[c + "t_adj"].view(ds, HT * T * HS) for c in cps], d_tes)
-    dlg = [cp[4].view(B * T, HS * N) for cp in cpp]
-    ops.poolgen_bwd_pool_multi(teb, dlg, [g[c + "adj"].view(ds, HS * N) for c in cps])
-    ops.poolgen_bwd_emb_multi(dlg, [p[c + "adj"].view(ds, HS * N) for c in cps], d_teb)
-    timefeat_bwd(p, g, pfx + "time_feature1.", tidx, d_te)
-    timefeat_bwd(p, g, pfx + "time_feature1_.", tidx, d_teb)
-    timefeat_bwd(p, g, pfx + "time_feature2.", tidx, d_tes, spg=True)
+
+    def reductions():
+        # ---- gradient reductions of all generated parameters, batched: 11 launches (was 32) ----
+        hps = (hp1, hp2, hp3, hp4)
+        dWs = [t for hp in hps for t in (hp[0], hp[2])]
+        nss = [v for hp in hps for v in (hp[1], 1)]
+        pools = [t for h in hts for t in (p[h + "weights_pool"], p[h + "bias_pool"])]
+        ops.poolgen_bwd_pool_multi(time_eb, dWs, [t for h in hts for t in (g[h + "weights_pool"], g[h + "bias_pool"])], nss)
+        ops.poolgen_bwd_emb_multi(dWs, pools, d_te, nss)
+        dA_all = ops.gram_bwd(A_all.view(4 * N, Hm, T), dG_all.view(4 * N, T, T)).view(4, N, Hm * T)
+        dAs = [dA_all[i] for i in range(4)]
+        ops.poolgen_bwd_pool_multi(ne, dAs, [g[h + "adj"].view(d, Hm * T) for h in hts])
+        ops.poolgen_bwd_emb_multi(dAs, [p[h + "adj"].view(d, Hm * T) for h in hts], dne)
+        cpp = (cp1, cp2)
+        dWn = [t for cp in cpp for t in (cp[0], cp[2])]
+        nsn = [v for cp in cpp for v in (cp[1], 1)]
+        ops.poolgen_bwd_pool_multi(nes, dWn, [t for c in cps for t in (g[c + "weights_spa"], g[c + "bias_spa"])], nsn)
+        ops.poolgen_bwd_emb_multi(dWn, [t for c in cps for t in (p[c + "weights_spa"], p[c + "bias_spa"])], dnes, nsn)
+        ddyn = [cp[3].view(B, HT * T * HS) for cp in cpp]
+        ops.poolgen_bwd_pool_multi(tes, ddyn, [g[c + "t_adj"].view(ds, HT * T * HS) for c in cps])
+        ops.poolgen_bwd_emb_multi(ddyn, [p[c + "t_adj"].view(ds, HT * T * HS) for c in cps], d_tes)
+        dlg = [cp[4].view(B * T, HS * N) for cp in cpp]
+        ops.poolgen_bwd_pool_multi(teb, dlg, [g[c + "adj"].view(ds, HS * N) for c in cps])
+        ops.poolgen_bwd_emb_multi(dlg, [p[c + "adj"].view(ds, HS * N) for c in cps], d_teb)
+        timefeat_bwd(p, g, pfx + "time_feature1.", tidx, d_te)
+        timefeat_bwd(p, g, pfx + "time_feature1_.", tidx, d_teb)
+        timefeat_bwd(p, g, pfx + "time_feature2.", tidx, d_tes, spg=True)
+
+    # none of these results is needed before the optimiser: they overlap with the next backward chain on the TAIL stream
+    _off_critical_path(reductions, keep=(sv, hp1, hp2, hp3, hp4, cp1, cp2, d_te, d_teb, d_tes, dG_all, dout))
     return dd
 
 
@@ -324,8 +356,15 @@ def model_fwd(p, source, mask, dims, base, num_route, scaler_zeros):
     return emb, c1, tidx, sv_e
 
 
-def decoder_fwd(p, tidx, emb, dims, num_route):
-    dec, _, sv_d = sthcn_fwd(p, "decoder.STHCN_decode.", tidx, emb, dims, num_route)                        # :454
+def decoder_gen(p, tidx, dims):
+    """Generated parameters of the decoder, requested early: they run on the TAIL stream under the encoder forward."""
+    return _off_critical_path(lambda: sthcn_gen(p, "decoder.STHCN_decode.", tidx, dims), keep=(tidx,))
+
+
+def decoder_fwd(p, tidx, emb, dims, num_route, gen=None):
+    if gen is not None:
+        _join_tail()
+    dec, _, sv_d = sthcn_fwd(p, "decoder.STHCN_decode.", tidx, emb, dims, num_route, gen=gen)               # :454
     out = ops.rowdot(dec, p["decoder.dim_flow_out.weight"], p["decoder.dim_flow_out.bias"])                 # :455
     return out, dec, sv_d
 

@@ -62,6 +62,8 @@ class PretrainStep:
             self.label_graph = None
         # measured: running weight gradients on a second stream slows the step (364 vs 403 steps/s), so opt-in only
         self.side = engine.SideStream() if os.environ.get("GPTST_SIDE_STREAM", "0") == "1" else None
+        # small latency-bound kernels off the critical path (decoder parameter generation, pool / embedding gradient reductions)
+        self.tail = engine.SideStream() if os.environ.get("GPTST_TAIL_STREAM", "1") == "1" else None
 
     # ---- the enqueued work ---------------------------------------------------------------------------------------
     def _fwd_bwd(self, phase):
@@ -71,9 +73,11 @@ class PretrainStep:
         self.gbuf.zero_()
         engine.ARENA = self.arena
         engine.SIDE = self.side
+        engine.TAIL = self.tail
         self.arena.begin()
         src = self.src
         tidx = src[:, :, 0, base:base + 2].contiguous()
+        gen_d = engine.decoder_gen(p, tidx, dims) if self.tail is not None else None
         prob, sv_g = engine.guide_fwd(p, src, tidx, dims, base)
         if self.gmask:
             mask = self._global_mask(phase)
@@ -93,7 +97,7 @@ class PretrainStep:
                                          a.ada_type == "all", base)[2]
         self.last_mask = mask
         emb, c1, tidx, sv_e = engine.model_fwd(p, src, mask, dims, base, mdl.num_route, mdl.scaler_zeros)
-        out, dec, sv_d = engine.decoder_fwd(p, tidx, emb, dims, mdl.num_route)
+        out, dec, sv_d = engine.decoder_fwd(p, tidx, emb, dims, mdl.num_route, gen=gen_d)
         ops.mae_fwd(out, src, base + 2, mask, self.std, self.mean, a.mape_thresh, M, base, self.stats)
         d_out = ops.mae_bwd(out, src, base + 2, mask, self.std, self.mean, a.mape_thresh, M, base, self.stats,
                             normalize=self.dp is None)
@@ -102,8 +106,10 @@ class PretrainStep:
             dlogit = ops.kl(prob, c1, self.N, 0.1, self.stats)
             engine.guide_bwd(p, g, src, tidx, sv_g, dlogit, dims, base)
         engine._join_side()
+        engine._join_tail()
         engine.ARENA = None
         engine.SIDE = None
+        engine.TAIL = None
 
     def _global_mask(self, phase):
         """Mask of this rank's rows cut out of the selection over the global batch (identical on every rank)."""
