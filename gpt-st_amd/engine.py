@@ -61,6 +61,12 @@ class SideStream:
     def keep(self, *ts):
         self.pending.extend(ts)
 
+    def mark(self):
+        """Event after the work enqueued on the side stream so far (a partial join point)."""
+        ev = torch.cuda.Event()
+        ev.record(self.stream)
+        return ev
+
     def join(self):
         if self.active:
             torch.cuda.current_stream().wait_stream(self.stream)
@@ -346,19 +352,27 @@ def guide_bwd(p, g, source, tidx, saved, dlogit, dims, base):
     timefeat_bwd(p, g, "encoder.teb4mask.", tidx, d_t4m)
 
 
-def model_fwd(p, source, mask, dims, base, num_route, scaler_zeros):
+def model_fwd(p, source, mask, dims, base, num_route, scaler_zeros, gen=None, gen_ready=None):
     """Masked-autoencoder body — GPTST.py:415-421 + 453-456.  mask (BTN*base) fp32, 1 = visible; None -> no masking (eval)."""
     B, T, N, C = dims
     tidx = source[:, :, 0, base:base + 2].contiguous()
     x0 = ops.lin_in(source, base + 2, base, p["encoder.dim_in_flow.weight"], p["encoder.dim_in_flow.bias"], C,
                     mask=mask, fill=scaler_zeros)                                                          # :416-418
-    emb, c1, sv_e = sthcn_fwd(p, "encoder.STHCN_encode.", tidx, x0, dims, num_route)                        # :421
+    if gen_ready is not None:
+        torch.cuda.current_stream().wait_event(gen_ready)
+    emb, c1, sv_e = sthcn_fwd(p, "encoder.STHCN_encode.", tidx, x0, dims, num_route, gen=gen)               # :421
     return emb, c1, tidx, sv_e
 
 
-def decoder_gen(p, tidx, dims):
-    """Generated parameters of the decoder, requested early: they run on the TAIL stream under the encoder forward."""
-    return _off_critical_path(lambda: sthcn_gen(p, "decoder.STHCN_decode.", tidx, dims), keep=(tidx,))
+def early_gen(p, tidx, dims):
+    """Generated parameters of both STHCNs, requested at the start of the step on the TAIL stream: the encoder's overlap with
+    the guide forward + mask selection, the decoder's with the encoder forward.  -> (gen_e, event after gen_e, gen_d)."""
+    if TAIL is None:
+        return None, None, None
+    gen_e = _off_critical_path(lambda: sthcn_gen(p, "encoder.STHCN_encode.", tidx, dims), keep=(tidx,))
+    ev = TAIL.mark()
+    gen_d = _off_critical_path(lambda: sthcn_gen(p, "decoder.STHCN_decode.", tidx, dims))
+    return gen_e, ev, gen_d
 
 
 def decoder_fwd(p, tidx, emb, dims, num_route, gen=None):

@@ -77,7 +77,7 @@ class PretrainStep:
         self.arena.begin()
         src = self.src
         tidx = src[:, :, 0, base:base + 2].contiguous()
-        gen_d = engine.decoder_gen(p, tidx, dims) if self.tail is not None else None
+        gen_e, gen_e_ready, gen_d = engine.early_gen(p, tidx, dims)
         prob, sv_g = engine.guide_fwd(p, src, tidx, dims, base)
         if self.gmask:
             mask = self._global_mask(phase)
@@ -96,7 +96,7 @@ class PretrainStep:
                 mask = ops.mask_adaptive(label, counts, self.ctrl[:self.HS], self.ctrl[self.HS:], self.noise_a, self.noise_r,
                                          a.ada_type == "all", base)[2]
         self.last_mask = mask
-        emb, c1, tidx, sv_e = engine.model_fwd(p, src, mask, dims, base, mdl.num_route, mdl.scaler_zeros)
+        emb, c1, tidx, sv_e = engine.model_fwd(p, src, mask, dims, base, mdl.num_route, mdl.scaler_zeros, gen=gen_e, gen_ready=gen_e_ready)
         out, dec, sv_d = engine.decoder_fwd(p, tidx, emb, dims, mdl.num_route, gen=gen_d)
         ops.mae_fwd(out, src, base + 2, mask, self.std, self.mean, a.mape_thresh, M, base, self.stats)
         d_out = ops.mae_bwd(out, src, base + 2, mask, self.std, self.mean, a.mape_thresh, M, base, self.stats,
