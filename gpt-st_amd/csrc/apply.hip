@@ -12,6 +12,7 @@
 #include "mfma_tile.h"
 __device__ long long g_ap_ts[64];     // debug: per-phase s_memtime stamps (enabled by gptst_ap_dbg(1))
 int g_ap_dbg = 0;
+int g_apply_tpw = 0;                                   // experiments: gptst_tune(4, n) forces tiles per wave of apply64
 extern "C" int gptst_ap_dbg(int v) { g_ap_dbg = v; return 0; }
 extern "C" int gptst_ap_ts(long long* out) { return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_ap_ts), sizeof(long long) * 64); }
 
@@ -159,6 +160,147 @@ __global__ __launch_bounds__(256) void apply_kernel(const float* __restrict__ A,
             }
         }
     }
+}
+
+// C = 64 apply with register-resident operands, one barrier (second generation; apply_kernel above stays for C = 128):
+//   a wave keeps the whole C x C weight of its group as MFMA B fragments in registers (16 float4 = 64 VGPRs, staged once per
+//   workgroup through LDS) and walks `tiles_per_wave` 16-row tiles; the A fragment of a lane is row (tile*16 + j), channels 16q+4kk..+3, loaded straight
+//   from global as float4; accumulator tile ct, column j stands for output channel 4j+ct, so a lane owns four CONSECUTIVE channels
+//   of rows kk*4+r and the epilogue (bias / residual / LReLU / dPre) runs from registers with float4 loads and stores.
+//   The next tile's operands are requested before the current tile's stores (vmcnt retires in order).
+template <int PRO, int EPI>
+__global__ __launch_bounds__(256, 2) void apply64_kernel(const float* __restrict__ A, const float* __restrict__ A2,
+                                                         const float* __restrict__ W, long w_gstride, int transw,
+                                                         const float* __restrict__ bias, const float* __restrict__ resid,
+                                                         const float* __restrict__ resid2, float* __restrict__ out,
+                                                         float* __restrict__ colsum, RowMap rm, int tiles_per_wave) {
+    constexpr int C = 64;
+    __shared__ __attribute__((aligned(16))) float Wl[C * C];
+    __shared__ __attribute__((aligned(16))) float csl[4][C];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int j = lane & 15, kk = lane >> 4;
+    const int g = blockIdx.x;
+    const int ntiles = (rm.M + 15) / 16;
+    const int t0 = (blockIdx.y * 4 + wave) * tiles_per_wave, t1 = min(ntiles, t0 + tiles_per_wave);
+    const float* Wg = W + (size_t)g * w_gstride;
+    float4 bias4 = f4zero();
+    if (bias != nullptr) bias4 = ld4(bias + (size_t)g * C + 4 * j);
+    float4 cs[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) cs[q] = f4zero();
+    float4 an[4], on[4];
+    auto fetch = [&](int t) {
+        const int m = min(t * 16 + j, rm.M - 1);
+        const size_t off = ((size_t)g * rm.rs_g + (size_t)m * rm.rs_m) * C + 4 * kk;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            an[q] = ld4(A + off + 16 * q);
+            if (PRO == PRO_DPRE) on[q] = ld4(A2 + off + 16 * q);
+        }
+    };
+    if (t0 < t1) fetch(t0);                          // in flight while the weight is staged
+    // the group's weight goes through LDS once per workgroup (coalesced, transposed on the way if needed) and from there into
+    // the B fragments of every wave: bv[q][e], components = column tile ct  (reading fragments straight from L2 cost 4x the traffic)
+    load_w_lds<C, 256>(Wl, Wg, transw, threadIdx.x);
+    __syncthreads();
+    float4 bv[4][4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) bv[q][e] = ld4(Wl + (16 * q + 4 * kk + e) * C + 4 * j);
+    for (int t = t0; t < t1; ++t) {
+        float4 a[4];
+        const bool rowok = t * 16 + j < rm.M;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            float4 v = an[q];
+            if (PRO == PRO_DPRE) {
+                v.x *= lrelu_grad_from_out(on[q].x); v.y *= lrelu_grad_from_out(on[q].y);
+                v.z *= lrelu_grad_from_out(on[q].z); v.w *= lrelu_grad_from_out(on[q].w);
+            }
+            if (!rowok) v = f4zero();
+            a[q] = v;
+            cs[q] = f4add(cs[q], v);
+        }
+        // epilogue operands of this tile, then the next tile's A fragments: all in flight while the MFMAs run
+        float4 rv[4], rv2[4];
+        size_t orow[4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int m = min(t * 16 + kk * 4 + r, rm.M - 1);
+            orow[r] = ((size_t)g * rm.rs_g + (size_t)m * rm.rs_m) * C + 4 * j;
+            if (EPI == EPI_RES_LRELU || EPI == EPI_ADD_DPRE) rv[r] = ld4(resid + orow[r]);
+            if (EPI == EPI_ADD_DPRE) rv2[r] = ld4(resid2 + orow[r]);
+        }
+        if (t + 1 < t1) fetch(t + 1);
+        f32x4 acc[4];
+#pragma unroll
+        for (int ct = 0; ct < 4; ++ct) acc[ct] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const float av[4] = {a[q].x, a[q].y, a[q].z, a[q].w};
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                acc[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[e], bv[q][e].x, acc[0], 0, 0, 0);
+                acc[1] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[e], bv[q][e].y, acc[1], 0, 0, 0);
+                acc[2] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[e], bv[q][e].z, acc[2], 0, 0, 0);
+                acc[3] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[e], bv[q][e].w, acc[3], 0, 0, 0);
+            }
+        }
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            if (t * 16 + kk * 4 + r < rm.M) {
+                float4 y = f4add(make_float4(acc[0][r], acc[1][r], acc[2][r], acc[3][r]), bias4);
+                if (EPI == EPI_RES_LRELU) {
+                    y = f4add(y, rv[r]);
+                    y.x = lrelu(y.x); y.y = lrelu(y.y); y.z = lrelu(y.z); y.w = lrelu(y.w);
+                }
+                if (EPI == EPI_LRELU) { y.x = lrelu(y.x); y.y = lrelu(y.y); y.z = lrelu(y.z); y.w = lrelu(y.w); }
+                if (EPI == EPI_ADD_DPRE) {
+                    const float4 d = rv[r], o = rv2[r];
+                    y.x = fmaf(d.x, lrelu_grad_from_out(o.x), y.x); y.y = fmaf(d.y, lrelu_grad_from_out(o.y), y.y);
+                    y.z = fmaf(d.z, lrelu_grad_from_out(o.z), y.z); y.w = fmaf(d.w, lrelu_grad_from_out(o.w), y.w);
+                }
+                st4(out + orow[r], y);
+            }
+        }
+    }
+    if (colsum != nullptr) {          // column sums of (pro-applied) A: 16-lane row reduction, 4 waves folded in LDS, one atomic per column
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            cs[q].x = group_sum<16>(cs[q].x); cs[q].y = group_sum<16>(cs[q].y);
+            cs[q].z = group_sum<16>(cs[q].z); cs[q].w = group_sum<16>(cs[q].w);
+            if (j == 0) st4(&csl[wave][16 * q + 4 * kk], cs[q]);
+        }
+        __syncthreads();
+        if (wave == 0) atomicAdd(colsum + (size_t)g * C + lane, csl[0][lane] + csl[1][lane] + csl[2][lane] + csl[3][lane]);
+    }
+}
+
+template <int PRO, int EPI>
+static void launch_apply64_t(const float* A, const float* A2, const float* W, long gs, int transw, const float* bias, const float* resid,
+                             const float* resid2, float* out, float* colsum, RowMap rm, hipStream_t st) {
+    const int ntiles = (rm.M + 15) / 16;
+    long tot = (long)rm.G * ntiles;
+    int tpw = (int)((tot + 4 * 512 - 1) / (4 * 512));          // ~512 workgroups of 4 waves: one round at 2 per CU ...
+    if (tpw > 2) tpw = 2;                                      // ... but never more than 2 tiles per wave (measured: 3+ is 15-40 % slower)
+    if (colsum != nullptr && rm.G == 1) { const int lim = (ntiles + 4 * 128 - 1) / (4 * 128); if (tpw < lim) tpw = lim; }   // <= 128 atomics per address
+    if (g_apply_tpw > 0) tpw = g_apply_tpw;
+    if (tpw < 1) tpw = 1;
+    const int gy = (ntiles + 4 * tpw - 1) / (4 * tpw);
+    hipLaunchKernelGGL((apply64_kernel<PRO, EPI>), dim3(rm.G, gy), dim3(256), 0, st, A, A2, W, gs, transw, bias, resid, resid2, out, colsum, rm, tpw);
+}
+
+static int launch_apply64(const float* A, const float* A2, const float* W, long gs, int transw, const float* bias, const float* resid,
+                          const float* resid2, float* out, float* colsum, RowMap rm, int pro, int epi, hipStream_t st) {
+    if (pro == PRO_NONE && epi == EPI_PLAIN) launch_apply64_t<PRO_NONE, EPI_PLAIN>(A, A2, W, gs, transw, bias, resid, resid2, out, colsum, rm, st);
+    else if (pro == PRO_NONE && epi == EPI_RES_LRELU) launch_apply64_t<PRO_NONE, EPI_RES_LRELU>(A, A2, W, gs, transw, bias, resid, resid2, out, colsum, rm, st);
+    else if (pro == PRO_DPRE && epi == EPI_PLAIN) launch_apply64_t<PRO_DPRE, EPI_PLAIN>(A, A2, W, gs, transw, bias, resid, resid2, out, colsum, rm, st);
+    else if (pro == PRO_NONE && epi == EPI_ADD_DPRE) launch_apply64_t<PRO_NONE, EPI_ADD_DPRE>(A, A2, W, gs, transw, bias, resid, resid2, out, colsum, rm, st);
+    else if (pro == PRO_NONE && epi == EPI_LRELU) launch_apply64_t<PRO_NONE, EPI_LRELU>(A, A2, W, gs, transw, bias, resid, resid2, out, colsum, rm, st);
+    else return GPTST_EARG;
+    GPTST_CHECK_LAUNCH();
+    return GPTST_OK;
 }
 
 // C = 64 weight gradient on fp32 MFMA 16x16x4, operands straight from global memory as float4:
@@ -311,6 +453,7 @@ static int launch_apply(const float* A, const float* A2, const float* W, long w_
 }
 
 static int g_smem_attr_done = 0;
+int g_apply_v1 = 0;                                    // experiments: gptst_tune(3, 1) selects the LDS-staged apply_kernel for C = 64
 template <int C>
 static void raise_smem_limits() {
     const int smem = (int)((C * C + 4 * Tile<C>::TILE_FLOATS) * sizeof(float));
@@ -332,6 +475,7 @@ extern "C" int gptst_apply(const float* A, const float* A2, const float* W, int 
     RowMap rm = make_rowmap(mode, BT, N);
     const long gs = w_per_group ? (long)C * C : 0;
     hipStream_t st = (hipStream_t)stream;
+    if (C == 64 && !g_apply_v1) return launch_apply64(A, A2, W, gs, transw, bias, resid, resid2, out, colsum, rm, pro, epi, st);
     if (C == 64) return launch_apply<64>(A, A2, W, gs, transw, bias, resid, resid2, out, colsum, rm, pro, epi, st);
     if (C == 128) return launch_apply<128>(A, A2, W, gs, transw, bias, resid, resid2, out, colsum, rm, pro, epi, st);
     return GPTST_ESHAPE;
