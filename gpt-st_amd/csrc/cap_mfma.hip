@@ -81,21 +81,23 @@ __device__ __forceinline__ void cm_type2(const float* __restrict__ Ps, const flo
     }
 }
 
-// cs[h][n] = softmax_h( use_bl*bl + use_l0*(teb . adj) ): a quad of lanes per node, lane q takes h = q, q+4, ...;
-// optional copy to global c_out[h*N + n].  HS <= 64 (16 logits per lane).
+// cs[h][n] = softmax_h( use_bl*bl + use_l0*(teb . adj) ): L lanes per node, lane q takes h = q, q+L, ... (at most UB of them);
+// optional copy to global c_out[h*N + n].  The kernel picks (L, UB) = (2, 8) when N <= 256 and HS <= 16 — all nodes in ONE pass of
+// the 512 threads — and the generic (4, 16) otherwise (HS <= 64, several passes).
+template <int L, int UB>
 __device__ __forceinline__ void cm_softmax(const float* __restrict__ bl, float* __restrict__ cs, const float* __restrict__ l0g,
                                            float* __restrict__ c_out, int N, int NP, int HS, bool use_bl, bool use_l0) {
-    const int q = threadIdx.x & 3;
-    for (int n0 = 0; n0 < N; n0 += CM_NT / 4) {
-        const int n = n0 + (threadIdx.x >> 2);
+    const int q = threadIdx.x & (L - 1);
+    for (int n0 = 0; n0 < N; n0 += CM_NT / L) {
+        const int n = n0 + threadIdx.x / L;
         const bool valid = n < N;
-        float l[16];
+        float l[UB];
         float m = -3.0e38f;
 #pragma unroll
-        for (int u = 0; u < 16; ++u) {
+        for (int u = 0; u < UB; ++u) {
             l[u] = -3.0e38f;
-            if (4 * u < HS) {                                    // uniform
-                const int h = q + 4 * u;
+            if (L * u < HS) {                                    // uniform
+                const int h = q + L * u;
                 if (h < HS && valid) {
                     float v = use_bl ? bl[h * NP + n] : 0.f;
                     if (use_l0) v += l0g[(size_t)h * N + n];
@@ -104,19 +106,19 @@ __device__ __forceinline__ void cm_softmax(const float* __restrict__ bl, float* 
                 }
             }
         }
-        m = group_max<4>(m);
+        m = group_max<L>(m);
         float sum = 0.f;
 #pragma unroll
-        for (int u = 0; u < 16; ++u) {
-            const int h = q + 4 * u;
-            if (4 * u < HS && h < HS && valid) { l[u] = __expf(l[u] - m); sum += l[u]; }     // v_exp_f32 path: rel. error ~2e-6 for |x| < 50
+        for (int u = 0; u < UB; ++u) {
+            const int h = q + L * u;
+            if (L * u < HS && h < HS && valid) { l[u] = __expf(l[u] - m); sum += l[u]; }     // v_exp_f32 path: rel. error ~2e-6 for |x| < 50
         }
-        sum = group_sum<4>(sum);
+        sum = group_sum<L>(sum);
         const float inv = 1.f / sum;
 #pragma unroll
-        for (int u = 0; u < 16; ++u) {
-            const int h = q + 4 * u;
-            if (4 * u < HS && h < HS && valid) {
+        for (int u = 0; u < UB; ++u) {
+            const int h = q + L * u;
+            if (L * u < HS && h < HS && valid) {
                 const float c = l[u] * inv;
                 cs[h * NP + n] = c;
                 if (c_out != nullptr) c_out[(size_t)h * N + n] = c;
@@ -150,6 +152,39 @@ __device__ __forceinline__ void cm_post(const float* __restrict__ S, const float
     }
 }
 
+// C = 64: one 16-row tile of  Y = X Wp^T + bp  with register-resident operands (same scheme as apply64_kernel): A fragments are
+// float4s straight from global (lane (j,kk): row tile*16+j, channels 16q+4kk..+3), B fragments bv[q][e] come from the staged
+// Wl[k][col] (components = column tile ct <-> channel 4j+ct).  On return y[r] holds row tile*16 + kk*4 + r, channels 4j..4j+3.
+__device__ __forceinline__ void cm_fetch_a16(float4 (&a)[4], const float* __restrict__ Xbt, int tile, int N, int j, int kk) {
+    const float* row = Xbt + (size_t)min(tile * 16 + j, N - 1) * 64 + 4 * kk;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) a[q] = ld4(row + 16 * q);
+}
+__device__ __forceinline__ void cm_load_bfrag(float4 (&bv)[4][4], const float* __restrict__ Wl, int j, int kk) {
+#pragma unroll
+    for (int q = 0; q < 4; ++q)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) bv[q][e] = ld4(Wl + (16 * q + 4 * kk + e) * 64 + 4 * j);
+}
+__device__ __forceinline__ void cm_tile16(const float4 (&a)[4], const float4 (&bv)[4][4], float4 b4, float4 (&y)[4]) {
+    f32x4 acc[4];
+#pragma unroll
+    for (int ct = 0; ct < 4; ++ct) acc[ct] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        const float av[4] = {a[q].x, a[q].y, a[q].z, a[q].w};
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            acc[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[e], bv[q][e].x, acc[0], 0, 0, 0);
+            acc[1] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[e], bv[q][e].y, acc[1], 0, 0, 0);
+            acc[2] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[e], bv[q][e].z, acc[2], 0, 0, 0);
+            acc[3] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[e], bv[q][e].w, acc[3], 0, 0, 0);
+        }
+    }
+#pragma unroll
+    for (int r = 0; r < 4; ++r) y[r] = f4add(make_float4(acc[0][r], acc[1][r], acc[2][r], acc[3][r]), b4);
+}
+
 // one batch of float4 loads for the 32 x C row tile t of a (b,t) slice; rows beyond N are clamped (and zeroed when staged)
 template <int C>
 __device__ __forceinline__ void cm_fetch_x(float4 (&xv)[Tile<C>::F4_PER_LANE], const float* __restrict__ Xbt, int t, int N, int lane) {
@@ -161,7 +196,7 @@ __device__ __forceinline__ void cm_fetch_x(float4 (&xv)[Tile<C>::F4_PER_LANE], c
     }
 }
 
-template <int C>
+template <int C, int SL, int SU>
 __global__ __launch_bounds__(CM_NT, 4) void cap_route_fwd2_kernel(const float* __restrict__ X, const float* __restrict__ Wp,
                                                                const float* __restrict__ bp, const float* __restrict__ dadj,
                                                                float* __restrict__ c_out,
@@ -183,6 +218,34 @@ __global__ __launch_bounds__(CM_NT, 4) void cap_route_fwd2_kernel(const float* _
     const int bt = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const float* Xbt = X + (size_t)bt * N * C;
 
+    if constexpr (C == 64) {
+        // ---- P = squash(X Wp^T + bp): 16-row tiles, register operands, squash fused into the MFMA epilogue (row norm = 16-lane
+        //      DPP sum), P written to LDS once.  Replaces: X tile -> LDS -> MFMA 32x32x2 -> LDS -> separate squash pass + barrier. ----
+        const int j = lane & 15, kk = lane >> 4;
+        float4 a[4];
+        cm_fetch_a16(a, Xbt, wave, N, j, kk);                      // in flight while the weight is staged
+        const float4 b4 = ld4(bp + 4 * j);
+        load_w_lds<C, CM_NT>(Wl, Wp, 1, tid);
+        for (int i = tid; i < 2 * HSP * P + HSP * C; i += CM_NT) Vs[i] = 0.f;      // Vs, V0s, S
+        __syncthreads(); TS();
+        float4 bv[4][4];
+        cm_load_bfrag(bv, Wl, j, kk);
+        for (int tile = wave; tile < NR / 16; tile += CM_NW) {
+            if (tile != wave) cm_fetch_a16(a, Xbt, tile, N, j, kk);
+            float4 y[4];
+            cm_tile16(a, bv, b4, y);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int n = tile * 16 + kk * 4 + r;
+                float4 v = n < N ? y[r] : f4zero();
+                const float sc = squash_scale(group_sum<16>(f4dot(v, v)));
+                st4(Ps + n * P + 4 * j, make_float4(v.x * sc, v.y * sc, v.z * sc, v.w * sc));
+            }
+        }
+        __syncthreads(); TS();                                     // all B fragments are in registers: Wl may be recycled
+        for (int i = tid; i < (HS + HSP) * NP; i += CM_NT) bl[i] = 0.f;
+        __syncthreads(); TS();
+    } else {
     float4 xv[T::F4_PER_LANE];              // this wave's X tile: requested before the weight is staged (one batch, clamped rows)
     cm_fetch_x<C>(xv, Xbt, wave, N, lane);
     load_w_lds<C, CM_NT>(Wl, Wp, 1, tid);
@@ -246,8 +309,9 @@ __global__ __launch_bounds__(CM_NT, 4) void cap_route_fwd2_kernel(const float* _
         for (int i = tid; i < (HS + HSP) * NP; i += CM_NT) bl[i] = 0.f;
     }
     __syncthreads(); TS();
+    }
     const float* l0g = dadj + (size_t)bt * HS * N;
-    cm_softmax(bl, cs, l0g, nullptr, N, NP, HS, false, true);               // c0 = softmax_h(dadj)      :105
+    cm_softmax<SL, SU>(bl, cs, l0g, nullptr, N, NP, HS, false, true);       // c0 = softmax_h(dadj)      :105
     __syncthreads(); TS();
     cm_type1<C>(Ps, cs, S, N, NP, HSP);
     __syncthreads(); TS();
@@ -255,7 +319,7 @@ __global__ __launch_bounds__(CM_NT, 4) void cap_route_fwd2_kernel(const float* _
     __syncthreads(); TS();
     for (int r = 0; r < R; ++r) {                                                       // routing (no grad)          :113-118
         if (r > 0) { cm_type2<C>(Ps, Vs, bl, N, NP, HS, HSP); __syncthreads(); TS(); }        // b += v . P^T
-        cm_softmax(bl, cs, l0g, nullptr, N, NP, HS, true, false);           // c = softmax_h(b)
+        cm_softmax<SL, SU>(bl, cs, l0g, nullptr, N, NP, HS, true, false);   // c = softmax_h(b)
         __syncthreads(); TS();
         cm_type1<C>(Ps, cs, S, N, NP, HSP);
         __syncthreads(); TS();
@@ -263,7 +327,7 @@ __global__ __launch_bounds__(CM_NT, 4) void cap_route_fwd2_kernel(const float* _
         __syncthreads(); TS();
     }
     if (R > 0) { cm_type2<C>(Ps, Vs, bl, N, NP, HS, HSP); __syncthreads(); TS(); }
-    cm_softmax(bl, cs, l0g, c_out + (size_t)bt * HS * N, N, NP, HS, true, true);   // c = softmax_h(b + dadj)  :120
+    cm_softmax<SL, SU>(bl, cs, l0g, c_out + (size_t)bt * HS * N, N, NP, HS, true, true);   // c = softmax_h(b + dadj)  :120
     __syncthreads(); TS();
     cm_type1<C>(Ps, cs, S, N, NP, HSP);
     __syncthreads(); TS();
@@ -280,9 +344,15 @@ static int launch_route_fwd2(const float* X, const float* Wp, const float* bp, c
     r2 = (r2 + 3) & ~(size_t)3;
     const size_t smem = ((size_t)NR * Tile<C>::PITCH + r2 + 2 * (size_t)HSP * Tile<C>::PITCH + (size_t)HSP * C) * sizeof(float);
     if (smem > 160 * 1024) return GPTST_ESHAPE;
-    static size_t cur = 0;
-    if (smem > cur) { hipFuncSetAttribute((const void*)cap_route_fwd2_kernel<C>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem); cur = smem; }
-    hipLaunchKernelGGL((cap_route_fwd2_kernel<C>), dim3(BT), dim3(CM_NT), smem, st, X, Wp, bp, dadj, c_out, s_out, N, HS, R, (int)r2, g_cap_dbg);
+    static size_t cur[2] = {0, 0};
+    const bool one_pass = N <= CM_NT / 2 && HS <= 16;              // softmax: 2 lanes per node, all nodes in one pass
+    if (one_pass) {
+        if (smem > cur[0]) { hipFuncSetAttribute((const void*)cap_route_fwd2_kernel<C, 2, 8>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem); cur[0] = smem; }
+        hipLaunchKernelGGL((cap_route_fwd2_kernel<C, 2, 8>), dim3(BT), dim3(CM_NT), smem, st, X, Wp, bp, dadj, c_out, s_out, N, HS, R, (int)r2, g_cap_dbg);
+    } else {
+        if (smem > cur[1]) { hipFuncSetAttribute((const void*)cap_route_fwd2_kernel<C, 4, 16>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem); cur[1] = smem; }
+        hipLaunchKernelGGL((cap_route_fwd2_kernel<C, 4, 16>), dim3(BT), dim3(CM_NT), smem, st, X, Wp, bp, dadj, c_out, s_out, N, HS, R, (int)r2, g_cap_dbg);
+    }
     GPTST_CHECK_LAUNCH();
     return GPTST_OK;
 }
@@ -309,8 +379,8 @@ extern "C" int gptst_cap_occupancy(int N, int HS) {
     r2 = (r2 + 3) & ~(size_t)3;
     const size_t smem = ((size_t)NR * Tile<C>::PITCH + r2 + 2 * (size_t)HSP * Tile<C>::PITCH + (size_t)HSP * C) * sizeof(float);
     int n = -1;
-    hipFuncSetAttribute((const void*)cap_route_fwd2_kernel<C>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
-    hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, (const void*)cap_route_fwd2_kernel<C>, CM_NT, smem);
+    hipFuncSetAttribute((const void*)cap_route_fwd2_kernel<C, 2, 8>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+    hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, (const void*)cap_route_fwd2_kernel<C, 2, 8>, CM_NT, smem);
     return n * 1000000 + (int)smem;
 }
 
@@ -343,6 +413,34 @@ __global__ __launch_bounds__(CM_NT, 4) void cap_route_bwd2_kernel(const float* _
     const int bt = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const float* Xbt = X + (size_t)bt * N * C;
 
+    if constexpr (C == 64) {
+        // ---- Y = X Wp^T + bp, q = |Y|^2, g = squash factor: fused MFMA epilogue as in the forward ----
+        const int j = lane & 15, kk = lane >> 4;
+        float4 a[4];
+        cm_fetch_a16(a, Xbt, wave, N, j, kk);
+        const float4 b4 = ld4(bp + 4 * j);
+        load_w_lds<C, CM_NT>(Wl, Wp, 1, tid);
+        for (int i = tid; i < HSP * P; i += CM_NT) Vs[i] = 0.f;
+        __syncthreads();
+        float4 bv[4][4];
+        cm_load_bfrag(bv, Wl, j, kk);
+        for (int tile = wave; tile < NR / 16; tile += CM_NW) {
+            if (tile != wave) cm_fetch_a16(a, Xbt, tile, N, j, kk);
+            float4 y[4];
+            cm_tile16(a, bv, b4, y);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int n = tile * 16 + kk * 4 + r;
+                const float4 v = n < N ? y[r] : f4zero();
+                const float q = group_sum<16>(f4dot(v, v));
+                st4(Ys + n * P + 4 * j, v);
+                if (j == 0) { qq[n] = q; gq[n] = q / ((1.f + q) * (sqrtf(q) + 1e-8f)); }
+            }
+        }
+        __syncthreads();
+        for (int i = tid; i < 2 * HSP * NP; i += CM_NT) cs[i] = 0.f;
+        __syncthreads();
+    } else {
     float4 xv[T::F4_PER_LANE];
     cm_fetch_x<C>(xv, Xbt, wave, N, lane);
     load_w_lds<C, CM_NT>(Wl, Wp, 1, tid);
@@ -407,6 +505,7 @@ __global__ __launch_bounds__(CM_NT, 4) void cap_route_bwd2_kernel(const float* _
         for (int i = tid; i < 2 * HSP * NP; i += CM_NT) cs[i] = 0.f;
     }
     __syncthreads();
+    }
     for (int i0 = 0; i0 < HS * N; i0 += 4 * CM_NT) {             // c, dc1: batches of 4 + 4 loads per thread
         float cv[4], dv[4];
 #pragma unroll

@@ -228,17 +228,21 @@ __global__ __launch_bounds__(256, 2) void hypertem_bwd_kernel(const float* __res
         for (int q = 0; q < C / 16; ++q) bq[q] = ld4(dt + j * P + 16 * q + 4 * kk);
         f32x4 acc[C / 16];
 #pragma unroll
-        for (int it = 0; it < C / 16; ++it) {
-            acc[it] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        for (int it = 0; it < C / 16; ++it) acc[it] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        // the four output tiles are interleaved so that consecutive MFMAs never depend on each other
+        if (!(dbg & 64))
 #pragma unroll
-            for (int q = 0; q < C / 16; ++q) {
-                acc[it] = __builtin_amdgcn_mfma_f32_16x16x4f32(aq[it][q].x, bq[q].x, acc[it], 0, 0, 0);
-                acc[it] = __builtin_amdgcn_mfma_f32_16x16x4f32(aq[it][q].y, bq[q].y, acc[it], 0, 0, 0);
-                acc[it] = __builtin_amdgcn_mfma_f32_16x16x4f32(aq[it][q].z, bq[q].z, acc[it], 0, 0, 0);
-                acc[it] = __builtin_amdgcn_mfma_f32_16x16x4f32(aq[it][q].w, bq[q].w, acc[it], 0, 0, 0);
-            }
+        for (int q = 0; q < C / 16; ++q) {
+#pragma unroll
+            for (int it = 0; it < C / 16; ++it) acc[it] = __builtin_amdgcn_mfma_f32_16x16x4f32(aq[it][q].x, bq[q].x, acc[it], 0, 0, 0);
+#pragma unroll
+            for (int it = 0; it < C / 16; ++it) acc[it] = __builtin_amdgcn_mfma_f32_16x16x4f32(aq[it][q].y, bq[q].y, acc[it], 0, 0, 0);
+#pragma unroll
+            for (int it = 0; it < C / 16; ++it) acc[it] = __builtin_amdgcn_mfma_f32_16x16x4f32(aq[it][q].z, bq[q].z, acc[it], 0, 0, 0);
+#pragma unroll
+            for (int it = 0; it < C / 16; ++it) acc[it] = __builtin_amdgcn_mfma_f32_16x16x4f32(aq[it][q].w, bq[q].w, acc[it], 0, 0, 0);
         }
-        if (t + 4 < HT_T) HT_LOAD_WT(t + 4);
+        if (t + 4 < HT_T && !(dbg & 128)) HT_LOAD_WT(t + 4);
         if (!(dbg & 4)) atomicAdd(dbias + g * C + lane, s);
         // D reg r: row i = it*16 + kk*4 + r (input channel), col j = node  ->  dR_t[node][channel] over the slab
 #pragma unroll
