@@ -158,18 +158,142 @@ static int launch_cross(bool fwd, const float* a0, const float* a1, const float*
     return GPTST_OK;
 }
 
+// ---- large token counts (T*HS*C no longer fits LDS, e.g. HS = 40 -> 480 tokens): plain global-memory kernels, same algebra -------
+// Correctness path for BASELINE config 4's HS sweep; every kernel is a thread / wave per output with a short loop.
+template <int C>
+__global__ void cx_big_ht_kernel(const float* __restrict__ s, const float* __restrict__ dyn, const float* __restrict__ tmpl,
+                                 float* __restrict__ Ht, int KK, int HS, int HT) {           // Ht[b,j,c] = LReLU(sum_k dyn[b,j,k] (s[b,k,c] + tm[k]))
+    const int b = blockIdx.y, i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= HT * C) return;
+    const int j = i / C, c = i % C;
+    float acc = 0.f;
+    for (int k = 0; k < KK; ++k) acc = fmaf(dyn[((size_t)b * HT + j) * KK + k], s[((size_t)b * KK + k) * C + c] + tmpl[k / HS], acc);
+    Ht[((size_t)b * HT + j) * C + c] = lrelu(acc);
+}
+template <int C>
+__global__ void cx_big_v_kernel(const float* __restrict__ s, const float* __restrict__ dyn, const float* __restrict__ Ht,
+                                float* __restrict__ v, float* __restrict__ Rt, int KK, int HT) {   // one wave per token row
+    constexpr int E = C / 64;
+    const int lane = threadIdx.x & 63, k = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6), b = blockIdx.y;
+    if (k >= KK) return;
+    float u[E], sq = 0.f;
+#pragma unroll
+    for (int e = 0; e < E; ++e) {
+        const int c = lane + 64 * e;
+        float acc = 0.f;
+        for (int j = 0; j < HT; ++j) acc = fmaf(dyn[((size_t)b * HT + j) * KK + k], Ht[((size_t)b * HT + j) * C + c], acc);
+        const float rt = lrelu(acc);
+        Rt[((size_t)b * KK + k) * C + c] = rt;
+        u[e] = rt + s[((size_t)b * KK + k) * C + c];
+        sq = fmaf(u[e], u[e], sq);
+    }
+    const float sc = squash_scale(group_sum<64>(sq));
+#pragma unroll
+    for (int e = 0; e < E; ++e) v[((size_t)b * KK + k) * C + lane + 64 * e] = u[e] * sc;
+}
+template <int C>
+__global__ void cx_big_du_kernel(const float* __restrict__ dv, const float* __restrict__ s, const float* __restrict__ Rt,
+                                 float* __restrict__ dS, int KK) {                                 // dS = du = squash_bwd(Rt + s, dv)
+    constexpr int E = C / 64;
+    const int lane = threadIdx.x & 63, k = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6), b = blockIdx.y;
+    if (k >= KK) return;
+    float u[E], g[E], q = 0.f, udg = 0.f;
+#pragma unroll
+    for (int e = 0; e < E; ++e) {
+        const size_t off = ((size_t)b * KK + k) * C + lane + 64 * e;
+        u[e] = Rt[off] + s[off]; g[e] = dv[off];
+        q = fmaf(u[e], u[e], q); udg = fmaf(u[e], g[e], udg);
+    }
+    q = group_sum<64>(q); udg = group_sum<64>(udg);
+    const float r = sqrtf(q), den = (1.f + q) * (r + 1e-8f);
+    const float gq = q / den;
+    float gp = 0.f;
+    if (r > 0.f) gp = (den - q * ((r + 1e-8f) + (1.f + q) * 0.5f / r)) / (den * den);
+    const float k2 = 2.f * gp * udg;
+#pragma unroll
+    for (int e = 0; e < E; ++e) dS[((size_t)b * KK + k) * C + lane + 64 * e] = fmaf(k2, u[e], gq * g[e]);
+}
+template <int C>
+__global__ void cx_big_dh_kernel(const float* __restrict__ dS, const float* __restrict__ Rt, const float* __restrict__ Ht,
+                                 const float* __restrict__ dyn, float* __restrict__ dH, int KK, int HT) {
+    const int b = blockIdx.y, i = blockIdx.x * blockDim.x + threadIdx.x;       // dHpre[j,c] = lrelu'(Ht) sum_k dyn[j,k] du[k,c] lrelu'(Rt[k,c])
+    if (i >= HT * C) return;
+    const int j = i / C, c = i % C;
+    float acc = 0.f;
+    for (int k = 0; k < KK; ++k) {
+        const size_t off = ((size_t)b * KK + k) * C + c;
+        acc = fmaf(dyn[((size_t)b * HT + j) * KK + k], dS[off] * lrelu_grad_from_out(Rt[off]), acc);
+    }
+    dH[((size_t)b * HT + j) * C + c] = acc * lrelu_grad_from_out(Ht[((size_t)b * HT + j) * C + c]);
+}
+template <int C>
+__global__ void cx_big_ddyn_kernel(const float* __restrict__ dS, const float* __restrict__ Rt, const float* __restrict__ Ht,
+                                   const float* __restrict__ dH, const float* __restrict__ s, const float* __restrict__ tmpl,
+                                   float* __restrict__ ddyn, int KK, int HS, int HT) {
+    const int b = blockIdx.y, i = blockIdx.x * blockDim.x + threadIdx.x;       // ddyn[j,k] = Ht[j].dRpre[k] + dHpre[j].Z[k]
+    if (i >= HT * KK) return;
+    const int j = i / KK, k = i % KK;
+    const float tm = tmpl[k / HS];
+    float acc = 0.f;
+    for (int c = 0; c < C; ++c) {
+        const size_t off = ((size_t)b * KK + k) * C + c;
+        acc = fmaf(Ht[((size_t)b * HT + j) * C + c], dS[off] * lrelu_grad_from_out(Rt[off]), acc);
+        acc = fmaf(dH[((size_t)b * HT + j) * C + c], s[off] + tm, acc);
+    }
+    ddyn[(size_t)b * HT * KK + i] = acc;
+}
+template <int C>
+__global__ void cx_big_ds_kernel(const float* __restrict__ dyn, const float* __restrict__ dH, float* __restrict__ dS, int KK, int HT) {
+    const int b = blockIdx.y, i = blockIdx.x * blockDim.x + threadIdx.x;       // dS[k,c] += sum_j dyn[j,k] dHpre[j,c]   (LAST: dS held du until here)
+    if (i >= KK * C) return;
+    const int k = i / C, c = i % C;
+    float acc = 0.f;
+    for (int j = 0; j < HT; ++j) acc = fmaf(dyn[((size_t)b * HT + j) * KK + k], dH[((size_t)b * HT + j) * C + c], acc);
+    dS[((size_t)b * KK + k) * C + c] += acc;
+}
+
+template <int C>
+static int launch_cross_big(bool fwd, const float* a0, const float* a1, const float* a2, const float* a3, const float* a4, const float* a5,
+                            float* o0, float* o1, float* o2, float* ws, int B, int T, int HS, int HT, hipStream_t st) {
+    const int KK = T * HS;
+    if (fwd) {       // (s, dyn, tmpl) -> v = o0, Ht = o1, Rt = o2
+        hipLaunchKernelGGL((cx_big_ht_kernel<C>), dim3((HT * C + 255) / 256, B), dim3(256), 0, st, a0, a1, a2, o1, KK, HS, HT);
+        hipLaunchKernelGGL((cx_big_v_kernel<C>), dim3((KK + 3) / 4, B), dim3(256), 0, st, a0, a1, (const float*)o1, o0, o2, KK, HT);
+    } else {         // (dv, s, Rt, Ht, dyn, tmpl) -> dS = o0, ddyn = o1; ws = dHpre (B*HT*C)
+        if (!ws) return GPTST_EARG;
+        hipLaunchKernelGGL((cx_big_du_kernel<C>), dim3((KK + 3) / 4, B), dim3(256), 0, st, a0, a1, a2, o0, KK);
+        hipLaunchKernelGGL((cx_big_dh_kernel<C>), dim3((HT * C + 255) / 256, B), dim3(256), 0, st, (const float*)o0, a2, a3, a4, ws, KK, HT);
+        hipLaunchKernelGGL((cx_big_ddyn_kernel<C>), dim3((HT * KK + 255) / 256, B), dim3(256), 0, st, (const float*)o0, a2, a3, (const float*)ws, a1, a5, o1, KK, HS, HT);
+        hipLaunchKernelGGL((cx_big_ds_kernel<C>), dim3((KK * C + 255) / 256, B), dim3(256), 0, st, a4, (const float*)ws, o0, KK, HT);
+    }
+    GPTST_CHECK_LAUNCH();
+    return GPTST_OK;
+}
+
+// floats of device scratch gptst_cap_cross_bwd needs at this shape (0 while the tokens fit LDS)
+extern "C" int gptst_cap_cross_ws_floats(int B, int T, int C, int HS, int HT) {
+    const size_t smem = ((size_t)2 * T * HS * (C + 4) + (size_t)2 * HT * (C + 4) + (size_t)HT * T * HS) * sizeof(float);
+    return smem > 160 * 1024 ? B * HT * C : 0;
+}
+
 extern "C" int gptst_cap_cross_fwd(const float* s, const float* dyn, const float* tmpl, float* v, float* Ht, float* Rt, int B, int T,
                                    int C, int HS, int HT, void* stream) {
     if (!s || !dyn || !tmpl || !v || !Ht || !Rt) return GPTST_EARG;
-    if (C == 64) return launch_cross<64>(true, s, dyn, tmpl, 0, 0, 0, v, Ht, Rt, B, T, HS, HT, (hipStream_t)stream);
-    if (C == 128) return launch_cross<128>(true, s, dyn, tmpl, 0, 0, 0, v, Ht, Rt, B, T, HS, HT, (hipStream_t)stream);
-    return GPTST_ESHAPE;
+    int rc = GPTST_ESHAPE;
+    if (C == 64) rc = launch_cross<64>(true, s, dyn, tmpl, 0, 0, 0, v, Ht, Rt, B, T, HS, HT, (hipStream_t)stream);
+    if (C == 128) rc = launch_cross<128>(true, s, dyn, tmpl, 0, 0, 0, v, Ht, Rt, B, T, HS, HT, (hipStream_t)stream);
+    if (rc == GPTST_ESHAPE && C == 64) rc = launch_cross_big<64>(true, s, dyn, tmpl, 0, 0, 0, v, Ht, Rt, 0, B, T, HS, HT, (hipStream_t)stream);
+    if (rc == GPTST_ESHAPE && C == 128) rc = launch_cross_big<128>(true, s, dyn, tmpl, 0, 0, 0, v, Ht, Rt, 0, B, T, HS, HT, (hipStream_t)stream);
+    return rc;
 }
 
 extern "C" int gptst_cap_cross_bwd(const float* dv, const float* s, const float* Rt, const float* Ht, const float* dyn,
-                                   const float* tmpl, float* dS, float* ddyn, int B, int T, int C, int HS, int HT, void* stream) {
+                                   const float* tmpl, float* dS, float* ddyn, float* ws, int B, int T, int C, int HS, int HT, void* stream) {
     if (!dv || !s || !Rt || !Ht || !dyn || !tmpl || !dS || !ddyn) return GPTST_EARG;
-    if (C == 64) return launch_cross<64>(false, dv, s, Rt, Ht, dyn, tmpl, dS, ddyn, 0, B, T, HS, HT, (hipStream_t)stream);
-    if (C == 128) return launch_cross<128>(false, dv, s, Rt, Ht, dyn, tmpl, dS, ddyn, 0, B, T, HS, HT, (hipStream_t)stream);
-    return GPTST_ESHAPE;
+    int rc = GPTST_ESHAPE;
+    if (C == 64) rc = launch_cross<64>(false, dv, s, Rt, Ht, dyn, tmpl, dS, ddyn, 0, B, T, HS, HT, (hipStream_t)stream);
+    if (C == 128) rc = launch_cross<128>(false, dv, s, Rt, Ht, dyn, tmpl, dS, ddyn, 0, B, T, HS, HT, (hipStream_t)stream);
+    if (rc == GPTST_ESHAPE && C == 64) rc = launch_cross_big<64>(false, dv, s, Rt, Ht, dyn, tmpl, dS, ddyn, 0, ws, B, T, HS, HT, (hipStream_t)stream);
+    if (rc == GPTST_ESHAPE && C == 128) rc = launch_cross_big<128>(false, dv, s, Rt, Ht, dyn, tmpl, dS, ddyn, 0, ws, B, T, HS, HT, (hipStream_t)stream);
+    return rc;
 }

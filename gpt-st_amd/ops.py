@@ -226,7 +226,9 @@ def cap_cross_bwd(dv, s, Rt, Ht, dyn, tmpl, B, T, HS, HT):
     C = s.shape[-1]
     dS = torch.empty_like(s)
     ddyn = torch.empty_like(dyn)
-    _call("gptst_cap_cross_bwd", _p(dv), _p(s), _p(Rt), _p(Ht), _p(dyn), _p(tmpl), _p(dS), _p(ddyn), B, T, C, HS, HT)
+    nws = _C.lib().value("gptst_cap_cross_ws_floats", B, T, C, HS, HT)      # 0 while the cluster tokens fit LDS
+    ws = torch.empty(nws, device=s.device, dtype=torch.float32) if nws else None
+    _call("gptst_cap_cross_bwd", _p(dv), _p(s), _p(Rt), _p(Ht), _p(dyn), _p(tmpl), _p(dS), _p(ddyn), _p(ws), B, T, C, HS, HT)
     return dS, ddyn
 
 

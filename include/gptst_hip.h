@@ -99,8 +99,11 @@ int gptst_cap_route_fwd(const float* X, const float* Wp, const float* bp, const 
  * dyn (B,HT,T*HS) = time_eb_spg . t_adj (poolgen); saves Ht (B,HT,C), Rt (B,T*HS,C) for backward. */
 int gptst_cap_cross_fwd(const float* s, const float* dyn, const float* tmpl, float* v, float* Ht, float* Rt, int B, int T, int C,
                         int HS, int HT, void* stream);
+/* ws: device scratch of gptst_cap_cross_ws_floats() floats — 0 (ws may be NULL) while the T*HS cluster tokens of a sample fit LDS;
+ * beyond that (e.g. HS = 40: 480 tokens) both calls switch to plain global-memory kernels and the backward needs B*HT*C floats. */
+int gptst_cap_cross_ws_floats(int B, int T, int C, int HS, int HT);
 int gptst_cap_cross_bwd(const float* dv, const float* s, const float* Rt, const float* Ht, const float* dyn, const float* tmpl,
-                        float* dS, float* ddyn, int B, int T, int C, int HS, int HT, void* stream);
+                        float* dS, float* ddyn, float* ws, int B, int T, int C, int HS, int HT, void* stream);
 /* cluster -> node scatter (GPTST.py:135): rec[bt,n,:] = sum_h c[bt,h,n] v[bt,h,:]; and its backward (dc1, dv). */
 int gptst_cap_rec_fwd(const float* c, const float* v, float* rec, int BT, int N, int C, int HS, void* stream);
 int gptst_cap_rec_bwd(const float* drec, const float* c, const float* v, float* dc1, float* dv, int BT, int N, int C, int HS,

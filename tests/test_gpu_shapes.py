@@ -30,9 +30,6 @@ CASES = {
 def test_model_vs_oracle(name):
     from gptst_amd.model import GPTST_Model
     c = CASES[name]
-    if name == "hs40":
-        pytest.xfail("T*HS = 480 cluster tokens: cap_cross keeps them LDS-resident (130 KB) -> GPTST_ESHAPE (-2), raised loudly; "
-                     "column-sliced cross-time kernel is listed in DESIGN.md §7")
     args = make_args(c["ds"], scaler_zeros=synth.scaler_zeros(), **c["over"])
     B, T, N, base, HS = c["B"], 12, args.num_nodes, args.input_base_dim, args.HS
     sd = O.init_state_dict(args, 11)
