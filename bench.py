@@ -235,8 +235,11 @@ def main():
         "metric": "pretrain steps/sec at (B=32,T=12,N=170,C=64)", "value": steps_s * 1.0, "unit": "steps/s",
         "n_gpus": a.gpus, "steps": a.steps, "warmup": a.warmup, "ms_per_step": 1e3 * el / a.steps,
         "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-        "config": {"workload": "BASELINE configs[1]: PEMS08-shape synthetic pretrain step, per-GPU B=%d T=%d N=%d C=%d, epoch %d/300 "
-                               "(adaptive mask + KL), fwd+loss+bwd+clip+Adam, hipGraph=%s" % (B, T, N, C, a.epoch, not a.no_graph),
+        "config": {"workload": "%s: %s-shape synthetic pretrain step, per-GPU B=%d T=%d N=%d C=%d base=%d, epoch %d/300 (%s), "
+                               "fwd+loss+bwd+clip+Adam, hipGraph=%s" % (
+                                   {"PEMS08": "BASELINE configs[1]", "METR_LA": "BASELINE configs[2] shape", "NYC_TAXI": "BASELINE configs[3] shape"}.get(a.dataset, a.dataset),
+                                   a.dataset, B, T, N, C, args.input_base_dim, a.epoch,
+                                   "adaptive mask + KL" if a.epoch > args.change_epoch else "random mask", not a.no_graph),
                    "global_batch": B * a.gpus, "parallelism": "dp%d" % a.gpus},
         "samples_per_s": steps_s * B * a.gpus,
         "steps_per_s_random_mask_phase": rnd_rate,
