@@ -164,6 +164,8 @@ def main():
     ap.add_argument("--batch", type=int, default=32)
     ap.add_argument("--dataset", default="PEMS08")
     ap.add_argument("--epoch", type=int, default=200, help="epoch whose masking schedule is benchmarked (of 300)")
+    ap.add_argument("--nodes", type=int, default=0, help="override num_nodes (BASELINE configs[4]: 4096)")
+    ap.add_argument("--hidden", type=int, default=0, help="override hidden_dim (BASELINE configs[4]: 128)")
     ap.add_argument("--no-graph", action="store_true")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-timing", action="store_true")
@@ -188,7 +190,12 @@ def main():
         from gptst_amd.dist import DataParallel
         dp = DataParallel("nccl")
 
-    args = make_args(a.dataset, scaler_zeros=synth.scaler_zeros(), device=str(dev))
+    over = {}
+    if a.nodes:
+        over["num_nodes"] = a.nodes
+    if a.hidden:
+        over["hidden_dim"] = a.hidden
+    args = make_args(a.dataset, scaler_zeros=synth.scaler_zeros(), device=str(dev), **over)
     init_seed(args.seed)
     model = xavier_init_(GPTST_Model(args)).to(dev)
     B, T, N, C = a.batch, 12, args.num_nodes, args.hidden_dim
@@ -232,11 +239,12 @@ def main():
     steps_s = a.steps / el
     dims = dict(B=B, T=T, N=N, C=C, HS=args.HS, R=args.num_route)
     out = {
-        "metric": "pretrain steps/sec at (B=32,T=12,N=170,C=64)", "value": steps_s * 1.0, "unit": "steps/s",
+        "metric": "pretrain steps/sec at (B=%d,T=%d,N=%d,C=%d)" % (B, T, N, C), "value": steps_s * 1.0, "unit": "steps/s",
         "n_gpus": a.gpus, "steps": a.steps, "warmup": a.warmup, "ms_per_step": 1e3 * el / a.steps,
         "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
         "config": {"workload": "%s: %s-shape synthetic pretrain step, per-GPU B=%d T=%d N=%d C=%d base=%d, epoch %d/300 (%s), "
                                "fwd+loss+bwd+clip+Adam, hipGraph=%s" % (
+                                   "BASELINE configs[4] shape (unsharded)" if (a.nodes or a.hidden) else
                                    {"PEMS08": "BASELINE configs[1]", "METR_LA": "BASELINE configs[2] shape", "NYC_TAXI": "BASELINE configs[3] shape"}.get(a.dataset, a.dataset),
                                    a.dataset, B, T, N, C, args.input_base_dim, a.epoch,
                                    "adaptive mask + KL" if a.epoch > args.change_epoch else "random mask", not a.no_graph),

@@ -201,10 +201,57 @@ def tmix_dgraph(dR, X, out=None):
 
 
 # ---- cap -----------------------------------------------------------------------------------------------------
-def cap_route_fwd(X, Wp, bp, dadj, HS, R):
+FORCE_CAP_BIG = False      # tests: take the streaming (capbig) path even when the (b,t) capsule matrix would fit LDS
+
+
+def cap_fits_lds(N, C, HS):
+    return (not FORCE_CAP_BIG) and bool(_C.lib().value("gptst_cap_fits_lds", N, C, HS))
+
+
+def _capbig_linear(X, Wp, bp):
+    """Y = X Wp^T + bp over all rows (ln_p, GPTST.py:102) on the shared-weight apply kernel."""
+    B, T, N, C = X.shape
+    return apply(X.reshape(-1, C), Wp, MODE_SHARED, B * T, N, bias=bp, transw=True)
+
+
+def _capbig_type1(cs, P, S, BT, HS, N, C, reduce_nodes=None):
+    _call("gptst_capbig_type1", _p(cs), _p(P), _p(S), BT, HS, N, C)
+    if reduce_nodes is not None:            # node-sharded run: the one sum over nodes is completed across ranks here
+        reduce_nodes(S)
+
+
+def _cap_route_fwd_big(X, Wp, bp, dadj, HS, R, reduce_nodes=None):
+    B, T, N, C = X.shape
+    BT, dev = B * T, X.device
+    P = _capbig_linear(X, Wp, bp)
+    _call("gptst_capbig_squash_rows", _p(P), BT * N, C)
+    f = dict(device=dev, dtype=torch.float32)
+    cs, c = torch.empty(BT, HS, N, **f), torch.empty(BT, HS, N, **f)
+    S, V0, V, s = (torch.empty(BT, HS, C, **f) for _ in range(4))
+    bl = torch.zeros(BT, HS, N, **f)
+    _call("gptst_capbig_softmax", None, _p(dadj), _p(cs), BT, HS, N, 0, 1)                  # c0 = softmax_h(dadj)        :105
+    _capbig_type1(cs, P, S, BT, HS, N, C, reduce_nodes)
+    _call("gptst_capbig_post", _p(S), None, _p(V0), BT * HS, C, 1)                          # v0 = squash(c0 . P)         :105-106
+    for r in range(R):                                                                      # routing (no grad)           :113-118
+        if r > 0:
+            _call("gptst_capbig_type2", _p(V), _p(P), _p(bl), BT, HS, N, C)                 # b += v . P^T
+        _call("gptst_capbig_softmax", _p(bl), None, _p(cs), BT, HS, N, 1, 0)
+        _capbig_type1(cs, P, S, BT, HS, N, C, reduce_nodes)
+        _call("gptst_capbig_post", _p(S), _p(V0), _p(V), BT * HS, C, 2)                     # v = squash(v0 (.) c.P)
+    if R > 0:
+        _call("gptst_capbig_type2", _p(V), _p(P), _p(bl), BT, HS, N, C)
+    _call("gptst_capbig_softmax", _p(bl), _p(dadj), _p(c), BT, HS, N, 1, 1)                 # c = softmax_h(b + dadj)     :120
+    _capbig_type1(c, P, S, BT, HS, N, C, reduce_nodes)
+    _call("gptst_capbig_post", _p(S), None, _p(s), BT * HS, C, 0)                           # s = c . P                   :123
+    return c, s
+
+
+def cap_route_fwd(X, Wp, bp, dadj, HS, R, reduce_nodes=None):
     """X (B,T,N,C); Wp (C,C) ln_p.weight; dadj (BT, HS*N) logits = teb . adj -> c (BT,HS,N), s (BT,HS,C)."""
     _chk(X, Wp, bp, dadj)
     B, T, N, C = X.shape
+    if not cap_fits_lds(N, C, HS) or reduce_nodes is not None:
+        return _cap_route_fwd_big(X, Wp, bp, dadj, HS, R, reduce_nodes)
     c = torch.empty(B * T, HS, N, device=X.device, dtype=torch.float32)
     s = torch.empty(B * T, HS, C, device=X.device, dtype=torch.float32)
     _call("gptst_cap_route_fwd", _p(X), _p(Wp), _p(bp), _p(dadj), _p(c), _p(s), B * T, N, C, HS, R, nbytes=_nb(X, Wp, bp, dadj, c, s))
@@ -236,16 +283,23 @@ def cap_rec_fwd(c, v, N, C):
     _chk(c, v)
     BT, HS = c.shape[0], c.shape[1]
     rec = torch.empty(BT * N, C, device=c.device, dtype=torch.float32)
+    if not cap_fits_lds(N, C, HS):
+        _call("gptst_capbig_rec_fwd", _p(c), _p(v), _p(rec), BT, HS, N, C)
+        return rec
     _call("gptst_cap_rec_fwd", _p(c), _p(v), _p(rec), BT, N, C, HS, nbytes=_nb(c, v, rec))
     return rec
 
 
-def cap_rec_bwd(drec, c, v):
+def cap_rec_bwd(drec, c, v, reduce_nodes=None):
     _chk(drec, c, v)
     BT, HS, N = c.shape
     C = v.shape[-1]
     dc1 = torch.empty_like(c)
     dv = torch.empty_like(v)
+    if not cap_fits_lds(N, C, HS) or reduce_nodes is not None:
+        _call("gptst_capbig_rec_bwd_dc", _p(drec), _p(v), _p(dc1), BT, HS, N, C)
+        _capbig_type1(c, drec, dv, BT, HS, N, C, reduce_nodes)                       # dv = sum_n c drec: a sum over nodes
+        return dc1, dv
     _call("gptst_cap_rec_bwd", _p(drec), _p(c), _p(v), _p(dc1), _p(dv), BT, N, C, HS, nbytes=_nb(drec, c, v, dc1, dv))
     return dc1, dv
 
@@ -256,6 +310,10 @@ def cap_route_bwd(X, Wp, bp, c, dc1, dS):
     HS = c.shape[1]
     dY = torch.empty(B * T * N, C, device=X.device, dtype=torch.float32)
     dlogit = torch.empty_like(c)
+    if not cap_fits_lds(N, C, HS):
+        Y = _capbig_linear(X, Wp, bp)
+        _call("gptst_capbig_route_bwd_rows", _p(Y), _p(c), _p(dc1), _p(dS), _p(dY), _p(dlogit), B * T, HS, N, C)
+        return dY, dlogit
     _call("gptst_cap_route_bwd", _p(X), _p(Wp), _p(bp), _p(c), _p(dc1), _p(dS), _p(dY), _p(dlogit), B * T, N, C, HS,
           nbytes=_nb(X, Wp, bp, c, dc1, dS, dY, dlogit))
     return dY, dlogit

@@ -113,6 +113,23 @@ int gptst_cap_rec_bwd(const float* drec, const float* c, const float* v, float* 
 int gptst_cap_route_bwd(const float* X, const float* Wp, const float* bp, const float* c, const float* dc1, const float* dS,
                         float* dY, float* dlogit, int BT, int N, int C, int HS, void* stream);
 
+/* ---- cap for node counts whose (b,t) capsule matrix does not fit LDS (cap_big.hip; BASELINE config 5: N = 4096, C = 128) ----
+ * gptst_cap_fits_lds() == 0 -> the host composes the same algebra from these streaming kernels (ops.py: cap_route_fwd/bwd, cap_rec_*):
+ * P = squash(X Wp^T + bp) via gptst_apply + capbig_squash_rows;  cs = softmax_h(use_bl*bl + use_l0*l0)  (all (BT,HS,N));
+ * type1: S (BT,HS,C) = cs . P  — the ONLY sum over nodes, i.e. the all-reduce point of a node-sharded run;
+ * post: 0 out = S, 1 out = squash(S), 2 out = squash(V0 (.) S);  type2: bl += V . P^T;  rec_fwd / rec_bwd_dc: cluster -> node scatter
+ * and the c-gradient of it (dv = type1(c, drec));  route_bwd_rows: backward of gptst_cap_route_bwd given Y = X Wp^T + bp. */
+int gptst_cap_fits_lds(int N, int C, int HS);
+int gptst_capbig_squash_rows(float* Y, long rows, int C, void* stream);
+int gptst_capbig_softmax(const float* bl, const float* l0, float* cs, int BT, int HS, int N, int use_bl, int use_l0, void* stream);
+int gptst_capbig_type1(const float* cs, const float* P, float* S, int BT, int HS, int N, int C, void* stream);
+int gptst_capbig_post(const float* S, const float* V0, float* out, long rows, int C, int post, void* stream);
+int gptst_capbig_type2(const float* V, const float* P, float* bl, int BT, int HS, int N, int C, void* stream);
+int gptst_capbig_rec_fwd(const float* c, const float* v, float* rec, int BT, int HS, int N, int C, void* stream);
+int gptst_capbig_rec_bwd_dc(const float* drec, const float* v, float* dc1, int BT, int HS, int N, int C, void* stream);
+int gptst_capbig_route_bwd_rows(const float* Y, const float* c, const float* dc1, const float* dS, float* dY, float* dlogit, int BT,
+                                int HS, int N, int C, void* stream);
+
 /* ---- mask generation, integer work, bit-exact given noise/labels/class order (maskgen.hip), GPTST.py:314-323,344-413 ----
  * Masks are fp32 {0,1} arrays, 1 = visible, 0 = masked.  Top-k = multi-workgroup radix select on the float bits, one launch per
  * 11/11/10-bit digit + one to write the mask (ties at rank k -> lowest index). */

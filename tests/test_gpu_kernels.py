@@ -186,6 +186,37 @@ def test_cap_layer(B, N, d, ds, HS, HT, R):
         close(a.grad, b.grad, tol=3e-4, what="cap d" + nm)
 
 
+@pytest.mark.parametrize("B,N,C,d,ds,HS,HT,R,force", [(2, 20, 64, 8, 4, 5, 6, 3, True), (1, 170, 64, 16, 4, 10, 16, 2, True),
+                                                       (1, 600, 64, 8, 4, 10, 16, 2, False), (1, 300, 128, 8, 4, 10, 8, 2, False),
+                                                       (1, 37, 128, 4, 3, 40, 5, 1, True)])
+def test_cap_layer_streaming_path(B, N, C, d, ds, HS, HT, R, force):
+    """cap through the capbig kernels (cap_big.hip): taken when the (b,t) capsule matrix does not fit LDS (N = 600 at C = 64,
+    N = 300 at C = 128 — BASELINE config 5 territory) or forced, vs the oracle; the LDS path is covered by test_cap_layer."""
+    from gptst_amd import layers, ops
+    dev = _dev()
+    T = 12
+    assert force or not ops.cap_fits_lds(N, C, HS)
+    ts, go = _cap_case(B, N, C, d, ds, HS, HT, 33)
+    tmpl = torch.linspace(1, T, steps=T) / 12.0
+    cpu = [t.clone().requires_grad_() for t in ts]
+    sd = {"c.t_adj": cpu[4], "c.adj": cpu[5], "c.weights_spa": cpu[6], "c.bias_spa": cpu[7], "c.ln_p.weight": cpu[8],
+          "c.ln_p.bias": cpu[9], "c.mask_template": tmpl}
+    ref, cref, dynref, aux = O.cap(sd, "c.", cpu[0], cpu[1], cpu[2], cpu[3], R, materialize_5d=False, return_aux=True)
+    (ref * go).sum().backward()
+    gpu = [t.to(dev).requires_grad_() for t in ts]
+    ops.FORCE_CAP_BIG = force
+    try:
+        out, c, dyn = layers.cap(*gpu, tmpl.to(dev), R)
+        (out * go.to(dev)).sum().backward()
+    finally:
+        ops.FORCE_CAP_BIG = False
+    close(c, cref.squeeze(-1), what="cap c")
+    close(out, ref, what="cap out")
+    names = ["x", "node_emb", "time_eb_spg", "teb", "t_adj", "adj", "wspa", "bspa", "lnp_w", "lnp_b"]
+    for nm, a, b in zip(names, gpu, cpu):
+        close(a.grad, b.grad, tol=3e-4, what="cap d" + nm)
+
+
 # ---------------------------------------------------------------------------------------------------------------
 # integer path: mask generation, bit-exact vs the oracle's sort/scatter restatement
 # ---------------------------------------------------------------------------------------------------------------

@@ -23,6 +23,8 @@ CASES = {
     "route4": dict(ds="PEMS08", over=dict(num_route=4, num_nodes=33, embed_dim=8), B=2, epoch=100),
     "c128": dict(ds="PEMS08", over=dict(hidden_dim=128, num_nodes=40, embed_dim=8), B=2, epoch=100),
     "c128_rand": dict(ds="NYC_TAXI", over=dict(hidden_dim=128, num_nodes=23, embed_dim=4), B=1, epoch=2),
+    "n600": dict(ds="PEMS08", over=dict(num_nodes=600, embed_dim=8), B=1, epoch=100),                 # capsule matrix beyond LDS: capbig path
+    "n260_c128": dict(ds="PEMS08", over=dict(num_nodes=260, hidden_dim=128, embed_dim=8), B=1, epoch=100),   # config-5 style (C = 128)
 }
 
 
