@@ -166,6 +166,9 @@ def main():
     ap.add_argument("--epoch", type=int, default=200, help="epoch whose masking schedule is benchmarked (of 300)")
     ap.add_argument("--nodes", type=int, default=0, help="override num_nodes (BASELINE configs[4]: 4096)")
     ap.add_argument("--hidden", type=int, default=0, help="override hidden_dim (BASELINE configs[4]: 128)")
+    ap.add_argument("--shard", choices=["batch", "nodes"], default="batch",
+                    help="multi-GPU partitioning: batch = data parallel (default, weak scaling); nodes = node sharding of ONE global "
+                         "batch (SURVEY §8e row 2 / BASELINE configs[4], strong scaling; eager, no hipGraph)")
     ap.add_argument("--no-graph", action="store_true")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-timing", action="store_true")
@@ -197,11 +200,27 @@ def main():
         over["hidden_dim"] = a.hidden
     args = make_args(a.dataset, scaler_zeros=synth.scaler_zeros(), device=str(dev), **over)
     init_seed(args.seed)
-    model = xavier_init_(GPTST_Model(args)).to(dev)
     B, T, N, C = a.batch, 12, args.num_nodes, args.hidden_dim
-    stepper = PretrainStep(model, args, synth.SCALER_MEAN, synth.SCALER_STD, batch_size=B, use_graph=not a.no_graph, dp=dp,
-                           seed=7 + rank)
-    src = synth.make_batch(B, T, N, args.input_base_dim, interval=args.interval, seed=2024 + rank, start_slot=1000 * rank).to(dev)
+    if a.shard == "nodes":
+        # every rank owns N/world nodes of the SAME global batch; parameters are initialised globally and sliced (shard.py)
+        from gptst_amd.shard import DistNodeGroup, ShardedPretrainStep, shard_state_dict
+        assert N % world == 0, "equal node shards"
+        Nl = N // world
+        gmodel = xavier_init_(GPTST_Model(args))                                     # same seed on every rank -> same global init
+        sd_l = shard_state_dict(gmodel.state_dict(), rank * Nl, (rank + 1) * Nl)
+        largs = make_args(a.dataset, scaler_zeros=synth.scaler_zeros(), device=str(dev), **dict(over, num_nodes=Nl))
+        model = GPTST_Model(largs)
+        model.load_state_dict(sd_l)
+        model = model.to(dev)
+        del gmodel
+        stepper = ShardedPretrainStep(model, largs, N, DistNodeGroup(rank, world), synth.SCALER_MEAN, synth.SCALER_STD, batch_size=B, seed=7)
+        gsrc = synth.make_batch(B, T, N, args.input_base_dim, interval=args.interval, seed=2024)
+        src = gsrc[:, :, rank * Nl:(rank + 1) * Nl].contiguous().to(dev)
+    else:
+        model = xavier_init_(GPTST_Model(args)).to(dev)
+        stepper = PretrainStep(model, args, synth.SCALER_MEAN, synth.SCALER_STD, batch_size=B, use_graph=not a.no_graph, dp=dp,
+                               seed=7 + rank)
+        src = synth.make_batch(B, T, N, args.input_base_dim, interval=args.interval, seed=2024 + rank, start_slot=1000 * rank).to(dev)
     stepper.src.copy_(src)                           # inputs resident in HBM before the timed region
 
     for _ in range(max(a.warmup, 1)):
@@ -224,7 +243,7 @@ def main():
 
     # random-mask phase (epochs 1..change_epoch) rate, informative
     rnd_rate = None
-    if world == 1:
+    if world == 1 and a.shard != "nodes":
         for _ in range(5):
             stepper.step(stepper.src, 1)
         torch.cuda.synchronize()
@@ -241,15 +260,16 @@ def main():
     out = {
         "metric": "pretrain steps/sec at (B=%d,T=%d,N=%d,C=%d)" % (B, T, N, C), "value": steps_s * 1.0, "unit": "steps/s",
         "n_gpus": a.gpus, "steps": a.steps, "warmup": a.warmup, "ms_per_step": 1e3 * el / a.steps,
-        "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+        "higher_is_better": True, "scaling": "strong" if a.shard == "nodes" else "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
         "config": {"workload": "%s: %s-shape synthetic pretrain step, per-GPU B=%d T=%d N=%d C=%d base=%d, epoch %d/300 (%s), "
                                "fwd+loss+bwd+clip+Adam, hipGraph=%s" % (
                                    "BASELINE configs[4] shape (unsharded)" if (a.nodes or a.hidden) else
                                    {"PEMS08": "BASELINE configs[1]", "METR_LA": "BASELINE configs[2] shape", "NYC_TAXI": "BASELINE configs[3] shape"}.get(a.dataset, a.dataset),
                                    a.dataset, B, T, N, C, args.input_base_dim, a.epoch,
-                                   "adaptive mask + KL" if a.epoch > args.change_epoch else "random mask", not a.no_graph),
-                   "global_batch": B * a.gpus, "parallelism": "dp%d" % a.gpus},
-        "samples_per_s": steps_s * B * a.gpus,
+                                   "adaptive mask + KL" if a.epoch > args.change_epoch else "random mask", not a.no_graph and a.shard != "nodes"),
+                   "global_batch": B if a.shard == "nodes" else B * a.gpus,
+                   "parallelism": ("nodes%d" if a.shard == "nodes" else "dp%d") % a.gpus},
+        "samples_per_s": steps_s * (B if a.shard == "nodes" else B * a.gpus),
         "steps_per_s_random_mask_phase": rnd_rate,
         "last_loss": loss[0],
     }
@@ -267,7 +287,7 @@ def main():
                             "t_mfma_us": 1e6 * flops_alg / MFMA_F32_PEAK, "hbm_frac": (bytes_alg / HBM_PEAK) / t_step,
                             "mfma_frac": (flops_alg / MFMA_F32_PEAK) / t_step}
 
-    if not a.no_kernel_timing and world == 1:
+    if not a.no_kernel_timing and world == 1 and a.shard != "nodes":
         kt = time_kernels(stepper, a.epoch)
         tot = sum(v["total_s"] for v in kt.values())
         (dn, dt), dv = max(kt.items(), key=lambda kv: kv[1]["total_s"])

@@ -4,6 +4,8 @@ Every ``*_fwd`` returns ``(outputs..., saved)`` and every ``*_bwd`` ACCUMULATES 
 gradient dict ``g`` (views into one flat buffer) and returns the input gradients.  ``p`` / ``g`` map the reference's
 state_dict keys to tensors.  Citations: reference model/Pretrain_model/GPTST.py.
 """
+import threading
+
 import torch
 
 from . import ops
@@ -39,7 +41,19 @@ class ZeroArena:
         return t
 
 
-ARENA = None      # set by PretrainStep; None -> plain torch.zeros
+class _Context(threading.local):
+    """Per-thread execution context of a step (thread-local so that several shard steppers can run side by side in one process:
+    tests emulate the ranks of a node-sharded run with threads).
+      ARENA        ZeroArena of the running step (None -> plain torch.zeros)
+      SIDE / TAIL  optional extra streams (see SideStream)
+      NODE_REDUCE  node-sharded run: callable that completes a sum over nodes across the ranks, in place (None -> single shard)"""
+    ARENA = None
+    SIDE = None
+    TAIL = None
+    NODE_REDUCE = None
+
+
+CTX = _Context()
 
 
 class SideStream:
@@ -74,45 +88,45 @@ class SideStream:
         self.pending = []
 
 
-SIDE = None       # set by PretrainStep (None -> everything on one stream)
-TAIL = None       # second stream for the small, latency-bound kernels off the critical path: parameter generation of the decoder
-                  # (depends only on the time index) and the pool / embedding gradient reductions at the end of an STHCN backward
+# CTX.SIDE: weight gradients on a second stream (opt-in).  CTX.TAIL: second stream for the small, latency-bound kernels off the
+# critical path: parameter generation (depends only on the time index) and the pool / embedding gradient reductions at the end of
+# an STHCN backward.
 
 
 def _off_critical_path(fn, keep=()):
     """Run fn() on the TAIL stream (after everything enqueued so far on the main stream); tensors in `keep` stay referenced until
     the join so the caching allocator cannot recycle them under the side kernels."""
-    if TAIL is None:
+    if CTX.TAIL is None:
         return fn()
-    with TAIL.fork():
+    with CTX.TAIL.fork():
         r = fn()
-    TAIL.keep(r, *keep)
+    CTX.TAIL.keep(r, *keep)
     return r
 
 
 def _join_tail():
-    if TAIL is not None:
-        TAIL.join()
+    if CTX.TAIL is not None:
+        CTX.TAIL.join()
 
 
 def _wgrad_async(*args, **kw):
     """ops.wgrad on the side stream when one is installed."""
-    if SIDE is None:
+    if CTX.SIDE is None:
         return ops.wgrad(*args, **kw)
-    with SIDE.fork():
+    with CTX.SIDE.fork():
         r = ops.wgrad(*args, **kw)
-    SIDE.keep(r[0], *[a for a in args if torch.is_tensor(a)], *[v for v in kw.values() if torch.is_tensor(v)])
+    CTX.SIDE.keep(r[0], *[a for a in args if torch.is_tensor(a)], *[v for v in kw.values() if torch.is_tensor(v)])
     return r
 
 
 def _join_side():
-    if SIDE is not None:
-        SIDE.join()
+    if CTX.SIDE is not None:
+        CTX.SIDE.join()
 
 
 def _zeros(ref, *shape):
-    if ARENA is not None:
-        return ARENA.zeros(*shape)
+    if CTX.ARENA is not None:
+        return CTX.ARENA.zeros(*shape)
     return torch.zeros(*shape, device=ref.device)
 
 
@@ -172,7 +186,8 @@ def hypertem_core_bwd(saved, dout, dG_out, dims):
 def cap_core_fwd(p, pfx, x, dadj, dyn, Wn, bn, dims, num_route, HS, HT):
     """x (BTN,C); dadj (BT,HS*N), dyn (B,HT,T*HS), Wn (N,C,C), bn (N,C) precomputed -> out, c (BT,HS,N), saved."""
     B, T, N, C = dims
-    c, s = ops.cap_route_fwd(x.view(B, T, N, C), p[pfx + "ln_p.weight"], p[pfx + "ln_p.bias"], dadj, HS, num_route)   # :102-123
+    c, s = ops.cap_route_fwd(x.view(B, T, N, C), p[pfx + "ln_p.weight"], p[pfx + "ln_p.bias"], dadj, HS, num_route,
+                             reduce_nodes=CTX.NODE_REDUCE)                                                            # :102-123
     v, Ht, Rt = ops.cap_cross_fwd(s, dyn, p[pfx + "mask_template"], B, T, HS, HT)                                     # :125-134
     rec = ops.cap_rec_fwd(c, v, N, C)                                                                                 # :135
     out = ops.apply(rec, Wn, MODE_NODE, B * T, N, bias=bn, resid=x, epi=EPI_RES_LRELU)                                # :139-141
@@ -187,7 +202,7 @@ def cap_core_bwd(p, g, pfx, saved, dout, dims, HS, HT):
     dbn = _zeros(x, N, C)
     drec = ops.apply(dout, Wn, MODE_NODE, BT, N, A2=out, transw=True, pro=PRO_DPRE, colsum=dbn)
     dWn, ns = _wgrad_async(rec, dout, MODE_NODE, BT, N, D2=out, pro=PRO_DPRE)
-    dc1, dv = ops.cap_rec_bwd(drec, c, v)
+    dc1, dv = ops.cap_rec_bwd(drec, c, v, reduce_nodes=CTX.NODE_REDUCE)
     dS, ddyn = ops.cap_cross_bwd(dv, s, Rt, Ht, dyn, p[pfx + "mask_template"], B, T, HS, HT)
     dY, dlogit = ops.cap_route_bwd(x.view(B, T, N, C), p[pfx + "ln_p.weight"], p[pfx + "ln_p.bias"], c, dc1, dS)
     dx = ops.apply(dY, p[pfx + "ln_p.weight"], MODE_SHARED, BT, N, resid=dout, resid2=out, epi=EPI_ADD_DPRE)
@@ -367,10 +382,10 @@ def model_fwd(p, source, mask, dims, base, num_route, scaler_zeros, gen=None, ge
 def early_gen(p, tidx, dims):
     """Generated parameters of both STHCNs, requested at the start of the step on the TAIL stream: the encoder's overlap with
     the guide forward + mask selection, the decoder's with the encoder forward.  -> (gen_e, event after gen_e, gen_d)."""
-    if TAIL is None:
+    if CTX.TAIL is None:
         return None, None, None
     gen_e = _off_critical_path(lambda: sthcn_gen(p, "encoder.STHCN_encode.", tidx, dims), keep=(tidx,))
-    ev = TAIL.mark()
+    ev = CTX.TAIL.mark()
     gen_d = _off_critical_path(lambda: sthcn_gen(p, "decoder.STHCN_decode.", tidx, dims))
     return gen_e, ev, gen_d
 

@@ -18,7 +18,14 @@ TIMER = None      # bench.py sets this to a list to collect (name, tag, start_ev
 LAST_CALL = {}    # (name, tag) -> argument tuple of the most recent timed launch (bench.py replays the dominant kernel)
 
 
+CALL_LOCK = None  # tests that emulate ranks with threads set a threading.Lock: one C-ABI call (= all launches of one op) at a time
+
+
 def _call(name, *args, tag="", nbytes=0):
+    if CALL_LOCK is not None:
+        with CALL_LOCK:
+            _C.lib().call(name, *args, _C.stream())
+        return
     if TIMER is None:
         _C.lib().call(name, *args, _C.stream())
         return

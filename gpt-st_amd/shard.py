@@ -1,0 +1,222 @@
+"""Node-sharded pretraining step (BASELINE config 5: N = 4096 split 512 nodes per GPU).
+
+Every rank owns a contiguous range of nodes [n0, n1): its slice of the input, of the node-indexed parameters
+(``*.node_embeddings``, ``*.node_embeddings_spg``, ``encoder.neb4mask``, ``*.cap{1,2}.adj``) and of every activation.
+hyperTem, MLP_RL, the in/out projections and the per-node parts of ``cap`` are node-local.  The only sums over nodes are the
+cluster aggregations ``S = c . P`` of ``cap`` (R+2 = 4 per forward, 1 per backward: ``dv = sum_n c drec``); each is ONE kernel
+(ops._capbig_type1) followed by ONE all-reduce of (B*T, HS, C) floats.  The cross-time hyperedge block of ``cap`` runs replicated
+on the all-reduced ``s``, so the gradients it produces (``t_adj``, ``time_feature2``) are identical on every rank and are scaled
+by 1/world before the gradient all-reduce.  Gradients of shared parameters: one all-reduce of the flat buffer (node-local slices
+are put back afterwards — they belong to this rank alone); the global gradient norm adds the other ranks' node-local squared
+norms (one scalar all-reduce).  Masks: the selection runs replicated over the GLOBAL (B,T,N) cells from identical noise and each
+rank keeps its node columns; the adaptive phase all-gathers the per-cell cluster labels and sums the class counts.
+Loss statistics (sum |e|, kept count, KL sum) travel in the tail of the gradient buffer, as in dist.py.
+
+Eager (no hipGraph: collectives sit between kernels).  The collectives go through a small group object: ``DistNodeGroup``
+(torch.distributed, RCCL on GPUs) or ``ThreadNodeGroup`` (ranks emulated by threads on ONE GPU — how the tests check the
+protocol against the unsharded step).
+"""
+import threading
+
+import torch
+
+from . import engine, ops
+from .step import PretrainStep
+
+
+def is_node_local(key):
+    return (key.endswith("node_embeddings") or key.endswith("node_embeddings_spg") or key == "encoder.neb4mask"
+            or (key.endswith(".adj") and ".cap" in key))
+
+
+def is_replicated_compute(key):
+    """Parameters whose gradient is computed identically on every rank (cross-time block on the all-reduced cluster capsules)."""
+    return key.endswith(".t_adj") or ".time_feature2." in key
+
+
+def shard_state_dict(sd, n0, n1):
+    """Global state dict -> this rank's (node-indexed tensors sliced to [n0, n1))."""
+    out = {}
+    for k, v in sd.items():
+        if is_node_local(k):
+            out[k] = (v[..., n0:n1] if k.endswith(".adj") else v[n0:n1]).clone()
+        else:
+            out[k] = v.clone()
+    return out
+
+
+def unshard_state_dicts(sds):
+    """Inverse of shard_state_dict for a list of per-rank state dicts (rank order = node order)."""
+    out = {}
+    for k, v in sds[0].items():
+        if is_node_local(k):
+            out[k] = torch.cat([sd[k] for sd in sds], dim=-1 if k.endswith(".adj") else 0)
+        else:
+            out[k] = v.clone()
+    return out
+
+
+class DistNodeGroup:
+    """Collectives of a node-sharded run over torch.distributed (nccl = RCCL over xGMI on the GPUs)."""
+
+    def __init__(self, rank, world):
+        self.rank, self.world = rank, world
+
+    def all_reduce_(self, t):
+        import torch.distributed as dist
+        if self.world > 1:
+            dist.all_reduce(t, op=dist.ReduceOp.SUM)
+        return t
+
+    def all_gather(self, t):
+        """-> (world, *t.shape)"""
+        import torch.distributed as dist
+        flat = t.contiguous().view(-1)
+        out = torch.empty(self.world * flat.numel(), dtype=t.dtype, device=t.device)      # concatenation form (gloo and nccl)
+        if self.world == 1:
+            out.copy_(flat)
+        else:
+            dist.all_gather_into_tensor(out, flat)
+        return out.view((self.world,) + tuple(t.shape))
+
+
+class ThreadNodeGroup:
+    """The same collectives between `world` threads of one process sharing one GPU stream (tests).  Kernels of all threads land
+    on the same stream in enqueue order, and a barrier separates 'everybody has enqueued its contribution' from the sum."""
+
+    class Shared:
+        def __init__(self, world):
+            self.world = world
+            self.barrier = threading.Barrier(world)
+            self.slots = [None] * world
+
+    def __init__(self, rank, shared):
+        self.rank, self.world, self.sh = rank, shared.world, shared
+
+    def all_reduce_(self, t):
+        sh = self.sh
+        sh.slots[self.rank] = t
+        sh.barrier.wait()
+        total = sh.slots[0].clone()
+        for r in range(1, self.world):
+            total += sh.slots[r]
+        sh.barrier.wait()                      # everybody has read every slot
+        t.copy_(total)
+        sh.barrier.wait()
+        return t
+
+    def all_gather(self, t):
+        sh = self.sh
+        sh.slots[self.rank] = t
+        sh.barrier.wait()
+        out = torch.stack([sh.slots[r] for r in range(self.world)])
+        sh.barrier.wait()
+        return out
+
+
+class ShardedPretrainStep(PretrainStep):
+    """One optimisation step of a rank that owns nodes [n0, n1) of N (all ranks: equal shard sizes)."""
+
+    def __init__(self, model_local, args_local, n_global, group, scaler_mean, scaler_std, batch_size, seed=0):
+        super().__init__(model_local, args_local, scaler_mean, scaler_std, batch_size, use_graph=False, dp=None, seed=seed)
+        self.group, self.Ng = group, n_global
+        self.Nl = args_local.num_nodes
+        assert self.Nl * group.world == n_global, "equal node shards"
+        self.n0 = group.rank * self.Nl
+        Mg = self.B * self.T * self.Ng
+        torch.cuda.manual_seed(7654321 + seed)              # identical global mask noise on every rank
+        self.noise_g = torch.zeros(Mg * self.base, device=self.dev)
+        self.noise_a_g, self.noise_r_g = torch.zeros(Mg, device=self.dev), torch.zeros(Mg, device=self.dev)
+        self.tail = None                                    # single stream: collectives order against everything
+        self.global_count_scale = True
+        named = dict(model_local.named_parameters())
+        self.local_keys = [k for k in named if is_node_local(k)]
+        self.repl_keys = [k for k in named if is_replicated_compute(k)]
+        self.segA = {k: model_local._offs[k] < model_local.nA for k in self.local_keys}
+
+    # global mask -> this rank's node columns
+    def _cols(self, flat_global, per_cell):
+        return flat_global.view(self.B, self.T, self.Ng, per_cell)[:, :, self.n0:self.n0 + self.Nl].contiguous().view(-1)
+
+    def _mask(self, phase, prob):
+        a, base = self.args, self.base
+        Mg = self.B * self.T * self.Ng
+        if not self.inject_noise:
+            if phase == 0:
+                self.noise_g.uniform_()
+            else:
+                self.noise_a_g.uniform_(); self.noise_r_g.uniform_()
+        if phase == 0:
+            mask_g = ops.mask_random(self.noise_g, int(Mg * base * a.mask_ratio))
+        else:
+            label, counts = ops.mask_labels(prob)                                          # local cells (B,T,Nl)
+            lab = self.group.all_gather(label.view(self.B, self.T, self.Nl))               # (W,B,T,Nl)
+            label_g = lab.permute(1, 2, 0, 3).contiguous().view(-1)                        # (B,T,N) node-major within a cell row
+            self.group.all_reduce_(counts)
+            mask_g = ops.mask_adaptive(label_g, counts, self.ctrl[:self.HS], self.ctrl[self.HS:], self.noise_a_g, self.noise_r_g,
+                                       a.ada_type == "all", base)[2]
+        self.last_mask_global = mask_g
+        return self._cols(mask_g, base)
+
+    def step(self, source, epoch, noise=None, noise_a=None, noise_r=None, list_c=None):
+        """source: this rank's (B,T,Nl,base+2) slice; injected noise (tests) covers the GLOBAL (B,T,N[,base]) cells."""
+        mdl, a, base, dims = self.model, self.args, self.base, self.dims
+        phase = 0 if epoch <= a.change_epoch else 1
+        self.src.copy_(source, non_blocking=True)
+        self.inject_noise = noise is not None or noise_a is not None
+        if self.inject_noise:
+            if phase == 0:
+                self.noise_g.copy_(noise.reshape(-1))
+            else:
+                self.noise_a_g.copy_(noise_a.reshape(-1)); self.noise_r_g.copy_(noise_r.reshape(-1))
+        self._host_prepare(phase, epoch, list_c)
+        p, g = mdl.param_views(), self.g
+        M = self.B * self.T * self.Nl
+        self.gbuf.zero_()
+        ctx = engine.CTX
+        ctx.ARENA, ctx.SIDE, ctx.TAIL, ctx.NODE_REDUCE = self.arena, None, None, self.group.all_reduce_
+        try:
+            self.arena.begin()
+            src = self.src
+            tidx = src[:, :, 0, base:base + 2].contiguous()       # every node carries the same time index (GPTST.py:256-257 uses node 0)
+            prob, sv_g = engine.guide_fwd(p, src, tidx, dims, base)
+            mask = self._mask(phase, prob)
+            self.last_mask = mask
+            emb, c1, tidx, sv_e = engine.model_fwd(p, src, mask, dims, base, mdl.num_route, mdl.scaler_zeros)
+            out, dec, sv_d = engine.decoder_fwd(p, tidx, emb, dims, mdl.num_route)
+            ops.mae_fwd(out, src, base + 2, mask, self.std, self.mean, a.mape_thresh, M, base, self.stats)
+            d_out = ops.mae_bwd(out, src, base + 2, mask, self.std, self.mean, a.mape_thresh, M, base, self.stats, normalize=False)
+            engine.model_bwd(p, g, src, mask, tidx, sv_e, sv_d, dec, d_out, None, dims, base, mdl.scaler_zeros)
+            if phase == 1:
+                dlogit = ops.kl(prob, c1, self.Nl, 0.1, self.stats)
+                engine.guide_bwd(p, g, src, tidx, sv_g, dlogit, dims, base)
+        finally:
+            ctx.ARENA = ctx.NODE_REDUCE = None
+        # ---- gradients: replicated-compute parameters count once, node-local ones stay local, the rest is summed ----
+        W = self.group.world
+        for k in self.repl_keys:
+            g[k].mul_(1.0 / W)
+        keep = {k: g[k].clone() for k in self.local_keys}
+        self.group.all_reduce_(self.gbuf)                          # [flat gradient | loss statistics]
+        for k, t in keep.items():
+            g[k].copy_(t)
+        # global gradient norm: the optimiser kernel sees the shared part + OWN node-local part; add the other ranks' local parts
+        sa = 1.0 / torch.clamp(self.stats[1], min=1.0)
+        own = torch.zeros(1, device=self.dev)
+        for k, t in keep.items():
+            if self.segA[k]:
+                own += (t * sa).pow(2).sum()
+            elif phase == 1:
+                own += t.pow(2).sum()
+        tot = own.clone()
+        self.group.all_reduce_(tot)
+        self.stats[3] += (tot - own)[0]
+        self._optim()
+
+    def _host_prepare(self, phase, epoch, list_c):
+        super()._host_prepare(phase, epoch, list_c)
+        if phase == 1:                                            # mask budgets over the GLOBAL cell count
+            ada, rnd = self.model.adaptive_counts(self.B * self.T * self.Ng, epoch)
+            c = self.ctrl_host
+            c[self.HS], c[self.HS + 1] = ada, rnd
+            self.ctrl.copy_(c)

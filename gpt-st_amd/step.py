@@ -46,6 +46,7 @@ class PretrainStep:
         self.rng = random.Random(seed)
         self.graphs = {}
         self.inject_noise = False
+        self.global_count_scale = False      # set by subclasses that all-reduce [gradient | statistics] themselves (shard.py)
         self.arena = engine.ZeroArena(self.dev)
         # ---- data parallel: masks over the GLOBAL batch (dist.py) ----
         self.W = dp.world if dp is not None else 1
@@ -71,9 +72,9 @@ class PretrainStep:
         a = self.args
         M = self.B * self.T * self.N
         self.gbuf.zero_()
-        engine.ARENA = self.arena
-        engine.SIDE = self.side
-        engine.TAIL = self.tail
+        engine.CTX.ARENA = self.arena
+        engine.CTX.SIDE = self.side
+        engine.CTX.TAIL = self.tail
         self.arena.begin()
         src = self.src
         tidx = src[:, :, 0, base:base + 2].contiguous()
@@ -107,9 +108,9 @@ class PretrainStep:
             engine.guide_bwd(p, g, src, tidx, sv_g, dlogit, dims, base)
         engine._join_side()
         engine._join_tail()
-        engine.ARENA = None
-        engine.SIDE = None
-        engine.TAIL = None
+        engine.CTX.ARENA = None
+        engine.CTX.SIDE = None
+        engine.CTX.TAIL = None
 
     def _global_mask(self, phase):
         """Mask of this rank's rows cut out of the selection over the global batch (identical on every rank)."""
@@ -132,13 +133,13 @@ class PretrainStep:
 
     def _labels_body(self):
         p, dims, base = self.model.param_views(), self.dims, self.base
-        engine.ARENA = self.arena_l
+        engine.CTX.ARENA = self.arena_l
         self.arena_l.begin()
         tidx = self.src[:, :, 0, base:base + 2].contiguous()
         prob, _ = engine.guide_fwd(p, self.src, tidx, dims, base)
         label, counts = ops.mask_labels(prob)
         self.label_l.copy_(label); self.counts_g.copy_(counts)
-        engine.ARENA = None
+        engine.CTX.ARENA = None
 
     def _exchange_labels(self):
         """Adaptive phase under DP: cluster labels of the local rows (guide forward + argmax, its own small hipGraph), then one
@@ -185,7 +186,7 @@ class PretrainStep:
         h[4], h[5], h[6] = b1, b2, 1e-8
         h[7] = float(a.max_grad_norm) if a.grad_norm else 0.0
         h[8] = 1.0 if phase == 1 else 0.0
-        h[9] = 0.0 if self.dp is None else 1.0
+        h[9] = 1.0 if (self.dp is not None or self.global_count_scale) else 0.0     # divide path-A gradients by the GLOBAL kept count
         h[10] = 1.0
         self.hyper.copy_(h, non_blocking=True)
         if phase == 1:

@@ -148,10 +148,10 @@ def test_dp_global_mask_equals_single_process_global_batch(use_graph):
     labels, counts = [], []
     for r in range(W):
         src = src_g[r * Bl:(r + 1) * Bl].contiguous()
-        engine.ARENA = engine.ZeroArena(torch.device(DEV)); engine.ARENA.begin()
+        engine.CTX.ARENA = engine.ZeroArena(torch.device(DEV)); engine.CTX.ARENA.begin()
         prob, _ = engine.guide_fwd(model.param_views(), src, src[:, :, 0, 1:3].contiguous(), (Bl, 12, 20, args.hidden_dim), 1)
         lab, cnt = ops.mask_labels(prob)
-        engine.ARENA = None
+        engine.CTX.ARENA = None
         labels.append(lab.clone()); counts.append(cnt.clone())
     for epoch in (1, 20):
         _, st = fresh(4)
