@@ -423,3 +423,36 @@ def kl(prob, c, N, w, stats, want_grad=True):
 
 def clip_adam(p, g, m, v, nA, nB, hyper, stats):
     _call("gptst_clip_adam", _p(p), _p(g), _p(m), _p(v), int(nA), int(nB), _p(hyper), _p(stats))
+
+
+# ---- evaluation metrics (Trainer.test) ---------------------------------------------------------------------------------
+def metrics_new(T, N, device):
+    return torch.zeros(T, 5, device=device, dtype=torch.float64), torch.zeros(T, N, 6, device=device, dtype=torch.float64)
+
+
+def metrics_accum(out, src, lda, vis, sigma, mu, mae_thresh, mape_thresh, B, T, N, D, sums_t, sums_tn):
+    """Add one batch to the metric sums: out (B*T*N, D), src (B,T,N,lda) normalised input (label = first D channels), vis fp32 mask or None."""
+    _call("gptst_metrics_accum", _p(out), _p(src), lda, _p(vis), float(sigma), float(mu), int(mae_thresh is not None),
+          float(mae_thresh if mae_thresh is not None else 0.0), float(mape_thresh), B, T, N, D, _p(sums_t), _p(sums_tn))
+
+
+def metrics_report(sums_t, sums_tn):
+    """-> (T+1, 4) float64 rows [mae, rmse, mape, corr]: one per horizon, then the average over all horizons
+    (BasicTrainer.py:241-248; CORR per lib/metrics.py:52-77: per node over (batch, [time,] channel), unbiased std, nodes with
+    constant truth skipped, mean over nodes)."""
+    st, sn = sums_t.cpu(), sums_tn.cpu()
+
+    def rows_of(a, m):
+        mae, rmse, mape = a[..., 1] / a[..., 0], torch.sqrt(a[..., 2] / a[..., 0]), a[..., 4] / a[..., 3]
+        K, sp, sy, spp, syy, spy = (m[..., k] for k in range(6))
+        pm, ym = sp / K, sy / K
+        cov = spy / K - pm * ym
+        pvar, yvar = (spp - K * pm * pm) / (K - 1), (syy - K * ym * ym) / (K - 1)
+        c = cov / torch.sqrt(pvar.clamp_min(0) * yvar.clamp_min(0))
+        ok = yvar > 1e-9 * (syy / K).clamp_min(1e-30)                     # true_std != 0
+        corr = torch.stack([c[i][ok[i]].mean() for i in range(c.shape[0])]) if c.dim() == 2 else c[ok].mean()
+        return torch.stack([mae, rmse, mape, corr], -1)
+
+    per_t = rows_of(st, sn)
+    avg = rows_of(st.sum(0), sn.sum(0))
+    return torch.cat([per_t, avg[None]], 0)

@@ -97,4 +97,35 @@ class Trainer:
         if a.debug and best_state is not None and (self.dp is None or self.dp.rank == 0):   # :187-189 (flag is inverted in the reference too)
             torch.save(best_state, self.best_path)
             self.logger.info("Saving current best model to " + self.best_path)
+        if best_state is not None and (self.dp is None or self.dp.rank == 0):   # :193-195: pretrain mode evaluates on the TRAIN loader
+            last = copy.deepcopy(self.model.state_dict())
+            self.model.load_state_dict(best_state)
+            self.test(self.batches(a.epochs))
+            self.model.load_state_dict(last)
         return best_state
+
+    def test(self, batches):
+        """Trainer.test of the reference in pretrain mode (model/BasicTrainer.py:209-248): forward at epoch = args.epochs (adaptive
+        masks), y_true = label*mask, y_pred = output*mask, inverse transform, per-horizon MAE / RMSE / MAPE / CORR and their average.
+        The sums are accumulated on the device by gptst_metrics_accum — no concatenated prediction tensor."""
+        from . import ops
+        a, model = self.args, self.model
+        base = a.input_base_dim
+        sums = None
+        with torch.no_grad():
+            for src in batches:
+                src = src.contiguous()
+                B, T, N, _ = src.shape
+                out, _, masked, _, _ = model(src, None, None, a.epochs)
+                if sums is None:
+                    sums = ops.metrics_new(T, N, src.device)
+                vis = (1 - masked).to(torch.float32).reshape(-1).contiguous()
+                ops.metrics_accum(out.reshape(-1, base).contiguous(), src, base + 2, vis, self.scaler[1], self.scaler[0],
+                                  getattr(a, "mae_thresh", None), a.mape_thresh, B, T, N, base, *sums)
+        rows = ops.metrics_report(*sums)
+        for t in range(rows.shape[0] - 1):
+            mae, rmse, mape, corr = (float(v) for v in rows[t])
+            self.logger.info("Horizon {:02d}, MAE: {:.2f}, RMSE: {:.2f}, MAPE: {:.4f}, CORR:{:.4f}%".format(t + 1, mae, rmse, mape * 100, corr))
+        mae, rmse, mape, corr = (float(v) for v in rows[-1])
+        self.logger.info("Average Horizon, MAE: {:.2f}, RMSE: {:.2f}, MAPE: {:.4f}%, CORR:{:.4f}".format(mae, rmse, mape * 100, corr))
+        return rows

@@ -130,6 +130,13 @@ int gptst_capbig_rec_bwd_dc(const float* drec, const float* v, float* dc1, int B
 int gptst_capbig_route_bwd_rows(const float* Y, const float* c, const float* dc1, const float* dS, float* dY, float* dlogit, int BT,
                                 int HS, int N, int C, void* stream);
 
+/* ---- evaluation metrics of Trainer.test (metrics.hip), reference model/BasicTrainer.py:209-248 + lib/metrics.py:11-18,38-43,52-86 ----
+ * Accumulates, over one batch, the sums the per-horizon MAE / RMSE / MAPE / CORR need (doubles; caller zeroes them once per evaluation):
+ * sums_t (T,5) = [n1, sum|e|, sum e^2, n2, sum|e/y|], sums_tn (T,N,6) = [K, sum p, sum y, sum p^2, sum y^2, sum p y];
+ * p = (out*m)*sigma+mu, y = (label*m)*sigma+mu with m = 1 - vis (pretrain mode, :229-235); vis == NULL -> m = 1. */
+int gptst_metrics_accum(const float* out, const float* src, int lda, const float* vis, float sigma, float mu, int has_mae_thresh,
+                        float mae_thresh, float mape_thresh, int B, int T, int N, int D, double* sums_t, double* sums_tn, void* stream);
+
 /* ---- mask generation, integer work, bit-exact given noise/labels/class order (maskgen.hip), GPTST.py:314-323,344-413 ----
  * Masks are fp32 {0,1} arrays, 1 = visible, 0 = masked.  Top-k = multi-workgroup radix select on the float bits, one launch per
  * 11/11/10-bit digit + one to write the mask (ties at rank k -> lowest index). */
