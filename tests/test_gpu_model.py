@@ -104,3 +104,33 @@ def test_model_full_pems08_forward():
     emodel = _build(make_args("PEMS08", scaler_zeros=synth.scaler_zeros(), mode="eval"), O.init_state_dict(args, 12))
     emb = emodel(src, None)[0]
     assert _rel(emb[:, :, ::7, ::5], t(fx, "eval.emb_sub")) < 1e-4
+
+
+def test_enhance_front_end_consumes_pretrain_checkpoint(tmp_path):
+    """the downstream consumer (reference Enhance_model.forward_pretrain + Fusion, model/Model.py:5-18,91-107)
+    loads a checkpoint written by the pretraining model and produces the fused embedding; encoder vs the oracle's eval forward,
+    fusion with the same torch weights on CPU; gradients reach only the downstream modules."""
+    from gptst_amd.enhance import EnhanceFrontEnd
+    from gptst_amd.model import GPTST_Model
+    args = make_args("PEMS08", num_nodes=30, embed_dim=8, HS=5, HT=6, scaler_zeros=synth.scaler_zeros())
+    sd = O.init_state_dict(args, 9)
+    pre = GPTST_Model(args); pre.load_state_dict(sd)
+    path = str(tmp_path / "pretrain.pth")
+    torch.save(pre.state_dict(), path)                                   # what Trainer.train saves (BasicTrainer.py:187-189)
+    eargs = make_args("PEMS08", num_nodes=30, embed_dim=8, HS=5, HT=6, scaler_zeros=synth.scaler_zeros(), mode="eval")
+    torch.manual_seed(0)
+    fe = EnhanceFrontEnd(eargs)
+    fe.load_pretrained_model(path)
+    src = synth.make_batch(3, 12, 30, 1, seed=8)
+    want_emb = O.forward_eval(sd, args, src)
+    cpu_fusion = {k: v.detach().clone() for k, v in fe.state_dict().items() if not k.startswith("pretrain_model.")}
+    x_t1 = src[..., :1] @ cpu_fusion["lin_test.weight"].T + cpu_fusion["lin_test.bias"]
+    z = torch.sigmoid(want_emb @ cpu_fusion["fusion.HS_fc.weight"].T + cpu_fusion["fusion.HS_fc.bias"]
+                      + x_t1 @ cpu_fusion["fusion.HT_fc.weight"].T + cpu_fusion["fusion.HT_fc.bias"])
+    want = (z * want_emb + (1 - z) * x_t1) @ cpu_fusion["fusion.output_fc.weight"].T + cpu_fusion["fusion.output_fc.bias"]
+    fe = fe.to(DEV)
+    got = fe(src.to(DEV))
+    torch.testing.assert_close(got.detach().cpu(), want.detach(), rtol=1e-4, atol=1e-4)
+    got.square().mean().backward()
+    assert fe.fusion.output_fc.weight.grad is not None and fe.lin_test.weight.grad is not None
+    assert all(p.grad is None for p in fe.pretrain_model.parameters())
