@@ -219,7 +219,7 @@ def main():
     else:
         model = xavier_init_(GPTST_Model(args)).to(dev)
         stepper = PretrainStep(model, args, synth.SCALER_MEAN, synth.SCALER_STD, batch_size=B, use_graph=not a.no_graph, dp=dp,
-                               seed=7 + rank)
+                               seed=7)          # same seed on every rank: global mask noise and class order must agree (dist.py)
         src = synth.make_batch(B, T, N, args.input_base_dim, interval=args.interval, seed=2024 + rank, start_slot=1000 * rank).to(dev)
     stepper.src.copy_(src)                           # inputs resident in HBM before the timed region
 

@@ -16,6 +16,8 @@ from . import engine, ops
 
 class PretrainStep:
     def __init__(self, model, args, scaler_mean, scaler_std, batch_size, use_graph=True, dp=None, seed=0, global_mask=True):
+        """``seed`` drives the class-order shuffle and (data parallel, global masks) the mask noise: it must be the SAME on every
+        rank, because every rank regenerates the selection over the global batch and keeps its rows (dist.py)."""
         self.model, self.args = model, args
         self.mean, self.std = float(scaler_mean), float(scaler_std)
         self.B, self.T, self.N = batch_size, args.lag, args.num_nodes
