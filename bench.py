@@ -49,9 +49,9 @@ def kernel_flops(name, tag, d):
 
 # C-ABI entry point (+ tag) -> kernel symbol prefix in rocprofv3 traces / profiles/pmc_traffic.json
 KERNEL_SYMBOL = {
-    "gptst_cap_route_fwd": "void cap_route_fwd2_kernel<64>", "gptst_cap_route_bwd": "void cap_route_bwd2_kernel<64>",
+    "gptst_cap_route_fwd": "void cap_route_fwd2_kernel<64,", "gptst_cap_route_bwd": "void cap_route_bwd2_kernel<64>",
     "gptst_hypertem_fwd": "hypertem_fwd_kernel", "gptst_hypertem_bwd": "hypertem_bwd_kernel", "gptst_wgrad": "void wgrad64_kernel",
-    "gptst_apply": "void apply_kernel<64", "gptst_tmix": "void tmix_kernel<64", "gptst_tmix_dgraph": "void tmix_dgraph_kernel<64>",
+    "gptst_apply": "void apply64_kernel<", "gptst_tmix": "void tmix_kernel<64", "gptst_tmix_dgraph": "void tmix_dgraph_kernel<64>",
     "gptst_cap_rec_bwd": "void cap_rec_bwd2_kernel<64>", "gptst_cap_cross_bwd": "void cap_cross_bwd_kernel<64>",
     "gptst_cap_rec_fwd": "void cap_rec_fwd_kernel<64>",
 }
@@ -67,7 +67,7 @@ def pmc_traffic(name, tag, grid_hint=None):
     if name == "gptst_apply":
         m = {"mode0": None, "mode1": None, "mode2": None}
         pro, epi = tag.split()[1][3:], tag.split()[2][3:]
-        sym = "void apply_kernel<64, %s, %s>" % (pro, epi)
+        sym = "void apply64_kernel<%s, %s>" % (pro, epi)
     if name == "gptst_wgrad":
         sym = "void wgrad64_kernel<%s," % tag.split()[1][3:4]
     cands = [(k, v) for k, v in ks.items() if k.startswith(sym)]
