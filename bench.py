@@ -186,12 +186,13 @@ def main():
         raise SystemExit("--gpus %d but WORLD_SIZE=%d" % (a.gpus, world))
     if a.gpus > 1 and world == 1:
         raise SystemExit("launch with torch.distributed.run for --gpus > 1")
+    local = local % max(torch.cuda.device_count(), 1)             # (tests: several ranks may share one GPU over gloo)
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     dp = None
     if world > 1 or os.environ.get("GPTST_FORCE_DP") == "1":      # FORCE_DP: exercise the RCCL path with one rank
         from gptst_amd.dist import DataParallel
-        dp = DataParallel("nccl")
+        dp = DataParallel(os.environ.get("GPTST_DIST_BACKEND", "nccl"))   # nccl = RCCL over xGMI; gloo only to exercise the path on one GPU
 
     over = {}
     if a.nodes:

@@ -482,11 +482,13 @@ extern "C" int gptst_apply(const float* A, const float* A2, const float* W, int 
 }
 
 // dW has room for nsplit * G matrices; returns nsplit through *nsplit_out (consumers sum the splits).
+int g_wgrad_ns0_override = 0;
 int g_wgrad_ns_override = 0;                           // experiments: gptst_tune(2, ns) forces the NODE-mode split
 extern "C" int gptst_wgrad_nsplit(int mode, int BT, int N) {
     RowMap rm = make_rowmap(mode, BT, N);
     if (mode == 2) return (rm.M + 255) / 256;          // shared weight: 256-row chunks
     if (mode == 1 && g_wgrad_ns_override > 0) return g_wgrad_ns_override;
+    if (mode == 0 && g_wgrad_ns0_override > 0) return g_wgrad_ns0_override;
     if (rm.G >= 256) return 1;
     int want = 512 / rm.G;                             // largest split that still fits ONE round of 2 workgroups per CU
     if (want < 1) want = 1;                            // (G = 170: 3 x 170 = 510 workgroups 12.8 us; 4 x 170 = 680 -> 16.4 us)

@@ -190,11 +190,13 @@ __global__ __launch_bounds__(256) void poolgen_bwd_emb_kernel(PgBwd a, float* __
 }
 
 extern int g_wgrad_ns_override;
+extern int g_wgrad_ns0_override;
 extern int g_apply_v1;
 extern int g_apply_tpw;
 extern "C" int gptst_tune(int id, int value) {
     if (id == 1) g_pg_nchunk = value;
     if (id == 2) g_wgrad_ns_override = value;
+    if (id == 5) g_wgrad_ns0_override = value;
     if (id == 3) g_apply_v1 = value;
     if (id == 4) g_apply_tpw = value;
     return GPTST_OK;
