@@ -259,7 +259,12 @@ def main():
     steps_s = a.steps / el
     dims = dict(B=B, T=T, N=N, C=C, HS=args.HS, R=args.num_route)
     out = {
-        "metric": "pretrain steps/sec at (B=%d,T=%d,N=%d,C=%d)" % (B, T, N, C), "value": steps_s * 1.0, "unit": "steps/s",
+        # whole-job aggregate: per-GPU-batch steps per second summed over the ranks (weak-scaling data parallelism processes
+        # n_gpus batches of B per optimizer step); node sharding (strong scaling) processes ONE batch per step
+        "metric": "pretrain steps/sec at (B=%d,T=%d,N=%d,C=%d)" % (B, T, N, C),
+        "value": steps_s * (1 if a.shard == "nodes" else a.gpus), "unit": "steps/s",
+        "value_definition": "batches of B=%d processed per second by the whole job (= optimizer steps/s x n_gpus under data parallelism)" % B,
+        "optimizer_steps_per_s": steps_s,
         "n_gpus": a.gpus, "steps": a.steps, "warmup": a.warmup, "ms_per_step": 1e3 * el / a.steps,
         "higher_is_better": True, "scaling": "strong" if a.shard == "nodes" else "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
         "config": {"workload": "%s: %s-shape synthetic pretrain step, per-GPU B=%d T=%d N=%d C=%d base=%d, epoch %d/300 (%s), "
