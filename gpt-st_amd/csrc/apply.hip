@@ -434,7 +434,7 @@ static int launch_apply(const float* A, const float* A2, const float* W, long w_
     const int ntiles = (rm.M + 31) / 32;
     int gy = (ntiles + 3) / 4;
     if (rm.G == 1) gy = min(gy, colsum ? 128 : 1024);  // shared weight: with colsum keep the atomics per address low
-    else gy = min(gy, 2);
+    else gy = min(gy, max(2, (768 + rm.G - 1) / rm.G));      // >= ~768 workgroups when the groups are few and long (N = 4096: 96 groups x 128 tiles)
     if (gy < 1) gy = 1;
     dim3 grid(rm.G, gy), block(256);
     const size_t smem = (size_t)(C * C + 4 * Tile<C>::TILE_FLOATS) * sizeof(float);

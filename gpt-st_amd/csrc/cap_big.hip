@@ -49,35 +49,48 @@ __global__ void cb_softmax_kernel(const float* __restrict__ bl, const float* __r
     }
 }
 
-// S[bt,h,c] += sum_{n in chunk} cs[bt,h,n] P[bt,n,c];  grid (BT, node chunks, ceil(HS/16)), block = C threads x (256/C) node lanes
+// S[bt,h,c] += sum_{n in chunk} cs[bt,h,n] P[bt,n,c];  grid (BT, node chunks, ceil(HS/16)).  A thread owns four channels (one float4
+// of P per node, 4 nodes in flight) and 256/(C/4) node slots share a chunk; slots fold in LDS, one atomic per output and workgroup.
 #define CB_CHUNK 256
 template <int C>
 __global__ __launch_bounds__(256) void cb_type1_kernel(const float* __restrict__ cs, const float* __restrict__ P, float* __restrict__ S,
                                                        int HS, int N) {
-    constexpr int SL = 256 / C;                         // node slots per workgroup
-    __shared__ float red[SL][16][C];
+    constexpr int L = C / 4, SL = 256 / L;              // lanes per node row, node slots per workgroup
+    __shared__ float4 red[SL][16][L];
     const int bt = blockIdx.x, n0 = blockIdx.y * CB_CHUNK, h0 = blockIdx.z * 16;
-    const int c = threadIdx.x % C, sl = threadIdx.x / C;
-    const int nh = min(16, HS - h0);
-    float acc[16];
+    const int c4 = threadIdx.x % L, sl = threadIdx.x / L;
+    const int nh = min(16, HS - h0), nend = min(N, n0 + CB_CHUNK);
+    float4 acc[16];
 #pragma unroll
-    for (int h = 0; h < 16; ++h) acc[h] = 0.f;
-    for (int n = n0 + sl; n < min(N, n0 + CB_CHUNK); n += SL) {
-        const float p = P[((long)bt * N + n) * C + c];
+    for (int h = 0; h < 16; ++h) acc[h] = f4zero();
+    const float* csb = cs + ((long)bt * HS + h0) * N;
+    for (int n = n0 + sl; n < nend; n += 4 * SL) {
+        float4 p[4];
 #pragma unroll
-        for (int h = 0; h < 16; ++h)
-            if (h < nh) acc[h] = fmaf(cs[((long)bt * HS + h0 + h) * N + n], p, acc[h]);
+        for (int u = 0; u < 4; ++u) {
+            const int nn = min(n + u * SL, nend - 1);
+            p[u] = ld4(P + ((long)bt * N + nn) * C + 4 * c4);
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int nn = n + u * SL;
+            if (nn < nend) {
+#pragma unroll
+                for (int h = 0; h < 16; ++h)
+                    if (h < nh) acc[h] = f4fma(csb[(long)h * N + nn], p[u], acc[h]);
+            }
+        }
     }
 #pragma unroll
-    for (int h = 0; h < 16; ++h) red[sl][h][c] = acc[h];
+    for (int h = 0; h < 16; ++h) red[sl][h][c4] = acc[h];
     __syncthreads();
-    if (sl == 0) {
-        for (int h = 0; h < nh; ++h) {
-            float s = 0.f;
+    for (int o = threadIdx.x; o < nh * L; o += 256) {
+        const int h = o / L, cc = o % L;
+        float4 s = red[0][h][cc];
 #pragma unroll
-            for (int q = 0; q < SL; ++q) s += red[q][h][c];
-            atomicAdd(S + ((long)bt * HS + h0 + h) * C + c, s);
-        }
+        for (int q = 1; q < SL; ++q) s = f4add(s, red[q][h][cc]);
+        float* dst = S + ((long)bt * HS + h0 + h) * C + 4 * cc;
+        atomicAdd(dst + 0, s.x); atomicAdd(dst + 1, s.y); atomicAdd(dst + 2, s.z); atomicAdd(dst + 3, s.w);
     }
 }
 __global__ void cb_zero_kernel(float* __restrict__ p, long n) {
@@ -104,23 +117,21 @@ __global__ void cb_post_kernel(const float* __restrict__ S, const float* __restr
     for (int e = 0; e < E; ++e) out[row * C + lane + 64 * e] = v[e] * sc;
 }
 
-// bl[bt,h,n] += V[bt,h,:] . P[bt,n,:], one wave per (bt, n)
+// bl[bt,h,n] += V[bt,h,:] . P[bt,n,:]:  C/4 lanes per (bt, n) row, each with one float4 of P; the HS dot products are reduced over
+// those lanes with DPP (16 lanes) plus one shuffle for C = 128
 template <int C>
 __global__ void cb_type2_kernel(const float* __restrict__ V, const float* __restrict__ P, float* __restrict__ bl, int BT, int HS, int N) {
-    constexpr int E = C / 64;
-    const long row = (long)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
-    const int lane = threadIdx.x & 63;
-    if (row >= (long)BT * N) return;
-    const long bt = row / N, n = row % N;
-    float p[E];
-#pragma unroll
-    for (int e = 0; e < E; ++e) p[e] = P[row * C + lane + 64 * e];
+    constexpr int L = C / 4, RPB = 256 / L;
+    const long row = (long)blockIdx.x * RPB + threadIdx.x / L;
+    const int c4 = threadIdx.x % L;
+    const bool ok = row < (long)BT * N;
+    const long r = ok ? row : 0;
+    const long bt = r / N, n = r % N;
+    const float4 p = ld4(P + r * C + 4 * c4);
     for (int h = 0; h < HS; ++h) {
-        float d = 0.f;
-#pragma unroll
-        for (int e = 0; e < E; ++e) d = fmaf(V[(bt * HS + h) * C + lane + 64 * e], p[e], d);
-        d = group_sum<64>(d);
-        if (lane == 0) bl[(bt * HS + h) * N + n] += d;
+        float d = f4dot(ld4(V + (bt * HS + h) * C + 4 * c4), p);
+        d = group_sum<L>(d);
+        if (c4 == 0 && ok) bl[(bt * HS + h) * N + n] += d;
     }
 }
 
@@ -256,7 +267,12 @@ extern "C" int gptst_capbig_post(const float* S, const float* V0, float* out, lo
 }
 extern "C" int gptst_capbig_type2(const float* V, const float* P, float* bl, int BT, int HS, int N, int C, void* stream) {
     if (!V || !P || !bl) return GPTST_EARG;
-    CB_DISPATCH(cb_type2_kernel, CB_ROWS_GRID((long)BT * N), V, P, bl, BT, HS, N);
+    const long rows = (long)BT * N;
+    if (C == 64) hipLaunchKernelGGL((cb_type2_kernel<64>), dim3((unsigned)((rows + 15) / 16)), dim3(256), 0, (hipStream_t)stream, V, P, bl, BT, HS, N);
+    else if (C == 128) hipLaunchKernelGGL((cb_type2_kernel<128>), dim3((unsigned)((rows + 7) / 8)), dim3(256), 0, (hipStream_t)stream, V, P, bl, BT, HS, N);
+    else return GPTST_ESHAPE;
+    GPTST_CHECK_LAUNCH();
+    return GPTST_OK;
 }
 extern "C" int gptst_capbig_rec_fwd(const float* c, const float* v, float* rec, int BT, int HS, int N, int C, void* stream) {
     if (!c || !v || !rec) return GPTST_EARG;
