@@ -13,7 +13,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np   # noqa: E402
 import torch         # noqa: E402
 
-from gptst_amd import data as gdata                          # noqa: E402
+from gptst_amd import data as gdata, synth                   # noqa: E402
 from gptst_amd.config import parse_args                      # noqa: E402
 from gptst_amd.model import GPTST_Model, init_seed, xavier_init_   # noqa: E402
 from gptst_amd.trainer import Trainer                        # noqa: E402
@@ -36,13 +36,8 @@ def main():
     fname = gdata.DATASETS[args.dataset][0]
     raw = None
     if not os.path.exists(os.path.join(data_root, fname)):                       # synthetic stand-in of the dataset's shape
-        S = 24 * 60 // gdata.DATASETS[args.dataset][2]
-        L = 14 * S
-        rng = np.random.RandomState(args.seed)
-        t = np.arange(L)[:, None]
         F = 3 if args.dataset == "PEMS08" else args.input_base_dim
-        base = 230 + 120 * np.sin(2 * np.pi * t / S + rng.uniform(0, 6.28, (1, args.num_nodes)))
-        raw = np.maximum(base[..., None] + rng.normal(0, 30, (L, args.num_nodes, F)), 0.0)
+        raw = synth.make_series(args.num_nodes, F, interval=gdata.DATASETS[args.dataset][2], seed=args.seed)
         if args.dataset == "METR_LA":
             raw = raw[..., 0]
         print("gpt-st_amd: %s not found -> synthetic %s-shaped series %s" % (os.path.join(data_root, fname), args.dataset, raw.shape))

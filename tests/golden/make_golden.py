@@ -354,6 +354,82 @@ def gen_steps():
     print("losses", np.array(losses)[:, 0])
 
 
+class Injector:
+    """Feeds prepared tensors to the reference's torch.rand_like calls and a prepared order to random.shuffle (GPTST.py:316,358,
+    389,400), so that a long run is reproducible from seeds alone."""
+
+    def __init__(self, noises, order):
+        self.noises, self.order = list(noises), order
+
+    def __enter__(self):
+        self._rl, self._sh = torch.rand_like, random.shuffle
+
+        def rl(x, *a, **k):
+            return self.noises.pop(0).view_as(x).to(x.dtype)
+
+        def sh(lst, *a, **k):
+            lst[:] = self.order
+
+        torch.rand_like, random.shuffle = rl, sh
+        return self
+
+    def __exit__(self, *exc):
+        torch.rand_like, random.shuffle = self._rl, self._sh
+
+
+def gen_curve(nsteps=200, per_epoch=50):
+    """Loss curve at the BASELINE configs[1] shape (G5b): `nsteps` optimiser steps of the REFERENCE model (B=32, N=170, C=64) with a
+    shortened schedule (epochs=4, change_epoch=2: random-mask phase, then adaptive mask + KL), mask noise / class order derived
+    from seeds (synth.make_noise / synth.class_order).  Stored per step: epoch, seeds, the reference's mask (bit-packed), losses."""
+    from gptst_amd import data as gdata
+    args = make_args("PEMS08", epochs=nsteps // per_epoch, change_epoch=nsteps // per_epoch // 2, batch_size=32)
+    raw = synth.make_series(args.num_nodes, 3, interval=5, seed=10)          # learnable series (see synth.make_series)
+    train, _, _, scaler, _, _ = gdata.get_dataloader(args, raw=raw)
+    args.scaler_zeros = float(scaler.transform(0))
+    model = build_ref_model(args, 12)
+    opt = torch.optim.Adam(params=model.parameters(), lr=args.lr_init, eps=1.0e-8, weight_decay=0, amsgrad=False)
+    sc = StandardScaler(float(scaler.mean), float(scaler.std))
+    B, T, N, base, HS = 32, 12, args.num_nodes, 1, args.HS
+    M = B * T * N
+    A = {"sd_seed": np.int64(12), "sd0_hash": np.array(sd_hash(model.state_dict())), "epochs": np.int64(args.epochs),
+         "change_epoch": np.int64(args.change_epoch), "scaler": np.array([float(scaler.mean), float(scaler.std)])}
+    losses, seeds, masks, orders, epochs = [], [], [], [], []
+    import time
+    t0 = time.time()
+    for step in range(nsteps):
+        epoch = step // per_epoch + 1
+        src = train.windows((torch.arange(B) * 7 + 13 * step) % train.n)[0]       # deterministic, spread over the series
+        s0 = 50000 + 10 * step
+        if epoch <= args.change_epoch:
+            while not tie_free(synth.make_noise(M * base, s0), int(M * base * args.mask_ratio)):
+                s0 += 1
+            noises, sd3 = [synth.make_noise(M * base, s0)], (s0, 0, 0)
+        else:
+            noises, sd3 = [synth.make_noise(M, s0), synth.make_noise(M, s0 + 1)], (0, s0, s0 + 1)
+        order = synth.class_order(HS, 900 + step)
+        opt.zero_grad()
+        with Injector(noises, order):
+            out, dec, mask, prob, hs1 = model(src, src, None, epoch)
+        p = sc.inverse_transform(out) * mask; y = sc.inverse_transform(src[..., :base]) * mask
+        lf, _ = MAE_torch(pred=p, true=y, mask_value=args.mape_thresh)
+        ls = torch.zeros(())
+        loss = lf
+        if epoch > args.change_epoch:
+            ls = torch.nn.KLDivLoss(reduction="sum")(prob.log(), hs1) * 0.1
+            loss = lf + ls
+        loss.backward()
+        torch.nn.utils.clip_grad_norm_(model.parameters(), args.max_grad_norm)
+        opt.step()
+        losses.append([float(loss), float(lf), float(ls)]); seeds.append(sd3); orders.append(order); epochs.append(epoch)
+        masks.append(np.packbits(mask.reshape(-1).to(torch.uint8).numpy()))
+        if step % 20 == 0:
+            print("step", step, "epoch", epoch, losses[-1], "%.0fs" % (time.time() - t0), flush=True)
+    A["losses"], A["seeds"], A["orders"], A["epoch"] = np.array(losses), np.array(seeds), np.array(orders), np.array(epochs)
+    A["masks"] = np.stack(masks)                       # (nsteps, M/8) uint8: the reference's `1 - final_mask` (1 = masked cell)
+    np.savez_compressed(os.path.join(HERE, "curve_c2.npz"), **A)
+    print("wrote curve_c2.npz")
+
+
 if __name__ == "__main__":
     torch.set_num_threads(8)
     which = sys.argv[1:] or ["init", "modules", "small", "full", "steps"]
@@ -367,3 +443,5 @@ if __name__ == "__main__":
         gen_full_forward()
     if "steps" in which:
         gen_steps()
+    if "curve" in which:            # not in the default list: ~10 min of reference CPU time
+        gen_curve()
