@@ -377,12 +377,14 @@ class Injector:
         torch.rand_like, random.shuffle = self._rl, self._sh
 
 
-def gen_curve(nsteps=200, per_epoch=50):
+def gen_curve(nsteps=200, per_epoch=50, lr=None, name="curve_c2.npz"):
     """Loss curve at the BASELINE configs[1] shape (G5b): `nsteps` optimiser steps of the REFERENCE model (B=32, N=170, C=64) with a
     shortened schedule (epochs=4, change_epoch=2: random-mask phase, then adaptive mask + KL), mask noise / class order derived
     from seeds (synth.make_noise / synth.class_order).  Stored per step: epoch, seeds, the reference's mask (bit-packed), losses."""
     from gptst_amd import data as gdata
     args = make_args("PEMS08", epochs=nsteps // per_epoch, change_epoch=nsteps // per_epoch // 2, batch_size=32)
+    if lr is not None:
+        args.lr_init = lr
     raw = synth.make_series(args.num_nodes, 3, interval=5, seed=10)          # learnable series (see synth.make_series)
     train, _, _, scaler, _, _ = gdata.get_dataloader(args, raw=raw)
     args.scaler_zeros = float(scaler.transform(0))
@@ -392,7 +394,8 @@ def gen_curve(nsteps=200, per_epoch=50):
     B, T, N, base, HS = 32, 12, args.num_nodes, 1, args.HS
     M = B * T * N
     A = {"sd_seed": np.int64(12), "sd0_hash": np.array(sd_hash(model.state_dict())), "epochs": np.int64(args.epochs),
-         "change_epoch": np.int64(args.change_epoch), "scaler": np.array([float(scaler.mean), float(scaler.std)])}
+         "change_epoch": np.int64(args.change_epoch), "scaler": np.array([float(scaler.mean), float(scaler.std)]),
+         "lr": np.float64(args.lr_init)}
     losses, seeds, masks, orders, epochs = [], [], [], [], []
     import time
     t0 = time.time()
@@ -426,8 +429,8 @@ def gen_curve(nsteps=200, per_epoch=50):
             print("step", step, "epoch", epoch, losses[-1], "%.0fs" % (time.time() - t0), flush=True)
     A["losses"], A["seeds"], A["orders"], A["epoch"] = np.array(losses), np.array(seeds), np.array(orders), np.array(epochs)
     A["masks"] = np.stack(masks)                       # (nsteps, M/8) uint8: the reference's `1 - final_mask` (1 = masked cell)
-    np.savez_compressed(os.path.join(HERE, "curve_c2.npz"), **A)
-    print("wrote curve_c2.npz")
+    np.savez_compressed(os.path.join(HERE, name), **A)
+    print("wrote", name)
 
 
 if __name__ == "__main__":
@@ -443,5 +446,7 @@ if __name__ == "__main__":
         gen_full_forward()
     if "steps" in which:
         gen_steps()
-    if "curve" in which:            # not in the default list: ~10 min of reference CPU time
+    if "curve" in which:            # not in the default list: ~3 min of reference CPU time each
         gen_curve()
+    if "curve_lowlr" in which:      # the same run at a tenth of the learning rate: contracting enough to be compared pointwise
+        gen_curve(lr=3e-4, name="curve_c2_lr3e-4.npz")
