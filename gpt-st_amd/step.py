@@ -156,7 +156,7 @@ class PretrainStep:
                 torch.cuda.current_stream().wait_stream(s)
                 torch.cuda.synchronize()
                 g = torch.cuda.CUDAGraph()
-                with torch.cuda.graph(g):
+                with torch.cuda.graph(g, capture_error_mode="thread_local"):      # other threads (RCCL watchdog) may call the runtime meanwhile
                     self._labels_body()
                 self.label_graph = g
             self.label_graph.replay()
@@ -246,7 +246,7 @@ class PretrainStep:
         torch.cuda.current_stream().wait_stream(s)
         torch.cuda.synchronize()
         g = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(g):
+        with torch.cuda.graph(g, capture_error_mode="thread_local"):      # other threads (RCCL watchdog) may call the runtime meanwhile
             self._body(phase)
         self.graphs[key] = g
         self.model.flat.copy_(keep[0]); self.m.copy_(keep[1]); self.v.copy_(keep[2])   # undo the warm-up updates
