@@ -20,7 +20,7 @@ from gptst_amd.trainer import Trainer                        # noqa: E402
 
 
 def main():
-    dev = torch.device("cuda", int(os.environ.get("LOCAL_RANK", "0")))
+    dev = torch.device("cuda", int(os.environ.get("LOCAL_RANK", "0")) % max(torch.cuda.device_count(), 1))
     torch.cuda.set_device(dev)
     args = parse_args(str(dev))
     if args.mode != "pretrain":

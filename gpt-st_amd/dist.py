@@ -21,6 +21,7 @@ class DataParallel:
         self.rank = int(os.environ.get("RANK", "0"))
         self.world = int(os.environ.get("WORLD_SIZE", "1"))
         self.local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+        backend = os.environ.get("GPTST_DIST_BACKEND", backend)       # tests: gloo to run several ranks on one GPU
         if backend is None:
             backend = "nccl" if torch.cuda.is_available() else "gloo"
         if not dist.is_initialized():

@@ -39,6 +39,8 @@ class Trainer:
         self.use_graph = use_graph
         os.makedirs(args.log_dir, exist_ok=True)
         self.logger = get_logger(args.log_dir, name=str(args.model), debug=args.debug)
+        if dp is not None and dp.rank != 0:              # one log stream per job (losses are global: every rank would print the same lines)
+            self.logger.setLevel(logging.WARNING)
         self.best_path = os.path.join(args.log_dir, args.save_pretrain_path)
         self.lr_steps = [int(i) for i in str(args.lr_decay_step).split(",")] if args.lr_decay else []
         self.up_epoch = [int(i) for i in str(args.up_epoch).split(",")]
