@@ -367,10 +367,11 @@ def guide_bwd(p, g, source, tidx, saved, dlogit, dims, base):
     timefeat_bwd(p, g, "encoder.teb4mask.", tidx, d_t4m)
 
 
-def model_fwd(p, source, mask, dims, base, num_route, scaler_zeros, gen=None, gen_ready=None):
+def model_fwd(p, source, mask, dims, base, num_route, scaler_zeros, gen=None, gen_ready=None, tidx=None):
     """Masked-autoencoder body — GPTST.py:415-421 + 453-456.  mask (BTN*base) fp32, 1 = visible; None -> no masking (eval)."""
     B, T, N, C = dims
-    tidx = source[:, :, 0, base:base + 2].contiguous()
+    if tidx is None:
+        tidx = source[:, :, 0, base:base + 2].contiguous()
     x0 = ops.lin_in(source, base + 2, base, p["encoder.dim_in_flow.weight"], p["encoder.dim_in_flow.bias"], C,
                     mask=mask, fill=scaler_zeros)                                                          # :416-418
     if gen_ready is not None:

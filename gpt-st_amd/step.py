@@ -34,7 +34,8 @@ class PretrainStep:
         M = self.B * self.T * self.N
         self.src = torch.zeros(self.B, self.T, self.N, self.base + 2, device=self.dev)
         self.noise = torch.zeros(M * self.base, device=self.dev)
-        self.noise_a, self.noise_r = torch.zeros(M, device=self.dev), torch.zeros(M, device=self.dev)
+        self.noise_ar = torch.zeros(2 * M, device=self.dev)          # adaptive phase: [noise_a | noise_r], drawn by ONE launch
+        self.noise_a, self.noise_r = self.noise_ar[:M], self.noise_ar[M:]
         self.ctrl = torch.zeros(self.HS + 2, dtype=torch.int32, device=self.dev)    # [list_c | adaptive_num, random_num]
         self.ctrl_host = torch.zeros(self.HS + 2, dtype=torch.int32).pin_memory()
         self.hyper = torch.zeros(16, device=self.dev)
@@ -57,7 +58,8 @@ class PretrainStep:
             torch.cuda.manual_seed(1234567 + seed)              # every rank draws the same global mask noise
             Mg = M * self.W
             self.noise_g = torch.zeros(Mg * self.base, device=self.dev)
-            self.noise_a_g, self.noise_r_g = torch.zeros(Mg, device=self.dev), torch.zeros(Mg, device=self.dev)
+            self.noise_ar_g = torch.zeros(2 * Mg, device=self.dev)
+            self.noise_a_g, self.noise_r_g = self.noise_ar_g[:Mg], self.noise_ar_g[Mg:]
             self.label_l = torch.zeros(M, dtype=torch.int32, device=self.dev)
             self.label_g = torch.zeros(Mg, dtype=torch.int32, device=self.dev)
             self.counts_g = torch.zeros(self.HS, dtype=torch.int32, device=self.dev)
@@ -89,7 +91,7 @@ class PretrainStep:
                 if phase == 0:
                     self.noise.uniform_()
                 else:
-                    self.noise_a.uniform_(); self.noise_r.uniform_()
+                    self.noise_ar.uniform_()
             if self.force_mask:
                 mask = self.mask_buf
             elif phase == 0:
@@ -99,7 +101,8 @@ class PretrainStep:
                 mask = ops.mask_adaptive(label, counts, self.ctrl[:self.HS], self.ctrl[self.HS:], self.noise_a, self.noise_r,
                                          a.ada_type == "all", base)[2]
         self.last_mask = mask
-        emb, c1, tidx, sv_e = engine.model_fwd(p, src, mask, dims, base, mdl.num_route, mdl.scaler_zeros, gen=gen_e, gen_ready=gen_e_ready)
+        emb, c1, tidx, sv_e = engine.model_fwd(p, src, mask, dims, base, mdl.num_route, mdl.scaler_zeros, gen=gen_e, gen_ready=gen_e_ready,
+                                               tidx=tidx)
         out, dec, sv_d = engine.decoder_fwd(p, tidx, emb, dims, mdl.num_route, gen=gen_d)
         ops.mae_fwd(out, src, base + 2, mask, self.std, self.mean, a.mape_thresh, M, base, self.stats)
         d_out = ops.mae_bwd(out, src, base + 2, mask, self.std, self.mean, a.mape_thresh, M, base, self.stats,
@@ -124,7 +127,7 @@ class PretrainStep:
             if phase == 0:
                 self.noise_g.uniform_()
             else:
-                self.noise_a_g.uniform_(); self.noise_r_g.uniform_()
+                self.noise_ar_g.uniform_()
         if phase == 0:
             mask_g = ops.mask_random(self.noise_g, int(Mg * base * a.mask_ratio))
         else:                                              # label_g / counts_g were exchanged by _exchange_labels()
