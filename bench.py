@@ -166,6 +166,7 @@ def main():
     ap.add_argument("--epoch", type=int, default=200, help="epoch whose masking schedule is benchmarked (of 300)")
     ap.add_argument("--nodes", type=int, default=0, help="override num_nodes (BASELINE configs[4]: 4096)")
     ap.add_argument("--hidden", type=int, default=0, help="override hidden_dim (BASELINE configs[4]: 128)")
+    ap.add_argument("--hs", type=int, default=0, help="override the cluster count HS (BASELINE configs[3]: sweep 2/5/10/20/40)")
     ap.add_argument("--shard", choices=["batch", "nodes"], default="batch",
                     help="multi-GPU partitioning: batch = data parallel (default, weak scaling); nodes = node sharding of ONE global "
                          "batch (SURVEY §8e row 2 / BASELINE configs[4], strong scaling; eager, no hipGraph)")
@@ -199,6 +200,8 @@ def main():
         over["num_nodes"] = a.nodes
     if a.hidden:
         over["hidden_dim"] = a.hidden
+    if a.hs:
+        over["HS"] = a.hs
     args = make_args(a.dataset, scaler_zeros=synth.scaler_zeros(), device=str(dev), **over)
     init_seed(args.seed)
     B, T, N, C = a.batch, 12, args.num_nodes, args.hidden_dim
