@@ -38,7 +38,10 @@ def parse_header(path=HEADER):
 
 
 class GptstError(RuntimeError):
-    pass
+    code = 0
+
+
+ESHAPE = -2          # "this shape is not served by this kernel" (e.g. the (b,t) capsule matrix does not fit LDS)
 
 
 class _Lib:
@@ -58,7 +61,9 @@ class _Lib:
     def call(self, name, *args):
         rc = getattr(self, "_raw_" + name)(*args)
         if rc != 0:
-            raise GptstError("%s failed with code %d" % (name, rc))
+            e = GptstError("%s failed with code %d" % (name, rc))
+            e.code = rc
+            raise e
 
     def value(self, name, *args):
         return getattr(self, "_raw_" + name)(*args)

@@ -215,6 +215,19 @@ def cap_fits_lds(N, C, HS):
     return (not FORCE_CAP_BIG) and bool(_C.lib().value("gptst_cap_fits_lds", N, C, HS))
 
 
+def _lds_or_stream(lds_call, stream_call):
+    """Try the one-workgroup-per-(b,t) LDS kernel; when it reports that the shape does not fit (ESHAPE, nothing was launched),
+    take the streaming capbig path.  (gptst_cap_fits_lds is a conservative bound over all four cap kernels together.)"""
+    if FORCE_CAP_BIG:
+        return stream_call()
+    try:
+        return lds_call()
+    except _C.GptstError as e:
+        if e.code != _C.ESHAPE:
+            raise
+        return stream_call()
+
+
 def _capbig_linear(X, Wp, bp):
     """Y = X Wp^T + bp over all rows (ln_p, GPTST.py:102) on the shared-weight apply kernel."""
     B, T, N, C = X.shape
@@ -257,12 +270,15 @@ def cap_route_fwd(X, Wp, bp, dadj, HS, R, reduce_nodes=None):
     """X (B,T,N,C); Wp (C,C) ln_p.weight; dadj (BT, HS*N) logits = teb . adj -> c (BT,HS,N), s (BT,HS,C)."""
     _chk(X, Wp, bp, dadj)
     B, T, N, C = X.shape
-    if not cap_fits_lds(N, C, HS) or reduce_nodes is not None:
+    if reduce_nodes is not None:
         return _cap_route_fwd_big(X, Wp, bp, dadj, HS, R, reduce_nodes)
-    c = torch.empty(B * T, HS, N, device=X.device, dtype=torch.float32)
-    s = torch.empty(B * T, HS, C, device=X.device, dtype=torch.float32)
-    _call("gptst_cap_route_fwd", _p(X), _p(Wp), _p(bp), _p(dadj), _p(c), _p(s), B * T, N, C, HS, R, nbytes=_nb(X, Wp, bp, dadj, c, s))
-    return c, s
+
+    def lds():
+        c = torch.empty(B * T, HS, N, device=X.device, dtype=torch.float32)
+        s = torch.empty(B * T, HS, C, device=X.device, dtype=torch.float32)
+        _call("gptst_cap_route_fwd", _p(X), _p(Wp), _p(bp), _p(dadj), _p(c), _p(s), B * T, N, C, HS, R, nbytes=_nb(X, Wp, bp, dadj, c, s))
+        return c, s
+    return _lds_or_stream(lds, lambda: _cap_route_fwd_big(X, Wp, bp, dadj, HS, R, None))
 
 
 def cap_cross_fwd(s, dyn, tmpl, B, T, HS, HT):
@@ -290,10 +306,8 @@ def cap_rec_fwd(c, v, N, C):
     _chk(c, v)
     BT, HS = c.shape[0], c.shape[1]
     rec = torch.empty(BT * N, C, device=c.device, dtype=torch.float32)
-    if not cap_fits_lds(N, C, HS):
-        _call("gptst_capbig_rec_fwd", _p(c), _p(v), _p(rec), BT, HS, N, C)
-        return rec
-    _call("gptst_cap_rec_fwd", _p(c), _p(v), _p(rec), BT, N, C, HS, nbytes=_nb(c, v, rec))
+    _lds_or_stream(lambda: _call("gptst_cap_rec_fwd", _p(c), _p(v), _p(rec), BT, N, C, HS, nbytes=_nb(c, v, rec)),
+                   lambda: _call("gptst_capbig_rec_fwd", _p(c), _p(v), _p(rec), BT, HS, N, C))
     return rec
 
 
@@ -303,11 +317,14 @@ def cap_rec_bwd(drec, c, v, reduce_nodes=None):
     C = v.shape[-1]
     dc1 = torch.empty_like(c)
     dv = torch.empty_like(v)
-    if not cap_fits_lds(N, C, HS) or reduce_nodes is not None:
+    def stream():
         _call("gptst_capbig_rec_bwd_dc", _p(drec), _p(v), _p(dc1), BT, HS, N, C)
         _capbig_type1(c, drec, dv, BT, HS, N, C, reduce_nodes)                       # dv = sum_n c drec: a sum over nodes
-        return dc1, dv
-    _call("gptst_cap_rec_bwd", _p(drec), _p(c), _p(v), _p(dc1), _p(dv), BT, N, C, HS, nbytes=_nb(drec, c, v, dc1, dv))
+    if reduce_nodes is not None:
+        stream()
+    else:
+        _lds_or_stream(lambda: _call("gptst_cap_rec_bwd", _p(drec), _p(c), _p(v), _p(dc1), _p(dv), BT, N, C, HS, nbytes=_nb(drec, c, v, dc1, dv)),
+                       stream)
     return dc1, dv
 
 
@@ -317,12 +334,11 @@ def cap_route_bwd(X, Wp, bp, c, dc1, dS):
     HS = c.shape[1]
     dY = torch.empty(B * T * N, C, device=X.device, dtype=torch.float32)
     dlogit = torch.empty_like(c)
-    if not cap_fits_lds(N, C, HS):
+    def stream():
         Y = _capbig_linear(X, Wp, bp)
         _call("gptst_capbig_route_bwd_rows", _p(Y), _p(c), _p(dc1), _p(dS), _p(dY), _p(dlogit), B * T, HS, N, C)
-        return dY, dlogit
-    _call("gptst_cap_route_bwd", _p(X), _p(Wp), _p(bp), _p(c), _p(dc1), _p(dS), _p(dY), _p(dlogit), B * T, N, C, HS,
-          nbytes=_nb(X, Wp, bp, c, dc1, dS, dY, dlogit))
+    _lds_or_stream(lambda: _call("gptst_cap_route_bwd", _p(X), _p(Wp), _p(bp), _p(c), _p(dc1), _p(dS), _p(dY), _p(dlogit), B * T, N, C, HS,
+                                 nbytes=_nb(X, Wp, bp, c, dc1, dS, dY, dlogit)), stream)
     return dY, dlogit
 
 
