@@ -24,7 +24,8 @@ extern "C" {
 
 #define GPTST_ABI_VERSION 1
 int gptst_abi_version(void);
-/* launch-geometry knobs for benchmarking (id 1: row chunks = atomics per output of poolgen_bwd_pool); not needed for correctness */
+/* launch-geometry knobs for benchmarking, not needed for correctness.  id 1: row chunks of poolgen_bwd_pool; 2 / 5: forced split
+ * count of the NODE / TIME weight gradient; 3: 1 = first-generation (LDS-staged) apply for C = 64; 4: tiles per wave of apply64 */
 int gptst_tune(int id, int value);
 
 /* ---- embedding-conditioned parameter generation (poolgen.hip) -----------------------------------------
