@@ -156,6 +156,21 @@ def cpu_baseline(args, B, budget_s=12.0):
                        % (n, B, el, torch.__version__, cores))
 
 
+def self_launch(n):
+    """`python bench.py --gpus N` without a launcher: re-exec this script under torch.distributed.run (one rank per GPU, RCCL
+    over xGMI), rendezvous on 127.0.0.1 and a free port; rank 0's single JSON line is the only thing on stdout."""
+    import socket
+    import subprocess
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n), "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    return subprocess.run(cmd, env=env).returncode
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -170,6 +185,10 @@ def main():
     ap.add_argument("--shard", choices=["batch", "nodes"], default="batch",
                     help="multi-GPU partitioning: batch = data parallel (default, weak scaling); nodes = node sharding of ONE global "
                          "batch (SURVEY §8e row 2 / BASELINE configs[4], strong scaling; eager, no hipGraph)")
+    ap.add_argument("--scaling", choices=["weak", "strong"], default="weak",
+                    help="data parallel only: weak = every rank steps its own batch of --batch (default); strong = ONE global batch of "
+                         "--global-batch samples split evenly over the ranks (SURVEY 8d c3: 256 = 32 x 8)")
+    ap.add_argument("--global-batch", type=int, default=256, help="global batch of --scaling strong")
     ap.add_argument("--no-graph", action="store_true")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-timing", action="store_true")
@@ -185,8 +204,11 @@ def main():
     local = int(os.environ.get("LOCAL_RANK", "0"))
     if world != a.gpus and world > 1:
         raise SystemExit("--gpus %d but WORLD_SIZE=%d" % (a.gpus, world))
-    if a.gpus > 1 and world == 1:
-        raise SystemExit("launch with torch.distributed.run for --gpus > 1")
+    if a.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(self_launch(a.gpus))              # plain `python bench.py --gpus N`: spawn the N ranks ourselves
+    if a.scaling == "strong" and a.shard == "batch":
+        assert a.global_batch % a.gpus == 0, "--global-batch must divide over the ranks"
+        a.batch = a.global_batch // a.gpus
     local = local % max(torch.cuda.device_count(), 1)             # (tests: several ranks may share one GPU over gloo)
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
@@ -260,25 +282,30 @@ def main():
     if rank != 0:
         return
     steps_s = a.steps / el
+    strong = a.shard == "nodes" or a.scaling == "strong"
+    gbatch = B if a.shard == "nodes" else B * a.gpus
+    b32_per_step = gbatch / 32.0 if (a.shard == "batch" and a.scaling == "strong") else (1 if a.shard == "nodes" else a.gpus)
     dims = dict(B=B, T=T, N=N, C=C, HS=args.HS, R=args.num_route)
     out = {
         # whole-job aggregate: per-GPU-batch steps per second summed over the ranks (weak-scaling data parallelism processes
         # n_gpus batches of B per optimizer step); node sharding (strong scaling) processes ONE batch per step
         "metric": "pretrain steps/sec at (B=%d,T=%d,N=%d,C=%d)" % (B, T, N, C),
-        "value": steps_s * (1 if a.shard == "nodes" else a.gpus), "unit": "steps/s",
-        "value_definition": "batches of B=%d processed per second by the whole job (= optimizer steps/s x n_gpus under data parallelism)" % B,
+        "value": steps_s * b32_per_step, "unit": "steps/s",
+        "value_definition": ("batches of 32 samples processed per second by the whole job (= optimizer steps/s x global batch %d / 32)" % gbatch)
+                            if (a.shard == "batch" and a.scaling == "strong") else
+                            ("batches of B=%d processed per second by the whole job (= optimizer steps/s x n_gpus under data parallelism)" % B),
         "optimizer_steps_per_s": steps_s,
         "n_gpus": a.gpus, "steps": a.steps, "warmup": a.warmup, "ms_per_step": 1e3 * el / a.steps,
-        "higher_is_better": True, "scaling": "strong" if a.shard == "nodes" else "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+        "higher_is_better": True, "scaling": "strong" if strong else "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
         "config": {"workload": "%s: %s-shape synthetic pretrain step, per-GPU B=%d T=%d N=%d C=%d base=%d, epoch %d/300 (%s), "
                                "fwd+loss+bwd+clip+Adam, hipGraph=%s" % (
                                    "BASELINE configs[4] shape (unsharded)" if (a.nodes or a.hidden) else
                                    {"PEMS08": "BASELINE configs[1]", "METR_LA": "BASELINE configs[2] shape", "NYC_TAXI": "BASELINE configs[3] shape"}.get(a.dataset, a.dataset),
                                    a.dataset, B, T, N, C, args.input_base_dim, a.epoch,
                                    "adaptive mask + KL" if a.epoch > args.change_epoch else "random mask", not a.no_graph and a.shard != "nodes"),
-                   "global_batch": B if a.shard == "nodes" else B * a.gpus,
+                   "global_batch": gbatch,
                    "parallelism": ("nodes%d" if a.shard == "nodes" else "dp%d") % a.gpus},
-        "samples_per_s": steps_s * (B if a.shard == "nodes" else B * a.gpus),
+        "samples_per_s": steps_s * gbatch,
         "steps_per_s_random_mask_phase": rnd_rate,
         "last_loss": loss[0],
     }

@@ -141,6 +141,9 @@ __global__ __launch_bounds__(MS_THREADS) void ms_apply_kernel(MsPlan p, const un
     const bool ties = k > 0 && need != cnt_eq;                   // uniform
     for (int i = blockIdx.x * MS_THREADS + threadIdx.x; i < p.M; i += MS_BLOCKS * MS_THREADS) {
         const unsigned key = ms_key(p, cls, i);
+        // a tie straddling rank k: threshold-equal cells belong to workgroup 0 alone (below) — nobody else writes them, so the
+        // result does not depend on the order in which workgroups finish
+        if (ties && key == thr) continue;
         float vis = 1.f;
         if (k > 0 && (key > thr || (key == thr && !ties))) vis = 0.f;
         if (p.mode == 1 && cls.d[p.label[i]]) vis = 0.f;
@@ -148,8 +151,8 @@ __global__ __launch_bounds__(MS_THREADS) void ms_apply_kernel(MsPlan p, const un
         if (p.mode == 2) { const float f = p.gate[i] * vis; for (int j = 0; j < base; ++j) final_mask[(size_t)i * base + j] = f; }
     }
     if (!ties || blockIdx.x != 0) return;
-    // rare: a tie straddles rank k.  Workgroup 0 hands the `need` threshold-equal slots out in index order.
-    // (the other workgroups left threshold-equal cells visible; cells are revisited here only to clear them)
+    // rare: a tie straddles rank k.  Workgroup 0 hands the `need` threshold-equal slots out in index order and writes BOTH
+    // values (0 for the first `need` of them, 1 for the rest).
     if (threadIdx.x == 0) s_base = 0u;
     __syncthreads();
     for (int i0 = 0; i0 < p.M; i0 += MS_THREADS) {
@@ -164,15 +167,171 @@ __global__ __launch_bounds__(MS_THREADS) void ms_apply_kernel(MsPlan p, const un
             __syncthreads();
         }
         const unsigned rank = s_base + sc[threadIdx.x] - (eq ? 1u : 0u);
+        if (eq) {
+            float vis = rank < need ? 0.f : 1.f;
+            if (p.mode == 1 && cls.d[p.label[i]]) vis = 0.f;
+            out[i] = vis;
+            if (p.mode == 2) { const float f = p.gate[i] * vis; for (int j = 0; j < base; ++j) final_mask[(size_t)i * base + j] = f; }
+        }
+        __syncthreads();
+        if (threadIdx.x == MS_THREADS - 1) s_base += sc[threadIdx.x];
+        __syncthreads();
+    }
+}
+
+// ======================================================================================================================
+// Small problems (M <= MSS_MAXM = 8192 cells): the WHOLE mask generation of a step — class histogram, class roles, both radix
+// selects and the mask writes — runs as ONE launch of ONE 1024-thread workgroup instead of 12 launches.  Measured at the bench
+// shape (65 280 cells): 234 us against 64 us for the multi-launch path — one CU re-reading the keys nine times at ~60 GB/s and
+// the skewed float-bit digits (half of all keys in four bins of the top digit, every ineligible cell in bin 0) serialising the LDS
+// atomics — so the single launch is only used where the data is a few KB.
+// ======================================================================================================================
+#define MSS_T 1024
+#define MSS_MAXM (1 << 13)
+
+struct MssShared {
+    unsigned hist[MS_BINS];
+    unsigned sc[MSS_T + 8];
+    int counts[256];
+    unsigned s_base;
+    MsClass cls;
+};
+
+// threshold of rank k (from the top) among the keys of plan p: -> thr, need (how many threshold-equal keys are selected), cnt_eq
+__device__ void mss_select(const MsPlan& p, MssShared& sh, int k, unsigned& thr, unsigned& need, unsigned& cnt_eq) {
+    unsigned prefix = 0u, remaining = (unsigned)k;
+    cnt_eq = 0u;
+    for (int d = 0; d < 3; ++d) {
+        const int shf = ms_shift(d), nb = ms_bins(d);
+        const unsigned hi_mask = d == 0 ? 0u : (0xFFFFFFFFu << (shf + (d == 1 ? 11 : 10)));
+        for (int b = threadIdx.x; b < MS_BINS; b += MSS_T) sh.hist[b] = 0u;
+        __syncthreads();
+        for (int i0 = threadIdx.x; i0 < p.M; i0 += 8 * MSS_T) {
+            unsigned key[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) { const int i = i0 + u * MSS_T; key[u] = i < p.M ? ms_key(p, sh.cls, i) : 0u; }
+#pragma unroll
+            for (int u = 0; u < 8; ++u)
+                if (i0 + u * MSS_T < p.M && (key[u] & hi_mask) == (prefix & hi_mask)) atomicAdd(&sh.hist[(key[u] >> shf) & (unsigned)(nb - 1)], 1u);
+        }
+        __syncthreads();
+        // suffix scan over the bins (descending key order): thread t owns bins nb-1 - (t*per + j)
+        const int per = (nb + MSS_T - 1) / MSS_T;
+        unsigned loc = 0u;
+        for (int j = 0; j < per; ++j) { const int b = nb - 1 - (threadIdx.x * per + j); if (b >= 0) loc += sh.hist[b]; }
+        sh.sc[threadIdx.x] = loc;
+        __syncthreads();
+        for (int off = 1; off < MSS_T; off <<= 1) {
+            const unsigned v = threadIdx.x >= off ? sh.sc[threadIdx.x - off] : 0u;
+            __syncthreads();
+            sh.sc[threadIdx.x] += v;
+            __syncthreads();
+        }
+        const unsigned before = sh.sc[threadIdx.x] - loc;
+        if (before < remaining && before + loc >= remaining) {        // exactly one thread
+            unsigned cum = before;
+            for (int j = 0; j < per; ++j) {
+                const int b = nb - 1 - (threadIdx.x * per + j);
+                if (b < 0) break;
+                if (cum + sh.hist[b] >= remaining) { sh.sc[MSS_T] = (unsigned)b; sh.sc[MSS_T + 1] = remaining - cum; sh.sc[MSS_T + 2] = sh.hist[b]; break; }
+                cum += sh.hist[b];
+            }
+        }
+        __syncthreads();
+        prefix |= sh.sc[MSS_T] << shf;
+        remaining = sh.sc[MSS_T + 1];
+        cnt_eq = sh.sc[MSS_T + 2];
+        __syncthreads();
+    }
+    thr = prefix; need = remaining;
+}
+
+// write the {0,1} result of one selection (same semantics as ms_apply_kernel, one workgroup: ties are resolved in index order here)
+__device__ void mss_apply(const MsPlan& p, MssShared& sh, int k, unsigned thr, unsigned need, unsigned cnt_eq, float* __restrict__ out,
+                          float* __restrict__ final_mask, int base) {
+    const bool ties = k > 0 && need != cnt_eq;
+    for (int i = threadIdx.x; i < p.M; i += MSS_T) {
+        const unsigned key = ms_key(p, sh.cls, i);
+        float vis = 1.f;
+        if (k > 0 && (key > thr || (key == thr && !ties))) vis = 0.f;
+        if (p.mode == 1 && sh.cls.d[p.label[i]]) vis = 0.f;
+        out[i] = vis;
+        if (p.mode == 2) { const float f = p.gate[i] * vis; for (int j = 0; j < base; ++j) final_mask[(size_t)i * base + j] = f; }
+    }
+    if (!ties) return;                                               // uniform
+    __syncthreads();
+    if (threadIdx.x == 0) sh.s_base = 0u;
+    __syncthreads();
+    for (int i0 = 0; i0 < p.M; i0 += MSS_T) {
+        const int i = i0 + threadIdx.x;
+        const bool eq = i < p.M && ms_key(p, sh.cls, i) == thr;
+        sh.sc[threadIdx.x] = eq ? 1u : 0u;
+        __syncthreads();
+        for (int off = 1; off < MSS_T; off <<= 1) {
+            const unsigned v = threadIdx.x >= off ? sh.sc[threadIdx.x - off] : 0u;
+            __syncthreads();
+            sh.sc[threadIdx.x] += v;
+            __syncthreads();
+        }
+        const unsigned rank = sh.s_base + sh.sc[threadIdx.x] - (eq ? 1u : 0u);
         if (eq && rank < need) {
             out[i] = 0.f;
             if (p.mode == 2) for (int j = 0; j < base; ++j) final_mask[(size_t)i * base + j] = 0.f;
         }
         __syncthreads();
-        if (threadIdx.x == MS_THREADS - 1) s_base += sc[threadIdx.x];
+        if (threadIdx.x == MSS_T - 1) sh.s_base += sh.sc[threadIdx.x];
         __syncthreads();
-        if (s_base >= need) break;                                // uniform
+        if (sh.s_base >= need) break;                                // uniform
     }
+}
+
+__global__ __launch_bounds__(MSS_T) void mss_random_kernel(MsPlan p, float* __restrict__ mask) {
+    __shared__ MssShared sh;
+    unsigned thr = 0xFFFFFFFFu, need = 0u, cnt_eq = 0u;
+    if (p.k_const > 0) mss_select(p, sh, p.k_const, thr, need, cnt_eq);
+    mss_apply(p, sh, p.k_const, thr, need, cnt_eq, mask, nullptr, 1);
+}
+
+// counts_in may be null: the class histogram is then taken from the labels here (what mask_labels_kernel would have produced)
+__global__ __launch_bounds__(MSS_T) void mss_adaptive_kernel(MsPlan a, const float* __restrict__ noise_r, const int* __restrict__ counts_in,
+                                                             float* __restrict__ m_ada, float* __restrict__ m_rnd,
+                                                             float* __restrict__ mask, int base) {
+    __shared__ MssShared sh;
+    for (int h = threadIdx.x; h < 256; h += MSS_T) sh.counts[h] = (counts_in && h < a.HS) ? counts_in[h] : 0;
+    __syncthreads();
+    if (!counts_in) {
+        for (int i = threadIdx.x; i < a.M; i += MSS_T) atomicAdd(&sh.counts[a.label[i]], 1);
+        __syncthreads();
+    }
+    a.counts = sh.counts;
+    // class roles (ms_classes with this launch's thread count)
+    for (int h = threadIdx.x; h < 256; h += MSS_T) { sh.cls.d[h] = 0; sh.cls.f[h] = 0; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const int ada_num = a.nums[0];
+        int num = 0, i = 0;
+        while (num < ada_num && i < a.HS) { num += sh.counts[a.list_c[i]]; ++i; }        // GPTST.py:366-369 / :379-382
+        int dnum = 0;
+        if (a.ada_all && i >= 2) {                                                        // :370-374
+            for (int k = 0; k < i - 1; ++k) { sh.cls.d[a.list_c[k]] = 1; dnum += sh.counts[a.list_c[k]]; }
+            sh.cls.f[a.list_c[i - 1]] = 1;
+        } else {                                                                          // :375-377 / :383-384
+            for (int k = 0; k < i; ++k) sh.cls.f[a.list_c[k]] = 1;
+        }
+        sh.cls.ka = ada_num - dnum;                                                       // :393
+    }
+    __syncthreads();
+    unsigned thr = 0xFFFFFFFFu, need = 0u, cnt_eq = 0u;
+    const int ka = sh.cls.ka;
+    if (ka > 0) mss_select(a, sh, ka, thr, need, cnt_eq);                                 // :386-397
+    mss_apply(a, sh, ka, thr, need, cnt_eq, m_ada, nullptr, base);
+    __syncthreads();                                   // m_ada (global) is read back by other threads of this workgroup below
+    MsPlan r = a;
+    r.noise = noise_r; r.gate = m_ada; r.mode = 2;
+    const int kr = a.nums[1];
+    thr = 0xFFFFFFFFu; need = 0u; cnt_eq = 0u;
+    if (kr > 0) mss_select(r, sh, kr, thr, need, cnt_eq);                                 // :399-413
+    mss_apply(r, sh, kr, thr, need, cnt_eq, m_rnd, mask, base);
 }
 
 // label[i] = argmax_h prob[i, h] (first maximum), counts[h] += 1      (GPTST.py:344-345)
@@ -211,9 +370,18 @@ static int ms_select(const MsPlan& p, unsigned* hist, float* out, float* final_m
 // ws: device scratch of gptst_mask_ws_bytes() bytes
 extern "C" int gptst_mask_ws_bytes(void) { return (int)(sizeof(unsigned) * 3 * MS_BINS); }
 
+int g_ms_force_multi = 0;       // tests: 1 = take the multi-launch path for every size
+
+extern "C" int gptst_mask_force_multi(int on) { g_ms_force_multi = on; return GPTST_OK; }
+
 extern "C" int gptst_mask_random(const float* noise, int M, int k, float* mask, void* ws, void* stream) {
     if (!noise || !mask || !ws || M <= 0 || k < 0 || k > M) return GPTST_EARG;
     MsPlan p{nullptr, nullptr, nullptr, nullptr, noise, nullptr, 0, 0, 0, M, k};
+    if (M <= MSS_MAXM && !g_ms_force_multi) {
+        hipLaunchKernelGGL(mss_random_kernel, dim3(1), dim3(MSS_T), 0, (hipStream_t)stream, p, mask);
+        GPTST_CHECK_LAUNCH();
+        return GPTST_OK;
+    }
     return ms_select(p, (unsigned*)ws, mask, nullptr, 1, (hipStream_t)stream);
 }
 
@@ -229,8 +397,14 @@ extern "C" int gptst_mask_labels(const float* prob, int rows, int HS, int* label
 extern "C" int gptst_mask_adaptive(const int* label, const int* counts, const int* list_c, const int* nums, const float* noise_a,
                                    const float* noise_r, int ada_all, int M, int HS, int base, float* m_ada, float* m_rnd,
                                    float* mask, void* ws, void* stream) {
-    if (!label || !counts || !list_c || !nums || !noise_a || !noise_r || !m_ada || !m_rnd || !mask || !ws || HS > 256) return GPTST_EARG;
+    if (!label || !list_c || !nums || !noise_a || !noise_r || !m_ada || !m_rnd || !mask || !ws || HS > 256) return GPTST_EARG;
     MsPlan a{label, counts, list_c, nums, noise_a, nullptr, 1, ada_all, HS, M, 0};
+    if (M <= MSS_MAXM && !g_ms_force_multi) {        // counts may be NULL here: the single-workgroup kernel histograms the labels itself
+        hipLaunchKernelGGL(mss_adaptive_kernel, dim3(1), dim3(MSS_T), 0, (hipStream_t)stream, a, noise_r, counts, m_ada, m_rnd, mask, base);
+        GPTST_CHECK_LAUNCH();
+        return GPTST_OK;
+    }
+    if (!counts) return GPTST_EARG;
     int rc = ms_select(a, (unsigned*)ws, m_ada, nullptr, base, (hipStream_t)stream);                       // :386-397
     if (rc) return rc;
     MsPlan r{label, counts, list_c, nums, noise_r, m_ada, 2, ada_all, HS, M, 0};

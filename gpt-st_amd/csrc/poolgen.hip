@@ -4,8 +4,7 @@
 // (GPTST.py:24-25,29-30,137-138,160-161), einsum('btd,dhn->bthn') (:104), einsum('bd,dhk->bhk') (:129) and
 // einsum('nk,kht->nht') (:156): a skinny GEMM (R rows <= a few hundred, K <= 16, up to C*C columns).  It is HBM/L2
 // bound on the R x cols operand, so it runs on the VALU with coalesced float4 columns; the two gradient reductions are here
-// too.  Every kernel takes up to PG_MAXP problems that share emb (weights_pool + bias_pool of several layers in ONE launch:
-// each launch has a ~4-5 us latency floor on this GPU, so per-layer launches are batched per STHCN).
+// too (fp32 MFMA 16x16x4: the reduction over rows / columns happens inside the matrix core).
 //
 // Gradient kernels are written around ONE rule learnt from the first profile (profiles/r01a): global atomics are only cheap
 // when few land on the same address (a same-address atomic serialises at ~80 ns) and when there are few of them overall —
@@ -13,7 +12,7 @@
 #include "common.h"
 
 #define PG_MAXK 16
-#define PG_ROWS 4
+#define PG_ROWS 16     // rows per block of the forward: the K pool rows a thread keeps in registers are re-read from L2 once per block
 
 // V = 4: float4 columns (cols % 4 == 0, rows 16-byte aligned);  V = 1: scalar columns (e.g. HS*N = 2070 for METR_LA)
 template <int V> __device__ __forceinline__ float4 ldv(const float* p) { return ld4(p); }
@@ -21,71 +20,86 @@ template <> __device__ __forceinline__ float4 ldv<1>(const float* p) { return ma
 template <int V> __device__ __forceinline__ void stv(float* p, float4 v) { st4(p, v); }
 template <> __device__ __forceinline__ void stv<1>(float* p, float4 v) { *p = v.x; }
 
-#define PG_MAXP 8
-struct PgFwd { const float* pool[PG_MAXP]; float* out[PG_MAXP]; int cols[PG_MAXP]; int blk0[PG_MAXP + 1]; int n; };
-struct PgBwd {
-    const float* dW[PG_MAXP]; const float* pool[PG_MAXP]; float* dpool[PG_MAXP];
-    int cols[PG_MAXP]; int nsplit[PG_MAXP]; int blk0[PG_MAXP + 1]; int n;
+// ---- job table ------------------------------------------------------------------------------------------------------------
+// One launch serves up to PJ_MAX independent problems ("jobs"), each with its OWN embedding, shapes and kind.  A pretraining step has
+// ~50 generated-parameter problems in the forward and ~90 gradient reductions in the backward, every one of them a few microseconds
+// of work: as one launch per embedding they were ~60 launches of 4-20 us each at the head and the tail of the step (25 % of it,
+// profiles/r02b timeline); as job tables they are a handful.  The table travels in the kernel arguments (<= 4 KB).
+#define PJ_MAX 48
+enum { PJ_FWD = 0, PJ_BWD_POOL = 1, PJ_BWD_EMB = 2 };
+struct PJob {
+    const float* emb;      // FWD / BWD_POOL: (R, K)
+    const float* x;        // BWD_POOL / BWD_EMB: dW (R * nsplit, cols)
+    const float* pool;     // FWD / BWD_EMB: (K, cols)
+    float* out;            // FWD: (R, cols);  BWD_POOL: dpool (K, cols) +=;  BWD_EMB: demb (R, K) +=
+    int R, K, cols, nsplit;
+    int blk0, kind, nbx, pad;
 };
-template <class A> __device__ __forceinline__ int pg_find(const A& a, int bx) {
-    int p = 0;
-#pragma unroll
-    for (int q = 1; q < PG_MAXP; ++q) if (q < a.n && bx >= a.blk0[q]) p = q;
-    return p;
-}
+struct PJobs { PJob j[PJ_MAX]; int n; };
 
-// out_p[r, :] = sum_k emb[r,k] pool_p[k, :].   grid: (sum_p ceil(cols_p/V/256), ceil(R/PG_ROWS))
+// out[r, :] = sum_k emb[r,k] pool[k, :].   blocks: (ceil(cols/V/256), ceil(R/rows)), rows <= PG_MAXROWS
+// The block's emb rows are staged in LDS (zero-padded to PG_MAXK) BEFORE the store loop: read per row from global memory they
+// became vector loads whose s_waitcnt vmcnt(0) also waited for the previous row's stores (vmcnt retires in order) — one HBM
+// write round trip per row, 30 us for 50 MB where a memset takes 9.
+#define PG_MAXROWS 64
 template <int V>
-__global__ __launch_bounds__(256) void poolgen_fwd_kernel(const float* __restrict__ emb, PgFwd a, int R, int K) {
-    const int p = pg_find(a, blockIdx.x);
-    const float* __restrict__ pool = a.pool[p];
-    float* __restrict__ out = a.out[p];
-    const int cols = a.cols[p];
-    const int c4 = (blockIdx.x - a.blk0[p]) * 256 + threadIdx.x;
-    if (V * c4 >= cols) return;
+__device__ __forceinline__ void pj_fwd(const PJob& a, int bx, int by, int rows, float* __restrict__ embs /* [PG_MAXROWS][PG_MAXK] */) {
+    const float* __restrict__ emb = a.emb;
+    const float* __restrict__ pool = a.pool;
+    float* __restrict__ out = a.out;
+    const int cols = a.cols, K = a.K, R = a.R;
+    const int r0 = by * rows, nr = min(R, r0 + rows) - r0;
+    for (int i = threadIdx.x; i < nr * PG_MAXK; i += 256) {
+        const int r = i / PG_MAXK, k = i % PG_MAXK;
+        embs[i] = k < K ? emb[(size_t)(r0 + r) * K + k] : 0.f;
+    }
+    const int c4 = bx * 256 + threadIdx.x;
+    const bool ok = V * c4 < cols;
     float4 pv[PG_MAXK];
 #pragma unroll
-    for (int k = 0; k < PG_MAXK; ++k) pv[k] = (k < K) ? ldv<V>(pool + (size_t)k * cols + V * c4) : f4zero();
-    const int r0 = blockIdx.y * PG_ROWS;
-#pragma unroll 1
-    for (int r = r0; r < min(R, r0 + PG_ROWS); ++r) {
+    for (int k = 0; k < PG_MAXK; ++k) pv[k] = (k < K && ok) ? ldv<V>(pool + (size_t)k * cols + V * c4) : f4zero();
+    __syncthreads();
+    if (!ok) return;
+#pragma unroll 2
+    for (int r = 0; r < nr; ++r) {
         float4 acc = f4zero();
 #pragma unroll
-        for (int k = 0; k < PG_MAXK; ++k)
-            if (k < K) acc = f4fma(emb[(size_t)r * K + k], pv[k], acc);
-        stv<V>(out + (size_t)r * cols + V * c4, acc);
+        for (int k = 0; k < PG_MAXK; k += 4) {
+            const float4 e = ld4(embs + r * PG_MAXK + k);           // same address in every lane: LDS broadcast
+            acc = f4fma(e.x, pv[k], acc); acc = f4fma(e.y, pv[k + 1], acc); acc = f4fma(e.z, pv[k + 2], acc); acc = f4fma(e.w, pv[k + 3], acc);
+        }
+        stv<V>(out + (size_t)(r0 + r) * cols + V * c4, acc);
     }
 }
 
-// dpool_p[k, c] += sum_rr emb[rr % R, k] * dW_p[rr, c]   (rr < R*nsplit_p: wgrad's K-splits are summed here)
+// dpool[k, c] += sum_rr emb[rr % R, k] * dW[rr, c]   (rr < R*nsplit: wgrad's K-splits are summed here)
 // on fp32 MFMA 16x16x4:  D[i = k][j] += A[i][kk] B[kk][j],  A = emb[row][k],  B = dW[row][col];  lane (kk = l>>4, j = l&15).
 // V = 4: a lane fetches the float4 dW[row+kk][c0 + 4j ..] (the four lane groups read four consecutive rows, 256 B each) and
 // component e feeds column tile e (columns c0 + 4j + e), so one load drives 4 MFMAs and a wave owns a 64-column slab.
-// The reduction over rows happens inside the MFMA; a workgroup's 4 waves take 4 row chunks of the slab and every output
-// gets g_pg_nchunk atomics in total.   grid: (sum_p slabs_p, ceil(nchunk / 4))
-int g_pg_nchunk = 4;
+// The reduction over rows happens inside the MFMA; the workgroup's 4 waves take 4 row chunks of the slab and fold through LDS:
+// ONE read-modify-write per output element by ONE workgroup (no atomics: the result does not depend on scheduling).
+// blocks: (ceil(cols / (16 V)), 1)
 template <int V>
-__global__ __launch_bounds__(256) void poolgen_bwd_pool_kernel(const float* __restrict__ emb, PgBwd a, int R, int K, int nchunk) {
+__device__ __forceinline__ void pj_bwd_pool(const PJob& a, int bx, float (*fold)[PG_MAXK][65]) {
     constexpr int SLAB = 16 * V;
-    const int p = pg_find(a, blockIdx.x);
-    const float* __restrict__ dW = a.dW[p];
-    float* __restrict__ dpool = a.dpool[p];
-    const int cols = a.cols[p], RR = R * a.nsplit[p];
-    const int bx = blockIdx.x - a.blk0[p];
+    const float* __restrict__ emb = a.emb;
+    const float* __restrict__ dW = a.x;
+    float* __restrict__ dpool = a.out;
+    const int cols = a.cols, R = a.R, K = a.K, RR = R * a.nsplit;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int j = lane & 15, kk = lane >> 4;
-    const int chunk = blockIdx.y * 4 + wave;
+    int nchunk = 4;
+    if (nchunk * 16 > RR) nchunk = (RR + 15) / 16;
     int per = (RR + nchunk - 1) / nchunk;
     per = (per + 3) & ~3;
-    const int r0 = chunk < nchunk ? chunk * per : RR, r1 = min(RR, r0 + per);       // an idle wave gets an empty row range
+    const int r0 = wave < nchunk ? wave * per : RR, r1 = min(RR, r0 + per);       // an idle wave gets an empty row range
     const int c = bx * SLAB + V * j;
     const bool cok = c < cols;
     f32x4 acc[V];
 #pragma unroll
     for (int e = 0; e < V; ++e) acc[e] = (f32x4){0.f, 0.f, 0.f, 0.f};
     // NU k-steps (4 rows each) per batch: all dW / emb loads of a batch are issued before the first MFMA (row and column are
-    // clamped instead of predicated; a row beyond the chunk contributes through a zero emb operand).  The per-16-row loop of
-    // the first version paid one memory round trip per 16 rows with 4 waves per CU: 23 us for 25 MB.
+    // clamped instead of predicated; a row beyond the chunk contributes through a zero emb operand).
     constexpr int NU = 4;
     const int cl = cok ? c : 0;
     for (int rb = r0; rb < r1; rb += 4 * NU) {
@@ -108,9 +122,6 @@ __global__ __launch_bounds__(256) void poolgen_bwd_pool_kernel(const float* __re
             }
         }
     }
-    // fold the 4 waves (= 4 row chunks of the same slab) through LDS: one atomic per output and workgroup instead of four
-    // (the atomics, not the loads, bounded this kernel: 4 x 16 x 4160 x 4 problems = 1 M atomics per launch).
-    __shared__ float fold[4][PG_MAXK][SLAB + 1];
 #pragma unroll
     for (int e = 0; e < V; ++e)
 #pragma unroll
@@ -118,31 +129,34 @@ __global__ __launch_bounds__(256) void poolgen_bwd_pool_kernel(const float* __re
     __syncthreads();
     for (int o = threadIdx.x; o < PG_MAXK * SLAB; o += 256) {
         const int k = o / SLAB, cc = o % SLAB, col = bx * SLAB + cc;
-        if (k < K && col < cols) atomicAdd(dpool + (size_t)k * cols + col, fold[0][k][cc] + fold[1][k][cc] + fold[2][k][cc] + fold[3][k][cc]);
+        if (k < K && col < cols) {
+            float* d = dpool + (size_t)k * cols + col;
+            *d += (fold[0][k][cc] + fold[1][k][cc]) + (fold[2][k][cc] + fold[3][k][cc]);      // this workgroup owns the element
+        }
     }
 }
 
-// demb[r, k] += sum_p sum_split sum_c dW_p[split*R + r, c] * pool_p[k, c]   on fp32 MFMA 16x16x4:
+// demb[r, k] += sum_split sum_c dW[split*R + r, c] * pool[k, c]   on fp32 MFMA 16x16x4:
 // D[i = row][j = k] += A[i][kk] B[kk][j] with A = dW[row0+i][c], B = pool[j][c]; lane (kk = l>>4, i = l&15) fetches
 // float4s at c + 4kk so one load pair feeds four MFMA steps (the usual k-permutation); the MFMA does the reduction over the
-// columns that a VALU version would have to do with cross-lane shuffles.  A wave owns (16-row tile, column chunk of one problem).
-// grid: (ceil(R/16), ceil(total chunks / 4)); blk0[] counts chunks here.
+// columns that a VALU version would have to do with cross-lane shuffles.  A wave owns (16-row tile, 256-column chunk); several
+// jobs (and chunks) add into one demb, so the final add is an atomic.   blocks: (ceil(R/16), ceil(chunks/4))
 template <int V>
-__global__ __launch_bounds__(256) void poolgen_bwd_emb_kernel(PgBwd a, float* __restrict__ demb, int R, int K, int chunk_cols) {
+__device__ __forceinline__ void pj_bwd_emb(const PJob& a, int bx, int by) {
+    constexpr int chunk_cols = 256;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int i = lane & 15, kk = lane >> 4;
-    const int row = blockIdx.x * 16 + i;
-    const int gch = blockIdx.y * 4 + wave;
-    if (gch >= a.blk0[a.n]) return;
-    const int p = pg_find(a, gch);
-    const float* __restrict__ w = a.dW[p];
-    const float* __restrict__ pl = a.pool[p];
-    const int cc = a.cols[p], ns = a.nsplit[p];
-    const int cbeg = (gch - a.blk0[p]) * chunk_cols, cend = min(cc, cbeg + chunk_cols);
+    const int R = a.R, K = a.K;
+    const int row = bx * 16 + i;
+    const float* __restrict__ w = a.x;
+    const float* __restrict__ pl = a.pool;
+    float* __restrict__ demb = a.out;
+    const int cc = a.cols, ns = a.nsplit;
+    const int cbeg = (by * 4 + wave) * chunk_cols, cend = min(cc, cbeg + chunk_cols);
+    if (cbeg >= cc) return;
     f32x4 acc = {0.f, 0.f, 0.f, 0.f};
     if (V == 4) {
-        // UC column steps (16 columns each) per batch, all loads issued before the MFMAs (clamped, not predicated): the
-        // one-step loop paid one L2 round trip per 16 columns (32 per chunk -> 22 us).
+        // UC column steps (16 columns each) per batch, all loads issued before the MFMAs (clamped, not predicated)
         constexpr int UC = 8;
         const int rowc = min(row, R - 1), ic = min(i, K - 1);
         const bool rok = row < R, kok = i < K;
@@ -184,9 +198,68 @@ __global__ __launch_bounds__(256) void poolgen_bwd_emb_kernel(PgBwd a, float* __
     }
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
-        const int orow = blockIdx.x * 16 + kk * 4 + r;      // D reg r: row (l>>4)*4 + r, col l&15
+        const int orow = bx * 16 + kk * 4 + r;      // D reg r: row (l>>4)*4 + r, col l&15
         if (orow < R && i < K) atomicAdd(demb + (size_t)orow * K + i, acc[r]);
     }
+}
+
+__global__ __launch_bounds__(256) void pool_jobs_kernel(PJobs t, int fwd_rows) {
+    __shared__ __attribute__((aligned(16))) float fold[4][PG_MAXK][65];
+    int p = 0;
+    for (int q = 1; q < t.n; ++q) if ((int)blockIdx.x >= t.j[q].blk0) p = q;      // uniform scan of the (scalar) table
+    const PJob& a = t.j[p];
+    const int rel = blockIdx.x - a.blk0, bx = rel % a.nbx, by = rel / a.nbx;
+    const bool v4 = (a.cols & 3) == 0;
+    if (a.kind == PJ_FWD) { if (v4) pj_fwd<4>(a, bx, by, fwd_rows, &fold[0][0][0]); else pj_fwd<1>(a, bx, by, fwd_rows, &fold[0][0][0]); }
+    else if (a.kind == PJ_BWD_POOL) { if (v4) pj_bwd_pool<4>(a, bx, fold); else pj_bwd_pool<1>(a, bx, fold); }
+    else { if (v4) pj_bwd_emb<4>(a, bx, by); else pj_bwd_emb<1>(a, bx, by); }
+}
+
+// Host side: fill one job and its block range; returns the number of blocks.
+int g_pg_rows = PG_ROWS;            // experiments: gptst_tune(1, rows)
+static int pj_blocks(PJob& j) {
+    const int V = (j.cols & 3) ? 1 : 4;
+    if (j.kind == PJ_FWD) { j.nbx = ((j.cols + V - 1) / V + 255) / 256; return j.nbx * ((j.R + g_pg_rows - 1) / g_pg_rows); }
+    if (j.kind == PJ_BWD_POOL) { j.nbx = (j.cols + 16 * V - 1) / (16 * V); return j.nbx; }
+    j.nbx = (j.R + 15) / 16;
+    return j.nbx * (((j.cols + 255) / 256 + 3) / 4);
+}
+
+static int pj_launch(PJobs& t, hipStream_t st) {
+    int nb = 0;
+    for (int p = 0; p < t.n; ++p) {
+        PJob& j = t.j[p];
+        if (j.R <= 0 || j.K <= 0 || j.K > PG_MAXK || j.cols <= 0 || j.nsplit <= 0 || !j.out) return GPTST_EARG;
+        if ((j.kind == PJ_FWD || j.kind == PJ_BWD_POOL) && !j.emb) return GPTST_EARG;
+        if ((j.kind == PJ_BWD_POOL || j.kind == PJ_BWD_EMB) && !j.x) return GPTST_EARG;
+        if ((j.kind == PJ_FWD || j.kind == PJ_BWD_EMB) && !j.pool) return GPTST_EARG;
+        j.blk0 = nb; j.pad = 0;
+        nb += pj_blocks(j);
+    }
+    if (nb == 0) return GPTST_OK;
+    hipLaunchKernelGGL(pool_jobs_kernel, dim3(nb), dim3(256), 0, st, t, g_pg_rows);
+    GPTST_CHECK_LAUNCH();
+    return GPTST_OK;
+}
+
+// Generic entry: njobs problems of any kind in as few launches as the 4 KB argument block allows (PJ_MAX jobs each).
+// A BWD_EMB job must not share a launch with a job that produces its input; callers order dependent work into separate calls.
+extern "C" int gptst_pool_jobs(int njobs, const int* kind, const void* const* emb, const void* const* x, const void* const* pool,
+                               const void* const* out, const int* R, const int* K, const int* cols, const int* nsplit, void* stream) {
+    if (njobs < 0 || (njobs && (!kind || !emb || !x || !pool || !out || !R || !K || !cols || !nsplit))) return GPTST_EARG;
+    for (int p0 = 0; p0 < njobs; p0 += PJ_MAX) {
+        PJobs t;
+        t.n = njobs - p0 < PJ_MAX ? njobs - p0 : PJ_MAX;
+        for (int q = 0; q < t.n; ++q) {
+            const int p = p0 + q;
+            if (kind[p] < PJ_FWD || kind[p] > PJ_BWD_EMB) return GPTST_EARG;
+            t.j[q] = PJob{(const float*)emb[p], (const float*)x[p], (const float*)pool[p], (float*)out[p], R[p], K[p], cols[p], nsplit[p],
+                          0, kind[p], 0, 0};
+        }
+        const int rc = pj_launch(t, (hipStream_t)stream);
+        if (rc) return rc;
+    }
+    return GPTST_OK;
 }
 
 extern int g_wgrad_ns_override;
@@ -194,7 +267,7 @@ extern int g_wgrad_ns0_override;
 extern int g_apply_v1;
 extern int g_apply_tpw;
 extern "C" int gptst_tune(int id, int value) {
-    if (id == 1) g_pg_nchunk = value;
+    if (id == 1 && value > 0 && value <= PG_MAXROWS) g_pg_rows = value;
     if (id == 2) g_wgrad_ns_override = value;
     if (id == 5) g_wgrad_ns0_override = value;
     if (id == 3) g_apply_v1 = value;
@@ -202,80 +275,33 @@ extern "C" int gptst_tune(int id, int value) {
     return GPTST_OK;
 }
 
-static int pg_vec(int n, const int* cols) {
-    for (int p = 0; p < n; ++p) if (cols[p] & 3) return 1;
-    return 4;
-}
-
 extern "C" int gptst_poolgen_fwd_multi(const float* emb, int nprob, const void* pools, const void* outs, const int* cols, int R, int K,
                                        void* stream) {
-    if (!emb || !pools || !outs || !cols || nprob <= 0 || nprob > PG_MAXP || K > PG_MAXK || K <= 0) return GPTST_EARG;
-    const int V = pg_vec(nprob, cols);
-    PgFwd a; a.n = nprob; a.blk0[0] = 0;
-    for (int p = 0; p < nprob; ++p) {
-        a.pool[p] = ((const float* const*)pools)[p]; a.out[p] = ((float* const*)outs)[p]; a.cols[p] = cols[p];
-        if (!a.pool[p] || !a.out[p] || cols[p] <= 0) return GPTST_EARG;
-        a.blk0[p + 1] = a.blk0[p] + ((cols[p] + V - 1) / V + 255) / 256;
-    }
-    dim3 grid(a.blk0[nprob], (R + PG_ROWS - 1) / PG_ROWS);
-    if (V == 4) hipLaunchKernelGGL(poolgen_fwd_kernel<4>, grid, dim3(256), 0, (hipStream_t)stream, emb, a, R, K);
-    else hipLaunchKernelGGL(poolgen_fwd_kernel<1>, grid, dim3(256), 0, (hipStream_t)stream, emb, a, R, K);
-    GPTST_CHECK_LAUNCH();
-    return GPTST_OK;
-}
-
-static int pg_fill_bwd(PgBwd& a, int nprob, const void* dWs, const void* pools, const void* dpools, const int* cols, const int* nsplit) {
-    a.n = nprob;
-    for (int p = 0; p < nprob; ++p) {
-        a.dW[p] = ((const float* const*)dWs)[p];
-        a.pool[p] = pools ? ((const float* const*)pools)[p] : nullptr;
-        a.dpool[p] = dpools ? ((float* const*)dpools)[p] : nullptr;
-        a.cols[p] = cols[p]; a.nsplit[p] = nsplit ? nsplit[p] : 1;
-        if (!a.dW[p] || cols[p] <= 0 || a.nsplit[p] <= 0) return GPTST_EARG;
-    }
-    return GPTST_OK;
+    if (!emb || !pools || !outs || !cols || nprob <= 0 || nprob > PJ_MAX || K > PG_MAXK || K <= 0) return GPTST_EARG;
+    PJobs t; t.n = nprob;
+    for (int p = 0; p < nprob; ++p)
+        t.j[p] = PJob{emb, nullptr, ((const float* const*)pools)[p], ((float* const*)outs)[p], R, K, cols[p], 1, 0, PJ_FWD, 0, 0};
+    return pj_launch(t, (hipStream_t)stream);
 }
 
 extern "C" int gptst_poolgen_bwd_pool_multi(const float* emb, int nprob, const void* dWs, const void* dpools, const int* cols,
                                             const int* nsplit, int R, int K, void* stream) {
-    if (!emb || !dWs || !dpools || !cols || nprob <= 0 || nprob > PG_MAXP || K > PG_MAXK || K <= 0) return GPTST_EARG;
-    const int V = pg_vec(nprob, cols);
-    PgBwd a;
-    if (pg_fill_bwd(a, nprob, dWs, nullptr, dpools, cols, nsplit)) return GPTST_EARG;
-    a.blk0[0] = 0;
-    int minrr = 1 << 30;
-    for (int p = 0; p < nprob; ++p) {
-        if (!a.dpool[p]) return GPTST_EARG;
-        a.blk0[p + 1] = a.blk0[p] + (cols[p] + 16 * V - 1) / (16 * V);
-        if (R * a.nsplit[p] < minrr) minrr = R * a.nsplit[p];
-    }
-    int nchunk = g_pg_nchunk;                            // row chunks = atomics per output element
-    if (nchunk * 16 > minrr) nchunk = (minrr + 15) / 16;
-    if (nchunk < 1) nchunk = 1;
-    dim3 grid(a.blk0[nprob], (nchunk + 3) / 4);
-    if (V == 4) hipLaunchKernelGGL(poolgen_bwd_pool_kernel<4>, grid, dim3(256), 0, (hipStream_t)stream, emb, a, R, K, nchunk);
-    else hipLaunchKernelGGL(poolgen_bwd_pool_kernel<1>, grid, dim3(256), 0, (hipStream_t)stream, emb, a, R, K, nchunk);
-    GPTST_CHECK_LAUNCH();
-    return GPTST_OK;
+    if (!emb || !dWs || !dpools || !cols || nprob <= 0 || nprob > PJ_MAX || K > PG_MAXK || K <= 0) return GPTST_EARG;
+    PJobs t; t.n = nprob;
+    for (int p = 0; p < nprob; ++p)
+        t.j[p] = PJob{emb, ((const float* const*)dWs)[p], nullptr, ((float* const*)dpools)[p], R, K, cols[p], nsplit ? nsplit[p] : 1, 0,
+                      PJ_BWD_POOL, 0, 0};
+    return pj_launch(t, (hipStream_t)stream);
 }
 
 extern "C" int gptst_poolgen_bwd_emb_multi(int nprob, const void* dWs, const void* pools, const int* cols, const int* nsplit, float* demb,
                                            int R, int K, void* stream) {
-    if (!dWs || !pools || !cols || !demb || nprob <= 0 || nprob > PG_MAXP || K > PG_MAXK || K <= 0) return GPTST_EARG;
-    const int V = pg_vec(nprob, cols);
-    PgBwd a;
-    if (pg_fill_bwd(a, nprob, dWs, pools, nullptr, cols, nsplit)) return GPTST_EARG;
-    const int chunk = 256;                               // columns per wave: 16 MFMA load pairs
-    a.blk0[0] = 0;
-    for (int p = 0; p < nprob; ++p) {
-        if (!a.pool[p]) return GPTST_EARG;
-        a.blk0[p + 1] = a.blk0[p] + (cols[p] + chunk - 1) / chunk;
-    }
-    dim3 grid((R + 15) / 16, (a.blk0[nprob] + 3) / 4);
-    if (V == 4) hipLaunchKernelGGL(poolgen_bwd_emb_kernel<4>, grid, dim3(256), 0, (hipStream_t)stream, a, demb, R, K, chunk);
-    else hipLaunchKernelGGL(poolgen_bwd_emb_kernel<1>, grid, dim3(256), 0, (hipStream_t)stream, a, demb, R, K, chunk);
-    GPTST_CHECK_LAUNCH();
-    return GPTST_OK;
+    if (!dWs || !pools || !cols || !demb || nprob <= 0 || nprob > PJ_MAX || K > PG_MAXK || K <= 0) return GPTST_EARG;
+    PJobs t; t.n = nprob;
+    for (int p = 0; p < nprob; ++p)
+        t.j[p] = PJob{nullptr, ((const float* const*)dWs)[p], ((const float* const*)pools)[p], demb, R, K, cols[p], nsplit ? nsplit[p] : 1, 0,
+                      PJ_BWD_EMB, 0, 0};
+    return pj_launch(t, (hipStream_t)stream);
 }
 
 // ---- one / two problem convenience forms (thin wrappers) -----------------------------------------------------------

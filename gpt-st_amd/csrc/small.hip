@@ -39,7 +39,7 @@ __global__ __launch_bounds__(256) void lin_in_kernel(const float* __restrict__ a
 // Z[i,j] = X[i,:].W[j,:] + b[j];  softmax over j when do_softmax.  C/4 lanes per row, butterfly reduce.
 template <int C>
 __global__ __launch_bounds__(256) void rowdot_kernel(const float* __restrict__ X, const float* __restrict__ W, const float* __restrict__ b,
-                                                     float* __restrict__ Z, int rows, int J, int do_softmax) {
+                                                     float* __restrict__ Z, int rows, int J, int do_softmax, int* __restrict__ label) {
     constexpr int LPR = C / 4, RPB = 256 / LPR;
     __shared__ float Ws[SM_MAXJ * C];
     for (int i = threadIdx.x; i < J * C / 4; i += 256) st4(Ws + 4 * i, ld4(W + 4 * i));
@@ -77,6 +77,17 @@ __global__ __launch_bounds__(256) void rowdot_kernel(const float* __restrict__ X
 #pragma unroll
         for (int q = 0; q < (SM_MAXJ + LPR - 1) / LPR; ++q)
             if (q * LPR + c4 < J) Z[i * J + q * LPR + c4] = mine[q];
+    }
+    if (label != nullptr) {       // label[i] = argmax_j Z[i,j], FIRST maximum (GPTST.py:344-345) — on the values just stored
+        float bv = -3.0e38f;
+        int bj = 1 << 20;
+#pragma unroll
+        for (int q = 0; q < (SM_MAXJ + LPR - 1) / LPR; ++q)
+            if (q * LPR + c4 < J && mine[q] > bv) { bv = mine[q]; bj = q * LPR + c4; }
+        const float gm = group_max<LPR>(bv);
+        const float cand = bv == gm ? -(float)bj : -3.0e38f;        // smallest index among the lanes that hold the maximum
+        const int first = (int)(-group_max<LPR>(cand));
+        if (valid && c4 == 0) label[i] = first;
     }
 }
 
@@ -181,11 +192,11 @@ extern "C" int gptst_lin_in(const float* a, int lda, const float* mask, float fi
 }
 
 extern "C" int gptst_rowdot(const float* X, const float* W, const float* b, float* Z, int rows, int J, int C, int do_softmax,
-                            void* stream) {
+                            int* label, void* stream) {
     if (!X || !W || !Z || J <= 0 || J > SM_MAXJ) return GPTST_EARG;
     hipStream_t st = (hipStream_t)stream;
-    if (C == 64) hipLaunchKernelGGL((rowdot_kernel<64>), dim3((rows + 15) / 16), dim3(256), 0, st, X, W, b, Z, rows, J, do_softmax);
-    else if (C == 128) hipLaunchKernelGGL((rowdot_kernel<128>), dim3((rows + 7) / 8), dim3(256), 0, st, X, W, b, Z, rows, J, do_softmax);
+    if (C == 64) hipLaunchKernelGGL((rowdot_kernel<64>), dim3((rows + 15) / 16), dim3(256), 0, st, X, W, b, Z, rows, J, do_softmax, label);
+    else if (C == 128) hipLaunchKernelGGL((rowdot_kernel<128>), dim3((rows + 7) / 8), dim3(256), 0, st, X, W, b, Z, rows, J, do_softmax, label);
     else return GPTST_ESHAPE;
     GPTST_CHECK_LAUNCH();
     return GPTST_OK;

@@ -35,13 +35,15 @@ __device__ __forceinline__ float tf_input(const TfParams& p, const float* __rest
     return s;
 }
 
+#define TF_SH_FLOATS (7 * 128 * 3)      // largest footprint: E = 2 -> 7 x [128][3]
+
 template <int E>
-__global__ __launch_bounds__(256) void timefeat_fwd_kernel(TfParams p, const float* __restrict__ tidx, float* __restrict__ out,
-                                                           int rows, int K) {
+__device__ __forceinline__ void tf_fwd_body(const TfParams& p, const float* __restrict__ tidx, float* __restrict__ out,
+                                            int rows, int K, int blk, float* __restrict__ shraw) {
     constexpr int ROWS = TfCfg<E>::ROWS;
-    __shared__ float line[ROWS][E + 1];
+    float (*line)[E + 1] = reinterpret_cast<float (*)[E + 1]>(shraw);
     const int e = threadIdx.x % E, rl = threadIdx.x / E;
-    const int r = blockIdx.x * ROWS + rl;
+    const int r = blk * ROWS + rl;
     const bool valid = r < rows;
     float w1[E], w2[E], w3[E];
 #pragma unroll
@@ -61,12 +63,12 @@ __global__ __launch_bounds__(256) void timefeat_fwd_kernel(TfParams p, const flo
 }
 
 template <int E>
-__global__ __launch_bounds__(256) void timefeat_bwd_kernel(TfParams p, TfGrads g, const float* __restrict__ tidx,
-                                                           const float* __restrict__ dout, int rows, int K) {
+__device__ __forceinline__ void tf_bwd_body(const TfParams& p, const TfGrads& g, const float* __restrict__ tidx,
+                                            const float* __restrict__ dout, int rows, int K, int blk, float* __restrict__ shraw) {
     constexpr int ROWS = TfCfg<E>::ROWS;
-    __shared__ float sh[7][ROWS][E + 1];              // h0, h1, h2, d3, z2, z1, z0 per row
+    float (*sh)[ROWS][E + 1] = reinterpret_cast<float (*)[ROWS][E + 1]>(shraw);      // h0, h1, h2, d3, z2, z1, z0 per row
     const int tid = threadIdx.x, e = tid % E, rl = tid / E;
-    const int r = blockIdx.x * ROWS + rl;
+    const int r = blk * ROWS + rl;
     const bool valid = r < rows;
     float w1[E], w2[E], w3[E], c1[E], c2[E], c3[E];   // rows (forward) and columns (backward) of the three E x E weights
 #pragma unroll
@@ -94,7 +96,7 @@ __global__ __launch_bounds__(256) void timefeat_bwd_kernel(TfParams p, TfGrads g
     const float z0 = tf_matvec<E>(c1, 0.f, sh[5][rl]);
     sh[6][rl][e] = z0;
     __syncthreads();
-    const int nrow = min(ROWS, rows - blockIdx.x * ROWS);
+    const int nrow = min(ROWS, rows - blk * ROWS);
     // dW3[e][i] = sum_r d3[e] h2[i]; dW2 = z2 (x) h1; dW1 = z1 (x) h0; biases = column sums of d3, z2, z1, z0
     for (int idx = tid; idx < 3 * E * E; idx += 256) {
         const int which = idx / (E * E), eo = (idx / E) % E, i = idx % E;
@@ -119,30 +121,55 @@ __global__ __launch_bounds__(256) void timefeat_bwd_kernel(TfParams p, TfGrads g
         const int ch = idx / (E * K), eo = (idx / K) % E, k = idx % K;
         float s = 0.f;
         for (int rr = 0; rr < nrow; ++rr)
-            s = fmaf(sh[6][rr][eo], tidx[((size_t)(blockIdx.x * ROWS + rr) * K + k) * 2 + ch], s);
+            s = fmaf(sh[6][rr][eo], tidx[((size_t)(blk * ROWS + rr) * K + k) * 2 + ch], s);
         atomicAdd((ch == 0 ? g.wd : g.ww) + eo * K + k, s);
     }
 }
 
-#define TF_DISPATCH(E_, CALL)                  \
-    switch (E_) {                              \
-        case 2: { constexpr int EE = 2; CALL; } break;   \
-        case 4: { constexpr int EE = 4; CALL; } break;   \
-        case 8: { constexpr int EE = 8; CALL; } break;   \
-        case 16: { constexpr int EE = 16; CALL; } break; \
-        default: return GPTST_ESHAPE;          \
+// One launch for up to TF_MAXJ time-feature instances (a step has seven: three per STHCN + teb4mask): block range per job.
+#define TF_MAXJ 16
+struct TfJob { TfParams p; TfGrads g; const float* tidx; float* out; const float* dout; int rows, K, E, blk0; };
+struct TfJobs { TfJob j[TF_MAXJ]; int n; };
+
+template <int BWD>
+__global__ __launch_bounds__(256) void timefeat_jobs_kernel(TfJobs t) {
+    __shared__ float shraw[TF_SH_FLOATS];
+    int q = 0;
+    for (int i = 1; i < t.n; ++i) if ((int)blockIdx.x >= t.j[i].blk0) q = i;
+    const TfJob& a = t.j[q];
+    const int blk = blockIdx.x - a.blk0;
+#define TF_CASE(EE)                                                                              \
+    case EE:                                                                                     \
+        if (BWD) tf_bwd_body<EE>(a.p, a.g, a.tidx, a.dout, a.rows, a.K, blk, shraw);             \
+        else tf_fwd_body<EE>(a.p, a.tidx, a.out, a.rows, a.K, blk, shraw);                       \
+        break;
+    switch (a.E) { TF_CASE(2) TF_CASE(4) TF_CASE(8) TF_CASE(16) default: break; }
+#undef TF_CASE
+}
+
+static int tf_launch(TfJobs& t, int bwd, hipStream_t st) {
+    int nb = 0;
+    for (int q = 0; q < t.n; ++q) {
+        TfJob& a = t.j[q];
+        if (!a.p.wd || !a.tidx || a.rows <= 0 || a.K <= 0 || (bwd ? (!a.dout || !a.g.wd) : !a.out)) return GPTST_EARG;
+        if (a.E != 2 && a.E != 4 && a.E != 8 && a.E != 16) return GPTST_ESHAPE;
+        const int rows_per = 256 / a.E;
+        a.blk0 = nb;
+        nb += (a.rows + rows_per - 1) / rows_per;
     }
+    if (bwd) hipLaunchKernelGGL(timefeat_jobs_kernel<1>, dim3(nb), dim3(256), 0, st, t);
+    else hipLaunchKernelGGL(timefeat_jobs_kernel<0>, dim3(nb), dim3(256), 0, st, t);
+    GPTST_CHECK_LAUNCH();
+    return GPTST_OK;
+}
 
 // params / grads: the 10 nn.Linear tensors in module order: ln_day.{weight,bias}, ln_week.{..}, ln1, ln2, ln.
 extern "C" int gptst_timefeat_fwd(const float* wd, const float* bd, const float* ww, const float* bw, const float* w1, const float* b1,
                                   const float* w2, const float* b2, const float* w3, const float* b3, const float* tidx, float* out,
                                   int rows, int K, int E, void* stream) {
-    if (!wd || !tidx || !out || rows <= 0 || K <= 0) return GPTST_EARG;
-    TfParams p{wd, bd, ww, bw, w1, b1, w2, b2, w3, b3};
-    TF_DISPATCH(E, hipLaunchKernelGGL((timefeat_fwd_kernel<EE>), dim3((rows + TfCfg<EE>::ROWS - 1) / TfCfg<EE>::ROWS), dim3(256), 0,
-                                      (hipStream_t)stream, p, tidx, out, rows, K));
-    GPTST_CHECK_LAUNCH();
-    return GPTST_OK;
+    TfJobs t; t.n = 1;
+    t.j[0] = TfJob{TfParams{wd, bd, ww, bw, w1, b1, w2, b2, w3, b3}, TfGrads{}, tidx, out, nullptr, rows, K, E, 0};
+    return tf_launch(t, 0, (hipStream_t)stream);
 }
 
 // gradients are ACCUMULATED (+=) into gwd..gb3
@@ -150,11 +177,24 @@ extern "C" int gptst_timefeat_bwd(const float* wd, const float* bd, const float*
                                   const float* w2, const float* b2, const float* w3, const float* b3, float* gwd, float* gbd, float* gww,
                                   float* gbw, float* gw1, float* gb1, float* gw2, float* gb2, float* gw3, float* gb3, const float* tidx,
                                   const float* dout, int rows, int K, int E, void* stream) {
-    if (!wd || !tidx || !dout || !gwd || rows <= 0 || K <= 0) return GPTST_EARG;
-    TfParams p{wd, bd, ww, bw, w1, b1, w2, b2, w3, b3};
-    TfGrads g{gwd, gbd, gww, gbw, gw1, gb1, gw2, gb2, gw3, gb3};
-    TF_DISPATCH(E, hipLaunchKernelGGL((timefeat_bwd_kernel<EE>), dim3((rows + TfCfg<EE>::ROWS - 1) / TfCfg<EE>::ROWS), dim3(256), 0,
-                                      (hipStream_t)stream, p, g, tidx, dout, rows, K));
-    GPTST_CHECK_LAUNCH();
-    return GPTST_OK;
+    TfJobs t; t.n = 1;
+    t.j[0] = TfJob{TfParams{wd, bd, ww, bw, w1, b1, w2, b2, w3, b3}, TfGrads{gwd, gbd, gww, gbw, gw1, gb1, gw2, gb2, gw3, gb3}, tidx,
+                   nullptr, dout, rows, K, E, 0};
+    return tf_launch(t, 1, (hipStream_t)stream);
+}
+
+// njobs instances in ONE launch.  params: njobs x 10 pointers (module order, as above); grads: njobs x 10 pointers (bwd only, +=);
+// io: njobs outputs (fwd) or output gradients (bwd); rows / K / E per job; all jobs read the same tidx (B,T,2).
+extern "C" int gptst_timefeat_jobs(int njobs, int bwd, const void* const* params, const void* const* grads, const float* tidx,
+                                   const void* const* io, const int* rows, const int* K, const int* E, void* stream) {
+    if (njobs <= 0 || njobs > TF_MAXJ || !params || !io || !rows || !K || !E || (bwd && !grads)) return GPTST_EARG;
+    TfJobs t; t.n = njobs;
+    for (int q = 0; q < njobs; ++q) {
+        const float* const* pp = (const float* const*)params + 10 * q;
+        TfGrads g{};
+        if (bwd) { float* const* gg = (float* const*)grads + 10 * q; g = TfGrads{gg[0], gg[1], gg[2], gg[3], gg[4], gg[5], gg[6], gg[7], gg[8], gg[9]}; }
+        t.j[q] = TfJob{TfParams{pp[0], pp[1], pp[2], pp[3], pp[4], pp[5], pp[6], pp[7], pp[8], pp[9]}, g, tidx,
+                       bwd ? nullptr : (float*)io[q], bwd ? (const float*)io[q] : nullptr, rows[q], K[q], E[q], 0};
+    }
+    return tf_launch(t, bwd, (hipStream_t)stream);
 }

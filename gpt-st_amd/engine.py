@@ -45,11 +45,10 @@ class _Context(threading.local):
     """Per-thread execution context of a step (thread-local so that several shard steppers can run side by side in one process:
     tests emulate the ranks of a node-sharded run with threads).
       ARENA        ZeroArena of the running step (None -> plain torch.zeros)
-      SIDE / TAIL  optional extra streams (see SideStream)
+      SIDE         optional second stream for the weight gradients (see SideStream; measured slower, opt-in)
       NODE_REDUCE  node-sharded run: callable that completes a sum over nodes across the ranks, in place (None -> single shard)"""
     ARENA = None
     SIDE = None
-    TAIL = None
     NODE_REDUCE = None
 
 
@@ -58,9 +57,10 @@ CTX = _Context()
 
 class SideStream:
     """Weight-gradient kernels depend only on saved activations and the incoming gradient, and nothing needs their result
-    until the batched reductions at the end of an STHCN backward — so they run on a second HIP stream, concurrently with the
+    until the reductions at the end of the backward — so they can run on a second HIP stream, concurrently with the
     data-gradient chain on the main stream (fork/join with events; works inside hipGraph capture).  Tensors touched on the side
-    stream are kept alive until the join so the caching allocator cannot hand their memory out on the main stream."""
+    stream are kept alive until the join so the caching allocator cannot hand their memory out on the main stream.
+    Measured twice (r01: 364 vs 403, r02: 495 vs 518 steps/s): slower — the side kernels take CU slots from the critical chain."""
 
     def __init__(self):
         self.stream = torch.cuda.Stream()
@@ -75,38 +75,11 @@ class SideStream:
     def keep(self, *ts):
         self.pending.extend(ts)
 
-    def mark(self):
-        """Event after the work enqueued on the side stream so far (a partial join point)."""
-        ev = torch.cuda.Event()
-        ev.record(self.stream)
-        return ev
-
     def join(self):
         if self.active:
             torch.cuda.current_stream().wait_stream(self.stream)
             self.active = False
         self.pending = []
-
-
-# CTX.SIDE: weight gradients on a second stream (opt-in).  CTX.TAIL: second stream for the small, latency-bound kernels off the
-# critical path: parameter generation (depends only on the time index) and the pool / embedding gradient reductions at the end of
-# an STHCN backward.
-
-
-def _off_critical_path(fn, keep=()):
-    """Run fn() on the TAIL stream (after everything enqueued so far on the main stream); tensors in `keep` stay referenced until
-    the join so the caching allocator cannot recycle them under the side kernels."""
-    if CTX.TAIL is None:
-        return fn()
-    with CTX.TAIL.fork():
-        r = fn()
-    CTX.TAIL.keep(r, *keep)
-    return r
-
-
-def _join_tail():
-    if CTX.TAIL is not None:
-        CTX.TAIL.join()
 
 
 def _wgrad_async(*args, **kw):
@@ -124,6 +97,45 @@ def _join_side():
         CTX.SIDE.join()
 
 
+class Reductions:
+    """Everything of a backward pass that only produces PARAMETER gradients from per-layer partial results — the sums of the
+    generated weights' gradients into their pools and embeddings (GPTST.py:24-25,29-30,104,129,137-138,156,160-161 backward), the
+    temporal-graph factor gradients and the seven time-feature MLPs — is collected here while the data-gradient chain runs and
+    executed at the end of the backward as THREE launches (gram_bwd, one job table, one time-feature job table) instead of ~20
+    small launches per STHCN.  Nothing on the critical chain waits for these results; only the optimiser does."""
+
+    def __init__(self):
+        self.jobs = ops.PoolJobs()
+        self.grams = []          # (A (L*N,Hm,T), dG (L*N,T,T), dA out)
+        self.tf = []             # (params, grads, dout, rows, K)
+        self.keep = []
+
+    def gram(self, A, dG, dA):
+        self.grams.append((A, dG, dA))
+
+    def timefeat(self, p, g, pfx, tidx, dout, spg=False):
+        B, T = tidx.shape[0], tidx.shape[1]
+        rows, K = (B, T) if spg else (B * T, 1)
+        self.tf.append((_tf_tensors(p, pfx), _tf_tensors(g, pfx), dout, rows, K))
+
+    def flush(self, tidx):
+        gr, self.grams = sorted(self.grams, key=lambda t: t[0].data_ptr()), []
+        while gr:                                   # adjacent (A, dG, dA) triples (both STHCNs of a step) share one launch
+            A, dG, dA = gr.pop(0)
+            while gr and gr[0][0].data_ptr() == A.data_ptr() + 4 * A.numel() and gr[0][1].data_ptr() == dG.data_ptr() + 4 * dG.numel() \
+                    and gr[0][2].data_ptr() == dA.data_ptr() + 4 * dA.numel():
+                A2, dG2, dA2 = gr.pop(0)
+                n = A.shape[0] + A2.shape[0]
+                A = torch.as_strided(A, (n,) + tuple(A.shape[1:]), A.stride())
+                dG = torch.as_strided(dG, (n,) + tuple(dG.shape[1:]), dG.stride())
+                dA = torch.as_strided(dA, (n,) + tuple(dA.shape[1:]), dA.stride())
+            ops.gram_bwd(A, dG, out=dA)
+        self.jobs.launch()
+        tf, self.tf = self.tf, []
+        ops.timefeat_jobs_bwd(tf, tidx)
+        self.keep = []
+
+
 def _zeros(ref, *shape):
     if CTX.ARENA is not None:
         return CTX.ARENA.zeros(*shape)
@@ -138,16 +150,10 @@ def _tf_tensors(d, pfx):
 
 
 # ---- time features (GPTST.py:187-219) -----------------------------------------------------------------------------
-def timefeat_fwd(p, pfx, tidx, spg=False):
+def _tf_job(p, pfx, tidx, spg=False):
     B, T = tidx.shape[0], tidx.shape[1]
     rows, K = (B, T) if spg else (B * T, 1)
-    return ops.timefeat_fwd(_tf_tensors(p, pfx), tidx, rows, K)
-
-
-def timefeat_bwd(p, g, pfx, tidx, dout, spg=False):
-    B, T = tidx.shape[0], tidx.shape[1]
-    rows, K = (B, T) if spg else (B * T, 1)
-    ops.timefeat_bwd(_tf_tensors(p, pfx), _tf_tensors(g, pfx), tidx, dout, rows, K)
+    return (_tf_tensors(p, pfx), rows, K)
 
 
 # ---- hyperTem (GPTST.py:154-163) -----------------------------------------------------------------------------------
@@ -194,7 +200,7 @@ def cap_core_fwd(p, pfx, x, dadj, dyn, Wn, bn, dims, num_route, HS, HT):
     return out, c, (x, out, rec, c, s, v, Ht, Rt, dyn, Wn)
 
 
-def cap_core_bwd(p, g, pfx, saved, dout, dims, HS, HT):
+def cap_core_bwd(p, g, pfx, saved, dout, dims, HS, HT, red):
     """-> dx and the pieces whose reductions are batched by the caller: (dWn, nsplit, dbn, ddyn, dlogit)."""
     B, T, N, C = dims
     x, out, rec, c, s, v, Ht, Rt, dyn, Wn = saved
@@ -212,10 +218,10 @@ def cap_core_bwd(p, g, pfx, saved, dout, dims, HS, HT):
         # tensors are adjacent in the flat buffer ([ln_p.weight | ln_p.bias])
         dWp, ns2 = ops.wgrad(dY, x, MODE_SHARED, BT, N, colsum_a=True)
         gwb = torch.as_strided(gw, (1, C * C + C), (C * C + C, 1))
-        ops.poolgen_bwd_pool(_ones(dev), dWp, gwb, nsplit=ns2)
+        red.jobs.bwd_pool(_ones(dev), dWp, gwb, nsplit=ns2)
     else:
         dWp, ns2 = ops.wgrad(dY, x, MODE_SHARED, BT, N)
-        ops.poolgen_bwd_pool(_ones(dev), dWp, gw.view(1, C * C), nsplit=ns2)
+        red.jobs.bwd_pool(_ones(dev), dWp.view(ns2, C * C), gw.view(1, C * C), nsplit=ns2)
         ops.rowouter(None, 0, 0, dY, None, 0, csum=gb)
     return dx, (dWn, ns, dbn, ddyn, dlogit)
 
@@ -230,52 +236,93 @@ def _ones(dev):
 
 
 # ---- LReLU(x W_g + b_g) with generated weights, no residual (MLP_RL, GPTST.py:24-32) --------------------------------
-def condlin_fwd(x, emb, wpool, bpool, mode, dims):
+def condlin_fwd(x, Wg, bg, mode, dims):
     B, T, N, C = dims
-    Wg, bg = ops.poolgen(emb, wpool, bpool)
     out = ops.apply(x, Wg, mode, B * T, N, bias=bg, epi=EPI_LRELU)
     return out, (x, out, Wg)
 
 
-def condlin_bwd(saved, dout, emb, wpool, bpool, g_wpool, g_bpool, d_emb, mode, dims):
+def condlin_bwd(saved, dout, emb, wpool, bpool, g_wpool, g_bpool, d_emb, mode, dims, red):
     B, T, N, C = dims
     x, out, Wg = saved
-    db = _zeros(x, emb.shape[0], C)
+    R, K = emb.shape
+    db = _zeros(x, R, C)
     dx = ops.apply(dout, Wg, mode, B * T, N, A2=out, transw=True, pro=PRO_DPRE, colsum=db)
     dW, ns = ops.wgrad(x, dout, mode, B * T, N, D2=out, pro=PRO_DPRE)
-    ops.poolgen_bwd_pool(emb, dW, g_wpool, db, g_bpool, nsplit=ns)
-    ops.poolgen_bwd_emb(dW, wpool, d_emb, db, bpool, nsplit=ns)
+    dW = dW.view(ns * R, C * C)
+    red.jobs.bwd_pool(emb, dW, g_wpool.view(K, C * C), nsplit=ns)
+    red.jobs.bwd_pool(emb, db, g_bpool)
+    red.jobs.bwd_emb(dW, wpool.view(K, C * C), d_emb, nsplit=ns)
+    red.jobs.bwd_emb(db, bpool, d_emb)
     return dx
 
 
 # ---- STHCN (GPTST.py:253-273) --------------------------------------------------------------------------------------
-def sthcn_gen(p, pfx, tidx, dims):
-    """Everything of an STHCN forward that depends only on the time index and the parameters: the three time embeddings and all
-    generated parameters of the six layers (5 launches + 1 gram; was 18)."""
+ENC, DEC = "encoder.STHCN_encode.", "decoder.STHCN_decode."
+GUIDE_TF = "encoder.teb4mask."
+
+
+def _sthcn_names(pfx):
+    return [pfx + "hyperTem%d." % i for i in (1, 2, 3, 4)], [pfx + "cap1.", pfx + "cap2."]
+
+
+def _sthcn_gen_jobs(p, pfx, emb, jobs, A_all, dims):
+    """Queue the generated-parameter problems of one STHCN (20 jobs); -> gen dict (tensors are filled by jobs.launch())."""
     B, T, N, C = dims
-    time_eb = timefeat_fwd(p, pfx + "time_feature1.", tidx)                       # (BT,d)   :259
-    teb = timefeat_fwd(p, pfx + "time_feature1_.", tidx)                          # (BT,ds)  :260
-    tes = timefeat_fwd(p, pfx + "time_feature2.", tidx, spg=True)                 # (B,ds)   :261
+    time_eb, teb, tes = emb
     ne, nes = p[pfx + "node_embeddings"], p[pfx + "node_embeddings_spg"]
-    hts = [pfx + "hyperTem%d." % i for i in (1, 2, 3, 4)]
-    cps = [pfx + "cap1.", pfx + "cap2."]
+    hts, cps = _sthcn_names(pfx)
     adj0 = p[hts[0] + "adj"]
     d, Hm = adj0.shape[0], adj0.shape[1]
     cadj, tadj = p[cps[0] + "adj"], p[cps[0] + "t_adj"]
     ds, HS, HT = cadj.shape[0], cadj.shape[1], tadj.shape[1]
-    A_all = torch.empty(4, N, Hm * T, device=tidx.device)
-    ops.poolgen_multi(ne, [p[h + "adj"].view(d, Hm * T) for h in hts], outs=[A_all[i] for i in range(4)])       # :156
-    G_all = ops.gram_fwd(A_all.view(4 * N, Hm, T)).view(4, N, T, T)
-    Wb = ops.poolgen_multi(time_eb, [t for h in hts for t in (p[h + "weights_pool"], p[h + "bias_pool"])])       # :160-161
-    Wn = ops.poolgen_multi(nes, [t for c in cps for t in (p[c + "weights_spa"], p[c + "bias_spa"])])             # :137-138
-    dadj = ops.poolgen_multi(teb, [p[c + "adj"].view(ds, HS * N) for c in cps])                                  # :104
-    dyn = [t.view(B, HT, T * HS) for t in ops.poolgen_multi(tes, [p[c + "t_adj"].view(ds, HT * T * HS) for c in cps])]   # :129
-    return dict(emb=(time_eb, teb, tes), gen=(A_all, hts, cps, d, Hm, ds, HS, HT), G_all=G_all, Wb=Wb, Wn=Wn, dadj=dadj, dyn=dyn)
+    for i, h in enumerate(hts):
+        jobs.fwd(ne, p[h + "adj"].view(d, Hm * T), out=A_all[i])                                          # :156
+    Wb = [jobs.fwd(time_eb, t) for h in hts for t in (p[h + "weights_pool"], p[h + "bias_pool"])]         # :160-161
+    Wn = [jobs.fwd(nes, t) for c in cps for t in (p[c + "weights_spa"], p[c + "bias_spa"])]               # :137-138
+    dadj = [jobs.fwd(teb, p[c + "adj"].view(ds, HS * N)) for c in cps]                                    # :104
+    dyn = [jobs.fwd(tes, p[c + "t_adj"].view(ds, HT * T * HS)).view(B, HT, T * HS) for c in cps]          # :129
+    return dict(emb=emb, gen=(A_all, hts, cps, d, Hm, ds, HS, HT), Wb=Wb, Wn=Wn, dadj=dadj, dyn=dyn)
+
+
+def gen_all(p, tidx, dims, which=(ENC, DEC), guide=True):
+    """Everything of a step that depends only on the time index and the parameters — the seven time embeddings (:256-261, :337)
+    and every generated parameter of both STHCNs and of the guide MLP — in THREE launches (one time-feature job table, one
+    poolgen job table, one gram) instead of 23.  -> {prefix: gen dict, "guide": (t4m, Wspa, bspa, Wtem, btem)}"""
+    B, T, N, C = dims
+    tfj = []
+    for pfx in which:
+        tfj += [_tf_job(p, pfx + "time_feature1.", tidx), _tf_job(p, pfx + "time_feature1_.", tidx),
+                _tf_job(p, pfx + "time_feature2.", tidx, spg=True)]
+    if guide:
+        tfj.append(_tf_job(p, GUIDE_TF, tidx))
+    embs = ops.timefeat_jobs_fwd(tfj, tidx)
+    jobs = ops.PoolJobs()
+    res = {}
+    L = 4 * len(which)
+    if L:
+        adj0 = p[which[0] + "hyperTem1.adj"]
+        Hm = adj0.shape[1]
+        A_all = torch.empty(L, N, Hm * T, device=tidx.device)
+        for k, pfx in enumerate(which):
+            res[pfx] = _sthcn_gen_jobs(p, pfx, embs[3 * k:3 * k + 3], jobs, A_all[4 * k:4 * k + 4], dims)
+            res[pfx]["slot"] = (k, len(which))
+    if guide:
+        m = "encoder.MLP_RL."
+        t4m = embs[-1]
+        res["guide"] = (t4m, jobs.fwd(p["encoder.neb4mask"], p[m + "weights_pool_spa"]), jobs.fwd(p["encoder.neb4mask"], p[m + "bias_pool_spa"]),
+                        jobs.fwd(t4m, p[m + "weights_pool_tem"]), jobs.fwd(t4m, p[m + "bias_pool_tem"]))
+    jobs.launch()
+    if L:
+        G_all = ops.gram_fwd(A_all.view(L * N, Hm, T)).view(L, N, T, T)
+        for k, pfx in enumerate(which):
+            res[pfx]["G_all"] = G_all[4 * k:4 * k + 4]
+    return res
 
 
 def sthcn_fwd(p, pfx, tidx, x, dims, num_route, gen=None):
     if gen is None:
-        gen = sthcn_gen(p, pfx, tidx, dims)
+        gen = gen_all(p, tidx, dims, which=(pfx,), guide=False)[pfx]
     A_all, hts, cps, d, Hm, ds, HS, HT = gen["gen"]
     G_all, Wb, Wn, dadj, dyn = gen["G_all"], gen["Wb"], gen["Wn"], gen["dadj"], gen["dyn"]
     sv = {}
@@ -287,127 +334,128 @@ def sthcn_fwd(p, pfx, tidx, x, dims, num_route, gen=None):
     x, sv["h4"] = hypertem_core_fwd(x, G_all[3], Wb[6], Wb[7], dims)
     sv["emb"] = gen["emb"]
     sv["gen"] = gen["gen"]
+    sv["slot"] = gen.get("slot")
     return x, c1, sv
 
 
-def sthcn_bwd(p, g, pfx, tidx, sv, dout, dims):
+def _grad_buffers(red, slot, N, T, HmT, ref):
+    """dG (4,N,T,T) zeroed and dA (4,N,Hm*T) of one STHCN.  Both STHCNs of a step get adjacent halves of one buffer each, so that
+    Reductions.flush() turns their temporal-graph gradients into the factor gradients with ONE gram_bwd launch."""
+    if slot is None:
+        return _zeros(ref, 4, N, T, T), torch.empty(4, N, HmT, device=ref.device)
+    k, n = slot
+    if getattr(red, "_dG", None) is None or red._dG.shape[0] != 4 * n:
+        red._dG = _zeros(ref, 4 * n, N, T, T)
+        red._dA = torch.empty(4 * n, N, HmT, device=ref.device)
+    return red._dG[4 * k:4 * k + 4], red._dA[4 * k:4 * k + 4]
+
+
+def sthcn_bwd(p, g, pfx, tidx, sv, dout, dims, red):
     B, T, N, C = dims
     time_eb, teb, tes = sv["emb"]
     A_all, hts, cps, d, Hm, ds, HS, HT = sv["gen"]
     ne, nes = p[pfx + "node_embeddings"], p[pfx + "node_embeddings_spg"]
     dne, dnes = g[pfx + "node_embeddings"], g[pfx + "node_embeddings_spg"]
     d_te, d_teb, d_tes = _zeros(time_eb, *time_eb.shape), _zeros(teb, *teb.shape), _zeros(tes, *tes.shape)
-    dG_all = _zeros(dout, 4, N, T, T)
+    dG_all, dA_all = _grad_buffers(red, sv.get("slot"), N, T, Hm * T, dout)
     dd, hp4 = hypertem_core_bwd(sv["h4"], dout, dG_all[3], dims)
-    dd, cp2 = cap_core_bwd(p, g, cps[1], sv["c2"], dd, dims, HS, HT)
+    dd, cp2 = cap_core_bwd(p, g, cps[1], sv["c2"], dd, dims, HS, HT, red)
     dd, hp3 = hypertem_core_bwd(sv["h3"], dd, dG_all[2], dims)
     dd, hp2 = hypertem_core_bwd(sv["h2"], dd, dG_all[1], dims)
-    dd, cp1 = cap_core_bwd(p, g, cps[0], sv["c1"], dd, dims, HS, HT)
+    dd, cp1 = cap_core_bwd(p, g, cps[0], sv["c1"], dd, dims, HS, HT, red)
     dd, hp1 = hypertem_core_bwd(sv["h1"], dd, dG_all[0], dims)
     _join_side()
-
-    def reductions():
-        # ---- gradient reductions of all generated parameters, batched: 11 launches (was 32) ----
-        hps = (hp1, hp2, hp3, hp4)
-        dWs = [t for hp in hps for t in (hp[0], hp[2])]
-        nss = [v for hp in hps for v in (hp[1], 1)]
-        pools = [t for h in hts for t in (p[h + "weights_pool"], p[h + "bias_pool"])]
-        ops.poolgen_bwd_pool_multi(time_eb, dWs, [t for h in hts for t in (g[h + "weights_pool"], g[h + "bias_pool"])], nss)
-        ops.poolgen_bwd_emb_multi(dWs, pools, d_te, nss)
-        dA_all = ops.gram_bwd(A_all.view(4 * N, Hm, T), dG_all.view(4 * N, T, T)).view(4, N, Hm * T)
-        dAs = [dA_all[i] for i in range(4)]
-        ops.poolgen_bwd_pool_multi(ne, dAs, [g[h + "adj"].view(d, Hm * T) for h in hts])
-        ops.poolgen_bwd_emb_multi(dAs, [p[h + "adj"].view(d, Hm * T) for h in hts], dne)
-        cpp = (cp1, cp2)
-        dWn = [t for cp in cpp for t in (cp[0], cp[2])]
-        nsn = [v for cp in cpp for v in (cp[1], 1)]
-        ops.poolgen_bwd_pool_multi(nes, dWn, [t for c in cps for t in (g[c + "weights_spa"], g[c + "bias_spa"])], nsn)
-        ops.poolgen_bwd_emb_multi(dWn, [t for c in cps for t in (p[c + "weights_spa"], p[c + "bias_spa"])], dnes, nsn)
-        ddyn = [cp[3].view(B, HT * T * HS) for cp in cpp]
-        ops.poolgen_bwd_pool_multi(tes, ddyn, [g[c + "t_adj"].view(ds, HT * T * HS) for c in cps])
-        ops.poolgen_bwd_emb_multi(ddyn, [p[c + "t_adj"].view(ds, HT * T * HS) for c in cps], d_tes)
-        dlg = [cp[4].view(B * T, HS * N) for cp in cpp]
-        ops.poolgen_bwd_pool_multi(teb, dlg, [g[c + "adj"].view(ds, HS * N) for c in cps])
-        ops.poolgen_bwd_emb_multi(dlg, [p[c + "adj"].view(ds, HS * N) for c in cps], d_teb)
-        timefeat_bwd(p, g, pfx + "time_feature1.", tidx, d_te)
-        timefeat_bwd(p, g, pfx + "time_feature1_.", tidx, d_teb)
-        timefeat_bwd(p, g, pfx + "time_feature2.", tidx, d_tes, spg=True)
-
-    # none of these results is needed before the optimiser: they overlap with the next backward chain on the TAIL stream
-    _off_critical_path(reductions, keep=(sv, hp1, hp2, hp3, hp4, cp1, cp2, d_te, d_teb, d_tes, dG_all, dout))
+    # ---- gradient reductions of all generated parameters: queued, executed by red.flush() ----
+    J = red.jobs
+    CC, BT = C * C, B * T
+    for h, (dWbt, ns, dbias) in zip(hts, (hp1, hp2, hp3, hp4)):
+        dW2 = dWbt.view(ns * BT, CC)
+        J.bwd_pool(time_eb, dW2, g[h + "weights_pool"].view(d, CC), nsplit=ns)
+        J.bwd_pool(time_eb, dbias, g[h + "bias_pool"])
+        J.bwd_emb(dW2, p[h + "weights_pool"].view(d, CC), d_te, nsplit=ns)
+        J.bwd_emb(dbias, p[h + "bias_pool"], d_te)
+    red.gram(A_all.view(4 * N, Hm, T), dG_all.view(4 * N, T, T), dA_all.view(4 * N, Hm, T))
+    for i, h in enumerate(hts):
+        J.bwd_pool(ne, dA_all[i], g[h + "adj"].view(d, Hm * T))
+        J.bwd_emb(dA_all[i], p[h + "adj"].view(d, Hm * T), dne)
+    for c, (dWn, ns, dbn, ddyn, dlogit) in zip(cps, (cp1, cp2)):
+        dW2 = dWn.view(ns * N, CC)
+        J.bwd_pool(nes, dW2, g[c + "weights_spa"].view(d, CC), nsplit=ns)
+        J.bwd_pool(nes, dbn, g[c + "bias_spa"])
+        J.bwd_emb(dW2, p[c + "weights_spa"].view(d, CC), dnes, nsplit=ns)
+        J.bwd_emb(dbn, p[c + "bias_spa"], dnes)
+        dd2 = ddyn.view(B, HT * T * HS)
+        J.bwd_pool(tes, dd2, g[c + "t_adj"].view(ds, HT * T * HS))
+        J.bwd_emb(dd2, p[c + "t_adj"].view(ds, HT * T * HS), d_tes)
+        dl2 = dlogit.view(BT, HS * N)
+        J.bwd_pool(teb, dl2, g[c + "adj"].view(ds, HS * N))
+        J.bwd_emb(dl2, p[c + "adj"].view(ds, HS * N), d_teb)
+    red.timefeat(p, g, pfx + "time_feature1.", tidx, d_te)
+    red.timefeat(p, g, pfx + "time_feature1_.", tidx, d_teb)
+    red.timefeat(p, g, pfx + "time_feature2.", tidx, d_tes, spg=True)
+    red.keep.append((sv, hp1, hp2, hp3, hp4, cp1, cp2, dout))
     return dd
 
 
 # ---- whole model ---------------------------------------------------------------------------------------------------
-def guide_fwd(p, source, tidx, dims, base):
+def guide_fwd(p, source, tidx, dims, base, gen=None):
     """softmax(MLP_RL(raw flow, teb4mask(t), neb4mask)) — GPTST.py:326-332 / 337-343.  -> prob (BTN,HS), saved."""
     B, T, N, C = dims
-    t4m = timefeat_fwd(p, "encoder.teb4mask.", tidx)
+    if gen is None:
+        gen = gen_all(p, tidx, dims, which=(), guide=True)["guide"]
+    t4m, Wspa, bspa, Wtem, btem = gen
     m = "encoder.MLP_RL."
     h0 = ops.lin_in(source, base + 2, base, p[m + "ln1.weight"], p[m + "ln1.bias"], C)                    # :22
-    h1, s1 = condlin_fwd(h0, p["encoder.neb4mask"], p[m + "weights_pool_spa"], p[m + "bias_pool_spa"], MODE_NODE, dims)   # :24-27
-    h2, s2 = condlin_fwd(h1, t4m, p[m + "weights_pool_tem"], p[m + "bias_pool_tem"], MODE_TIME, dims)     # :29-32
-    prob = ops.rowdot(h2, p[m + "ln3.weight"], p[m + "ln3.bias"], softmax=True)                           # :33, :332
-    return prob, (t4m, s1, s2, h2)
+    h1, s1 = condlin_fwd(h0, Wspa, bspa, MODE_NODE, dims)                                                 # :24-27
+    h2, s2 = condlin_fwd(h1, Wtem, btem, MODE_TIME, dims)                                                 # :29-32
+    prob, label = ops.rowdot(h2, p[m + "ln3.weight"], p[m + "ln3.bias"], softmax=True, want_label=True)   # :33, :332, :344-345
+    return prob, (t4m, s1, s2, h2, label)
 
 
-def guide_bwd(p, g, source, tidx, saved, dlogit, dims, base):
+def guide_bwd(p, g, source, tidx, saved, dlogit, dims, base, red):
     B, T, N, C = dims
-    t4m, s1, s2, h2 = saved
+    t4m, s1, s2, h2 = saved[:4]
     m = "encoder.MLP_RL."
     HS = dlogit.shape[1]
     dh2 = ops.lin_in(dlogit, HS, HS, p[m + "ln3.weight"], None, C, wlayout=1)
     ops.rowouter(dlogit, HS, HS, h2, g[m + "ln3.weight"], 1, asum=g[m + "ln3.bias"])
     d_t4m = _zeros(t4m, *t4m.shape)
     dh1 = condlin_bwd(s2, dh2, t4m, p[m + "weights_pool_tem"], p[m + "bias_pool_tem"], g[m + "weights_pool_tem"],
-                      g[m + "bias_pool_tem"], d_t4m, MODE_TIME, dims)
+                      g[m + "bias_pool_tem"], d_t4m, MODE_TIME, dims, red)
     dh0 = condlin_bwd(s1, dh1, p["encoder.neb4mask"], p[m + "weights_pool_spa"], p[m + "bias_pool_spa"],
-                      g[m + "weights_pool_spa"], g[m + "bias_pool_spa"], g["encoder.neb4mask"], MODE_NODE, dims)
+                      g[m + "weights_pool_spa"], g[m + "bias_pool_spa"], g["encoder.neb4mask"], MODE_NODE, dims, red)
     ops.rowouter(source, base + 2, base, dh0, g[m + "ln1.weight"], 0, csum=g[m + "ln1.bias"])
-    timefeat_bwd(p, g, "encoder.teb4mask.", tidx, d_t4m)
+    red.timefeat(p, g, GUIDE_TF, tidx, d_t4m)
+    red.keep.append((saved, dlogit, dh2, dh1, dh0))
 
 
-def model_fwd(p, source, mask, dims, base, num_route, scaler_zeros, gen=None, gen_ready=None, tidx=None):
+def model_fwd(p, source, mask, dims, base, num_route, scaler_zeros, gen=None, tidx=None):
     """Masked-autoencoder body — GPTST.py:415-421 + 453-456.  mask (BTN*base) fp32, 1 = visible; None -> no masking (eval)."""
     B, T, N, C = dims
     if tidx is None:
         tidx = source[:, :, 0, base:base + 2].contiguous()
     x0 = ops.lin_in(source, base + 2, base, p["encoder.dim_in_flow.weight"], p["encoder.dim_in_flow.bias"], C,
                     mask=mask, fill=scaler_zeros)                                                          # :416-418
-    if gen_ready is not None:
-        torch.cuda.current_stream().wait_event(gen_ready)
-    emb, c1, sv_e = sthcn_fwd(p, "encoder.STHCN_encode.", tidx, x0, dims, num_route, gen=gen)               # :421
+    emb, c1, sv_e = sthcn_fwd(p, ENC, tidx, x0, dims, num_route, gen=gen)                                  # :421
     return emb, c1, tidx, sv_e
 
 
-def early_gen(p, tidx, dims):
-    """Generated parameters of both STHCNs, requested at the start of the step on the TAIL stream: the encoder's overlap with
-    the guide forward + mask selection, the decoder's with the encoder forward.  -> (gen_e, event after gen_e, gen_d)."""
-    if CTX.TAIL is None:
-        return None, None, None
-    gen_e = _off_critical_path(lambda: sthcn_gen(p, "encoder.STHCN_encode.", tidx, dims), keep=(tidx,))
-    ev = CTX.TAIL.mark()
-    gen_d = _off_critical_path(lambda: sthcn_gen(p, "decoder.STHCN_decode.", tidx, dims))
-    return gen_e, ev, gen_d
-
-
 def decoder_fwd(p, tidx, emb, dims, num_route, gen=None):
-    if gen is not None:
-        _join_tail()
-    dec, _, sv_d = sthcn_fwd(p, "decoder.STHCN_decode.", tidx, emb, dims, num_route, gen=gen)               # :454
+    dec, _, sv_d = sthcn_fwd(p, DEC, tidx, emb, dims, num_route, gen=gen)                                  # :454
     out = ops.rowdot(dec, p["decoder.dim_flow_out.weight"], p["decoder.dim_flow_out.bias"])                 # :455
     return out, dec, sv_d
 
 
-def model_bwd(p, g, source, mask, tidx, sv_e, sv_d, dec, d_out, d_dec, dims, base, scaler_zeros):
-    """Backward of decoder_fwd . model_fwd given d_out (BTN, base) [and optional d_dec (BTN, C)]."""
+def model_bwd(p, g, source, mask, tidx, sv_e, sv_d, dec, d_out, d_dec, dims, base, scaler_zeros, red):
+    """Backward of decoder_fwd . model_fwd given d_out (BTN, base) [and optional d_dec (BTN, C)].  Parameter-gradient reductions
+    are queued on ``red`` (Reductions): the caller runs red.flush(tidx) once the whole backward is enqueued."""
     B, T, N, C = dims
     wo = "decoder.dim_flow_out."
     dd = ops.lin_in(d_out, base, base, p[wo + "weight"], None, C, wlayout=1)
     if d_dec is not None:
         dd = dd + d_dec
     ops.rowouter(d_out, base, base, dec, g[wo + "weight"], 1, asum=g[wo + "bias"])
-    d_emb = sthcn_bwd(p, g, "decoder.STHCN_decode.", tidx, sv_d, dd, dims)
-    d_x0 = sthcn_bwd(p, g, "encoder.STHCN_encode.", tidx, sv_e, d_emb, dims)
+    d_emb = sthcn_bwd(p, g, DEC, tidx, sv_d, dd, dims, red)
+    d_x0 = sthcn_bwd(p, g, ENC, tidx, sv_e, d_emb, dims, red)
     ops.rowouter(source, base + 2, base, d_x0, g["encoder.dim_in_flow.weight"], 0, csum=g["encoder.dim_in_flow.bias"],
                  mask=mask, fill=scaler_zeros)

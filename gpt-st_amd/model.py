@@ -111,9 +111,11 @@ class _PretrainFn(torch.autograd.Function):
     def forward(ctx, model, source, mask, *params):
         p = model.param_views()
         dims, base = model._dims(source), model.input_base_dim
-        prob, sv_g = engine.guide_fwd(p, source, model._tidx(source), dims, base)
-        emb, c1, tidx, sv_e = engine.model_fwd(p, source, mask, dims, base, model.num_route, model.scaler_zeros)
-        out, dec, sv_d = engine.decoder_fwd(p, tidx, emb, dims, model.num_route)
+        tidx = model._tidx(source)
+        gen = engine.gen_all(p, tidx, dims)
+        prob, sv_g = engine.guide_fwd(p, source, tidx, dims, base, gen=gen["guide"])
+        emb, c1, tidx, sv_e = engine.model_fwd(p, source, mask, dims, base, model.num_route, model.scaler_zeros, gen=gen[engine.ENC], tidx=tidx)
+        out, dec, sv_d = engine.decoder_fwd(p, tidx, emb, dims, model.num_route, gen=gen[engine.DEC])
         ctx.model, ctx.saved = model, (source, mask, tidx, sv_g, sv_e, sv_d, dec, prob, dims)
         B, T, N, C = dims
         ctx.mark_non_differentiable(c1)
@@ -130,12 +132,14 @@ class _PretrainFn(torch.autograd.Function):
         g = model.views_of(gflat)
         d_out = d_out.contiguous().view(-1, base)
         d_dec2 = None if d_dec is None or not bool(d_dec.any()) else d_dec.contiguous().view(-1, C)
-        engine.model_bwd(p, g, source, mask, tidx, sv_e, sv_d, dec, d_out, d_dec2, dims, base, model.scaler_zeros)
+        red = engine.Reductions()
+        engine.model_bwd(p, g, source, mask, tidx, sv_e, sv_d, dec, d_out, d_dec2, dims, base, model.scaler_zeros, red)
         has_kl = d_prob is not None and bool(d_prob.any())
         if has_kl:      # softmax backward: dlogit = prob * (d_prob - sum(d_prob * prob))
             dp = d_prob.contiguous().view(-1, prob.shape[1])
             dlogit = (prob * (dp - (dp * prob).sum(-1, keepdim=True))).contiguous()
-            engine.guide_bwd(p, g, source, tidx, sv_g, dlogit, dims, base)
+            engine.guide_bwd(p, g, source, tidx, sv_g, dlogit, dims, base, red)
+        red.flush(tidx)
         grads = []
         for k in model.param_keys:
             seg = _segment(k)

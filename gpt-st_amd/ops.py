@@ -124,6 +124,49 @@ def poolgen_bwd_emb_multi(dWs, pools, demb, nsplits=None):
           nbytes=_nb(demb, *dWs, *pools))
 
 
+class PoolJobs:
+    """A list of independent poolgen problems (forward generation and/or gradient reductions, each with its own embedding) that
+    run as ONE launch per 48 jobs (gptst_pool_jobs).  Tensors are kept referenced until launch()."""
+    FWD, BWD_POOL, BWD_EMB = 0, 1, 2
+
+    def __init__(self):
+        self.jobs = []
+
+    def fwd(self, emb, pool, out=None):
+        """out (R, ...) = emb (R,K) @ pool (K, ...)"""
+        _chk(emb, pool, out)
+        R, K = emb.shape
+        if out is None:
+            out = torch.empty((R,) + tuple(pool.shape[1:]), device=emb.device, dtype=torch.float32)
+        self.jobs.append((self.FWD, emb, None, pool, out, R, K, pool.numel() // K, 1))
+        return out
+
+    def bwd_pool(self, emb, dW, dpool, nsplit=1):
+        """dpool (K, ...) += emb^T dW, summing nsplit row blocks of R rows.  (Owned, non-atomic update: one job per dpool.)"""
+        _chk(emb, dW, dpool)
+        R, K = emb.shape
+        self.jobs.append((self.BWD_POOL, emb, dW, None, dpool, R, K, dpool.numel() // K, nsplit))
+
+    def bwd_emb(self, dW, pool, demb, nsplit=1):
+        """demb (R,K) += (sum of nsplit row blocks of dW) @ pool^T"""
+        _chk(dW, pool, demb)
+        R, K = demb.shape
+        self.jobs.append((self.BWD_EMB, None, dW, pool, demb, R, K, pool.numel() // K, nsplit))
+
+    def launch(self):
+        js, self.jobs = self.jobs, []
+        if not js:
+            return
+        col = lambda i: [j[i] for j in js]
+        _call("gptst_pool_jobs", len(js), _ints(col(0)), _ptrs0(col(1)), _ptrs0(col(2)), _ptrs0(col(3)), _ptrs0(col(4)), _ints(col(5)),
+              _ints(col(6)), _ints(col(7)), _ints(col(8)), nbytes=_nb(*[t for j in js for t in j[1:5]]))
+
+
+def _ptrs0(ts):
+    import ctypes
+    return (ctypes.c_void_p * len(ts))(*[(t.data_ptr() if t is not None else None) for t in ts])
+
+
 # ---- MFMA contractions ---------------------------------------------------------------------------------------
 def apply(A, W, mode, BT, N, bias=None, resid=None, A2=None, transw=False, pro=PRO_NONE, epi=EPI_PLAIN, colsum=None,
           out=None, resid2=None):
@@ -163,9 +206,9 @@ def gram_fwd(A):
     return G
 
 
-def gram_bwd(A, dG):
+def gram_bwd(A, dG, out=None):
     N, Hm, T = A.shape
-    dA = torch.empty_like(A)
+    dA = out if out is not None else torch.empty_like(A)
     _call("gptst_gram_bwd", _p(A), _p(dG), _p(dA), N, Hm)
     return dA
 
@@ -360,6 +403,17 @@ def mask_random(noise, k):
     return mask
 
 
+MASK_SMALL = 1 << 13      # cells up to which the whole mask generation is one single-workgroup launch (masksel.hip MSS_MAXM)
+
+
+def labels_and_counts(prob, label):
+    """(label, counts) for mask_adaptive: the guide's rowdot already produced the argmax labels; the single-launch mask kernel
+    histograms them itself (counts = None), the multi-launch path needs the class histogram up front."""
+    if label.numel() <= MASK_SMALL:
+        return label, None
+    return mask_labels(prob)
+
+
 def mask_labels(prob):
     """prob (rows, HS) -> label int32 (rows), counts int32 (HS)."""
     _chk(prob)
@@ -372,7 +426,7 @@ def mask_labels(prob):
 
 def mask_adaptive(label, counts, list_c, nums, noise_a, noise_r, ada_all, base):
     """-> (m_ada (M), m_rnd (M), mask (M*base)) fp32 {0,1}."""
-    M, HS = label.numel(), counts.numel()
+    M, HS = label.numel(), list_c.numel()
     m_ada = torch.empty(M, device=label.device, dtype=torch.float32)
     m_rnd = torch.empty_like(m_ada)
     mask = torch.empty(M * base, device=label.device, dtype=torch.float32)
@@ -389,12 +443,14 @@ def lin_in(a, lda, J, W, b, C, mask=None, fill=0.0, wlayout=0, rows=None):
     return Y
 
 
-def rowdot(X, W, b, softmax=False):
+def rowdot(X, W, b, softmax=False, want_label=False):
+    """Z = X W^T + b [softmax over the J outputs]; want_label -> (Z, int32 argmax per row: first maximum)."""
     rows, C = X.shape
     J = W.shape[0]
     Z = torch.empty(rows, J, device=X.device, dtype=torch.float32)
-    _call("gptst_rowdot", _p(X), _p(W), _p(b), _p(Z), rows, J, C, int(softmax), nbytes=_nb(X, W, b, Z))
-    return Z
+    label = torch.empty(rows, device=X.device, dtype=torch.int32) if want_label else None
+    _call("gptst_rowdot", _p(X), _p(W), _p(b), _p(Z), rows, J, C, int(softmax), _p(label), nbytes=_nb(X, W, b, Z))
+    return (Z, label) if want_label else Z
 
 
 def rowouter(a, lda, J, X, out, olayout, csum=None, asum=None, mask=None, fill=0.0):
@@ -416,6 +472,22 @@ def timefeat_fwd(params, tidx, rows, K):
 def timefeat_bwd(params, grads, tidx, dout, rows, K):
     E = params[1].numel()
     _call("gptst_timefeat_bwd", *[_p(t) for t in params], *[_p(t) for t in grads], _p(tidx), _p(dout), rows, K, E)
+
+
+def timefeat_jobs_fwd(jobs, tidx):
+    """jobs: [(params (10 tensors), rows, K)] -> list of outputs (rows, E); ONE launch."""
+    outs = [torch.empty(rows, params[1].numel(), device=tidx.device, dtype=torch.float32) for params, rows, K in jobs]
+    _call("gptst_timefeat_jobs", len(jobs), 0, _ptrs([t for params, _, _ in jobs for t in params]), None, _p(tidx), _ptrs(outs),
+          _ints([r for _, r, _ in jobs]), _ints([k for _, _, k in jobs]), _ints([params[1].numel() for params, _, _ in jobs]))
+    return outs
+
+
+def timefeat_jobs_bwd(jobs, tidx):
+    """jobs: [(params, grads, dout, rows, K)]; gradients are accumulated; ONE launch."""
+    if not jobs:
+        return
+    _call("gptst_timefeat_jobs", len(jobs), 1, _ptrs([t for j in jobs for t in j[0]]), _ptrs([t for j in jobs for t in j[1]]), _p(tidx),
+          _ptrs([j[2] for j in jobs]), _ints([j[3] for j in jobs]), _ints([j[4] for j in jobs]), _ints([j[0][1].numel() for j in jobs]))
 
 
 # ---- loss / optimiser -------------------------------------------------------------------------------------------

@@ -174,22 +174,25 @@ class ShardedPretrainStep(PretrainStep):
         M = self.B * self.T * self.Nl
         self.gbuf.zero_()
         ctx = engine.CTX
-        ctx.ARENA, ctx.SIDE, ctx.TAIL, ctx.NODE_REDUCE = self.arena, None, None, self.group.all_reduce_
+        ctx.ARENA, ctx.SIDE, ctx.NODE_REDUCE = self.arena, None, self.group.all_reduce_
         try:
             self.arena.begin()
             src = self.src
             tidx = src[:, :, 0, base:base + 2].contiguous()       # every node carries the same time index (GPTST.py:256-257 uses node 0)
-            prob, sv_g = engine.guide_fwd(p, src, tidx, dims, base)
+            gen = engine.gen_all(p, tidx, dims)
+            red = engine.Reductions()
+            prob, sv_g = engine.guide_fwd(p, src, tidx, dims, base, gen=gen["guide"])
             mask = self._mask(phase, prob)
             self.last_mask = mask
-            emb, c1, tidx, sv_e = engine.model_fwd(p, src, mask, dims, base, mdl.num_route, mdl.scaler_zeros)
-            out, dec, sv_d = engine.decoder_fwd(p, tidx, emb, dims, mdl.num_route)
+            emb, c1, tidx, sv_e = engine.model_fwd(p, src, mask, dims, base, mdl.num_route, mdl.scaler_zeros, gen=gen[engine.ENC], tidx=tidx)
+            out, dec, sv_d = engine.decoder_fwd(p, tidx, emb, dims, mdl.num_route, gen=gen[engine.DEC])
             ops.mae_fwd(out, src, base + 2, mask, self.std, self.mean, a.mape_thresh, M, base, self.stats)
             d_out = ops.mae_bwd(out, src, base + 2, mask, self.std, self.mean, a.mape_thresh, M, base, self.stats, normalize=False)
-            engine.model_bwd(p, g, src, mask, tidx, sv_e, sv_d, dec, d_out, None, dims, base, mdl.scaler_zeros)
+            engine.model_bwd(p, g, src, mask, tidx, sv_e, sv_d, dec, d_out, None, dims, base, mdl.scaler_zeros, red)
             if phase == 1:
                 dlogit = ops.kl(prob, c1, self.Nl, 0.1, self.stats)
-                engine.guide_bwd(p, g, src, tidx, sv_g, dlogit, dims, base)
+                engine.guide_bwd(p, g, src, tidx, sv_g, dlogit, dims, base, red)
+            red.flush(tidx)
         finally:
             ctx.ARENA = ctx.NODE_REDUCE = None
         # ---- gradients: replicated-compute parameters count once, node-local ones stay local, the rest is summed ----
@@ -213,10 +216,5 @@ class ShardedPretrainStep(PretrainStep):
         self.stats[3] += (tot - own)[0]
         self._optim()
 
-    def _host_prepare(self, phase, epoch, list_c):
-        super()._host_prepare(phase, epoch, list_c)
-        if phase == 1:                                            # mask budgets over the GLOBAL cell count
-            ada, rnd = self.model.adaptive_counts(self.B * self.T * self.Ng, epoch)
-            c = self.ctrl_host
-            c[self.HS], c[self.HS + 1] = ada, rnd
-            self.ctrl.copy_(c)
+    def _budgets(self, ada, rnd, epoch):
+        return self.model.adaptive_counts(self.B * self.T * self.Ng, epoch)      # mask budgets over the GLOBAL cell count

@@ -15,6 +15,8 @@ from . import engine, ops
 
 
 class PretrainStep:
+    RING = 8                                  # pinned host slots in flight (see __init__)
+
     def __init__(self, model, args, scaler_mean, scaler_std, batch_size, use_graph=True, dp=None, seed=0, global_mask=True):
         """``seed`` drives the class-order shuffle and (data parallel, global masks) the mask noise: it must be the SAME on every
         rank, because every rank regenerates the selection over the global batch and keeps its rows (dist.py)."""
@@ -37,9 +39,14 @@ class PretrainStep:
         self.noise_ar = torch.zeros(2 * M, device=self.dev)          # adaptive phase: [noise_a | noise_r], drawn by ONE launch
         self.noise_a, self.noise_r = self.noise_ar[:M], self.noise_ar[M:]
         self.ctrl = torch.zeros(self.HS + 2, dtype=torch.int32, device=self.dev)    # [list_c | adaptive_num, random_num]
-        self.ctrl_host = torch.zeros(self.HS + 2, dtype=torch.int32).pin_memory()
         self.hyper = torch.zeros(16, device=self.dev)
-        self.hyper_host = torch.zeros(16).pin_memory()
+        # Per-step host scalars travel through a RING of pinned slots, each guarded by an event recorded behind its H2D copies:
+        # step() never synchronises, so with a single pinned buffer the host could rewrite the Adam bias corrections / class
+        # order of step k+j before the DMA of step k has read them (hundreds of steps are queued back to back by bench.py).
+        self._ring = [dict(hyper=torch.zeros(16).pin_memory(), ctrl=torch.zeros(self.HS + 2, dtype=torch.int32).pin_memory(), ev=None)
+                      for _ in range(self.RING)]
+        self._ring_i = 0
+        self.phase_kl = False                                        # phase of the last enqueued step (losses())
         self.stats_out = torch.zeros(8, device=self.dev)            # snapshot of stats after the step (graph output)
         self.mask_buf = torch.ones(M * self.base, device=self.dev)   # teacher-forced mask (parity runs)
         self.last_mask = None
@@ -67,8 +74,6 @@ class PretrainStep:
             self.label_graph = None
         # measured: running weight gradients on a second stream slows the step (364 vs 403 steps/s), so opt-in only
         self.side = engine.SideStream() if os.environ.get("GPTST_SIDE_STREAM", "0") == "1" else None
-        # small latency-bound kernels off the critical path (decoder parameter generation, pool / embedding gradient reductions)
-        self.tail = engine.SideStream() if os.environ.get("GPTST_TAIL_STREAM", "1") == "1" else None
 
     # ---- the enqueued work ---------------------------------------------------------------------------------------
     def _fwd_bwd(self, phase):
@@ -78,12 +83,12 @@ class PretrainStep:
         self.gbuf.zero_()
         engine.CTX.ARENA = self.arena
         engine.CTX.SIDE = self.side
-        engine.CTX.TAIL = self.tail
         self.arena.begin()
         src = self.src
         tidx = src[:, :, 0, base:base + 2].contiguous()
-        gen_e, gen_e_ready, gen_d = engine.early_gen(p, tidx, dims)
-        prob, sv_g = engine.guide_fwd(p, src, tidx, dims, base)
+        gen = engine.gen_all(p, tidx, dims)                       # time embeddings + every generated parameter: 3 launches
+        red = engine.Reductions()
+        prob, sv_g = engine.guide_fwd(p, src, tidx, dims, base, gen=gen["guide"])
         if self.gmask:
             mask = self._global_mask(phase)
         else:
@@ -97,25 +102,23 @@ class PretrainStep:
             elif phase == 0:
                 mask = ops.mask_random(self.noise, int(M * base * a.mask_ratio))
             else:
-                label, counts = ops.mask_labels(prob)
+                label, counts = ops.labels_and_counts(prob, sv_g[4])
                 mask = ops.mask_adaptive(label, counts, self.ctrl[:self.HS], self.ctrl[self.HS:], self.noise_a, self.noise_r,
                                          a.ada_type == "all", base)[2]
         self.last_mask = mask
-        emb, c1, tidx, sv_e = engine.model_fwd(p, src, mask, dims, base, mdl.num_route, mdl.scaler_zeros, gen=gen_e, gen_ready=gen_e_ready,
-                                               tidx=tidx)
-        out, dec, sv_d = engine.decoder_fwd(p, tidx, emb, dims, mdl.num_route, gen=gen_d)
+        emb, c1, tidx, sv_e = engine.model_fwd(p, src, mask, dims, base, mdl.num_route, mdl.scaler_zeros, gen=gen[engine.ENC], tidx=tidx)
+        out, dec, sv_d = engine.decoder_fwd(p, tidx, emb, dims, mdl.num_route, gen=gen[engine.DEC])
         ops.mae_fwd(out, src, base + 2, mask, self.std, self.mean, a.mape_thresh, M, base, self.stats)
         d_out = ops.mae_bwd(out, src, base + 2, mask, self.std, self.mean, a.mape_thresh, M, base, self.stats,
                             normalize=self.dp is None)
-        engine.model_bwd(p, g, src, mask, tidx, sv_e, sv_d, dec, d_out, None, dims, base, mdl.scaler_zeros)
+        engine.model_bwd(p, g, src, mask, tidx, sv_e, sv_d, dec, d_out, None, dims, base, mdl.scaler_zeros, red)
         if phase == 1:
             dlogit = ops.kl(prob, c1, self.N, 0.1, self.stats)
-            engine.guide_bwd(p, g, src, tidx, sv_g, dlogit, dims, base)
+            engine.guide_bwd(p, g, src, tidx, sv_g, dlogit, dims, base, red)
         engine._join_side()
-        engine._join_tail()
+        red.flush(tidx)                                           # all parameter-gradient reductions: 3 launches
         engine.CTX.ARENA = None
         engine.CTX.SIDE = None
-        engine.CTX.TAIL = None
 
     def _global_mask(self, phase):
         """Mask of this rank's rows cut out of the selection over the global batch (identical on every rank)."""
@@ -178,13 +181,23 @@ class PretrainStep:
             self._optim()
 
     # ---- host side of one step -------------------------------------------------------------------------------------
+    def _slot(self):
+        """Next pinned slot of the ring; waits (host side) until the copies that last used it have run."""
+        sl = self._ring[self._ring_i]
+        self._ring_i = (self._ring_i + 1) % self.RING
+        if sl["ev"] is not None:
+            sl["ev"].synchronize()
+        return sl
+
     def _host_prepare(self, phase, epoch, list_c):
         a = self.args
         self.tA += 1
         if phase == 1:
             self.tB += 1
+        self.phase_kl = phase == 1
         b1, b2 = 0.9, 0.999
-        h = self.hyper_host
+        sl = self._slot()
+        h = sl["hyper"]
         h[0] = self.lr / (1 - b1 ** self.tA); h[1] = math.sqrt(1 - b2 ** self.tA)
         h[2] = self.lr / (1 - b1 ** self.tB) if self.tB else 0.0
         h[3] = math.sqrt(1 - b2 ** self.tB) if self.tB else 1.0
@@ -199,11 +212,17 @@ class PretrainStep:
                 list_c = list(range(self.HS))
                 self.rng.shuffle(list_c)                                   # GPTST.py:357-358
             ada, rnd = self.model.adaptive_counts(self.B * self.T * self.N * (self.W if self.gmask else 1), epoch)
-            c = self.ctrl_host
-            for i, v in enumerate(list_c):
-                c[i] = int(v)
-            c[self.HS], c[self.HS + 1] = ada, rnd
+            ada, rnd = self._budgets(ada, rnd, epoch)
+            c = sl["ctrl"]
+            c.copy_(torch.tensor([int(v) for v in list_c] + [int(ada), int(rnd)], dtype=torch.int32))
             self.ctrl.copy_(c, non_blocking=True)
+        if sl["ev"] is None:
+            sl["ev"] = torch.cuda.Event()
+        sl["ev"].record()
+
+    def _budgets(self, ada, rnd, epoch):
+        """Hook: subclasses whose masks cover more cells than this rank's batch (node sharding) replace the budgets."""
+        return ada, rnd
 
     def step(self, source, epoch, noise=None, noise_a=None, noise_r=None, list_c=None, forced_mask=None):
         """Enqueue one optimisation step on ``source`` (B,T,N,base+2).  Never synchronises.
@@ -260,5 +279,5 @@ class PretrainStep:
         """(loss, loss_flow, loss_s) of the last step — synchronises (reference BasicTrainer.py:98-103 does so every step)."""
         st = self.stats_out.cpu()
         lf = float(st[0] / max(float(st[1]), 1.0))
-        ls = float(st[2]) * 0.1 if self.tB and self.hyper_host[8] != 0 else 0.0
+        ls = float(st[2]) * 0.1 if self.tB and self.phase_kl else 0.0
         return lf + ls, lf, ls

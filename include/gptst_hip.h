@@ -24,7 +24,7 @@ extern "C" {
 
 #define GPTST_ABI_VERSION 1
 int gptst_abi_version(void);
-/* launch-geometry knobs for benchmarking, not needed for correctness.  id 1: row chunks of poolgen_bwd_pool; 2 / 5: forced split
+/* launch-geometry knobs for benchmarking, not needed for correctness.  1: rows per block of the poolgen forward; 2 / 5: forced split
  * count of the NODE / TIME weight gradient; 3: 1 = first-generation (LDS-staged) apply for C = 64; 4: tiles per wave of apply64 */
 int gptst_tune(int id, int value);
 
@@ -41,7 +41,7 @@ int gptst_poolgen_bwd_pool(const float* emb, const float* dW, float* dpool, int 
 int gptst_poolgen_bwd_emb(const float* dW, const float* pool, int cols, const float* dW2, const float* pool2, int cols2,
                           float* demb, int R, int nsplit, int K, void* stream);
 
-/* multi-problem forms (<= 8 problems sharing emb; host arrays of device pointers, read at call time): one launch generates /
+/* multi-problem forms (<= 48 problems sharing emb; host arrays of device pointers, read at call time): one launch generates /
  * reduces the generated parameters of several layers (every launch has a ~4-5 us floor on MI355X). */
 int gptst_poolgen_fwd_multi(const float* emb, int nprob, const void* pools, const void* outs, const int* cols, int R, int K,
                             void* stream);
@@ -49,6 +49,15 @@ int gptst_poolgen_bwd_pool_multi(const float* emb, int nprob, const void* dWs, c
                                  int R, int K, void* stream);
 int gptst_poolgen_bwd_emb_multi(int nprob, const void* dWs, const void* pools, const int* cols, const int* nsplit, float* demb, int R,
                                 int K, void* stream);
+
+/* Job table: njobs independent problems of ANY kind, each with its own embedding and shapes, in ceil(njobs / 48) launches
+ * (host arrays, read at call time).  kind 0: out (R,cols) = emb (R,K) . pool (K,cols);  kind 1: out = dpool (K,cols) += sum_rr
+ * emb[rr % R,:]^T x[rr,:], rr < R*nsplit — owned by ONE workgroup per element (no atomics: two kind-1 jobs of one call must
+ * not share `out`);  kind 2: out = demb (R,K) += (sum_s x[s*R + r,:]) . pool^T (atomic: several jobs may add into one demb).
+ * Unused pointers of a kind may be NULL.  A whole pretraining step needs 3 calls (forward generation, two backward reductions)
+ * where per-embedding launches needed ~50. */
+int gptst_pool_jobs(int njobs, const int* kind, const void* const* emb, const void* const* x, const void* const* pool,
+                    const void* const* out, const int* R, const int* K, const int* cols, const int* nsplit, void* stream);
 
 /* ---- C x C contractions on fp32 MFMA (apply.hip) ------------------------------------------------------
  * out[g,m,:] = epi( pro(A)[g,m,:] @ W[g] (+bias[g]) (+resid) ).   mode: 0 TIME (g=(b,t), rows n), 1 NODE (g=n, rows
@@ -138,19 +147,22 @@ int gptst_capbig_route_bwd_rows(const float* Y, const float* c, const float* dc1
 int gptst_metrics_accum(const float* out, const float* src, int lda, const float* vis, float sigma, float mu, int has_mae_thresh,
                         float mae_thresh, float mape_thresh, int B, int T, int N, int D, double* sums_t, double* sums_tn, void* stream);
 
-/* ---- mask generation, integer work, bit-exact given noise/labels/class order (maskgen.hip), GPTST.py:314-323,344-413 ----
- * Masks are fp32 {0,1} arrays, 1 = visible, 0 = masked.  Top-k = multi-workgroup radix select on the float bits, one launch per
- * 11/11/10-bit digit + one to write the mask (ties at rank k -> lowest index). */
+/* ---- mask generation, integer work, bit-exact given noise/labels/class order (masksel.hip), GPTST.py:314-323,344-413 ----
+ * Masks are fp32 {0,1} arrays, 1 = visible, 0 = masked.  Top-k = radix select on the float bits, 11/11/10-bit digits (ties at
+ * rank k -> lowest index).  Up to 2^13 cells the whole generation (class histogram and roles, both selections, mask writes) is ONE
+ * launch of one 1024-thread workgroup; beyond, one launch per digit + one to write the mask, 64 workgroups each. */
 int gptst_mask_ws_bytes(void);   /* device scratch (ws) needed by the two selections below */
 int gptst_mask_random(const float* noise, int M, int k, float* mask, void* ws, void* stream);
 /* label[i] = argmax_h prob[i,h] (int32), counts[h] (int32, zeroed here) — replaces sort(..)[..., 0] (:344-345). */
 int gptst_mask_labels(const float* prob, int rows, int HS, int* label, int* counts, void* stream);
 /* adaptive phase: device-side class selection (:356-384) + two selections (:386-407) + product (:410-413).
  * list_c: shuffled class order (int32[HS]); nums: {adaptive_mask_num, random_mask_num} int32[2] on the device;
- * m_ada / m_rnd (M) are the partial masks, mask (M*base) the final one. */
+ * m_ada / m_rnd (M) are the partial masks, mask (M*base) the final one.
+ * counts may be NULL for M <= 2^13 (the class histogram is then taken from the labels inside the launch). */
 int gptst_mask_adaptive(const int* label, const int* counts, const int* list_c, const int* nums, const float* noise_a,
                         const float* noise_r, int ada_all, int M, int HS, int base, float* m_ada, float* m_rnd, float* mask,
                         void* ws, void* stream);
+int gptst_mask_force_multi(int on);   /* tests: 1 = multi-launch path for every size */
 
 /* ---- thin projections (small.hip) ------------------------------------------------------------------------
  * lin_in: Y[i,:] = sum_j a'[i,j] W(:,j) + b, a' = mask ? (mask[i,j] ? a[i*lda+j] : fill) : a;  wlayout 0: W[c*J+j], 1: W[j*C+c].
@@ -160,7 +172,9 @@ int gptst_mask_adaptive(const int* label, const int* counts, const int* list_c, 
  *   asum[j] += sum_i a'[i,j]    (weight / bias gradients of both) */
 int gptst_lin_in(const float* a, int lda, const float* mask, float fill, const float* W, int wlayout, const float* b, float* Y,
                  int rows, int J, int C, void* stream);
-int gptst_rowdot(const float* X, const float* W, const float* b, float* Z, int rows, int J, int C, int do_softmax, void* stream);
+/* label (optional, int32 per row): argmax_j Z[i,j], first maximum — the cluster label of the adaptive mask (GPTST.py:344-345) */
+int gptst_rowdot(const float* X, const float* W, const float* b, float* Z, int rows, int J, int C, int do_softmax, int* label,
+                 void* stream);
 int gptst_rowouter_ws_floats(int J, int C);   /* scratch (ws) size of gptst_rowouter */
 int gptst_rowouter(const float* a, int lda, const float* mask, float fill, const float* X, float* out, int olayout, float* csum,
                    float* asum, float* ws, int rows, int J, int C, void* stream);
@@ -175,6 +189,11 @@ int gptst_timefeat_bwd(const float* wd, const float* bd, const float* ww, const 
                        const float* w2, const float* b2, const float* w3, const float* b3, float* gwd, float* gbd, float* gww,
                        float* gbw, float* gw1, float* gb1, float* gw2, float* gb2, float* gw3, float* gb3, const float* tidx,
                        const float* dout, int rows, int K, int E, void* stream);
+
+/* njobs (<= 16) time-feature instances in ONE launch (a step has seven).  params: njobs x 10 device pointers in the module order
+ * above; grads likewise (bwd != 0 only, +=); io[q]: output (fwd) or output gradient (bwd) of job q; all jobs read one tidx. */
+int gptst_timefeat_jobs(int njobs, int bwd, const void* const* params, const void* const* grads, const float* tidx,
+                        const void* const* io, const int* rows, const int* K, const int* E, void* stream);
 
 /* ---- loss + optimiser (loss_adam.hip) ---------------------------------------------------------------------
  * stats: device float[8] zeroed once per step: [0] sum|y-p| [1] kept count [2] KL sum [3] sum g^2.

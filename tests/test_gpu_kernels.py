@@ -226,22 +226,45 @@ def test_mask_random_bit_exact(M, ratio, seed):
     dev = _dev()
     noise = synth.make_noise(M, seed)
     ref = O.random_mask(noise, ratio)
-    got = ops.mask_random(noise.to(dev), int(M * ratio))
-    assert torch.equal(got.cpu().to(torch.int64), ref)
+    for multi in (0, 1):                  # single-workgroup launch (M <= 2^18) and the multi-launch radix select
+        with _mask_path(multi):
+            got = ops.mask_random(noise.to(dev), int(M * ratio))
+        assert torch.equal(got.cpu().to(torch.int64), ref), multi
 
 
-def test_mask_random_ties_lowest_index():
-    """Duplicated values straddling rank k: exactly k cells are dropped, larger values first, ties -> lowest index."""
+class _mask_path:
+    """force the multi-launch (1) or allow the single-workgroup (0) mask generation path"""
+
+    def __init__(self, multi):
+        self.multi = multi
+
+    def __enter__(self):
+        from gptst_amd import _C
+        _C.lib().call("gptst_mask_force_multi", int(self.multi))
+
+    def __exit__(self, *a):
+        from gptst_amd import _C
+        _C.lib().call("gptst_mask_force_multi", 0)
+
+
+@pytest.mark.parametrize("multi", [0, 1])
+@pytest.mark.parametrize("reps", [40, 4000])
+def test_mask_random_ties_lowest_index(multi, reps):
+    """Duplicated values straddling rank k: exactly k cells are dropped, larger values first, ties -> lowest index.  reps = 4000
+    spreads the tied cells over all 64 workgroups of the multi-launch path (tied cells are written by ONE workgroup)."""
     from gptst_amd import ops
     dev = _dev()
-    noise = torch.tensor([0.5, 0.25, 0.5, 0.75, 0.5, 0.1, 0.5, 0.0] * 40)
-    for k in (0, 40, 41, 100, 199, 200, 201, 320):
-        got = ops.mask_random(noise.to(dev), k).cpu()
-        assert int((got == 0).sum()) == k
-        order = sorted(range(noise.numel()), key=lambda i: (-float(noise[i]), i))
-        ref = torch.ones(noise.numel())
-        ref[order[:k]] = 0
-        assert torch.equal(got, ref), k
+    noise = torch.tensor([0.5, 0.25, 0.5, 0.75, 0.5, 0.1, 0.5, 0.0] * reps)
+    n = noise.numel()
+    order = torch.sort(-noise, stable=True)[1]                 # descending value, ties -> lowest index
+    for k in (0, reps, reps + 1, reps * 5 // 2, 5 * reps - 1, 5 * reps, 5 * reps + 1, 8 * reps):
+        with _mask_path(multi):
+            for _ in range(3 if reps > 40 else 1):             # the old cross-workgroup race was timing dependent
+                got = ops.mask_random(noise.to(dev), k).cpu()
+                assert int((got == 0).sum()) == k
+                ref = torch.ones(n)
+                ref[order[:k]] = 0
+                assert torch.equal(got, ref), k
 
 
 @pytest.mark.parametrize("ada_all", [1, 0])
@@ -263,8 +286,10 @@ def test_mask_adaptive_bit_exact(ada_all, B, N, HS, frac):
     list_c = synth.class_order(HS, 5)
     na, nr = synth.make_noise(M, 11), synth.make_noise(M, 12)
     m_ada_r, m_rnd_r, fin_r = O.adaptive_mask(label_ref.view(B, T, N), list_c, na, nr, ada, rnd_n, "all" if ada_all else "half")
-    for base in (1, 2):
-        m_ada, m_rnd, mask = ops.mask_adaptive(label, counts, torch.tensor(list_c, dtype=torch.int32, device=dev),
+    small = M <= ops.MASK_SMALL           # single-workgroup launch; there `counts` may be None (histogram inside the launch)
+    for base, multi, cnt in ((1, 0, counts), (2, 0, None if small else counts), (1, 1, counts), (2, 1, counts)):
+      with _mask_path(multi):
+        m_ada, m_rnd, mask = ops.mask_adaptive(label, cnt, torch.tensor(list_c, dtype=torch.int32, device=dev),
                                                torch.tensor([ada, rnd_n], dtype=torch.int32, device=dev), na.to(dev), nr.to(dev),
                                                ada_all, base)
         assert torch.equal(m_ada.cpu().long(), m_ada_r)
@@ -293,6 +318,8 @@ def test_small_projections():
         X = rnd(rows, C, g=g); W2 = rnd(J, C, g=g); b2 = rnd(J, g=g)
         close(ops.rowdot(X.to(dev), W2.to(dev), b2.to(dev)), X @ W2.t() + b2, what="rowdot")
         close(ops.rowdot(X.to(dev), W2.to(dev), b2.to(dev), softmax=True), torch.softmax(X @ W2.t() + b2, -1), what="rowdot softmax")
+        Zs, lab = ops.rowdot(X.to(dev), W2.to(dev), b2.to(dev), softmax=True, want_label=True)
+        assert torch.equal(lab.cpu().long(), torch.sort(Zs.cpu(), dim=-1, descending=True, stable=True)[1][..., 0]), "rowdot label = first argmax"
         out0 = torch.zeros(C, J, device=dev); out1 = torch.zeros(J, C, device=dev)
         cs = torch.zeros(C, device=dev); asum = torch.zeros(J, device=dev)
         ops.rowouter(a.to(dev), lda, J, X.to(dev), out0, 0, csum=cs, asum=asum, mask=mask.to(dev), fill=-1.5)
@@ -398,3 +425,60 @@ def test_clip_adam_matches_torch():
         ops.clip_adam(p, gr.to(dev), m, v, nA, nB, hy.to(dev), stats)
         ref = torch.cat([pa.detach(), pb.detach(), p0[nA + nB:]])
         close(p, ref, tol=2e-6, what="adam step %d" % step)
+
+
+def test_pool_jobs_mixed_table():
+    """gptst_pool_jobs: problems of all three kinds, each with its own embedding / shape, in one call (60 jobs -> 2 launches)."""
+    from gptst_amd import ops
+    dev = _dev()
+    g = torch.Generator().manual_seed(11)
+    J = ops.PoolJobs()
+    checks = []
+    shapes = [(384, 16, 4096), (170, 16, 64), (32, 4, 1920), (384, 4, 1700), (24, 8, 70), (1, 1, 4160), (207, 16, 2070), (5, 3, 7)]
+    for rep in range(3):
+        for (R, K, cols) in shapes:
+            emb, pool = rnd(R, K, g=g), rnd(K, cols, g=g)
+            out = J.fwd(emb.to(dev), pool.to(dev))
+            checks.append((out, emb @ pool, "fwd %s" % ((R, K, cols),)))
+            for ns in ((1, 3) if rep == 0 else (1,)):
+                dW = rnd(ns * R, cols, g=g)
+                dpool = rnd(K, cols, g=g)
+                dp = dpool.to(dev)
+                J.bwd_pool(emb.to(dev), dW.to(dev), dp, nsplit=ns)
+                checks.append((dp, dpool + emb.t() @ dW.view(ns, R, cols).sum(0), "bwd_pool %s ns=%d" % ((R, K, cols), ns)))
+                demb = rnd(R, K, g=g)
+                de = demb.to(dev)
+                J.bwd_emb(dW.to(dev), pool.to(dev), de, nsplit=ns)
+                J.bwd_emb(dW.to(dev), pool.to(dev), de, nsplit=ns)                       # two jobs add into one demb
+                checks.append((de, demb + 2 * dW.view(ns, R, cols).sum(0) @ pool.t(), "bwd_emb %s ns=%d" % ((R, K, cols), ns)))
+    assert len(J.jobs) > 96
+    J.launch()
+    for got, ref, what in checks:
+        close(got, ref, tol=2e-4, what=what)
+
+
+def test_timefeat_jobs_equal_single_launches():
+    from gptst_amd import ops
+    dev = _dev()
+    g = torch.Generator().manual_seed(3)
+    B, T = 5, 12
+    tidx = rnd(B, T, 2, g=g).to(dev)
+
+    def params(E, K):
+        return [t.to(dev) for t in (rnd(E, K, g=g), rnd(E, g=g), rnd(E, K, g=g), rnd(E, g=g), rnd(E, E, g=g), rnd(E, g=g), rnd(E, E, g=g),
+                                    rnd(E, g=g), rnd(E, E, g=g), rnd(E, g=g))]
+    jobs = [(params(16, 1), B * T, 1), (params(4, 1), B * T, 1), (params(4, 12), B, 12), (params(8, 1), B * T, 1), (params(2, 12), B, 12)]
+    outs = ops.timefeat_jobs_fwd(jobs, tidx)
+    bj = []
+    for (pp, rows, K), o in zip(jobs, outs):
+        ref = ops.timefeat_fwd(pp, tidx, rows, K)
+        assert torch.equal(o, ref)
+        go = rnd(rows, pp[1].numel(), g=g).to(dev)
+        g1 = [torch.zeros_like(t) for t in pp]
+        ops.timefeat_bwd(pp, g1, tidx, go, rows, K)
+        g2 = [torch.zeros_like(t) for t in pp]
+        bj.append((pp, g2, go, rows, K, g1))
+    ops.timefeat_jobs_bwd([j[:5] for j in bj], tidx)
+    for pp, g2, go, rows, K, g1 in bj:
+        for a, b in zip(g1, g2):
+            close(b, a.cpu(), tol=1e-5, what="timefeat_jobs bwd")

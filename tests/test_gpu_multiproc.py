@@ -29,3 +29,42 @@ def test_bench_two_ranks(extra, scaling, par):
     assert out["n_gpus"] == 2 and out["scaling"] == scaling and out["config"]["parallelism"] == par
     assert out["value"] > 0 and out["steps"] == 4 and out["higher_is_better"] is True
     assert out["last_loss"] == out["last_loss"] and out["last_loss"] > 0          # finite
+
+
+def _run_plain(args, env_extra, timeout=900):
+    """`python bench.py ...` with NO launcher and no WORLD_SIZE in the environment (the shape of the driver's N = 1 command)."""
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    env.update(env_extra)
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py")] + args, cwd=ROOT, env=env, capture_output=True, text=True,
+                       timeout=timeout)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, r.stdout[-2000:]
+    return json.loads(lines[0])
+
+
+def test_bench_self_launch_two_ranks():
+    """`python bench.py --gpus 2` spawns its two ranks itself (torch.distributed.run on 127.0.0.1) and still prints ONE JSON line."""
+    out = _run_plain(["--gpus", "2", "--steps", "4", "--warmup", "1", "--batch", "4"], dict(GPTST_DIST_BACKEND="gloo"))
+    assert out["n_gpus"] == 2 and out["scaling"] == "weak" and out["config"]["parallelism"] == "dp2" and out["value"] > 0
+
+
+def test_bench_strong_scaling_splits_global_batch():
+    out = _run_plain(["--gpus", "2", "--steps", "4", "--warmup", "1", "--scaling", "strong", "--global-batch", "8"],
+                     dict(GPTST_DIST_BACKEND="gloo"))
+    assert out["scaling"] == "strong" and out["config"]["global_batch"] == 8 and "B=4 " in out["config"]["workload"]
+    assert abs(out["value"] - out["optimizer_steps_per_s"] * 8 / 32.0) < 1e-6 * out["value"]
+
+
+def test_bench_rccl_backend():
+    """The RCCL ("nccl") process group, all-reduce of [gradient | statistics], label all-gather and count all-reduce on real
+    hardware: two ranks when the box has two GPUs, otherwise ONE rank forced through the data-parallel path."""
+    import torch
+    if torch.cuda.device_count() >= 2:
+        out = _run_plain(["--gpus", "2", "--steps", "6", "--warmup", "2", "--batch", "4"], {})
+        assert out["n_gpus"] == 2
+    else:
+        out = _run_plain(["--gpus", "1", "--steps", "6", "--warmup", "2", "--batch", "4", "--no-cpu-baseline", "--no-kernel-timing"],
+                         dict(GPTST_FORCE_DP="1", GPTST_DIST_BACKEND="nccl"))
+        assert out["n_gpus"] == 1
+    assert out["value"] > 0 and out["last_loss"] == out["last_loss"] and out["last_loss"] > 0

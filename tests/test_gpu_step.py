@@ -171,3 +171,42 @@ def test_dp_global_mask_equals_single_process_global_batch(use_graph):
                 sr.step(src_g[r * Bl:(r + 1) * Bl].contiguous(), epoch, noise=n0, noise_a=na, noise_r=nr, list_c=list_c)
                 torch.cuda.synchronize()
                 assert torch.equal(sr.last_mask, mask_ref[r * M:(r + 1) * M]), (epoch, r)
+
+
+@pytest.mark.parametrize("use_graph", [False, True])
+def test_unsynced_queue_equals_synced_steps(use_graph):
+    """50 steps enqueued back to back with NO host sync (what bench.py does) must see the same per-step host scalars (Adam bias
+    corrections, class order, mask budgets) on the device as 50 steps with a sync after each: the pinned host slots are a ring
+    guarded by events — a single reused pinned buffer is overwritten before its H2D copy has run (ADVICE r1, step.py)."""
+    from gptst_amd.model import GPTST_Model
+    from gptst_amd.step import PretrainStep
+    args = _args()
+    sd = O.init_state_dict(args, 2)
+    src = synth.make_batch(4, 12, 20, 1, seed=77).to(DEV)
+    M = 4 * 12 * 20
+    noise = [synth.make_noise(M, 100 + i).to(DEV) for i in range(50)]
+    noise_r = [synth.make_noise(M, 200 + i).to(DEV) for i in range(50)]
+    orders = [synth.class_order(5, 300 + i) for i in range(50)]
+    outs = []
+    for sync in (True, False):
+        model = GPTST_Model(args); model.load_state_dict(sd); model = model.to(DEV)
+        st = PretrainStep(model, args, synth.SCALER_MEAN, synth.SCALER_STD, batch_size=4, use_graph=use_graph)
+        seen = []
+        for i in range(50):
+            epoch = 1 + (i * 29) // 50                      # crosses change_epoch = 3 -> both phases, tB lags tA
+            if epoch <= args.change_epoch:
+                st.step(src, epoch, noise=noise[i])
+            else:
+                st.step(src, epoch, noise_a=noise[i], noise_r=noise_r[i], list_c=orders[i])
+            seen.append((st.hyper.clone(), st.ctrl.clone()))        # stream-ordered snapshots of what step i ran with
+            if sync:
+                torch.cuda.synchronize()
+        torch.cuda.synchronize()
+        outs.append((seen, model.flat.clone()))
+    for i, ((h0, c0), (h1, c1)) in enumerate(zip(outs[0][0], outs[1][0])):
+        assert torch.equal(h0, h1), "step %d ran with another step's Adam bias corrections" % i
+        assert torch.equal(c0, c1), "step %d ran with another step's class order / mask budgets" % i
+    # float atomics make two runs differ at round-off level (amplified over 50 Adam steps, argmax flips of the guide included);
+    # a stale bias correction moves every parameter by O(lr) per step instead
+    rel = float((outs[0][1] - outs[1][1]).norm() / outs[0][1].norm().clamp_min(1e-12))
+    assert rel < 0.2, rel

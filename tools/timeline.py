@@ -1,0 +1,37 @@
+#!/usr/bin/env python
+"""Timeline of ONE step from a rocprofv3 rocpd sqlite database (kernel-trace): per-kernel start offset, duration, and the gap
+to the previous kernel on the same queue, for the last complete step of the run (steps are delimited by `marker` kernel name,
+default adam_kernel).  usage: python tools/timeline.py results.db [marker] [which_from_end] > gpurun_out/timeline.txt"""
+import re
+import sqlite3
+import sys
+
+db = sqlite3.connect(sys.argv[1])
+marker = sys.argv[2] if len(sys.argv) > 2 else "adam_kernel"
+which = int(sys.argv[3]) if len(sys.argv) > 3 else 3
+cols = [r[1] for r in db.execute("pragma table_info(kernels)")]
+print("# columns:", cols)
+name_c = "name" if "name" in cols else "kernel_name"
+qc = "queue_id" if "queue_id" in cols else ("queue" if "queue" in cols else None)
+sc = "stream_id" if "stream_id" in cols else None
+sel = "select %s, grid_x, grid_y, workgroup_x, start, end%s%s from kernels order by start" % (
+    name_c, (", " + qc) if qc else "", (", " + sc) if sc else "")
+rows = db.execute(sel).fetchall()
+ends = [i for i, r in enumerate(rows) if marker in r[0]]
+if len(ends) < which + 1:
+    print("not enough steps", len(ends)); sys.exit(0)
+i0, i1 = ends[-which - 1] + 1, ends[-which] + 1
+step = rows[i0:i1]
+t0 = step[0][4]
+print("# step: %d kernels, span %.1f us" % (len(step), (step[-1][5] - t0) / 1e3))
+last_end = {}
+busy = {}
+for r in step:
+    n = re.sub(r"\(.*$", "", r[0])[:44]
+    q = r[6] if qc else 0
+    s = r[7] if (qc and sc) else (r[6] if sc else 0)
+    gap = (r[4] - last_end[q]) / 1e3 if q in last_end else 0.0
+    last_end[q] = r[5]
+    busy[q] = busy.get(q, 0.0) + (r[5] - r[4]) / 1e3
+    print("%9.1f %7.1f gap %6.1f q%-3s s%-3s %s [%d,%d]" % ((r[4] - t0) / 1e3, (r[5] - r[4]) / 1e3, gap, q, s, n, r[1] // max(r[3], 1), r[2]))
+print("# busy us per queue:", {k: round(v, 1) for k, v in busy.items()})
