@@ -57,13 +57,22 @@ def main():
         rank draws the same permutation and takes every world-th batch (all ranks see the same number of equally sized batches)."""
         full = train.n // args.batch_size                                        # batches of the full size
         usable = full if dp is None else (full // dp.world) * dp.world           # DP: whole groups of `world` full batches
-        for i, (x, _) in enumerate(train):
+        for i, x in enumerate(train.iter_x()):
             if dp is None:
                 yield x.contiguous()                                             # incl. the ragged last batch
             elif i < usable and i % dp.world == dp.rank:
                 yield x.contiguous()
 
-    Trainer(model, args, batches, mean, std, args.batch_size, dp=dp).train()
+    full = train.n // args.batch_size
+    nb = len(train) if dp is None else full // dp.world
+    if dp is not None and dp.rank == 0 and len(train) != nb * dp.world:
+        print("gpt-st_amd: data parallel over %d ranks drops %d of %d batches per epoch (ragged tail / incomplete group)"
+              % (dp.world, len(train) - nb * dp.world, len(train)))
+    Trainer(model, args, batches, mean, std, args.batch_size, dp=dp, batches_per_epoch=nb).train()
+    if dp is not None:
+        import torch.distributed as dist
+        dp.barrier()
+        dist.destroy_process_group()
 
 
 if __name__ == "__main__":

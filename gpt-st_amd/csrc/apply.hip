@@ -10,11 +10,16 @@
 //   mode 1 (NODE)   g = n,     rows m = (b,t)  : row = m*N + g          (node-conditioned weights, cap / MLP_RL)
 //   mode 2 (SHARED) one group, rows = all                                (nn.Linear)
 #include "mfma_tile.h"
-__device__ long long g_ap_ts[64];     // debug: per-phase s_memtime stamps (enabled by gptst_ap_dbg(1))
-int g_ap_dbg = 0;
-int g_apply_tpw = 0;                                   // experiments: gptst_tune(4, n) forces tiles per wave of apply64
+#ifdef GPTST_DEBUG
+__device__ long long g_ap_ts[64];     // per-phase s_memtime stamps (enabled by gptst_ap_dbg(1))
+static thread_local int g_ap_dbg = 0;
 extern "C" int gptst_ap_dbg(int v) { g_ap_dbg = v; return 0; }
 extern "C" int gptst_ap_ts(long long* out) { return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_ap_ts), sizeof(long long) * 64); }
+#else
+static constexpr int g_ap_dbg = 0;
+#endif
+// launch-geometry knobs of gptst_tune: thread-local (ranks emulated by threads must not see each other's experiments)
+thread_local int g_apply_tpw = 0;                      // gptst_tune(4, n) forces tiles per wave of apply64
 
 enum { PRO_NONE = 0, PRO_DPRE = 1 };          // PRO_DPRE: a = A * lrelu'(A2)   (A = dOut, A2 = layer output)
 enum { EPI_PLAIN = 0, EPI_RES_LRELU = 1, EPI_ADD_DPRE = 2, EPI_LRELU = 3 };   // 1: lrelu(acc+bias+resid)  2: acc + resid*lrelu'(resid2)  3: lrelu(acc+bias)
@@ -39,7 +44,11 @@ __global__ __launch_bounds__(256) void apply_kernel(const float* __restrict__ A,
                                                     const float* __restrict__ resid2, float* __restrict__ out, float* __restrict__ colsum, RowMap rm, int dbg) {
     using T = Tile<C>;
     int tsi = 0;
+#ifdef GPTST_DEBUG
 #define TS() do { if (dbg && blockIdx.x == 100 && blockIdx.y == 0 && threadIdx.x == 0) g_ap_ts[tsi] = clock64(); ++tsi; } while (0)
+#else
+#define TS() do { } while (0)
+#endif
     TS();
     extern __shared__ __attribute__((aligned(16))) float smem[];
     float* Wl = smem;                                   // C*C
@@ -233,6 +242,7 @@ __global__ __launch_bounds__(256, 2) void apply64_kernel(const float* __restrict
             if (EPI == EPI_ADD_DPRE) rv2[r] = ld4(resid2 + orow[r]);
         }
         if (t + 1 < t1) fetch(t + 1);
+        SB();
         f32x4 acc[4];
 #pragma unroll
         for (int ct = 0; ct < 4; ++ct) acc[ct] = (f32x4){0.f, 0.f, 0.f, 0.f};
@@ -247,6 +257,7 @@ __global__ __launch_bounds__(256, 2) void apply64_kernel(const float* __restrict
                 acc[3] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[e], bv[q][e].w, acc[3], 0, 0, 0);
             }
         }
+        SB();
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
             if (t * 16 + kk * 4 + r < rm.M) {
@@ -330,7 +341,9 @@ __global__ __launch_bounds__(256, 2) void wgrad64_kernel(const float* __restrict
         for (int cb = 0; cb < 4; ++cb) acc[ca][cb] = (f32x4){0.f, 0.f, 0.f, 0.f};
     float4 sa = f4zero();
     // U = k-steps (of 4 rows) per batch of loads (2-3 float4 per step in flight per lane); the launcher picks 4 or 6 so that the
-    // wave's step count divides evenly (measured: TIME 11 steps 13.5 us either way, NODE 6 steps 13.7 vs 16.8, SHARED 16 steps 10.5 vs 13.0)
+    // wave's step count divides evenly (measured: TIME 11 steps 13.5 us either way, NODE 6 steps 13.7 vs 16.8, SHARED 16 steps 10.5 vs 13.0).
+    // The scheduler fence keeps the whole batch of loads ahead of the MFMA block (18.0 -> 15.1 us on the TIME weight gradient); a
+    // ping-pong pair of register buffers (loads of batch i+1 behind the MFMAs of batch i) was slower again: 251 VGPRs, 15.9 us.
     for (int m0 = mbeg; m0 < mend; m0 += 4 * U) {
         float4 a[U], d[U], y[U];
 #pragma unroll
@@ -340,6 +353,7 @@ __global__ __launch_bounds__(256, 2) void wgrad64_kernel(const float* __restrict
             a[u] = ld4(A + off); d[u] = ld4(D + off);
             if (PRO == PRO_DPRE) y[u] = ld4(D2 + off);
         }
+        SB();
 #pragma unroll
         for (int u = 0; u < U; ++u) {
             if (m0 + 4 * u + kk >= mend) a[u] = f4zero();
@@ -453,7 +467,7 @@ static int launch_apply(const float* A, const float* A2, const float* W, long w_
 }
 
 static int g_smem_attr_done = 0;
-int g_apply_v1 = 0;                                    // experiments: gptst_tune(3, 1) selects the LDS-staged apply_kernel for C = 64
+thread_local int g_apply_v1 = 0;                                    // experiments: gptst_tune(3, 1) selects the LDS-staged apply_kernel for C = 64
 template <int C>
 static void raise_smem_limits() {
     const int smem = (int)((C * C + 4 * Tile<C>::TILE_FLOATS) * sizeof(float));
@@ -482,8 +496,8 @@ extern "C" int gptst_apply(const float* A, const float* A2, const float* W, int 
 }
 
 // dW has room for nsplit * G matrices; returns nsplit through *nsplit_out (consumers sum the splits).
-int g_wgrad_ns0_override = 0;
-int g_wgrad_ns_override = 0;                           // experiments: gptst_tune(2, ns) forces the NODE-mode split
+thread_local int g_wgrad_ns0_override = 0;
+thread_local int g_wgrad_ns_override = 0;                           // experiments: gptst_tune(2, ns) forces the NODE-mode split
 extern "C" int gptst_wgrad_nsplit(int mode, int BT, int N) {
     RowMap rm = make_rowmap(mode, BT, N);
     if (mode == 2) return (rm.M + 255) / 256;          // shared weight: 256-row chunks

@@ -308,7 +308,7 @@ static int launch_route_fwd(const float* X, const float* Wp, const float* bp, co
 }
 
 // first-generation (VALU contractions) forward: kept as the fallback for shapes the MFMA version rejects (HS > 64)
-extern "C" int gptst_cap_route_fwd_v1(const float* X, const float* Wp, const float* bp, const float* dadj, float* c_out, float* s_out,
+GPTST_INTERNAL int gptst_cap_route_fwd_v1(const float* X, const float* Wp, const float* bp, const float* dadj, float* c_out, float* s_out,
                                       int BT, int N, int C, int HS, int R, void* stream) {
     if (!X || !Wp || !bp || !dadj || !c_out || !s_out || HS <= 0 || R < 0) return GPTST_EARG;
     if (C == 64) return launch_route_fwd<64>(X, Wp, bp, dadj, c_out, s_out, BT, N, HS, R, (hipStream_t)stream);
@@ -343,7 +343,7 @@ extern "C" int gptst_cap_rec_fwd(const float* c, const float* v, float* rec, int
     return GPTST_ESHAPE;
 }
 
-extern "C" int gptst_cap_rec_bwd_v1(const float* drec, const float* c, const float* v, float* dc1, float* dv, int BT, int N, int C,
+GPTST_INTERNAL int gptst_cap_rec_bwd_v1(const float* drec, const float* c, const float* v, float* dc1, float* dv, int BT, int N, int C,
                                  int HS, void* stream) {
     if (!drec || !c || !v || !dc1 || !dv) return GPTST_EARG;
     if (C == 64) return launch_rec<64>(c, v, nullptr, drec, dc1, dv, BT, N, HS, (hipStream_t)stream);
@@ -365,7 +365,7 @@ static int launch_route_bwd(const float* X, const float* Wp, const float* bp, co
     return GPTST_OK;
 }
 
-extern "C" int gptst_cap_route_bwd_v1(const float* X, const float* Wp, const float* bp, const float* c, const float* dc1,
+GPTST_INTERNAL int gptst_cap_route_bwd_v1(const float* X, const float* Wp, const float* bp, const float* c, const float* dc1,
                                    const float* dS, float* dY, float* dlogit, int BT, int N, int C, int HS, void* stream) {
     if (!X || !Wp || !bp || !c || !dc1 || !dS || !dY || !dlogit) return GPTST_EARG;
     if (C == 64) return launch_route_bwd<64>(X, Wp, bp, c, dc1, dS, dY, dlogit, BT, N, HS, (hipStream_t)stream);

@@ -9,10 +9,14 @@
 // both took ~90 us: every phase was a serial latency chain (ds_add_f32 with 8-way bank conflicts, one thread per node doing
 // 30 dependent LDS round trips, 2 waves per SIMD).  LDS at N=170, HS=10, C=64: 78.7 KB -> two workgroups per CU.
 #include "mfma_tile.h"
-__device__ long long g_cap_ts[64];     // debug: per-phase s_memtime stamps of workgroup 5 (enabled by gptst_tune2(99))
-int g_cap_dbg = 0;
+#ifdef GPTST_DEBUG
+__device__ long long g_cap_ts[64];     // per-phase s_memtime stamps of workgroup 5 (enabled by gptst_tune2(99))
+static thread_local int g_cap_dbg = 0;
 extern "C" int gptst_tune2(int v) { g_cap_dbg = v; return 0; }
 extern "C" int gptst_cap_ts(long long* out) { return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_cap_ts), sizeof(long long) * 64); }
+#else
+static constexpr int g_cap_dbg = 0;
+#endif
 
 #define CM_NT 512
 #define CM_NW (CM_NT / 64)
@@ -204,7 +208,11 @@ __global__ __launch_bounds__(CM_NT, 4) void cap_route_fwd2_kernel(const float* _
     using T = Tile<C>;
     constexpr int P = T::PITCH, LPR = C / 4, RPP = CM_NT / LPR;
     int tsi = 0;
+#ifdef GPTST_DEBUG
 #define TS() do { if (dbg == 99 && blockIdx.x == 5 && threadIdx.x == 0) g_cap_ts[tsi] = clock64(); ++tsi; } while (0)
+#else
+#define TS() SB()
+#endif
     TS();
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const int NR = cm_rows(N), NP = cm_np(N), HSP = cm_hsp(HS);
@@ -357,7 +365,7 @@ static int launch_route_fwd2(const float* X, const float* Wp, const float* bp, c
     return GPTST_OK;
 }
 
-extern "C" int gptst_cap_route_fwd_v1(const float* X, const float* Wp, const float* bp, const float* dadj, float* c_out, float* s_out,
+GPTST_INTERNAL int gptst_cap_route_fwd_v1(const float* X, const float* Wp, const float* bp, const float* dadj, float* c_out, float* s_out,
                                       int BT, int N, int C, int HS, int R, void* stream);
 
 extern "C" int gptst_cap_route_fwd(const float* X, const float* Wp, const float* bp, const float* dadj, float* c_out, float* s_out,
@@ -370,7 +378,8 @@ extern "C" int gptst_cap_route_fwd(const float* X, const float* Wp, const float*
     return rc;
 }
 
-// debug: resident workgroups per CU of the forward kernel at a given shape
+#ifdef GPTST_DEBUG
+// resident workgroups per CU of the forward kernel at a given shape
 extern "C" int gptst_cap_occupancy(int N, int HS) {
     constexpr int C = 64;
     const int NR = cm_rows(N), NP = cm_np(N), HSP = cm_hsp(HS);
@@ -383,6 +392,7 @@ extern "C" int gptst_cap_occupancy(int N, int HS) {
     hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, (const void*)cap_route_fwd2_kernel<C, 2, 8>, CM_NT, smem);
     return n * 1000000 + (int)smem;
 }
+#endif
 
 // =====================================================================================================================
 // backward through s = c.P, c = softmax_h(b + dadj), P = squash(X Wp^T + bp)   (routing logits b are detached, GPTST.py:108-109)
@@ -619,7 +629,7 @@ static int launch_route_bwd2(const float* X, const float* Wp, const float* bp, c
     return GPTST_OK;
 }
 
-extern "C" int gptst_cap_route_bwd_v1(const float* X, const float* Wp, const float* bp, const float* c, const float* dc1,
+GPTST_INTERNAL int gptst_cap_route_bwd_v1(const float* X, const float* Wp, const float* bp, const float* c, const float* dc1,
                                       const float* dS, float* dY, float* dlogit, int BT, int N, int C, int HS, void* stream);
 
 extern "C" int gptst_cap_route_bwd(const float* X, const float* Wp, const float* bp, const float* c, const float* dc1,
@@ -665,7 +675,7 @@ __global__ __launch_bounds__(CM_NT, 4) void cap_rec_bwd2_kernel(const float* __r
     for (int i = tid; i < HS * LPR; i += CM_NT) st4(dv + (size_t)bt * HS * C + 4 * i, ld4(S + (i / LPR) * C + 4 * (i % LPR)));
 }
 
-extern "C" int gptst_cap_rec_bwd_v1(const float* drec, const float* c, const float* v, float* dc1, float* dv, int BT, int N, int C,
+GPTST_INTERNAL int gptst_cap_rec_bwd_v1(const float* drec, const float* c, const float* v, float* dc1, float* dv, int BT, int N, int C,
                                     int HS, void* stream);
 
 extern "C" int gptst_cap_rec_bwd(const float* drec, const float* c, const float* v, float* dc1, float* dv, int BT, int N, int C, int HS,

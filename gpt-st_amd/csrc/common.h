@@ -11,6 +11,11 @@
 
 #define LRELU_SLOPE 0.01f
 
+// cross-file helpers that are not part of the C ABI (include/gptst_hip.h): C linkage for the linker, hidden from the .so's exports
+#define GPTST_INTERNAL extern "C" __attribute__((visibility("hidden")))
+// In-kernel s_memtime stamps, phase-ablation flags and the entry points that drive them exist only in -DGPTST_DEBUG builds
+// (GPTST_EXTRA_HIPCC_FLAGS=-DGPTST_DEBUG python -m gptst_amd.build --force): the product library carries none of them.
+
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
@@ -19,6 +24,14 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
         hipError_t e__ = hipGetLastError();                   \
         if (e__ != hipSuccess) return (int)e__;               \
     } while (0)
+
+// Phase fence for the machine scheduler: instructions are not moved across it.  The kernels are written as explicit phases (batch
+// of global loads -> LDS / MFMA -> prefetch of the next tile -> stores) and lose 10-40 % when the compiler re-interleaves them.
+#ifdef GPTST_NO_SB
+#define SB() do { } while (0)
+#else
+#define SB() __builtin_amdgcn_sched_barrier(0)
+#endif
 
 __device__ __forceinline__ float lrelu(float x) { return x > 0.f ? x : LRELU_SLOPE * x; }
 // derivative selected by the sign of the OUTPUT (slope > 0 keeps the sign; x == 0 -> slope, as ATen).

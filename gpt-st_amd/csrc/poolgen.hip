@@ -111,6 +111,7 @@ __device__ __forceinline__ void pj_bwd_pool(const PJob& a, int bx, float (*fold)
             av[u] = emb[(size_t)(row % R) * K + min(j, K - 1)];
             b[u] = ldv<V>(dW + (size_t)row * cols + cl);
         }
+        SB();
 #pragma unroll
         for (int u = 0; u < NU; ++u) {
             const float a_ = (rb + 4 * u + kk < r1 && j < K) ? av[u] : 0.f;
@@ -175,6 +176,7 @@ __device__ __forceinline__ void pj_bwd_emb(const PJob& a, int bx, int by) {
                     av[u] = f4add(av[u], ld4(w + ((size_t)s * R + rowc) * cc + c));
                 }
             }
+            SB();
 #pragma unroll
             for (int u = 0; u < UC; ++u) {
                 const bool ok = c0 + 16 * u + 4 * kk < cend;
@@ -216,7 +218,7 @@ __global__ __launch_bounds__(256) void pool_jobs_kernel(PJobs t, int fwd_rows) {
 }
 
 // Host side: fill one job and its block range; returns the number of blocks.
-int g_pg_rows = PG_ROWS;            // experiments: gptst_tune(1, rows)
+thread_local int g_pg_rows = PG_ROWS;            // experiments: gptst_tune(1, rows)
 static int pj_blocks(PJob& j) {
     const int V = (j.cols & 3) ? 1 : 4;
     if (j.kind == PJ_FWD) { j.nbx = ((j.cols + V - 1) / V + 255) / 256; return j.nbx * ((j.R + g_pg_rows - 1) / g_pg_rows); }
@@ -262,10 +264,10 @@ extern "C" int gptst_pool_jobs(int njobs, const int* kind, const void* const* em
     return GPTST_OK;
 }
 
-extern int g_wgrad_ns_override;
-extern int g_wgrad_ns0_override;
-extern int g_apply_v1;
-extern int g_apply_tpw;
+extern thread_local int g_wgrad_ns_override;
+extern thread_local int g_wgrad_ns0_override;
+extern thread_local int g_apply_v1;
+extern thread_local int g_apply_tpw;
 extern "C" int gptst_tune(int id, int value) {
     if (id == 1 && value > 0 && value <= PG_MAXROWS) g_pg_rows = value;
     if (id == 2) g_wgrad_ns_override = value;

@@ -1,0 +1,171 @@
+// Fused "thin head" kernels at the two places where the loss meets the network — one pass over the C-wide activation each,
+// replacing chains of 4-6 small launches:
+//
+//   mae tail  (reference GPTST.py:455 dim_flow_out, Run.py:92-100 scaler_mae_loss, lib/metrics.py:11-18 and their autograd backward)
+//       out = dec W^T + b;  p = (out s + m) M, y = (label s + m) M, keep = y > thresh;  stats += (sum_keep |y-p|, #keep);
+//       a = sign(p-y) M s [keep]  (gradient of the SUM loss: the 1/#keep of the mean is applied by the optimiser, hyper[9] = 1);
+//       d_dec = a W;  partial (gW, gb) = (a^T dec, sum a)                    was rowdot, mae_fwd, mae_bwd, lin_in, rowouter x2
+//   kl head   (reference BasicTrainer.py:85 0.1 KLDivLoss(sum)(log prob, eb), softmax + MLP_RL.ln3 GPTST.py:33 backward)
+//       a = w (prob sum_h eb - eb);  stats[2] += sum eb (log eb - log prob);  d_h2 = a W3;  partial (gW3, gb3) = (a^T h2, sum a)
+//                                                                          was kl, lin_in, rowouter x2
+// Layout as small.hip: C/4 lanes per row (float4 columns), 16 row slots per workgroup; TL_NB persistent workgroups walk contiguous
+// row chunks, keep the weight-gradient partials in registers and fold them through LDS once at the end: part[blk][J*C + J]
+// (the caller sums the TL_NB partials into [gW | gb] with one bwd_pool job).  C = 64, J <= TL_MAXJ; other shapes use the unfused ops.
+#include "common.h"
+
+#define TL_NB 512
+#define TL_MAXJ 16
+
+struct TailArgs {
+    const float* X; const float* W; const float* b; float* dX; float* part; float* stats;
+    int rows, J, rows_per_block;
+    // mae tail
+    const float* src; const float* mask; float* out; int lda; float sigma, mu, thresh;
+    // kl head
+    const float* prob; const float* c; int N; float w;
+};
+
+template <int KIND>      // 0: mae tail, 1: kl head
+__global__ __launch_bounds__(256) void tail_kernel(TailArgs t) {
+    constexpr int C = 64, LPR = C / 4, RPB = 256 / LPR;
+    __shared__ __attribute__((aligned(16))) float Ws[TL_MAXJ * C];
+    __shared__ float4 red[RPB][LPR];
+    __shared__ float redb[RPB];
+    __shared__ float reds[3][4];
+    const int J = t.J;
+    for (int i = threadIdx.x; i < J * C / 4; i += 256) st4(Ws + 4 * i, ld4(t.W + 4 * i));
+    __syncthreads();
+    const int c4 = threadIdx.x % LPR, slot = threadIdx.x / LPR;
+    const size_t r0 = (size_t)blockIdx.x * t.rows_per_block;
+    const size_t r1 = min((size_t)t.rows, r0 + t.rows_per_block);
+    float4 accW[TL_MAXJ];
+    float accb[TL_MAXJ];
+#pragma unroll
+    for (int j = 0; j < TL_MAXJ; ++j) { accW[j] = f4zero(); accb[j] = 0.f; }
+    float s0 = 0.f, s1 = 0.f;                                         // mae: sum |y-p|, count;  kl: sum, -
+    constexpr int UR = 4;                                             // independent rows in flight per thread
+    for (size_t i0 = r0 + slot; i0 < r1; i0 += UR * RPB) {
+      float4 xs[UR];
+#pragma unroll
+      for (int u = 0; u < UR; ++u) { const size_t i = i0 + (size_t)u * RPB; xs[u] = i < r1 ? ld4(t.X + i * C + 4 * c4) : f4zero(); }
+      SB();
+#pragma unroll
+      for (int u = 0; u < UR; ++u) {
+        const size_t i = i0 + (size_t)u * RPB;
+        if (i >= r1) continue;                                        // uniform per 16-lane row group; no barrier inside
+        const float4 x = xs[u];
+        float a[TL_MAXJ];
+        if (KIND == 0) {
+#pragma unroll
+            for (int j = 0; j < TL_MAXJ; ++j) {
+                a[j] = 0.f;
+                if (j < J) {                                          // uniform
+                    const float o = group_sum<LPR>(f4dot(x, ld4(Ws + j * C + 4 * c4))) + (t.b ? t.b[j] : 0.f);
+                    const size_t e = i * J + j;
+                    const float M = 1.f - t.mask[e];
+                    const float p = (o * t.sigma + t.mu) * M;
+                    const float y = (t.src[i * t.lda + j] * t.sigma + t.mu) * M;
+                    if (y > t.thresh) {
+                        const float d = p - y;
+                        if (c4 == 0) { s0 += fabsf(d); s1 += 1.f; }
+                        a[j] = (d > 0.f ? 1.f : (d < 0.f ? -1.f : 0.f)) * M * t.sigma;
+                    }
+                    if (c4 == 0) t.out[e] = o;
+                }
+            }
+        } else {
+            const size_t bt = i / t.N, n = i % t.N;
+            const float* cp = t.c + bt * J * t.N + n;
+            float se = 0.f, e_[TL_MAXJ], p_[TL_MAXJ];
+#pragma unroll
+            for (int j = 0; j < TL_MAXJ; ++j) {
+                e_[j] = 0.f; p_[j] = 1.f;
+                if (j < J) { e_[j] = cp[(size_t)j * t.N]; p_[j] = t.prob[i * J + j]; }
+            }
+#pragma unroll
+            for (int j = 0; j < TL_MAXJ; ++j)
+                if (j < J) {
+                    se += e_[j];
+                    if (c4 == 0 && e_[j] > 0.f) s0 += e_[j] * (logf(e_[j]) - logf(p_[j]));
+                }
+#pragma unroll
+            for (int j = 0; j < TL_MAXJ; ++j) a[j] = j < J ? t.w * (p_[j] * se - e_[j]) : 0.f;
+        }
+        float4 dx = f4zero();
+#pragma unroll
+        for (int j = 0; j < TL_MAXJ; ++j)
+            if (j < J) {
+                dx = f4fma(a[j], ld4(Ws + j * C + 4 * c4), dx);
+                accW[j] = f4fma(a[j], x, accW[j]);
+                accb[j] += a[j];
+            }
+        st4(t.dX + i * C + 4 * c4, dx);
+      }
+    }
+    // ---- fold the 16 row slots of the workgroup, then the loss statistics ----
+    float* mine = t.part + (size_t)blockIdx.x * (J * C + J);
+#pragma unroll
+    for (int j = 0; j < TL_MAXJ; ++j) {
+        if (j >= J) continue;                                         // uniform
+        red[slot][c4] = accW[j];
+        if (c4 == 0) redb[slot] = accb[j];
+        __syncthreads();
+        if (slot == 0) {
+            float4 s = red[0][c4];
+            for (int q = 1; q < RPB; ++q) s = f4add(s, red[q][c4]);
+            st4(mine + j * C + 4 * c4, s);
+            if (c4 == 0) {
+                float sb = redb[0];
+                for (int q = 1; q < RPB; ++q) sb += redb[q];
+                mine[J * C + j] = sb;
+            }
+        }
+        __syncthreads();
+    }
+    s0 = group_sum<64>(s0); s1 = group_sum<64>(s1);
+    if ((threadIdx.x & 63) == 0) { reds[0][threadIdx.x >> 6] = s0; reds[1][threadIdx.x >> 6] = s1; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        if (KIND == 0) {
+            atomicAdd(t.stats + 0, reds[0][0] + reds[0][1] + reds[0][2] + reds[0][3]);
+            atomicAdd(t.stats + 1, reds[1][0] + reds[1][1] + reds[1][2] + reds[1][3]);
+        } else {
+            atomicAdd(t.stats + 2, reds[0][0] + reds[0][1] + reds[0][2] + reds[0][3]);
+        }
+    }
+}
+
+static void tl_geometry(int rows, int& nb, int& rpb) {
+    rpb = (rows + TL_NB - 1) / TL_NB; if (rpb < 16) rpb = 16;
+    nb = (rows + rpb - 1) / rpb;
+}
+
+// number of row-chunk partials that gptst_tail_mae / gptst_tail_kl write: part must hold that many x (J*C + J) floats
+extern "C" int gptst_tail_parts(int rows) { int nb, rpb; tl_geometry(rows, nb, rpb); return nb; }
+
+extern "C" int gptst_tail_mae(const float* dec, const float* W, const float* b, const float* src, int lda, const float* mask, float sigma,
+                              float mu, float thresh, float* out, float* d_dec, float* part, float* stats, int rows, int J, int C,
+                              void* stream) {
+    if (!dec || !W || !src || !mask || !out || !d_dec || !part || !stats || rows <= 0 || J <= 0) return GPTST_EARG;
+    if (C != 64 || J > TL_MAXJ) return GPTST_ESHAPE;
+    TailArgs t{};
+    t.X = dec; t.W = W; t.b = b; t.dX = d_dec; t.part = part; t.stats = stats; t.rows = rows; t.J = J;
+    t.src = src; t.mask = mask; t.out = out; t.lda = lda; t.sigma = sigma; t.mu = mu; t.thresh = thresh;
+    int nb; tl_geometry(rows, nb, t.rows_per_block);
+    hipLaunchKernelGGL(tail_kernel<0>, dim3(nb), dim3(256), 0, (hipStream_t)stream, t);
+    GPTST_CHECK_LAUNCH();
+    return GPTST_OK;
+}
+
+extern "C" int gptst_tail_kl(const float* h2, const float* W3, const float* prob, const float* c, float w, float* d_h2, float* part,
+                             float* stats, int rows, int N, int HS, int C, void* stream) {
+    if (!h2 || !W3 || !prob || !c || !d_h2 || !part || !stats || rows <= 0 || HS <= 0 || N <= 0) return GPTST_EARG;
+    if (C != 64 || HS > TL_MAXJ) return GPTST_ESHAPE;
+    TailArgs t{};
+    t.X = h2; t.W = W3; t.dX = d_h2; t.part = part; t.stats = stats; t.rows = rows; t.J = HS;
+    t.prob = prob; t.c = c; t.N = N; t.w = w;
+    int nb; tl_geometry(rows, nb, t.rows_per_block);
+    hipLaunchKernelGGL(tail_kernel<1>, dim3(nb), dim3(256), 0, (hipStream_t)stream, t);
+    GPTST_CHECK_LAUNCH();
+    return GPTST_OK;
+}

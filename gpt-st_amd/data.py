@@ -95,10 +95,20 @@ class WindowLoader:
         idx = idx.to(self.series.device)
         return self.series[idx[:, None] + self._tx[None, :]], self.series[idx[:, None] + self._ty[None, :]]
 
+    def _order(self):
+        return torch.randperm(self.n, generator=self.gen) if self.shuffle else torch.arange(self.n)
+
     def __iter__(self):
-        order = torch.randperm(self.n, generator=self.gen) if self.shuffle else torch.arange(self.n)
+        order = self._order()
         for i in range(0, self.n, self.bs):
             yield self.windows(order[i:i + self.bs])
+
+    def iter_x(self):
+        """Input windows only (pretraining never reads the y windows, BasicTrainer.py:74-76): one gather per batch instead of two."""
+        order = self._order()
+        for i in range(0, self.n, self.bs):
+            idx = order[i:i + self.bs].to(self.series.device)
+            yield self.series[idx[:, None] + self._tx[None, :]]
 
 
 def get_dataloader(args, root="../data", device="cpu", raw=None, single=False, generator=None):

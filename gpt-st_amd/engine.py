@@ -229,10 +229,11 @@ def cap_core_bwd(p, g, pfx, saved, dout, dims, HS, HT, red):
 _ONES = {}
 
 
-def _ones(dev):
-    if dev not in _ONES:
-        _ONES[dev] = torch.ones(1, 1, device=dev)
-    return _ONES[dev]
+def _ones(dev, n=1):
+    """cached (n, 1) column of ones: the 'embedding' of a plain sum over n partial rows"""
+    if (dev, n) not in _ONES:
+        _ONES[(dev, n)] = torch.ones(n, 1, device=dev)
+    return _ONES[(dev, n)]
 
 
 # ---- LReLU(x W_g + b_g) with generated weights, no residual (MLP_RL, GPTST.py:24-32) --------------------------------
@@ -412,13 +413,48 @@ def guide_fwd(p, source, tidx, dims, base, gen=None):
     return prob, (t4m, s1, s2, h2, label)
 
 
-def guide_bwd(p, g, source, tidx, saved, dlogit, dims, base, red):
+def _wb_view(gw, gb):
+    """[weight | bias] gradient of an nn.Linear as ONE (1, J*C + J) row when the two tensors are adjacent in the flat buffer."""
+    n = gw.numel() + gb.numel()
+    if gb.data_ptr() != gw.data_ptr() + 4 * gw.numel():
+        return None
+    return torch.as_strided(gw, (1, n), (n, 1))
+
+
+def fused_tails_ok(p, C, base, HS):
+    """The fused loss heads (tails.hip) serve C = 64 and J, HS <= 16 with [weight | bias] adjacent in the flat buffer."""
+    return (C == 64 and base <= ops.TAIL_MAXJ and HS <= ops.TAIL_MAXJ
+            and _wb_view(p["decoder.dim_flow_out.weight"], p["decoder.dim_flow_out.bias"]) is not None
+            and _wb_view(p["encoder.MLP_RL.ln3.weight"], p["encoder.MLP_RL.ln3.bias"]) is not None)
+
+
+def loss_tail(p, g, dec, source, mask, base, sigma, mu, thresh, stats, red):
+    """dim_flow_out + masked MAE + their backward in one pass over dec (GPTST.py:455, Run.py:92-100) -> out (BTN, base), d_dec."""
+    wo = "decoder.dim_flow_out."
+    out, dd, part = ops.tail_mae(dec, p[wo + "weight"], p[wo + "bias"], source, base + 2, mask, sigma, mu, thresh, stats)
+    red.jobs.bwd_pool(_ones(dec.device, part.shape[0]), part, _wb_view(g[wo + "weight"], g[wo + "bias"]))
+    red.keep.append((part, dd))
+    return out, dd
+
+
+def kl_head(p, g, sv_g, prob, c1, N, w, stats, red):
+    """0.1 KL(eb || prob) and the backward through softmax + MLP_RL.ln3 in one pass over h2 -> d_h2 (guide_bwd(dh2=...))."""
+    m = "encoder.MLP_RL."
+    dh2, part = ops.tail_kl(sv_g[3], p[m + "ln3.weight"], prob, c1, N, w, stats)
+    red.jobs.bwd_pool(_ones(prob.device, part.shape[0]), part, _wb_view(g[m + "ln3.weight"], g[m + "ln3.bias"]))
+    red.keep.append((part, dh2))
+    return dh2
+
+
+def guide_bwd(p, g, source, tidx, saved, dlogit, dims, base, red, dh2=None):
+    """dlogit (BTN,HS): gradient of the logits — or dh2 (BTN,C) when kl_head already went through ln3."""
     B, T, N, C = dims
     t4m, s1, s2, h2 = saved[:4]
     m = "encoder.MLP_RL."
-    HS = dlogit.shape[1]
-    dh2 = ops.lin_in(dlogit, HS, HS, p[m + "ln3.weight"], None, C, wlayout=1)
-    ops.rowouter(dlogit, HS, HS, h2, g[m + "ln3.weight"], 1, asum=g[m + "ln3.bias"])
+    if dh2 is None:
+        HS = dlogit.shape[1]
+        dh2 = ops.lin_in(dlogit, HS, HS, p[m + "ln3.weight"], None, C, wlayout=1)
+        ops.rowouter(dlogit, HS, HS, h2, g[m + "ln3.weight"], 1, asum=g[m + "ln3.bias"])
     d_t4m = _zeros(t4m, *t4m.shape)
     dh1 = condlin_bwd(s2, dh2, t4m, p[m + "weights_pool_tem"], p[m + "bias_pool_tem"], g[m + "weights_pool_tem"],
                       g[m + "bias_pool_tem"], d_t4m, MODE_TIME, dims, red)
@@ -440,21 +476,25 @@ def model_fwd(p, source, mask, dims, base, num_route, scaler_zeros, gen=None, ti
     return emb, c1, tidx, sv_e
 
 
-def decoder_fwd(p, tidx, emb, dims, num_route, gen=None):
+def decoder_fwd(p, tidx, emb, dims, num_route, gen=None, head=True):
     dec, _, sv_d = sthcn_fwd(p, DEC, tidx, emb, dims, num_route, gen=gen)                                  # :454
+    if not head:
+        return None, dec, sv_d
     out = ops.rowdot(dec, p["decoder.dim_flow_out.weight"], p["decoder.dim_flow_out.bias"])                 # :455
     return out, dec, sv_d
 
 
-def model_bwd(p, g, source, mask, tidx, sv_e, sv_d, dec, d_out, d_dec, dims, base, scaler_zeros, red):
-    """Backward of decoder_fwd . model_fwd given d_out (BTN, base) [and optional d_dec (BTN, C)].  Parameter-gradient reductions
-    are queued on ``red`` (Reductions): the caller runs red.flush(tidx) once the whole backward is enqueued."""
+def model_bwd(p, g, source, mask, tidx, sv_e, sv_d, dec, d_out, d_dec, dims, base, scaler_zeros, red, dd=None):
+    """Backward of decoder_fwd . model_fwd given d_out (BTN, base) [and optional d_dec (BTN, C)] — or given dd, the gradient
+    w.r.t. the decoder STHCN output, when loss_tail already went through dim_flow_out.  Parameter-gradient reductions are queued
+    on ``red`` (Reductions): the caller runs red.flush(tidx) once the whole backward is enqueued."""
     B, T, N, C = dims
     wo = "decoder.dim_flow_out."
-    dd = ops.lin_in(d_out, base, base, p[wo + "weight"], None, C, wlayout=1)
-    if d_dec is not None:
-        dd = dd + d_dec
-    ops.rowouter(d_out, base, base, dec, g[wo + "weight"], 1, asum=g[wo + "bias"])
+    if dd is None:
+        dd = ops.lin_in(d_out, base, base, p[wo + "weight"], None, C, wlayout=1)
+        if d_dec is not None:
+            dd = dd + d_dec
+        ops.rowouter(d_out, base, base, dec, g[wo + "weight"], 1, asum=g[wo + "bias"])
     d_emb = sthcn_bwd(p, g, DEC, tidx, sv_d, dd, dims, red)
     d_x0 = sthcn_bwd(p, g, ENC, tidx, sv_e, d_emb, dims, red)
     ops.rowouter(source, base + 2, base, d_x0, g["encoder.dim_in_flow.weight"], 0, csum=g["encoder.dim_in_flow.bias"],

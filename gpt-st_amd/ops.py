@@ -509,6 +509,34 @@ def kl(prob, c, N, w, stats, want_grad=True):
     return dlogit
 
 
+TAIL_MAXJ = 16
+
+
+def tail_mae(dec, W, b, src, lda, mask, sigma, mu, thresh, stats):
+    """Fused output head + masked-MAE + its backward (tails.hip) -> out (rows,J), d_dec (rows,C) [gradient of the SUM loss],
+    part (nparts, J*C+J) partials of (gW, gb)."""
+    rows, C = dec.shape
+    J = W.shape[0]
+    nparts = _C.lib().value("gptst_tail_parts", rows)
+    out = torch.empty(rows, J, device=dec.device, dtype=torch.float32)
+    d_dec = torch.empty_like(dec)
+    part = torch.empty(nparts, J * C + J, device=dec.device, dtype=torch.float32)
+    _call("gptst_tail_mae", _p(dec), _p(W), _p(b), _p(src), lda, _p(mask), float(sigma), float(mu), float(thresh), _p(out), _p(d_dec),
+          _p(part), _p(stats), rows, J, C, nbytes=_nb(dec, d_dec))
+    return out, d_dec, part
+
+
+def tail_kl(h2, W3, prob, c, N, w, stats):
+    """Fused KL + softmax/ln3 backward (tails.hip) -> d_h2 (rows,C), part (nparts, HS*C+HS) partials of (gW3, gb3)."""
+    rows, C = h2.shape
+    HS = W3.shape[0]
+    nparts = _C.lib().value("gptst_tail_parts", rows)
+    d_h2 = torch.empty_like(h2)
+    part = torch.empty(nparts, HS * C + HS, device=h2.device, dtype=torch.float32)
+    _call("gptst_tail_kl", _p(h2), _p(W3), _p(prob), _p(c), float(w), _p(d_h2), _p(part), _p(stats), rows, N, HS, C, nbytes=_nb(h2, d_h2))
+    return d_h2, part
+
+
 def clip_adam(p, g, m, v, nA, nB, hyper, stats):
     _call("gptst_clip_adam", _p(p), _p(g), _p(m), _p(v), int(nA), int(nB), _p(hyper), _p(stats))
 

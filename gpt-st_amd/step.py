@@ -58,6 +58,7 @@ class PretrainStep:
         self.inject_noise = False
         self.global_count_scale = False      # set by subclasses that all-reduce [gradient | statistics] themselves (shard.py)
         self.arena = engine.ZeroArena(self.dev)
+        self.fused_tails = os.environ.get("GPTST_FUSED_TAILS", "1") == "1" and engine.fused_tails_ok(model.param_views(), self.C, self.base, self.HS)
         # ---- data parallel: masks over the GLOBAL batch (dist.py) ----
         self.W = dp.world if dp is not None else 1
         self.gmask = bool(global_mask) and dp is not None and self.W > 1
@@ -107,14 +108,22 @@ class PretrainStep:
                                          a.ada_type == "all", base)[2]
         self.last_mask = mask
         emb, c1, tidx, sv_e = engine.model_fwd(p, src, mask, dims, base, mdl.num_route, mdl.scaler_zeros, gen=gen[engine.ENC], tidx=tidx)
-        out, dec, sv_d = engine.decoder_fwd(p, tidx, emb, dims, mdl.num_route, gen=gen[engine.DEC])
-        ops.mae_fwd(out, src, base + 2, mask, self.std, self.mean, a.mape_thresh, M, base, self.stats)
-        d_out = ops.mae_bwd(out, src, base + 2, mask, self.std, self.mean, a.mape_thresh, M, base, self.stats,
-                            normalize=self.dp is None)
-        engine.model_bwd(p, g, src, mask, tidx, sv_e, sv_d, dec, d_out, None, dims, base, mdl.scaler_zeros, red)
-        if phase == 1:
-            dlogit = ops.kl(prob, c1, self.N, 0.1, self.stats)
-            engine.guide_bwd(p, g, src, tidx, sv_g, dlogit, dims, base, red)
+        if self.fused_tails:
+            # output head + masked MAE + their backward: one pass over dec (the mean's 1/#kept is applied by the optimiser)
+            _, dec, sv_d = engine.decoder_fwd(p, tidx, emb, dims, mdl.num_route, gen=gen[engine.DEC], head=False)
+            out, dd = engine.loss_tail(p, g, dec, src, mask, base, self.std, self.mean, a.mape_thresh, self.stats, red)
+            engine.model_bwd(p, g, src, mask, tidx, sv_e, sv_d, dec, None, None, dims, base, mdl.scaler_zeros, red, dd=dd)
+            if phase == 1:
+                dh2 = engine.kl_head(p, g, sv_g, prob, c1, self.N, 0.1, self.stats, red)
+                engine.guide_bwd(p, g, src, tidx, sv_g, None, dims, base, red, dh2=dh2)
+        else:
+            out, dec, sv_d = engine.decoder_fwd(p, tidx, emb, dims, mdl.num_route, gen=gen[engine.DEC])
+            ops.mae_fwd(out, src, base + 2, mask, self.std, self.mean, a.mape_thresh, M, base, self.stats)
+            d_out = ops.mae_bwd(out, src, base + 2, mask, self.std, self.mean, a.mape_thresh, M, base, self.stats, normalize=False)
+            engine.model_bwd(p, g, src, mask, tidx, sv_e, sv_d, dec, d_out, None, dims, base, mdl.scaler_zeros, red)
+            if phase == 1:
+                dlogit = ops.kl(prob, c1, self.N, 0.1, self.stats)
+                engine.guide_bwd(p, g, src, tidx, sv_g, dlogit, dims, base, red)
         engine._join_side()
         red.flush(tidx)                                           # all parameter-gradient reductions: 3 launches
         engine.CTX.ARENA = None
@@ -204,7 +213,7 @@ class PretrainStep:
         h[4], h[5], h[6] = b1, b2, 1e-8
         h[7] = float(a.max_grad_norm) if a.grad_norm else 0.0
         h[8] = 1.0 if phase == 1 else 0.0
-        h[9] = 1.0 if (self.dp is not None or self.global_count_scale) else 0.0     # divide path-A gradients by the GLOBAL kept count
+        h[9] = 1.0          # the backward carries the gradient of the SUM loss: the optimiser divides path A by the (global) kept count
         h[10] = 1.0
         self.hyper.copy_(h, non_blocking=True)
         if phase == 1:

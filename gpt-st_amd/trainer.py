@@ -29,10 +29,11 @@ def get_logger(log_dir, name="GPTST", debug=True):
 
 
 class Trainer:
-    def __init__(self, model, args, batches, scaler_mean, scaler_std, batch_size, dp=None, use_graph=True):
-        """batches: a callable epoch -> iterable of (B,T,N,base+2) device tensors (ragged last batch allowed)."""
+    def __init__(self, model, args, batches, scaler_mean, scaler_std, batch_size, dp=None, use_graph=True, batches_per_epoch=None):
+        """batches: a callable epoch -> iterable of (B,T,N,base+2) device tensors (ragged last batch allowed), consumed lazily — the
+        windowed dataset is 12x the series and is never materialised; batches_per_epoch: the 'i/n' of the log line when known."""
         self.model, self.args, self.batches = model, args, batches
-        self.dp = dp
+        self.dp, self.nb_epoch = dp, batches_per_epoch
         self.step = PretrainStep(model, args, scaler_mean, scaler_std, batch_size, use_graph=use_graph, dp=dp, seed=args.seed)
         self.ragged = {}
         self.scaler = (scaler_mean, scaler_std)
@@ -60,8 +61,7 @@ class Trainer:
         a = self.args
         tot = tot_f = tot_s = 0.0
         nb = 0
-        data = list(self.batches(epoch))
-        for bi, src in enumerate(data):
+        for bi, src in enumerate(self.batches(epoch)):
             st = self._stepper_for(src.shape[0])
             st.step(src, epoch)
             if st is not self.step:
@@ -69,7 +69,9 @@ class Trainer:
             loss, lf, ls = st.losses()                   # the reference syncs every step too (BasicTrainer.py:98-103)
             tot += loss; tot_f += lf; tot_s += ls; nb += 1
             if bi % a.log_step == 0:
-                self.logger.info("Train Epoch {}: {}/{} Loss: {:.6f}".format(epoch, bi, len(data), loss))
+                self.logger.info("Train Epoch {}: {}/{} Loss: {:.6f}".format(epoch, bi, self.nb_epoch if self.nb_epoch is not None else "?", loss))
+        if nb == 0:
+            raise RuntimeError("epoch %d: this rank received no batch (dataset smaller than world_size x batch_size?)" % epoch)
         self.logger.info("**********Train Epoch {}: averaged Loss: {:.6f} averaged Loss_s: {:.6f}".format(epoch, tot_f / nb, tot_s / nb))
         if a.lr_decay and epoch in self.lr_steps:        # MultiStepLR (Run.py:141), stepped per epoch (BasicTrainer.py:117-118)
             self.step.lr *= a.lr_decay_rate
@@ -99,7 +101,9 @@ class Trainer:
         if a.debug and best_state is not None and (self.dp is None or self.dp.rank == 0):   # :187-189 (flag is inverted in the reference too)
             torch.save(best_state, self.best_path)
             self.logger.info("Saving current best model to " + self.best_path)
-        if best_state is not None and (self.dp is None or self.dp.rank == 0):   # :193-195: pretrain mode evaluates on the TRAIN loader
+        if best_state is not None:                       # :193-195: pretrain mode evaluates on the TRAIN loader
+            # data parallel: every rank evaluates ITS share of the batches and the metric sums are all-reduced (test()), so the
+            # report covers what the job trained on, as the reference's covers its whole loader
             last = copy.deepcopy(self.model.state_dict())
             self.model.load_state_dict(best_state)
             self.test(self.batches(a.epochs))
@@ -124,6 +128,10 @@ class Trainer:
                 vis = (1 - masked).to(torch.float32).reshape(-1).contiguous()
                 ops.metrics_accum(out.reshape(-1, base).contiguous(), src, base + 2, vis, self.scaler[1], self.scaler[0],
                                   getattr(a, "mae_thresh", None), a.mape_thresh, B, T, N, base, *sums)
+        if self.dp is not None and self.dp.world > 1:
+            import torch.distributed as dist
+            for t_ in sums:                              # float64 sums over this rank's batches -> over the job's
+                dist.all_reduce(t_, op=dist.ReduceOp.SUM)
         rows = ops.metrics_report(*sums)
         for t in range(rows.shape[0] - 1):
             mae, rmse, mape, corr = (float(v) for v in rows[t])

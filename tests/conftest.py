@@ -24,3 +24,41 @@ def pytest_sessionstart(session):
     if not os.path.exists(lib) and os.path.exists("/opt/rocm/bin/hipcc"):
         import subprocess
         subprocess.run([sys.executable, "-m", "gptst_amd.build"], cwd=ROOT, check=True)
+
+
+# ---- measured parity errors -------------------------------------------------------------------------------------------------------
+# GPU tests report the worst error they measured through the `parity` fixture; the session writes them to gpurun_out/parity.json
+# (copied to profiles/parity_rNN.json after a GPU run), so that tolerances can be set from measurements and regressions are visible.
+_PARITY = {}
+
+
+def record_current(key, value):
+    """Record a measured error under the running test (usable from helpers that have no fixture access)."""
+    name = os.environ.get("PYTEST_CURRENT_TEST", "?").split("::")[-1].split(" ")[0]
+    d = _PARITY.setdefault(name, {})
+    d[key] = max(float(value), d.get(key, 0.0))
+
+
+@pytest.fixture
+def parity(request):
+    def rec(key, value):
+        d = _PARITY.setdefault(request.node.name, {})
+        d[key] = max(float(value), d.get(key, 0.0))
+    return rec
+
+
+def pytest_sessionfinish(session, exitstatus):
+    if not _PARITY:
+        return
+    import json
+    out = os.path.join(ROOT, "gpurun_out")
+    os.makedirs(out, exist_ok=True)
+    path = os.path.join(out, "parity.json")
+    old = {}
+    if os.path.exists(path):
+        try:
+            old = json.load(open(path))
+        except Exception:
+            old = {}
+    old.update(_PARITY)
+    json.dump(old, open(path, "w"), indent=1, sort_keys=True)

@@ -65,7 +65,8 @@ def test_model_vs_reference_golden(tag):
     check(fx, tag + ".prob", prob, 1e-4, 1e-5)
     check(fx, tag + ".hs1", hs1.contiguous(), 1e-4, 1e-5)
     loss, lf, ls = _loss(outs, src, args, epoch)
-    np.testing.assert_allclose([float(loss), float(lf), float(ls)], fx[tag + ".loss"], rtol=2e-4)
+    np.testing.assert_allclose([float(loss), float(lf)], fx[tag + ".loss"][:2], rtol=2e-5)
+    np.testing.assert_allclose(float(ls), fx[tag + ".loss"][2], rtol=2e-4, atol=1e-7)          # KL: a small difference of logs
     loss.backward()
     worst = 0.0
     for k, p in model.named_parameters():
@@ -82,7 +83,9 @@ def test_model_vs_reference_golden(tag):
         scale = float(ref.abs().max())
         err = float((val - ref).abs().max()) / max(scale, 1e-6)
         worst = max(worst, err)
-        assert err < 2e-3, (k, err, scale)          # gradients through ~40 fp32 layers
+        assert err < 3e-4, (k, err, scale)          # gradients through ~40 fp32 layers vs the REFERENCE's own gradients
+    from conftest import record_current
+    record_current("grad_worst_vs_reference", worst)
     print(tag, "worst grad rel err", worst)
 
 

@@ -20,6 +20,11 @@ CASES = {
     "hs5": dict(ds="PEMS08", over=dict(HS=5, num_nodes=50), B=2, epoch=100),
     "hs20": dict(ds="PEMS08", over=dict(HS=20, num_nodes=45), B=2, epoch=100),
     "hs40": dict(ds="NYC_TAXI", over=dict(HS=40, num_nodes=37), B=1, epoch=100),
+    # BASELINE configs[3] at its real node count: the (b,t) capsule matrix fits LDS for some cap kernels and not for others, so one
+    # cap mixes LDS and streaming kernels (per-kernel ESHAPE fallback, ops._lds_or_stream); HS = 40 also takes the global cap_cross path
+    "nyc266_hs20": dict(ds="NYC_TAXI", over=dict(HS=20), B=1, epoch=100),
+    "nyc266_hs40": dict(ds="NYC_TAXI", over=dict(HS=40), B=1, epoch=100),
+    "nyc266_hs20_rand": dict(ds="NYC_TAXI", over=dict(HS=20), B=1, epoch=2),
     "route4": dict(ds="PEMS08", over=dict(num_route=4, num_nodes=33, embed_dim=8), B=2, epoch=100),
     "c128": dict(ds="PEMS08", over=dict(hidden_dim=128, num_nodes=40, embed_dim=8), B=2, epoch=100),
     "c128_rand": dict(ds="NYC_TAXI", over=dict(hidden_dim=128, num_nodes=23, embed_dim=4), B=1, epoch=2),
@@ -29,7 +34,7 @@ CASES = {
 
 
 @pytest.mark.parametrize("name", list(CASES))
-def test_model_vs_oracle(name):
+def test_model_vs_oracle(name, parity):
     from gptst_amd.model import GPTST_Model
     c = CASES[name]
     args = make_args(c["ds"], scaler_zeros=synth.scaler_zeros(), **c["over"])
@@ -66,17 +71,18 @@ def test_model_vs_oracle(name):
         a, b = a.detach().cpu().double(), b.detach().double()
         return float((a - b).abs().max() / b.abs().max().clamp_min(1e-6))
 
-    assert rel(out, outs_r[0]) < 1e-4, ("out", rel(out, outs_r[0]))
-    assert rel(dec, outs_r[1]) < 1e-4
-    assert rel(prob, outs_r[3]) < 1e-4
-    assert rel(hs1, outs_r[4]) < 1e-4
+    for nm, a_, b_ in (("out", out, outs_r[0]), ("dec", dec, outs_r[1]), ("prob", prob, outs_r[3]), ("hs1", hs1, outs_r[4])):
+        e = rel(a_, b_)
+        parity("fwd_" + nm, e)
+        assert e < 1e-5, (nm, e)            # measured <= 1.3e-6
     p = (out * synth.SCALER_STD + synth.SCALER_MEAN) * mask
     y = (srcd[..., :base] * synth.SCALER_STD + synth.SCALER_MEAN) * mask
     keep = y > args.mape_thresh
     loss = torch.abs(torch.masked_select(y, keep) - torch.masked_select(p, keep)).mean()
     if epoch > args.change_epoch:
         loss = loss + torch.nn.functional.kl_div(prob.log(), hs1, reduction="sum") * 0.1
-    assert abs(float(loss) - float(loss_r)) < 2e-4 * abs(float(loss_r))
+    parity("loss", abs(float(loss) - float(loss_r)) / abs(float(loss_r)))
+    assert abs(float(loss) - float(loss_r)) < 2e-6 * abs(float(loss_r))      # measured <= 1.5e-7
     loss.backward()
     worst = 0.0
     for k, pm in model.named_parameters():
@@ -86,5 +92,6 @@ def test_model_vs_oracle(name):
             continue
         e = rel(pm.grad, gr)
         worst = max(worst, e)
-        assert e < 3e-3, (name, k, e)
+        assert e < 6e-4, (name, k, e)       # measured worst over all cases 2.6e-4 (c128_rand), typically 2e-5 (profiles/parity_r02.json)
+    parity("grad_worst", worst)
     print(name, "worst grad rel err %.2e" % worst)

@@ -66,6 +66,8 @@ def test_step_sequence_vs_reference(use_graph):
         # Adam maps a sign flip of a round-off-level gradient (e.g. cap.t_adj early on) to a +-lr move per step, so single
         # tensors are chaotic across devices; 0.1 still catches a wrong optimiser (>=0.3).  Exact Adam/clip arithmetic is
         # pinned separately by test_clip_adam_matches_torch (2e-6).
+        from conftest import record_current
+        record_current("param_rel_l2_after_12_steps", rel)
         assert rel < 0.1, (k, rel)
     assert (st.tA, st.tB) == (12, 6)
 

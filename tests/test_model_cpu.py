@@ -68,3 +68,18 @@ def test_c_abi_exports_every_header_symbol():
     for n in names:
         assert hasattr(dll, n), n
     assert lib.value("gptst_abi_version") == 1
+
+
+def test_library_exports_exactly_the_header():
+    """The C-ABI library exports every symbol include/gptst_hip.h declares and NOTHING else (no debug / tuning scaffolding:
+    those exist only in -DGPTST_DEBUG builds; cross-file helpers have hidden visibility)."""
+    import shutil
+    import subprocess
+    from gptst_amd import _C
+    hdr = set(_C.parse_header())
+    lib = _C.lib()
+    assert all(hasattr(lib, "_raw_" + n) for n in hdr)
+    nm = shutil.which("nm") or "/opt/rocm/lib/llvm/bin/llvm-nm"
+    out = subprocess.run([nm, "-D", "--defined-only", _C.LIB_PATH], capture_output=True, text=True, check=True).stdout
+    exp = {ln.split()[-1] for ln in out.splitlines() if " T " in ln and ln.split()[-1].startswith("gptst_")}
+    assert exp == hdr, (sorted(exp - hdr), sorted(hdr - exp))
