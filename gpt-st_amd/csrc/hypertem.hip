@@ -115,10 +115,6 @@ __global__ __launch_bounds__(256, 2) void hypertem_fwd_kernel(const float* __res
                 for (int q = 0; q < C / 16; ++q) a4[q] = f4fma(gu, ld4(xr + u * NT * P + 16 * q), a4[q]);
             }
         }
-        if (j < NT && n0 + j < N) {
-#pragma unroll
-            for (int q = 0; q < C / 16; ++q) st4(R_out + (g * N + n0 + j) * C + 16 * q + 4 * kk, a4[q]);
-        }
         TS();
         // ---- (2) R_t @ W_bt on MFMA 16x16x4: A = R_t (registers), B = W_bt fragments (registers) ----
         f32x4 acc[C / 16];
@@ -138,6 +134,13 @@ __global__ __launch_bounds__(256, 2) void hypertem_fwd_kernel(const float* __res
         TS();
         const float4 bias = b4;
         if (t + 4 < HT_T) HT_LOAD_W(t + 4);
+        TS();
+        // R_t (kept for the weight gradient) is stored only now, together with the output rows: every store of a time step is
+        // issued BEHIND the next step's W_bt loads (vmcnt retires in order)
+        if (j < NT && n0 + j < N) {
+#pragma unroll
+            for (int q = 0; q < C / 16; ++q) st4(R_out + (g * N + n0 + j) * C + 16 * q + 4 * kk, a4[q]);
+        }
         // ---- (3) epilogue from registers: lane (j, kk) owns rows kk*4 + r, channels 4j .. 4j+3 ----
 #pragma unroll
         for (int r = 0; r < 4; ++r) {

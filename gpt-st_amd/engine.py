@@ -104,11 +104,15 @@ class Reductions:
     executed at the end of the backward as THREE launches (gram_bwd, one job table, one time-feature job table) instead of ~20
     small launches per STHCN.  Nothing on the critical chain waits for these results; only the optimiser does."""
 
-    def __init__(self):
+    def __init__(self, side=None):
+        """side: optional SideStream — flush_async() then runs what has been queued so far on it, concurrently with the rest of
+        the backward chain (one fork per call, ONE join in flush())."""
         self.jobs = ops.PoolJobs()
         self.grams = []          # (A (L*N,Hm,T), dG (L*N,T,T), dA out)
         self.tf = []             # (params, grads, dout, rows, K)
         self.keep = []
+        self.side = side
+        self.held = []
 
     def gram(self, A, dG, dA):
         self.grams.append((A, dG, dA))
@@ -118,7 +122,21 @@ class Reductions:
         rows, K = (B, T) if spg else (B * T, 1)
         self.tf.append((_tf_tensors(p, pfx), _tf_tensors(g, pfx), dout, rows, K))
 
+    def flush_async(self, tidx):
+        """Run everything queued so far on the side stream (it depends only on finished layers of the backward); no-op without one."""
+        if self.side is None or not (self.jobs.jobs or self.grams or self.tf):
+            return
+        self.held.append((self.keep, list(self.jobs.jobs), list(self.grams), list(self.tf)))      # alive until the join
+        with self.side.fork():
+            self._run(tidx)
+
     def flush(self, tidx):
+        self._run(tidx)
+        if self.side is not None:
+            self.side.join()
+        self.held = []
+
+    def _run(self, tidx):
         gr, self.grams = sorted(self.grams, key=lambda t: t[0].data_ptr()), []
         while gr:                                   # adjacent (A, dG, dA) triples (both STHCNs of a step) share one launch
             A, dG, dA = gr.pop(0)
@@ -496,6 +514,8 @@ def model_bwd(p, g, source, mask, tidx, sv_e, sv_d, dec, d_out, d_dec, dims, bas
             dd = dd + d_dec
         ops.rowouter(d_out, base, base, dec, g[wo + "weight"], 1, asum=g[wo + "bias"])
     d_emb = sthcn_bwd(p, g, DEC, tidx, sv_d, dd, dims, red)
+    red.flush_async(tidx)                                   # the decoder's reductions overlap with the encoder's backward chain
     d_x0 = sthcn_bwd(p, g, ENC, tidx, sv_e, d_emb, dims, red)
+    red.flush_async(tidx)                                   # ... and the encoder's with the guide's
     ops.rowouter(source, base + 2, base, d_x0, g["encoder.dim_in_flow.weight"], 0, csum=g["encoder.dim_in_flow.bias"],
                  mask=mask, fill=scaler_zeros)

@@ -75,6 +75,9 @@ class PretrainStep:
             self.label_graph = None
         # measured: running weight gradients on a second stream slows the step (364 vs 403 steps/s), so opt-in only
         self.side = engine.SideStream() if os.environ.get("GPTST_SIDE_STREAM", "0") == "1" else None
+        # opt-in: parameter-gradient reductions of finished layers on a second stream under the rest of the backward chain
+        # (measured r02k: 558-579 vs 597 steps/s — the side kernels take CU slots from the chain, as the weight gradients did)
+        self.red_side = engine.SideStream() if os.environ.get("GPTST_RED_STREAM", "0") == "1" else None
 
     # ---- the enqueued work ---------------------------------------------------------------------------------------
     def _fwd_bwd(self, phase):
@@ -88,7 +91,7 @@ class PretrainStep:
         src = self.src
         tidx = src[:, :, 0, base:base + 2].contiguous()
         gen = engine.gen_all(p, tidx, dims)                       # time embeddings + every generated parameter: 3 launches
-        red = engine.Reductions()
+        red = engine.Reductions(side=self.red_side)
         prob, sv_g = engine.guide_fwd(p, src, tidx, dims, base, gen=gen["guide"])
         if self.gmask:
             mask = self._global_mask(phase)

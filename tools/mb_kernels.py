@@ -1,0 +1,74 @@
+#!/usr/bin/env python
+"""Micro-benchmark of the hot kernels at the bench shape (B=32,T=12,N=170,C=64,HS=10): each C-ABI call is captured 20x back to back
+in a hipGraph and replayed; prints us per launch.  usage (GPU box): python tools/mb_kernels.py [name-filter]"""
+import sys
+sys.path.insert(0, '.')
+import torch
+from gptst_amd import ops
+from gptst_amd.ops import MODE_TIME, MODE_NODE, MODE_SHARED, PRO_DPRE, EPI_RES_LRELU, EPI_ADD_DPRE
+
+dev = 'cuda:0'
+B, T, N, C, HS, HT, R = 32, 12, 170, 64, 10, 16, 2
+BT = B * T
+torch.manual_seed(0)
+f = lambda *s: torch.randn(*s, device=dev)
+X, dO = f(B, T, N, C), f(B, T, N, C)
+G = f(N, 12, 12) * 0.1
+Wbt, bbt = f(BT, C, C) * 0.1, f(BT, C)
+Wn, bn = f(N, C, C) * 0.1, f(N, C)
+Wp, bp = f(C, C) * 0.1, f(C)
+dadj = f(BT, HS * N)
+dyn = f(B, HT, T * HS) * 0.1
+tmpl = torch.arange(12, device=dev, dtype=torch.float32) / 12
+Rr, out = ops.hypertem_fwd(X, G, Wbt, bbt)
+X2, dO2, out2 = X.view(-1, C), dO.view(-1, C), out.view(-1, C)
+db, dG = torch.zeros(BT, C, device=dev), torch.zeros(N, 12, 12, device=dev)
+dbn = torch.zeros(N, C, device=dev)
+c, s = ops.cap_route_fwd(X, Wp, bp, dadj, HS, R)
+v, Ht, Rt = ops.cap_cross_fwd(s, dyn, tmpl, B, T, HS, HT)
+rec = ops.cap_rec_fwd(c, v, N, C)
+dc1, dv = ops.cap_rec_bwd(dO2, c, v)
+dS, ddyn = ops.cap_cross_bwd(dv, s, Rt, Ht, dyn, tmpl, B, T, HS, HT)
+
+CASES = {
+    "hypertem_fwd": lambda: ops.hypertem_fwd(X, G, Wbt, bbt),
+    "hypertem_bwd": lambda: ops.hypertem_bwd(dO, out, X, G, Wbt, db, dG),
+    "wgrad_time_dpre": lambda: ops.wgrad(Rr.view(-1, C), dO2, MODE_TIME, BT, N, D2=out2, pro=PRO_DPRE),
+    "wgrad_node_dpre": lambda: ops.wgrad(rec, dO2, MODE_NODE, BT, N, D2=out2, pro=PRO_DPRE),
+    "wgrad_shared_cs": lambda: ops.wgrad(dO2, X2, MODE_SHARED, BT, N, colsum_a=True),
+    "apply_node_fwd": lambda: ops.apply(rec, Wn, MODE_NODE, BT, N, bias=bn, resid=X2, epi=EPI_RES_LRELU),
+    "apply_node_dpre": lambda: ops.apply(dO2, Wn, MODE_NODE, BT, N, A2=out2, transw=True, pro=PRO_DPRE, colsum=dbn),
+    "apply_shared_dx": lambda: ops.apply(dO2, Wp, MODE_SHARED, BT, N, resid=dO2, resid2=out2, epi=EPI_ADD_DPRE),
+    "cap_route_fwd": lambda: ops.cap_route_fwd(X, Wp, bp, dadj, HS, R),
+    "cap_cross_fwd": lambda: ops.cap_cross_fwd(s, dyn, tmpl, B, T, HS, HT),
+    "cap_rec_fwd": lambda: ops.cap_rec_fwd(c, v, N, C),
+    "cap_rec_bwd": lambda: ops.cap_rec_bwd(dO2, c, v),
+    "cap_cross_bwd": lambda: ops.cap_cross_bwd(dv, s, Rt, Ht, dyn, tmpl, B, T, HS, HT),
+    "cap_route_bwd": lambda: ops.cap_route_bwd(X, Wp, bp, c, dc1, dS),
+    "copy_A": lambda: X2.clone(),
+}
+
+
+def bench(fn, n=20):
+    for _ in range(3):
+        fn()
+    torch.cuda.synchronize()
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g):
+        for _ in range(n):
+            fn()
+    g.replay(); torch.cuda.synchronize()
+    best = 1e9
+    for _ in range(3):
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record(); g.replay(); e1.record(); torch.cuda.synchronize()
+        best = min(best, e0.elapsed_time(e1) / n * 1000)
+    return best
+
+
+flt = sys.argv[1] if len(sys.argv) > 1 else ""
+tot = 0.0
+for k, fn in CASES.items():
+    if flt in k:
+        t = bench(fn)
+        print("%-20s %7.2f us" % (k, t))
