@@ -154,7 +154,7 @@ __global__ __launch_bounds__(256) void apply_kernel(const float* __restrict__ A,
         }
         TS();
     }
-    if (colsum != nullptr) {          // fold the 4 waves in LDS first: one atomic per column and workgroup
+    if (colsum != nullptr) {          // fold the 4 waves in LDS: one partial per column and workgroup
         __syncthreads();
 #pragma unroll
         for (int u = 0; u < C / 64; ++u) tile[u * 64 + lane] = cs[u];
@@ -165,7 +165,7 @@ __global__ __launch_bounds__(256) void apply_kernel(const float* __restrict__ A,
                 float s = 0.f;
 #pragma unroll
                 for (int w = 0; w < 4; ++w) s += smem[C * C + w * T::TILE_FLOATS + u * 64 + lane];
-                atomicAdd(colsum + (size_t)g * C + u * 64 + lane, s);
+                colsum[((size_t)blockIdx.y * rm.G + g) * C + u * 64 + lane] = s;      // partial of this row split (plain store)
             }
         }
     }
@@ -276,7 +276,8 @@ __global__ __launch_bounds__(256, 2) void apply64_kernel(const float* __restrict
             }
         }
     }
-    if (colsum != nullptr) {          // column sums of (pro-applied) A: 16-lane row reduction, 4 waves folded in LDS, one atomic per column
+    if (colsum != nullptr) {          // column sums of (pro-applied) A: 16-lane row reduction, 4 waves folded in LDS in fixed order, and
+        // stored as this workgroup's PARTIAL [blockIdx.y][g][:] — no atomics: the consumer sums the gridDim.y row splits
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
             cs[q].x = group_sum<16>(cs[q].x); cs[q].y = group_sum<16>(cs[q].y);
@@ -284,21 +285,27 @@ __global__ __launch_bounds__(256, 2) void apply64_kernel(const float* __restrict
             if (j == 0) st4(&csl[wave][16 * q + 4 * kk], cs[q]);
         }
         __syncthreads();
-        if (wave == 0) atomicAdd(colsum + (size_t)g * C + lane, csl[0][lane] + csl[1][lane] + csl[2][lane] + csl[3][lane]);
+        if (wave == 0) colsum[((size_t)blockIdx.y * rm.G + g) * C + lane] = (csl[0][lane] + csl[1][lane]) + (csl[2][lane] + csl[3][lane]);
     }
+}
+
+// launch geometry of apply64: tiles per wave and row splits (gridDim.y = number of colsum partials per group)
+static void apply64_geometry(const RowMap& rm, bool has_colsum, int& tpw, int& gy) {
+    const int ntiles = (rm.M + 15) / 16;
+    long tot = (long)rm.G * ntiles;
+    tpw = (int)((tot + 4 * 512 - 1) / (4 * 512));              // ~512 workgroups of 4 waves: one round at 2 per CU ...
+    if (tpw > 2) tpw = 2;                                      // ... but never more than 2 tiles per wave (measured: 3+ is 15-40 % slower)
+    if (has_colsum && rm.G == 1) { const int lim = (ntiles + 4 * 128 - 1) / (4 * 128); if (tpw < lim) tpw = lim; }   // <= 128 partials
+    if (g_apply_tpw > 0) tpw = g_apply_tpw;
+    if (tpw < 1) tpw = 1;
+    gy = (ntiles + 4 * tpw - 1) / (4 * tpw);
 }
 
 template <int PRO, int EPI>
 static void launch_apply64_t(const float* A, const float* A2, const float* W, long gs, int transw, const float* bias, const float* resid,
                              const float* resid2, float* out, float* colsum, RowMap rm, hipStream_t st) {
-    const int ntiles = (rm.M + 15) / 16;
-    long tot = (long)rm.G * ntiles;
-    int tpw = (int)((tot + 4 * 512 - 1) / (4 * 512));          // ~512 workgroups of 4 waves: one round at 2 per CU ...
-    if (tpw > 2) tpw = 2;                                      // ... but never more than 2 tiles per wave (measured: 3+ is 15-40 % slower)
-    if (colsum != nullptr && rm.G == 1) { const int lim = (ntiles + 4 * 128 - 1) / (4 * 128); if (tpw < lim) tpw = lim; }   // <= 128 atomics per address
-    if (g_apply_tpw > 0) tpw = g_apply_tpw;
-    if (tpw < 1) tpw = 1;
-    const int gy = (ntiles + 4 * tpw - 1) / (4 * tpw);
+    int tpw, gy;
+    apply64_geometry(rm, colsum != nullptr, tpw, gy);
     hipLaunchKernelGGL((apply64_kernel<PRO, EPI>), dim3(rm.G, gy), dim3(256), 0, st, A, A2, W, gs, transw, bias, resid, resid2, out, colsum, rm, tpw);
 }
 
@@ -361,7 +368,8 @@ __global__ __launch_bounds__(256, 2) void wgrad64_kernel(const float* __restrict
                 d[u].x *= lrelu_grad_from_out(y[u].x); d[u].y *= lrelu_grad_from_out(y[u].y);
                 d[u].z *= lrelu_grad_from_out(y[u].z); d[u].w *= lrelu_grad_from_out(y[u].w);
             }
-            sa = f4add(sa, a[u]);
+            if (csa == 2) { if (m0 + 4 * u + kk < mend) sa = f4add(sa, d[u]); }      // column sums of pro(D): the bias gradient
+            else sa = f4add(sa, a[u]);
             const float av[4] = {a[u].x, a[u].y, a[u].z, a[u].w}, dv[4] = {d[u].x, d[u].y, d[u].z, d[u].w};
 #pragma unroll
             for (int ca = 0; ca < 4; ++ca)
@@ -442,14 +450,18 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const float* __restrict__ A,
     }
 }
 
+static int apply_v1_gy(const RowMap& rm, bool has_colsum) {
+    const int ntiles = (rm.M + 31) / 32;
+    int gy = (ntiles + 3) / 4;
+    if (rm.G == 1) gy = min(gy, has_colsum ? 128 : 1024);  // shared weight: with colsum keep the partial count low
+    else gy = min(gy, max(2, (768 + rm.G - 1) / rm.G));      // >= ~768 workgroups when the groups are few and long (N = 4096: 96 groups x 128 tiles)
+    return gy < 1 ? 1 : gy;
+}
+
 template <int C>
 static int launch_apply(const float* A, const float* A2, const float* W, long w_gstride, int transw, const float* bias,
                         const float* resid, const float* resid2, float* out, float* colsum, RowMap rm, int pro, int epi, hipStream_t st) {
-    const int ntiles = (rm.M + 31) / 32;
-    int gy = (ntiles + 3) / 4;
-    if (rm.G == 1) gy = min(gy, colsum ? 128 : 1024);  // shared weight: with colsum keep the atomics per address low
-    else gy = min(gy, max(2, (768 + rm.G - 1) / rm.G));      // >= ~768 workgroups when the groups are few and long (N = 4096: 96 groups x 128 tiles)
-    if (gy < 1) gy = 1;
+    const int gy = apply_v1_gy(rm, colsum != nullptr);
     dim3 grid(rm.G, gy), block(256);
     const size_t smem = (size_t)(C * C + 4 * Tile<C>::TILE_FLOATS) * sizeof(float);
 #define LAUNCH(P, E)                                                                                              \
@@ -476,6 +488,13 @@ static void raise_smem_limits() {
     hipFuncSetAttribute((const void*)apply_kernel<C, PRO_DPRE, EPI_PLAIN>, hipFuncAttributeMaxDynamicSharedMemorySize, smem);
     hipFuncSetAttribute((const void*)apply_kernel<C, PRO_NONE, EPI_ADD_DPRE>, hipFuncAttributeMaxDynamicSharedMemorySize, smem);
     hipFuncSetAttribute((const void*)apply_kernel<C, PRO_NONE, EPI_LRELU>, hipFuncAttributeMaxDynamicSharedMemorySize, smem);
+}
+
+// number of row-split partials gptst_apply writes per group into `colsum` (shape [nsplit][G][C]) at this shape
+extern "C" int gptst_apply_nsplit(int mode, int BT, int N, int C) {
+    RowMap rm = make_rowmap(mode, BT, N);
+    if (C == 64 && !g_apply_v1) { int tpw, gy; apply64_geometry(rm, true, tpw, gy); return gy; }
+    return apply_v1_gy(rm, true);
 }
 
 extern "C" int gptst_apply(const float* A, const float* A2, const float* W, int w_per_group, int transw,
@@ -518,11 +537,14 @@ extern "C" int gptst_wgrad(const float* A, const float* D, const float* D2, floa
     return wgrad_impl(A, D, D2, dW, mode, pro, BT, N, C, 0, stream);
 }
 
-// as gptst_wgrad, plus the column sums of A appended to every split: dW rows are C*C + C floats ([dW | sum_m A[m,:]])
-extern "C" int gptst_wgrad_colsum(const float* A, const float* D, const float* D2, float* dW, int mode, int pro, int BT, int N,
+// as gptst_wgrad, plus column sums appended to every split: dW rows are C*C + C floats, [dW | sum_m A[m,:]] (which = 1: the bias
+// gradient of a Linear whose OUTPUT gradient is A) or [dW | sum_m pro(D)[m,:]] (which = 2: the bias gradient next to a weight
+// gradient dW = A^T pro(D), e.g. hyperTem's b_bt).  C = 64.
+extern "C" int gptst_wgrad_colsum(const float* A, const float* D, const float* D2, float* dW, int mode, int pro, int which, int BT, int N,
                                   int C, void* stream) {
     if (C != 64) return GPTST_ESHAPE;
-    return wgrad_impl(A, D, D2, dW, mode, pro, BT, N, C, 1, stream);
+    if (which != 1 && which != 2) return GPTST_EARG;
+    return wgrad_impl(A, D, D2, dW, mode, pro, BT, N, C, which, stream);
 }
 
 static int wgrad_impl(const float* A, const float* D, const float* D2, float* dW, int mode, int pro, int BT, int N, int C, int csa,

@@ -33,6 +33,28 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 #define SB() __builtin_amdgcn_sched_barrier(0)
 #endif
 
+// Deterministic mode (gptst_set_deterministic): the few reductions that still end in float atomics (embedding gradients of the pool
+// jobs, time-feature weight gradients) switch to single-owner kernels with a fixed summation order, so that two runs of a step are
+// bit-identical.  Everything else is order-fixed by construction (partials + ordered folds, "last workgroup folds" for scalars).
+extern thread_local int g_deterministic;
+
+// "last workgroup folds": every workgroup publishes its partial, takes a ticket, and the one that draws the last ticket sums all
+// partials in index order — the result does not depend on which workgroup that is.  Returns true in the last workgroup (all threads),
+// after an agent-scope acquire; the caller then reads the partials with ld_agent().
+__device__ __forceinline__ bool last_block_arrives(unsigned* ticket, unsigned nblocks) {
+    __shared__ unsigned s_last;
+    __syncthreads();                                                 // all partial stores of this workgroup are issued
+    if (threadIdx.x == 0) {
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        s_last = (__hip_atomic_fetch_add(ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == nblocks - 1) ? 1u : 0u;
+        if (s_last) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+    }
+    __syncthreads();
+    return s_last != 0u;
+}
+__device__ __forceinline__ float ld_agent(const float* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+
 __device__ __forceinline__ float lrelu(float x) { return x > 0.f ? x : LRELU_SLOPE * x; }
 // derivative selected by the sign of the OUTPUT (slope > 0 keeps the sign; x == 0 -> slope, as ATen).
 __device__ __forceinline__ float lrelu_grad_from_out(float out) { return out > 0.f ? 1.f : LRELU_SLOPE; }

@@ -172,11 +172,12 @@ extern "C" int gptst_hypertem_fwd(const float* X, const float* G, const float* W
 // =====================================================================================================================
 // hyperTem backward, fused (everything except the weight gradient, which is grouped by (b,t) and stays in wgrad64_kernel):
 //   dPre = dOut * lrelu'(out)                               (LDS slab, 12 x 16 x C per workgroup = (sample, 16 nodes))
-//   dbias[b,t,:] += sum_n dPre                              (column sums of the slab, 11 atomics per address)
+//   dbias[tile][b,t,:] = sum_{n in tile} dPre               (column sums of the slab: one PARTIAL per node tile, plain stores)
 //   dR_t = dPre_t W_bt^T                                    MFMA 16x16x4 as  dR_t^T = W_bt dPre_t^T  so that W_bt (L2) is the
 //                                                           A operand with coalesced float4 rows; result overwrites the slab
 //   dX_u = dPre_u + sum_t G_n[t,u] dR_t                     VALU from the slab (dPre re-read from L2)
-//   dG_n[t,u] += sum_c dR_t[n,c] X_u[n,c]                   MFMA 16x16x4 per node, 32 atomics per address (one per sample)
+//   dG[b][n][t,u] = sum_c dR_t[n,c] X_u[n,c]                MFMA 16x16x4 per node: one PARTIAL per sample (gram_bwd sums them)
+// No atomics: every output element is written by exactly one lane, so the result does not depend on scheduling.
 // Replaces apply_kernel<TIME, dPre> + tmix_kernel<bwd> + tmix_dgraph_kernel (19 + 14 + 11 us, and the dR round trip).
 // =====================================================================================================================
 // Scheduling notes (measured): all global loads of a phase are issued as one batch into registers (a copy loop
@@ -235,8 +236,10 @@ __global__ __launch_bounds__(256, 2) void hypertem_bwd_kernel(const float* __res
         float* dt = Ds + t * NT * P;
         // bias gradient: column sums of dPre_t over the 16 nodes (lane = channel)
         float s = 0.f;
+        if (dbias != nullptr) {
 #pragma unroll
-        for (int r = 0; r < NT; ++r) s += dt[r * P + lane];
+            for (int r = 0; r < NT; ++r) s += dt[r * P + lane];
+        }
         float4 bq[C / 16];
 #pragma unroll
         for (int q = 0; q < C / 16; ++q) bq[q] = ld4(dt + j * P + 16 * q + 4 * kk);
@@ -259,7 +262,7 @@ __global__ __launch_bounds__(256, 2) void hypertem_bwd_kernel(const float* __res
         SB();
         if (t + 4 < HT_T && !(HT_DBG(dbg) & 128)) HT_LOAD_WT(t + 4);
         SB();
-        if (!(HT_DBG(dbg) & 4)) atomicAdd(dbias + g * C + lane, s);
+        if (dbias != nullptr && !(HT_DBG(dbg) & 4)) dbias[((size_t)tile * B * HT_T + g) * C + lane] = s;   // partial of this node tile
         // D reg r: row i = it*16 + kk*4 + r (input channel), col j = node  ->  dR_t[node][channel] over the slab
 #pragma unroll
         for (int it = 0; it < C / 16; ++it)
@@ -309,15 +312,17 @@ __global__ __launch_bounds__(256, 2) void hypertem_bwd_kernel(const float* __res
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
             const int t = kk * 4 + r, u = j;
-            if (t < HT_T && u < HT_T && !(HT_DBG(dbg) & 2)) atomicAdd(dG + (size_t)n * 144 + t * HT_T + u, acc[r]);
+            if (t < HT_T && u < HT_T && !(HT_DBG(dbg) & 2)) dG[((size_t)b * N + n) * 144 + t * HT_T + u] = acc[r];   // partial of sample b
         }
     }
 }
 
-// dbias (B*T, C) and dG (N, T, T) are ACCUMULATED (+=): zero them first.
+// dbias: (gptst_hypertem_ntiles(N) * B*T, C) node-tile partials;  dG: (B * N, T, T) per-sample partials — both fully written here.
+extern "C" int gptst_hypertem_ntiles(int N) { return (N + 15) / 16; }
+
 extern "C" int gptst_hypertem_bwd(const float* dOut, const float* Y, const float* X, const float* G, const float* Wbt, float* dX,
                                   float* dbias, float* dG, int B, int T, int N, int C, void* stream) {
-    if (!dOut || !Y || !X || !G || !Wbt || !dX || !dbias || !dG || T != HT_T) return GPTST_EARG;
+    if (!dOut || !Y || !X || !G || !Wbt || !dX || !dG || T != HT_T) return GPTST_EARG;      // dbias may be NULL (bias gradient from gptst_wgrad_colsum)
     if (C != 64) return GPTST_ESHAPE;
     const size_t smem = ht_smem(16);
     static int done = 0;

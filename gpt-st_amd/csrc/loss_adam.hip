@@ -3,7 +3,8 @@
 //           (lib/normalization.py:23-27):  p=(out*s+m)*M, y=(label*s+m)*M, keep = y > thresh, loss = mean_keep |y-p|
 //   kl    : 0.1 * KLDivLoss(sum)(log prob, eb) (Run.py:132, BasicTrainer.py:85) fused with the softmax backward of MLP_RL
 //   adam  : clip_grad_norm_(5) + Adam (BasicTrainer.py:95-97, Run.py:134) as ONE pass over a flat parameter buffer
-// stats (device float[8]): [0] sum |y-p| over kept cells, [1] kept count, [2] sum eb*(log eb - log prob), [3] sum g^2 (scaled)
+// stats (device float[8]): [0] sum |y-p| over kept cells, [1] kept count, [2] sum eb*(log eb - log prob), [3] extra sum g^2 terms in,
+// [4] total sum g^2 (scaled) out, [6] [7] tickets of the ordered folds in tails.hip
 // Everything stays on the device: the reference syncs on loss.item() and masked_select every step.
 #include "common.h"
 
@@ -83,8 +84,11 @@ __device__ __forceinline__ float seg_scale(const float* hyper, const float* stat
     return hyper[10];
 }
 
+#define GN_NB 256      // workgroups of gradnorm_kernel = partial sums in ws
+
+// ws[blk] = this workgroup's partial of sum (scale g)^2 — no atomics: adam_kernel folds the GN_NB partials in a fixed order
 __global__ __launch_bounds__(256) void gradnorm_kernel(const float* __restrict__ g, long nA, long nB, const float* __restrict__ hyper,
-                                                       float* __restrict__ stats) {
+                                                       const float* __restrict__ stats, float* __restrict__ ws) {
     // float4 loads, 4 in flight per thread (tensors are padded to 16 bytes, so nA % 4 == 0 and a float4 never straddles the
     // segment boundary); the first version walked scalars with one load in flight: 15 us for 4 MB whatever the grid size.
     __shared__ float red[4];
@@ -110,17 +114,27 @@ __global__ __launch_bounds__(256) void gradnorm_kernel(const float* __restrict__
     s = group_sum<64>(s);
     if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
     __syncthreads();
-    if (threadIdx.x == 0) atomicAdd(stats + 3, red[0] + red[1] + red[2] + red[3]);
+    if (threadIdx.x == 0) ws[blockIdx.x] = (red[0] + red[1]) + (red[2] + red[3]);
 }
 
+// stats[3] on entry: squared-norm contributions that are not in g on this rank (node-sharded runs add the other ranks' node-local
+// parts there; otherwise 0); on exit (written by workgroup 0): the total squared gradient norm.
 __global__ __launch_bounds__(256) void adam_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m,
                                                    float* __restrict__ v, long nA, long nB, const float* __restrict__ hyper,
-                                                   const float* __restrict__ stats) {
+                                                   float* __restrict__ stats, const float* __restrict__ ws, int nws) {
+    __shared__ float red[4];
+    {   // every workgroup folds the gradient-norm partials in the same fixed order
+        float s = (int)threadIdx.x < nws ? ws[threadIdx.x] : 0.f;
+        s = group_sum<64>(s);
+        if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
+        __syncthreads();
+    }
+    const float gsq = stats[3] + ((red[0] + red[1]) + (red[2] + red[3]));
     const bool actB = hyper[8] != 0.f;
     const long n = nA + (actB ? nB : 0);
     const float b1 = hyper[4], b2 = hyper[5], eps = hyper[6], maxn = hyper[7];
     float clip = 1.f;
-    if (maxn > 0.f) clip = fminf(1.f, maxn / (sqrtf(stats[3]) + 1e-6f));          // clip_grad_norm_
+    if (maxn > 0.f) clip = fminf(1.f, maxn / (sqrtf(gsq) + 1e-6f));               // clip_grad_norm_
     const float sa = seg_scale(hyper, stats, true) * clip, sb = seg_scale(hyper, stats, false) * clip;
     for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256) {
         const bool A = i < nA;
@@ -133,6 +147,9 @@ __global__ __launch_bounds__(256) void adam_kernel(float* __restrict__ p, const 
         p[i] = p[i] - step * (mi / denom);                     // param.addcdiv_(exp_avg, denom, -step_size)
         m[i] = mi; v[i] = vi;
     }
+    // (stats[3] is rewritten only after every workgroup has read it: the caller's next kernel boundary orders that — here the
+    // total goes to stats[4], which nobody reads inside this launch)
+    if (blockIdx.x == 0 && threadIdx.x == 0) stats[4] = gsq;
 }
 
 extern "C" int gptst_mae_fwd(const float* out, const float* src, int lda, const float* mask, float sigma, float mu, float thresh,
@@ -162,15 +179,18 @@ extern "C" int gptst_kl(const float* prob, const float* c, int rows, int N, int 
     return GPTST_OK;
 }
 
-// stats[3] must be zero on entry (the caller zeroes the stats block once per step)
+extern "C" int gptst_clip_adam_ws_floats(void) { return GN_NB; }
+
+// ws: gptst_clip_adam_ws_floats() floats of scratch.  stats[3]: extra squared-norm terms (0 unless node-sharded), stats[4] <- the
+// total squared gradient norm (after scaling, before clipping).  No atomics: the norm is folded in a fixed order.
 extern "C" int gptst_clip_adam(float* p, const float* g, float* m, float* v, long nA, long nB, const float* hyper, float* stats,
-                               void* stream) {
-    if (!p || !g || !m || !v || !hyper || !stats) return GPTST_EARG;
+                               float* ws, void* stream) {
+    if (!p || !g || !m || !v || !hyper || !stats || !ws) return GPTST_EARG;
     long n = nA + nB;
     int nb = (int)((n + 255) / 256); if (nb > 1024) nb = 1024;
-    const int nbn = nb > 256 ? 256 : nb;     // gradnorm ends in ONE same-address atomic per workgroup: keep them few
-    hipLaunchKernelGGL(gradnorm_kernel, dim3(nbn), dim3(256), 0, (hipStream_t)stream, g, nA, nB, hyper, stats);
-    hipLaunchKernelGGL(adam_kernel, dim3(nb), dim3(256), 0, (hipStream_t)stream, p, g, m, v, nA, nB, hyper, stats);
+    const int nbn = nb > GN_NB ? GN_NB : nb;
+    hipLaunchKernelGGL(gradnorm_kernel, dim3(nbn), dim3(256), 0, (hipStream_t)stream, g, nA, nB, hyper, (const float*)stats, ws);
+    hipLaunchKernelGGL(adam_kernel, dim3(nb), dim3(256), 0, (hipStream_t)stream, p, g, m, v, nA, nB, hyper, stats, (const float*)ws, nbn);
     GPTST_CHECK_LAUNCH();
     return GPTST_OK;
 }

@@ -33,7 +33,7 @@ struct PJob {
     const float* pool;     // FWD / BWD_EMB: (K, cols)
     float* out;            // FWD: (R, cols);  BWD_POOL: dpool (K, cols) +=;  BWD_EMB: demb (R, K) +=
     int R, K, cols, nsplit;
-    int blk0, kind, nbx, pad;
+    int blk0, kind, nbx, ldx;   // ldx: row stride of x (>= cols: x may be a column window of a wider matrix)
 };
 struct PJobs { PJob j[PJ_MAX]; int n; };
 
@@ -109,7 +109,7 @@ __device__ __forceinline__ void pj_bwd_pool(const PJob& a, int bx, float (*fold)
         for (int u = 0; u < NU; ++u) {
             const int row = min(rb + 4 * u + kk, r1 - 1);
             av[u] = emb[(size_t)(row % R) * K + min(j, K - 1)];
-            b[u] = ldv<V>(dW + (size_t)row * cols + cl);
+            b[u] = ldv<V>(dW + (size_t)row * a.ldx + cl);
         }
         SB();
 #pragma unroll
@@ -142,20 +142,19 @@ __device__ __forceinline__ void pj_bwd_pool(const PJob& a, int bx, float (*fold)
 // float4s at c + 4kk so one load pair feeds four MFMA steps (the usual k-permutation); the MFMA does the reduction over the
 // columns that a VALU version would have to do with cross-lane shuffles.  A wave owns (16-row tile, 256-column chunk); several
 // jobs (and chunks) add into one demb, so the final add is an atomic.   blocks: (ceil(R/16), ceil(chunks/4))
+// accumulate one 256-column chunk of one job into acc (D[i = row][j = k])
 template <int V>
-__device__ __forceinline__ void pj_bwd_emb(const PJob& a, int bx, int by) {
+__device__ __forceinline__ void pj_emb_accum(const PJob& a, int bx, int chunk, f32x4& acc) {
     constexpr int chunk_cols = 256;
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int lane = threadIdx.x & 63;
     const int i = lane & 15, kk = lane >> 4;
     const int R = a.R, K = a.K;
     const int row = bx * 16 + i;
     const float* __restrict__ w = a.x;
     const float* __restrict__ pl = a.pool;
-    float* __restrict__ demb = a.out;
-    const int cc = a.cols, ns = a.nsplit;
-    const int cbeg = (by * 4 + wave) * chunk_cols, cend = min(cc, cbeg + chunk_cols);
+    const int cc = a.cols, ns = a.nsplit, ldx = a.ldx;
+    const int cbeg = chunk * chunk_cols, cend = min(cc, cbeg + chunk_cols);
     if (cbeg >= cc) return;
-    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
     if (V == 4) {
         // UC column steps (16 columns each) per batch, all loads issued before the MFMAs (clamped, not predicated)
         constexpr int UC = 8;
@@ -166,14 +165,14 @@ __device__ __forceinline__ void pj_bwd_emb(const PJob& a, int bx, int by) {
 #pragma unroll
             for (int u = 0; u < UC; ++u) {
                 const int c = min(c0 + 16 * u + 4 * kk, cc - 4);
-                av[u] = ld4(w + (size_t)rowc * cc + c);
+                av[u] = ld4(w + (size_t)rowc * ldx + c);
                 b[u] = ld4(pl + (size_t)ic * cc + c);
             }
             for (int s = 1; s < ns; ++s) {
 #pragma unroll
                 for (int u = 0; u < UC; ++u) {
                     const int c = min(c0 + 16 * u + 4 * kk, cc - 4);
-                    av[u] = f4add(av[u], ld4(w + ((size_t)s * R + rowc) * cc + c));
+                    av[u] = f4add(av[u], ld4(w + ((size_t)s * R + rowc) * ldx + c));
                 }
             }
             SB();
@@ -192,17 +191,51 @@ __device__ __forceinline__ void pj_bwd_emb(const PJob& a, int bx, int by) {
         for (int c = cbeg + kk; c < cend + kk; c += 4) {
             float av = 0.f, b = 0.f;
             if (c < cend) {
-                if (row < R) for (int s = 0; s < ns; ++s) av += w[((size_t)s * R + row) * cc + c];
+                if (row < R) for (int s = 0; s < ns; ++s) av += w[((size_t)s * R + row) * ldx + c];
                 if (i < K) b = pl[(size_t)i * cc + c];
             }
             acc = __builtin_amdgcn_mfma_f32_16x16x4f32(av, b, acc, 0, 0, 0);
         }
     }
+}
+
+template <int V>
+__device__ __forceinline__ void pj_bwd_emb(const PJob& a, int bx, int by) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int i = lane & 15, kk = lane >> 4;
+    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+    pj_emb_accum<V>(a, bx, by * 4 + wave, acc);
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
         const int orow = bx * 16 + kk * 4 + r;      // D reg r: row (l>>4)*4 + r, col l&15
-        if (orow < R && i < K) atomicAdd(demb + (size_t)orow * K + i, acc[r]);
+        if (orow < a.R && i < a.K && (by * 4 + wave) * 256 < a.cols) atomicAdd(a.out + (size_t)orow * a.K + i, acc[r]);
     }
+}
+
+// Deterministic form (gptst_set_deterministic): ALL jobs of the table add into the same demb; one workgroup owns a 16-row tile of it,
+// walks every 256-column chunk of every job (chunks dealt round-robin to its 4 waves, each accumulating in order), folds the waves in
+// a fixed order and updates demb with a plain read-modify-write.
+__global__ __launch_bounds__(256) void pool_emb_det_kernel(PJobs t) {
+    __shared__ float fold[4][16][17];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int i = lane & 15, kk = lane >> 4;
+    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+    int chunk_id = 0;
+    for (int q = 0; q < t.n; ++q) {
+        const PJob& a = t.j[q];
+        const bool v4 = ((a.cols | a.ldx) & 3) == 0;
+        const int nch = (a.cols + 255) / 256;
+        for (int ch = 0; ch < nch; ++ch, ++chunk_id) {
+            if ((chunk_id & 3) != wave) continue;
+            if (v4) pj_emb_accum<4>(a, blockIdx.x, ch, acc); else pj_emb_accum<1>(a, blockIdx.x, ch, acc);
+        }
+    }
+#pragma unroll
+    for (int r = 0; r < 4; ++r) fold[wave][kk * 4 + r][i] = acc[r];
+    __syncthreads();
+    const int R = t.j[0].R, K = t.j[0].K;
+    const int rr = threadIdx.x >> 4, k = threadIdx.x & 15, orow = blockIdx.x * 16 + rr;
+    if (orow < R && k < K) t.j[0].out[(size_t)orow * K + k] += (fold[0][rr][k] + fold[1][rr][k]) + (fold[2][rr][k] + fold[3][rr][k]);
 }
 
 __global__ __launch_bounds__(256) void pool_jobs_kernel(PJobs t, int fwd_rows) {
@@ -211,7 +244,7 @@ __global__ __launch_bounds__(256) void pool_jobs_kernel(PJobs t, int fwd_rows) {
     for (int q = 1; q < t.n; ++q) if ((int)blockIdx.x >= t.j[q].blk0) p = q;      // uniform scan of the (scalar) table
     const PJob& a = t.j[p];
     const int rel = blockIdx.x - a.blk0, bx = rel % a.nbx, by = rel / a.nbx;
-    const bool v4 = (a.cols & 3) == 0;
+    const bool v4 = ((a.cols | a.ldx) & 3) == 0;
     if (a.kind == PJ_FWD) { if (v4) pj_fwd<4>(a, bx, by, fwd_rows, &fold[0][0][0]); else pj_fwd<1>(a, bx, by, fwd_rows, &fold[0][0][0]); }
     else if (a.kind == PJ_BWD_POOL) { if (v4) pj_bwd_pool<4>(a, bx, fold); else pj_bwd_pool<1>(a, bx, fold); }
     else { if (v4) pj_bwd_emb<4>(a, bx, by); else pj_bwd_emb<1>(a, bx, by); }
@@ -220,7 +253,7 @@ __global__ __launch_bounds__(256) void pool_jobs_kernel(PJobs t, int fwd_rows) {
 // Host side: fill one job and its block range; returns the number of blocks.
 thread_local int g_pg_rows = PG_ROWS;            // experiments: gptst_tune(1, rows)
 static int pj_blocks(PJob& j) {
-    const int V = (j.cols & 3) ? 1 : 4;
+    const int V = ((j.cols | j.ldx) & 3) ? 1 : 4;
     if (j.kind == PJ_FWD) { j.nbx = ((j.cols + V - 1) / V + 255) / 256; return j.nbx * ((j.R + g_pg_rows - 1) / g_pg_rows); }
     if (j.kind == PJ_BWD_POOL) { j.nbx = (j.cols + 16 * V - 1) / (16 * V); return j.nbx; }
     j.nbx = (j.R + 15) / 16;
@@ -235,7 +268,9 @@ static int pj_launch(PJobs& t, hipStream_t st) {
         if ((j.kind == PJ_FWD || j.kind == PJ_BWD_POOL) && !j.emb) return GPTST_EARG;
         if ((j.kind == PJ_BWD_POOL || j.kind == PJ_BWD_EMB) && !j.x) return GPTST_EARG;
         if ((j.kind == PJ_FWD || j.kind == PJ_BWD_EMB) && !j.pool) return GPTST_EARG;
-        j.blk0 = nb; j.pad = 0;
+        j.blk0 = nb;
+        if (j.ldx <= 0) j.ldx = j.cols;
+        if (j.ldx < j.cols) return GPTST_EARG;
         nb += pj_blocks(j);
     }
     if (nb == 0) return GPTST_OK;
@@ -247,19 +282,40 @@ static int pj_launch(PJobs& t, hipStream_t st) {
 // Generic entry: njobs problems of any kind in as few launches as the 4 KB argument block allows (PJ_MAX jobs each).
 // A BWD_EMB job must not share a launch with a job that produces its input; callers order dependent work into separate calls.
 extern "C" int gptst_pool_jobs(int njobs, const int* kind, const void* const* emb, const void* const* x, const void* const* pool,
-                               const void* const* out, const int* R, const int* K, const int* cols, const int* nsplit, void* stream) {
+                               const void* const* out, const int* R, const int* K, const int* cols, const int* nsplit, const int* ldx,
+                               void* stream) {
     if (njobs < 0 || (njobs && (!kind || !emb || !x || !pool || !out || !R || !K || !cols || !nsplit))) return GPTST_EARG;
-    for (int p0 = 0; p0 < njobs; p0 += PJ_MAX) {
-        PJobs t;
-        t.n = njobs - p0 < PJ_MAX ? njobs - p0 : PJ_MAX;
-        for (int q = 0; q < t.n; ++q) {
-            const int p = p0 + q;
-            if (kind[p] < PJ_FWD || kind[p] > PJ_BWD_EMB) return GPTST_EARG;
-            t.j[q] = PJob{(const float*)emb[p], (const float*)x[p], (const float*)pool[p], (float*)out[p], R[p], K[p], cols[p], nsplit[p],
-                          0, kind[p], 0, 0};
+    for (int p = 0; p < njobs; ++p) if (kind[p] < PJ_FWD || kind[p] > PJ_BWD_EMB) return GPTST_EARG;
+    auto job = [&](int p) {
+        return PJob{(const float*)emb[p], (const float*)x[p], (const float*)pool[p], (float*)out[p], R[p], K[p], cols[p], nsplit[p],
+                    0, kind[p], 0, ldx ? ldx[p] : 0};
+    };
+    const bool det = g_deterministic != 0;
+    PJobs t; t.n = 0;
+    for (int p = 0; p < njobs; ++p) {                            // table launches (in deterministic mode: everything but the kind-2 jobs)
+        if (det && kind[p] == PJ_BWD_EMB) continue;
+        t.j[t.n++] = job(p);
+        if (t.n == PJ_MAX) { const int rc = pj_launch(t, (hipStream_t)stream); if (rc) return rc; t.n = 0; }
+    }
+    if (t.n) { const int rc = pj_launch(t, (hipStream_t)stream); if (rc) return rc; }
+    if (!det) return GPTST_OK;
+    // deterministic embedding gradients: one launch per distinct demb, all its jobs in one table, one workgroup per 16-row tile
+    for (int p = 0; p < njobs; ++p) {
+        if (kind[p] != PJ_BWD_EMB) continue;
+        bool seen = false;
+        for (int q = 0; q < p; ++q) if (kind[q] == PJ_BWD_EMB && out[q] == out[p]) seen = true;
+        if (seen) continue;
+        PJobs g; g.n = 0;
+        for (int q = p; q < njobs; ++q) {
+            if (kind[q] != PJ_BWD_EMB || out[q] != out[p]) continue;
+            if (g.n == PJ_MAX || R[q] != R[p] || K[q] != K[p]) return GPTST_EARG;
+            PJob j = job(q);
+            if (!j.x || !j.pool || !j.out || j.R <= 0 || j.K <= 0 || j.K > PG_MAXK || j.cols <= 0 || j.nsplit <= 0) return GPTST_EARG;
+            if (j.ldx <= 0) j.ldx = j.cols;
+            g.j[g.n++] = j;
         }
-        const int rc = pj_launch(t, (hipStream_t)stream);
-        if (rc) return rc;
+        hipLaunchKernelGGL(pool_emb_det_kernel, dim3((R[p] + 15) / 16), dim3(256), 0, (hipStream_t)stream, g);
+        GPTST_CHECK_LAUNCH();
     }
     return GPTST_OK;
 }

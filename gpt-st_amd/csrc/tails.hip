@@ -9,8 +9,10 @@
 //       a = w (prob sum_h eb - eb);  stats[2] += sum eb (log eb - log prob);  d_h2 = a W3;  partial (gW3, gb3) = (a^T h2, sum a)
 //                                                                          was kl, lin_in, rowouter x2
 // Layout as small.hip: C/4 lanes per row (float4 columns), 16 row slots per workgroup; TL_NB persistent workgroups walk contiguous
-// row chunks, keep the weight-gradient partials in registers and fold them through LDS once at the end: part[blk][J*C + J]
-// (the caller sums the TL_NB partials into [gW | gb] with one bwd_pool job).  C = 64, J <= TL_MAXJ; other shapes use the unfused ops.
+// row chunks, keep the weight-gradient partials in registers and fold them through LDS once at the end: part[blk][J*C + J + 2]
+// (the caller sums the TL_NB partials of [gW | gb] with one bwd_pool job over the first J*C + J columns; the last two columns carry
+// the workgroup's loss statistics, which the LAST workgroup to finish folds in index order into stats: no float atomics, the
+// result does not depend on scheduling).  C = 64, J <= TL_MAXJ; other shapes use the unfused ops.
 #include "common.h"
 
 #define TL_NB 512
@@ -103,7 +105,8 @@ __global__ __launch_bounds__(256) void tail_kernel(TailArgs t) {
       }
     }
     // ---- fold the 16 row slots of the workgroup, then the loss statistics ----
-    float* mine = t.part + (size_t)blockIdx.x * (J * C + J);
+    const int PS = J * C + J + 2;                                     // row stride of part
+    float* mine = t.part + (size_t)blockIdx.x * PS;
 #pragma unroll
     for (int j = 0; j < TL_MAXJ; ++j) {
         if (j >= J) continue;                                         // uniform
@@ -126,11 +129,21 @@ __global__ __launch_bounds__(256) void tail_kernel(TailArgs t) {
     if ((threadIdx.x & 63) == 0) { reds[0][threadIdx.x >> 6] = s0; reds[1][threadIdx.x >> 6] = s1; }
     __syncthreads();
     if (threadIdx.x == 0) {
-        if (KIND == 0) {
-            atomicAdd(t.stats + 0, reds[0][0] + reds[0][1] + reds[0][2] + reds[0][3]);
-            atomicAdd(t.stats + 1, reds[1][0] + reds[1][1] + reds[1][2] + reds[1][3]);
-        } else {
-            atomicAdd(t.stats + 2, reds[0][0] + reds[0][1] + reds[0][2] + reds[0][3]);
+        mine[J * C + J + 0] = (reds[0][0] + reds[0][1]) + (reds[0][2] + reds[0][3]);
+        mine[J * C + J + 1] = (reds[1][0] + reds[1][1]) + (reds[1][2] + reds[1][3]);
+    }
+    unsigned* ticket = reinterpret_cast<unsigned*>(t.stats + (KIND == 0 ? 6 : 7));       // zero on entry, reset below
+    if (!last_block_arrives(ticket, gridDim.x)) return;
+    if (threadIdx.x < 64) {                                            // one wave: lane-strided, then a fixed butterfly
+        float a0 = 0.f, a1 = 0.f;
+        for (unsigned blk = threadIdx.x; blk < gridDim.x; blk += 64) {
+            a0 += ld_agent(t.part + (size_t)blk * PS + J * C + J + 0);
+            a1 += ld_agent(t.part + (size_t)blk * PS + J * C + J + 1);
+        }
+        a0 = group_sum<64>(a0); a1 = group_sum<64>(a1);
+        if (threadIdx.x == 0) {
+            if (KIND == 0) { t.stats[0] += a0; t.stats[1] += a1; } else { t.stats[2] += a0; }
+            *ticket = 0u;
         }
     }
 }

@@ -62,7 +62,10 @@ __device__ __forceinline__ void tf_fwd_body(const TfParams& p, const float* __re
     if (valid) out[(size_t)r * E + e] = h;
 }
 
-template <int E>
+template <bool DET> __device__ __forceinline__ void tf_add(float* p, float v) { if (DET) *p += v; else atomicAdd(p, v); }
+
+// DET: this workgroup is the only one that touches the job's gradients (it walks all row blocks itself): plain += in a fixed order
+template <int E, bool DET>
 __device__ __forceinline__ void tf_bwd_body(const TfParams& p, const TfGrads& g, const float* __restrict__ tidx,
                                             const float* __restrict__ dout, int rows, int K, int blk, float* __restrict__ shraw) {
     constexpr int ROWS = TfCfg<E>::ROWS;
@@ -104,17 +107,17 @@ __device__ __forceinline__ void tf_bwd_body(const TfParams& p, const TfGrads& g,
         float s = 0.f;
         for (int rr = 0; rr < nrow; ++rr) s = fmaf(sh[ga][rr][eo], sh[gb][rr][i], s);
         float* dst = which == 0 ? g.w3 : (which == 1 ? g.w2 : g.w1);
-        atomicAdd(dst + eo * E + i, s);
+        tf_add<DET>(dst + eo * E + i, s);
     }
     for (int idx = tid; idx < 4 * E; idx += 256) {
         const int which = idx / E, eo = idx % E;
         const int ga = which == 0 ? 3 : (which == 1 ? 4 : (which == 2 ? 5 : 6));
         float s = 0.f;
         for (int rr = 0; rr < nrow; ++rr) s += sh[ga][rr][eo];
-        if (which == 0) atomicAdd(g.b3 + eo, s);
-        else if (which == 1) atomicAdd(g.b2 + eo, s);
-        else if (which == 2) atomicAdd(g.b1 + eo, s);
-        else { atomicAdd(g.bd + eo, s); atomicAdd(g.bw + eo, s); }
+        if (which == 0) tf_add<DET>(g.b3 + eo, s);
+        else if (which == 1) tf_add<DET>(g.b2 + eo, s);
+        else if (which == 2) tf_add<DET>(g.b1 + eo, s);
+        else { tf_add<DET>(g.bd + eo, s); tf_add<DET>(g.bw + eo, s); }
     }
     // input Linears: dWd[e][k] = sum_r z0[e] * day[r,k]; dWw likewise
     for (int idx = tid; idx < 2 * E * K; idx += 256) {
@@ -122,7 +125,7 @@ __device__ __forceinline__ void tf_bwd_body(const TfParams& p, const TfGrads& g,
         float s = 0.f;
         for (int rr = 0; rr < nrow; ++rr)
             s = fmaf(sh[6][rr][eo], tidx[((size_t)(blk * ROWS + rr) * K + k) * 2 + ch], s);
-        atomicAdd((ch == 0 ? g.wd : g.ww) + eo * K + k, s);
+        tf_add<DET>((ch == 0 ? g.wd : g.ww) + eo * K + k, s);
     }
 }
 
@@ -131,16 +134,20 @@ __device__ __forceinline__ void tf_bwd_body(const TfParams& p, const TfGrads& g,
 struct TfJob { TfParams p; TfGrads g; const float* tidx; float* out; const float* dout; int rows, K, E, blk0; };
 struct TfJobs { TfJob j[TF_MAXJ]; int n; };
 
+// BWD: 0 forward, 1 backward (workgroup per row block, atomics), 2 deterministic backward (ONE workgroup per job walks its blocks)
 template <int BWD>
 __global__ __launch_bounds__(256) void timefeat_jobs_kernel(TfJobs t) {
     __shared__ float shraw[TF_SH_FLOATS];
     int q = 0;
-    for (int i = 1; i < t.n; ++i) if ((int)blockIdx.x >= t.j[i].blk0) q = i;
+    if (BWD == 2) q = blockIdx.x;
+    else for (int i = 1; i < t.n; ++i) if ((int)blockIdx.x >= t.j[i].blk0) q = i;
     const TfJob& a = t.j[q];
     const int blk = blockIdx.x - a.blk0;
+    const int nblk = (a.rows + 256 / a.E - 1) / (256 / a.E);
 #define TF_CASE(EE)                                                                              \
     case EE:                                                                                     \
-        if (BWD) tf_bwd_body<EE>(a.p, a.g, a.tidx, a.dout, a.rows, a.K, blk, shraw);             \
+        if (BWD == 2) { for (int b2 = 0; b2 < nblk; ++b2) { tf_bwd_body<EE, true>(a.p, a.g, a.tidx, a.dout, a.rows, a.K, b2, shraw); __syncthreads(); } } \
+        else if (BWD == 1) tf_bwd_body<EE, false>(a.p, a.g, a.tidx, a.dout, a.rows, a.K, blk, shraw); \
         else tf_fwd_body<EE>(a.p, a.tidx, a.out, a.rows, a.K, blk, shraw);                       \
         break;
     switch (a.E) { TF_CASE(2) TF_CASE(4) TF_CASE(8) TF_CASE(16) default: break; }
@@ -157,7 +164,8 @@ static int tf_launch(TfJobs& t, int bwd, hipStream_t st) {
         a.blk0 = nb;
         nb += (a.rows + rows_per - 1) / rows_per;
     }
-    if (bwd) hipLaunchKernelGGL(timefeat_jobs_kernel<1>, dim3(nb), dim3(256), 0, st, t);
+    if (bwd && g_deterministic) hipLaunchKernelGGL(timefeat_jobs_kernel<2>, dim3(t.n), dim3(256), 0, st, t);
+    else if (bwd) hipLaunchKernelGGL(timefeat_jobs_kernel<1>, dim3(nb), dim3(256), 0, st, t);
     else hipLaunchKernelGGL(timefeat_jobs_kernel<0>, dim3(nb), dim3(256), 0, st, t);
     GPTST_CHECK_LAUNCH();
     return GPTST_OK;

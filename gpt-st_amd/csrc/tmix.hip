@@ -22,17 +22,25 @@ __global__ __launch_bounds__(256) void gram_fwd_kernel(const float* __restrict__
 }
 
 // ---- dA[n,h,t] = sum_u A[n,h,u] (dG[n,t,u] + dG[n,u,t]) -----------------------------------------------------
+// one workgroup per (layer, node): the nsplit partial graphs dG[l][s][n] are summed in a fixed order into LDS first
 __global__ __launch_bounds__(256) void gram_bwd_kernel(const float* __restrict__ A, const float* __restrict__ dG,
-                                                       float* __restrict__ dA, int N, int Hm) {
-    const int idx = blockIdx.x * 256 + threadIdx.x;
-    if (idx >= N * Hm * TT) return;
-    const int n = idx / (Hm * TT), h = (idx / TT) % Hm, t = idx % TT;
-    const float* a = A + ((size_t)n * Hm + h) * TT;
-    const float* g = dG + (size_t)n * TT2;
+                                                       float* __restrict__ dA, int N, int Hm, int nsplit) {
+    __shared__ float gs[TT2];
+    const int gn = blockIdx.x, l = gn / N, n = gn % N;
+    if (threadIdx.x < TT2) {
+        const float* g = dG + ((size_t)l * nsplit * N + n) * TT2 + threadIdx.x;
+        float s = 0.f;
+        for (int sp = 0; sp < nsplit; ++sp) s += g[(size_t)sp * N * TT2];
+        gs[threadIdx.x] = s;
+    }
+    __syncthreads();
+    if (threadIdx.x >= Hm * TT) return;
+    const int h = threadIdx.x / TT, t = threadIdx.x % TT;
+    const float* a = A + ((size_t)gn * Hm + h) * TT;
     float s = 0.f;
 #pragma unroll
-    for (int u = 0; u < TT; ++u) s = fmaf(a[u], g[t * TT + u] + g[u * TT + t], s);
-    dA[idx] = s;
+    for (int u = 0; u < TT; ++u) s = fmaf(a[u], gs[t * TT + u] + gs[u * TT + t], s);
+    dA[((size_t)gn * Hm + h) * TT + t] = s;
 }
 
 // ---- out[b,t,n,:] = sum_u G[n,t,u] X[b,u,n,:]  (+ dOut * lrelu'(Y) when ADD_DPRE: the residual branch of backward) --
@@ -122,9 +130,10 @@ extern "C" int gptst_gram_fwd(const float* A, float* G, int N, int Hm, void* str
     return GPTST_OK;
 }
 
-extern "C" int gptst_gram_bwd(const float* A, const float* dG, float* dA, int N, int Hm, void* stream) {
-    if (!A || !dG || !dA) return GPTST_EARG;
-    hipLaunchKernelGGL(gram_bwd_kernel, dim3((N * Hm * TT + 255) / 256), dim3(256), 0, (hipStream_t)stream, A, dG, dA, N, Hm);
+// A (L*N, Hm, T), dG (L, nsplit, N, T, T) partial graph gradients (summed here in a fixed order), dA (L*N, Hm, T)
+extern "C" int gptst_gram_bwd(const float* A, const float* dG, float* dA, int L, int N, int Hm, int nsplit, void* stream) {
+    if (!A || !dG || !dA || L <= 0 || N <= 0 || nsplit <= 0 || Hm * TT > 256) return GPTST_EARG;
+    hipLaunchKernelGGL(gram_bwd_kernel, dim3(L * N), dim3(256), 0, (hipStream_t)stream, A, dG, dA, N, Hm, nsplit);
     GPTST_CHECK_LAUNCH();
     return GPTST_OK;
 }

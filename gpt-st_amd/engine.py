@@ -114,8 +114,9 @@ class Reductions:
         self.side = side
         self.held = []
 
-    def gram(self, A, dG, dA):
-        self.grams.append((A, dG, dA))
+    def gram(self, A, dG, dA, N, nsG):
+        """A (L*N,Hm,T), dG (L, nsG, N, T, T) partial graph gradients, dA (L*N,Hm,T) output"""
+        self.grams.append((A, dG, dA, N, nsG))
 
     def timefeat(self, p, g, pfx, tidx, dout, spg=False):
         B, T = tidx.shape[0], tidx.shape[1]
@@ -139,15 +140,14 @@ class Reductions:
     def _run(self, tidx):
         gr, self.grams = sorted(self.grams, key=lambda t: t[0].data_ptr()), []
         while gr:                                   # adjacent (A, dG, dA) triples (both STHCNs of a step) share one launch
-            A, dG, dA = gr.pop(0)
+            A, dG, dA, N, nsG = gr.pop(0)
             while gr and gr[0][0].data_ptr() == A.data_ptr() + 4 * A.numel() and gr[0][1].data_ptr() == dG.data_ptr() + 4 * dG.numel() \
-                    and gr[0][2].data_ptr() == dA.data_ptr() + 4 * dA.numel():
-                A2, dG2, dA2 = gr.pop(0)
-                n = A.shape[0] + A2.shape[0]
-                A = torch.as_strided(A, (n,) + tuple(A.shape[1:]), A.stride())
-                dG = torch.as_strided(dG, (n,) + tuple(dG.shape[1:]), dG.stride())
-                dA = torch.as_strided(dA, (n,) + tuple(dA.shape[1:]), dA.stride())
-            ops.gram_bwd(A, dG, out=dA)
+                    and gr[0][2].data_ptr() == dA.data_ptr() + 4 * dA.numel() and gr[0][3:] == (N, nsG):
+                A2, dG2, dA2 = gr.pop(0)[:3]
+                A = torch.as_strided(A, (A.shape[0] + A2.shape[0],) + tuple(A.shape[1:]), A.stride())
+                dG = torch.as_strided(dG, (dG.shape[0] + dG2.shape[0],) + tuple(dG.shape[1:]), dG.stride())
+                dA = torch.as_strided(dA, (dA.shape[0] + dA2.shape[0],) + tuple(dA.shape[1:]), dA.stride())
+            ops.gram_bwd(A, dG, out=dA, layers=A.shape[0] // N, nsplit=nsG)
         self.jobs.launch()
         tf, self.tf = self.tf, []
         ops.timefeat_jobs_bwd(tf, tidx)
@@ -189,21 +189,30 @@ def hypertem_core_fwd(x, G, Wbt, bbt, dims):
     return out, (x, R, out, G, Wbt)
 
 
+def graph_grad_splits(dims):
+    """partial graph gradients per layer: the fused C = 64 backward writes one per sample, the unfused path one in total"""
+    return dims[0] if dims[3] == 64 else 1
+
+
 def hypertem_core_bwd(saved, dout, dG_out, dims):
-    """-> dx, (dWbt, nsplit, dbias); dG is written into dG_out (N,T,T)."""
+    """-> dx, (dWbt, nsplit, (dbias partials, their count)); the graph-gradient partials are written into dG_out (nsG, N, T, T)."""
     B, T, N, C = dims
     x, R, out, G, Wbt = saved
     BT = B * T
-    dbias = _zeros(x, BT, C)
-    dWbt, ns = _wgrad_async(R, dout, MODE_TIME, BT, N, D2=out, pro=PRO_DPRE)
     if C == 64:
-        dx = ops.hypertem_bwd(dout.view(B, T, N, C), out.view(B, T, N, C), x.view(B, T, N, C), G, Wbt, dbias, dG_out).view(-1, C)
+        # the weight-gradient kernel also emits the bias gradient (column sums of dPre per (b,t)): rows [dW_bt | db_bt]
+        dWb, ns = _wgrad_async(R, dout, MODE_TIME, BT, N, D2=out, pro=PRO_DPRE, colsum_d=True)
+        dWbt, dbias, nsb = dWb[:, :C * C], dWb[:, C * C:], ns
+        dx, _, _ = ops.hypertem_bwd(dout.view(B, T, N, C), out.view(B, T, N, C), x.view(B, T, N, C), G, Wbt, dG=dG_out, want_dbias=False)
+        dx = dx.view(-1, C)
     else:
-        dR = ops.apply(dout, Wbt, MODE_TIME, BT, N, A2=out, transw=True, pro=PRO_DPRE, colsum=dbias)
+        dWbt, ns = _wgrad_async(R, dout, MODE_TIME, BT, N, D2=out, pro=PRO_DPRE)
+        dWbt = dWbt.view(ns * BT, C * C)
+        dR, dbias, nsb = ops.apply(dout, Wbt, MODE_TIME, BT, N, A2=out, transw=True, pro=PRO_DPRE, colsum=True)
         dx = ops.tmix(dR.view(B, T, N, C), G, dOut=dout.view(B, T, N, C), Y=out.view(B, T, N, C)).view(-1, C)
         dG_out.zero_()
-        ops.tmix_dgraph(dR.view(B, T, N, C), x.view(B, T, N, C), out=dG_out)
-    return dx, (dWbt, ns, dbias)
+        ops.tmix_dgraph(dR.view(B, T, N, C), x.view(B, T, N, C), out=dG_out[0])
+    return dx, (dWbt, ns, (dbias, nsb))
 
 
 # ---- cap (GPTST.py:100-141) ----------------------------------------------------------------------------------------
@@ -223,8 +232,7 @@ def cap_core_bwd(p, g, pfx, saved, dout, dims, HS, HT, red):
     B, T, N, C = dims
     x, out, rec, c, s, v, Ht, Rt, dyn, Wn = saved
     BT, dev = B * T, x.device
-    dbn = _zeros(x, N, C)
-    drec = ops.apply(dout, Wn, MODE_NODE, BT, N, A2=out, transw=True, pro=PRO_DPRE, colsum=dbn)
+    drec, dbn, nsb = ops.apply(dout, Wn, MODE_NODE, BT, N, A2=out, transw=True, pro=PRO_DPRE, colsum=True)      # dbn: (nsb*N, C) partials
     dWn, ns = _wgrad_async(rec, dout, MODE_NODE, BT, N, D2=out, pro=PRO_DPRE)
     dc1, dv = ops.cap_rec_bwd(drec, c, v, reduce_nodes=CTX.NODE_REDUCE)
     dS, ddyn = ops.cap_cross_bwd(dv, s, Rt, Ht, dyn, p[pfx + "mask_template"], B, T, HS, HT)
@@ -241,7 +249,7 @@ def cap_core_bwd(p, g, pfx, saved, dout, dims, HS, HT, red):
         dWp, ns2 = ops.wgrad(dY, x, MODE_SHARED, BT, N)
         red.jobs.bwd_pool(_ones(dev), dWp.view(ns2, C * C), gw.view(1, C * C), nsplit=ns2)
         ops.rowouter(None, 0, 0, dY, None, 0, csum=gb)
-    return dx, (dWn, ns, dbn, ddyn, dlogit)
+    return dx, (dWn, ns, (dbn, nsb), ddyn, dlogit)
 
 
 _ONES = {}
@@ -265,14 +273,13 @@ def condlin_bwd(saved, dout, emb, wpool, bpool, g_wpool, g_bpool, d_emb, mode, d
     B, T, N, C = dims
     x, out, Wg = saved
     R, K = emb.shape
-    db = _zeros(x, R, C)
-    dx = ops.apply(dout, Wg, mode, B * T, N, A2=out, transw=True, pro=PRO_DPRE, colsum=db)
+    dx, db, nsb = ops.apply(dout, Wg, mode, B * T, N, A2=out, transw=True, pro=PRO_DPRE, colsum=True)
     dW, ns = ops.wgrad(x, dout, mode, B * T, N, D2=out, pro=PRO_DPRE)
     dW = dW.view(ns * R, C * C)
     red.jobs.bwd_pool(emb, dW, g_wpool.view(K, C * C), nsplit=ns)
-    red.jobs.bwd_pool(emb, db, g_bpool)
+    red.jobs.bwd_pool(emb, db, g_bpool, nsplit=nsb)
     red.jobs.bwd_emb(dW, wpool.view(K, C * C), d_emb, nsplit=ns)
-    red.jobs.bwd_emb(db, bpool, d_emb)
+    red.jobs.bwd_emb(db, bpool, d_emb, nsplit=nsb)
     return dx
 
 
@@ -357,14 +364,14 @@ def sthcn_fwd(p, pfx, tidx, x, dims, num_route, gen=None):
     return x, c1, sv
 
 
-def _grad_buffers(red, slot, N, T, HmT, ref):
-    """dG (4,N,T,T) zeroed and dA (4,N,Hm*T) of one STHCN.  Both STHCNs of a step get adjacent halves of one buffer each, so that
-    Reductions.flush() turns their temporal-graph gradients into the factor gradients with ONE gram_bwd launch."""
+def _grad_buffers(red, slot, N, T, HmT, ref, nsG):
+    """dG (4, nsG, N,T,T) partial graph gradients and dA (4,N,Hm*T) of one STHCN.  Both STHCNs of a step get adjacent halves of one
+    buffer each, so that Reductions.flush() turns their temporal-graph gradients into the factor gradients with ONE gram_bwd launch."""
     if slot is None:
-        return _zeros(ref, 4, N, T, T), torch.empty(4, N, HmT, device=ref.device)
+        return torch.empty(4, nsG, N, T, T, device=ref.device), torch.empty(4, N, HmT, device=ref.device)
     k, n = slot
     if getattr(red, "_dG", None) is None or red._dG.shape[0] != 4 * n:
-        red._dG = _zeros(ref, 4 * n, N, T, T)
+        red._dG = torch.empty(4 * n, nsG, N, T, T, device=ref.device)
         red._dA = torch.empty(4 * n, N, HmT, device=ref.device)
     return red._dG[4 * k:4 * k + 4], red._dA[4 * k:4 * k + 4]
 
@@ -376,7 +383,8 @@ def sthcn_bwd(p, g, pfx, tidx, sv, dout, dims, red):
     ne, nes = p[pfx + "node_embeddings"], p[pfx + "node_embeddings_spg"]
     dne, dnes = g[pfx + "node_embeddings"], g[pfx + "node_embeddings_spg"]
     d_te, d_teb, d_tes = _zeros(time_eb, *time_eb.shape), _zeros(teb, *teb.shape), _zeros(tes, *tes.shape)
-    dG_all, dA_all = _grad_buffers(red, sv.get("slot"), N, T, Hm * T, dout)
+    nsG = graph_grad_splits(dims)
+    dG_all, dA_all = _grad_buffers(red, sv.get("slot"), N, T, Hm * T, dout, nsG)
     dd, hp4 = hypertem_core_bwd(sv["h4"], dout, dG_all[3], dims)
     dd, cp2 = cap_core_bwd(p, g, cps[1], sv["c2"], dd, dims, HS, HT, red)
     dd, hp3 = hypertem_core_bwd(sv["h3"], dd, dG_all[2], dims)
@@ -387,22 +395,22 @@ def sthcn_bwd(p, g, pfx, tidx, sv, dout, dims, red):
     # ---- gradient reductions of all generated parameters: queued, executed by red.flush() ----
     J = red.jobs
     CC, BT = C * C, B * T
-    for h, (dWbt, ns, dbias) in zip(hts, (hp1, hp2, hp3, hp4)):
-        dW2 = dWbt.view(ns * BT, CC)
+    for h, (dWbt, ns, (dbias, nsb)) in zip(hts, (hp1, hp2, hp3, hp4)):
+        dW2 = dWbt                                              # (ns*BT, CC), possibly a column window of [dW | db] rows
         J.bwd_pool(time_eb, dW2, g[h + "weights_pool"].view(d, CC), nsplit=ns)
-        J.bwd_pool(time_eb, dbias, g[h + "bias_pool"])
+        J.bwd_pool(time_eb, dbias, g[h + "bias_pool"], nsplit=nsb)
         J.bwd_emb(dW2, p[h + "weights_pool"].view(d, CC), d_te, nsplit=ns)
-        J.bwd_emb(dbias, p[h + "bias_pool"], d_te)
-    red.gram(A_all.view(4 * N, Hm, T), dG_all.view(4 * N, T, T), dA_all.view(4 * N, Hm, T))
+        J.bwd_emb(dbias, p[h + "bias_pool"], d_te, nsplit=nsb)
+    red.gram(A_all.view(4 * N, Hm, T), dG_all, dA_all.view(4 * N, Hm, T), N, nsG)
     for i, h in enumerate(hts):
         J.bwd_pool(ne, dA_all[i], g[h + "adj"].view(d, Hm * T))
         J.bwd_emb(dA_all[i], p[h + "adj"].view(d, Hm * T), dne)
-    for c, (dWn, ns, dbn, ddyn, dlogit) in zip(cps, (cp1, cp2)):
+    for c, (dWn, ns, (dbn, nsb), ddyn, dlogit) in zip(cps, (cp1, cp2)):
         dW2 = dWn.view(ns * N, CC)
         J.bwd_pool(nes, dW2, g[c + "weights_spa"].view(d, CC), nsplit=ns)
-        J.bwd_pool(nes, dbn, g[c + "bias_spa"])
+        J.bwd_pool(nes, dbn, g[c + "bias_spa"], nsplit=nsb)
         J.bwd_emb(dW2, p[c + "weights_spa"].view(d, CC), dnes, nsplit=ns)
-        J.bwd_emb(dbn, p[c + "bias_spa"], dnes)
+        J.bwd_emb(dbn, p[c + "bias_spa"], dnes, nsplit=nsb)
         dd2 = ddyn.view(B, HT * T * HS)
         J.bwd_pool(tes, dd2, g[c + "t_adj"].view(ds, HT * T * HS))
         J.bwd_emb(dd2, p[c + "t_adj"].view(ds, HT * T * HS), d_tes)

@@ -16,9 +16,12 @@ class HyperTemFn(torch.autograd.Function):
         te = time_eb.reshape(B * T, d).contiguous()
         A = ops.poolgen(node_emb.contiguous(), adj.reshape(d, Hm * T)).view(N, Hm, T)     # :156
         G = ops.gram_fwd(A)
-        R = ops.tmix(x, G)                                                               # :157-158
         Wbt, bbt = ops.poolgen(te, wpool, bpool)                                         # :160-161
-        out = ops.apply(R, Wbt, MODE_TIME, B * T, N, bias=bbt, resid=x, epi=EPI_RES_LRELU)   # :162-163
+        if C == 64:                                                                      # fused kernel (hypertem.hip)
+            R, out = ops.hypertem_fwd(x, G, Wbt, bbt)
+        else:
+            R = ops.tmix(x, G)                                                           # :157-158
+            out = ops.apply(R, Wbt, MODE_TIME, B * T, N, bias=bbt, resid=x, epi=EPI_RES_LRELU)   # :162-163
         ctx.save_for_backward(x, R, out, A, G, Wbt, te, node_emb, adj, wpool, bpool)
         return out
 
@@ -29,16 +32,23 @@ class HyperTemFn(torch.autograd.Function):
         d, Hm = adj.shape[0], adj.shape[1]
         BT = B * T
         dout = dout.contiguous()
-        dbias = torch.zeros(BT, C, device=x.device)
-        dR = ops.apply(dout, Wbt, MODE_TIME, BT, N, A2=out, transw=True, pro=PRO_DPRE, colsum=dbias)
         dWbt, ns = ops.wgrad(R, dout, MODE_TIME, BT, N, D2=out, pro=PRO_DPRE)
+        if C == 64:                                                # fused backward: partial bias / graph gradients, no atomics
+            dx, dbias, dG = ops.hypertem_bwd(dout, out, x, G, Wbt)
+            nsb, nsG = ops.hypertem_ntiles(N), B
+        else:
+            dR, dbias, nsb = ops.apply(dout, Wbt, MODE_TIME, BT, N, A2=out, transw=True, pro=PRO_DPRE, colsum=True)
+            dx = ops.tmix(dR, G, dOut=dout, Y=out)
+            dG, nsG = ops.tmix_dgraph(dR, x), 1
         dwpool, dbpool = torch.zeros_like(wpool), torch.zeros_like(bpool)
         dte = torch.zeros_like(te)
-        ops.poolgen_bwd_pool(te, dWbt, dwpool, dbias, dbpool, nsplit=ns)
-        ops.poolgen_bwd_emb(dWbt, wpool, dte, dbias, bpool, nsplit=ns)
-        dx = ops.tmix(dR, G, dOut=dout, Y=out)
-        dG = ops.tmix_dgraph(dR, x)
-        dA = ops.gram_bwd(A, dG)
+        J = ops.PoolJobs()
+        J.bwd_pool(te, dWbt.view(ns * BT, C * C), dwpool.view(d, C * C), nsplit=ns)
+        J.bwd_pool(te, dbias, dbpool, nsplit=nsb)
+        J.bwd_emb(dWbt.view(ns * BT, C * C), wpool.view(d, C * C), dte, nsplit=ns)
+        J.bwd_emb(dbias, bpool, dte, nsplit=nsb)
+        J.launch()
+        dA = ops.gram_bwd(A, dG, nsplit=nsG)
         dadj, dne = torch.zeros_like(adj), torch.zeros_like(node_emb)
         ops.poolgen_bwd_pool(node_emb.contiguous(), dA, dadj)
         ops.poolgen_bwd_emb(dA, adj, dne)

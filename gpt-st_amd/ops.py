@@ -138,20 +138,28 @@ class PoolJobs:
         R, K = emb.shape
         if out is None:
             out = torch.empty((R,) + tuple(pool.shape[1:]), device=emb.device, dtype=torch.float32)
-        self.jobs.append((self.FWD, emb, None, pool, out, R, K, pool.numel() // K, 1))
+        self.jobs.append((self.FWD, emb, None, pool, out, R, K, pool.numel() // K, 1, 0))
         return out
+
+    @staticmethod
+    def _ldx(dW, cols):
+        """dW is a (rows, cols) matrix or a column window of a wider row-major one: -> its row stride"""
+        assert dW.is_cuda and dW.dtype == torch.float32 and dW.dim() == 2 and dW.shape[1] == cols and dW.stride(1) == 1, (dW.shape, dW.stride(), cols)
+        return dW.stride(0)
 
     def bwd_pool(self, emb, dW, dpool, nsplit=1):
         """dpool (K, ...) += emb^T dW, summing nsplit row blocks of R rows.  (Owned, non-atomic update: one job per dpool.)"""
-        _chk(emb, dW, dpool)
+        _chk(emb, dpool)
         R, K = emb.shape
-        self.jobs.append((self.BWD_POOL, emb, dW, None, dpool, R, K, dpool.numel() // K, nsplit))
+        cols = dpool.numel() // K
+        self.jobs.append((self.BWD_POOL, emb, dW, None, dpool, R, K, cols, nsplit, self._ldx(dW, cols)))
 
     def bwd_emb(self, dW, pool, demb, nsplit=1):
         """demb (R,K) += (sum of nsplit row blocks of dW) @ pool^T"""
-        _chk(dW, pool, demb)
+        _chk(pool, demb)
         R, K = demb.shape
-        self.jobs.append((self.BWD_EMB, None, dW, pool, demb, R, K, pool.numel() // K, nsplit))
+        cols = pool.numel() // K
+        self.jobs.append((self.BWD_EMB, None, dW, pool, demb, R, K, cols, nsplit, self._ldx(dW, cols)))
 
     def launch(self):
         js, self.jobs = self.jobs, []
@@ -159,7 +167,7 @@ class PoolJobs:
             return
         col = lambda i: [j[i] for j in js]
         _call("gptst_pool_jobs", len(js), _ints(col(0)), _ptrs0(col(1)), _ptrs0(col(2)), _ptrs0(col(3)), _ptrs0(col(4)), _ints(col(5)),
-              _ints(col(6)), _ints(col(7)), _ints(col(8)), nbytes=_nb(*[t for j in js for t in j[1:5]]))
+              _ints(col(6)), _ints(col(7)), _ints(col(8)), _ints(col(9)), nbytes=_nb(*[t for j in js for t in j[1:5]]))
 
 
 def _ptrs0(ts):
@@ -170,12 +178,24 @@ def _ptrs0(ts):
 # ---- MFMA contractions ---------------------------------------------------------------------------------------
 def apply(A, W, mode, BT, N, bias=None, resid=None, A2=None, transw=False, pro=PRO_NONE, epi=EPI_PLAIN, colsum=None,
           out=None, resid2=None):
-    _chk(A, W, bias, resid, A2, colsum, resid2)
+    """colsum=True -> (out, cs, ns): cs (ns*G, C) holds ns row-split partials of the column sums of pro(A) per group (the bias
+    gradient; consumers sum the splits: PoolJobs.bwd_pool / bwd_emb nsplit=ns).  colsum=<tensor (G,C)>: the summed partials are
+    added to it (convenience for tests)."""
+    _chk(A, W, bias, resid, A2, resid2)
     C = A.shape[-1]
     if out is None:
         out = torch.empty_like(A)
-    _call("gptst_apply", _p(A), _p(A2), _p(W), int(W.dim() == 3), int(transw), _p(bias), _p(resid), _p(resid2), _p(out), _p(colsum),
+    cs, ns = None, 0
+    if colsum is not None:
+        G = BT if mode == MODE_TIME else (N if mode == MODE_NODE else 1)
+        ns = _C.lib().value("gptst_apply_nsplit", mode, BT, N, C)
+        cs = torch.empty(ns * G, C, device=A.device, dtype=torch.float32)
+    _call("gptst_apply", _p(A), _p(A2), _p(W), int(W.dim() == 3), int(transw), _p(bias), _p(resid), _p(resid2), _p(out), _p(cs),
           mode, pro, epi, BT, N, C, tag="mode%d pro%d epi%d" % (mode, pro, epi), nbytes=_nb(A, A2, W, bias, resid, resid2, out))
+    if colsum is True:
+        return out, cs, ns
+    if colsum is not None:
+        colsum.add_(cs.view(ns, -1, C).sum(0).view_as(colsum))
     return out
 
 
@@ -183,15 +203,16 @@ def wgrad_nsplit(mode, BT, N):
     return _C.lib().value("gptst_wgrad_nsplit", mode, BT, N)
 
 
-def wgrad(A, D, mode, BT, N, D2=None, pro=PRO_NONE, colsum_a=False):
-    """-> (dW (nsplit*G, C, C), nsplit);  colsum_a: rows become [dW (C*C) | column sums of A (C)]."""
+def wgrad(A, D, mode, BT, N, D2=None, pro=PRO_NONE, colsum_a=False, colsum_d=False):
+    """-> (dW (nsplit*G, C, C), nsplit);  colsum_a / colsum_d: rows become [dW (C*C) | column sums of A / of pro(D) (C)]."""
     _chk(A, D, D2)
     C = A.shape[-1]
     ns = wgrad_nsplit(mode, BT, N)
     G = BT if mode == MODE_TIME else (N if mode == MODE_NODE else 1)
-    if colsum_a:
+    if colsum_a or colsum_d:
         dW = torch.empty(ns * G, C * C + C, device=A.device, dtype=torch.float32)
-        _call("gptst_wgrad_colsum", _p(A), _p(D), _p(D2), _p(dW), mode, pro, BT, N, C, tag="mode%d pro%d cs" % (mode, pro), nbytes=_nb(A, D, D2, dW))
+        _call("gptst_wgrad_colsum", _p(A), _p(D), _p(D2), _p(dW), mode, pro, 1 if colsum_a else 2, BT, N, C,
+              tag="mode%d pro%d cs" % (mode, pro), nbytes=_nb(A, D, D2, dW))
     else:
         dW = torch.empty(ns * G, C, C, device=A.device, dtype=torch.float32)
         _call("gptst_wgrad", _p(A), _p(D), _p(D2), _p(dW), mode, pro, BT, N, C, tag="mode%d pro%d" % (mode, pro), nbytes=_nb(A, D, D2, dW))
@@ -206,10 +227,11 @@ def gram_fwd(A):
     return G
 
 
-def gram_bwd(A, dG, out=None):
-    N, Hm, T = A.shape
+def gram_bwd(A, dG, out=None, layers=1, nsplit=1):
+    """A (L*N,Hm,T); dG (L, nsplit, N, T, T) partial graph gradients (summed in a fixed order) -> dA (L*N,Hm,T)."""
+    LN, Hm, T = A.shape
     dA = out if out is not None else torch.empty_like(A)
-    _call("gptst_gram_bwd", _p(A), _p(dG), _p(dA), N, Hm)
+    _call("gptst_gram_bwd", _p(A), _p(dG), _p(dA), layers, LN // layers, Hm, nsplit)
     return dA
 
 
@@ -232,14 +254,23 @@ def hypertem_fwd(X, G, Wbt, bbt):
     return R, out
 
 
-def hypertem_bwd(dOut, Y, X, G, Wbt, dbias, dG):
-    """Fused hyperTem backward: returns dX; accumulates dbias (BT,C) and dG (N,T,T)."""
-    _chk(dOut, Y, X, G, Wbt, dbias, dG)
+def hypertem_ntiles(N):
+    return _C.lib().value("gptst_hypertem_ntiles", N)
+
+
+def hypertem_bwd(dOut, Y, X, G, Wbt, dG=None, want_dbias=True):
+    """Fused hyperTem backward -> (dX, dbias (ntiles*BT, C) node-tile partials or None, dG (B,N,T,T) per-sample partials); dG may
+    be a preallocated (B,N,T,T) buffer.  No atomics: consumers sum the partials (nsplit = ntiles / B)."""
+    _chk(dOut, Y, X, G, Wbt, dG)
     B, T, N, C = X.shape
     dX = torch.empty_like(X)
+    nt = hypertem_ntiles(N)
+    dbias = torch.empty(nt * B * T, C, device=X.device, dtype=torch.float32) if want_dbias else None
+    if dG is None:
+        dG = torch.empty(B, N, T, T, device=X.device, dtype=torch.float32)
     _call("gptst_hypertem_bwd", _p(dOut), _p(Y), _p(X), _p(G), _p(Wbt), _p(dX), _p(dbias), _p(dG), B, T, N, C,
-          nbytes=_nb(dOut, Y, X, G, Wbt, dX, dbias, dG))
-    return dX
+          nbytes=_nb(dOut, Y, X, G, Wbt, dX))
+    return dX, dbias, dG
 
 
 def tmix_dgraph(dR, X, out=None):
@@ -512,18 +543,26 @@ def kl(prob, c, N, w, stats, want_grad=True):
 TAIL_MAXJ = 16
 
 
+def set_deterministic(on):
+    """Bit-reproducible steps: the reductions that end in float atomics by default (embedding gradients of the pool jobs, time-feature
+    weight gradients) run as single-owner kernels with a fixed summation order.  Thread-local in the library."""
+    _C.lib().call("gptst_set_deterministic", int(bool(on)))
+
+
+
 def tail_mae(dec, W, b, src, lda, mask, sigma, mu, thresh, stats):
     """Fused output head + masked-MAE + its backward (tails.hip) -> out (rows,J), d_dec (rows,C) [gradient of the SUM loss],
-    part (nparts, J*C+J) partials of (gW, gb)."""
+    part (nparts, J*C+J) partials of (gW, gb) — a column window of the kernel's (nparts, J*C+J+2) scratch rows.
+    stats (float[8], [6] / [7] zero on entry: tickets of the ordered fold)."""
     rows, C = dec.shape
     J = W.shape[0]
     nparts = _C.lib().value("gptst_tail_parts", rows)
     out = torch.empty(rows, J, device=dec.device, dtype=torch.float32)
     d_dec = torch.empty_like(dec)
-    part = torch.empty(nparts, J * C + J, device=dec.device, dtype=torch.float32)
+    part = torch.empty(nparts, J * C + J + 2, device=dec.device, dtype=torch.float32)
     _call("gptst_tail_mae", _p(dec), _p(W), _p(b), _p(src), lda, _p(mask), float(sigma), float(mu), float(thresh), _p(out), _p(d_dec),
           _p(part), _p(stats), rows, J, C, nbytes=_nb(dec, d_dec))
-    return out, d_dec, part
+    return out, d_dec, part[:, :J * C + J]
 
 
 def tail_kl(h2, W3, prob, c, N, w, stats):
@@ -532,13 +571,22 @@ def tail_kl(h2, W3, prob, c, N, w, stats):
     HS = W3.shape[0]
     nparts = _C.lib().value("gptst_tail_parts", rows)
     d_h2 = torch.empty_like(h2)
-    part = torch.empty(nparts, HS * C + HS, device=h2.device, dtype=torch.float32)
+    part = torch.empty(nparts, HS * C + HS + 2, device=h2.device, dtype=torch.float32)
     _call("gptst_tail_kl", _p(h2), _p(W3), _p(prob), _p(c), float(w), _p(d_h2), _p(part), _p(stats), rows, N, HS, C, nbytes=_nb(h2, d_h2))
-    return d_h2, part
+    return d_h2, part[:, :HS * C + HS]
 
 
-def clip_adam(p, g, m, v, nA, nB, hyper, stats):
-    _call("gptst_clip_adam", _p(p), _p(g), _p(m), _p(v), int(nA), int(nB), _p(hyper), _p(stats))
+_ADAM_WS = {}
+
+
+def clip_adam(p, g, m, v, nA, nB, hyper, stats, ws=None):
+    """clip_grad_norm_ + Adam over the flat buffers; stats[3] (in): extra squared-norm terms, stats[4] (out): total squared norm.
+    ws: gptst_clip_adam_ws_floats() floats of scratch (default: one cached buffer per device — stream-ordered reuse)."""
+    if ws is None:
+        if p.device not in _ADAM_WS:
+            _ADAM_WS[p.device] = torch.empty(_C.lib().value("gptst_clip_adam_ws_floats"), device=p.device, dtype=torch.float32)
+        ws = _ADAM_WS[p.device]
+    _call("gptst_clip_adam", _p(p), _p(g), _p(m), _p(v), int(nA), int(nB), _p(hyper), _p(stats), _p(ws))
 
 
 # ---- evaluation metrics (Trainer.test) ---------------------------------------------------------------------------------

@@ -17,7 +17,8 @@ from . import engine, ops
 class PretrainStep:
     RING = 8                                  # pinned host slots in flight (see __init__)
 
-    def __init__(self, model, args, scaler_mean, scaler_std, batch_size, use_graph=True, dp=None, seed=0, global_mask=True):
+    def __init__(self, model, args, scaler_mean, scaler_std, batch_size, use_graph=True, dp=None, seed=0, global_mask=True,
+                 deterministic=None):
         """``seed`` drives the class-order shuffle and (data parallel, global masks) the mask noise: it must be the SAME on every
         rank, because every rank regenerates the selection over the global batch and keeps its rows (dist.py)."""
         self.model, self.args = model, args
@@ -28,6 +29,9 @@ class PretrainStep:
         self.dev = model.flat.device
         assert self.dev.type == "cuda", "PretrainStep needs the model on an MI355X (no CPU fallback)"
         self.use_graph, self.dp = use_graph, dp
+        # bit-reproducible steps (GPTST_DETERMINISTIC=1): single-owner, fixed-order variants of the two reductions that end in float
+        # atomics by default (ops.set_deterministic); with injected mask noise two runs of a step sequence are then bit-identical
+        self.deterministic = (os.environ.get("GPTST_DETERMINISTIC", "0") == "1") if deterministic is None else bool(deterministic)
         n = model.flat.numel()
         self.gbuf = torch.zeros(n + 8, device=self.dev)             # [flat gradient | stats] -> one collective
         self.gflat, self.stats = self.gbuf[:n], self.gbuf[n:]
@@ -188,9 +192,13 @@ class PretrainStep:
         self.stats_out.copy_(self.stats)
 
     def _body(self, phase):
-        self._fwd_bwd(phase)
-        if self.dp is None:
-            self._optim()
+        ops.set_deterministic(self.deterministic)           # thread-local launch mode of the library (captured into the graph)
+        try:
+            self._fwd_bwd(phase)
+            if self.dp is None:
+                self._optim()
+        finally:
+            ops.set_deterministic(False)
 
     # ---- host side of one step -------------------------------------------------------------------------------------
     def _slot(self):

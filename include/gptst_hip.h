@@ -24,6 +24,10 @@ extern "C" {
 
 #define GPTST_ABI_VERSION 1
 int gptst_abi_version(void);
+/* 1: bit-reproducible steps — the two reductions that end in float atomics by default (embedding gradients of gptst_pool_jobs kind 2,
+ * weight gradients of gptst_timefeat_jobs) run as single-owner kernels with a fixed summation order (slower).  Everything else is
+ * order-fixed by construction.  Thread-local. */
+int gptst_set_deterministic(int on);
 /* launch-geometry knobs for benchmarking, not needed for correctness.  1: rows per block of the poolgen forward; 2 / 5: forced split
  * count of the NODE / TIME weight gradient; 3: 1 = first-generation (LDS-staged) apply for C = 64; 4: tiles per wave of apply64 */
 int gptst_tune(int id, int value);
@@ -54,19 +58,22 @@ int gptst_poolgen_bwd_emb_multi(int nprob, const void* dWs, const void* pools, c
  * (host arrays, read at call time).  kind 0: out (R,cols) = emb (R,K) . pool (K,cols);  kind 1: out = dpool (K,cols) += sum_rr
  * emb[rr % R,:]^T x[rr,:], rr < R*nsplit — owned by ONE workgroup per element (no atomics: two kind-1 jobs of one call must
  * not share `out`);  kind 2: out = demb (R,K) += (sum_s x[s*R + r,:]) . pool^T (atomic: several jobs may add into one demb).
+ * ldx[j]: row stride of x in floats (0 = cols) — a job may read a column window of a wider matrix.
  * Unused pointers of a kind may be NULL.  A whole pretraining step needs 3 calls (forward generation, two backward reductions)
  * where per-embedding launches needed ~50. */
 int gptst_pool_jobs(int njobs, const int* kind, const void* const* emb, const void* const* x, const void* const* pool,
-                    const void* const* out, const int* R, const int* K, const int* cols, const int* nsplit, void* stream);
+                    const void* const* out, const int* R, const int* K, const int* cols, const int* nsplit, const int* ldx, void* stream);
 
 /* ---- C x C contractions on fp32 MFMA (apply.hip) ------------------------------------------------------
  * out[g,m,:] = epi( pro(A)[g,m,:] @ W[g] (+bias[g]) (+resid) ).   mode: 0 TIME (g=(b,t), rows n), 1 NODE (g=n, rows
  * (b,t)), 2 SHARED (one weight).  w_per_group: W is (G,C,C) else (C,C).  transw: W[g] stored [out][in].
  * pro: 0 none, 1 A*lrelu'(A2) (A=dOut, A2=layer output).  epi: 0 plain, 1 lrelu(acc+bias+resid),
  * 2 acc + resid*lrelu'(resid2) (adds the residual branch of a layer's backward), 3 lrelu(acc+bias).
- * colsum (optional, += via atomics): colsum[g,:] += sum_m pro(A)[g,m,:]  (bias gradient).
+ * colsum (optional): row-split PARTIALS of the bias gradient, colsum[s][g][:] = sum over the rows m of split s of pro(A)[g,m,:],
+ *   s < gptst_apply_nsplit(mode, BT, N, C); plain stores in a fixed order (no atomics): the consumer sums the splits.
  * Replaces einsum('btni,btio->btno') / einsum('btni,nio->btno') + bias + residual + LeakyReLU
  * (GPTST.py:26-27,31-32,139-141,162-163), nn.Linear C->C (:102) and their backward w.r.t. the data. */
+int gptst_apply_nsplit(int mode, int BT, int N, int C);
 int gptst_apply(const float* A, const float* A2, const float* W, int w_per_group, int transw, const float* bias,
                 const float* resid, const float* resid2, float* out, float* colsum, int mode, int pro, int epi, int BT,
                 int N, int C, void* stream);
@@ -75,14 +82,18 @@ int gptst_apply(const float* A, const float* A2, const float* W, int w_per_group
 int gptst_wgrad_nsplit(int mode, int BT, int N);
 int gptst_wgrad(const float* A, const float* D, const float* D2, float* dW, int mode, int pro, int BT, int N, int C,
                 void* stream);
-/* same, with the column sums of A appended to every split (rows of C*C + C floats): weight AND bias gradient of a shared Linear */
-int gptst_wgrad_colsum(const float* A, const float* D, const float* D2, float* dW, int mode, int pro, int BT, int N, int C,
+/* same, with column sums appended to every split (rows of C*C + C floats): which = 1: [dW | sum_m A[m,:]] (weight AND bias gradient
+ * of a shared Linear whose output gradient is A); which = 2: [dW | sum_m pro(D)[m,:]] (weight and bias gradient of a generated
+ * layer, e.g. hyperTem's W_bt / b_bt — replaces a separate, atomically accumulated bias-gradient pass).  C = 64. */
+int gptst_wgrad_colsum(const float* A, const float* D, const float* D2, float* dW, int mode, int pro, int which, int BT, int N, int C,
                        void* stream);
 
 /* ---- per-node temporal hypergraph of hyperTem (tmix.hip), GPTST.py:156-158 -----------------------------
  * A (N,Hm,T) = node_emb . adj (via poolgen);  G[n] = A[n]^T A[n] (T x T);  ret[b,:,n,:] = G[n] X[b,:,n,:]. */
 int gptst_gram_fwd(const float* A, float* G, int N, int Hm, void* stream);
-int gptst_gram_bwd(const float* A, const float* dG, float* dA, int N, int Hm, void* stream);
+/* gram_bwd: A (L*N,Hm,T) of L layers, dG (L, nsplit, N, T, T) PARTIAL graph gradients (e.g. one per sample from gptst_hypertem_bwd),
+ * summed in a fixed order -> dA (L*N,Hm,T). */
+int gptst_gram_bwd(const float* A, const float* dG, float* dA, int L, int N, int Hm, int nsplit, void* stream);
 /* out = G (*) X  [+ dOut*lrelu'(Y) when dOut != NULL: fuses the residual branch of hyperTem's backward]. */
 int gptst_tmix(const float* X, const float* G, const float* dOut, const float* Y, float* out, int B, int T, int N, int C,
                void* stream);
@@ -94,8 +105,11 @@ int gptst_tmix_dgraph(const float* dR, const float* X, float* dG, int B, int T, 
 int gptst_hypertem_fwd(const float* X, const float* G, const float* Wbt, const float* bbt, float* R_out, float* out, int B, int T,
                        int N, int C, void* stream);
 
-/* fused hyperTem backward w.r.t. data and graph: dX = dPre + G (*) (dPre W_bt^T), dbias[b,t,:] += sum_n dPre, dG[n] += dR X^T,
- * dPre = dOut*lrelu'(Y).  (The weight gradient stays in gptst_wgrad.)  C = 64. */
+/* fused hyperTem backward w.r.t. data and graph: dX = dPre + G (*) (dPre W_bt^T), dPre = dOut*lrelu'(Y), and PARTIALS of the bias and
+ * graph gradients, plain stores in a fixed order (no atomics): dbias (gptst_hypertem_ntiles(N) * B*T, C) — one partial per 16-node
+ * tile — and dG (B*N, T, T) — one per sample; the consumers sum them (pool jobs nsplit, gptst_gram_bwd nsplit).
+ * (The weight gradient stays in gptst_wgrad.)  C = 64. */
+int gptst_hypertem_ntiles(int N);
 int gptst_hypertem_bwd(const float* dOut, const float* Y, const float* X, const float* G, const float* Wbt, float* dX, float* dbias,
                        float* dG, int B, int T, int N, int C, void* stream);
 
@@ -193,7 +207,9 @@ int gptst_timefeat_bwd(const float* wd, const float* bd, const float* ww, const 
 /* ---- fused thin heads (tails.hip): one pass over the C-wide activation where the loss meets the network --------------------
  * tail_mae: out = dec W^T + b (GPTST.py:455), masked-MAE statistics stats[0..1] += (Run.py:92-100, lib/metrics.py:11-18), gradient of
  *   the SUM loss w.r.t. dec -> d_dec (the 1/#kept of the mean is applied by gptst_clip_adam, hyper[9] = 1), and per-workgroup partials
- *   part[blk][J*C + J] of (gW, gb) — gptst_tail_parts(rows) of them, summed by the caller (one kind-1 pool job).
+ *   part[blk][J*C + J + 2]: (gW, gb) partials in the first J*C + J columns — gptst_tail_parts(rows) rows, summed by the caller (one
+ *   kind-1 pool job with ldx = J*C + J + 2) — and the workgroup's loss statistics in the last two, folded into stats in index order by
+ *   the last workgroup to finish (stats[6] / stats[7] are its tickets: zero on entry, zero on exit).
  * tail_kl: KL statistics stats[2] += and the backward through softmax + MLP_RL.ln3 (BasicTrainer.py:85, GPTST.py:33): d_h2 and the
  *   partials of (gW3, gb3).  prob (rows,HS) row-major, c (BT,HS,N).  C = 64 and J / HS <= 16, else GPTST_ESHAPE (use the unfused ops). */
 int gptst_tail_parts(int rows);
@@ -208,7 +224,8 @@ int gptst_timefeat_jobs(int njobs, int bwd, const void* const* params, const voi
                         const void* const* io, const int* rows, const int* K, const int* E, void* stream);
 
 /* ---- loss + optimiser (loss_adam.hip) ---------------------------------------------------------------------
- * stats: device float[8] zeroed once per step: [0] sum|y-p| [1] kept count [2] KL sum [3] sum g^2.
+ * stats: device float[8] zeroed once per step: [0] sum|y-p| [1] kept count [2] KL sum [3] extra sum g^2 terms (in; node-sharded
+ * runs) [4] total sum g^2 (out) [6] [7] fold tickets of tails.hip.
  * mae: Run.py:92-100 + lib/metrics.py:11-18 + lib/normalization.py:23-27;  kl: Run.py:132 + BasicTrainer.py:85 (w = 0.1),
  * also emits the gradient w.r.t. the MLP_RL logits;  clip_adam: BasicTrainer.py:95-97 + Run.py:134 over flat buffers
  * (hyper layout documented in loss_adam.hip). */
@@ -217,7 +234,9 @@ int gptst_mae_fwd(const float* out, const float* src, int lda, const float* mask
 int gptst_mae_bwd(const float* out, const float* src, int lda, const float* mask, float sigma, float mu, float thresh, int rows,
                   int J, const float* stats, int normalize, float* dOut, void* stream);
 int gptst_kl(const float* prob, const float* c, int rows, int N, int HS, float w, float* dlogit, float* stats, void* stream);
-int gptst_clip_adam(float* p, const float* g, float* m, float* v, long nA, long nB, const float* hyper, float* stats, void* stream);
+int gptst_clip_adam_ws_floats(void);   /* scratch floats (ws) of gptst_clip_adam: one gradient-norm partial per workgroup, folded in order */
+int gptst_clip_adam(float* p, const float* g, float* m, float* v, long nA, long nB, const float* hyper, float* stats, float* ws,
+                    void* stream);
 
 #ifdef __cplusplus
 }

@@ -440,8 +440,10 @@ def test_clip_adam_matches_torch():
         close(p, ref, tol=2e-6, what="adam step %d" % step)
 
 
-def test_pool_jobs_mixed_table():
-    """gptst_pool_jobs: problems of all three kinds, each with its own embedding / shape, in one call (60 jobs -> 2 launches)."""
+@pytest.mark.parametrize("det", [0, 1])
+def test_pool_jobs_mixed_table(det):
+    """gptst_pool_jobs: problems of all three kinds, each with its own embedding / shape, in one call (60 jobs -> 2 launches);
+    det = 1: the deterministic routing (one single-owner launch per distinct demb)."""
     from gptst_amd import ops
     dev = _dev()
     g = torch.Generator().manual_seed(11)
@@ -465,7 +467,11 @@ def test_pool_jobs_mixed_table():
                 J.bwd_emb(dW.to(dev), pool.to(dev), de, nsplit=ns)                       # two jobs add into one demb
                 checks.append((de, demb + 2 * dW.view(ns, R, cols).sum(0) @ pool.t(), "bwd_emb %s ns=%d" % ((R, K, cols), ns)))
     assert len(J.jobs) > 96
-    J.launch()
+    ops.set_deterministic(det)
+    try:
+        J.launch()
+    finally:
+        ops.set_deterministic(0)
     for got, ref, what in checks:
         close(got, ref, what=what)
 
@@ -495,6 +501,20 @@ def test_timefeat_jobs_equal_single_launches():
     for pp, g2, go, rows, K, g1 in bj:
         for a, b in zip(g1, g2):
             close(b, a.cpu(), tol=1e-5, what="timefeat_jobs bwd")
+    # deterministic variant: one workgroup per job walks its row blocks in order; two runs are bit-identical
+    runs = []
+    for rep in range(2):
+        g3 = [[torch.zeros_like(t) for t in j[0]] for j in bj]
+        ops.set_deterministic(1)
+        try:
+            ops.timefeat_jobs_bwd([(j[0], g3[q], j[2], j[3], j[4]) for q, j in enumerate(bj)], tidx)
+        finally:
+            ops.set_deterministic(0)
+        runs.append(g3)
+    for q, j in enumerate(bj):
+        for a, b, c in zip(j[5], runs[0][q], runs[1][q]):
+            close(b, a.cpu(), tol=1e-5, what="timefeat_jobs bwd det")
+            assert torch.equal(b, c)
 
 
 @pytest.mark.parametrize("J,rows", [(1, 65280), (2, 1000), (1, 37)])
@@ -544,3 +564,32 @@ def test_tail_kl_matches_unfused_ops(HS, N, BT):
     gwb = part.sum(0).cpu()
     close(gwb[:HS * C].view(HS, C), dlogit.t() @ h2, what="tail gW3")
     close(gwb[HS * C:], dlogit.sum(0), what="tail gb3")
+
+
+def test_wgrad_colsum_of_dpre_and_column_window_jobs():
+    """gptst_wgrad_colsum(which=2): rows [dW | column sums of dPre] (hyperTem's weight AND bias gradient from one pass), consumed by
+    pool jobs that read column windows of those rows (ldx > cols)."""
+    from gptst_amd import ops
+    from gptst_amd.ops import MODE_TIME, PRO_DPRE
+    dev = _dev()
+    g = torch.Generator().manual_seed(31)
+    BT, N, C, d = 24, 37, 64, 8
+    A, D, Y = rnd(BT * N, C, g=g), rnd(BT * N, C, g=g), rnd(BT * N, C, g=g)
+    dpre = D * torch.where(Y > 0, torch.ones_like(Y), torch.full_like(Y, 0.01))
+    dWb, ns = ops.wgrad(A.to(dev), D.to(dev), MODE_TIME, BT, N, D2=Y.to(dev), pro=PRO_DPRE, colsum_d=True)
+    got = dWb.view(ns, BT, C * C + C).sum(0).cpu()
+    dW_ref = torch.einsum("gmi,gmo->gio", A.view(BT, N, C), dpre.view(BT, N, C)).reshape(BT, C * C)
+    close(got[:, :C * C], dW_ref, what="wgrad dW")
+    close(got[:, C * C:], dpre.view(BT, N, C).sum(1), what="wgrad colsum dPre")
+    te, wpool, bpool = rnd(BT, d, g=g), rnd(d, C * C, g=g), rnd(d, C, g=g)
+    gw, gb, dte = torch.zeros(d, C * C, device=dev), torch.zeros(d, C, device=dev), torch.zeros(BT, d, device=dev)
+    J = ops.PoolJobs()
+    J.bwd_pool(te.to(dev), dWb[:, :C * C], gw, nsplit=ns)
+    J.bwd_pool(te.to(dev), dWb[:, C * C:], gb, nsplit=ns)
+    J.bwd_emb(dWb[:, :C * C], wpool.to(dev), dte, nsplit=ns)
+    J.bwd_emb(dWb[:, C * C:], bpool.to(dev), dte, nsplit=ns)
+    J.launch()
+    db_ref = dpre.view(BT, N, C).sum(1)
+    close(gw, te.t() @ dW_ref, what="window bwd_pool W")
+    close(gb, te.t() @ db_ref, what="window bwd_pool b")
+    close(dte, dW_ref @ wpool.t() + db_ref @ bpool.t(), what="window bwd_emb")

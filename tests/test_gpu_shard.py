@@ -148,6 +148,6 @@ def test_config4_full_size_properties(parity):
             e = abs(out[r][0][i][0] - loss) / abs(loss)
             parity("loss_sharded_vs_unsharded", e)
             assert e < 2e-4, (i, r, out[r][0][i], loss)
-            gn, gn_ref = float(out[r][3][i][3]) ** 0.5, float(stats[3]) ** 0.5        # stats[3] = sum g^2 after the global reduction
+            gn, gn_ref = float(out[r][3][i][4]) ** 0.5, float(stats[4]) ** 0.5        # stats[4] = total sum g^2 seen by the optimiser
             parity("gradnorm_sharded_vs_unsharded", abs(gn - gn_ref) / gn_ref)
             assert abs(gn - gn_ref) < 1e-3 * gn_ref, (i, r, gn, gn_ref)

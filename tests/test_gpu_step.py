@@ -211,3 +211,32 @@ def test_unsynced_queue_equals_synced_steps(use_graph):
     # (the final parameters are NOT compared: float atomics make two runs differ at round-off level and 50 Adam steps at lr 3e-3
     # with free-running adaptive masks amplify that to O(0.2) relative — the device-side snapshots above are the exact check)
     assert torch.isfinite(outs[1][1]).all()
+
+
+@pytest.mark.parametrize("use_graph", [False, True])
+def test_deterministic_mode_is_bit_reproducible(use_graph):
+    """GPTST_DETERMINISTIC / PretrainStep(deterministic=True): two runs of the same 12 steps (both phases, injected noise, free-running
+    adaptive masks) end in bit-identical parameters and optimiser state — no float atomics are left on the path."""
+    from gptst_amd.model import GPTST_Model
+    from gptst_amd.step import PretrainStep
+    args = _args()
+    sd = O.init_state_dict(args, 2)
+    src = [synth.make_batch(4, 12, 20, 1, seed=70 + i).to(DEV) for i in range(12)]
+    M = 4 * 12 * 20
+    outs = []
+    for rep in range(2):
+        model = GPTST_Model(args); model.load_state_dict(sd); model = model.to(DEV)
+        st = PretrainStep(model, args, synth.SCALER_MEAN, synth.SCALER_STD, batch_size=4, use_graph=use_graph, deterministic=True)
+        losses = []
+        for i in range(12):
+            epoch = 1 + i // 2                               # change_epoch = 3: steps 6.. are adaptive + KL
+            na, nr = synth.make_noise(M, 500 + i).to(DEV), synth.make_noise(M, 600 + i).to(DEV)
+            if epoch <= args.change_epoch:
+                st.step(src[i], epoch, noise=na)
+            else:
+                st.step(src[i], epoch, noise_a=na, noise_r=nr, list_c=synth.class_order(5, i))
+            losses.append(st.losses())
+        outs.append((model.flat.clone(), st.m.clone(), st.v.clone(), losses))
+    assert outs[0][3] == outs[1][3], "losses differ between two deterministic runs"
+    for a, b, nm in zip(outs[0][:3], outs[1][:3], ("parameters", "exp_avg", "exp_avg_sq")):
+        assert torch.equal(a, b), "%s differ between two deterministic runs" % nm

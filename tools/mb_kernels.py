@@ -22,7 +22,7 @@ dyn = f(B, HT, T * HS) * 0.1
 tmpl = torch.arange(12, device=dev, dtype=torch.float32) / 12
 Rr, out = ops.hypertem_fwd(X, G, Wbt, bbt)
 X2, dO2, out2 = X.view(-1, C), dO.view(-1, C), out.view(-1, C)
-db, dG = torch.zeros(BT, C, device=dev), torch.zeros(N, 12, 12, device=dev)
+dGp = torch.empty(B, N, 12, 12, device=dev)
 dbn = torch.zeros(N, C, device=dev)
 c, s = ops.cap_route_fwd(X, Wp, bp, dadj, HS, R)
 v, Ht, Rt = ops.cap_cross_fwd(s, dyn, tmpl, B, T, HS, HT)
@@ -32,12 +32,12 @@ dS, ddyn = ops.cap_cross_bwd(dv, s, Rt, Ht, dyn, tmpl, B, T, HS, HT)
 
 CASES = {
     "hypertem_fwd": lambda: ops.hypertem_fwd(X, G, Wbt, bbt),
-    "hypertem_bwd": lambda: ops.hypertem_bwd(dO, out, X, G, Wbt, db, dG),
-    "wgrad_time_dpre": lambda: ops.wgrad(Rr.view(-1, C), dO2, MODE_TIME, BT, N, D2=out2, pro=PRO_DPRE),
+    "hypertem_bwd": lambda: ops.hypertem_bwd(dO, out, X, G, Wbt, dG=dGp, want_dbias=False),
+    "wgrad_time_dpre_cs": lambda: ops.wgrad(Rr.view(-1, C), dO2, MODE_TIME, BT, N, D2=out2, pro=PRO_DPRE, colsum_d=True),
     "wgrad_node_dpre": lambda: ops.wgrad(rec, dO2, MODE_NODE, BT, N, D2=out2, pro=PRO_DPRE),
     "wgrad_shared_cs": lambda: ops.wgrad(dO2, X2, MODE_SHARED, BT, N, colsum_a=True),
     "apply_node_fwd": lambda: ops.apply(rec, Wn, MODE_NODE, BT, N, bias=bn, resid=X2, epi=EPI_RES_LRELU),
-    "apply_node_dpre": lambda: ops.apply(dO2, Wn, MODE_NODE, BT, N, A2=out2, transw=True, pro=PRO_DPRE, colsum=dbn),
+    "apply_node_dpre": lambda: ops.apply(dO2, Wn, MODE_NODE, BT, N, A2=out2, transw=True, pro=PRO_DPRE, colsum=True),
     "apply_shared_dx": lambda: ops.apply(dO2, Wp, MODE_SHARED, BT, N, resid=dO2, resid2=out2, epi=EPI_ADD_DPRE),
     "cap_route_fwd": lambda: ops.cap_route_fwd(X, Wp, bp, dadj, HS, R),
     "cap_cross_fwd": lambda: ops.cap_cross_fwd(s, dyn, tmpl, B, T, HS, HT),
