@@ -38,22 +38,22 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 // bit-identical.  Everything else is order-fixed by construction (partials + ordered folds, "last workgroup folds" for scalars).
 extern thread_local int g_deterministic;
 
-// "last workgroup folds": every workgroup publishes its partial, takes a ticket, and the one that draws the last ticket sums all
-// partials in index order — the result does not depend on which workgroup that is.  Returns true in the last workgroup (all threads),
-// after an agent-scope acquire; the caller then reads the partials with ld_agent().
+// "last workgroup folds": every workgroup publishes its partial with st_agent() (write-through stores, thread 0), takes a ticket, and
+// the one that draws the last ticket sums all partials (ld_agent()) in index order — the result does not depend on which workgroup
+// that is.  Returns true in the last workgroup (all threads).  No agent-scope FENCE: a release fence writes back every dirty L2 line of
+// the XCD (the kernel's own 16.7 MB output) — 510 workgroups doing that cost ~20 us; write-through payload + drained vmcnt + relaxed
+// agent-scope ticket is the cheap valid form (MI355X_MICROARCH.md, inter-workgroup visibility).
+__device__ __forceinline__ void st_agent(float* p, float v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ float ld_agent(const float* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 __device__ __forceinline__ bool last_block_arrives(unsigned* ticket, unsigned nblocks) {
     __shared__ unsigned s_last;
-    __syncthreads();                                                 // all partial stores of this workgroup are issued
-    if (threadIdx.x == 0) {
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+    if (threadIdx.x == 0) {                                          // thread 0 published the partials: drain its stores, then arrive
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         s_last = (__hip_atomic_fetch_add(ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == nblocks - 1) ? 1u : 0u;
-        if (s_last) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
     }
     __syncthreads();
     return s_last != 0u;
 }
-__device__ __forceinline__ float ld_agent(const float* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 
 __device__ __forceinline__ float lrelu(float x) { return x > 0.f ? x : LRELU_SLOPE * x; }
 // derivative selected by the sign of the OUTPUT (slope > 0 keeps the sign; x == 0 -> slope, as ATen).

@@ -324,8 +324,10 @@ extern thread_local int g_wgrad_ns_override;
 extern thread_local int g_wgrad_ns0_override;
 extern thread_local int g_apply_v1;
 extern thread_local int g_apply_tpw;
+extern thread_local int g_tl_nb;
 extern "C" int gptst_tune(int id, int value) {
     if (id == 1 && value > 0 && value <= PG_MAXROWS) g_pg_rows = value;
+    if (id == 6 && value > 0) g_tl_nb = value;
     if (id == 2) g_wgrad_ns_override = value;
     if (id == 5) g_wgrad_ns0_override = value;
     if (id == 3) g_apply_v1 = value;

@@ -9,17 +9,19 @@
 //       a = w (prob sum_h eb - eb);  stats[2] += sum eb (log eb - log prob);  d_h2 = a W3;  partial (gW3, gb3) = (a^T h2, sum a)
 //                                                                          was kl, lin_in, rowouter x2
 // Layout as small.hip: C/4 lanes per row (float4 columns), 16 row slots per workgroup; TL_NB persistent workgroups walk contiguous
-// row chunks, keep the weight-gradient partials in registers and fold them through LDS once at the end: part[blk][J*C + J + 2]
-// (the caller sums the TL_NB partials of [gW | gb] with one bwd_pool job over the first J*C + J columns; the last two columns carry
-// the workgroup's loss statistics, which the LAST workgroup to finish folds in index order into stats: no float atomics, the
-// result does not depend on scheduling).  C = 64, J <= TL_MAXJ; other shapes use the unfused ops.
+// row chunks, keep the weight-gradient partials in registers and fold them through LDS once at the end: part[blk][J*C + J]
+// (the caller sums the TL_NB partials of [gW | gb] with one bwd_pool job) and write their loss statistics to sws[blk][4]
+// ([0] sum |y-p|, [1] kept count: mae tail; [2] KL sum: kl head), which gptst_stats_fold sums in index order into stats: no float
+// atomics, the result does not depend on scheduling.  (Measured: 510 same-address atomics at the end of a launch — the stats
+// themselves, or a "last workgroup folds" ticket — cost ~8 us; one extra 1-workgroup launch costs 2.5.)
+// C = 64, J <= TL_MAXJ; other shapes use the unfused ops.
 #include "common.h"
 
 #define TL_NB 512
 #define TL_MAXJ 16
 
 struct TailArgs {
-    const float* X; const float* W; const float* b; float* dX; float* part; float* stats;
+    const float* X; const float* W; const float* b; float* dX; float* part; float* sws;
     int rows, J, rows_per_block;
     // mae tail
     const float* src; const float* mask; float* out; int lda; float sigma, mu, thresh;
@@ -56,43 +58,44 @@ __global__ __launch_bounds__(256) void tail_kernel(TailArgs t) {
         const size_t i = i0 + (size_t)u * RPB;
         if (i >= r1) continue;                                        // uniform per 16-lane row group; no barrier inside
         const float4 x = xs[u];
+        // per-row scalars: lane j of the row's 16-lane group loads / computes entry j (J <= 16) and the group shares the results —
+        // every lane loading all J entries itself cost 16x the load instructions (42 us for the KL head at the bench shape)
         float a[TL_MAXJ];
+        float a_own = 0.f;
+        const int gl = (threadIdx.x & 63) & ~(LPR - 1);                // first lane of this row group within the wave
         if (KIND == 0) {
+            float o_all[TL_MAXJ];
 #pragma unroll
             for (int j = 0; j < TL_MAXJ; ++j) {
-                a[j] = 0.f;
-                if (j < J) {                                          // uniform
-                    const float o = group_sum<LPR>(f4dot(x, ld4(Ws + j * C + 4 * c4))) + (t.b ? t.b[j] : 0.f);
-                    const size_t e = i * J + j;
-                    const float M = 1.f - t.mask[e];
-                    const float p = (o * t.sigma + t.mu) * M;
-                    const float y = (t.src[i * t.lda + j] * t.sigma + t.mu) * M;
-                    if (y > t.thresh) {
-                        const float d = p - y;
-                        if (c4 == 0) { s0 += fabsf(d); s1 += 1.f; }
-                        a[j] = (d > 0.f ? 1.f : (d < 0.f ? -1.f : 0.f)) * M * t.sigma;
-                    }
-                    if (c4 == 0) t.out[e] = o;
+                o_all[j] = 0.f;
+                if (j < J) o_all[j] = group_sum<LPR>(f4dot(x, ld4(Ws + j * C + 4 * c4)));      // uniform branch
+            }
+            float o = 0.f;
+#pragma unroll
+            for (int j = 0; j < TL_MAXJ; ++j) if (j == c4) o = o_all[j];
+            if (c4 < J) {
+                o += t.b ? t.b[c4] : 0.f;
+                const size_t e = i * J + c4;
+                const float M = 1.f - t.mask[e];
+                const float p = (o * t.sigma + t.mu) * M;
+                const float y = (t.src[i * t.lda + c4] * t.sigma + t.mu) * M;
+                if (y > t.thresh) {
+                    const float d = p - y;
+                    s0 += fabsf(d); s1 += 1.f;
+                    a_own = (d > 0.f ? 1.f : (d < 0.f ? -1.f : 0.f)) * M * t.sigma;
                 }
+                t.out[e] = o;
             }
         } else {
             const size_t bt = i / t.N, n = i % t.N;
-            const float* cp = t.c + bt * J * t.N + n;
-            float se = 0.f, e_[TL_MAXJ], p_[TL_MAXJ];
-#pragma unroll
-            for (int j = 0; j < TL_MAXJ; ++j) {
-                e_[j] = 0.f; p_[j] = 1.f;
-                if (j < J) { e_[j] = cp[(size_t)j * t.N]; p_[j] = t.prob[i * J + j]; }
-            }
-#pragma unroll
-            for (int j = 0; j < TL_MAXJ; ++j)
-                if (j < J) {
-                    se += e_[j];
-                    if (c4 == 0 && e_[j] > 0.f) s0 += e_[j] * (logf(e_[j]) - logf(p_[j]));
-                }
-#pragma unroll
-            for (int j = 0; j < TL_MAXJ; ++j) a[j] = j < J ? t.w * (p_[j] * se - e_[j]) : 0.f;
+            float e_ = 0.f, p_ = 1.f;
+            if (c4 < J) { e_ = t.c[(bt * J + c4) * t.N + n]; p_ = t.prob[i * J + c4]; }
+            const float se = group_sum<LPR>(e_);
+            if (c4 < J && e_ > 0.f) s0 += e_ * (logf(e_) - logf(p_));
+            a_own = c4 < J ? t.w * (p_ * se - e_) : 0.f;
         }
+#pragma unroll
+        for (int j = 0; j < TL_MAXJ; ++j) a[j] = j < J ? __shfl(a_own, gl + j, 64) : 0.f;
         float4 dx = f4zero();
 #pragma unroll
         for (int j = 0; j < TL_MAXJ; ++j)
@@ -105,8 +108,7 @@ __global__ __launch_bounds__(256) void tail_kernel(TailArgs t) {
       }
     }
     // ---- fold the 16 row slots of the workgroup, then the loss statistics ----
-    const int PS = J * C + J + 2;                                     // row stride of part
-    float* mine = t.part + (size_t)blockIdx.x * PS;
+    float* mine = t.part + (size_t)blockIdx.x * (J * C + J);
 #pragma unroll
     for (int j = 0; j < TL_MAXJ; ++j) {
         if (j >= J) continue;                                         // uniform
@@ -129,40 +131,53 @@ __global__ __launch_bounds__(256) void tail_kernel(TailArgs t) {
     if ((threadIdx.x & 63) == 0) { reds[0][threadIdx.x >> 6] = s0; reds[1][threadIdx.x >> 6] = s1; }
     __syncthreads();
     if (threadIdx.x == 0) {
-        mine[J * C + J + 0] = (reds[0][0] + reds[0][1]) + (reds[0][2] + reds[0][3]);
-        mine[J * C + J + 1] = (reds[1][0] + reds[1][1]) + (reds[1][2] + reds[1][3]);
-    }
-    unsigned* ticket = reinterpret_cast<unsigned*>(t.stats + (KIND == 0 ? 6 : 7));       // zero on entry, reset below
-    if (!last_block_arrives(ticket, gridDim.x)) return;
-    if (threadIdx.x < 64) {                                            // one wave: lane-strided, then a fixed butterfly
-        float a0 = 0.f, a1 = 0.f;
-        for (unsigned blk = threadIdx.x; blk < gridDim.x; blk += 64) {
-            a0 += ld_agent(t.part + (size_t)blk * PS + J * C + J + 0);
-            a1 += ld_agent(t.part + (size_t)blk * PS + J * C + J + 1);
-        }
-        a0 = group_sum<64>(a0); a1 = group_sum<64>(a1);
-        if (threadIdx.x == 0) {
-            if (KIND == 0) { t.stats[0] += a0; t.stats[1] += a1; } else { t.stats[2] += a0; }
-            *ticket = 0u;
-        }
+        float* w = t.sws + 4 * (size_t)blockIdx.x;
+        const float v0 = (reds[0][0] + reds[0][1]) + (reds[0][2] + reds[0][3]), v1 = (reds[1][0] + reds[1][1]) + (reds[1][2] + reds[1][3]);
+        if (KIND == 0) { w[0] = v0; w[1] = v1; } else { w[2] = v0; }
     }
 }
 
+// stats[k] += sum over rows of sws[row][k], k < 3, in a fixed order (thread t: rows t, t+256, ...; then a fixed tree)
+__global__ __launch_bounds__(256) void stats_fold_kernel(const float* __restrict__ sws, int rows, float* __restrict__ stats) {
+    __shared__ float red[3][4];
+    float s[3] = {0.f, 0.f, 0.f};
+    for (int r = threadIdx.x; r < rows; r += 256) {
+        const float4 v = ld4(sws + 4 * (size_t)r);
+        s[0] += v.x; s[1] += v.y; s[2] += v.z;
+    }
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+        s[k] = group_sum<64>(s[k]);
+        if ((threadIdx.x & 63) == 0) red[k][threadIdx.x >> 6] = s[k];
+    }
+    __syncthreads();
+    if (threadIdx.x < 3) stats[threadIdx.x] += (red[threadIdx.x][0] + red[threadIdx.x][1]) + (red[threadIdx.x][2] + red[threadIdx.x][3]);
+}
+
+thread_local int g_tl_nb = TL_NB;       // experiments: gptst_tune(6, nb)
 static void tl_geometry(int rows, int& nb, int& rpb) {
-    rpb = (rows + TL_NB - 1) / TL_NB; if (rpb < 16) rpb = 16;
+    rpb = (rows + g_tl_nb - 1) / g_tl_nb; if (rpb < 16) rpb = 16;
     nb = (rows + rpb - 1) / rpb;
 }
 
 // number of row-chunk partials that gptst_tail_mae / gptst_tail_kl write: part must hold that many x (J*C + J) floats
 extern "C" int gptst_tail_parts(int rows) { int nb, rpb; tl_geometry(rows, nb, rpb); return nb; }
 
+// sum the per-workgroup loss statistics sws (rows, 4) of the tail kernels into stats[0..2] (+=), in a fixed order
+extern "C" int gptst_stats_fold(const float* sws, int rows, float* stats, void* stream) {
+    if (!sws || !stats || rows <= 0) return GPTST_EARG;
+    hipLaunchKernelGGL(stats_fold_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, sws, rows, stats);
+    GPTST_CHECK_LAUNCH();
+    return GPTST_OK;
+}
+
 extern "C" int gptst_tail_mae(const float* dec, const float* W, const float* b, const float* src, int lda, const float* mask, float sigma,
-                              float mu, float thresh, float* out, float* d_dec, float* part, float* stats, int rows, int J, int C,
+                              float mu, float thresh, float* out, float* d_dec, float* part, float* sws, int rows, int J, int C,
                               void* stream) {
-    if (!dec || !W || !src || !mask || !out || !d_dec || !part || !stats || rows <= 0 || J <= 0) return GPTST_EARG;
+    if (!dec || !W || !src || !mask || !out || !d_dec || !part || !sws || rows <= 0 || J <= 0) return GPTST_EARG;
     if (C != 64 || J > TL_MAXJ) return GPTST_ESHAPE;
     TailArgs t{};
-    t.X = dec; t.W = W; t.b = b; t.dX = d_dec; t.part = part; t.stats = stats; t.rows = rows; t.J = J;
+    t.X = dec; t.W = W; t.b = b; t.dX = d_dec; t.part = part; t.sws = sws; t.rows = rows; t.J = J;
     t.src = src; t.mask = mask; t.out = out; t.lda = lda; t.sigma = sigma; t.mu = mu; t.thresh = thresh;
     int nb; tl_geometry(rows, nb, t.rows_per_block);
     hipLaunchKernelGGL(tail_kernel<0>, dim3(nb), dim3(256), 0, (hipStream_t)stream, t);
@@ -171,11 +186,11 @@ extern "C" int gptst_tail_mae(const float* dec, const float* W, const float* b, 
 }
 
 extern "C" int gptst_tail_kl(const float* h2, const float* W3, const float* prob, const float* c, float w, float* d_h2, float* part,
-                             float* stats, int rows, int N, int HS, int C, void* stream) {
-    if (!h2 || !W3 || !prob || !c || !d_h2 || !part || !stats || rows <= 0 || HS <= 0 || N <= 0) return GPTST_EARG;
+                             float* sws, int rows, int N, int HS, int C, void* stream) {
+    if (!h2 || !W3 || !prob || !c || !d_h2 || !part || !sws || rows <= 0 || HS <= 0 || N <= 0) return GPTST_EARG;
     if (C != 64 || HS > TL_MAXJ) return GPTST_ESHAPE;
     TailArgs t{};
-    t.X = h2; t.W = W3; t.dX = d_h2; t.part = part; t.stats = stats; t.rows = rows; t.J = HS;
+    t.X = h2; t.W = W3; t.dX = d_h2; t.part = part; t.sws = sws; t.rows = rows; t.J = HS;
     t.prob = prob; t.c = c; t.N = N; t.w = w;
     int nb; tl_geometry(rows, nb, t.rows_per_block);
     hipLaunchKernelGGL(tail_kernel<1>, dim3(nb), dim3(256), 0, (hipStream_t)stream, t);

@@ -454,19 +454,20 @@ def fused_tails_ok(p, C, base, HS):
             and _wb_view(p["encoder.MLP_RL.ln3.weight"], p["encoder.MLP_RL.ln3.bias"]) is not None)
 
 
-def loss_tail(p, g, dec, source, mask, base, sigma, mu, thresh, stats, red):
-    """dim_flow_out + masked MAE + their backward in one pass over dec (GPTST.py:455, Run.py:92-100) -> out (BTN, base), d_dec."""
+def loss_tail(p, g, dec, source, mask, base, sigma, mu, thresh, sws, red):
+    """dim_flow_out + masked MAE + their backward in one pass over dec (GPTST.py:455, Run.py:92-100) -> out (BTN, base), d_dec.
+    sws: the step's loss-statistics scratch (ops.tail_sws / arena zeros), folded into stats by ops.stats_fold."""
     wo = "decoder.dim_flow_out."
-    out, dd, part = ops.tail_mae(dec, p[wo + "weight"], p[wo + "bias"], source, base + 2, mask, sigma, mu, thresh, stats)
+    out, dd, part = ops.tail_mae(dec, p[wo + "weight"], p[wo + "bias"], source, base + 2, mask, sigma, mu, thresh, sws)
     red.jobs.bwd_pool(_ones(dec.device, part.shape[0]), part, _wb_view(g[wo + "weight"], g[wo + "bias"]))
     red.keep.append((part, dd))
     return out, dd
 
 
-def kl_head(p, g, sv_g, prob, c1, N, w, stats, red):
+def kl_head(p, g, sv_g, prob, c1, N, w, sws, red):
     """0.1 KL(eb || prob) and the backward through softmax + MLP_RL.ln3 in one pass over h2 -> d_h2 (guide_bwd(dh2=...))."""
     m = "encoder.MLP_RL."
-    dh2, part = ops.tail_kl(sv_g[3], p[m + "ln3.weight"], prob, c1, N, w, stats)
+    dh2, part = ops.tail_kl(sv_g[3], p[m + "ln3.weight"], prob, c1, N, w, sws)
     red.jobs.bwd_pool(_ones(prob.device, part.shape[0]), part, _wb_view(g[m + "ln3.weight"], g[m + "ln3.bias"]))
     red.keep.append((part, dh2))
     return dh2

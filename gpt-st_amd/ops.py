@@ -550,30 +550,43 @@ def set_deterministic(on):
 
 
 
-def tail_mae(dec, W, b, src, lda, mask, sigma, mu, thresh, stats):
+def tail_parts(rows):
+    return _C.lib().value("gptst_tail_parts", rows)
+
+
+def tail_sws(rows, device):
+    """zeroed per-workgroup loss-statistics scratch (nparts, 4) shared by tail_mae / tail_kl of one step -> stats_fold"""
+    return torch.zeros(_C.lib().value("gptst_tail_parts", rows), 4, device=device, dtype=torch.float32)
+
+
+def tail_mae(dec, W, b, src, lda, mask, sigma, mu, thresh, sws):
     """Fused output head + masked-MAE + its backward (tails.hip) -> out (rows,J), d_dec (rows,C) [gradient of the SUM loss],
-    part (nparts, J*C+J) partials of (gW, gb) — a column window of the kernel's (nparts, J*C+J+2) scratch rows.
-    stats (float[8], [6] / [7] zero on entry: tickets of the ordered fold)."""
+    part (nparts, J*C+J) partials of (gW, gb); the workgroups' (sum |y-p|, kept count) go to sws[:, 0:2] (see stats_fold)."""
     rows, C = dec.shape
     J = W.shape[0]
     nparts = _C.lib().value("gptst_tail_parts", rows)
     out = torch.empty(rows, J, device=dec.device, dtype=torch.float32)
     d_dec = torch.empty_like(dec)
-    part = torch.empty(nparts, J * C + J + 2, device=dec.device, dtype=torch.float32)
+    part = torch.empty(nparts, J * C + J, device=dec.device, dtype=torch.float32)
     _call("gptst_tail_mae", _p(dec), _p(W), _p(b), _p(src), lda, _p(mask), float(sigma), float(mu), float(thresh), _p(out), _p(d_dec),
-          _p(part), _p(stats), rows, J, C, nbytes=_nb(dec, d_dec))
-    return out, d_dec, part[:, :J * C + J]
+          _p(part), _p(sws), rows, J, C, nbytes=_nb(dec, d_dec))
+    return out, d_dec, part
 
 
-def tail_kl(h2, W3, prob, c, N, w, stats):
-    """Fused KL + softmax/ln3 backward (tails.hip) -> d_h2 (rows,C), part (nparts, HS*C+HS) partials of (gW3, gb3)."""
+def tail_kl(h2, W3, prob, c, N, w, sws):
+    """Fused KL + softmax/ln3 backward (tails.hip) -> d_h2 (rows,C), part (nparts, HS*C+HS) partials of (gW3, gb3); KL sums -> sws[:, 2]."""
     rows, C = h2.shape
     HS = W3.shape[0]
     nparts = _C.lib().value("gptst_tail_parts", rows)
     d_h2 = torch.empty_like(h2)
-    part = torch.empty(nparts, HS * C + HS + 2, device=h2.device, dtype=torch.float32)
-    _call("gptst_tail_kl", _p(h2), _p(W3), _p(prob), _p(c), float(w), _p(d_h2), _p(part), _p(stats), rows, N, HS, C, nbytes=_nb(h2, d_h2))
-    return d_h2, part[:, :HS * C + HS]
+    part = torch.empty(nparts, HS * C + HS, device=h2.device, dtype=torch.float32)
+    _call("gptst_tail_kl", _p(h2), _p(W3), _p(prob), _p(c), float(w), _p(d_h2), _p(part), _p(sws), rows, N, HS, C, nbytes=_nb(h2, d_h2))
+    return d_h2, part
+
+
+def stats_fold(sws, stats):
+    """stats[0..2] += column sums of sws in a fixed order"""
+    _call("gptst_stats_fold", _p(sws), sws.shape[0], _p(stats))
 
 
 _ADAM_WS = {}

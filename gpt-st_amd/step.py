@@ -118,11 +118,13 @@ class PretrainStep:
         if self.fused_tails:
             # output head + masked MAE + their backward: one pass over dec (the mean's 1/#kept is applied by the optimiser)
             _, dec, sv_d = engine.decoder_fwd(p, tidx, emb, dims, mdl.num_route, gen=gen[engine.DEC], head=False)
-            out, dd = engine.loss_tail(p, g, dec, src, mask, base, self.std, self.mean, a.mape_thresh, self.stats, red)
+            sws = self.arena.zeros(ops.tail_parts(M), 4)                       # per-workgroup loss statistics of the two heads
+            out, dd = engine.loss_tail(p, g, dec, src, mask, base, self.std, self.mean, a.mape_thresh, sws, red)
             engine.model_bwd(p, g, src, mask, tidx, sv_e, sv_d, dec, None, None, dims, base, mdl.scaler_zeros, red, dd=dd)
             if phase == 1:
-                dh2 = engine.kl_head(p, g, sv_g, prob, c1, self.N, 0.1, self.stats, red)
+                dh2 = engine.kl_head(p, g, sv_g, prob, c1, self.N, 0.1, sws, red)
                 engine.guide_bwd(p, g, src, tidx, sv_g, None, dims, base, red, dh2=dh2)
+            ops.stats_fold(sws, self.stats)                                    # ordered sum -> stats[0..2] (no float atomics)
         else:
             out, dec, sv_d = engine.decoder_fwd(p, tidx, emb, dims, mdl.num_route, gen=gen[engine.DEC])
             ops.mae_fwd(out, src, base + 2, mask, self.std, self.mean, a.mape_thresh, M, base, self.stats)

@@ -205,18 +205,20 @@ int gptst_timefeat_bwd(const float* wd, const float* bd, const float* ww, const 
                        const float* dout, int rows, int K, int E, void* stream);
 
 /* ---- fused thin heads (tails.hip): one pass over the C-wide activation where the loss meets the network --------------------
- * tail_mae: out = dec W^T + b (GPTST.py:455), masked-MAE statistics stats[0..1] += (Run.py:92-100, lib/metrics.py:11-18), gradient of
- *   the SUM loss w.r.t. dec -> d_dec (the 1/#kept of the mean is applied by gptst_clip_adam, hyper[9] = 1), and per-workgroup partials
- *   part[blk][J*C + J + 2]: (gW, gb) partials in the first J*C + J columns — gptst_tail_parts(rows) rows, summed by the caller (one
- *   kind-1 pool job with ldx = J*C + J + 2) — and the workgroup's loss statistics in the last two, folded into stats in index order by
- *   the last workgroup to finish (stats[6] / stats[7] are its tickets: zero on entry, zero on exit).
- * tail_kl: KL statistics stats[2] += and the backward through softmax + MLP_RL.ln3 (BasicTrainer.py:85, GPTST.py:33): d_h2 and the
- *   partials of (gW3, gb3).  prob (rows,HS) row-major, c (BT,HS,N).  C = 64 and J / HS <= 16, else GPTST_ESHAPE (use the unfused ops). */
+ * tail_mae: out = dec W^T + b (GPTST.py:455), masked-MAE statistics (Run.py:92-100, lib/metrics.py:11-18), gradient of the SUM loss
+ *   w.r.t. dec -> d_dec (the 1/#kept of the mean is applied by gptst_clip_adam, hyper[9] = 1), per-workgroup partials
+ *   part[blk][J*C + J] of (gW, gb) — gptst_tail_parts(rows) rows, summed by the caller (one kind-1 pool job) — and per-workgroup loss
+ *   statistics sws[blk][4] = (sum |y-p|, kept count, -, -).
+ * tail_kl: the backward through softmax + MLP_RL.ln3 (BasicTrainer.py:85, GPTST.py:33): d_h2, the partials of (gW3, gb3), and the
+ *   KL sum of the workgroup in sws[blk][2].  prob (rows,HS) row-major, c (BT,HS,N).
+ * stats_fold: stats[0..2] += the column sums of sws (rows, 4) in a fixed order (no float atomics anywhere on this path); rows the
+ *   tail kernels did not write must be zero.  C = 64 and J / HS <= 16, else GPTST_ESHAPE (use the unfused ops). */
 int gptst_tail_parts(int rows);
 int gptst_tail_mae(const float* dec, const float* W, const float* b, const float* src, int lda, const float* mask, float sigma, float mu,
-                   float thresh, float* out, float* d_dec, float* part, float* stats, int rows, int J, int C, void* stream);
-int gptst_tail_kl(const float* h2, const float* W3, const float* prob, const float* c, float w, float* d_h2, float* part, float* stats,
+                   float thresh, float* out, float* d_dec, float* part, float* sws, int rows, int J, int C, void* stream);
+int gptst_tail_kl(const float* h2, const float* W3, const float* prob, const float* c, float w, float* d_h2, float* part, float* sws,
                   int rows, int N, int HS, int C, void* stream);
+int gptst_stats_fold(const float* sws, int rows, float* stats, void* stream);
 
 /* njobs (<= 16) time-feature instances in ONE launch (a step has seven).  params: njobs x 10 device pointers in the module order
  * above; grads likewise (bwd != 0 only, +=); io[q]: output (fwd) or output gradient (bwd) of job q; all jobs read one tidx. */

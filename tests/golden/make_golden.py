@@ -377,7 +377,7 @@ class Injector:
         torch.rand_like, random.shuffle = self._rl, self._sh
 
 
-def gen_curve(nsteps=200, per_epoch=50, lr=None, name="curve_c2.npz", perturb_seed=None):
+def gen_curve(nsteps=200, per_epoch=50, lr=None, name="curve_c2.npz", perturb_seed=None, perturb_rel=None):
     """Loss curve at the BASELINE configs[1] shape (G5b): `nsteps` optimiser steps of the REFERENCE model (B=32, N=170, C=64) with a
     shortened schedule (epochs=4, change_epoch=2: random-mask phase, then adaptive mask + KL), mask noise / class order derived
     from seeds (synth.make_noise / synth.class_order).  Stored per step: epoch, seeds, the reference's mask (bit-packed), losses."""
@@ -389,12 +389,15 @@ def gen_curve(nsteps=200, per_epoch=50, lr=None, name="curve_c2.npz", perturb_se
     train, _, _, scaler, _, _ = gdata.get_dataloader(args, raw=raw)
     args.scaler_zeros = float(scaler.transform(0))
     model = build_ref_model(args, 12)
-    if perturb_seed is not None:          # envelope run: every initial parameter moved by ONE ulp in a random direction
+    if perturb_seed is not None:          # envelope run: every initial parameter moved by one ulp (or by perturb_rel, relative) randomly
         g = torch.Generator().manual_seed(perturb_seed)
         with torch.no_grad():
             for p in model.parameters():
-                up = torch.rand(p.shape, generator=g) < 0.5
-                p.copy_(torch.where(up, torch.nextafter(p, torch.full_like(p, float("inf"))), torch.nextafter(p, torch.full_like(p, -float("inf")))))
+                if perturb_rel is None:
+                    up = torch.rand(p.shape, generator=g) < 0.5
+                    p.copy_(torch.where(up, torch.nextafter(p, torch.full_like(p, float("inf"))), torch.nextafter(p, torch.full_like(p, -float("inf")))))
+                else:
+                    p.mul_(1.0 + perturb_rel * torch.randn(p.shape, generator=g))
     opt = torch.optim.Adam(params=model.parameters(), lr=args.lr_init, eps=1.0e-8, weight_decay=0, amsgrad=False)
     sc = StandardScaler(float(scaler.mean), float(scaler.std))
     B, T, N, base, HS = 32, 12, args.num_nodes, 1, args.HS
@@ -441,13 +444,14 @@ def gen_curve(nsteps=200, per_epoch=50, lr=None, name="curve_c2.npz", perturb_se
     print("wrote", name)
 
 
-def gen_curve_envelope(K=8, name="curve_c2_env.npz"):
+def gen_curve_envelope(K=8, name="curve_c2_env.npz", perturb_rel=None):
     """fp32 envelope of the reference's own loss curve: K more runs of gen_curve's schedule, each from an initial state that differs
     from the golden run's by one ulp per parameter (free-running masks: the same noise and class orders, the run's own cluster labels).
     Two correct fp32 implementations of the step can differ by this much and no less: tests/test_gpu_curve.py asks the HIP curve to
     stay inside [min, max] of these runs (plus the golden one) at every step."""
-    runs = [gen_curve(perturb_seed=100 + k) for k in range(K)]
-    np.savez_compressed(os.path.join(HERE, name), losses=np.stack(runs), perturb_seeds=np.arange(100, 100 + K))
+    runs = [gen_curve(perturb_seed=100 + k, perturb_rel=perturb_rel) for k in range(K)]
+    np.savez_compressed(os.path.join(HERE, name), losses=np.stack(runs), perturb_seeds=np.arange(100, 100 + K),
+                        perturb_rel=np.float64(perturb_rel if perturb_rel is not None else 0.0))
     print("wrote", name)
 
 
@@ -468,5 +472,7 @@ if __name__ == "__main__":
         gen_curve()
     if "curve_env" in which:        # K reference runs from 1-ulp perturbed initial states (~25 min)
         gen_curve_envelope()
+    if "curve_env_1e-6" in which:   # ... and from initial states perturbed by 1e-6 relative: the size of the difference between two fp32
+        gen_curve_envelope(name="curve_c2_env_rel1e-6.npz", perturb_rel=1e-6)     # implementations of ONE forward pass (measured)
     if "curve_lowlr" in which:      # the same run at a tenth of the learning rate: contracting enough to be compared pointwise
         gen_curve(lr=3e-4, name="curve_c2_lr3e-4.npz")

@@ -528,8 +528,9 @@ def test_tail_mae_matches_unfused_ops(J, rows):
     src = rnd(rows, lda, g=g)
     mask = (torch.rand(rows * J, generator=g) > 0.25).float()
     sigma, mu, thr = 146.0, 230.0, 0.0
-    stats = torch.zeros(8, device=dev)
-    out, dd, part = ops.tail_mae(dec.to(dev), W.to(dev), b.to(dev), src.to(dev), lda, mask.to(dev), sigma, mu, thr, stats)
+    stats, sws = torch.zeros(8, device=dev), ops.tail_sws(rows, dev)
+    out, dd, part = ops.tail_mae(dec.to(dev), W.to(dev), b.to(dev), src.to(dev), lda, mask.to(dev), sigma, mu, thr, sws)
+    ops.stats_fold(sws, stats)
     out_r = dec @ W.t() + b
     close(out, out_r, what="tail out")
     M = (1 - mask).view(rows, J)
@@ -553,8 +554,9 @@ def test_tail_kl_matches_unfused_ops(HS, N, BT):
     h2, W3 = rnd(rows, C, g=g), rnd(HS, C, g=g, scale=0.2)
     prob = torch.softmax(rnd(rows, HS, g=g), -1)
     c = torch.softmax(rnd(BT, HS, N, g=g), 1).contiguous()
-    stats = torch.zeros(8, device=dev)
-    dh2, part = ops.tail_kl(h2.to(dev), W3.to(dev), prob.to(dev), c.to(dev), N, 0.1, stats)
+    stats, sws = torch.zeros(8, device=dev), ops.tail_sws(rows, dev)
+    dh2, part = ops.tail_kl(h2.to(dev), W3.to(dev), prob.to(dev), c.to(dev), N, 0.1, sws)
+    ops.stats_fold(sws, stats)
     stats_r = torch.zeros(8, device=dev)
     dlogit = ops.kl(prob.to(dev), c.to(dev), N, 0.1, stats_r).cpu()
     assert abs(float(stats[2]) - float(stats_r[2])) < 1e-4 * abs(float(stats_r[2])) + 1e-6

@@ -30,6 +30,18 @@ rec = ops.cap_rec_fwd(c, v, N, C)
 dc1, dv = ops.cap_rec_bwd(dO2, c, v)
 dS, ddyn = ops.cap_cross_bwd(dv, s, Rt, Ht, dyn, tmpl, B, T, HS, HT)
 
+Wo, bo = f(1, C) * 0.2, f(1)
+W3, b3 = f(HS, C) * 0.2, f(HS)
+Wi, bi = f(C, 1), f(C)
+src = f(B * T * N, 3)
+mask = (torch.rand(B * T * N, device=dev) > 0.25).float()
+prob = torch.softmax(f(B * T * N, HS), -1)
+stats = torch.zeros(8, device=dev)
+sws = ops.tail_sws(B * T * N, dev)
+lc = torch.tensor([3, 1, 0, 4, 2, 9, 8, 7, 6, 5], dtype=torch.int32, device=dev)
+nums = torch.tensor([8000, 8320], dtype=torch.int32, device=dev)
+na, nr = torch.rand(B * T * N, device=dev), torch.rand(B * T * N, device=dev)
+
 CASES = {
     "hypertem_fwd": lambda: ops.hypertem_fwd(X, G, Wbt, bbt),
     "hypertem_bwd": lambda: ops.hypertem_bwd(dO, out, X, G, Wbt, dG=dGp, want_dbias=False),
@@ -46,6 +58,12 @@ CASES = {
     "cap_cross_bwd": lambda: ops.cap_cross_bwd(dv, s, Rt, Ht, dyn, tmpl, B, T, HS, HT),
     "cap_route_bwd": lambda: ops.cap_route_bwd(X, Wp, bp, c, dc1, dS),
     "copy_A": lambda: X2.clone(),
+    "tail_mae": lambda: ops.tail_mae(X2, Wo, bo, src, 3, mask, 146.0, 230.0, 0.0, sws),
+    "tail_kl": lambda: ops.tail_kl(X2, W3, prob, c, N, 0.1, sws),
+    "stats_fold": lambda: ops.stats_fold(sws, stats),
+    "rowdot_softmax": lambda: ops.rowdot(X2, W3, b3, softmax=True, want_label=True),
+    "lin_in": lambda: ops.lin_in(src, 3, 1, Wi, bi, C),
+    "mask_adaptive": lambda: ops.mask_adaptive(*ops.mask_labels(prob), lc, nums, na, nr, True, 1),
 }
 
 
@@ -67,6 +85,12 @@ def bench(fn, n=20):
 
 
 flt = sys.argv[1] if len(sys.argv) > 1 else ""
+if flt == "tailsweep":
+    from gptst_amd import _C
+    for nb in (256, 512, 1024, 2048, 4080):
+        _C.lib().call("gptst_tune", 6, nb)
+        print("TL_NB", nb, "tail_mae %.2f us  tail_kl %.2f us" % (bench(CASES["tail_mae"]), bench(CASES["tail_kl"])))
+    sys.exit(0)
 tot = 0.0
 for k, fn in CASES.items():
     if flt in k:
