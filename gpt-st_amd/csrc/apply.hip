@@ -399,6 +399,146 @@ __global__ __launch_bounds__(256, 2) void wgrad64_kernel(const float* __restrict
     }
 }
 
+// =====================================================================================================================
+// Backward of one generated-weight layer in ONE pass (C = 64):   out = lrelu(S W_g + b_g [+ x])   with saved input S
+//   dPre = dOut * lrelu'(out);   dS = dPre W_g^T   (data gradient);   dW_g = S^T dPre  (per row split);   db_g = colsum(dPre)
+// replacing apply64<PRO_DPRE> + wgrad64<PRO_DPRE>, which both read dOut and out (26 us -> one launch).  A wave walks its 16-row tiles:
+// dOut / out / S are loaded ONCE in the weight-gradient operand layout (lane (j,kk): rows 4s+kk, channels 4j..4j+3), dPre feeds the 64
+// weight-gradient MFMAs from registers, then goes through a wave-private LDS tile to change to the data-gradient operand layout (lane
+// (j,kk): row j, channels 16q+4kk..) for the 64 MFMAs against the register-resident W^T fragments.  The weight-gradient tiles of the 4
+// waves fold through LDS at the end (the fold buffer aliases the weight staging area and the transposition tiles: 64.3 KB, 2 per CU).
+// =====================================================================================================================
+__global__ __launch_bounds__(256, 2) void applywg64_kernel(const float* __restrict__ dOut, const float* __restrict__ Y,
+                                                            const float* __restrict__ S, const float* __restrict__ W, long w_gstride,
+                                                            float* __restrict__ dS, float* __restrict__ dW, float* __restrict__ colsum,
+                                                            RowMap rm, int tiles_per_wave) {
+    constexpr int C = 64, TP = C + 4;
+    __shared__ __attribute__((aligned(16))) float smem[4 * C * C];            // fold [4][C*C]; first: Wl [C*C] | 4 tiles [16][TP]
+    __shared__ __attribute__((aligned(16))) float csl[4][C];
+    float* Wl = smem;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    float* tile = smem + C * C + wave * 16 * TP;
+    const int j = lane & 15, kk = lane >> 4;
+    const int g = blockIdx.x;
+    const int ntiles = (rm.M + 15) / 16;
+    const int t0 = (blockIdx.y * 4 + wave) * tiles_per_wave, t1 = min(ntiles, t0 + tiles_per_wave);
+    float4 d[4], y[4], a[4];
+    auto fetch = [&](int t) {
+#pragma unroll
+        for (int s4 = 0; s4 < 4; ++s4) {
+            const int m = min(t * 16 + 4 * s4 + kk, rm.M - 1);
+            const size_t off = ((size_t)g * rm.rs_g + (size_t)m * rm.rs_m) * C + 4 * j;
+            d[s4] = ld4(dOut + off); y[s4] = ld4(Y + off); a[s4] = ld4(S + off);
+        }
+    };
+    if (t0 < t1) fetch(t0);                          // in flight while the weight is staged
+    load_w_lds<C, 256>(Wl, W + (size_t)g * w_gstride, 1, threadIdx.x);        // W_g^T: dS = dPre W_g^T
+    __syncthreads();
+    float4 bv[4][4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) bv[q][e] = ld4(Wl + (16 * q + 4 * kk + e) * C + 4 * j);
+    f32x4 accw[4][4];
+#pragma unroll
+    for (int ca = 0; ca < 4; ++ca)
+#pragma unroll
+        for (int cb = 0; cb < 4; ++cb) accw[ca][cb] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    float4 cs = f4zero();
+    for (int t = t0; t < t1; ++t) {
+        SB();
+        // ---- dPre in the weight-gradient layout; rows beyond M contribute nothing ----
+#pragma unroll
+        for (int s4 = 0; s4 < 4; ++s4) {
+            float4 v = make_float4(d[s4].x * lrelu_grad_from_out(y[s4].x), d[s4].y * lrelu_grad_from_out(y[s4].y),
+                                   d[s4].z * lrelu_grad_from_out(y[s4].z), d[s4].w * lrelu_grad_from_out(y[s4].w));
+            if (t * 16 + 4 * s4 + kk >= rm.M) v = f4zero();
+            d[s4] = v;
+            cs = f4add(cs, v);
+            st4(tile + (4 * s4 + kk) * TP + 4 * j, v);
+        }
+        // ---- dW += S^T dPre: component ca of S / cb of dPre feed accumulator tile (ca, cb) (as wgrad64_kernel) ----
+#pragma unroll
+        for (int s4 = 0; s4 < 4; ++s4) {
+            const float av[4] = {a[s4].x, a[s4].y, a[s4].z, a[s4].w}, dv[4] = {d[s4].x, d[s4].y, d[s4].z, d[s4].w};
+#pragma unroll
+            for (int ca = 0; ca < 4; ++ca)
+#pragma unroll
+                for (int cb = 0; cb < 4; ++cb) accw[ca][cb] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[ca], dv[cb], accw[ca][cb], 0, 0, 0);
+        }
+        SB();
+        // ---- dPre tile back in the data-gradient operand layout (wave-private tile: no barrier) ----
+        float4 ap[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) ap[q] = ld4(tile + j * TP + 16 * q + 4 * kk);
+        const int tcur = t;
+        if (t + 1 < t1) fetch(t + 1);                // next tile's operands: in flight during the 64 MFMAs below
+        SB();
+        f32x4 acc[4];
+#pragma unroll
+        for (int ct = 0; ct < 4; ++ct) acc[ct] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const float av[4] = {ap[q].x, ap[q].y, ap[q].z, ap[q].w};
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                acc[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[e], bv[q][e].x, acc[0], 0, 0, 0);
+                acc[1] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[e], bv[q][e].y, acc[1], 0, 0, 0);
+                acc[2] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[e], bv[q][e].z, acc[2], 0, 0, 0);
+                acc[3] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[e], bv[q][e].w, acc[3], 0, 0, 0);
+            }
+        }
+        SB();
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int m = tcur * 16 + kk * 4 + r;
+            if (m < rm.M) st4(dS + ((size_t)g * rm.rs_g + (size_t)m * rm.rs_m) * C + 4 * j, make_float4(acc[0][r], acc[1][r], acc[2][r], acc[3][r]));
+        }
+    }
+    // ---- column sums of dPre (bias gradient partial of this row split) and the weight-gradient fold ----
+    cs.x += __shfl_xor(cs.x, 16, 64); cs.y += __shfl_xor(cs.y, 16, 64); cs.z += __shfl_xor(cs.z, 16, 64); cs.w += __shfl_xor(cs.w, 16, 64);
+    cs.x += __shfl_xor(cs.x, 32, 64); cs.y += __shfl_xor(cs.y, 32, 64); cs.z += __shfl_xor(cs.z, 32, 64); cs.w += __shfl_xor(cs.w, 32, 64);
+    if (kk == 0) st4(&csl[wave][4 * j], cs);
+    __syncthreads();                                 // every wave is done with Wl and its tile: smem becomes the fold buffer
+    float* red = smem + wave * C * C;
+#pragma unroll
+    for (int ca = 0; ca < 4; ++ca)
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+            st4(&red[(4 * (kk * 4 + r) + ca) * C + 4 * j], make_float4(accw[ca][0][r], accw[ca][1][r], accw[ca][2][r], accw[ca][3][r]));
+    __syncthreads();
+    if (colsum != nullptr && threadIdx.x < C)
+        colsum[((size_t)blockIdx.y * rm.G + g) * C + threadIdx.x] = (csl[0][threadIdx.x] + csl[1][threadIdx.x]) + (csl[2][threadIdx.x] + csl[3][threadIdx.x]);
+    float* o = dW + ((size_t)blockIdx.y * rm.G + g) * (size_t)(C * C);
+#pragma unroll
+    for (int k = 0; k < C * C / 4 / 256; ++k) {
+        const int f = threadIdx.x + k * 256;
+        const float4 s4 = f4add(f4add(ld4(smem + 4 * f), ld4(smem + C * C + 4 * f)), f4add(ld4(smem + 2 * C * C + 4 * f), ld4(smem + 3 * C * C + 4 * f)));
+        st4(o + 4 * f, s4);
+    }
+}
+
+// row splits (= weight-gradient and bias-gradient partials per group) of gptst_apply_wgrad at this shape
+extern "C" int gptst_apply_wgrad_nsplit(int mode, int BT, int N) {
+    RowMap rm = make_rowmap(mode, BT, N);
+    int tpw, gy;
+    apply64_geometry(rm, false, tpw, gy);
+    return gy;
+}
+
+// dS (rows, C), dW (nsplit*G, C, C), colsum (nsplit*G, C) or NULL; W (G, C, C) row-major [in][out] as in the forward.  C = 64.
+extern "C" int gptst_apply_wgrad(const float* dOut, const float* Y, const float* S, const float* W, float* dS, float* dW, float* colsum,
+                                 int mode, int BT, int N, int C, void* stream) {
+    if (!dOut || !Y || !S || !W || !dS || !dW || BT <= 0 || N <= 0 || mode < 0 || mode > 1) return GPTST_EARG;
+    if (C != 64) return GPTST_ESHAPE;
+    RowMap rm = make_rowmap(mode, BT, N);
+    int tpw, gy;
+    apply64_geometry(rm, false, tpw, gy);
+    hipLaunchKernelGGL(applywg64_kernel, dim3(rm.G, gy), dim3(256), 0, (hipStream_t)stream, dOut, Y, S, W, (long)C * C, dS, dW, colsum, rm, tpw);
+    GPTST_CHECK_LAUNCH();
+    return GPTST_OK;
+}
+
 // dW[g] (C x C, [i][o]) = sum_m A[row(g,m)][i] * D[row(g,m)][o];  both operands come straight from global memory:
 // for MFMA step s the half-wave h reads row m = 2s+h, 32 consecutive floats (128 B) of each operand.
 template <int C, int PRO>

@@ -232,8 +232,12 @@ def cap_core_bwd(p, g, pfx, saved, dout, dims, HS, HT, red):
     B, T, N, C = dims
     x, out, rec, c, s, v, Ht, Rt, dyn, Wn = saved
     BT, dev = B * T, x.device
-    drec, dbn, nsb = ops.apply(dout, Wn, MODE_NODE, BT, N, A2=out, transw=True, pro=PRO_DPRE, colsum=True)      # dbn: (nsb*N, C) partials
-    dWn, ns = _wgrad_async(rec, dout, MODE_NODE, BT, N, D2=out, pro=PRO_DPRE)
+    if C == 64 and CTX.SIDE is None:     # data gradient, weight gradient and bias gradient of the node-conditioned layer in one pass
+        drec, dWn, dbn, ns = ops.apply_wgrad(dout, out, rec, Wn, MODE_NODE, BT, N)
+        nsb = ns
+    else:
+        drec, dbn, nsb = ops.apply(dout, Wn, MODE_NODE, BT, N, A2=out, transw=True, pro=PRO_DPRE, colsum=True)      # dbn: (nsb*N, C) partials
+        dWn, ns = _wgrad_async(rec, dout, MODE_NODE, BT, N, D2=out, pro=PRO_DPRE)
     dc1, dv = ops.cap_rec_bwd(drec, c, v, reduce_nodes=CTX.NODE_REDUCE)
     dS, ddyn = ops.cap_cross_bwd(dv, s, Rt, Ht, dyn, p[pfx + "mask_template"], B, T, HS, HT)
     dY, dlogit = ops.cap_route_bwd(x.view(B, T, N, C), p[pfx + "ln_p.weight"], p[pfx + "ln_p.bias"], c, dc1, dS)
@@ -273,8 +277,12 @@ def condlin_bwd(saved, dout, emb, wpool, bpool, g_wpool, g_bpool, d_emb, mode, d
     B, T, N, C = dims
     x, out, Wg = saved
     R, K = emb.shape
-    dx, db, nsb = ops.apply(dout, Wg, mode, B * T, N, A2=out, transw=True, pro=PRO_DPRE, colsum=True)
-    dW, ns = ops.wgrad(x, dout, mode, B * T, N, D2=out, pro=PRO_DPRE)
+    if C == 64:
+        dx, dW, db, ns = ops.apply_wgrad(dout, out, x, Wg, mode, B * T, N)
+        nsb = ns
+    else:
+        dx, db, nsb = ops.apply(dout, Wg, mode, B * T, N, A2=out, transw=True, pro=PRO_DPRE, colsum=True)
+        dW, ns = ops.wgrad(x, dout, mode, B * T, N, D2=out, pro=PRO_DPRE)
     dW = dW.view(ns * R, C * C)
     red.jobs.bwd_pool(emb, dW, g_wpool.view(K, C * C), nsplit=ns)
     red.jobs.bwd_pool(emb, db, g_bpool, nsplit=nsb)

@@ -199,6 +199,20 @@ def apply(A, W, mode, BT, N, bias=None, resid=None, A2=None, transw=False, pro=P
     return out
 
 
+def apply_wgrad(dOut, Y, S, W, mode, BT, N):
+    """Fused backward of a generated-weight layer (C = 64): -> (dS (rows,C), dW (ns*G, C*C), dbias (ns*G, C), ns)."""
+    _chk(dOut, Y, S, W)
+    C = dOut.shape[-1]
+    G = BT if mode == MODE_TIME else N
+    ns = _C.lib().value("gptst_apply_wgrad_nsplit", mode, BT, N)
+    dS = torch.empty_like(dOut)
+    dW = torch.empty(ns * G, C * C, device=dOut.device, dtype=torch.float32)
+    db = torch.empty(ns * G, C, device=dOut.device, dtype=torch.float32)
+    _call("gptst_apply_wgrad", _p(dOut), _p(Y), _p(S), _p(W), _p(dS), _p(dW), _p(db), mode, BT, N, C, tag="mode%d" % mode,
+          nbytes=_nb(dOut, Y, S, W, dS, dW))
+    return dS, dW, db, ns
+
+
 def wgrad_nsplit(mode, BT, N):
     return _C.lib().value("gptst_wgrad_nsplit", mode, BT, N)
 

@@ -88,6 +88,15 @@ int gptst_wgrad(const float* A, const float* D, const float* D2, float* dW, int 
 int gptst_wgrad_colsum(const float* A, const float* D, const float* D2, float* dW, int mode, int pro, int which, int BT, int N, int C,
                        void* stream);
 
+/* Backward of one generated-weight layer out = lrelu(S W_g + b_g [+ x]) in ONE pass (C = 64; mode 0 TIME / 1 NODE):
+ * dPre = dOut*lrelu'(Y); dS = dPre W_g^T; per row split s < gptst_apply_wgrad_nsplit: dW[s][g] = S^T dPre, colsum[s][g] = column sums
+ * of dPre (may be NULL).  Replaces gptst_apply(pro=1, transw=1, colsum) + gptst_wgrad(pro=1), which both read dOut and Y.
+ * W (G,C,C) as in the forward ([in][out]).  Backward of einsum('btni,nio->btno') / ('btni,btio->btno') + bias + LeakyReLU
+ * (GPTST.py:26-27,31-32,139-141). */
+int gptst_apply_wgrad_nsplit(int mode, int BT, int N);
+int gptst_apply_wgrad(const float* dOut, const float* Y, const float* S, const float* W, float* dS, float* dW, float* colsum, int mode,
+                      int BT, int N, int C, void* stream);
+
 /* ---- per-node temporal hypergraph of hyperTem (tmix.hip), GPTST.py:156-158 -----------------------------
  * A (N,Hm,T) = node_emb . adj (via poolgen);  G[n] = A[n]^T A[n] (T x T);  ret[b,:,n,:] = G[n] X[b,:,n,:]. */
 int gptst_gram_fwd(const float* A, float* G, int N, int Hm, void* stream);

@@ -595,3 +595,28 @@ def test_wgrad_colsum_of_dpre_and_column_window_jobs():
     close(gw, te.t() @ dW_ref, what="window bwd_pool W")
     close(gb, te.t() @ db_ref, what="window bwd_pool b")
     close(dte, dW_ref @ wpool.t() + db_ref @ bpool.t(), what="window bwd_emb")
+
+
+@pytest.mark.parametrize("mode,BT,N", [(1, 384, 170), (0, 384, 170), (1, 24, 37), (0, 24, 37), (1, 7, 5)])
+def test_apply_wgrad_fused_layer_backward(mode, BT, N):
+    """gptst_apply_wgrad == the reference backward of out = lrelu(S W_g + b_g + x): dS, dW_g, db_g (row-split partials summed)."""
+    from gptst_amd import ops
+    dev = _dev()
+    g = torch.Generator().manual_seed(41 + mode)
+    C = 64
+    G = BT if mode == 0 else N
+    dO, Y, S = rnd(BT, N, C, g=g), rnd(BT, N, C, g=g), rnd(BT, N, C, g=g)
+    W = rnd(G, C, C, g=g, scale=0.2)
+    dpre = dO * torch.where(Y > 0, torch.ones_like(Y), torch.full_like(Y, 0.01))
+    if mode == 0:
+        dS_r = torch.einsum("gno,gio->gni", dpre, W)
+        dW_r = torch.einsum("gni,gno->gio", S, dpre)
+        db_r = dpre.sum(1)
+    else:
+        dS_r = torch.einsum("bno,nio->bni", dpre, W)
+        dW_r = torch.einsum("bni,bno->nio", S, dpre)
+        db_r = dpre.sum(0)
+    dS, dW, db, ns = ops.apply_wgrad(dO.view(-1, C).to(dev), Y.view(-1, C).to(dev), S.view(-1, C).to(dev), W.to(dev), mode, BT, N)
+    close(dS.view(BT, N, C), dS_r, what="apply_wgrad dS")
+    close(dW.view(ns, G, C, C).sum(0), dW_r, what="apply_wgrad dW")
+    close(db.view(ns, G, C).sum(0), db_r, what="apply_wgrad db")
