@@ -408,8 +408,13 @@ __global__ __launch_bounds__(256, 2) void wgrad64_kernel(const float* __restrict
 // (j,kk): row j, channels 16q+4kk..) for the 64 MFMAs against the register-resident W^T fragments.  The weight-gradient tiles of the 4
 // waves fold through LDS at the end (the fold buffer aliases the weight staging area and the transposition tiles: 64.3 KB, 2 per CU).
 // =====================================================================================================================
+// KIND 0: generated-weight layer (above).  KIND 1: the shared Linear at the entry of `cap` (P = squash(X Wp^T + bp), GPTST.py:102) together
+// with the residual branch of the layer:  dX = dY Wp + dOut*lrelu'(out),  dWp = dY^T X,  dbp = colsum(dY)  — here "dOut" carries dY (no
+// activation), S = X, W = Wp ([out][in], used untransposed), and resid / resid2 = the layer's output gradient and output.
+template <int KIND>
 __global__ __launch_bounds__(256, 2) void applywg64_kernel(const float* __restrict__ dOut, const float* __restrict__ Y,
                                                             const float* __restrict__ S, const float* __restrict__ W, long w_gstride,
+                                                            const float* __restrict__ resid, const float* __restrict__ resid2,
                                                             float* __restrict__ dS, float* __restrict__ dW, float* __restrict__ colsum,
                                                             RowMap rm, int tiles_per_wave) {
     constexpr int C = 64, TP = C + 4;
@@ -428,11 +433,12 @@ __global__ __launch_bounds__(256, 2) void applywg64_kernel(const float* __restri
         for (int s4 = 0; s4 < 4; ++s4) {
             const int m = min(t * 16 + 4 * s4 + kk, rm.M - 1);
             const size_t off = ((size_t)g * rm.rs_g + (size_t)m * rm.rs_m) * C + 4 * j;
-            d[s4] = ld4(dOut + off); y[s4] = ld4(Y + off); a[s4] = ld4(S + off);
+            d[s4] = ld4(dOut + off); a[s4] = ld4(S + off);
+            if (KIND == 0) y[s4] = ld4(Y + off);
         }
     };
     if (t0 < t1) fetch(t0);                          // in flight while the weight is staged
-    load_w_lds<C, 256>(Wl, W + (size_t)g * w_gstride, 1, threadIdx.x);        // W_g^T: dS = dPre W_g^T
+    load_w_lds<C, 256>(Wl, W + (size_t)g * w_gstride, KIND == 0 ? 1 : 0, threadIdx.x);     // KIND 0: W_g^T (dS = dPre W_g^T); 1: Wp as stored
     __syncthreads();
     float4 bv[4][4];
 #pragma unroll
@@ -446,12 +452,14 @@ __global__ __launch_bounds__(256, 2) void applywg64_kernel(const float* __restri
         for (int cb = 0; cb < 4; ++cb) accw[ca][cb] = (f32x4){0.f, 0.f, 0.f, 0.f};
     float4 cs = f4zero();
     for (int t = t0; t < t1; ++t) {
+        if (KIND == 1 && t != t0) fetch(t);          // (KIND 1 keeps no prefetch: its epilogue operands need the registers)
         SB();
         // ---- dPre in the weight-gradient layout; rows beyond M contribute nothing ----
 #pragma unroll
         for (int s4 = 0; s4 < 4; ++s4) {
-            float4 v = make_float4(d[s4].x * lrelu_grad_from_out(y[s4].x), d[s4].y * lrelu_grad_from_out(y[s4].y),
-                                   d[s4].z * lrelu_grad_from_out(y[s4].z), d[s4].w * lrelu_grad_from_out(y[s4].w));
+            float4 v = d[s4];
+            if (KIND == 0) v = make_float4(d[s4].x * lrelu_grad_from_out(y[s4].x), d[s4].y * lrelu_grad_from_out(y[s4].y),
+                                           d[s4].z * lrelu_grad_from_out(y[s4].z), d[s4].w * lrelu_grad_from_out(y[s4].w));
             if (t * 16 + 4 * s4 + kk >= rm.M) v = f4zero();
             d[s4] = v;
             cs = f4add(cs, v);
@@ -460,11 +468,13 @@ __global__ __launch_bounds__(256, 2) void applywg64_kernel(const float* __restri
         // ---- dW += S^T dPre: component ca of S / cb of dPre feed accumulator tile (ca, cb) (as wgrad64_kernel) ----
 #pragma unroll
         for (int s4 = 0; s4 < 4; ++s4) {
-            const float av[4] = {a[s4].x, a[s4].y, a[s4].z, a[s4].w}, dv[4] = {d[s4].x, d[s4].y, d[s4].z, d[s4].w};
+            // KIND 0: dW = S^T dPre ([in][out]);  KIND 1: dWp = dY^T X ([out][in]) — the roles of the two operands swap
+            const float sv[4] = {a[s4].x, a[s4].y, a[s4].z, a[s4].w}, dv[4] = {d[s4].x, d[s4].y, d[s4].z, d[s4].w};
 #pragma unroll
             for (int ca = 0; ca < 4; ++ca)
 #pragma unroll
-                for (int cb = 0; cb < 4; ++cb) accw[ca][cb] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[ca], dv[cb], accw[ca][cb], 0, 0, 0);
+                for (int cb = 0; cb < 4; ++cb)
+                    accw[ca][cb] = __builtin_amdgcn_mfma_f32_16x16x4f32(KIND == 0 ? sv[ca] : dv[ca], KIND == 0 ? dv[cb] : sv[cb], accw[ca][cb], 0, 0, 0);
         }
         SB();
         // ---- dPre tile back in the data-gradient operand layout (wave-private tile: no barrier) ----
@@ -472,7 +482,16 @@ __global__ __launch_bounds__(256, 2) void applywg64_kernel(const float* __restri
 #pragma unroll
         for (int q = 0; q < 4; ++q) ap[q] = ld4(tile + j * TP + 16 * q + 4 * kk);
         const int tcur = t;
-        if (t + 1 < t1) fetch(t + 1);                // next tile's operands: in flight during the 64 MFMAs below
+        if (KIND == 0 && t + 1 < t1) fetch(t + 1);   // next tile's operands: in flight during the 64 MFMAs below
+        float4 rv[4], rv2[4];
+        if (KIND == 1) {                             // residual branch operands of the epilogue, in the D layout
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int m = min(tcur * 16 + kk * 4 + r, rm.M - 1);
+                const size_t off = ((size_t)g * rm.rs_g + (size_t)m * rm.rs_m) * C + 4 * j;
+                rv[r] = ld4(resid + off); rv2[r] = ld4(resid2 + off);
+            }
+        }
         SB();
         f32x4 acc[4];
 #pragma unroll
@@ -492,7 +511,12 @@ __global__ __launch_bounds__(256, 2) void applywg64_kernel(const float* __restri
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
             const int m = tcur * 16 + kk * 4 + r;
-            if (m < rm.M) st4(dS + ((size_t)g * rm.rs_g + (size_t)m * rm.rs_m) * C + 4 * j, make_float4(acc[0][r], acc[1][r], acc[2][r], acc[3][r]));
+            float4 o4 = make_float4(acc[0][r], acc[1][r], acc[2][r], acc[3][r]);
+            if (KIND == 1) {
+                o4.x = fmaf(rv[r].x, lrelu_grad_from_out(rv2[r].x), o4.x); o4.y = fmaf(rv[r].y, lrelu_grad_from_out(rv2[r].y), o4.y);
+                o4.z = fmaf(rv[r].z, lrelu_grad_from_out(rv2[r].z), o4.z); o4.w = fmaf(rv[r].w, lrelu_grad_from_out(rv2[r].w), o4.w);
+            }
+            if (m < rm.M) st4(dS + ((size_t)g * rm.rs_g + (size_t)m * rm.rs_m) * C + 4 * j, o4);
         }
     }
     // ---- column sums of dPre (bias gradient partial of this row split) and the weight-gradient fold ----
@@ -534,7 +558,30 @@ extern "C" int gptst_apply_wgrad(const float* dOut, const float* Y, const float*
     RowMap rm = make_rowmap(mode, BT, N);
     int tpw, gy;
     apply64_geometry(rm, false, tpw, gy);
-    hipLaunchKernelGGL(applywg64_kernel, dim3(rm.G, gy), dim3(256), 0, (hipStream_t)stream, dOut, Y, S, W, (long)C * C, dS, dW, colsum, rm, tpw);
+    hipLaunchKernelGGL(applywg64_kernel<0>, dim3(rm.G, gy), dim3(256), 0, (hipStream_t)stream, dOut, Y, S, W, (long)C * C, nullptr, nullptr, dS,
+                       dW, colsum, rm, tpw);
+    GPTST_CHECK_LAUNCH();
+    return GPTST_OK;
+}
+
+// Backward through the shared Linear at the entry of cap plus the residual branch of the layer (GPTST.py:102,139-141), one pass:
+//   dX = dY Wp + dOut*lrelu'(out);  per row split s < gptst_linear_bwd_nsplit: dWp[s] = dY^T X ([out][in]), dbp[s] = colsum(dY).
+// Replaces gptst_apply(mode 2, epi 2) + gptst_wgrad_colsum(mode 2).  rows = BT*N.  C = 64.
+extern "C" int gptst_linear_bwd_nsplit(int rows) {
+    RowMap rm = make_rowmap(2, rows, 1);
+    int tpw, gy;
+    apply64_geometry(rm, false, tpw, gy);
+    return gy;
+}
+
+extern "C" int gptst_linear_bwd(const float* dY, const float* X, const float* Wp, const float* dOut, const float* out, float* dX, float* dWp,
+                                float* dbp, int rows, int C, void* stream) {
+    if (!dY || !X || !Wp || !dOut || !out || !dX || !dWp || !dbp || rows <= 0) return GPTST_EARG;
+    if (C != 64) return GPTST_ESHAPE;
+    RowMap rm = make_rowmap(2, rows, 1);
+    int tpw, gy;
+    apply64_geometry(rm, false, tpw, gy);
+    hipLaunchKernelGGL(applywg64_kernel<1>, dim3(1, gy), dim3(256), 0, (hipStream_t)stream, dY, nullptr, X, Wp, 0L, dOut, out, dX, dWp, dbp, rm, tpw);
     GPTST_CHECK_LAUNCH();
     return GPTST_OK;
 }

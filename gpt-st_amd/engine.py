@@ -241,15 +241,14 @@ def cap_core_bwd(p, g, pfx, saved, dout, dims, HS, HT, red):
     dc1, dv = ops.cap_rec_bwd(drec, c, v, reduce_nodes=CTX.NODE_REDUCE)
     dS, ddyn = ops.cap_cross_bwd(dv, s, Rt, Ht, dyn, p[pfx + "mask_template"], B, T, HS, HT)
     dY, dlogit = ops.cap_route_bwd(x.view(B, T, N, C), p[pfx + "ln_p.weight"], p[pfx + "ln_p.bias"], c, dc1, dS)
-    dx = ops.apply(dY, p[pfx + "ln_p.weight"], MODE_SHARED, BT, N, resid=dout, resid2=out, epi=EPI_ADD_DPRE)
     gw, gb = g[pfx + "ln_p.weight"], g[pfx + "ln_p.bias"]
-    if C == 64 and gb.data_ptr() == gw.data_ptr() + 4 * C * C:
-        # weight and bias gradients of ln_p in one reduction: wgrad appends colsum(dY) to every split, and the two gradient
-        # tensors are adjacent in the flat buffer ([ln_p.weight | ln_p.bias])
-        dWp, ns2 = ops.wgrad(dY, x, MODE_SHARED, BT, N, colsum_a=True)
-        gwb = torch.as_strided(gw, (1, C * C + C), (C * C + C, 1))
-        red.jobs.bwd_pool(_ones(dev), dWp, gwb, nsplit=ns2)
+    if C == 64:
+        # dx = dY Wp + dout*lrelu'(out), the ln_p weight gradient and its bias gradient in one pass over dY
+        dx, dWp, dbp, ns2 = ops.linear_bwd(dY, x, p[pfx + "ln_p.weight"], dout, out)
+        red.jobs.bwd_pool(_ones(dev, ns2), dWp, gw.view(1, C * C))
+        red.jobs.bwd_pool(_ones(dev, ns2), dbp, gb.view(1, C))
     else:
+        dx = ops.apply(dY, p[pfx + "ln_p.weight"], MODE_SHARED, BT, N, resid=dout, resid2=out, epi=EPI_ADD_DPRE)
         dWp, ns2 = ops.wgrad(dY, x, MODE_SHARED, BT, N)
         red.jobs.bwd_pool(_ones(dev), dWp.view(ns2, C * C), gw.view(1, C * C), nsplit=ns2)
         ops.rowouter(None, 0, 0, dY, None, 0, csum=gb)

@@ -213,6 +213,18 @@ def apply_wgrad(dOut, Y, S, W, mode, BT, N):
     return dS, dW, db, ns
 
 
+def linear_bwd(dY, X, Wp, dOut, out):
+    """Fused backward of cap's entry Linear + the layer's residual branch (C = 64): -> (dX, dWp (ns, C*C), dbp (ns, C), ns)."""
+    _chk(dY, X, Wp, dOut, out)
+    rows, C = dY.shape
+    ns = _C.lib().value("gptst_linear_bwd_nsplit", rows)
+    dX = torch.empty_like(dY)
+    dWp = torch.empty(ns, C * C, device=dY.device, dtype=torch.float32)
+    dbp = torch.empty(ns, C, device=dY.device, dtype=torch.float32)
+    _call("gptst_linear_bwd", _p(dY), _p(X), _p(Wp), _p(dOut), _p(out), _p(dX), _p(dWp), _p(dbp), rows, C, nbytes=_nb(dY, X, dOut, out, dX, dWp))
+    return dX, dWp, dbp, ns
+
+
 def wgrad_nsplit(mode, BT, N):
     return _C.lib().value("gptst_wgrad_nsplit", mode, BT, N)
 

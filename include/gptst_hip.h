@@ -97,6 +97,13 @@ int gptst_apply_wgrad_nsplit(int mode, int BT, int N);
 int gptst_apply_wgrad(const float* dOut, const float* Y, const float* S, const float* W, float* dS, float* dW, float* colsum, int mode,
                       int BT, int N, int C, void* stream);
 
+/* Backward through the shared Linear at the entry of cap (P = squash(X Wp^T + bp), GPTST.py:102) plus the residual branch of the layer
+ * (:139-141) in ONE pass: dX = dY Wp + dOut*lrelu'(out); per row split s < gptst_linear_bwd_nsplit(rows): dWp[s] = dY^T X ([out][in]),
+ * dbp[s] = colsum(dY).  Replaces gptst_apply(mode 2, epi 2) + gptst_wgrad_colsum(mode 2).  C = 64. */
+int gptst_linear_bwd_nsplit(int rows);
+int gptst_linear_bwd(const float* dY, const float* X, const float* Wp, const float* dOut, const float* out, float* dX, float* dWp, float* dbp,
+                     int rows, int C, void* stream);
+
 /* ---- per-node temporal hypergraph of hyperTem (tmix.hip), GPTST.py:156-158 -----------------------------
  * A (N,Hm,T) = node_emb . adj (via poolgen);  G[n] = A[n]^T A[n] (T x T);  ret[b,:,n,:] = G[n] X[b,:,n,:]. */
 int gptst_gram_fwd(const float* A, float* G, int N, int Hm, void* stream);

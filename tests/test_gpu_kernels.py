@@ -620,3 +620,18 @@ def test_apply_wgrad_fused_layer_backward(mode, BT, N):
     close(dS.view(BT, N, C), dS_r, what="apply_wgrad dS")
     close(dW.view(ns, G, C, C).sum(0), dW_r, what="apply_wgrad dW")
     close(db.view(ns, G, C).sum(0), db_r, what="apply_wgrad db")
+
+
+@pytest.mark.parametrize("rows", [65280, 1000, 37])
+def test_linear_bwd_fused(rows):
+    """gptst_linear_bwd == dX = dY Wp + dOut*lrelu'(out), dWp = dY^T X, dbp = colsum(dY) (cap's entry Linear + residual branch)."""
+    from gptst_amd import ops
+    dev = _dev()
+    g = torch.Generator().manual_seed(51)
+    C = 64
+    dY, X, dO, out = rnd(rows, C, g=g), rnd(rows, C, g=g), rnd(rows, C, g=g), rnd(rows, C, g=g)
+    Wp = rnd(C, C, g=g, scale=0.2)
+    dX, dWp, dbp, ns = ops.linear_bwd(dY.to(dev), X.to(dev), Wp.to(dev), dO.to(dev), out.to(dev))
+    close(dX, dY @ Wp + dO * torch.where(out > 0, torch.ones_like(out), torch.full_like(out, 0.01)), what="linear_bwd dX")
+    close(dWp.view(ns, C, C).sum(0), dY.t() @ X, what="linear_bwd dWp")
+    close(dbp.sum(0), dY.sum(0), what="linear_bwd dbp")

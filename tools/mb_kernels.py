@@ -52,6 +52,7 @@ CASES = {
     "apply_node_dpre": lambda: ops.apply(dO2, Wn, MODE_NODE, BT, N, A2=out2, transw=True, pro=PRO_DPRE, colsum=True),
     "apply_wgrad_node": lambda: ops.apply_wgrad(dO2, out2, rec, Wn, MODE_NODE, BT, N),
     "apply_wgrad_time": lambda: ops.apply_wgrad(dO2, out2, X2, Wbt, MODE_TIME, BT, N),
+    "linear_bwd_shared": lambda: ops.linear_bwd(dO2, X2, Wp, dO2, out2),
     "apply_shared_dx": lambda: ops.apply(dO2, Wp, MODE_SHARED, BT, N, resid=dO2, resid2=out2, epi=EPI_ADD_DPRE),
     "cap_route_fwd": lambda: ops.cap_route_fwd(X, Wp, bp, dadj, HS, R),
     "cap_cross_fwd": lambda: ops.cap_cross_fwd(s, dyn, tmpl, B, T, HS, HT),
