@@ -49,7 +49,7 @@ def build(force=False, verbose=False):
     with ThreadPoolExecutor(max_workers=max(1, min(8, len(jobs) or 1))) as ex:
         list(ex.map(run, jobs))
     if jobs or not os.path.exists(LIB):
-        run([cc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB] + objs)
+        run([cc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB] + objs + ["-ldl"])
     return LIB
 
 

@@ -1,0 +1,71 @@
+// Communication entry points of the C ABI: a thin wrapper over RCCL (the ROCm collective library, xGMI on an MI355X
+// node) with an explicit stream, so that a collective can sit INSIDE a captured hipGraph next to the kernels — torch.distributed's
+// all_reduce cannot be called from a C-ABI consumer.  The reference has no distributed code (GPTST.py hard-codes 'cuda:0'); these are
+// what the data-parallel gradient exchange (one all-reduce of [flat gradient | statistics], dist.py) and the node-sharded cluster
+// aggregations (shard.py: R+2 all-reduces of (B,T,HS,C) per cap forward, one per backward) map to.
+// RCCL is bound at run time (dlopen of the copy the process already holds — torch ships one — or librccl.so.1): the library has no
+// link-time dependency on it, and a box without RCCL only loses these four entry points (GPTST_ECOMM).
+#include "common.h"
+#include <dlfcn.h>
+
+#define GPTST_ECOMM (-4)
+
+namespace {
+struct Uid { char internal[128]; };                        // == ncclUniqueId (rccl.h: NCCL_UNIQUE_ID_BYTES 128)
+typedef int (*GetUniqueId_t)(Uid*);
+typedef int (*CommInitRank_t)(void**, int, Uid, int);
+typedef int (*AllReduce_t)(const void*, void*, size_t, int, int, void*, hipStream_t);
+typedef int (*CommDestroy_t)(void*);
+struct Api { void* lib; GetUniqueId_t uid; CommInitRank_t init; AllReduce_t allreduce; CommDestroy_t destroy; };
+Api g_api = {nullptr, nullptr, nullptr, nullptr, nullptr};
+void* g_comm = nullptr;
+int g_world = 0;
+
+bool bind() {
+    if (g_api.lib) return true;
+    const char* names[] = {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"};
+    void* h = nullptr;
+    for (const char* n : names) { h = dlopen(n, RTLD_NOW | RTLD_NOLOAD); if (h) break; }      // the copy already in the process
+    if (!h) for (const char* n : names) { h = dlopen(n, RTLD_NOW | RTLD_GLOBAL); if (h) break; }
+    if (!h) return false;
+    Api a{h, (GetUniqueId_t)dlsym(h, "ncclGetUniqueId"), (CommInitRank_t)dlsym(h, "ncclCommInitRank"),
+          (AllReduce_t)dlsym(h, "ncclAllReduce"), (CommDestroy_t)dlsym(h, "ncclCommDestroy")};
+    if (!a.uid || !a.init || !a.allreduce || !a.destroy) return false;
+    g_api = a;
+    return true;
+}
+}  // namespace
+
+// out: 128 bytes (ncclUniqueId) created on ONE rank and handed to every rank of the job by the caller (file, socket, torch.distributed)
+extern "C" int gptst_comm_unique_id(void* out) {
+    if (!out) return GPTST_EARG;
+    if (!bind()) return GPTST_ECOMM;
+    const int rc = g_api.uid((Uid*)out);
+    return rc == 0 ? GPTST_OK : 1000 + rc;
+}
+
+// one communicator per process (= per GPU: hipSetDevice first); unique_id: the 128 bytes of gptst_comm_unique_id
+extern "C" int gptst_comm_init(int rank, int world, const void* unique_id) {
+    if (!unique_id || world <= 0 || rank < 0 || rank >= world || g_comm) return GPTST_EARG;
+    if (!bind()) return GPTST_ECOMM;
+    Uid u = *(const Uid*)unique_id;
+    const int rc = g_api.init(&g_comm, world, u, rank);
+    if (rc != 0) { g_comm = nullptr; return 1000 + rc; }
+    g_world = world;
+    return GPTST_OK;
+}
+
+// in-place sum over the ranks of buf[0..n) (fp32), enqueued on `stream` (capturable); dtype 7 = ncclFloat32, op 0 = ncclSum
+extern "C" int gptst_allreduce_f32(float* buf, long n, void* stream) {
+    if (!buf || n <= 0) return GPTST_EARG;
+    if (!g_comm) return GPTST_ECOMM;
+    const int rc = g_api.allreduce(buf, buf, (size_t)n, 7, 0, g_comm, (hipStream_t)stream);
+    return rc == 0 ? GPTST_OK : 1000 + rc;
+}
+
+extern "C" int gptst_comm_destroy(void) {
+    if (!g_comm) return GPTST_OK;
+    const int rc = g_api.destroy(g_comm);
+    g_comm = nullptr; g_world = 0;
+    return rc == 0 ? GPTST_OK : 1000 + rc;
+}

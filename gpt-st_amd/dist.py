@@ -75,3 +75,35 @@ def combine_local_gradients(local_bufs, nA, nB):
     g, stats = total[:n].clone(), total[n:]
     g[:nA] /= max(float(stats[1]), 1.0)
     return g, stats
+
+
+class NativeComm:
+    """The C-ABI communicator (csrc/comm.hip: RCCL with an explicit stream).  The 128-byte unique id is created on rank 0 and handed to
+    the other ranks through an existing torch.distributed group (any backend) — the only use of torch.distributed here; the collectives
+    themselves are plain enqueues on a HIP stream, so they can be captured inside a hipGraph together with the kernels around them."""
+
+    def __init__(self, rank=None, world=None):
+        import ctypes
+        from . import _C
+        self.lib = _C.lib()
+        self.rank = int(os.environ.get("RANK", "0")) if rank is None else rank
+        self.world = int(os.environ.get("WORLD_SIZE", "1")) if world is None else world
+        uid = (ctypes.c_char * 128)()
+        if self.rank == 0:
+            self.lib.call("gptst_comm_unique_id", uid)
+        if self.world > 1:
+            t = torch.tensor(list(bytes(uid)), dtype=torch.uint8)
+            if dist.get_backend() == "nccl":
+                t = t.cuda()
+            dist.broadcast(t, src=0)
+            uid = (ctypes.c_char * 128).from_buffer_copy(bytes(t.cpu().tolist()))
+        self.lib.call("gptst_comm_init", self.rank, self.world, uid)
+
+    def allreduce_(self, buf):
+        """in-place sum over the ranks, enqueued on torch's current stream"""
+        assert buf.is_cuda and buf.dtype == torch.float32 and buf.is_contiguous()
+        self.lib.call("gptst_allreduce_f32", buf.data_ptr(), buf.numel(), torch.cuda.current_stream().cuda_stream)
+        return buf
+
+    def close(self):
+        self.lib.call("gptst_comm_destroy")

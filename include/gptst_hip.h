@@ -256,6 +256,16 @@ int gptst_clip_adam_ws_floats(void);   /* scratch floats (ws) of gptst_clip_adam
 int gptst_clip_adam(float* p, const float* g, float* m, float* v, long nA, long nB, const float* hyper, float* stats, float* ws,
                     void* stream);
 
+/* ---- communication (comm.hip): RCCL over xGMI with an explicit stream — a collective can sit inside a captured hipGraph -------------
+ * The reference has no distributed code; these carry the data-parallel gradient exchange (one all-reduce of [flat gradient | statistics])
+ * and the node-sharded cluster aggregations.  RCCL is bound at run time (dlopen): -4 (GPTST_ECOMM) when it is not available or no
+ * communicator exists, 1000 + ncclResult_t on an RCCL error.  One communicator per process (= per GPU).
+ * unique_id: 128 bytes (ncclUniqueId) created on one rank and distributed by the caller. */
+int gptst_comm_unique_id(void* out128);
+int gptst_comm_init(int rank, int world, const void* unique_id);
+int gptst_allreduce_f32(float* buf, long n, void* stream);      /* in-place sum over the ranks */
+int gptst_comm_destroy(void);
+
 #ifdef __cplusplus
 }
 #endif

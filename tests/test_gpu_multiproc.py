@@ -68,3 +68,32 @@ def test_bench_rccl_backend():
                          dict(GPTST_FORCE_DP="1", GPTST_DIST_BACKEND="nccl"))
         assert out["n_gpus"] == 1
     assert out["value"] > 0 and out["last_loss"] == out["last_loss"] and out["last_loss"] > 0
+
+
+def test_native_comm_allreduce_inside_a_graph():
+    """C-ABI communication entry points (gptst_comm_* / gptst_allreduce_f32: RCCL bound at run time) with one rank: the all-reduce is an
+    ordinary stream enqueue — eager and captured in a hipGraph together with a kernel — and leaves a 1-rank sum unchanged."""
+    import torch
+    from gptst_amd.dist import NativeComm
+    comm = NativeComm(rank=0, world=1)
+    try:
+        x = torch.arange(1 << 20, device="cuda:0", dtype=torch.float32)
+        ref = x.clone()
+        comm.allreduce_(x)
+        torch.cuda.synchronize()
+        assert torch.equal(x, ref)
+        s = torch.cuda.Stream()
+        s.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(s):
+            comm.allreduce_(x)                                     # warm-up outside capture
+        torch.cuda.current_stream().wait_stream(s)
+        torch.cuda.synchronize()
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g, capture_error_mode="thread_local"):
+            x.mul_(2.0)
+            comm.allreduce_(x)
+        g.replay(); g.replay()
+        torch.cuda.synchronize()
+        assert torch.equal(x, ref * 4)                               # two replays (capture records, it does not execute)
+    finally:
+        comm.close()
