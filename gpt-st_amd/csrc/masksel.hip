@@ -359,16 +359,28 @@ __global__ __launch_bounds__(256) void ms_zero_kernel(unsigned* __restrict__ p, 
     for (int i = blockIdx.x * 256 + threadIdx.x; i < n; i += gridDim.x * 256) p[i] = 0u;
 }
 
+// one selection on a ZEROED histogram block (3 digit passes + the mask write)
 static int ms_select(const MsPlan& p, unsigned* hist, float* out, float* final_mask, int base, hipStream_t st) {
-    hipLaunchKernelGGL(ms_zero_kernel, dim3(6), dim3(256), 0, st, hist, 3 * MS_BINS);
     for (int d = 0; d < 3; ++d) hipLaunchKernelGGL(ms_hist_kernel, dim3(MS_BLOCKS), dim3(MS_THREADS), 0, st, p, hist, d);
     hipLaunchKernelGGL(ms_apply_kernel, dim3(MS_BLOCKS), dim3(MS_THREADS), 0, st, p, (const unsigned*)hist, out, final_mask, base);
     GPTST_CHECK_LAUNCH();
     return GPTST_OK;
 }
 
-// ws: device scratch of gptst_mask_ws_bytes() bytes
-extern "C" int gptst_mask_ws_bytes(void) { return (int)(sizeof(unsigned) * 3 * MS_BINS); }
+// counts[h] += number of cells with label h (LDS histogram per workgroup, one global atomic per class and workgroup); counts zeroed before
+__global__ __launch_bounds__(256) void ms_count_kernel(const int* __restrict__ label, int M, int HS, int* __restrict__ counts) {
+    __shared__ int hist[256];
+    for (int h = threadIdx.x; h < HS; h += 256) hist[h] = 0;
+    __syncthreads();
+    for (int i = blockIdx.x * 256 + threadIdx.x; i < M; i += gridDim.x * 256) atomicAdd(&hist[label[i]], 1);
+    __syncthreads();
+    for (int h = threadIdx.x; h < HS; h += 256) if (hist[h]) atomicAdd(counts + h, hist[h]);
+}
+
+// ws: device scratch of gptst_mask_ws_bytes() bytes: [histogram block of selection A / the random selection | block of selection R |
+// class counts (256)] — ONE zeroing launch per mask generation covers all of it
+#define MS_WS_WORDS (2 * 3 * MS_BINS + 256)
+extern "C" int gptst_mask_ws_bytes(void) { return (int)(sizeof(unsigned) * MS_WS_WORDS); }
 
 int g_ms_force_multi = 0;       // tests: 1 = take the multi-launch path for every size
 
@@ -382,6 +394,7 @@ extern "C" int gptst_mask_random(const float* noise, int M, int k, float* mask, 
         GPTST_CHECK_LAUNCH();
         return GPTST_OK;
     }
+    hipLaunchKernelGGL(ms_zero_kernel, dim3(6), dim3(256), 0, (hipStream_t)stream, (unsigned*)ws, 3 * MS_BINS);
     return ms_select(p, (unsigned*)ws, mask, nullptr, 1, (hipStream_t)stream);
 }
 
@@ -404,9 +417,16 @@ extern "C" int gptst_mask_adaptive(const int* label, const int* counts, const in
         GPTST_CHECK_LAUNCH();
         return GPTST_OK;
     }
-    if (!counts) return GPTST_EARG;
-    int rc = ms_select(a, (unsigned*)ws, m_ada, nullptr, base, (hipStream_t)stream);                       // :386-397
+    unsigned* w = (unsigned*)ws;
+    hipLaunchKernelGGL(ms_zero_kernel, dim3(12), dim3(256), 0, (hipStream_t)stream, w, MS_WS_WORDS);       // both histogram blocks + counts
+    if (!counts) {                                         // class histogram from the labels (what gptst_mask_labels would have produced)
+        int nb = (M + 255) / 256; if (nb > 64) nb = 64;
+        int* cw = (int*)(w + 2 * 3 * MS_BINS);
+        hipLaunchKernelGGL(ms_count_kernel, dim3(nb), dim3(256), 0, (hipStream_t)stream, label, M, HS, cw);
+        a.counts = cw;
+    }
+    int rc = ms_select(a, w, m_ada, nullptr, base, (hipStream_t)stream);                                   // :386-397
     if (rc) return rc;
-    MsPlan r{label, counts, list_c, nums, noise_r, m_ada, 2, ada_all, HS, M, 0};
-    return ms_select(r, (unsigned*)ws, m_rnd, mask, base, (hipStream_t)stream);                            // :399-413
+    MsPlan r{label, a.counts, list_c, nums, noise_r, m_ada, 2, ada_all, HS, M, 0};
+    return ms_select(r, w + 3 * MS_BINS, m_rnd, mask, base, (hipStream_t)stream);                          // :399-413
 }

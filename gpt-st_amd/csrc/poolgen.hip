@@ -25,7 +25,7 @@ template <> __device__ __forceinline__ void stv<1>(float* p, float4 v) { *p = v.
 // ~50 generated-parameter problems in the forward and ~90 gradient reductions in the backward, every one of them a few microseconds
 // of work: as one launch per embedding they were ~60 launches of 4-20 us each at the head and the tail of the step (25 % of it,
 // profiles/r02b timeline); as job tables they are a handful.  The table travels in the kernel arguments (<= 4 KB).
-#define PJ_MAX 48
+#define PJ_MAX 56      // 56 x 64 B of kernel arguments (limit 4 KB); a pretraining step queues 98 reductions -> 2 launches
 enum { PJ_FWD = 0, PJ_BWD_POOL = 1, PJ_BWD_EMB = 2 };
 struct PJob {
     const float* emb;      // FWD / BWD_POOL: (R, K)

@@ -126,7 +126,7 @@ def poolgen_bwd_emb_multi(dWs, pools, demb, nsplits=None):
 
 class PoolJobs:
     """A list of independent poolgen problems (forward generation and/or gradient reductions, each with its own embedding) that
-    run as ONE launch per 48 jobs (gptst_pool_jobs).  Tensors are kept referenced until launch()."""
+    run as ONE launch per 56 jobs (gptst_pool_jobs).  Tensors are kept referenced until launch()."""
     FWD, BWD_POOL, BWD_EMB = 0, 1, 2
 
     def __init__(self):
@@ -464,11 +464,9 @@ MASK_SMALL = 1 << 13      # cells up to which the whole mask generation is one s
 
 
 def labels_and_counts(prob, label):
-    """(label, counts) for mask_adaptive: the guide's rowdot already produced the argmax labels; the single-launch mask kernel
-    histograms them itself (counts = None), the multi-launch path needs the class histogram up front."""
-    if label.numel() <= MASK_SMALL:
-        return label, None
-    return mask_labels(prob)
+    """(label, counts) for mask_adaptive: the guide's rowdot already produced the argmax labels and gptst_mask_adaptive histograms
+    them itself (counts = None)."""
+    return label, None
 
 
 def mask_labels(prob):

@@ -45,7 +45,7 @@ int gptst_poolgen_bwd_pool(const float* emb, const float* dW, float* dpool, int 
 int gptst_poolgen_bwd_emb(const float* dW, const float* pool, int cols, const float* dW2, const float* pool2, int cols2,
                           float* demb, int R, int nsplit, int K, void* stream);
 
-/* multi-problem forms (<= 48 problems sharing emb; host arrays of device pointers, read at call time): one launch generates /
+/* multi-problem forms (<= 56 problems sharing emb; host arrays of device pointers, read at call time): one launch generates /
  * reduces the generated parameters of several layers (every launch has a ~4-5 us floor on MI355X). */
 int gptst_poolgen_fwd_multi(const float* emb, int nprob, const void* pools, const void* outs, const int* cols, int R, int K,
                             void* stream);
@@ -54,7 +54,7 @@ int gptst_poolgen_bwd_pool_multi(const float* emb, int nprob, const void* dWs, c
 int gptst_poolgen_bwd_emb_multi(int nprob, const void* dWs, const void* pools, const int* cols, const int* nsplit, float* demb, int R,
                                 int K, void* stream);
 
-/* Job table: njobs independent problems of ANY kind, each with its own embedding and shapes, in ceil(njobs / 48) launches
+/* Job table: njobs independent problems of ANY kind, each with its own embedding and shapes, in ceil(njobs / 56) launches
  * (host arrays, read at call time).  kind 0: out (R,cols) = emb (R,K) . pool (K,cols);  kind 1: out = dpool (K,cols) += sum_rr
  * emb[rr % R,:]^T x[rr,:], rr < R*nsplit — owned by ONE workgroup per element (no atomics: two kind-1 jobs of one call must
  * not share `out`);  kind 2: out = demb (R,K) += (sum_s x[s*R + r,:]) . pool^T (atomic: several jobs may add into one demb).
@@ -188,7 +188,8 @@ int gptst_mask_labels(const float* prob, int rows, int HS, int* label, int* coun
 /* adaptive phase: device-side class selection (:356-384) + two selections (:386-407) + product (:410-413).
  * list_c: shuffled class order (int32[HS]); nums: {adaptive_mask_num, random_mask_num} int32[2] on the device;
  * m_ada / m_rnd (M) are the partial masks, mask (M*base) the final one.
- * counts may be NULL for M <= 2^13 (the class histogram is then taken from the labels inside the launch). */
+ * counts may be NULL: the class histogram is then taken from the labels here (inside the single launch for M <= 2^13, by one more
+ * small launch beyond). */
 int gptst_mask_adaptive(const int* label, const int* counts, const int* list_c, const int* nums, const float* noise_a,
                         const float* noise_r, int ada_all, int M, int HS, int base, float* m_ada, float* m_rnd, float* mask,
                         void* ws, void* stream);

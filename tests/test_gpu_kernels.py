@@ -299,8 +299,7 @@ def test_mask_adaptive_bit_exact(ada_all, B, N, HS, frac):
     list_c = synth.class_order(HS, 5)
     na, nr = synth.make_noise(M, 11), synth.make_noise(M, 12)
     m_ada_r, m_rnd_r, fin_r = O.adaptive_mask(label_ref.view(B, T, N), list_c, na, nr, ada, rnd_n, "all" if ada_all else "half")
-    small = M <= ops.MASK_SMALL           # single-workgroup launch; there `counts` may be None (histogram inside the launch)
-    for base, multi, cnt in ((1, 0, counts), (2, 0, None if small else counts), (1, 1, counts), (2, 1, counts)):
+    for base, multi, cnt in ((1, 0, counts), (2, 0, None), (1, 1, counts), (2, 1, None)):      # cnt None: class histogram taken inside
       with _mask_path(multi):
         m_ada, m_rnd, mask = ops.mask_adaptive(label, cnt, torch.tensor(list_c, dtype=torch.int32, device=dev),
                                                torch.tensor([ada, rnd_n], dtype=torch.int32, device=dev), na.to(dev), nr.to(dev),
