@@ -202,6 +202,26 @@ extern "C" int gptst_rowdot(const float* X, const float* W, const float* b, floa
     return GPTST_OK;
 }
 
+// first stage only: part (gptst_rowouter_nparts(rows), J*C + C + J) row-chunk partials [sum a'^T X | column sums of X | sums of a'];
+// the caller folds them (e.g. one kind-1 pool job per target, next to the other reductions of the step)
+extern "C" int gptst_rowouter_nparts(int rows) {
+    int rpb = (rows + RO_NB - 1) / RO_NB; if (rpb < 16) rpb = 16;
+    return (rows + rpb - 1) / rpb;
+}
+
+extern "C" int gptst_rowouter_part(const float* a, int lda, const float* mask, float fill, const float* X, float* part, int want_asum,
+                                   int rows, int J, int C, void* stream) {
+    if (!X || !part || J < 0 || J > SM_MAXJ || (J > 0 && !a)) return GPTST_EARG;
+    int rpb = (rows + RO_NB - 1) / RO_NB; if (rpb < 16) rpb = 16;
+    const int nb = (rows + rpb - 1) / rpb;
+    hipStream_t st = (hipStream_t)stream;
+    if (C == 64) hipLaunchKernelGGL((rowouter_part_kernel<64>), dim3(nb), dim3(256), 0, st, a, lda, mask, fill, X, part, rows, J, rpb, want_asum);
+    else if (C == 128) hipLaunchKernelGGL((rowouter_part_kernel<128>), dim3(nb), dim3(256), 0, st, a, lda, mask, fill, X, part, rows, J, rpb, want_asum);
+    else return GPTST_ESHAPE;
+    GPTST_CHECK_LAUNCH();
+    return GPTST_OK;
+}
+
 // ws: device scratch of gptst_rowouter_ws_floats(J, C) floats
 extern "C" int gptst_rowouter(const float* a, int lda, const float* mask, float fill, const float* X, float* out, int olayout,
                               float* csum, float* asum, float* ws, int rows, int J, int C, void* stream) {

@@ -494,9 +494,23 @@ def guide_bwd(p, g, source, tidx, saved, dlogit, dims, base, red, dh2=None):
                       g[m + "bias_pool_tem"], d_t4m, MODE_TIME, dims, red)
     dh0 = condlin_bwd(s1, dh1, p["encoder.neb4mask"], p[m + "weights_pool_spa"], p[m + "bias_pool_spa"],
                       g[m + "weights_pool_spa"], g[m + "bias_pool_spa"], g["encoder.neb4mask"], MODE_NODE, dims, red)
-    ops.rowouter(source, base + 2, base, dh0, g[m + "ln1.weight"], 0, csum=g[m + "ln1.bias"])
+    _in_proj_grads(source, base, dh0, g[m + "ln1.weight"], g[m + "ln1.bias"], None, 0.0, red)
     red.timefeat(p, g, GUIDE_TF, tidx, d_t4m)
     red.keep.append((saved, dlogit, dh2, dh1, dh0))
+
+
+def _in_proj_grads(source, base, dY, gW, gb, mask, fill, red):
+    """Weight / bias gradient of an input projection Linear(base -> C) on the (masked) raw flow (GPTST.py:22, :416-418): gW (C, base) +=
+    dY^T a', gb += colsum(dY).  base = 1: the row-chunk partials [gW | gb] fold as ONE job of the step's reduction launch; else the
+    two-launch rowouter."""
+    wb = _wb_view(gW, gb)
+    if base == 1 and wb is not None:
+        C = dY.shape[1]
+        part = ops.rowouter_part(source, base + 2, base, dY, mask=mask, fill=fill)
+        red.jobs.bwd_pool(_ones(dY.device, part.shape[0]), part[:, :2 * C], wb)
+        red.keep.append(part)
+    else:
+        ops.rowouter(source, base + 2, base, dY, gW, 0, csum=gb, mask=mask, fill=fill)
 
 
 def model_fwd(p, source, mask, dims, base, num_route, scaler_zeros, gen=None, tidx=None):
@@ -533,5 +547,4 @@ def model_bwd(p, g, source, mask, tidx, sv_e, sv_d, dec, d_out, d_dec, dims, bas
     red.flush_async(tidx)                                   # the decoder's reductions overlap with the encoder's backward chain
     d_x0 = sthcn_bwd(p, g, ENC, tidx, sv_e, d_emb, dims, red)
     red.flush_async(tidx)                                   # ... and the encoder's with the guide's
-    ops.rowouter(source, base + 2, base, d_x0, g["encoder.dim_in_flow.weight"], 0, csum=g["encoder.dim_in_flow.bias"],
-                 mask=mask, fill=scaler_zeros)
+    _in_proj_grads(source, base, d_x0, g["encoder.dim_in_flow.weight"], g["encoder.dim_in_flow.bias"], mask, scaler_zeros, red)

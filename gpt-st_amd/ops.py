@@ -515,6 +515,15 @@ def rowouter(a, lda, J, X, out, olayout, csum=None, asum=None, mask=None, fill=0
           nbytes=_nb(a, mask, X, out))
 
 
+def rowouter_part(a, lda, J, X, mask=None, fill=0.0, want_asum=False):
+    """First stage of rowouter -> part (nparts, J*C + C + J): [sum a'^T X (j,c) | column sums of X | sums of a'] per row chunk."""
+    rows, C = X.shape
+    nparts = _C.lib().value("gptst_rowouter_nparts", rows)
+    part = torch.empty(nparts, J * C + C + J, device=X.device, dtype=torch.float32)
+    _call("gptst_rowouter_part", _p(a), lda, _p(mask), float(fill), _p(X), _p(part), int(want_asum), rows, J, C, nbytes=_nb(X))
+    return part
+
+
 # ---- time features ----------------------------------------------------------------------------------------------
 def timefeat_fwd(params, tidx, rows, K):
     """params: the 10 nn.Linear tensors in module order; tidx (B,T,2) contiguous."""

@@ -207,6 +207,11 @@ int gptst_lin_in(const float* a, int lda, const float* mask, float fill, const f
 int gptst_rowdot(const float* X, const float* W, const float* b, float* Z, int rows, int J, int C, int do_softmax, int* label,
                  void* stream);
 int gptst_rowouter_ws_floats(int J, int C);   /* scratch (ws) size of gptst_rowouter */
+/* first stage of gptst_rowouter alone: part (gptst_rowouter_nparts(rows), J*C + C + J) = row-chunk partials [sum a'^T X (j,c) | column
+ * sums of X | sums of a'] for the caller to fold (one kind-1 pool job next to the other reductions of a step). */
+int gptst_rowouter_nparts(int rows);
+int gptst_rowouter_part(const float* a, int lda, const float* mask, float fill, const float* X, float* part, int want_asum, int rows,
+                        int J, int C, void* stream);
 int gptst_rowouter(const float* a, int lda, const float* mask, float fill, const float* X, float* out, int olayout, float* csum,
                    float* asum, float* ws, int rows, int J, int C, void* stream);
 
