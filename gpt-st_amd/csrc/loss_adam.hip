@@ -121,7 +121,7 @@ __global__ __launch_bounds__(256) void gradnorm_kernel(const float* __restrict__
 // parts there; otherwise 0); on exit (written by workgroup 0): the total squared gradient norm.
 __global__ __launch_bounds__(256) void adam_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m,
                                                    float* __restrict__ v, long nA, long nB, const float* __restrict__ hyper,
-                                                   float* __restrict__ stats, const float* __restrict__ ws, int nws) {
+                                                   float* __restrict__ stats, const float* __restrict__ ws, int nws, float* __restrict__ stats_out) {
     __shared__ float red[4];
     {   // every workgroup folds the gradient-norm partials in the same fixed order
         float s = (int)threadIdx.x < nws ? ws[threadIdx.x] : 0.f;
@@ -150,6 +150,7 @@ __global__ __launch_bounds__(256) void adam_kernel(float* __restrict__ p, const 
     // (stats[3] is rewritten only after every workgroup has read it: the caller's next kernel boundary orders that — here the
     // total goes to stats[4], which nobody reads inside this launch)
     if (blockIdx.x == 0 && threadIdx.x == 0) stats[4] = gsq;
+    if (stats_out != nullptr && blockIdx.x == 0 && threadIdx.x < 8) stats_out[threadIdx.x] = threadIdx.x == 4 ? gsq : stats[threadIdx.x];
 }
 
 extern "C" int gptst_mae_fwd(const float* out, const float* src, int lda, const float* mask, float sigma, float mu, float thresh,
@@ -184,13 +185,13 @@ extern "C" int gptst_clip_adam_ws_floats(void) { return GN_NB; }
 // ws: gptst_clip_adam_ws_floats() floats of scratch.  stats[3]: extra squared-norm terms (0 unless node-sharded), stats[4] <- the
 // total squared gradient norm (after scaling, before clipping).  No atomics: the norm is folded in a fixed order.
 extern "C" int gptst_clip_adam(float* p, const float* g, float* m, float* v, long nA, long nB, const float* hyper, float* stats,
-                               float* ws, void* stream) {
+                               float* ws, float* stats_out, void* stream) {
     if (!p || !g || !m || !v || !hyper || !stats || !ws) return GPTST_EARG;
     long n = nA + nB;
     int nb = (int)((n + 255) / 256); if (nb > 1024) nb = 1024;
     const int nbn = nb > GN_NB ? GN_NB : nb;
     hipLaunchKernelGGL(gradnorm_kernel, dim3(nbn), dim3(256), 0, (hipStream_t)stream, g, nA, nB, hyper, (const float*)stats, ws);
-    hipLaunchKernelGGL(adam_kernel, dim3(nb), dim3(256), 0, (hipStream_t)stream, p, g, m, v, nA, nB, hyper, stats, (const float*)ws, nbn);
+    hipLaunchKernelGGL(adam_kernel, dim3(nb), dim3(256), 0, (hipStream_t)stream, p, g, m, v, nA, nB, hyper, stats, (const float*)ws, nbn, stats_out);
     GPTST_CHECK_LAUNCH();
     return GPTST_OK;
 }

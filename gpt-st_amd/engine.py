@@ -21,12 +21,18 @@ class ZeroArena:
     def __init__(self, device):
         self.device, self.buf, self.off, self.need = device, None, 0, 0
 
-    def begin(self):
+    def begin(self, zero=True):
+        """-> the buffer the caller has to zero itself when zero=False (None when there is none or it was just created zeroed)"""
+        pending = None
         if self.buf is None or self.buf.numel() < self.need:
             self.buf = torch.zeros(max(self.need, 1), device=self.device) if self.need else None
         elif self.buf is not None:
-            self.buf.zero_()
+            if zero:
+                self.buf.zero_()
+            else:
+                pending = self.buf
         self.off, self.need = 0, 0
+        return pending
 
     def zeros(self, *shape):
         n = 1

@@ -625,14 +625,22 @@ def stats_fold(sws, stats):
 _ADAM_WS = {}
 
 
-def clip_adam(p, g, m, v, nA, nB, hyper, stats, ws=None):
+def step_begin(z0, z1, src, base):
+    """Zero z0 (and z1, may be None) and gather the time index of node 0: -> tidx (B,T,2).  One launch."""
+    B, T, N, lda = src.shape
+    tidx = torch.empty(B, T, 2, device=src.device, dtype=torch.float32)
+    _call("gptst_step_begin", _p(z0), z0.numel(), _p(z1), z1.numel() if z1 is not None else 0, _p(src), _p(tidx), B * T, N, lda, base)
+    return tidx
+
+
+def clip_adam(p, g, m, v, nA, nB, hyper, stats, ws=None, stats_out=None):
     """clip_grad_norm_ + Adam over the flat buffers; stats[3] (in): extra squared-norm terms, stats[4] (out): total squared norm.
     ws: gptst_clip_adam_ws_floats() floats of scratch (default: one cached buffer per device — stream-ordered reuse)."""
     if ws is None:
         if p.device not in _ADAM_WS:
             _ADAM_WS[p.device] = torch.empty(_C.lib().value("gptst_clip_adam_ws_floats"), device=p.device, dtype=torch.float32)
         ws = _ADAM_WS[p.device]
-    _call("gptst_clip_adam", _p(p), _p(g), _p(m), _p(v), int(nA), int(nB), _p(hyper), _p(stats), _p(ws))
+    _call("gptst_clip_adam", _p(p), _p(g), _p(m), _p(v), int(nA), int(nB), _p(hyper), _p(stats), _p(ws), _p(stats_out))
 
 
 # ---- evaluation metrics (Trainer.test) ---------------------------------------------------------------------------------

@@ -42,13 +42,17 @@ class PretrainStep:
         self.noise = torch.zeros(M * self.base, device=self.dev)
         self.noise_ar = torch.zeros(2 * M, device=self.dev)          # adaptive phase: [noise_a | noise_r], drawn by ONE launch
         self.noise_a, self.noise_r = self.noise_ar[:M], self.noise_ar[M:]
-        self.ctrl = torch.zeros(self.HS + 2, dtype=torch.int32, device=self.dev)    # [list_c | adaptive_num, random_num]
-        self.hyper = torch.zeros(16, device=self.dev)
+        # per-step host scalars in ONE device buffer / ONE H2D copy: [hyper (16 fp32) | list_c (HS int32) | adaptive_num, random_num]
+        self.hc = torch.zeros(16 + self.HS + 2, dtype=torch.int32, device=self.dev)
+        self.hyper = self.hc[:16].view(torch.float32)
+        self.ctrl = self.hc[16:]
         # Per-step host scalars travel through a RING of pinned slots, each guarded by an event recorded behind its H2D copies:
         # step() never synchronises, so with a single pinned buffer the host could rewrite the Adam bias corrections / class
         # order of step k+j before the DMA of step k has read them (hundreds of steps are queued back to back by bench.py).
-        self._ring = [dict(hyper=torch.zeros(16).pin_memory(), ctrl=torch.zeros(self.HS + 2, dtype=torch.int32).pin_memory(), ev=None)
-                      for _ in range(self.RING)]
+        self._ring = []
+        for _ in range(self.RING):
+            hc = torch.zeros(16 + self.HS + 2, dtype=torch.int32).pin_memory()
+            self._ring.append(dict(hc=hc, hyper=hc[:16].view(torch.float32), ctrl=hc[16:], ev=None))
         self._ring_i = 0
         self.phase_kl = False                                        # phase of the last enqueued step (losses())
         self.stats_out = torch.zeros(8, device=self.dev)            # snapshot of stats after the step (graph output)
@@ -88,12 +92,11 @@ class PretrainStep:
         mdl, p, g, dims, base = self.model, self.model.param_views(), self.g, self.dims, self.base
         a = self.args
         M = self.B * self.T * self.N
-        self.gbuf.zero_()
         engine.CTX.ARENA = self.arena
         engine.CTX.SIDE = self.side
-        self.arena.begin()
         src = self.src
-        tidx = src[:, :, 0, base:base + 2].contiguous()
+        # zero_grad + the step's zero scratch + the time index of node 0: one launch
+        tidx = ops.step_begin(self.gbuf, self.arena.begin(zero=False), src, base)
         gen = engine.gen_all(p, tidx, dims)                       # time embeddings + every generated parameter: 3 launches
         red = engine.Reductions(side=self.red_side)
         prob, sv_g = engine.guide_fwd(p, src, tidx, dims, base, gen=gen["guide"])
@@ -190,8 +193,8 @@ class PretrainStep:
         self.dp.sum_counts_(self.counts_g)
 
     def _optim(self):
-        ops.clip_adam(self.model.flat, self.gflat, self.m, self.v, self.model.nA, self.model.nB, self.hyper, self.stats)
-        self.stats_out.copy_(self.stats)
+        ops.clip_adam(self.model.flat, self.gflat, self.m, self.v, self.model.nA, self.model.nB, self.hyper, self.stats,
+                      stats_out=self.stats_out)
 
     def _body(self, phase):
         ops.set_deterministic(self.deterministic)           # thread-local launch mode of the library (captured into the graph)
@@ -228,7 +231,6 @@ class PretrainStep:
         h[8] = 1.0 if phase == 1 else 0.0
         h[9] = 1.0          # the backward carries the gradient of the SUM loss: the optimiser divides path A by the (global) kept count
         h[10] = 1.0
-        self.hyper.copy_(h, non_blocking=True)
         if phase == 1:
             if list_c is None:
                 list_c = list(range(self.HS))
@@ -237,7 +239,7 @@ class PretrainStep:
             ada, rnd = self._budgets(ada, rnd, epoch)
             c = sl["ctrl"]
             c.copy_(torch.tensor([int(v) for v in list_c] + [int(ada), int(rnd)], dtype=torch.int32))
-            self.ctrl.copy_(c, non_blocking=True)
+        self.hc.copy_(sl["hc"], non_blocking=True)
         if sl["ev"] is None:
             sl["ev"] = torch.cuda.Event()
         sl["ev"].record()

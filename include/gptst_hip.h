@@ -247,6 +247,12 @@ int gptst_stats_fold(const float* sws, int rows, float* stats, void* stream);
 int gptst_timefeat_jobs(int njobs, int bwd, const void* const* params, const void* const* grads, const float* tidx,
                         const void* const* io, const int* rows, const int* K, const int* E, void* stream);
 
+/* start of a step in one launch (stepbegin.hip): zero z0[0..n0) (the [flat gradient | statistics] buffer: optimizer.zero_grad,
+ * BasicTrainer.py:79) and z1[0..n1) (the step's zero-initialised scratch; may be NULL), and gather tidx (BT,2) = src[:, 0, base:base+2]
+ * from src (BT, N, lda) (GPTST.py:256-257; tidx may be NULL). */
+int gptst_step_begin(float* z0, long n0, float* z1, long n1, const float* src, float* tidx, int BT, int N, int lda, int base,
+                     void* stream);
+
 /* ---- loss + optimiser (loss_adam.hip) ---------------------------------------------------------------------
  * stats: device float[8] zeroed once per step: [0] sum|y-p| [1] kept count [2] KL sum [3] extra sum g^2 terms (in; node-sharded
  * runs) [4] total sum g^2 (out) [6] [7] fold tickets of tails.hip.
@@ -260,7 +266,7 @@ int gptst_mae_bwd(const float* out, const float* src, int lda, const float* mask
 int gptst_kl(const float* prob, const float* c, int rows, int N, int HS, float w, float* dlogit, float* stats, void* stream);
 int gptst_clip_adam_ws_floats(void);   /* scratch floats (ws) of gptst_clip_adam: one gradient-norm partial per workgroup, folded in order */
 int gptst_clip_adam(float* p, const float* g, float* m, float* v, long nA, long nB, const float* hyper, float* stats, float* ws,
-                    void* stream);
+                    float* stats_out, void* stream);   /* stats_out (optional float[8]): copy of the final statistics block */
 
 /* ---- communication (comm.hip): RCCL over xGMI with an explicit stream — a collective can sit inside a captured hipGraph -------------
  * The reference has no distributed code; these carry the data-parallel gradient exchange (one all-reduce of [flat gradient | statistics])
