@@ -7,7 +7,8 @@ kept-count available everywhere; the optimiser kernel divides the reconstruction
 Masks follow the reference's GLOBAL-batch semantics (GPTST.py:316-321, 351-404: one top-k / one class selection over
 the whole batch): every rank draws the same global noise (same Philox seed), runs the bit-exact integer selection on the
 global batch and keeps its own rows.  The random phase needs no communication; the adaptive phase all-gathers the
-per-cell cluster labels (int32, 261 KB per 32-sample rank) and sums the per-class counts (HS int32) before the selection.
+per-cell cluster labels (int32, 261 KB per 32-sample rank) between the two hipGraphs of a step (step.py: part 1 ends with the
+guide classifier, part 2 starts with the mask); the per-class counts are the histogram of the gathered labels (taken on the device).
 ``PretrainStep(global_mask=False)`` falls back to per-rank masks (same ratio, no label exchange).
 """
 import os

@@ -78,9 +78,6 @@ class PretrainStep:
             self.noise_a_g, self.noise_r_g = self.noise_ar_g[:Mg], self.noise_ar_g[Mg:]
             self.label_l = torch.zeros(M, dtype=torch.int32, device=self.dev)
             self.label_g = torch.zeros(Mg, dtype=torch.int32, device=self.dev)
-            self.counts_g = torch.zeros(self.HS, dtype=torch.int32, device=self.dev)
-            self.arena_l = engine.ZeroArena(self.dev)
-            self.label_graph = None
         # measured: running weight gradients on a second stream slows the step (364 vs 403 steps/s), so opt-in only
         self.side = engine.SideStream() if os.environ.get("GPTST_SIDE_STREAM", "0") == "1" else None
         # opt-in: parameter-gradient reductions of finished layers on a second stream under the rest of the backward chain
@@ -88,10 +85,15 @@ class PretrainStep:
         self.red_side = engine.SideStream() if os.environ.get("GPTST_RED_STREAM", "0") == "1" else None
 
     # ---- the enqueued work ---------------------------------------------------------------------------------------
-    def _fwd_bwd(self, phase):
-        mdl, p, g, dims, base = self.model, self.model.param_views(), self.g, self.dims, self.base
-        a = self.args
-        M = self.B * self.T * self.N
+    # A step is enqueued in two parts: part 1 ends with the guide classifier (the cluster labels of the local rows), part 2 starts
+    # with the mask.  Under data parallelism with global masks the adaptive phase exchanges the labels BETWEEN the two parts (one
+    # all-gather; the class histogram is taken from the gathered labels) — as two hipGraphs sharing one memory pool, so that the
+    # guide forward is computed once and no collective sits inside a graph.  Everything else runs the two parts back to back.
+    def _needs_exchange(self, phase):
+        return self.gmask and phase == 1 and not self.force_mask
+
+    def _part1(self, phase):
+        p, dims, base = self.model.param_views(), self.dims, self.base
         engine.CTX.ARENA = self.arena
         engine.CTX.SIDE = self.side
         src = self.src
@@ -100,6 +102,17 @@ class PretrainStep:
         gen = engine.gen_all(p, tidx, dims)                       # time embeddings + every generated parameter: 3 launches
         red = engine.Reductions(side=self.red_side)
         prob, sv_g = engine.guide_fwd(p, src, tidx, dims, base, gen=gen["guide"])
+        if self._needs_exchange(phase):
+            self.label_l.copy_(sv_g[4])                           # this rank's cluster labels -> all-gather (_exchange_labels)
+        return dict(tidx=tidx, gen=gen, red=red, prob=prob, sv_g=sv_g)
+
+    def _part2(self, phase, ctx):
+        mdl, p, g, dims, base = self.model, self.model.param_views(), self.g, self.dims, self.base
+        a = self.args
+        M = self.B * self.T * self.N
+        src, tidx, gen, red, prob, sv_g = self.src, ctx["tidx"], ctx["gen"], ctx["red"], ctx["prob"], ctx["sv_g"]
+        engine.CTX.ARENA = self.arena
+        engine.CTX.SIDE = self.side
         if self.gmask:
             mask = self._global_mask(phase)
         else:
@@ -140,6 +153,8 @@ class PretrainStep:
         red.flush(tidx)                                           # all parameter-gradient reductions: 3 launches
         engine.CTX.ARENA = None
         engine.CTX.SIDE = None
+        if self.dp is None:
+            self._optim()
 
     def _global_mask(self, phase):
         """Mask of this rank's rows cut out of the selection over the global batch (identical on every rank)."""
@@ -154,54 +169,28 @@ class PretrainStep:
                 self.noise_ar_g.uniform_()
         if phase == 0:
             mask_g = ops.mask_random(self.noise_g, int(Mg * base * a.mask_ratio))
-        else:                                              # label_g / counts_g were exchanged by _exchange_labels()
-            mask_g = ops.mask_adaptive(self.label_g, self.counts_g, self.ctrl[:self.HS], self.ctrl[self.HS:], self.noise_a_g,
+        else:                                              # label_g was gathered by _exchange_labels(); class histogram taken inside
+            mask_g = ops.mask_adaptive(self.label_g, None, self.ctrl[:self.HS], self.ctrl[self.HS:], self.noise_a_g,
                                        self.noise_r_g, a.ada_type == "all", base)[2]
         self.last_mask_global = mask_g
         return self.dp.rows_of(mask_g, M * base)
 
-    def _labels_body(self):
-        p, dims, base = self.model.param_views(), self.dims, self.base
-        engine.CTX.ARENA = self.arena_l
-        self.arena_l.begin()
-        tidx = self.src[:, :, 0, base:base + 2].contiguous()
-        prob, _ = engine.guide_fwd(p, self.src, tidx, dims, base)
-        label, counts = ops.mask_labels(prob)
-        self.label_l.copy_(label); self.counts_g.copy_(counts)
-        engine.CTX.ARENA = None
-
     def _exchange_labels(self):
-        """Adaptive phase under DP: cluster labels of the local rows (guide forward + argmax, its own small hipGraph), then one
-        all-gather of the labels and one all-reduce of the class counts.  The main graph recomputes the guide forward (it
-        needs its activations for the KL backward): +~60 us per step, and no collective inside a captured graph."""
-        if self.use_graph:
-            if self.label_graph is None:
-                s = torch.cuda.Stream()
-                s.wait_stream(torch.cuda.current_stream())
-                with torch.cuda.stream(s):
-                    self._labels_body()
-                torch.cuda.current_stream().wait_stream(s)
-                torch.cuda.synchronize()
-                g = torch.cuda.CUDAGraph()
-                with torch.cuda.graph(g, capture_error_mode="thread_local"):      # other threads (RCCL watchdog) may call the runtime meanwhile
-                    self._labels_body()
-                self.label_graph = g
-            self.label_graph.replay()
-        else:
-            self._labels_body()
+        """Adaptive phase under DP: ONE all-gather of the int32 cluster labels (261 KB per 32-sample rank), between the two parts."""
         self.dp.gather_labels(self.label_l, out=self.label_g)
-        self.dp.sum_counts_(self.counts_g)
 
     def _optim(self):
         ops.clip_adam(self.model.flat, self.gflat, self.m, self.v, self.model.nA, self.model.nB, self.hyper, self.stats,
                       stats_out=self.stats_out)
 
     def _body(self, phase):
+        """eager: part 1 [-> label exchange] -> part 2 (+ optimiser when there is no gradient all-reduce in between)"""
         ops.set_deterministic(self.deterministic)           # thread-local launch mode of the library (captured into the graph)
         try:
-            self._fwd_bwd(phase)
-            if self.dp is None:
-                self._optim()
+            ctx = self._part1(phase)
+            if self._needs_exchange(phase):
+                self._exchange_labels()
+            self._part2(phase, ctx)
         finally:
             ops.set_deterministic(False)
 
@@ -266,8 +255,6 @@ class PretrainStep:
         if forced_mask is not None:
             self.mask_buf.copy_(forced_mask.reshape(-1), non_blocking=True)
         self._host_prepare(phase, epoch, list_c)
-        if self.gmask and phase == 1 and forced_mask is None:
-            self._exchange_labels()
         key = (phase, inject, forced_mask is not None)
         if not self.use_graph:
             self.inject_noise, self.force_mask = inject, forced_mask is not None
@@ -275,7 +262,11 @@ class PretrainStep:
         else:
             if key not in self.graphs:
                 self._capture(key)
-            self.graphs[key].replay()
+            g1, g2 = self.graphs[key]
+            g1.replay()
+            if g2 is not None:                          # global masks, adaptive phase: labels are exchanged between the two graphs
+                self._exchange_labels()
+                g2.replay()
         if self.dp is not None:
             self.dp.allreduce_(self.gbuf)
             self._optim()
@@ -291,10 +282,23 @@ class PretrainStep:
                 self._body(phase)
         torch.cuda.current_stream().wait_stream(s)
         torch.cuda.synchronize()
-        g = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(g, capture_error_mode="thread_local"):      # other threads (RCCL watchdog) may call the runtime meanwhile
-            self._body(phase)
-        self.graphs[key] = g
+        ops.set_deterministic(self.deterministic)
+        try:
+            g1 = torch.cuda.CUDAGraph()
+            if self._needs_exchange(phase):
+                with torch.cuda.graph(g1, capture_error_mode="thread_local"):      # other threads (RCCL watchdog) may call the runtime meanwhile
+                    ctx = self._part1(phase)
+                g2 = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(g2, pool=g1.pool(), capture_error_mode="thread_local"):
+                    self._part2(phase, ctx)
+                self._ctx_keep = getattr(self, "_ctx_keep", []) + [ctx]            # part 1's tensors are inputs of graph 2
+            else:
+                g2 = None
+                with torch.cuda.graph(g1, capture_error_mode="thread_local"):
+                    self._part2(phase, self._part1(phase))
+        finally:
+            ops.set_deterministic(False)
+        self.graphs[key] = (g1, g2)
         self.model.flat.copy_(keep[0]); self.m.copy_(keep[1]); self.v.copy_(keep[2])   # undo the warm-up updates
         torch.cuda.synchronize()
 
