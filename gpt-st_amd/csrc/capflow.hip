@@ -1,0 +1,425 @@
+// cap for node counts whose (b,t) capsule matrix does not fit LDS (BASELINE configs[4]: N = 4096, C = 128) — second generation of the
+// streaming path (cap_big.hip is the first: VALU, one wave per row, one kernel per algebraic step, 9 passes over the capsule matrix P
+// per forward).  Same algebra (reference GPTST.py:102-123,135):
+//     P = squash(X Wp^T + bp);  c0 = softmax_h(dadj);  v0 = squash(c0 P)
+//     b = 0;  R x { [b += v P^T];  cs = softmax_h(b);  v = squash(v0 (.) cs P) };  b += v P^T;  c = softmax_h(b + dadj);  s = c P
+// Every routing iteration is ONE pass over P: for a 16-node tile the wave computes the logits update  rows . V^T  (fp32 MFMA 16x16x4,
+// contraction over channels), the softmax over the clusters (the 16 lanes of a DPP row), and the tile's contribution  cs^T . rows  to
+// the cluster sums (MFMA, contraction over the tile's nodes) — the three kernels type2 / softmax / type1 of cap_big.hip, with P read
+// once instead of twice and the (BT,HS,N) coefficient matrix never written for the inner iterations.  The first iteration (b = 0: uniform
+// coefficients, i.e. column sums of P) is folded into the squash pass.  Per forward: Y written + read once, P written once and read R times.
+// Sums over nodes leave a kernel as PARTIALS per 256-node chunk, folded in index order by cf_post_kernel (no atomics, no zero fill);
+// a node-sharded run folds, all-reduces the (BT,HS,C) sums across ranks and resumes with the post step.
+//
+// Operand layouts of a 16-row tile (lane = (j, kk), j = lane & 15, kk = lane >> 4):
+//   "row form"     lane holds row j, channels 16q+4kk .. +3 (q < C/16):  A operand of a contraction over channels; D of a product whose
+//                  output rows are channels (rec^T, dP^T) lands in the same form, so row-wise epilogues run from registers;
+//   "column form"  lane holds rows 4kk+r (r < 4), channels 64hf+4j .. +3 (hf < C/64):  B operand of a contraction over the tile's rows
+//                  (k-step r <-> row 4kk+r), and 256-byte coalesced loads / stores;
+//   "node form" of a (BT,HS,N) matrix: lane holds cluster j, nodes 4kk .. 4kk+3 of the tile — one float4 along N; it is the D layout
+//                  of  rows . V^T  and the A layout of  cs^T . rows.
+// HS <= 16 and C in {64, 128}; other shapes stay on cap_big.hip.
+#include "common.h"
+
+#define CF_TILES 4                        // 16-row tiles per wave
+#define CF_ROWS (4 * CF_TILES * 16)       // node rows per workgroup (= per partial)
+
+__device__ __forceinline__ f32x4 mfma4(float a, float b, f32x4 c) { return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0); }
+__device__ __forceinline__ f32x4 fzero4() { return (f32x4){0.f, 0.f, 0.f, 0.f}; }
+
+// four consecutive node entries n .. n+3 of one (.., N) row (`row` points at node 0); `al` = rows are 16-byte aligned (N % 4 == 0)
+__device__ __forceinline__ float4 ldn4(const float* __restrict__ row, int n, int N, bool al) {
+    float4 v = f4zero();
+    if (al) { if (n < N) v = ld4(row + n); }
+    else {
+        if (n < N) v.x = row[n];
+        if (n + 1 < N) v.y = row[n + 1];
+        if (n + 2 < N) v.z = row[n + 2];
+        if (n + 3 < N) v.w = row[n + 3];
+    }
+    return v;
+}
+__device__ __forceinline__ void stn4(float* __restrict__ row, int n, int N, bool al, float4 v) {
+    if (al) { if (n < N) st4(row + n, v); }
+    else {
+        if (n < N) row[n] = v.x;
+        if (n + 1 < N) row[n + 1] = v.y;
+        if (n + 2 < N) row[n + 2] = v.z;
+        if (n + 3 < N) row[n + 3] = v.w;
+    }
+}
+
+// softmax over the clusters (lanes j < HS of a DPP row) of the four node columns of a lane; invalid nodes -> 0
+__device__ __forceinline__ void softmax_h4(const float (&x)[4], float (&cs)[4], int j, int HS, int n, int N) {
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        const float xv = j < HS ? x[r] : -3.0e38f;
+        const float m = group_max<16>(xv);
+        const float e = j < HS ? __expf(xv - m) : 0.f;
+        const float inv = 1.f / group_sum<16>(e);
+        cs[r] = (n + r < N) ? e * inv : 0.f;
+    }
+}
+
+// fold the per-wave cluster sums (acc[4hf+e][r'] = S[h = 4kk+r'][channel 64hf+4j+e]) through LDS and store the workgroup's partial
+template <int C, int XR>
+__device__ __forceinline__ void store_partial(float4 (*red)[16 + XR][C / 4], const f32x4 (&acc)[C / 16], float* __restrict__ dst, int rows_out,
+                                              int wave, int j, int kk) {
+#pragma unroll
+    for (int hf = 0; hf < C / 64; ++hf)
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+            red[wave][4 * kk + r][16 * hf + j] = make_float4(acc[4 * hf + 0][r], acc[4 * hf + 1][r], acc[4 * hf + 2][r], acc[4 * hf + 3][r]);
+    __syncthreads();
+    for (int o = threadIdx.x; o < rows_out * (C / 4); o += 256) {
+        const int h = o / (C / 4), c4 = o % (C / 4);
+        const int row = (XR && h == rows_out - 1) ? 16 : h;          // XR: the last output row is the extra LDS row (column sums)
+        const float4 s = f4add(f4add(red[0][row][c4], red[1][row][c4]), f4add(red[2][row][c4], red[3][row][c4]));
+        st4(dst + (size_t)h * C + 4 * c4, s);
+    }
+}
+
+// ---- pass 0:  P = squash(Y) (row-wise), c0 = softmax_h(dadj), partial [c0^T P ; colsum P] ------------------------------------------
+// part: (BT, nparts, HS+1, C) — rows h < HS: sum_n c0[h,n] P[n,:];  row HS: sum_n P[n,:]  (the first routing iteration: uniform coefficients)
+template <int C>
+__global__ __launch_bounds__(256) void cf_squash_kernel(const float* __restrict__ Y, const float* __restrict__ dadj, float* __restrict__ P,
+                                                        float* __restrict__ part, int HS, int N, int nparts) {
+    constexpr int H2 = C / 64;
+    __shared__ float4 red[4][17][C / 4];
+    const int bt = blockIdx.y, chunk = blockIdx.x;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, j = lane & 15, kk = lane >> 4;
+    const bool al = (N & 3) == 0;
+    f32x4 acc[C / 16];
+#pragma unroll
+    for (int i = 0; i < C / 16; ++i) acc[i] = fzero4();
+    float4 csum[H2];
+#pragma unroll
+    for (int hf = 0; hf < H2; ++hf) csum[hf] = f4zero();
+    const float* lrow = dadj + ((size_t)bt * HS + min(j, HS - 1)) * N;
+#pragma unroll 1
+    for (int it = 0; it < CF_TILES; ++it) {
+        const int n0 = chunk * CF_ROWS + (it * 4 + wave) * 16;
+        if (n0 >= N) break;                                           // wave-uniform
+        const int n = n0 + 4 * kk;
+        float4 y[4][H2];
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+#pragma unroll
+            for (int hf = 0; hf < H2; ++hf) y[r][hf] = ld4(Y + ((size_t)bt * N + min(n + r, N - 1)) * C + 64 * hf + 4 * j);
+        const float4 lg = ldn4(lrow, n, N, al);
+        SB();
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            float q = 0.f;
+#pragma unroll
+            for (int hf = 0; hf < H2; ++hf) q += f4dot(y[r][hf], y[r][hf]);
+            const float sc = (n + r < N) ? squash_scale(group_sum<16>(q)) : 0.f;
+#pragma unroll
+            for (int hf = 0; hf < H2; ++hf) {
+                y[r][hf] = make_float4(y[r][hf].x * sc, y[r][hf].y * sc, y[r][hf].z * sc, y[r][hf].w * sc);
+                csum[hf] = f4add(csum[hf], y[r][hf]);
+                if (n + r < N) st4(P + ((size_t)bt * N + n + r) * C + 64 * hf + 4 * j, y[r][hf]);
+            }
+        }
+        const float x[4] = {lg.x, lg.y, lg.z, lg.w};
+        float cs[4];
+        softmax_h4(x, cs, j, HS, n, N);
+        SB();
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+#pragma unroll
+            for (int hf = 0; hf < H2; ++hf) {
+                acc[4 * hf + 0] = mfma4(cs[r], y[r][hf].x, acc[4 * hf + 0]);
+                acc[4 * hf + 1] = mfma4(cs[r], y[r][hf].y, acc[4 * hf + 1]);
+                acc[4 * hf + 2] = mfma4(cs[r], y[r][hf].z, acc[4 * hf + 2]);
+                acc[4 * hf + 3] = mfma4(cs[r], y[r][hf].w, acc[4 * hf + 3]);
+            }
+    }
+#pragma unroll
+    for (int hf = 0; hf < H2; ++hf) {                                 // column sums: fold the four row groups of the wave
+        float4 s = csum[hf];
+        s.x += __shfl_xor(s.x, 16, 64); s.y += __shfl_xor(s.y, 16, 64); s.z += __shfl_xor(s.z, 16, 64); s.w += __shfl_xor(s.w, 16, 64);
+        s.x += __shfl_xor(s.x, 32, 64); s.y += __shfl_xor(s.y, 32, 64); s.z += __shfl_xor(s.z, 32, 64); s.w += __shfl_xor(s.w, 32, 64);
+        if (kk == 0) red[wave][16][16 * hf + j] = s;
+    }
+    store_partial<C, 1>(red, acc, part + ((size_t)bt * nparts + chunk) * (HS + 1) * C, HS + 1, wave, j, kk);
+}
+
+// ---- one pass over the rows of a (BT,N,C) matrix ------------------------------------------------------------------------------------
+//   L = V ? rows . V^T : 0;   b = L + (bl_in ? bl_in : 0);   bl_out <- b (if given)
+//   cs = c_in ? c_in : softmax_h(b + (l0 ? l0 : 0));   c_out <- cs (if given);   part <- partial of cs^T . rows
+// routing iteration r >= 1:  (P, v, b -> b);   last step:  (P, v, b, l0 = dadj -> c);   backward of rec = c^T v:  (drec, v -> dc1 = bl_out; c_in = c -> dv)
+template <int C>
+__global__ __launch_bounds__(256) void cf_route_kernel(const float* __restrict__ rows, const float* __restrict__ V, const float* __restrict__ bl_in,
+                                                       float* __restrict__ bl_out, const float* __restrict__ l0, const float* __restrict__ c_in,
+                                                       float* __restrict__ c_out, float* __restrict__ part, int HS, int N, int nparts) {
+    constexpr int Q = C / 16, H2 = C / 64;
+    __shared__ float4 red[4][16][C / 4];
+    const int bt = blockIdx.y, chunk = blockIdx.x;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, j = lane & 15, kk = lane >> 4;
+    const bool al = (N & 3) == 0;
+    f32x4 acc[C / 16];
+#pragma unroll
+    for (int i = 0; i < C / 16; ++i) acc[i] = fzero4();
+    float4 mb[Q];                                                     // V[h = j][16q+4kk ..]: B operand of rows . V^T
+#pragma unroll
+    for (int q = 0; q < Q; ++q) mb[q] = (V != nullptr && j < HS) ? ld4(V + ((size_t)bt * HS + j) * C + 16 * q + 4 * kk) : f4zero();
+    const size_t hrow = ((size_t)bt * HS + min(j, HS - 1)) * N;
+#pragma unroll 1
+    for (int it = 0; it < CF_TILES; ++it) {
+        const int n0 = chunk * CF_ROWS + (it * 4 + wave) * 16;
+        if (n0 >= N) break;
+        const int n = n0 + 4 * kk;
+        float4 a1[Q], a2[4][H2];
+        if (V != nullptr) {
+#pragma unroll
+            for (int q = 0; q < Q; ++q) a1[q] = ld4(rows + ((size_t)bt * N + min(n0 + j, N - 1)) * C + 16 * q + 4 * kk);
+        }
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+#pragma unroll
+            for (int hf = 0; hf < H2; ++hf) a2[r][hf] = ld4(rows + ((size_t)bt * N + min(n + r, N - 1)) * C + 64 * hf + 4 * j);
+        float4 b4 = f4zero(), l4 = f4zero(), c4 = f4zero();
+        if (bl_in != nullptr) b4 = ldn4(bl_in + hrow, n, N, al);
+        if (l0 != nullptr) l4 = ldn4(l0 + hrow, n, N, al);
+        if (c_in != nullptr) c4 = ldn4(c_in + hrow, n, N, al);
+        SB();
+        if (V != nullptr) {
+            f32x4 L0 = fzero4(), L1 = fzero4(), L2 = fzero4(), L3 = fzero4();          // four independent accumulation chains
+#pragma unroll
+            for (int q = 0; q < Q; ++q) {
+                L0 = mfma4(a1[q].x, mb[q].x, L0);
+                L1 = mfma4(a1[q].y, mb[q].y, L1);
+                L2 = mfma4(a1[q].z, mb[q].z, L2);
+                L3 = mfma4(a1[q].w, mb[q].w, L3);
+            }
+            b4.x += (L0[0] + L1[0]) + (L2[0] + L3[0]);
+            b4.y += (L0[1] + L1[1]) + (L2[1] + L3[1]);
+            b4.z += (L0[2] + L1[2]) + (L2[2] + L3[2]);
+            b4.w += (L0[3] + L1[3]) + (L2[3] + L3[3]);
+        }
+        if (bl_out != nullptr && j < HS) stn4(bl_out + hrow, n, N, al, b4);
+        float cs[4];
+        if (c_in != nullptr) {
+            cs[0] = (j < HS && n < N) ? c4.x : 0.f; cs[1] = (j < HS && n + 1 < N) ? c4.y : 0.f;
+            cs[2] = (j < HS && n + 2 < N) ? c4.z : 0.f; cs[3] = (j < HS && n + 3 < N) ? c4.w : 0.f;
+        } else {
+            const float x[4] = {b4.x + l4.x, b4.y + l4.y, b4.z + l4.z, b4.w + l4.w};
+            softmax_h4(x, cs, j, HS, n, N);
+            if (c_out != nullptr && j < HS) stn4(c_out + hrow, n, N, al, make_float4(cs[0], cs[1], cs[2], cs[3]));
+        }
+        SB();
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+#pragma unroll
+            for (int hf = 0; hf < H2; ++hf) {
+                acc[4 * hf + 0] = mfma4(cs[r], a2[r][hf].x, acc[4 * hf + 0]);
+                acc[4 * hf + 1] = mfma4(cs[r], a2[r][hf].y, acc[4 * hf + 1]);
+                acc[4 * hf + 2] = mfma4(cs[r], a2[r][hf].z, acc[4 * hf + 2]);
+                acc[4 * hf + 3] = mfma4(cs[r], a2[r][hf].w, acc[4 * hf + 3]);
+            }
+    }
+    store_partial<C, 0>(red, acc, part + ((size_t)bt * nparts + chunk) * HS * C, HS, wave, j, kk);
+}
+
+// ---- rec[bt,n,:] = sum_h c[bt,h,n] v[bt,h,:]  (cluster -> node scatter, GPTST.py:135) as rec^T = v^T c^T on MFMA --------------------------
+template <int C>
+__global__ __launch_bounds__(256) void cf_rec_fwd_kernel(const float* __restrict__ c, const float* __restrict__ v, float* __restrict__ rec,
+                                                         int HS, int N) {
+    constexpr int Q = C / 16;
+    const int bt = blockIdx.y, chunk = blockIdx.x;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, j = lane & 15, kk = lane >> 4;
+    float va[Q][4];                                                   // A[i = channel 16q+j][k-step s: h = 4kk+s]
+#pragma unroll
+    for (int q = 0; q < Q; ++q)
+#pragma unroll
+        for (int s = 0; s < 4; ++s) va[q][s] = (4 * kk + s < HS) ? v[((size_t)bt * HS + 4 * kk + s) * C + 16 * q + j] : 0.f;
+#pragma unroll 1
+    for (int it = 0; it < CF_TILES; ++it) {
+        const int n0 = chunk * CF_ROWS + (it * 4 + wave) * 16;
+        if (n0 >= N) break;
+        const bool ok = n0 + j < N;
+        float ct[4];                                                  // B[k: h = 4kk+s][row j]
+#pragma unroll
+        for (int s = 0; s < 4; ++s) ct[s] = (ok && 4 * kk + s < HS) ? c[((size_t)bt * HS + 4 * kk + s) * N + n0 + j] : 0.f;
+        f32x4 acc[Q];
+#pragma unroll
+        for (int q = 0; q < Q; ++q) acc[q] = fzero4();
+#pragma unroll
+        for (int s = 0; s < 4; ++s)
+#pragma unroll
+            for (int q = 0; q < Q; ++q) acc[q] = mfma4(va[q][s], ct[s], acc[q]);
+        if (ok) {
+#pragma unroll
+            for (int q = 0; q < Q; ++q)
+                st4(rec + ((size_t)bt * N + n0 + j) * C + 16 * q + 4 * kk, make_float4(acc[q][0], acc[q][1], acc[q][2], acc[q][3]));
+        }
+    }
+}
+
+// ---- backward through s = c P, c = softmax_h(b + dadj), P = squash(Y) for the rows of Y (cb_route_bwd_rows_kernel on MFMA) ------------
+//   U[n,h] = dS[h,:].P[n,:];  dc = dc1 + U;  dlogit[h] = c[h] (dc[h] - sum_h c dc);  dP = sum_h c[h] dS[h,:];  dY = g dP + Y 2 g'(q) (Y.dP)
+template <int C>
+__global__ __launch_bounds__(256) void cf_route_bwd_kernel(const float* __restrict__ Y, const float* __restrict__ c, const float* __restrict__ dc1,
+                                                           const float* __restrict__ dS, float* __restrict__ dY, float* __restrict__ dlogit,
+                                                           int HS, int N) {
+    constexpr int Q = C / 16;
+    const int bt = blockIdx.y, chunk = blockIdx.x;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, j = lane & 15, kk = lane >> 4;
+    const bool al = (N & 3) == 0;
+    float4 mb[Q];                                                     // dS[h = j][16q+4kk ..]: B operand of Y . dS^T
+    float da[Q][4];                                                   // dS[h = 4kk+s][16q+j]:  A operand of dP^T = dS^T c^T
+#pragma unroll
+    for (int q = 0; q < Q; ++q) {
+        mb[q] = j < HS ? ld4(dS + ((size_t)bt * HS + j) * C + 16 * q + 4 * kk) : f4zero();
+#pragma unroll
+        for (int s = 0; s < 4; ++s) da[q][s] = (4 * kk + s < HS) ? dS[((size_t)bt * HS + 4 * kk + s) * C + 16 * q + j] : 0.f;
+    }
+    const size_t hrow = ((size_t)bt * HS + min(j, HS - 1)) * N;
+#pragma unroll 1
+    for (int it = 0; it < CF_TILES; ++it) {
+        const int n0 = chunk * CF_ROWS + (it * 4 + wave) * 16;
+        if (n0 >= N) break;
+        const int n = n0 + 4 * kk;
+        const bool ok = n0 + j < N;
+        float4 a1[Q];
+#pragma unroll
+        for (int q = 0; q < Q; ++q) a1[q] = ld4(Y + ((size_t)bt * N + min(n0 + j, N - 1)) * C + 16 * q + 4 * kk);
+        const float4 c1 = ldn4(c + hrow, n, N, al), d1 = ldn4(dc1 + hrow, n, N, al);
+        float ct[4];
+#pragma unroll
+        for (int s = 0; s < 4; ++s) ct[s] = (ok && 4 * kk + s < HS) ? c[((size_t)bt * HS + 4 * kk + s) * N + n0 + j] : 0.f;
+        SB();
+        float qn = 0.f;
+#pragma unroll
+        for (int q = 0; q < Q; ++q) qn += f4dot(a1[q], a1[q]);
+        qn += __shfl_xor(qn, 16, 64); qn += __shfl_xor(qn, 32, 64);      // |Y[row j]|^2 in every lane of column j
+        const float rt = sqrtf(qn), den = (1.f + qn) * (rt + 1e-8f);
+        const float g = qn / den;
+        float gp = 0.f;
+        if (rt > 0.f) gp = (den - qn * ((rt + 1e-8f) + (1.f + qn) * 0.5f / rt)) / (den * den);
+        f32x4 L0 = fzero4(), L1 = fzero4(), L2 = fzero4(), L3 = fzero4();
+#pragma unroll
+        for (int q = 0; q < Q; ++q) {
+            L0 = mfma4(a1[q].x, mb[q].x, L0);
+            L1 = mfma4(a1[q].y, mb[q].y, L1);
+            L2 = mfma4(a1[q].z, mb[q].z, L2);
+            L3 = mfma4(a1[q].w, mb[q].w, L3);
+        }
+        f32x4 acc[Q];
+#pragma unroll
+        for (int q = 0; q < Q; ++q) acc[q] = fzero4();
+#pragma unroll
+        for (int s = 0; s < 4; ++s)
+#pragma unroll
+            for (int q = 0; q < Q; ++q) acc[q] = mfma4(da[q][s], ct[s], acc[q]);
+        // node form: rows 4kk+r, cluster j
+        const float cv[4] = {c1.x, c1.y, c1.z, c1.w}, dv[4] = {d1.x, d1.y, d1.z, d1.w};
+        float dl[4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const float gr = __shfl(g, 4 * kk + r, 64);                              // squash gain of row 4kk+r
+            const float dch = dv[r] + gr * ((L0[r] + L1[r]) + (L2[r] + L3[r]));
+            const float w = group_sum<16>(j < HS ? cv[r] * dch : 0.f);
+            dl[r] = cv[r] * (dch - w);
+        }
+        if (j < HS) stn4(dlogit + hrow, n, N, al, make_float4(dl[0], dl[1], dl[2], dl[3]));
+        // row form: dP[row j][16q+4kk+r'] = acc[q][r']
+        float ydp = 0.f;
+#pragma unroll
+        for (int q = 0; q < Q; ++q) ydp += a1[q].x * acc[q][0] + a1[q].y * acc[q][1] + a1[q].z * acc[q][2] + a1[q].w * acc[q][3];
+        ydp += __shfl_xor(ydp, 16, 64); ydp += __shfl_xor(ydp, 32, 64);
+        const float k2 = 2.f * gp * ydp;
+        if (ok) {
+#pragma unroll
+            for (int q = 0; q < Q; ++q)
+                st4(dY + ((size_t)bt * N + n0 + j) * C + 16 * q + 4 * kk,
+                    make_float4(fmaf(k2, a1[q].x, g * acc[q][0]), fmaf(k2, a1[q].y, g * acc[q][1]), fmaf(k2, a1[q].z, g * acc[q][2]),
+                                fmaf(k2, a1[q].w, g * acc[q][3])));
+        }
+    }
+}
+
+// ---- ordered fold of the chunk partials + the cluster-level post step; one workgroup per (b,t) -----------------------------------------
+//   part (BT, nparts, prow, C);  mode 0: prow = HS+1: v0 = squash(S0) -> V0, v = squash(v0 (.) colsum/HS) -> Vout (if given)
+//   mode 1: v = squash(V0 (.) S) -> Vout;   mode 2: S -> Vout;   mode 3: all prow rows -> Vout (fold only: a node-sharded run all-reduces it)
+template <int C>
+__global__ __launch_bounds__(256) void cf_post_kernel(const float* __restrict__ part, int nparts, int prow, float* __restrict__ V0,
+                                                      float* __restrict__ Vout, int mode, int HS) {
+    constexpr int L = C / 4, SL = 256 / L;
+    const int bt = blockIdx.x, c4 = threadIdx.x % L, slot = threadIdx.x / L;
+    const float* pb = part + (size_t)bt * nparts * prow * C;
+    float4 cs4 = f4zero();
+    if (mode == 0) {
+        for (int p = 0; p < nparts; ++p) cs4 = f4add(cs4, ld4(pb + ((size_t)p * prow + HS) * C + 4 * c4));
+        const float ih = 1.f / (float)HS;
+        cs4 = make_float4(cs4.x * ih, cs4.y * ih, cs4.z * ih, cs4.w * ih);
+    }
+    const int nrow = mode == 3 ? prow : HS;
+    for (int h = slot; h < nrow; h += SL) {
+        float4 s = f4zero();
+        for (int p = 0; p < nparts; ++p) s = f4add(s, ld4(pb + ((size_t)p * prow + h) * C + 4 * c4));
+        const size_t o = ((size_t)bt * nrow + h) * C + 4 * c4;
+        if (mode >= 2) { st4(Vout + o, s); continue; }
+        if (mode == 0) {
+            const float sc = squash_scale(group_sum<L>(f4dot(s, s)));
+            s = make_float4(s.x * sc, s.y * sc, s.z * sc, s.w * sc);
+            st4(V0 + o, s);
+            if (Vout == nullptr) continue;
+            s = make_float4(s.x * cs4.x, s.y * cs4.y, s.z * cs4.z, s.w * cs4.w);
+        } else {
+            const float4 v0 = ld4(V0 + o);
+            s = make_float4(s.x * v0.x, s.y * v0.y, s.z * v0.z, s.w * v0.w);
+        }
+        const float sc = squash_scale(group_sum<L>(f4dot(s, s)));
+        st4(Vout + o, make_float4(s.x * sc, s.y * sc, s.z * sc, s.w * sc));
+    }
+}
+
+// ---- C ABI ---------------------------------------------------------------------------------------------------------------------------
+#define CF_LAUNCH(KERNEL, GRID, ...)                                                                          \
+    do {                                                                                                      \
+        if (C == 64) hipLaunchKernelGGL((KERNEL<64>), GRID, dim3(256), 0, (hipStream_t)stream, __VA_ARGS__);        \
+        else hipLaunchKernelGGL((KERNEL<128>), GRID, dim3(256), 0, (hipStream_t)stream, __VA_ARGS__);               \
+        GPTST_CHECK_LAUNCH();                                                                                 \
+        return GPTST_OK;                                                                                      \
+    } while (0)
+#define CF_SHAPE_OK(HS, C) ((HS) >= 1 && (HS) <= 16 && ((C) == 64 || (C) == 128))
+
+extern "C" int gptst_capflow_supported(int HS, int C) { return CF_SHAPE_OK(HS, C) ? 1 : 0; }
+extern "C" int gptst_capflow_nparts(int N) { return (N + CF_ROWS - 1) / CF_ROWS; }
+
+extern "C" int gptst_capflow_squash(const float* Y, const float* dadj, float* P, float* part, int BT, int HS, int N, int C, void* stream) {
+    if (!Y || !dadj || !P || !part || BT < 1 || N < 1) return GPTST_EARG;
+    if (!CF_SHAPE_OK(HS, C)) return GPTST_ESHAPE;
+    const int np = gptst_capflow_nparts(N);
+    CF_LAUNCH(cf_squash_kernel, dim3(np, BT), Y, dadj, P, part, HS, N, np);
+}
+
+extern "C" int gptst_capflow_route(const float* rows, const float* V, const float* bl_in, float* bl_out, const float* l0, const float* c_in,
+                                   float* c_out, float* part, int BT, int HS, int N, int C, void* stream) {
+    if (!rows || !part || BT < 1 || N < 1) return GPTST_EARG;
+    if (!CF_SHAPE_OK(HS, C)) return GPTST_ESHAPE;
+    const int np = gptst_capflow_nparts(N);
+    CF_LAUNCH(cf_route_kernel, dim3(np, BT), rows, V, bl_in, bl_out, l0, c_in, c_out, part, HS, N, np);
+}
+
+extern "C" int gptst_capflow_post(const float* part, int nparts, int prow, float* V0, float* Vout, int mode, int BT, int HS, int C, void* stream) {
+    if (!part || nparts < 1 || mode < 0 || mode > 3 || (mode <= 1 && !V0) || (mode >= 1 && !Vout)) return GPTST_EARG;
+    if (prow != (mode == 0 ? HS + 1 : HS) && mode != 3) return GPTST_EARG;
+    if (!CF_SHAPE_OK(HS, C)) return GPTST_ESHAPE;
+    CF_LAUNCH(cf_post_kernel, dim3(BT), part, nparts, prow, V0, Vout, mode, HS);
+}
+
+extern "C" int gptst_capflow_rec_fwd(const float* c, const float* v, float* rec, int BT, int HS, int N, int C, void* stream) {
+    if (!c || !v || !rec || BT < 1 || N < 1) return GPTST_EARG;
+    if (!CF_SHAPE_OK(HS, C)) return GPTST_ESHAPE;
+    CF_LAUNCH(cf_rec_fwd_kernel, dim3(gptst_capflow_nparts(N), BT), c, v, rec, HS, N);
+}
+
+extern "C" int gptst_capflow_route_bwd(const float* Y, const float* c, const float* dc1, const float* dS, float* dY, float* dlogit, int BT,
+                                       int HS, int N, int C, void* stream) {
+    if (!Y || !c || !dc1 || !dS || !dY || !dlogit || BT < 1 || N < 1) return GPTST_EARG;
+    if (!CF_SHAPE_OK(HS, C)) return GPTST_ESHAPE;
+    CF_LAUNCH(cf_route_bwd_kernel, dim3(gptst_capflow_nparts(N), BT), Y, c, dc1, dS, dY, dlogit, HS, N);
+}

@@ -225,18 +225,18 @@ def hypertem_core_bwd(saved, dout, dG_out, dims):
 def cap_core_fwd(p, pfx, x, dadj, dyn, Wn, bn, dims, num_route, HS, HT):
     """x (BTN,C); dadj (BT,HS*N), dyn (B,HT,T*HS), Wn (N,C,C), bn (N,C) precomputed -> out, c (BT,HS,N), saved."""
     B, T, N, C = dims
-    c, s = ops.cap_route_fwd(x.view(B, T, N, C), p[pfx + "ln_p.weight"], p[pfx + "ln_p.bias"], dadj, HS, num_route,
-                             reduce_nodes=CTX.NODE_REDUCE)                                                            # :102-123
+    c, s, Y = ops.cap_route_fwd(x.view(B, T, N, C), p[pfx + "ln_p.weight"], p[pfx + "ln_p.bias"], dadj, HS, num_route,
+                                reduce_nodes=CTX.NODE_REDUCE, want_Y=True)                                            # :102-123
     v, Ht, Rt = ops.cap_cross_fwd(s, dyn, p[pfx + "mask_template"], B, T, HS, HT)                                     # :125-134
     rec = ops.cap_rec_fwd(c, v, N, C)                                                                                 # :135
     out = ops.apply(rec, Wn, MODE_NODE, B * T, N, bias=bn, resid=x, epi=EPI_RES_LRELU)                                # :139-141
-    return out, c, (x, out, rec, c, s, v, Ht, Rt, dyn, Wn)
+    return out, c, (x, out, rec, c, s, v, Ht, Rt, dyn, Wn, Y)
 
 
 def cap_core_bwd(p, g, pfx, saved, dout, dims, HS, HT, red):
     """-> dx and the pieces whose reductions are batched by the caller: (dWn, nsplit, dbn, ddyn, dlogit)."""
     B, T, N, C = dims
-    x, out, rec, c, s, v, Ht, Rt, dyn, Wn = saved
+    x, out, rec, c, s, v, Ht, Rt, dyn, Wn, Y = saved
     BT, dev = B * T, x.device
     if C == 64 and CTX.SIDE is None:     # data gradient, weight gradient and bias gradient of the node-conditioned layer in one pass
         drec, dWn, dbn, ns = ops.apply_wgrad(dout, out, rec, Wn, MODE_NODE, BT, N)
@@ -246,7 +246,7 @@ def cap_core_bwd(p, g, pfx, saved, dout, dims, HS, HT, red):
         dWn, ns = _wgrad_async(rec, dout, MODE_NODE, BT, N, D2=out, pro=PRO_DPRE)
     dc1, dv = ops.cap_rec_bwd(drec, c, v, reduce_nodes=CTX.NODE_REDUCE)
     dS, ddyn = ops.cap_cross_bwd(dv, s, Rt, Ht, dyn, p[pfx + "mask_template"], B, T, HS, HT)
-    dY, dlogit = ops.cap_route_bwd(x.view(B, T, N, C), p[pfx + "ln_p.weight"], p[pfx + "ln_p.bias"], c, dc1, dS)
+    dY, dlogit = ops.cap_route_bwd(x.view(B, T, N, C), p[pfx + "ln_p.weight"], p[pfx + "ln_p.bias"], c, dc1, dS, Y=Y)
     gw, gb = g[pfx + "ln_p.weight"], g[pfx + "ln_p.bias"]
     if C == 64:
         # dx = dY Wp + dout*lrelu'(out), the ln_p weight gradient and its bias gradient in one pass over dY

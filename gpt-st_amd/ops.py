@@ -366,19 +366,65 @@ def _cap_route_fwd_big(X, Wp, bp, dadj, HS, R, reduce_nodes=None):
     return c, s
 
 
-def cap_route_fwd(X, Wp, bp, dadj, HS, R, reduce_nodes=None):
-    """X (B,T,N,C); Wp (C,C) ln_p.weight; dadj (BT, HS*N) logits = teb . adj -> c (BT,HS,N), s (BT,HS,C)."""
+CAP_FLOW = True            # streaming cap on the fused MFMA passes of capflow.hip (False: first-generation cap_big.hip kernels)
+
+
+def capflow_ok(HS, C):
+    return CAP_FLOW and bool(_C.lib().value("gptst_capflow_supported", HS, C))
+
+
+def _capflow_post(part, nparts, prow, V0, Vout, mode, BT, HS, C, reduce_nodes):
+    """Ordered fold of the node-chunk partials + the cluster-level step; a node-sharded run completes the sums across ranks in between."""
+    if reduce_nodes is not None:
+        full = torch.empty(BT, prow, C, device=part.device, dtype=torch.float32)
+        _call("gptst_capflow_post", _p(part), nparts, prow, None, _p(full), 3, BT, HS, C)
+        reduce_nodes(full)
+        part, nparts = full, 1
+    _call("gptst_capflow_post", _p(part), nparts, prow, _p(V0), _p(Vout), mode, BT, HS, C)
+
+
+def _cap_route_fwd_flow(X, Wp, bp, dadj, HS, R, reduce_nodes=None):
+    """-> c, s, Y (pre-squash capsules, kept for the backward).  One pass over the capsule matrix per routing iteration (capflow.hip)."""
+    B, T, N, C = X.shape
+    BT, dev = B * T, X.device
+    f = dict(device=dev, dtype=torch.float32)
+    Y = _capbig_linear(X, Wp, bp)
+    P = torch.empty_like(Y)
+    npart = _C.lib().value("gptst_capflow_nparts", N)
+    part = torch.empty(BT, npart, HS + 1, C, **f)
+    c = torch.empty(BT, HS, N, **f)
+    V0, V, s = (torch.empty(BT, HS, C, **f) for _ in range(3))
+    _call("gptst_capflow_squash", _p(Y), _p(dadj), _p(P), _p(part), BT, HS, N, C)                          # P, c0, [c0 P ; colsum P]   :102-105
+    _capflow_post(part, npart, HS + 1, V0, V if R > 0 else None, 0, BT, HS, C, reduce_nodes)               # v0; v of iteration 0        :106,:113-118
+    bl = None
+    for r in range(1, R):                                                                                  # b += v P^T; cs; v           :113-118
+        bl2 = torch.empty(BT, HS, N, **f)
+        _call("gptst_capflow_route", _p(P), _p(V), _p(bl), _p(bl2), None, None, None, _p(part), BT, HS, N, C)
+        bl = bl2
+        _capflow_post(part, npart, HS, V0, V, 1, BT, HS, C, reduce_nodes)
+    _call("gptst_capflow_route", _p(P), _p(V) if R > 0 else None, _p(bl), None, _p(dadj), None, _p(c), _p(part), BT, HS, N, C)   # :120-123
+    _capflow_post(part, npart, HS, None, s, 2, BT, HS, C, reduce_nodes)
+    return c, s, Y
+
+
+def cap_route_fwd(X, Wp, bp, dadj, HS, R, reduce_nodes=None, want_Y=False):
+    """X (B,T,N,C); Wp (C,C) ln_p.weight; dadj (BT, HS*N) logits = teb . adj -> c (BT,HS,N), s (BT,HS,C)
+    [, Y (BT*N,C) = X Wp^T + bp when the streaming path computed it, else None]."""
     _chk(X, Wp, bp, dadj)
     B, T, N, C = X.shape
-    if reduce_nodes is not None:
-        return _cap_route_fwd_big(X, Wp, bp, dadj, HS, R, reduce_nodes)
+
+    def stream():
+        if capflow_ok(HS, C):
+            return _cap_route_fwd_flow(X, Wp, bp, dadj, HS, R, reduce_nodes)
+        return _cap_route_fwd_big(X, Wp, bp, dadj, HS, R, reduce_nodes) + (None,)
 
     def lds():
         c = torch.empty(B * T, HS, N, device=X.device, dtype=torch.float32)
         s = torch.empty(B * T, HS, C, device=X.device, dtype=torch.float32)
         _call("gptst_cap_route_fwd", _p(X), _p(Wp), _p(bp), _p(dadj), _p(c), _p(s), B * T, N, C, HS, R, nbytes=_nb(X, Wp, bp, dadj, c, s))
-        return c, s
-    return _lds_or_stream(lds, lambda: _cap_route_fwd_big(X, Wp, bp, dadj, HS, R, None))
+        return c, s, None
+    out = stream() if reduce_nodes is not None else _lds_or_stream(lds, stream)
+    return out if want_Y else out[:2]
 
 
 def cap_cross_fwd(s, dyn, tmpl, B, T, HS, HT):
@@ -406,8 +452,12 @@ def cap_rec_fwd(c, v, N, C):
     _chk(c, v)
     BT, HS = c.shape[0], c.shape[1]
     rec = torch.empty(BT * N, C, device=c.device, dtype=torch.float32)
-    _lds_or_stream(lambda: _call("gptst_cap_rec_fwd", _p(c), _p(v), _p(rec), BT, N, C, HS, nbytes=_nb(c, v, rec)),
-                   lambda: _call("gptst_capbig_rec_fwd", _p(c), _p(v), _p(rec), BT, HS, N, C))
+
+    def stream():
+        if capflow_ok(HS, C):
+            return _call("gptst_capflow_rec_fwd", _p(c), _p(v), _p(rec), BT, HS, N, C)
+        return _call("gptst_capbig_rec_fwd", _p(c), _p(v), _p(rec), BT, HS, N, C)
+    _lds_or_stream(lambda: _call("gptst_cap_rec_fwd", _p(c), _p(v), _p(rec), BT, N, C, HS, nbytes=_nb(c, v, rec)), stream)
     return rec
 
 
@@ -417,7 +467,14 @@ def cap_rec_bwd(drec, c, v, reduce_nodes=None):
     C = v.shape[-1]
     dc1 = torch.empty_like(c)
     dv = torch.empty_like(v)
+
     def stream():
+        if capflow_ok(HS, C):            # dc1 = drec . v^T and the partials of dv = sum_n c drec in ONE pass over drec
+            npart = _C.lib().value("gptst_capflow_nparts", N)
+            part = torch.empty(BT, npart, HS, C, device=c.device, dtype=torch.float32)
+            _call("gptst_capflow_route", _p(drec), _p(v), None, _p(dc1), None, _p(c), None, _p(part), BT, HS, N, C)
+            _capflow_post(part, npart, HS, None, dv, 2, BT, HS, C, reduce_nodes)
+            return
         _call("gptst_capbig_rec_bwd_dc", _p(drec), _p(v), _p(dc1), BT, HS, N, C)
         _capbig_type1(c, drec, dv, BT, HS, N, C, reduce_nodes)                       # dv = sum_n c drec: a sum over nodes
     if reduce_nodes is not None:
@@ -428,17 +485,23 @@ def cap_rec_bwd(drec, c, v, reduce_nodes=None):
     return dc1, dv
 
 
-def cap_route_bwd(X, Wp, bp, c, dc1, dS):
+def cap_route_bwd(X, Wp, bp, c, dc1, dS, Y=None):
+    """Y: the pre-squash capsules X Wp^T + bp when the forward kept them (streaming path); recomputed otherwise."""
     _chk(X, Wp, bp, c, dc1, dS)
     B, T, N, C = X.shape
     HS = c.shape[1]
     dY = torch.empty(B * T * N, C, device=X.device, dtype=torch.float32)
     dlogit = torch.empty_like(c)
+
     def stream():
-        Y = _capbig_linear(X, Wp, bp)
-        _call("gptst_capbig_route_bwd_rows", _p(Y), _p(c), _p(dc1), _p(dS), _p(dY), _p(dlogit), B * T, HS, N, C)
-    _lds_or_stream(lambda: _call("gptst_cap_route_bwd", _p(X), _p(Wp), _p(bp), _p(c), _p(dc1), _p(dS), _p(dY), _p(dlogit), B * T, N, C, HS,
-                                 nbytes=_nb(X, Wp, bp, c, dc1, dS, dY, dlogit)), stream)
+        Yv = Y if Y is not None else _capbig_linear(X, Wp, bp)
+        name = "gptst_capflow_route_bwd" if capflow_ok(HS, C) else "gptst_capbig_route_bwd_rows"
+        _call(name, _p(Yv), _p(c), _p(dc1), _p(dS), _p(dY), _p(dlogit), B * T, HS, N, C)
+    if Y is not None:
+        stream()
+    else:
+        _lds_or_stream(lambda: _call("gptst_cap_route_bwd", _p(X), _p(Wp), _p(bp), _p(c), _p(dc1), _p(dS), _p(dY), _p(dlogit), B * T, N, C, HS,
+                                     nbytes=_nb(X, Wp, bp, c, dc1, dS, dY, dlogit)), stream)
     return dY, dlogit
 
 

@@ -170,6 +170,28 @@ int gptst_capbig_rec_bwd_dc(const float* drec, const float* v, float* dc1, int B
 int gptst_capbig_route_bwd_rows(const float* Y, const float* c, const float* dc1, const float* dS, float* dY, float* dlogit, int BT,
                                 int HS, int N, int C, void* stream);
 
+/* ---- streaming cap, second generation (capflow.hip): one fused MFMA pass over the capsule matrix per routing iteration ----
+ * Same algebra as above for HS <= 16, C in {64,128} (gptst_capflow_supported); sums over nodes leave the kernels as partials per
+ * gptst_capflow_nparts(N) node chunks and are folded in index order by gptst_capflow_post (no atomics):
+ * squash:  P = squash(Y) row-wise; c0 = softmax_h(dadj); part (BT,nparts,HS+1,C) = [c0^T P ; colsum P]  (colsum = the first routing
+ *          iteration, whose coefficients are uniform);
+ * route:   L = V ? rows . V^T : 0;  b = L + bl_in;  bl_out <- b;  cs = c_in ? c_in : softmax_h(b + l0);  c_out <- cs;
+ *          part (BT,nparts,HS,C) = cs^T . rows   (NULL = operand absent).  Routing iteration: (P, v, b);  last step: (P, v, b, l0 = dadj,
+ *          c_out = c);  backward of rec = c^T v: rows = drec, V = v, bl_out = dc1, c_in = c, fold of part = dv;
+ * post:    part (BT,nparts,prow,C) -> mode 0 (prow = HS+1): V0 = squash(S0), Vout = squash(V0 (.) colsum/HS) (if given);
+ *          mode 1: Vout = squash(V0 (.) S);  mode 2: Vout = S;  mode 3: Vout (BT,prow,C) = plain fold (a node-sharded run all-reduces
+ *          it and calls post again with nparts = 1);
+ * rec_fwd: rec (BT*N,C) = c^T v;  route_bwd: as gptst_capbig_route_bwd_rows. */
+int gptst_capflow_supported(int HS, int C);
+int gptst_capflow_nparts(int N);
+int gptst_capflow_squash(const float* Y, const float* dadj, float* P, float* part, int BT, int HS, int N, int C, void* stream);
+int gptst_capflow_route(const float* rows, const float* V, const float* bl_in, float* bl_out, const float* l0, const float* c_in,
+                        float* c_out, float* part, int BT, int HS, int N, int C, void* stream);
+int gptst_capflow_post(const float* part, int nparts, int prow, float* V0, float* Vout, int mode, int BT, int HS, int C, void* stream);
+int gptst_capflow_rec_fwd(const float* c, const float* v, float* rec, int BT, int HS, int N, int C, void* stream);
+int gptst_capflow_route_bwd(const float* Y, const float* c, const float* dc1, const float* dS, float* dY, float* dlogit, int BT,
+                            int HS, int N, int C, void* stream);
+
 /* ---- evaluation metrics of Trainer.test (metrics.hip), reference model/BasicTrainer.py:209-248 + lib/metrics.py:11-18,38-43,52-86 ----
  * Accumulates, over one batch, the sums the per-horizon MAE / RMSE / MAPE / CORR need (doubles; caller zeroes them once per evaluation):
  * sums_t (T,5) = [n1, sum|e|, sum e^2, n2, sum|e/y|], sums_tn (T,N,6) = [K, sum p, sum y, sum p^2, sum y^2, sum p y];

@@ -199,12 +199,16 @@ def test_cap_layer(B, N, d, ds, HS, HT, R):
         close(a.grad, b.grad, what="cap d" + nm)
 
 
+@pytest.mark.parametrize("flow", [True, False], ids=["capflow", "capbig"])
 @pytest.mark.parametrize("B,N,C,d,ds,HS,HT,R,force", [(2, 20, 64, 8, 4, 5, 6, 3, True), (1, 170, 64, 16, 4, 10, 16, 2, True),
                                                        (1, 600, 64, 8, 4, 10, 16, 2, False), (1, 300, 128, 8, 4, 10, 8, 2, False),
-                                                       (1, 37, 128, 4, 3, 40, 5, 1, True)])
-def test_cap_layer_streaming_path(B, N, C, d, ds, HS, HT, R, force):
-    """cap through the capbig kernels (cap_big.hip): taken when the (b,t) capsule matrix does not fit LDS (N = 600 at C = 64,
-    N = 300 at C = 128 — BASELINE config 5 territory) or forced, vs the oracle; the LDS path is covered by test_cap_layer."""
+                                                       (1, 37, 128, 4, 3, 40, 5, 1, True), (2, 37, 64, 4, 3, 7, 5, 1, True),
+                                                       (1, 530, 128, 4, 3, 16, 5, 0, True), (1, 1030, 64, 4, 3, 3, 5, 4, False)])
+def test_cap_layer_streaming_path(B, N, C, d, ds, HS, HT, R, force, flow):
+    """cap through the streaming kernels — the fused MFMA passes of capflow.hip (HS <= 16) or the first-generation cap_big.hip kernels:
+    taken when the (b,t) capsule matrix does not fit LDS (N = 600 at C = 64, N = 300 at C = 128 — BASELINE config 5 territory) or
+    forced, vs the oracle; the LDS path is covered by test_cap_layer.  Ragged node counts (N % 4 != 0, N % 16 != 0, several 256-node
+    chunks) and R = 0 .. 4 routing iterations included."""
     from gptst_amd import layers, ops
     dev = _dev()
     T = 12
@@ -217,12 +221,12 @@ def test_cap_layer_streaming_path(B, N, C, d, ds, HS, HT, R, force):
     ref, cref, dynref, aux = O.cap(sd, "c.", cpu[0], cpu[1], cpu[2], cpu[3], R, materialize_5d=False, return_aux=True)
     (ref * go).sum().backward()
     gpu = [t.to(dev).requires_grad_() for t in ts]
-    ops.FORCE_CAP_BIG = force
+    ops.FORCE_CAP_BIG, ops.CAP_FLOW = force, flow
     try:
         out, c, dyn = layers.cap(*gpu, tmpl.to(dev), R)
         (out * go.to(dev)).sum().backward()
     finally:
-        ops.FORCE_CAP_BIG = False
+        ops.FORCE_CAP_BIG, ops.CAP_FLOW = False, True
     close(c, cref.squeeze(-1), what="cap c")
     close(out, ref, what="cap out")
     names = ["x", "node_emb", "time_eb_spg", "teb", "t_adj", "adj", "wspa", "bspa", "lnp_w", "lnp_b"]
