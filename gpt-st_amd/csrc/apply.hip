@@ -19,7 +19,8 @@ extern "C" int gptst_ap_ts(long long* out) { return (int)hipMemcpyFromSymbol(out
 static constexpr int g_ap_dbg = 0;
 #endif
 // launch-geometry knobs of gptst_tune: thread-local (ranks emulated by threads must not see each other's experiments)
-thread_local int g_apply_tpw = 0;                      // gptst_tune(4, n) forces tiles per wave of apply64
+thread_local int g_apply_tpw = 0;                      // gptst_tune(4, n) forces tiles per wave of apply64 / apply128
+thread_local int g_apply128_v1 = 0;                    // gptst_tune(8, 1) selects the first-generation apply_kernel for C = 128
 
 enum { PRO_NONE = 0, PRO_DPRE = 1 };          // PRO_DPRE: a = A * lrelu'(A2)   (A = dOut, A2 = layer output)
 enum { EPI_PLAIN = 0, EPI_RES_LRELU = 1, EPI_ADD_DPRE = 2, EPI_LRELU = 3 };   // 1: lrelu(acc+bias+resid)  2: acc + resid*lrelu'(resid2)  3: lrelu(acc+bias)
@@ -637,6 +638,248 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const float* __restrict__ A,
     }
 }
 
+// C = 128 apply, second generation (apply_kernel<128> above keeps the weight AND a 32-row A tile per wave in LDS: 132 KB, one workgroup of
+// 4 waves per CU, i.e. one wave per SIMD with load, MFMA and store phases strictly serial — 25-42 % of the fp32 MFMA roof, which bounds
+// this shape).  Here only the group's weight lives in LDS (64 KB, staged once per workgroup of 8 waves, two workgroups per CU = 4 waves per
+// SIMD whose phases overlap); a wave walks 16-row tiles with the A fragments straight from global memory (row j, channels 16q+4kk..+3, as
+// apply64) and reads the B fragments of k-row 16q+4kk+e as two float4 (channels 4j..+3 and 64+4j..+3) from the row-major LDS image —
+// conflict-free for ds_read_b128 without padding (every 16-lane service group covers the 16 slots of a 256-byte bank row).  Accumulator
+// tile ct, column j stands for channel 4j+ct (ct < 4) / 64+4j+ct-4, so a lane owns two float4 of output rows 4kk+r and the epilogue
+// (bias / residual / LReLU / dPre) runs from registers with 256-byte coalesced loads and stores.
+#define AP128_NW 8
+template <int PRO, int EPI, bool CS>
+__global__ __launch_bounds__(64 * AP128_NW, 4) void apply128_kernel(const float* __restrict__ A, const float* __restrict__ A2,
+                                                                    const float* __restrict__ W, long w_gstride, int transw,
+                                                                    const float* __restrict__ bias, const float* __restrict__ resid,
+                                                                    const float* __restrict__ resid2, float* __restrict__ out,
+                                                                    float* __restrict__ colsum, RowMap rm, int tiles_per_wave) {
+    constexpr int C = 128, Q = C / 16;
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    float* Wl = smem;                                   // [C][C]
+    float* csl = smem + C * C;                          // [AP128_NW][C]
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int j = lane & 15, kk = lane >> 4;
+    const int g = blockIdx.x;
+    const int ntiles = (rm.M + 15) / 16;
+    const int t0 = (blockIdx.y * AP128_NW + wave) * tiles_per_wave, t1 = min(ntiles, t0 + tiles_per_wave);
+    float4 bias0 = f4zero(), bias1 = f4zero();
+    if (bias != nullptr) { bias0 = ld4(bias + (size_t)g * C + 4 * j); bias1 = ld4(bias + (size_t)g * C + 64 + 4 * j); }
+    float4 a[Q], on[Q];
+    auto fetch = [&](int t) {
+        const int m = min(t * 16 + j, rm.M - 1);
+        const size_t off = ((size_t)g * rm.rs_g + (size_t)m * rm.rs_m) * C + 4 * kk;
+#pragma unroll
+        for (int q = 0; q < Q; ++q) {
+            a[q] = ld4(A + off + 16 * q);
+            if (PRO == PRO_DPRE) on[q] = ld4(A2 + off + 16 * q);
+        }
+    };
+    if (t0 < t1) fetch(t0);                              // in flight while the weight is staged
+    load_w_lds<C, 64 * AP128_NW>(Wl, W + (size_t)g * w_gstride, transw, threadIdx.x);
+    if (CS) { csl[wave * C + lane] = 0.f; csl[wave * C + 64 + lane] = 0.f; }    // column sums accumulate in the wave's own LDS row (no registers held across the MFMAs)
+    __syncthreads();
+    const float* wb = Wl + 4 * kk * C + 4 * j;
+    for (int t = t0; t < t1; ++t) {
+        const bool rowok = t * 16 + j < rm.M;
+#pragma unroll
+        for (int q = 0; q < Q; ++q) {
+            float4 v = a[q];
+            if (PRO == PRO_DPRE) {
+                v.x *= lrelu_grad_from_out(on[q].x); v.y *= lrelu_grad_from_out(on[q].y);
+                v.z *= lrelu_grad_from_out(on[q].z); v.w *= lrelu_grad_from_out(on[q].w);
+            }
+            if (!rowok) v = f4zero();
+            a[q] = v;
+            if (CS) {                                  // column sums of the tile: 16-lane row reduction, lane j = 0 adds it to the wave's LDS row
+                float4 c = make_float4(group_sum<16>(v.x), group_sum<16>(v.y), group_sum<16>(v.z), group_sum<16>(v.w));
+                if (j == 0) { float* p = csl + wave * C + 16 * q + 4 * kk; st4(p, f4add(ld4(p), c)); }
+            }
+        }
+        SB();
+        f32x4 acc[8];
+#pragma unroll
+        for (int ct = 0; ct < 8; ++ct) acc[ct] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int q = 0; q < Q; ++q) {                 // one k-block of 16 in batches of EB k-rows: B fragments, fence, MFMAs, fence (bounds the
+            constexpr int EB = 4;                     // LDS prefetch depth: the kernel has to fit 128 VGPRs for 4 waves per SIMD)
+            const float av[4] = {a[q].x, a[q].y, a[q].z, a[q].w};
+#pragma unroll
+            for (int e0 = 0; e0 < 4; e0 += EB) {
+                float4 b0[EB], b1[EB];
+#pragma unroll
+                for (int e = 0; e < EB; ++e) { b0[e] = ld4(wb + (16 * q + e0 + e) * C); b1[e] = ld4(wb + (16 * q + e0 + e) * C + 64); }
+                SB();
+#pragma unroll
+                for (int e = 0; e < EB; ++e) {
+                    acc[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[e0 + e], b0[e].x, acc[0], 0, 0, 0);
+                    acc[1] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[e0 + e], b0[e].y, acc[1], 0, 0, 0);
+                    acc[2] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[e0 + e], b0[e].z, acc[2], 0, 0, 0);
+                    acc[3] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[e0 + e], b0[e].w, acc[3], 0, 0, 0);
+                    acc[4] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[e0 + e], b1[e].x, acc[4], 0, 0, 0);
+                    acc[5] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[e0 + e], b1[e].y, acc[5], 0, 0, 0);
+                    acc[6] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[e0 + e], b1[e].z, acc[6], 0, 0, 0);
+                    acc[7] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[e0 + e], b1[e].w, acc[7], 0, 0, 0);
+                }
+                SB();
+            }
+        }
+        // the epilogue operands and the next tile's A fragments are requested once the A registers are free
+        float4 rv[4][2], rv2[4][2];
+        size_t orow[4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int m = min(t * 16 + kk * 4 + r, rm.M - 1);
+            orow[r] = ((size_t)g * rm.rs_g + (size_t)m * rm.rs_m) * C + 4 * j;
+            if (EPI == EPI_RES_LRELU || EPI == EPI_ADD_DPRE) { rv[r][0] = ld4(resid + orow[r]); rv[r][1] = ld4(resid + orow[r] + 64); }
+            if (EPI == EPI_ADD_DPRE) { rv2[r][0] = ld4(resid2 + orow[r]); rv2[r][1] = ld4(resid2 + orow[r] + 64); }
+        }
+        constexpr bool EARLY = (EPI == EPI_PLAIN || EPI == EPI_LRELU) && PRO == PRO_NONE;   // no residual / dPre operands: room for the next tile's fragments now
+        if (EARLY && t + 1 < t1) fetch(t + 1);
+        SB();
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            if (t * 16 + kk * 4 + r < rm.M) {
+#pragma unroll
+                for (int hf = 0; hf < 2; ++hf) {
+                    float4 y = f4add(make_float4(acc[4 * hf + 0][r], acc[4 * hf + 1][r], acc[4 * hf + 2][r], acc[4 * hf + 3][r]), hf ? bias1 : bias0);
+                    if (EPI == EPI_RES_LRELU) {
+                        y = f4add(y, rv[r][hf]);
+                        y.x = lrelu(y.x); y.y = lrelu(y.y); y.z = lrelu(y.z); y.w = lrelu(y.w);
+                    }
+                    if (EPI == EPI_LRELU) { y.x = lrelu(y.x); y.y = lrelu(y.y); y.z = lrelu(y.z); y.w = lrelu(y.w); }
+                    if (EPI == EPI_ADD_DPRE) {
+                        const float4 d = rv[r][hf], o = rv2[r][hf];
+                        y.x = fmaf(d.x, lrelu_grad_from_out(o.x), y.x); y.y = fmaf(d.y, lrelu_grad_from_out(o.y), y.y);
+                        y.z = fmaf(d.z, lrelu_grad_from_out(o.z), y.z); y.w = fmaf(d.w, lrelu_grad_from_out(o.w), y.w);
+                    }
+                    st4(out + orow[r] + 64 * hf, y);
+                }
+            }
+        }
+        SB();
+        if (!EARLY && t + 1 < t1) fetch(t + 1);
+    }
+    if (CS) {                         // fold the waves' column sums in fixed order: this workgroup's partial [blockIdx.y][g][:]
+        __syncthreads();
+        if (threadIdx.x < C) {
+            float s = 0.f;
+#pragma unroll
+            for (int w = 0; w < AP128_NW; ++w) s += csl[w * C + threadIdx.x];
+            colsum[((size_t)blockIdx.y * rm.G + g) * C + threadIdx.x] = s;
+        }
+    }
+}
+
+static void apply128_geometry(const RowMap& rm, bool has_colsum, int& tpw, int& gy) {
+    const int ntiles = (rm.M + 15) / 16;
+    tpw = rm.G == 1 ? 8 : 4;                                     // shared weight: fewer re-stagings of W; else >= ~2 workgroups per CU and group
+    if (has_colsum && rm.G == 1) { const int lim = (ntiles + AP128_NW * 128 - 1) / (AP128_NW * 128); if (tpw < lim) tpw = lim; }   // <= 128 partials
+    if (tpw * AP128_NW > ntiles) tpw = (ntiles + AP128_NW - 1) / AP128_NW;
+    if (g_apply_tpw > 0) tpw = g_apply_tpw;
+    if (tpw < 1) tpw = 1;
+    gy = (ntiles + AP128_NW * tpw - 1) / (AP128_NW * tpw);
+}
+
+template <int PRO, int EPI, bool CS>
+static void launch_apply128_t(const float* A, const float* A2, const float* W, long gs, int transw, const float* bias, const float* resid,
+                              const float* resid2, float* out, float* colsum, RowMap rm, hipStream_t st) {
+    constexpr size_t smem = (size_t)(128 * 128 + AP128_NW * 128) * sizeof(float);
+    static bool attr = false;
+    if (!attr) { hipFuncSetAttribute((const void*)apply128_kernel<PRO, EPI, CS>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem); attr = true; }
+    int tpw, gy;
+    apply128_geometry(rm, CS, tpw, gy);
+    hipLaunchKernelGGL((apply128_kernel<PRO, EPI, CS>), dim3(rm.G, gy), dim3(64 * AP128_NW), smem, st, A, A2, W, gs, transw, bias, resid, resid2, out,
+                       colsum, rm, tpw);
+}
+
+static int launch_apply128(const float* A, const float* A2, const float* W, long gs, int transw, const float* bias, const float* resid,
+                           const float* resid2, float* out, float* colsum, RowMap rm, int pro, int epi, hipStream_t st) {
+#define AP128(P, E, S) launch_apply128_t<P, E, S>(A, A2, W, gs, transw, bias, resid, resid2, out, colsum, rm, st)
+    if (colsum != nullptr) {                            // column sums ride on the two variants whose callers want them (bias gradients)
+        if (pro == PRO_DPRE && epi == EPI_PLAIN) AP128(PRO_DPRE, EPI_PLAIN, true);
+        else if (pro == PRO_NONE && epi == EPI_ADD_DPRE) AP128(PRO_NONE, EPI_ADD_DPRE, true);
+        else if (pro == PRO_NONE && epi == EPI_PLAIN) AP128(PRO_NONE, EPI_PLAIN, true);
+        else return GPTST_ESHAPE;
+    }
+    else if (pro == PRO_NONE && epi == EPI_PLAIN) AP128(PRO_NONE, EPI_PLAIN, false);
+    else if (pro == PRO_NONE && epi == EPI_RES_LRELU) AP128(PRO_NONE, EPI_RES_LRELU, false);
+    else if (pro == PRO_DPRE && epi == EPI_PLAIN) AP128(PRO_DPRE, EPI_PLAIN, false);
+    else if (pro == PRO_NONE && epi == EPI_ADD_DPRE) AP128(PRO_NONE, EPI_ADD_DPRE, false);
+    else if (pro == PRO_NONE && epi == EPI_LRELU) AP128(PRO_NONE, EPI_LRELU, false);
+    else return GPTST_EARG;
+#undef AP128
+    GPTST_CHECK_LAUNCH();
+    return GPTST_OK;
+}
+
+// C = 128 weight gradient, second generation (wgrad_kernel<128> above: dword operand loads, one k-step per trip — latency-bound at
+// ~25 % of the fp32 MFMA roof, which is the roof of this shape: 2*128*128 flop per 2*128*4 operand bytes).  Same operand scheme as
+// wgrad64_kernel (16x16x4, lane (j,kk): rows 4s+kk, four consecutive channels of A and of D as one float4 each, accumulator tile
+// (ca, cb) <-> channels 4i+ca / 4j+cb), with the 128 x 128 output split into four 64 x 64 quadrants, one per wave: every wave walks
+// ALL rows of the split (no fold through LDS), 16 MFMAs per pair of float4 loads, and the quadrant is stored straight from the
+// accumulators as coalesced float4 rows.  Row splits (gridDim.y) give the partial sums the pool jobs fold.
+template <int PRO, int U>
+__global__ __launch_bounds__(256, 2) void wgrad128_kernel(const float* __restrict__ A, const float* __restrict__ D,
+                                                          const float* __restrict__ D2, float* __restrict__ dW, RowMap rm,
+                                                          int rows_per_split, int ostride, int csa) {
+    constexpr int C = 128;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int j = lane & 15, kk = lane >> 4, wa = wave >> 1, wb = wave & 1;
+    const int g = blockIdx.x, sp = blockIdx.y;
+    const int mbeg = sp * rows_per_split, mend = min(rm.M, mbeg + rows_per_split);
+    f32x4 acc[4][4];
+#pragma unroll
+    for (int ca = 0; ca < 4; ++ca)
+#pragma unroll
+        for (int cb = 0; cb < 4; ++cb) acc[ca][cb] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    float4 sa = f4zero();
+    const float* Ab = A + (size_t)g * rm.rs_g * C + 64 * wa + 4 * j;
+    const float* Db = D + (size_t)g * rm.rs_g * C + 64 * wb + 4 * j;
+    const float* Yb = D2 + (size_t)g * rm.rs_g * C + 64 * wb + 4 * j;
+    for (int m0 = mbeg; m0 < mend; m0 += 4 * U) {
+        float4 a[U], d[U], y[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const size_t off = (size_t)min(m0 + 4 * u + kk, mend - 1) * rm.rs_m * C;      // clamped: out-of-range rows are zeroed below
+            a[u] = ld4(Ab + off); d[u] = ld4(Db + off);
+            if (PRO == PRO_DPRE) y[u] = ld4(Yb + off);
+        }
+        SB();
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const bool ok = m0 + 4 * u + kk < mend;
+            if (!ok) a[u] = f4zero();
+            if (PRO == PRO_DPRE) {
+                d[u].x *= lrelu_grad_from_out(y[u].x); d[u].y *= lrelu_grad_from_out(y[u].y);
+                d[u].z *= lrelu_grad_from_out(y[u].z); d[u].w *= lrelu_grad_from_out(y[u].w);
+            }
+            if (csa == 2) { if (ok) sa = f4add(sa, d[u]); }
+            else sa = f4add(sa, a[u]);
+            const float av[4] = {a[u].x, a[u].y, a[u].z, a[u].w}, dv[4] = {d[u].x, d[u].y, d[u].z, d[u].w};
+#pragma unroll
+            for (int ca = 0; ca < 4; ++ca)
+#pragma unroll
+                for (int cb = 0; cb < 4; ++cb) acc[ca][cb] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[ca], dv[cb], acc[ca][cb], 0, 0, 0);
+        }
+    }
+    // D reg r of tile (ca, cb): dW row 64wa + 4*(kk*4 + r) + ca, columns 64wb + 4j + cb
+    float* o = dW + ((size_t)sp * rm.G + g) * (size_t)ostride;
+#pragma unroll
+    for (int ca = 0; ca < 4; ++ca)
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+            st4(o + (size_t)(64 * wa + 4 * (kk * 4 + r) + ca) * C + 64 * wb + 4 * j,
+                make_float4(acc[ca][0][r], acc[ca][1][r], acc[ca][2][r], acc[ca][3][r]));
+    if (csa) {                                   // column sums: of A (which = 1) by the waves of column half wb = 0, of pro(D) by wa = 0
+        sa.x += __shfl_xor(sa.x, 16, 64); sa.y += __shfl_xor(sa.y, 16, 64); sa.z += __shfl_xor(sa.z, 16, 64); sa.w += __shfl_xor(sa.w, 16, 64);
+        sa.x += __shfl_xor(sa.x, 32, 64); sa.y += __shfl_xor(sa.y, 32, 64); sa.z += __shfl_xor(sa.z, 32, 64); sa.w += __shfl_xor(sa.w, 32, 64);
+        if (kk == 0) {
+            if (csa == 2 && wa == 0) st4(o + C * C + 64 * wb + 4 * j, sa);
+            if (csa != 2 && wb == 0) st4(o + C * C + 64 * wa + 4 * j, sa);
+        }
+    }
+}
+
 static int apply_v1_gy(const RowMap& rm, bool has_colsum) {
     const int ntiles = (rm.M + 31) / 32;
     int gy = (ntiles + 3) / 4;
@@ -681,6 +924,7 @@ static void raise_smem_limits() {
 extern "C" int gptst_apply_nsplit(int mode, int BT, int N, int C) {
     RowMap rm = make_rowmap(mode, BT, N);
     if (C == 64 && !g_apply_v1) { int tpw, gy; apply64_geometry(rm, true, tpw, gy); return gy; }
+    if (C == 128 && !g_apply128_v1) { int tpw, gy; apply128_geometry(rm, true, tpw, gy); return gy; }
     return apply_v1_gy(rm, true);
 }
 
@@ -697,6 +941,7 @@ extern "C" int gptst_apply(const float* A, const float* A2, const float* W, int 
     hipStream_t st = (hipStream_t)stream;
     if (C == 64 && !g_apply_v1) return launch_apply64(A, A2, W, gs, transw, bias, resid, resid2, out, colsum, rm, pro, epi, st);
     if (C == 64) return launch_apply<64>(A, A2, W, gs, transw, bias, resid, resid2, out, colsum, rm, pro, epi, st);
+    if (C == 128 && !g_apply128_v1) return launch_apply128(A, A2, W, gs, transw, bias, resid, resid2, out, colsum, rm, pro, epi, st);
     if (C == 128) return launch_apply<128>(A, A2, W, gs, transw, bias, resid, resid2, out, colsum, rm, pro, epi, st);
     return GPTST_ESHAPE;
 }
@@ -704,11 +949,17 @@ extern "C" int gptst_apply(const float* A, const float* A2, const float* W, int 
 // dW has room for nsplit * G matrices; returns nsplit through *nsplit_out (consumers sum the splits).
 thread_local int g_wgrad_ns0_override = 0;
 thread_local int g_wgrad_ns_override = 0;                           // experiments: gptst_tune(2, ns) forces the NODE-mode split
-extern "C" int gptst_wgrad_nsplit(int mode, int BT, int N) {
+thread_local int g_wgrad_v1 = 0;                                    // experiments: gptst_tune(7, 1) selects the first-generation wgrad_kernel for C = 128
+extern "C" int gptst_wgrad_nsplit(int mode, int BT, int N, int C) {
     RowMap rm = make_rowmap(mode, BT, N);
     if (mode == 2) return (rm.M + 255) / 256;          // shared weight: 256-row chunks
     if (mode == 1 && g_wgrad_ns_override > 0) return g_wgrad_ns_override;
     if (mode == 0 && g_wgrad_ns0_override > 0) return g_wgrad_ns0_override;
+    if (C == 128 && !g_wgrad_v1) {                     // MFMA-bound: >= ~4 equal workgroups per CU, splits of >= 128 rows
+        int want = (1024 + rm.G - 1) / rm.G, maxs = (rm.M + 127) / 128;
+        if (want > maxs) want = maxs;
+        return want < 1 ? 1 : want;
+    }
     if (rm.G >= 256) return 1;
     int want = 512 / rm.G;                             // largest split that still fits ONE round of 2 workgroups per CU
     if (want < 1) want = 1;                            // (G = 170: 3 x 170 = 510 workgroups 12.8 us; 4 x 170 = 680 -> 16.4 us)
@@ -729,7 +980,7 @@ extern "C" int gptst_wgrad(const float* A, const float* D, const float* D2, floa
 // gradient dW = A^T pro(D), e.g. hyperTem's b_bt).  C = 64.
 extern "C" int gptst_wgrad_colsum(const float* A, const float* D, const float* D2, float* dW, int mode, int pro, int which, int BT, int N,
                                   int C, void* stream) {
-    if (C != 64) return GPTST_ESHAPE;
+    if (C != 64 && C != 128) return GPTST_ESHAPE;
     if (which != 1 && which != 2) return GPTST_EARG;
     return wgrad_impl(A, D, D2, dW, mode, pro, BT, N, C, which, stream);
 }
@@ -739,7 +990,7 @@ static int wgrad_impl(const float* A, const float* D, const float* D2, float* dW
     if (!A || !D || !dW) return GPTST_EARG;
     if (pro == PRO_DPRE && !D2) return GPTST_EARG;
     RowMap rm = make_rowmap(mode, BT, N);
-    const int ns = gptst_wgrad_nsplit(mode, BT, N);
+    const int ns = gptst_wgrad_nsplit(mode, BT, N, C);
     int rps = (rm.M + ns - 1) / ns;
     rps = (rps + 1) & ~1;                               // even, so a k-step never straddles a split
     dim3 grid(rm.G, ns), block(256);
@@ -752,7 +1003,14 @@ static int wgrad_impl(const float* A, const float* D, const float* D2, float* dW
         if (pro == PRO_DPRE) { if (u6) WG64(PRO_DPRE, 6); else WG64(PRO_DPRE, 4); }
         else { if (u6) WG64(PRO_NONE, 6); else WG64(PRO_NONE, 4); }
 #undef WG64
+    } else if (C == 128 && !g_wgrad_v1) {
+        rps = (rps + 3) & ~3;                           // whole k-steps of 4 rows per split
+        if ((long)rps * (ns - 1) >= rm.M) return GPTST_EARG;
+        const int os = csa ? C * C + C : C * C;
+        if (pro == PRO_DPRE) hipLaunchKernelGGL((wgrad128_kernel<PRO_DPRE, 4>), grid, block, 0, st, A, D, D2, dW, rm, rps, os, csa);
+        else hipLaunchKernelGGL((wgrad128_kernel<PRO_NONE, 4>), grid, block, 0, st, A, D, D2 ? D2 : D, dW, rm, rps, os, csa);
     } else if (C == 128) {
+        if (csa) return GPTST_ESHAPE;
         if (pro == PRO_DPRE) hipLaunchKernelGGL((wgrad_kernel<128, PRO_DPRE>), grid, block, 0, st, A, D, D2, dW, rm, rps);
         else hipLaunchKernelGGL((wgrad_kernel<128, PRO_NONE>), grid, block, 0, st, A, D, D2, dW, rm, rps);
     } else return GPTST_ESHAPE;

@@ -325,6 +325,8 @@ extern thread_local int g_wgrad_ns0_override;
 extern thread_local int g_apply_v1;
 extern thread_local int g_apply_tpw;
 extern thread_local int g_tl_nb;
+extern thread_local int g_wgrad_v1;
+extern thread_local int g_apply128_v1;
 extern "C" int gptst_tune(int id, int value) {
     if (id == 1 && value > 0 && value <= PG_MAXROWS) g_pg_rows = value;
     if (id == 6 && value > 0) g_tl_nb = value;
@@ -332,6 +334,8 @@ extern "C" int gptst_tune(int id, int value) {
     if (id == 5) g_wgrad_ns0_override = value;
     if (id == 3) g_apply_v1 = value;
     if (id == 4) g_apply_tpw = value;
+    if (id == 7) g_wgrad_v1 = value;
+    if (id == 8) g_apply128_v1 = value;
     return GPTST_OK;
 }
 

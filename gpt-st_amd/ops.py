@@ -225,15 +225,15 @@ def linear_bwd(dY, X, Wp, dOut, out):
     return dX, dWp, dbp, ns
 
 
-def wgrad_nsplit(mode, BT, N):
-    return _C.lib().value("gptst_wgrad_nsplit", mode, BT, N)
+def wgrad_nsplit(mode, BT, N, C=64):
+    return _C.lib().value("gptst_wgrad_nsplit", mode, BT, N, C)
 
 
 def wgrad(A, D, mode, BT, N, D2=None, pro=PRO_NONE, colsum_a=False, colsum_d=False):
     """-> (dW (nsplit*G, C, C), nsplit);  colsum_a / colsum_d: rows become [dW (C*C) | column sums of A / of pro(D) (C)]."""
     _chk(A, D, D2)
     C = A.shape[-1]
-    ns = wgrad_nsplit(mode, BT, N)
+    ns = wgrad_nsplit(mode, BT, N, C)
     G = BT if mode == MODE_TIME else (N if mode == MODE_NODE else 1)
     if colsum_a or colsum_d:
         dW = torch.empty(ns * G, C * C + C, device=A.device, dtype=torch.float32)

@@ -77,9 +77,9 @@ int gptst_apply_nsplit(int mode, int BT, int N, int C);
 int gptst_apply(const float* A, const float* A2, const float* W, int w_per_group, int transw, const float* bias,
                 const float* resid, const float* resid2, float* out, float* colsum, int mode, int pro, int epi, int BT,
                 int N, int C, void* stream);
-/* dW[s*G + g] = sum_{m in split s} A[g,m,:]^T pro(D)[g,m,:];  nsplit = gptst_wgrad_nsplit(mode,BT,N) partial sums
+/* dW[s*G + g] = sum_{m in split s} A[g,m,:]^T pro(D)[g,m,:];  nsplit = gptst_wgrad_nsplit(mode,BT,N,C) partial sums
  * that the consumer (gptst_poolgen_bwd_*) adds up.  dW must hold nsplit*G*C*C floats. */
-int gptst_wgrad_nsplit(int mode, int BT, int N);
+int gptst_wgrad_nsplit(int mode, int BT, int N, int C);
 int gptst_wgrad(const float* A, const float* D, const float* D2, float* dW, int mode, int pro, int BT, int N, int C,
                 void* stream);
 /* same, with column sums appended to every split (rows of C*C + C floats): which = 1: [dW | sum_m A[m,:]] (weight AND bias gradient
