@@ -952,6 +952,10 @@ thread_local int g_wgrad_ns_override = 0;                           // experimen
 thread_local int g_wgrad_v1 = 0;                                    // experiments: gptst_tune(7, 1) selects the first-generation wgrad_kernel for C = 128
 extern "C" int gptst_wgrad_nsplit(int mode, int BT, int N, int C) {
     RowMap rm = make_rowmap(mode, BT, N);
+    if (mode == 2 && C == 128 && !g_wgrad_v1) {        // shared weight, 64 KB partials: <= 1024 of them (N = 4096: 1536-row chunks, 67 MB instead of 400 MB)
+        const int ns = (rm.M + 255) / 256;
+        return ns < 1024 ? ns : 1024;
+    }
     if (mode == 2) return (rm.M + 255) / 256;          // shared weight: 256-row chunks
     if (mode == 1 && g_wgrad_ns_override > 0) return g_wgrad_ns_override;
     if (mode == 0 && g_wgrad_ns0_override > 0) return g_wgrad_ns0_override;
@@ -1004,8 +1008,7 @@ static int wgrad_impl(const float* A, const float* D, const float* D2, float* dW
         else { if (u6) WG64(PRO_NONE, 6); else WG64(PRO_NONE, 4); }
 #undef WG64
     } else if (C == 128 && !g_wgrad_v1) {
-        rps = (rps + 3) & ~3;                           // whole k-steps of 4 rows per split
-        if ((long)rps * (ns - 1) >= rm.M) return GPTST_EARG;
+        rps = (rps + 3) & ~3;                           // whole k-steps of 4 rows per split (a trailing split may be empty: it stores zeros)
         const int os = csa ? C * C + C : C * C;
         if (pro == PRO_DPRE) hipLaunchKernelGGL((wgrad128_kernel<PRO_DPRE, 4>), grid, block, 0, st, A, D, D2, dW, rm, rps, os, csa);
         else hipLaunchKernelGGL((wgrad128_kernel<PRO_NONE, 4>), grid, block, 0, st, A, D, D2 ? D2 : D, dW, rm, rps, os, csa);

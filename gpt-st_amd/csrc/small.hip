@@ -95,7 +95,14 @@ __global__ __launch_bounds__(256) void rowdot_kernel(const float* __restrict__ X
 // Two launches: (1) RO_NB workgroups reduce their row chunk to a partial [J*C | C | J] in scratch (4 independent rows in flight per
 // thread, slots folded through LDS), (2) a fold kernel sums the RO_NB partials per output and accumulates into the gradients.
 // (The single-launch version needed one atomic per output and workgroup: 160..510 same-address atomics = 45..110 us.)
-#define RO_NB 256
+#define RO_NB 256                         // row chunks (= partials) up to 256 K rows ...
+#define RO_NB_MAX 2048                    // ... then chunks of 1024 rows, at most this many (N = 4096: 1.5 M rows)
+static int ro_rpb(int rows) {
+    int nb = RO_NB;
+    if (rows > RO_NB * 1024) { nb = (rows + 1023) / 1024; if (nb > RO_NB_MAX) nb = RO_NB_MAX; }
+    int rpb = (rows + nb - 1) / nb;
+    return rpb < 16 ? 16 : rpb;
+}
 template <int C>
 __global__ __launch_bounds__(256) void rowouter_part_kernel(const float* __restrict__ a, int lda, const float* __restrict__ mask, float fill,
                                                             const float* __restrict__ X, float* __restrict__ part, int rows, int J,
@@ -178,7 +185,7 @@ __global__ __launch_bounds__(256) void rowouter_fold_kernel(const float* __restr
     }
 }
 
-extern "C" int gptst_rowouter_ws_floats(int J, int C) { return RO_NB * (J * C + C + J); }
+extern "C" int gptst_rowouter_ws_floats(int J, int C) { return RO_NB_MAX * (J * C + C + J); }
 
 extern "C" int gptst_lin_in(const float* a, int lda, const float* mask, float fill, const float* W, int wlayout, const float* b,
                             float* Y, int rows, int J, int C, void* stream) {
@@ -205,14 +212,14 @@ extern "C" int gptst_rowdot(const float* X, const float* W, const float* b, floa
 // first stage only: part (gptst_rowouter_nparts(rows), J*C + C + J) row-chunk partials [sum a'^T X | column sums of X | sums of a'];
 // the caller folds them (e.g. one kind-1 pool job per target, next to the other reductions of the step)
 extern "C" int gptst_rowouter_nparts(int rows) {
-    int rpb = (rows + RO_NB - 1) / RO_NB; if (rpb < 16) rpb = 16;
+    const int rpb = ro_rpb(rows);
     return (rows + rpb - 1) / rpb;
 }
 
 extern "C" int gptst_rowouter_part(const float* a, int lda, const float* mask, float fill, const float* X, float* part, int want_asum,
                                    int rows, int J, int C, void* stream) {
     if (!X || !part || J < 0 || J > SM_MAXJ || (J > 0 && !a)) return GPTST_EARG;
-    int rpb = (rows + RO_NB - 1) / RO_NB; if (rpb < 16) rpb = 16;
+    const int rpb = ro_rpb(rows);
     const int nb = (rows + rpb - 1) / rpb;
     hipStream_t st = (hipStream_t)stream;
     if (C == 64) hipLaunchKernelGGL((rowouter_part_kernel<64>), dim3(nb), dim3(256), 0, st, a, lda, mask, fill, X, part, rows, J, rpb, want_asum);
@@ -226,7 +233,7 @@ extern "C" int gptst_rowouter_part(const float* a, int lda, const float* mask, f
 extern "C" int gptst_rowouter(const float* a, int lda, const float* mask, float fill, const float* X, float* out, int olayout,
                               float* csum, float* asum, float* ws, int rows, int J, int C, void* stream) {
     if (!X || !ws || J < 0 || J > SM_MAXJ || (J > 0 && (!a || !out))) return GPTST_EARG;
-    int rpb = (rows + RO_NB - 1) / RO_NB; if (rpb < 16) rpb = 16;
+    const int rpb = ro_rpb(rows);
     const int nb = (rows + rpb - 1) / rpb;
     const int tot = J * C + C + J;
     hipStream_t st = (hipStream_t)stream;

@@ -212,9 +212,9 @@ def hypertem_core_bwd(saved, dout, dG_out, dims):
         dx, _, _ = ops.hypertem_bwd(dout.view(B, T, N, C), out.view(B, T, N, C), x.view(B, T, N, C), G, Wbt, dG=dG_out, want_dbias=False)
         dx = dx.view(-1, C)
     else:
-        dWbt, ns = _wgrad_async(R, dout, MODE_TIME, BT, N, D2=out, pro=PRO_DPRE)
-        dWbt = dWbt.view(ns * BT, C * C)
-        dR, dbias, nsb = ops.apply(dout, Wbt, MODE_TIME, BT, N, A2=out, transw=True, pro=PRO_DPRE, colsum=True)
+        dWb, ns = _wgrad_async(R, dout, MODE_TIME, BT, N, D2=out, pro=PRO_DPRE, colsum_d=True)
+        dWbt, dbias, nsb = dWb[:, :C * C], dWb[:, C * C:], ns
+        dR = ops.apply(dout, Wbt, MODE_TIME, BT, N, A2=out, transw=True, pro=PRO_DPRE)
         dx = ops.tmix(dR.view(B, T, N, C), G, dOut=dout.view(B, T, N, C), Y=out.view(B, T, N, C)).view(-1, C)
         dG_out.zero_()
         ops.tmix_dgraph(dR.view(B, T, N, C), x.view(B, T, N, C), out=dG_out[0])
@@ -242,8 +242,9 @@ def cap_core_bwd(p, g, pfx, saved, dout, dims, HS, HT, red):
         drec, dWn, dbn, ns = ops.apply_wgrad(dout, out, rec, Wn, MODE_NODE, BT, N)
         nsb = ns
     else:
-        drec, dbn, nsb = ops.apply(dout, Wn, MODE_NODE, BT, N, A2=out, transw=True, pro=PRO_DPRE, colsum=True)      # dbn: (nsb*N, C) partials
-        dWn, ns = _wgrad_async(rec, dout, MODE_NODE, BT, N, D2=out, pro=PRO_DPRE)
+        drec = ops.apply(dout, Wn, MODE_NODE, BT, N, A2=out, transw=True, pro=PRO_DPRE)
+        dWb, ns = _wgrad_async(rec, dout, MODE_NODE, BT, N, D2=out, pro=PRO_DPRE, colsum_d=True)                    # rows [dWn | dbn] per split
+        dWn, dbn, nsb = dWb[:, :C * C], dWb[:, C * C:], ns
     dc1, dv = ops.cap_rec_bwd(drec, c, v, reduce_nodes=CTX.NODE_REDUCE)
     dS, ddyn = ops.cap_cross_bwd(dv, s, Rt, Ht, dyn, p[pfx + "mask_template"], B, T, HS, HT)
     dY, dlogit = ops.cap_route_bwd(x.view(B, T, N, C), p[pfx + "ln_p.weight"], p[pfx + "ln_p.bias"], c, dc1, dS, Y=Y)
@@ -255,9 +256,9 @@ def cap_core_bwd(p, g, pfx, saved, dout, dims, HS, HT, red):
         red.jobs.bwd_pool(_ones(dev, ns2), dbp, gb.view(1, C))
     else:
         dx = ops.apply(dY, p[pfx + "ln_p.weight"], MODE_SHARED, BT, N, resid=dout, resid2=out, epi=EPI_ADD_DPRE)
-        dWp, ns2 = ops.wgrad(dY, x, MODE_SHARED, BT, N)
-        red.jobs.bwd_pool(_ones(dev), dWp.view(ns2, C * C), gw.view(1, C * C), nsplit=ns2)
-        ops.rowouter(None, 0, 0, dY, None, 0, csum=gb)
+        dWp, ns2 = ops.wgrad(dY, x, MODE_SHARED, BT, N, colsum_a=True)                     # rows [dWp | colsum dY]
+        red.jobs.bwd_pool(_ones(dev, ns2), dWp[:, :C * C], gw.view(1, C * C))
+        red.jobs.bwd_pool(_ones(dev, ns2), dWp[:, C * C:], gb.view(1, C))
     return dx, (dWn, ns, (dbn, nsb), ddyn, dlogit)
 
 
@@ -286,9 +287,10 @@ def condlin_bwd(saved, dout, emb, wpool, bpool, g_wpool, g_bpool, d_emb, mode, d
         dx, dW, db, ns = ops.apply_wgrad(dout, out, x, Wg, mode, B * T, N)
         nsb = ns
     else:
-        dx, db, nsb = ops.apply(dout, Wg, mode, B * T, N, A2=out, transw=True, pro=PRO_DPRE, colsum=True)
-        dW, ns = ops.wgrad(x, dout, mode, B * T, N, D2=out, pro=PRO_DPRE)
-    dW = dW.view(ns * R, C * C)
+        dx = ops.apply(dout, Wg, mode, B * T, N, A2=out, transw=True, pro=PRO_DPRE)
+        dWb, ns = ops.wgrad(x, dout, mode, B * T, N, D2=out, pro=PRO_DPRE, colsum_d=True)
+        dW, db, nsb = dWb[:, :C * C], dWb[:, C * C:], ns
+    dW = dW if dW.dim() == 2 else dW.view(ns * R, C * C)
     red.jobs.bwd_pool(emb, dW, g_wpool.view(K, C * C), nsplit=ns)
     red.jobs.bwd_pool(emb, db, g_bpool, nsplit=nsb)
     red.jobs.bwd_emb(dW, wpool.view(K, C * C), d_emb, nsplit=ns)
@@ -419,7 +421,7 @@ def sthcn_bwd(p, g, pfx, tidx, sv, dout, dims, red):
         J.bwd_pool(ne, dA_all[i], g[h + "adj"].view(d, Hm * T))
         J.bwd_emb(dA_all[i], p[h + "adj"].view(d, Hm * T), dne)
     for c, (dWn, ns, (dbn, nsb), ddyn, dlogit) in zip(cps, (cp1, cp2)):
-        dW2 = dWn.view(ns * N, CC)
+        dW2 = dWn if dWn.dim() == 2 else dWn.view(ns * N, CC)      # (ns*N, CC), possibly a column window of [dW | db] rows
         J.bwd_pool(nes, dW2, g[c + "weights_spa"].view(d, CC), nsplit=ns)
         J.bwd_pool(nes, dbn, g[c + "bias_spa"], nsplit=nsb)
         J.bwd_emb(dW2, p[c + "weights_spa"].view(d, CC), dnes, nsplit=ns)

@@ -84,7 +84,7 @@ int gptst_wgrad(const float* A, const float* D, const float* D2, float* dW, int 
                 void* stream);
 /* same, with column sums appended to every split (rows of C*C + C floats): which = 1: [dW | sum_m A[m,:]] (weight AND bias gradient
  * of a shared Linear whose output gradient is A); which = 2: [dW | sum_m pro(D)[m,:]] (weight and bias gradient of a generated
- * layer, e.g. hyperTem's W_bt / b_bt — replaces a separate, atomically accumulated bias-gradient pass).  C = 64. */
+ * layer, e.g. hyperTem's W_bt / b_bt — replaces a separate, atomically accumulated bias-gradient pass).  C = 64 or 128. */
 int gptst_wgrad_colsum(const float* A, const float* D, const float* D2, float* dW, int mode, int pro, int which, int BT, int N, int C,
                        void* stream);
 
