@@ -150,7 +150,7 @@ __global__ __launch_bounds__(256) void cf_squash_kernel(const float* __restrict_
 //   cs = c_in ? c_in : softmax_h(b + (l0 ? l0 : 0));   c_out <- cs (if given);   part <- partial of cs^T . rows
 // routing iteration r >= 1:  (P, v, b -> b);   last step:  (P, v, b, l0 = dadj -> c);   backward of rec = c^T v:  (drec, v -> dc1 = bl_out; c_in = c -> dv)
 template <int C>
-__global__ __launch_bounds__(256) void cf_route_kernel(const float* __restrict__ rows, const float* __restrict__ V, const float* __restrict__ bl_in,
+__global__ __launch_bounds__(256, 3) void cf_route_kernel(const float* __restrict__ rows, const float* __restrict__ V, const float* __restrict__ bl_in,
                                                        float* __restrict__ bl_out, const float* __restrict__ l0, const float* __restrict__ c_in,
                                                        float* __restrict__ c_out, float* __restrict__ part, int HS, int N, int nparts) {
     constexpr int Q = C / 16, H2 = C / 64;

@@ -7,6 +7,8 @@
 #include "common.h"
 
 #define SM_MAXJ 64
+#define SM_MAXGRID 8192                     // workgroups of the row-streaming kernels (grid-stride beyond)
+static inline unsigned sm_grid(int rows, int rpb) { const long g = ((long)rows + rpb - 1) / rpb; return (unsigned)(g < SM_MAXGRID ? g : SM_MAXGRID); }
 
 // a'[i,j] = mask ? (mask[i*J+j] != 0 ? a : fill) : a          a has row stride lda
 __device__ __forceinline__ float masked_a(const float* __restrict__ a, const float* __restrict__ mask, float fill, size_t i, int j,
@@ -29,11 +31,14 @@ __global__ __launch_bounds__(256) void lin_in_kernel(const float* __restrict__ a
     }
     __syncthreads();
     const int c4 = threadIdx.x % LPR;
-    const size_t i = (size_t)blockIdx.x * RPB + threadIdx.x / LPR;
-    if (i >= (size_t)rows) return;
-    float4 acc = b ? ld4(b + 4 * c4) : f4zero();
-    for (int j = 0; j < J; ++j) acc = f4fma(masked_a(a, mask, fill, i, j, lda, J), ld4(Ws + j * C + 4 * c4), acc);
-    st4(Y + i * C + 4 * c4, acc);
+    const float4 b4 = b ? ld4(b + 4 * c4) : f4zero();
+    // grid-stride over the rows: the launcher caps the grid (SM_MAXGRID), so that at N = 4096 (1.5 M rows) the weight is staged a few
+    // thousand times instead of once per 8 rows
+    for (size_t i = (size_t)blockIdx.x * RPB + threadIdx.x / LPR; i < (size_t)rows; i += (size_t)gridDim.x * RPB) {
+        float4 acc = b4;
+        for (int j = 0; j < J; ++j) acc = f4fma(masked_a(a, mask, fill, i, j, lda, J), ld4(Ws + j * C + 4 * c4), acc);
+        st4(Y + i * C + 4 * c4, acc);
+    }
 }
 
 // Z[i,j] = X[i,:].W[j,:] + b[j];  softmax over j when do_softmax.  C/4 lanes per row, butterfly reduce.
@@ -45,7 +50,9 @@ __global__ __launch_bounds__(256) void rowdot_kernel(const float* __restrict__ X
     for (int i = threadIdx.x; i < J * C / 4; i += 256) st4(Ws + 4 * i, ld4(W + 4 * i));
     __syncthreads();
     const int c4 = threadIdx.x % LPR;
-    const size_t i = (size_t)blockIdx.x * RPB + threadIdx.x / LPR;
+    const size_t nrounds = ((size_t)rows + (size_t)gridDim.x * RPB - 1) / ((size_t)gridDim.x * RPB);      // uniform trip count (cross-lane ops inside)
+    for (size_t rd = 0; rd < nrounds; ++rd) {
+    const size_t i = (rd * gridDim.x + blockIdx.x) * RPB + threadIdx.x / LPR;
     const bool valid = i < (size_t)rows;
     const float4 x = valid ? ld4(X + i * C + 4 * c4) : f4zero();
     float mine[(SM_MAXJ + LPR - 1) / LPR];      // logits owned by this lane: j = c4 + q*LPR
@@ -88,6 +95,7 @@ __global__ __launch_bounds__(256) void rowdot_kernel(const float* __restrict__ X
         const float cand = bv == gm ? -(float)bj : -3.0e38f;        // smallest index among the lanes that hold the maximum
         const int first = (int)(-group_max<LPR>(cand));
         if (valid && c4 == 0) label[i] = first;
+    }
     }
 }
 
@@ -191,8 +199,8 @@ extern "C" int gptst_lin_in(const float* a, int lda, const float* mask, float fi
                             float* Y, int rows, int J, int C, void* stream) {
     if (!a || !W || !Y || J <= 0 || J > SM_MAXJ) return GPTST_EARG;
     hipStream_t st = (hipStream_t)stream;
-    if (C == 64) hipLaunchKernelGGL((lin_in_kernel<64>), dim3((rows + 15) / 16), dim3(256), 0, st, a, lda, mask, fill, W, wlayout, b, Y, rows, J);
-    else if (C == 128) hipLaunchKernelGGL((lin_in_kernel<128>), dim3((rows + 7) / 8), dim3(256), 0, st, a, lda, mask, fill, W, wlayout, b, Y, rows, J);
+    if (C == 64) hipLaunchKernelGGL((lin_in_kernel<64>), dim3(sm_grid(rows, 16)), dim3(256), 0, st, a, lda, mask, fill, W, wlayout, b, Y, rows, J);
+    else if (C == 128) hipLaunchKernelGGL((lin_in_kernel<128>), dim3(sm_grid(rows, 8)), dim3(256), 0, st, a, lda, mask, fill, W, wlayout, b, Y, rows, J);
     else return GPTST_ESHAPE;
     GPTST_CHECK_LAUNCH();
     return GPTST_OK;
@@ -202,8 +210,8 @@ extern "C" int gptst_rowdot(const float* X, const float* W, const float* b, floa
                             int* label, void* stream) {
     if (!X || !W || !Z || J <= 0 || J > SM_MAXJ) return GPTST_EARG;
     hipStream_t st = (hipStream_t)stream;
-    if (C == 64) hipLaunchKernelGGL((rowdot_kernel<64>), dim3((rows + 15) / 16), dim3(256), 0, st, X, W, b, Z, rows, J, do_softmax, label);
-    else if (C == 128) hipLaunchKernelGGL((rowdot_kernel<128>), dim3((rows + 7) / 8), dim3(256), 0, st, X, W, b, Z, rows, J, do_softmax, label);
+    if (C == 64) hipLaunchKernelGGL((rowdot_kernel<64>), dim3(sm_grid(rows, 16)), dim3(256), 0, st, X, W, b, Z, rows, J, do_softmax, label);
+    else if (C == 128) hipLaunchKernelGGL((rowdot_kernel<128>), dim3(sm_grid(rows, 8)), dim3(256), 0, st, X, W, b, Z, rows, J, do_softmax, label);
     else return GPTST_ESHAPE;
     GPTST_CHECK_LAUNCH();
     return GPTST_OK;

@@ -133,6 +133,97 @@ __global__ __launch_bounds__(256) void tmix_dgraph_kernel(const float* __restric
     }
 }
 
+// ---- backward of the temporal mixing in ONE pass over dR (C = 128 path; the C = 64 path has it inside hypertem_bwd) ---------------
+//   dX[b,u,n,:] = dOut[b,u,n,:] * lrelu'(Y[b,u,n,:]) + sum_t G[n,t,u] dR[b,t,n,:]        (tmix_kernel<C, true>)
+//   dG[n,t,u]   = sum_{b,c} dR[b,t,n,c] X[b,u,n,c]                                         (tmix_dgraph_kernel<C>)
+// One workgroup per node, the waves split the batch.  Both are MFMA 16x16x4 products on 12-of-16 padded time indices:
+//   dX^T-free form  D[i=u][col=channel] = sum_t G[t,u] dR[t,channel]:  A lane (i,kk) = G[t=4kk+s][u=i] (k-step s), B lane (j,kk) =
+//   dR[t=4kk+s][64hf+4j+e] — rows 4kk+s of the node's (T, C) block as 256-byte coalesced float4 loads, the same rows 4kk+r the lane's
+//   accumulators stand for, so dOut / Y of the residual branch are loaded with the same addressing and the epilogue is register-local;
+//   dG  D[i=t][j=u] = sum_c dR[t,c] X[u,c]:  lane (i,kk) holds row t=i (u=i), channels 16q+4kk..+3 of dR and of X.
+// dR is fetched in both layouts (the second one hits L1/L2): HBM traffic dR + X + dOut + Y + dX instead of 2 dR + X + dOut + Y + dX
+// in two launches (N = 4096, C = 128, B = 32: 595 + 482 us -> one launch).
+template <int C>
+__global__ __launch_bounds__(256, 2) void tmix_bwd_dgraph_kernel(const float* __restrict__ dR, const float* __restrict__ X,
+                                                                 const float* __restrict__ G, const float* __restrict__ dOut,
+                                                                 const float* __restrict__ Y, float* __restrict__ dX,
+                                                                 float* __restrict__ dG, int B, int N) {
+    constexpr int Q = C / 16, H2 = C / 64;
+    __shared__ float red[4][TT2];
+    const int n = blockIdx.x, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int j = lane & 15, kk = lane >> 4;
+    const size_t tstride = (size_t)N * C;
+    float ga[4];                                              // A operand of the dX product: G[n][t = 4kk+s][u = j]
+#pragma unroll
+    for (int s = 0; s < 4; ++s) ga[s] = (j < TT && 4 * kk + s < TT) ? G[(size_t)n * TT2 + (4 * kk + s) * TT + j] : 0.f;
+    f32x4 g0 = {0.f, 0.f, 0.f, 0.f}, g1 = g0, g2 = g0, g3 = g0;     // dG accumulators (four chains), summed over this wave's samples
+    for (int b = wave; b < B; b += 4) {
+        const size_t base = ((size_t)b * TT * N + n) * C;
+        float4 drr[Q], xr[Q];                                 // row form: time step j, channels 16q+4kk..
+        float4 drc[4][H2], doc[4][H2], yc[4][H2];             // column form: time steps 4kk+s, channels 64hf+4j..
+#pragma unroll
+        for (int q = 0; q < Q; ++q) {
+            drr[q] = f4zero(); xr[q] = f4zero();
+            if (j < TT) {
+                drr[q] = ld4(dR + base + j * tstride + 16 * q + 4 * kk);
+                xr[q] = ld4(X + base + j * tstride + 16 * q + 4 * kk);
+            }
+        }
+#pragma unroll
+        for (int s = 0; s < 4; ++s)
+#pragma unroll
+            for (int hf = 0; hf < H2; ++hf) {
+                drc[s][hf] = f4zero(); doc[s][hf] = f4zero(); yc[s][hf] = f4zero();
+                if (kk < 3) {
+                    const size_t o = base + (4 * kk + s) * tstride + 64 * hf + 4 * j;
+                    drc[s][hf] = ld4(dR + o); doc[s][hf] = ld4(dOut + o); yc[s][hf] = ld4(Y + o);
+                }
+            }
+        SB();
+#pragma unroll
+        for (int q = 0; q < Q; ++q) {
+            g0 = __builtin_amdgcn_mfma_f32_16x16x4f32(drr[q].x, xr[q].x, g0, 0, 0, 0);
+            g1 = __builtin_amdgcn_mfma_f32_16x16x4f32(drr[q].y, xr[q].y, g1, 0, 0, 0);
+            g2 = __builtin_amdgcn_mfma_f32_16x16x4f32(drr[q].z, xr[q].z, g2, 0, 0, 0);
+            g3 = __builtin_amdgcn_mfma_f32_16x16x4f32(drr[q].w, xr[q].w, g3, 0, 0, 0);
+        }
+        f32x4 acc[4 * H2];
+#pragma unroll
+        for (int ct = 0; ct < 4 * H2; ++ct) acc[ct] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int s = 0; s < 4; ++s)
+#pragma unroll
+            for (int hf = 0; hf < H2; ++hf) {
+                acc[4 * hf + 0] = __builtin_amdgcn_mfma_f32_16x16x4f32(ga[s], drc[s][hf].x, acc[4 * hf + 0], 0, 0, 0);
+                acc[4 * hf + 1] = __builtin_amdgcn_mfma_f32_16x16x4f32(ga[s], drc[s][hf].y, acc[4 * hf + 1], 0, 0, 0);
+                acc[4 * hf + 2] = __builtin_amdgcn_mfma_f32_16x16x4f32(ga[s], drc[s][hf].z, acc[4 * hf + 2], 0, 0, 0);
+                acc[4 * hf + 3] = __builtin_amdgcn_mfma_f32_16x16x4f32(ga[s], drc[s][hf].w, acc[4 * hf + 3], 0, 0, 0);
+            }
+        SB();
+        if (kk < 3) {                                         // rows u = 4kk+r of dX: residual branch from registers, coalesced stores
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+#pragma unroll
+                for (int hf = 0; hf < H2; ++hf) {
+                    const float4 d = doc[r][hf], y = yc[r][hf];
+                    st4(dX + base + (4 * kk + r) * tstride + 64 * hf + 4 * j,
+                        make_float4(fmaf(d.x, lrelu_grad_from_out(y.x), acc[4 * hf + 0][r]), fmaf(d.y, lrelu_grad_from_out(y.y), acc[4 * hf + 1][r]),
+                                    fmaf(d.z, lrelu_grad_from_out(y.z), acc[4 * hf + 2][r]), fmaf(d.w, lrelu_grad_from_out(y.w), acc[4 * hf + 3][r])));
+                }
+        }
+    }
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        const int t = kk * 4 + r, u = j;
+        if (t < TT && u < TT) red[wave][t * TT + u] = (g0[r] + g1[r]) + (g2[r] + g3[r]);
+    }
+    __syncthreads();
+    if (threadIdx.x < TT2) {
+        const int e = threadIdx.x;
+        dG[(size_t)n * TT2 + e] = (red[0][e] + red[1][e]) + (red[2][e] + red[3][e]);
+    }
+}
+
 extern "C" int gptst_gram_fwd(const float* A, float* G, int N, int Hm, void* stream) {
     if (!A || !G) return GPTST_EARG;
     hipLaunchKernelGGL(gram_fwd_kernel, dim3((N * TT2 + 255) / 256), dim3(256), 0, (hipStream_t)stream, A, G, N, Hm);
@@ -172,6 +263,18 @@ extern "C" int gptst_tmix_dgraph(const float* dR, const float* X, float* dG, int
     hipStream_t st = (hipStream_t)stream;
     if (C == 64) hipLaunchKernelGGL((tmix_dgraph_kernel<64>), dim3(N), dim3(256), 0, st, dR, X, dG, B, N);
     else if (C == 128) hipLaunchKernelGGL((tmix_dgraph_kernel<128>), dim3(N), dim3(256), 0, st, dR, X, dG, B, N);
+    else return GPTST_ESHAPE;
+    GPTST_CHECK_LAUNCH();
+    return GPTST_OK;
+}
+
+// dX (B,T,N,C) = dOut * lrelu'(Y) + G^T (*) dR  and  dG (N,T,T) = sum_b dR X^T  in one pass (overwrites both)
+extern "C" int gptst_tmix_bwd(const float* dR, const float* X, const float* G, const float* dOut, const float* Y, float* dX, float* dG,
+                              int B, int T, int N, int C, void* stream) {
+    if (!dR || !X || !G || !dOut || !Y || !dX || !dG || T != TT || B < 1 || N < 1) return GPTST_EARG;
+    hipStream_t st = (hipStream_t)stream;
+    if (C == 64) hipLaunchKernelGGL((tmix_bwd_dgraph_kernel<64>), dim3(N), dim3(256), 0, st, dR, X, G, dOut, Y, dX, dG, B, N);
+    else if (C == 128) hipLaunchKernelGGL((tmix_bwd_dgraph_kernel<128>), dim3(N), dim3(256), 0, st, dR, X, G, dOut, Y, dX, dG, B, N);
     else return GPTST_ESHAPE;
     GPTST_CHECK_LAUNCH();
     return GPTST_OK;

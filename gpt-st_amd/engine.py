@@ -215,9 +215,8 @@ def hypertem_core_bwd(saved, dout, dG_out, dims):
         dWb, ns = _wgrad_async(R, dout, MODE_TIME, BT, N, D2=out, pro=PRO_DPRE, colsum_d=True)
         dWbt, dbias, nsb = dWb[:, :C * C], dWb[:, C * C:], ns
         dR = ops.apply(dout, Wbt, MODE_TIME, BT, N, A2=out, transw=True, pro=PRO_DPRE)
-        dx = ops.tmix(dR.view(B, T, N, C), G, dOut=dout.view(B, T, N, C), Y=out.view(B, T, N, C)).view(-1, C)
-        dG_out.zero_()
-        ops.tmix_dgraph(dR.view(B, T, N, C), x.view(B, T, N, C), out=dG_out[0])
+        dx, _ = ops.tmix_bwd(dR.view(B, T, N, C), x.view(B, T, N, C), G, dout.view(B, T, N, C), out.view(B, T, N, C), dG=dG_out[0])
+        dx = dx.view(-1, C)
     return dx, (dWbt, ns, (dbias, nsb))
 
 

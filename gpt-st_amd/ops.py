@@ -299,6 +299,17 @@ def hypertem_bwd(dOut, Y, X, G, Wbt, dG=None, want_dbias=True):
     return dX, dbias, dG
 
 
+def tmix_bwd(dR, X, G, dOut, Y, dG=None):
+    """Backward of the temporal mixing in one pass: -> (dX = dOut*lrelu'(Y) + G (*) dR, dG (N,T,T) = sum_b dR X^T)."""
+    _chk(dR, X, G, dOut, Y, dG)
+    B, T, N, C = X.shape
+    dX = torch.empty_like(X)
+    if dG is None:
+        dG = torch.empty(N, T, T, device=X.device, dtype=torch.float32)
+    _call("gptst_tmix_bwd", _p(dR), _p(X), _p(G), _p(dOut), _p(Y), _p(dX), _p(dG), B, T, N, C, nbytes=_nb(dR, X, dOut, Y, dX))
+    return dX, dG
+
+
 def tmix_dgraph(dR, X, out=None):
     _chk(dR, X, out)
     B, T, N, C = X.shape

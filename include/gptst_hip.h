@@ -115,6 +115,9 @@ int gptst_tmix(const float* X, const float* G, const float* dOut, const float* Y
                void* stream);
 /* dG[n,t,u] = sum_{b,c} dR[b,t,n,c] X[b,u,n,c]   (fp32 MFMA 16x16x4). */
 int gptst_tmix_dgraph(const float* dR, const float* X, float* dG, int B, int T, int N, int C, void* stream);
+/* both of the above in one pass over dR (the unfused hyperTem backward, C = 128): dX = dOut*lrelu'(Y) + G (*) dR, dG = sum_b dR X^T */
+int gptst_tmix_bwd(const float* dR, const float* X, const float* G, const float* dOut, const float* Y, float* dX, float* dG, int B, int T,
+                   int N, int C, void* stream);
 
 /* fused hyperTem forward (hypertem.hip): R = G (*) X (saved for the weight gradient), out = LReLU(R W_bt + b_bt + X);
  * one workgroup per (sample, 16 nodes), MFMA 16x16x4 with W_bt read from L2.  C = 64. */

@@ -124,11 +124,12 @@ def test_apply_and_wgrad(mode, BT, N, C):
     close(dW, dW_ref, what="wgrad")
 
 
-def test_tmix_and_graph():
+@pytest.mark.parametrize("B,N,C", [(3, 21, 64), (5, 9, 128), (1, 3, 128)])
+def test_tmix_and_graph(B, N, C):
     from gptst_amd import ops
     dev = _dev()
     g = torch.Generator().manual_seed(3)
-    B, T, N, C, Hm = 3, 12, 21, 64, 8
+    T, Hm = 12, 8
     A = rnd(N, Hm, T, g=g); X = rnd(B, T, N, C, g=g); dR = rnd(B, T, N, C, g=g)
     G = ops.gram_fwd(A.to(dev))
     Gref = torch.einsum("nht,nhu->ntu", A, A)
@@ -140,6 +141,11 @@ def test_tmix_and_graph():
     close(out, torch.einsum("ntu,bunc->btnc", Gref, X) + dO * torch.where(Y > 0, 1.0, 0.01), what="tmix+dpre")
     dG = ops.tmix_dgraph(dR.to(dev), X.to(dev))
     close(dG, torch.einsum("btnc,bunc->ntu", dR, X), what="dgraph")
+    # both in one pass over dR (general, non-symmetric G: dX[u] = sum_t G[t,u] dR[t])
+    Gn = rnd(N, T, T, g=g)
+    dX1, dG1 = ops.tmix_bwd(dR.to(dev), X.to(dev), Gn.to(dev), dO.to(dev), Y.to(dev))
+    close(dX1, torch.einsum("ntu,btnc->bunc", Gn, dR) + dO * torch.where(Y > 0, 1.0, 0.01), what="tmix_bwd dX")
+    close(dG1, torch.einsum("btnc,bunc->ntu", dR, X), what="tmix_bwd dG")
     dGr = rnd(N, T, T, g=g)
     dA = ops.gram_bwd(A.to(dev), dGr.to(dev))
     Ar = A.clone().requires_grad_()
