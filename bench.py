@@ -308,6 +308,8 @@ def main():
         "samples_per_s": steps_s * gbatch,
         "steps_per_s_random_mask_phase": rnd_rate,
         "last_loss": loss[0],
+        "hbm_peak_gb": round(torch.cuda.max_memory_allocated() / 2**30, 2),
+        "alloc_retries": int(torch.cuda.memory_stats().get("num_alloc_retries", 0)),
     }
     # whole-step roofline (64A + side + optimiser bytes; 3 x forward FLOPs)
     A_bytes = 4.0 * B * T * N * C
