@@ -42,7 +42,7 @@ __global__ __launch_bounds__(256) void lin_in_kernel(const float* __restrict__ a
 }
 
 // Z[i,j] = X[i,:].W[j,:] + b[j];  softmax over j when do_softmax.  C/4 lanes per row, butterfly reduce.
-template <int C>
+template <int C, bool LOOP>
 __global__ __launch_bounds__(256) void rowdot_kernel(const float* __restrict__ X, const float* __restrict__ W, const float* __restrict__ b,
                                                      float* __restrict__ Z, int rows, int J, int do_softmax, int* __restrict__ label) {
     constexpr int LPR = C / 4, RPB = 256 / LPR;
@@ -50,9 +50,11 @@ __global__ __launch_bounds__(256) void rowdot_kernel(const float* __restrict__ X
     for (int i = threadIdx.x; i < J * C / 4; i += 256) st4(Ws + 4 * i, ld4(W + 4 * i));
     __syncthreads();
     const int c4 = threadIdx.x % LPR;
-    const size_t nrounds = ((size_t)rows + (size_t)gridDim.x * RPB - 1) / ((size_t)gridDim.x * RPB);      // uniform trip count (cross-lane ops inside)
-    for (size_t rd = 0; rd < nrounds; ++rd) {
-    const size_t i = (rd * gridDim.x + blockIdx.x) * RPB + threadIdx.x / LPR;
+    // LOOP: grid-stride over row blocks (workgroup-uniform trip count: cross-lane ops inside) when rows > SM_MAXGRID * RPB; the one-trip
+    // instantiation keeps the straight-line code (the loop form cost 7 us per launch at the bench shape)
+#pragma unroll 1
+    for (size_t i0 = (size_t)blockIdx.x * RPB; i0 < (LOOP ? (size_t)rows : (size_t)blockIdx.x * RPB + 1); i0 += (size_t)gridDim.x * RPB) {
+    const size_t i = i0 + threadIdx.x / LPR;
     const bool valid = i < (size_t)rows;
     const float4 x = valid ? ld4(X + i * C + 4 * c4) : f4zero();
     float mine[(SM_MAXJ + LPR - 1) / LPR];      // logits owned by this lane: j = c4 + q*LPR
@@ -210,8 +212,11 @@ extern "C" int gptst_rowdot(const float* X, const float* W, const float* b, floa
                             int* label, void* stream) {
     if (!X || !W || !Z || J <= 0 || J > SM_MAXJ) return GPTST_EARG;
     hipStream_t st = (hipStream_t)stream;
-    if (C == 64) hipLaunchKernelGGL((rowdot_kernel<64>), dim3(sm_grid(rows, 16)), dim3(256), 0, st, X, W, b, Z, rows, J, do_softmax, label);
-    else if (C == 128) hipLaunchKernelGGL((rowdot_kernel<128>), dim3(sm_grid(rows, 8)), dim3(256), 0, st, X, W, b, Z, rows, J, do_softmax, label);
+    const bool loop = (long)rows > (long)SM_MAXGRID * (C == 64 ? 16 : 8);
+    if (C == 64 && !loop) hipLaunchKernelGGL((rowdot_kernel<64, false>), dim3(sm_grid(rows, 16)), dim3(256), 0, st, X, W, b, Z, rows, J, do_softmax, label);
+    else if (C == 64) hipLaunchKernelGGL((rowdot_kernel<64, true>), dim3(sm_grid(rows, 16)), dim3(256), 0, st, X, W, b, Z, rows, J, do_softmax, label);
+    else if (C == 128 && !loop) hipLaunchKernelGGL((rowdot_kernel<128, false>), dim3(sm_grid(rows, 8)), dim3(256), 0, st, X, W, b, Z, rows, J, do_softmax, label);
+    else if (C == 128) hipLaunchKernelGGL((rowdot_kernel<128, true>), dim3(sm_grid(rows, 8)), dim3(256), 0, st, X, W, b, Z, rows, J, do_softmax, label);
     else return GPTST_ESHAPE;
     GPTST_CHECK_LAUNCH();
     return GPTST_OK;

@@ -29,7 +29,8 @@ int gptst_abi_version(void);
  * order-fixed by construction.  Thread-local. */
 int gptst_set_deterministic(int on);
 /* launch-geometry knobs for benchmarking, not needed for correctness.  1: rows per block of the poolgen forward; 2 / 5: forced split
- * count of the NODE / TIME weight gradient; 3: 1 = first-generation (LDS-staged) apply for C = 64; 4: tiles per wave of apply64 */
+ * count of the NODE / TIME weight gradient; 3: 1 = first-generation (LDS-staged) apply for C = 64; 4: tiles per wave of apply64 / apply128;
+ * 6: workgroups of the loss-head kernels; 7 / 8: 1 = first-generation weight gradient / apply for C = 128 */
 int gptst_tune(int id, int value);
 
 /* ---- embedding-conditioned parameter generation (poolgen.hip) -----------------------------------------

@@ -65,6 +65,8 @@ CASES = {
     "tail_kl": lambda: ops.tail_kl(X2, W3, prob, c, N, 0.1, sws),
     "stats_fold": lambda: ops.stats_fold(sws, stats),
     "rowdot_softmax": lambda: ops.rowdot(X2, W3, b3, softmax=True, want_label=True),
+    "rowdot_softmax_nolabel": lambda: ops.rowdot(X2, W3, b3, softmax=True),
+    "rowdot_j1": lambda: ops.rowdot(X2, Wo, bo),
     "lin_in": lambda: ops.lin_in(src, 3, 1, Wi, bi, C),
     "mask_adaptive": lambda: ops.mask_adaptive(*ops.mask_labels(prob), lc, nums, na, nr, True, 1),
 }
