@@ -18,7 +18,8 @@
 //                  (k-step r <-> row 4kk+r), and 256-byte coalesced loads / stores;
 //   "node form" of a (BT,HS,N) matrix: lane holds cluster j, nodes 4kk .. 4kk+3 of the tile — one float4 along N; it is the D layout
 //                  of  rows . V^T  and the A layout of  cs^T . rows.
-// HS <= 16 and C in {64, 128}; other shapes stay on cap_big.hip.
+// HS <= 16 at C in {64, 128} and HS <= 64 at C = 64 (NHT = ceil(HS/16) cluster tiles: cluster h = 16*ht + j; BASELINE configs[3] sweeps
+// HS up to 40); other shapes stay on cap_big.hip.
 #include "common.h"
 
 #define CF_TILES 4                        // 16-row tiles per wave
@@ -49,39 +50,58 @@ __device__ __forceinline__ void stn4(float* __restrict__ row, int n, int N, bool
     }
 }
 
-// softmax over the clusters (lanes j < HS of a DPP row) of the four node columns of a lane; invalid nodes -> 0
-__device__ __forceinline__ void softmax_h4(const float (&x)[4], float (&cs)[4], int j, int HS, int n, int N) {
+// softmax over the clusters h = 16*ht + j < HS (the lanes of a DPP row x the NHT cluster tiles) of the four node columns of a lane;
+// invalid nodes -> 0
+template <int NHT>
+__device__ __forceinline__ void softmax_h4(const float4 (&x)[NHT], float (&cs)[NHT][4], int j, int HS, int n, int N) {
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
-        const float xv = j < HS ? x[r] : -3.0e38f;
-        const float m = group_max<16>(xv);
-        const float e = j < HS ? __expf(xv - m) : 0.f;
-        const float inv = 1.f / group_sum<16>(e);
-        cs[r] = (n + r < N) ? e * inv : 0.f;
+        float xv[NHT], m = -3.0e38f;
+#pragma unroll
+        for (int ht = 0; ht < NHT; ++ht) {
+            const float v = r == 0 ? x[ht].x : (r == 1 ? x[ht].y : (r == 2 ? x[ht].z : x[ht].w));
+            xv[ht] = 16 * ht + j < HS ? v : -3.0e38f;
+            m = fmaxf(m, xv[ht]);
+        }
+        m = group_max<16>(m);
+        float e[NHT], sum = 0.f;
+#pragma unroll
+        for (int ht = 0; ht < NHT; ++ht) { e[ht] = 16 * ht + j < HS ? __expf(xv[ht] - m) : 0.f; sum += e[ht]; }
+        const float inv = 1.f / group_sum<16>(sum);
+#pragma unroll
+        for (int ht = 0; ht < NHT; ++ht) cs[ht][r] = (n + r < N) ? e[ht] * inv : 0.f;
     }
 }
 
-// fold the per-wave cluster sums (acc[4hf+e][r'] = S[h = 4kk+r'][channel 64hf+4j+e]) through LDS and store the workgroup's partial
-template <int C, int XR>
-__device__ __forceinline__ void store_partial(float4 (*red)[16 + XR][C / 4], const f32x4 (&acc)[C / 16], float* __restrict__ dst, int rows_out,
+// fold the per-wave cluster sums (acc[ht][4hf+e][r'] = S[h = 16ht+4kk+r'][channel 64hf+4j+e]) through LDS, one cluster tile at a time, and
+// store the workgroup's partial (rows h < HS; XR: plus row HS from the extra LDS row 16 — the column sums)
+template <int C, int NHT, int XR>
+__device__ __forceinline__ void store_partial(float4 (*red)[16 + XR][C / 4], const f32x4 (&acc)[NHT][C / 16], float* __restrict__ dst, int HS,
                                               int wave, int j, int kk) {
 #pragma unroll
-    for (int hf = 0; hf < C / 64; ++hf)
+    for (int ht = 0; ht < NHT; ++ht) {
+        if (ht) __syncthreads();                                      // the previous tile has been read
 #pragma unroll
-        for (int r = 0; r < 4; ++r)
-            red[wave][4 * kk + r][16 * hf + j] = make_float4(acc[4 * hf + 0][r], acc[4 * hf + 1][r], acc[4 * hf + 2][r], acc[4 * hf + 3][r]);
-    __syncthreads();
-    for (int o = threadIdx.x; o < rows_out * (C / 4); o += 256) {
-        const int h = o / (C / 4), c4 = o % (C / 4);
-        const int row = (XR && h == rows_out - 1) ? 16 : h;          // XR: the last output row is the extra LDS row (column sums)
-        const float4 s = f4add(f4add(red[0][row][c4], red[1][row][c4]), f4add(red[2][row][c4], red[3][row][c4]));
-        st4(dst + (size_t)h * C + 4 * c4, s);
+        for (int hf = 0; hf < C / 64; ++hf)
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+                red[wave][4 * kk + r][16 * hf + j] =
+                    make_float4(acc[ht][4 * hf + 0][r], acc[ht][4 * hf + 1][r], acc[ht][4 * hf + 2][r], acc[ht][4 * hf + 3][r]);
+        __syncthreads();
+        const int nrow = (XR && ht == 0) ? 17 : 16;
+        for (int o = threadIdx.x; o < nrow * (C / 4); o += 256) {
+            const int row = o / (C / 4), c4 = o % (C / 4);
+            const int h = row == 16 ? HS : 16 * ht + row;
+            if (row < 16 && h >= HS) continue;
+            const float4 s = f4add(f4add(red[0][row][c4], red[1][row][c4]), f4add(red[2][row][c4], red[3][row][c4]));
+            st4(dst + (size_t)h * C + 4 * c4, s);
+        }
     }
 }
 
 // ---- pass 0:  P = squash(Y) (row-wise), c0 = softmax_h(dadj), partial [c0^T P ; colsum P] ------------------------------------------
 // part: (BT, nparts, HS+1, C) — rows h < HS: sum_n c0[h,n] P[n,:];  row HS: sum_n P[n,:]  (the first routing iteration: uniform coefficients)
-template <int C>
+template <int C, int NHT>
 __global__ __launch_bounds__(256) void cf_squash_kernel(const float* __restrict__ Y, const float* __restrict__ dadj, float* __restrict__ P,
                                                         float* __restrict__ part, int HS, int N, int nparts) {
     constexpr int H2 = C / 64;
@@ -89,13 +109,14 @@ __global__ __launch_bounds__(256) void cf_squash_kernel(const float* __restrict_
     const int bt = blockIdx.y, chunk = blockIdx.x;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, j = lane & 15, kk = lane >> 4;
     const bool al = (N & 3) == 0;
-    f32x4 acc[C / 16];
+    f32x4 acc[NHT][C / 16];
 #pragma unroll
-    for (int i = 0; i < C / 16; ++i) acc[i] = fzero4();
+    for (int ht = 0; ht < NHT; ++ht)
+#pragma unroll
+        for (int i = 0; i < C / 16; ++i) acc[ht][i] = fzero4();
     float4 csum[H2];
 #pragma unroll
     for (int hf = 0; hf < H2; ++hf) csum[hf] = f4zero();
-    const float* lrow = dadj + ((size_t)bt * HS + min(j, HS - 1)) * N;
 #pragma unroll 1
     for (int it = 0; it < CF_TILES; ++it) {
         const int n0 = chunk * CF_ROWS + (it * 4 + wave) * 16;
@@ -106,7 +127,9 @@ __global__ __launch_bounds__(256) void cf_squash_kernel(const float* __restrict_
         for (int r = 0; r < 4; ++r)
 #pragma unroll
             for (int hf = 0; hf < H2; ++hf) y[r][hf] = ld4(Y + ((size_t)bt * N + min(n + r, N - 1)) * C + 64 * hf + 4 * j);
-        const float4 lg = ldn4(lrow, n, N, al);
+        float4 lg[NHT];
+#pragma unroll
+        for (int ht = 0; ht < NHT; ++ht) lg[ht] = ldn4(dadj + ((size_t)bt * HS + min(16 * ht + j, HS - 1)) * N, n, N, al);
         SB();
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
@@ -121,19 +144,20 @@ __global__ __launch_bounds__(256) void cf_squash_kernel(const float* __restrict_
                 if (n + r < N) st4(P + ((size_t)bt * N + n + r) * C + 64 * hf + 4 * j, y[r][hf]);
             }
         }
-        const float x[4] = {lg.x, lg.y, lg.z, lg.w};
-        float cs[4];
-        softmax_h4(x, cs, j, HS, n, N);
+        float cs[NHT][4];
+        softmax_h4<NHT>(lg, cs, j, HS, n, N);
         SB();
 #pragma unroll
-        for (int r = 0; r < 4; ++r)
+        for (int ht = 0; ht < NHT; ++ht)
 #pragma unroll
-            for (int hf = 0; hf < H2; ++hf) {
-                acc[4 * hf + 0] = mfma4(cs[r], y[r][hf].x, acc[4 * hf + 0]);
-                acc[4 * hf + 1] = mfma4(cs[r], y[r][hf].y, acc[4 * hf + 1]);
-                acc[4 * hf + 2] = mfma4(cs[r], y[r][hf].z, acc[4 * hf + 2]);
-                acc[4 * hf + 3] = mfma4(cs[r], y[r][hf].w, acc[4 * hf + 3]);
-            }
+            for (int r = 0; r < 4; ++r)
+#pragma unroll
+                for (int hf = 0; hf < H2; ++hf) {
+                    acc[ht][4 * hf + 0] = mfma4(cs[ht][r], y[r][hf].x, acc[ht][4 * hf + 0]);
+                    acc[ht][4 * hf + 1] = mfma4(cs[ht][r], y[r][hf].y, acc[ht][4 * hf + 1]);
+                    acc[ht][4 * hf + 2] = mfma4(cs[ht][r], y[r][hf].z, acc[ht][4 * hf + 2]);
+                    acc[ht][4 * hf + 3] = mfma4(cs[ht][r], y[r][hf].w, acc[ht][4 * hf + 3]);
+                }
     }
 #pragma unroll
     for (int hf = 0; hf < H2; ++hf) {                                 // column sums: fold the four row groups of the wave
@@ -142,29 +166,38 @@ __global__ __launch_bounds__(256) void cf_squash_kernel(const float* __restrict_
         s.x += __shfl_xor(s.x, 32, 64); s.y += __shfl_xor(s.y, 32, 64); s.z += __shfl_xor(s.z, 32, 64); s.w += __shfl_xor(s.w, 32, 64);
         if (kk == 0) red[wave][16][16 * hf + j] = s;
     }
-    store_partial<C, 1>(red, acc, part + ((size_t)bt * nparts + chunk) * (HS + 1) * C, HS + 1, wave, j, kk);
+    store_partial<C, NHT, 1>(red, acc, part + ((size_t)bt * nparts + chunk) * (HS + 1) * C, HS, wave, j, kk);
 }
 
 // ---- one pass over the rows of a (BT,N,C) matrix ------------------------------------------------------------------------------------
 //   L = V ? rows . V^T : 0;   b = L + (bl_in ? bl_in : 0);   bl_out <- b (if given)
 //   cs = c_in ? c_in : softmax_h(b + (l0 ? l0 : 0));   c_out <- cs (if given);   part <- partial of cs^T . rows
 // routing iteration r >= 1:  (P, v, b -> b);   last step:  (P, v, b, l0 = dadj -> c);   backward of rec = c^T v:  (drec, v -> dc1 = bl_out; c_in = c -> dv)
-template <int C>
-__global__ __launch_bounds__(256, 3) void cf_route_kernel(const float* __restrict__ rows, const float* __restrict__ V, const float* __restrict__ bl_in,
-                                                       float* __restrict__ bl_out, const float* __restrict__ l0, const float* __restrict__ c_in,
-                                                       float* __restrict__ c_out, float* __restrict__ part, int HS, int N, int nparts) {
+template <int C, int NHT>
+__global__ __launch_bounds__(256, 2) void cf_route_kernel(const float* __restrict__ rows, const float* __restrict__ V,
+                                                                         const float* __restrict__ bl_in, float* __restrict__ bl_out,
+                                                                         const float* __restrict__ l0, const float* __restrict__ c_in,
+                                                                         float* __restrict__ c_out, float* __restrict__ part, int HS, int N,
+                                                                         int nparts) {
     constexpr int Q = C / 16, H2 = C / 64;
     __shared__ float4 red[4][16][C / 4];
     const int bt = blockIdx.y, chunk = blockIdx.x;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, j = lane & 15, kk = lane >> 4;
     const bool al = (N & 3) == 0;
-    f32x4 acc[C / 16];
+    f32x4 acc[NHT][C / 16];
 #pragma unroll
-    for (int i = 0; i < C / 16; ++i) acc[i] = fzero4();
-    float4 mb[Q];                                                     // V[h = j][16q+4kk ..]: B operand of rows . V^T
+    for (int ht = 0; ht < NHT; ++ht)
 #pragma unroll
-    for (int q = 0; q < Q; ++q) mb[q] = (V != nullptr && j < HS) ? ld4(V + ((size_t)bt * HS + j) * C + 16 * q + 4 * kk) : f4zero();
-    const size_t hrow = ((size_t)bt * HS + min(j, HS - 1)) * N;
+        for (int i = 0; i < C / 16; ++i) acc[ht][i] = fzero4();
+    float4 mb[NHT][Q];                                                // V[h = 16ht + j][16q+4kk ..]: B operand of rows . V^T
+    size_t hrow[NHT];
+#pragma unroll
+    for (int ht = 0; ht < NHT; ++ht) {
+        const int h = 16 * ht + j;
+        hrow[ht] = ((size_t)bt * HS + min(h, HS - 1)) * N;
+#pragma unroll
+        for (int q = 0; q < Q; ++q) mb[ht][q] = (V != nullptr && h < HS) ? ld4(V + ((size_t)bt * HS + h) * C + 16 * q + 4 * kk) : f4zero();
+    }
 #pragma unroll 1
     for (int it = 0; it < CF_TILES; ++it) {
         const int n0 = chunk * CF_ROWS + (it * 4 + wave) * 16;
@@ -179,76 +212,110 @@ __global__ __launch_bounds__(256, 3) void cf_route_kernel(const float* __restric
         for (int r = 0; r < 4; ++r)
 #pragma unroll
             for (int hf = 0; hf < H2; ++hf) a2[r][hf] = ld4(rows + ((size_t)bt * N + min(n + r, N - 1)) * C + 64 * hf + 4 * j);
-        float4 b4 = f4zero(), l4 = f4zero(), c4 = f4zero();
-        if (bl_in != nullptr) b4 = ldn4(bl_in + hrow, n, N, al);
-        if (l0 != nullptr) l4 = ldn4(l0 + hrow, n, N, al);
-        if (c_in != nullptr) c4 = ldn4(c_in + hrow, n, N, al);
+        float4 b4[NHT], l4[NHT], c4[NHT];
+#pragma unroll
+        for (int ht = 0; ht < NHT; ++ht) {
+            b4[ht] = f4zero(); l4[ht] = f4zero(); c4[ht] = f4zero();
+            if (bl_in != nullptr) b4[ht] = ldn4(bl_in + hrow[ht], n, N, al);
+            if (l0 != nullptr) l4[ht] = ldn4(l0 + hrow[ht], n, N, al);
+            if (c_in != nullptr) c4[ht] = ldn4(c_in + hrow[ht], n, N, al);
+        }
         SB();
         if (V != nullptr) {
-            f32x4 L0 = fzero4(), L1 = fzero4(), L2 = fzero4(), L3 = fzero4();          // four independent accumulation chains
 #pragma unroll
-            for (int q = 0; q < Q; ++q) {
-                L0 = mfma4(a1[q].x, mb[q].x, L0);
-                L1 = mfma4(a1[q].y, mb[q].y, L1);
-                L2 = mfma4(a1[q].z, mb[q].z, L2);
-                L3 = mfma4(a1[q].w, mb[q].w, L3);
+            for (int ht = 0; ht < NHT; ++ht) {
+                f32x4 L0 = fzero4(), L1 = fzero4(), L2 = fzero4(), L3 = fzero4();      // four independent accumulation chains
+#pragma unroll
+                for (int q = 0; q < Q; ++q) {
+                    L0 = mfma4(a1[q].x, mb[ht][q].x, L0);
+                    L1 = mfma4(a1[q].y, mb[ht][q].y, L1);
+                    L2 = mfma4(a1[q].z, mb[ht][q].z, L2);
+                    L3 = mfma4(a1[q].w, mb[ht][q].w, L3);
+                }
+                b4[ht].x += (L0[0] + L1[0]) + (L2[0] + L3[0]);
+                b4[ht].y += (L0[1] + L1[1]) + (L2[1] + L3[1]);
+                b4[ht].z += (L0[2] + L1[2]) + (L2[2] + L3[2]);
+                b4[ht].w += (L0[3] + L1[3]) + (L2[3] + L3[3]);
             }
-            b4.x += (L0[0] + L1[0]) + (L2[0] + L3[0]);
-            b4.y += (L0[1] + L1[1]) + (L2[1] + L3[1]);
-            b4.z += (L0[2] + L1[2]) + (L2[2] + L3[2]);
-            b4.w += (L0[3] + L1[3]) + (L2[3] + L3[3]);
         }
-        if (bl_out != nullptr && j < HS) stn4(bl_out + hrow, n, N, al, b4);
-        float cs[4];
+        float cs[NHT][4];
         if (c_in != nullptr) {
-            cs[0] = (j < HS && n < N) ? c4.x : 0.f; cs[1] = (j < HS && n + 1 < N) ? c4.y : 0.f;
-            cs[2] = (j < HS && n + 2 < N) ? c4.z : 0.f; cs[3] = (j < HS && n + 3 < N) ? c4.w : 0.f;
+#pragma unroll
+            for (int ht = 0; ht < NHT; ++ht) {
+                const bool hok = 16 * ht + j < HS;
+                if (bl_out != nullptr && hok) stn4(bl_out + hrow[ht], n, N, al, b4[ht]);
+                cs[ht][0] = (hok && n < N) ? c4[ht].x : 0.f; cs[ht][1] = (hok && n + 1 < N) ? c4[ht].y : 0.f;
+                cs[ht][2] = (hok && n + 2 < N) ? c4[ht].z : 0.f; cs[ht][3] = (hok && n + 3 < N) ? c4[ht].w : 0.f;
+            }
         } else {
-            const float x[4] = {b4.x + l4.x, b4.y + l4.y, b4.z + l4.z, b4.w + l4.w};
-            softmax_h4(x, cs, j, HS, n, N);
-            if (c_out != nullptr && j < HS) stn4(c_out + hrow, n, N, al, make_float4(cs[0], cs[1], cs[2], cs[3]));
+            float4 x[NHT];
+#pragma unroll
+            for (int ht = 0; ht < NHT; ++ht) {
+                if (bl_out != nullptr && 16 * ht + j < HS) stn4(bl_out + hrow[ht], n, N, al, b4[ht]);
+                x[ht] = f4add(b4[ht], l4[ht]);
+            }
+            softmax_h4<NHT>(x, cs, j, HS, n, N);
+            if (c_out != nullptr) {
+#pragma unroll
+                for (int ht = 0; ht < NHT; ++ht)
+                    if (16 * ht + j < HS) stn4(c_out + hrow[ht], n, N, al, make_float4(cs[ht][0], cs[ht][1], cs[ht][2], cs[ht][3]));
+            }
         }
         SB();
 #pragma unroll
-        for (int r = 0; r < 4; ++r)
+        for (int ht = 0; ht < NHT; ++ht)
 #pragma unroll
-            for (int hf = 0; hf < H2; ++hf) {
-                acc[4 * hf + 0] = mfma4(cs[r], a2[r][hf].x, acc[4 * hf + 0]);
-                acc[4 * hf + 1] = mfma4(cs[r], a2[r][hf].y, acc[4 * hf + 1]);
-                acc[4 * hf + 2] = mfma4(cs[r], a2[r][hf].z, acc[4 * hf + 2]);
-                acc[4 * hf + 3] = mfma4(cs[r], a2[r][hf].w, acc[4 * hf + 3]);
-            }
+            for (int r = 0; r < 4; ++r)
+#pragma unroll
+                for (int hf = 0; hf < H2; ++hf) {
+                    acc[ht][4 * hf + 0] = mfma4(cs[ht][r], a2[r][hf].x, acc[ht][4 * hf + 0]);
+                    acc[ht][4 * hf + 1] = mfma4(cs[ht][r], a2[r][hf].y, acc[ht][4 * hf + 1]);
+                    acc[ht][4 * hf + 2] = mfma4(cs[ht][r], a2[r][hf].z, acc[ht][4 * hf + 2]);
+                    acc[ht][4 * hf + 3] = mfma4(cs[ht][r], a2[r][hf].w, acc[ht][4 * hf + 3]);
+                }
     }
-    store_partial<C, 0>(red, acc, part + ((size_t)bt * nparts + chunk) * HS * C, HS, wave, j, kk);
+    store_partial<C, NHT, 0>(red, acc, part + ((size_t)bt * nparts + chunk) * HS * C, HS, wave, j, kk);
 }
 
 // ---- rec[bt,n,:] = sum_h c[bt,h,n] v[bt,h,:]  (cluster -> node scatter, GPTST.py:135) as rec^T = v^T c^T on MFMA --------------------------
-template <int C>
+template <int C, int NHT>
 __global__ __launch_bounds__(256) void cf_rec_fwd_kernel(const float* __restrict__ c, const float* __restrict__ v, float* __restrict__ rec,
                                                          int HS, int N) {
     constexpr int Q = C / 16;
     const int bt = blockIdx.y, chunk = blockIdx.x;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, j = lane & 15, kk = lane >> 4;
-    float va[Q][4];                                                   // A[i = channel 16q+j][k-step s: h = 4kk+s]
+    float va[NHT][Q][4];                                              // A[i = channel 16q+j][k-step (ht, s): h = 16ht+4kk+s]
 #pragma unroll
-    for (int q = 0; q < Q; ++q)
+    for (int ht = 0; ht < NHT; ++ht)
 #pragma unroll
-        for (int s = 0; s < 4; ++s) va[q][s] = (4 * kk + s < HS) ? v[((size_t)bt * HS + 4 * kk + s) * C + 16 * q + j] : 0.f;
+        for (int q = 0; q < Q; ++q)
+#pragma unroll
+            for (int s = 0; s < 4; ++s) {
+                const int h = 16 * ht + 4 * kk + s;
+                va[ht][q][s] = h < HS ? v[((size_t)bt * HS + h) * C + 16 * q + j] : 0.f;
+            }
 #pragma unroll 1
     for (int it = 0; it < CF_TILES; ++it) {
         const int n0 = chunk * CF_ROWS + (it * 4 + wave) * 16;
         if (n0 >= N) break;
         const bool ok = n0 + j < N;
-        float ct[4];                                                  // B[k: h = 4kk+s][row j]
+        float ct[NHT][4];                                             // B[k: h = 16ht+4kk+s][row j]
 #pragma unroll
-        for (int s = 0; s < 4; ++s) ct[s] = (ok && 4 * kk + s < HS) ? c[((size_t)bt * HS + 4 * kk + s) * N + n0 + j] : 0.f;
+        for (int ht = 0; ht < NHT; ++ht)
+#pragma unroll
+            for (int s = 0; s < 4; ++s) {
+                const int h = 16 * ht + 4 * kk + s;
+                ct[ht][s] = (ok && h < HS) ? c[((size_t)bt * HS + h) * N + n0 + j] : 0.f;
+            }
         f32x4 acc[Q];
 #pragma unroll
         for (int q = 0; q < Q; ++q) acc[q] = fzero4();
 #pragma unroll
-        for (int s = 0; s < 4; ++s)
+        for (int ht = 0; ht < NHT; ++ht)
 #pragma unroll
-            for (int q = 0; q < Q; ++q) acc[q] = mfma4(va[q][s], ct[s], acc[q]);
+            for (int s = 0; s < 4; ++s)
+#pragma unroll
+                for (int q = 0; q < Q; ++q) acc[q] = mfma4(va[ht][q][s], ct[ht][s], acc[q]);
         if (ok) {
 #pragma unroll
             for (int q = 0; q < Q; ++q)
@@ -259,7 +326,7 @@ __global__ __launch_bounds__(256) void cf_rec_fwd_kernel(const float* __restrict
 
 // ---- backward through s = c P, c = softmax_h(b + dadj), P = squash(Y) for the rows of Y (cb_route_bwd_rows_kernel on MFMA) ------------
 //   U[n,h] = dS[h,:].P[n,:];  dc = dc1 + U;  dlogit[h] = c[h] (dc[h] - sum_h c dc);  dP = sum_h c[h] dS[h,:];  dY = g dP + Y 2 g'(q) (Y.dP)
-template <int C>
+template <int C, int NHT>
 __global__ __launch_bounds__(256) void cf_route_bwd_kernel(const float* __restrict__ Y, const float* __restrict__ c, const float* __restrict__ dc1,
                                                            const float* __restrict__ dS, float* __restrict__ dY, float* __restrict__ dlogit,
                                                            int HS, int N) {
@@ -267,15 +334,22 @@ __global__ __launch_bounds__(256) void cf_route_bwd_kernel(const float* __restri
     const int bt = blockIdx.y, chunk = blockIdx.x;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, j = lane & 15, kk = lane >> 4;
     const bool al = (N & 3) == 0;
-    float4 mb[Q];                                                     // dS[h = j][16q+4kk ..]: B operand of Y . dS^T
-    float da[Q][4];                                                   // dS[h = 4kk+s][16q+j]:  A operand of dP^T = dS^T c^T
+    float4 mb[NHT][Q];                                                // dS[h = 16ht+j][16q+4kk ..]: B operand of Y . dS^T
+    float da[NHT][Q][4];                                              // dS[h = 16ht+4kk+s][16q+j]:  A operand of dP^T = dS^T c^T
+    size_t hrow[NHT];
 #pragma unroll
-    for (int q = 0; q < Q; ++q) {
-        mb[q] = j < HS ? ld4(dS + ((size_t)bt * HS + j) * C + 16 * q + 4 * kk) : f4zero();
+    for (int ht = 0; ht < NHT; ++ht) {
+        hrow[ht] = ((size_t)bt * HS + min(16 * ht + j, HS - 1)) * N;
 #pragma unroll
-        for (int s = 0; s < 4; ++s) da[q][s] = (4 * kk + s < HS) ? dS[((size_t)bt * HS + 4 * kk + s) * C + 16 * q + j] : 0.f;
+        for (int q = 0; q < Q; ++q) {
+            mb[ht][q] = 16 * ht + j < HS ? ld4(dS + ((size_t)bt * HS + 16 * ht + j) * C + 16 * q + 4 * kk) : f4zero();
+#pragma unroll
+            for (int s = 0; s < 4; ++s) {
+                const int h = 16 * ht + 4 * kk + s;
+                da[ht][q][s] = h < HS ? dS[((size_t)bt * HS + h) * C + 16 * q + j] : 0.f;
+            }
+        }
     }
-    const size_t hrow = ((size_t)bt * HS + min(j, HS - 1)) * N;
 #pragma unroll 1
     for (int it = 0; it < CF_TILES; ++it) {
         const int n0 = chunk * CF_ROWS + (it * 4 + wave) * 16;
@@ -285,10 +359,17 @@ __global__ __launch_bounds__(256) void cf_route_bwd_kernel(const float* __restri
         float4 a1[Q];
 #pragma unroll
         for (int q = 0; q < Q; ++q) a1[q] = ld4(Y + ((size_t)bt * N + min(n0 + j, N - 1)) * C + 16 * q + 4 * kk);
-        const float4 c1 = ldn4(c + hrow, n, N, al), d1 = ldn4(dc1 + hrow, n, N, al);
-        float ct[4];
+        float4 c1[NHT], d1[NHT];
+        float ct[NHT][4];
 #pragma unroll
-        for (int s = 0; s < 4; ++s) ct[s] = (ok && 4 * kk + s < HS) ? c[((size_t)bt * HS + 4 * kk + s) * N + n0 + j] : 0.f;
+        for (int ht = 0; ht < NHT; ++ht) {
+            c1[ht] = ldn4(c + hrow[ht], n, N, al); d1[ht] = ldn4(dc1 + hrow[ht], n, N, al);
+#pragma unroll
+            for (int s = 0; s < 4; ++s) {
+                const int h = 16 * ht + 4 * kk + s;
+                ct[ht][s] = (ok && h < HS) ? c[((size_t)bt * HS + h) * N + n0 + j] : 0.f;
+            }
+        }
         SB();
         float qn = 0.f;
 #pragma unroll
@@ -298,33 +379,45 @@ __global__ __launch_bounds__(256) void cf_route_bwd_kernel(const float* __restri
         const float g = qn / den;
         float gp = 0.f;
         if (rt > 0.f) gp = (den - qn * ((rt + 1e-8f) + (1.f + qn) * 0.5f / rt)) / (den * den);
-        f32x4 L0 = fzero4(), L1 = fzero4(), L2 = fzero4(), L3 = fzero4();
+        float gr[4];
 #pragma unroll
-        for (int q = 0; q < Q; ++q) {
-            L0 = mfma4(a1[q].x, mb[q].x, L0);
-            L1 = mfma4(a1[q].y, mb[q].y, L1);
-            L2 = mfma4(a1[q].z, mb[q].z, L2);
-            L3 = mfma4(a1[q].w, mb[q].w, L3);
+        for (int r = 0; r < 4; ++r) gr[r] = __shfl(g, 4 * kk + r, 64);                 // squash gain of row 4kk+r
+        // node form: rows 4kk+r, cluster 16ht+j
+        float dch[NHT][4], w[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int ht = 0; ht < NHT; ++ht) {
+            f32x4 L0 = fzero4(), L1 = fzero4(), L2 = fzero4(), L3 = fzero4();
+#pragma unroll
+            for (int q = 0; q < Q; ++q) {
+                L0 = mfma4(a1[q].x, mb[ht][q].x, L0);
+                L1 = mfma4(a1[q].y, mb[ht][q].y, L1);
+                L2 = mfma4(a1[q].z, mb[ht][q].z, L2);
+                L3 = mfma4(a1[q].w, mb[ht][q].w, L3);
+            }
+            const float cv[4] = {c1[ht].x, c1[ht].y, c1[ht].z, c1[ht].w}, dv[4] = {d1[ht].x, d1[ht].y, d1[ht].z, d1[ht].w};
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                dch[ht][r] = dv[r] + gr[r] * ((L0[r] + L1[r]) + (L2[r] + L3[r]));
+                w[r] += 16 * ht + j < HS ? cv[r] * dch[ht][r] : 0.f;
+            }
         }
+#pragma unroll
+        for (int r = 0; r < 4; ++r) w[r] = group_sum<16>(w[r]);
+#pragma unroll
+        for (int ht = 0; ht < NHT; ++ht)
+            if (16 * ht + j < HS)
+                stn4(dlogit + hrow[ht], n, N, al, make_float4(c1[ht].x * (dch[ht][0] - w[0]), c1[ht].y * (dch[ht][1] - w[1]),
+                                                                c1[ht].z * (dch[ht][2] - w[2]), c1[ht].w * (dch[ht][3] - w[3])));
+        // row form: dP[row j][16q+4kk+r'] = acc[q][r']
         f32x4 acc[Q];
 #pragma unroll
         for (int q = 0; q < Q; ++q) acc[q] = fzero4();
 #pragma unroll
-        for (int s = 0; s < 4; ++s)
+        for (int ht = 0; ht < NHT; ++ht)
 #pragma unroll
-            for (int q = 0; q < Q; ++q) acc[q] = mfma4(da[q][s], ct[s], acc[q]);
-        // node form: rows 4kk+r, cluster j
-        const float cv[4] = {c1.x, c1.y, c1.z, c1.w}, dv[4] = {d1.x, d1.y, d1.z, d1.w};
-        float dl[4];
+            for (int s = 0; s < 4; ++s)
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            const float gr = __shfl(g, 4 * kk + r, 64);                              // squash gain of row 4kk+r
-            const float dch = dv[r] + gr * ((L0[r] + L1[r]) + (L2[r] + L3[r]));
-            const float w = group_sum<16>(j < HS ? cv[r] * dch : 0.f);
-            dl[r] = cv[r] * (dch - w);
-        }
-        if (j < HS) stn4(dlogit + hrow, n, N, al, make_float4(dl[0], dl[1], dl[2], dl[3]));
-        // row form: dP[row j][16q+4kk+r'] = acc[q][r']
+                for (int q = 0; q < Q; ++q) acc[q] = mfma4(da[ht][q][s], ct[ht][s], acc[q]);
         float ydp = 0.f;
 #pragma unroll
         for (int q = 0; q < Q; ++q) ydp += a1[q].x * acc[q][0] + a1[q].y * acc[q][1] + a1[q].z * acc[q][2] + a1[q].w * acc[q][3];
@@ -377,14 +470,19 @@ __global__ __launch_bounds__(256) void cf_post_kernel(const float* __restrict__ 
 }
 
 // ---- C ABI ---------------------------------------------------------------------------------------------------------------------------
-#define CF_LAUNCH(KERNEL, GRID, ...)                                                                          \
-    do {                                                                                                      \
-        if (C == 64) hipLaunchKernelGGL((KERNEL<64>), GRID, dim3(256), 0, (hipStream_t)stream, __VA_ARGS__);        \
-        else hipLaunchKernelGGL((KERNEL<128>), GRID, dim3(256), 0, (hipStream_t)stream, __VA_ARGS__);               \
-        GPTST_CHECK_LAUNCH();                                                                                 \
-        return GPTST_OK;                                                                                      \
+#define CF_SHAPE_OK(HS, C) ((HS) >= 1 && (((HS) <= 16 && ((C) == 64 || (C) == 128)) || ((HS) <= 64 && (C) == 64)))
+#define CF_LAUNCH(KERNEL, GRID, ...)                                                                                   \
+    do {                                                                                                               \
+        const int nht_ = (HS + 15) / 16;                                                                               \
+        hipStream_t st_ = (hipStream_t)stream;                                                                         \
+        if (C == 128) hipLaunchKernelGGL((KERNEL<128, 1>), GRID, dim3(256), 0, st_, __VA_ARGS__);                      \
+        else if (nht_ == 1) hipLaunchKernelGGL((KERNEL<64, 1>), GRID, dim3(256), 0, st_, __VA_ARGS__);                 \
+        else if (nht_ == 2) hipLaunchKernelGGL((KERNEL<64, 2>), GRID, dim3(256), 0, st_, __VA_ARGS__);                 \
+        else if (nht_ == 3) hipLaunchKernelGGL((KERNEL<64, 3>), GRID, dim3(256), 0, st_, __VA_ARGS__);                 \
+        else hipLaunchKernelGGL((KERNEL<64, 4>), GRID, dim3(256), 0, st_, __VA_ARGS__);                                \
+        GPTST_CHECK_LAUNCH();                                                                                          \
+        return GPTST_OK;                                                                                               \
     } while (0)
-#define CF_SHAPE_OK(HS, C) ((HS) >= 1 && (HS) <= 16 && ((C) == 64 || (C) == 128))
 
 extern "C" int gptst_capflow_supported(int HS, int C) { return CF_SHAPE_OK(HS, C) ? 1 : 0; }
 extern "C" int gptst_capflow_nparts(int N) { return (N + CF_ROWS - 1) / CF_ROWS; }
@@ -408,7 +506,10 @@ extern "C" int gptst_capflow_post(const float* part, int nparts, int prow, float
     if (!part || nparts < 1 || mode < 0 || mode > 3 || (mode <= 1 && !V0) || (mode >= 1 && !Vout)) return GPTST_EARG;
     if (prow != (mode == 0 ? HS + 1 : HS) && mode != 3) return GPTST_EARG;
     if (!CF_SHAPE_OK(HS, C)) return GPTST_ESHAPE;
-    CF_LAUNCH(cf_post_kernel, dim3(BT), part, nparts, prow, V0, Vout, mode, HS);
+    if (C == 64) hipLaunchKernelGGL((cf_post_kernel<64>), dim3(BT), dim3(256), 0, (hipStream_t)stream, part, nparts, prow, V0, Vout, mode, HS);
+    else hipLaunchKernelGGL((cf_post_kernel<128>), dim3(BT), dim3(256), 0, (hipStream_t)stream, part, nparts, prow, V0, Vout, mode, HS);
+    GPTST_CHECK_LAUNCH();
+    return GPTST_OK;
 }
 
 extern "C" int gptst_capflow_rec_fwd(const float* c, const float* v, float* rec, int BT, int HS, int N, int C, void* stream) {

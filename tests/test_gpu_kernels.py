@@ -219,7 +219,9 @@ def test_cap_layer(B, N, d, ds, HS, HT, R):
 @pytest.mark.parametrize("B,N,C,d,ds,HS,HT,R,force", [(2, 20, 64, 8, 4, 5, 6, 3, True), (1, 170, 64, 16, 4, 10, 16, 2, True),
                                                        (1, 600, 64, 8, 4, 10, 16, 2, False), (1, 300, 128, 8, 4, 10, 8, 2, False),
                                                        (1, 37, 128, 4, 3, 40, 5, 1, True), (2, 37, 64, 4, 3, 7, 5, 1, True),
-                                                       (1, 530, 128, 4, 3, 16, 5, 0, True), (1, 1030, 64, 4, 3, 3, 5, 4, False)])
+                                                       (1, 530, 128, 4, 3, 16, 5, 0, True), (1, 1030, 64, 4, 3, 3, 5, 4, False),
+                                                       (1, 266, 64, 4, 3, 40, 5, 2, True), (2, 70, 64, 4, 3, 20, 5, 2, True), (1, 45, 64, 4, 3, 64, 5, 1, True),
+                                                       (1, 33, 64, 4, 3, 17, 5, 3, True)])
 def test_cap_layer_streaming_path(B, N, C, d, ds, HS, HT, R, force, flow):
     """cap through the streaming kernels — the fused MFMA passes of capflow.hip (HS <= 16) or the first-generation cap_big.hip kernels:
     taken when the (b,t) capsule matrix does not fit LDS (N = 600 at C = 64, N = 300 at C = 128 — BASELINE config 5 territory) or
