@@ -167,6 +167,7 @@ __global__ void cx_big_ht_kernel(const float* __restrict__ s, const float* __res
     if (i >= HT * C) return;
     const int j = i / C, c = i % C;
     float acc = 0.f;
+#pragma unroll 8                      // eight tokens' loads in flight per trip (the plain loop is one dependent round trip per token)
     for (int k = 0; k < KK; ++k) acc = fmaf(dyn[((size_t)b * HT + j) * KK + k], s[((size_t)b * KK + k) * C + c] + tmpl[k / HS], acc);
     Ht[((size_t)b * HT + j) * C + c] = lrelu(acc);
 }
@@ -220,6 +221,7 @@ __global__ void cx_big_dh_kernel(const float* __restrict__ dS, const float* __re
     if (i >= HT * C) return;
     const int j = i / C, c = i % C;
     float acc = 0.f;
+#pragma unroll 8
     for (int k = 0; k < KK; ++k) {
         const size_t off = ((size_t)b * KK + k) * C + c;
         acc = fmaf(dyn[((size_t)b * HT + j) * KK + k], dS[off] * lrelu_grad_from_out(Rt[off]), acc);

@@ -8,7 +8,7 @@
 // the cluster sums (MFMA, contraction over the tile's nodes) — the three kernels type2 / softmax / type1 of cap_big.hip, with P read
 // once instead of twice and the (BT,HS,N) coefficient matrix never written for the inner iterations.  The first iteration (b = 0: uniform
 // coefficients, i.e. column sums of P) is folded into the squash pass.  Per forward: Y written + read once, P written once and read R times.
-// Sums over nodes leave a kernel as PARTIALS per 256-node chunk, folded in index order by cf_post_kernel (no atomics, no zero fill);
+// Sums over nodes leave a kernel as PARTIALS per node chunk (64 - 256 nodes), folded in index order by cf_post_kernel (no atomics, no zero fill);
 // a node-sharded run folds, all-reduces the (BT,HS,C) sums across ranks and resumes with the post step.
 //
 // Operand layouts of a 16-row tile (lane = (j, kk), j = lane & 15, kk = lane >> 4):
@@ -22,8 +22,9 @@
 // HS up to 40); other shapes stay on cap_big.hip.
 #include "common.h"
 
-#define CF_TILES 4                        // 16-row tiles per wave
-#define CF_ROWS (4 * CF_TILES * 16)       // node rows per workgroup (= per partial)
+// 16-row tiles per wave: 4 for long node ranges (N = 4096: 16 partials per (b,t)), fewer when a (b,t) has only a few tiles, so that the
+// tile loop of a wave — one dependent chain of loads, MFMAs and cross-lane steps per tile — stays short and more workgroups share the work
+static inline int cf_tpw(int N) { const int nt = (N + 15) / 16; return nt >= 128 ? 4 : (nt >= 32 ? 2 : 1); }
 
 __device__ __forceinline__ f32x4 mfma4(float a, float b, f32x4 c) { return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0); }
 __device__ __forceinline__ f32x4 fzero4() { return (f32x4){0.f, 0.f, 0.f, 0.f}; }
@@ -103,7 +104,7 @@ __device__ __forceinline__ void store_partial(float4 (*red)[16 + XR][C / 4], con
 // part: (BT, nparts, HS+1, C) — rows h < HS: sum_n c0[h,n] P[n,:];  row HS: sum_n P[n,:]  (the first routing iteration: uniform coefficients)
 template <int C, int NHT>
 __global__ __launch_bounds__(256) void cf_squash_kernel(const float* __restrict__ Y, const float* __restrict__ dadj, float* __restrict__ P,
-                                                        float* __restrict__ part, int HS, int N, int nparts) {
+                                                        float* __restrict__ part, int HS, int N, int nparts, int tpw) {
     constexpr int H2 = C / 64;
     __shared__ float4 red[4][17][C / 4];
     const int bt = blockIdx.y, chunk = blockIdx.x;
@@ -118,8 +119,8 @@ __global__ __launch_bounds__(256) void cf_squash_kernel(const float* __restrict_
 #pragma unroll
     for (int hf = 0; hf < H2; ++hf) csum[hf] = f4zero();
 #pragma unroll 1
-    for (int it = 0; it < CF_TILES; ++it) {
-        const int n0 = chunk * CF_ROWS + (it * 4 + wave) * 16;
+    for (int it = 0; it < tpw; ++it) {
+        const int n0 = (chunk * tpw + it) * 64 + wave * 16;
         if (n0 >= N) break;                                           // wave-uniform
         const int n = n0 + 4 * kk;
         float4 y[4][H2];
@@ -178,7 +179,7 @@ __global__ __launch_bounds__(256, 2) void cf_route_kernel(const float* __restric
                                                                          const float* __restrict__ bl_in, float* __restrict__ bl_out,
                                                                          const float* __restrict__ l0, const float* __restrict__ c_in,
                                                                          float* __restrict__ c_out, float* __restrict__ part, int HS, int N,
-                                                                         int nparts) {
+                                                                         int nparts, int tpw) {
     constexpr int Q = C / 16, H2 = C / 64;
     __shared__ float4 red[4][16][C / 4];
     const int bt = blockIdx.y, chunk = blockIdx.x;
@@ -199,8 +200,8 @@ __global__ __launch_bounds__(256, 2) void cf_route_kernel(const float* __restric
         for (int q = 0; q < Q; ++q) mb[ht][q] = (V != nullptr && h < HS) ? ld4(V + ((size_t)bt * HS + h) * C + 16 * q + 4 * kk) : f4zero();
     }
 #pragma unroll 1
-    for (int it = 0; it < CF_TILES; ++it) {
-        const int n0 = chunk * CF_ROWS + (it * 4 + wave) * 16;
+    for (int it = 0; it < tpw; ++it) {
+        const int n0 = (chunk * tpw + it) * 64 + wave * 16;
         if (n0 >= N) break;
         const int n = n0 + 4 * kk;
         float4 a1[Q], a2[4][H2];
@@ -280,7 +281,7 @@ __global__ __launch_bounds__(256, 2) void cf_route_kernel(const float* __restric
 // ---- rec[bt,n,:] = sum_h c[bt,h,n] v[bt,h,:]  (cluster -> node scatter, GPTST.py:135) as rec^T = v^T c^T on MFMA --------------------------
 template <int C, int NHT>
 __global__ __launch_bounds__(256) void cf_rec_fwd_kernel(const float* __restrict__ c, const float* __restrict__ v, float* __restrict__ rec,
-                                                         int HS, int N) {
+                                                         int HS, int N, int tpw) {
     constexpr int Q = C / 16;
     const int bt = blockIdx.y, chunk = blockIdx.x;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, j = lane & 15, kk = lane >> 4;
@@ -295,8 +296,8 @@ __global__ __launch_bounds__(256) void cf_rec_fwd_kernel(const float* __restrict
                 va[ht][q][s] = h < HS ? v[((size_t)bt * HS + h) * C + 16 * q + j] : 0.f;
             }
 #pragma unroll 1
-    for (int it = 0; it < CF_TILES; ++it) {
-        const int n0 = chunk * CF_ROWS + (it * 4 + wave) * 16;
+    for (int it = 0; it < tpw; ++it) {
+        const int n0 = (chunk * tpw + it) * 64 + wave * 16;
         if (n0 >= N) break;
         const bool ok = n0 + j < N;
         float ct[NHT][4];                                             // B[k: h = 16ht+4kk+s][row j]
@@ -329,7 +330,7 @@ __global__ __launch_bounds__(256) void cf_rec_fwd_kernel(const float* __restrict
 template <int C, int NHT>
 __global__ __launch_bounds__(256) void cf_route_bwd_kernel(const float* __restrict__ Y, const float* __restrict__ c, const float* __restrict__ dc1,
                                                            const float* __restrict__ dS, float* __restrict__ dY, float* __restrict__ dlogit,
-                                                           int HS, int N) {
+                                                           int HS, int N, int tpw) {
     constexpr int Q = C / 16;
     const int bt = blockIdx.y, chunk = blockIdx.x;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, j = lane & 15, kk = lane >> 4;
@@ -351,8 +352,8 @@ __global__ __launch_bounds__(256) void cf_route_bwd_kernel(const float* __restri
         }
     }
 #pragma unroll 1
-    for (int it = 0; it < CF_TILES; ++it) {
-        const int n0 = chunk * CF_ROWS + (it * 4 + wave) * 16;
+    for (int it = 0; it < tpw; ++it) {
+        const int n0 = (chunk * tpw + it) * 64 + wave * 16;
         if (n0 >= N) break;
         const int n = n0 + 4 * kk;
         const bool ok = n0 + j < N;
@@ -485,13 +486,13 @@ __global__ __launch_bounds__(256) void cf_post_kernel(const float* __restrict__ 
     } while (0)
 
 extern "C" int gptst_capflow_supported(int HS, int C) { return CF_SHAPE_OK(HS, C) ? 1 : 0; }
-extern "C" int gptst_capflow_nparts(int N) { return (N + CF_ROWS - 1) / CF_ROWS; }
+extern "C" int gptst_capflow_nparts(int N) { const int rows = 64 * cf_tpw(N); return (N + rows - 1) / rows; }
 
 extern "C" int gptst_capflow_squash(const float* Y, const float* dadj, float* P, float* part, int BT, int HS, int N, int C, void* stream) {
     if (!Y || !dadj || !P || !part || BT < 1 || N < 1) return GPTST_EARG;
     if (!CF_SHAPE_OK(HS, C)) return GPTST_ESHAPE;
     const int np = gptst_capflow_nparts(N);
-    CF_LAUNCH(cf_squash_kernel, dim3(np, BT), Y, dadj, P, part, HS, N, np);
+    CF_LAUNCH(cf_squash_kernel, dim3(np, BT), Y, dadj, P, part, HS, N, np, cf_tpw(N));
 }
 
 extern "C" int gptst_capflow_route(const float* rows, const float* V, const float* bl_in, float* bl_out, const float* l0, const float* c_in,
@@ -499,7 +500,7 @@ extern "C" int gptst_capflow_route(const float* rows, const float* V, const floa
     if (!rows || !part || BT < 1 || N < 1) return GPTST_EARG;
     if (!CF_SHAPE_OK(HS, C)) return GPTST_ESHAPE;
     const int np = gptst_capflow_nparts(N);
-    CF_LAUNCH(cf_route_kernel, dim3(np, BT), rows, V, bl_in, bl_out, l0, c_in, c_out, part, HS, N, np);
+    CF_LAUNCH(cf_route_kernel, dim3(np, BT), rows, V, bl_in, bl_out, l0, c_in, c_out, part, HS, N, np, cf_tpw(N));
 }
 
 extern "C" int gptst_capflow_post(const float* part, int nparts, int prow, float* V0, float* Vout, int mode, int BT, int HS, int C, void* stream) {
@@ -515,12 +516,12 @@ extern "C" int gptst_capflow_post(const float* part, int nparts, int prow, float
 extern "C" int gptst_capflow_rec_fwd(const float* c, const float* v, float* rec, int BT, int HS, int N, int C, void* stream) {
     if (!c || !v || !rec || BT < 1 || N < 1) return GPTST_EARG;
     if (!CF_SHAPE_OK(HS, C)) return GPTST_ESHAPE;
-    CF_LAUNCH(cf_rec_fwd_kernel, dim3(gptst_capflow_nparts(N), BT), c, v, rec, HS, N);
+    CF_LAUNCH(cf_rec_fwd_kernel, dim3(gptst_capflow_nparts(N), BT), c, v, rec, HS, N, cf_tpw(N));
 }
 
 extern "C" int gptst_capflow_route_bwd(const float* Y, const float* c, const float* dc1, const float* dS, float* dY, float* dlogit, int BT,
                                        int HS, int N, int C, void* stream) {
     if (!Y || !c || !dc1 || !dS || !dY || !dlogit || BT < 1 || N < 1) return GPTST_EARG;
     if (!CF_SHAPE_OK(HS, C)) return GPTST_ESHAPE;
-    CF_LAUNCH(cf_route_bwd_kernel, dim3(gptst_capflow_nparts(N), BT), Y, c, dc1, dS, dY, dlogit, HS, N);
+    CF_LAUNCH(cf_route_bwd_kernel, dim3(gptst_capflow_nparts(N), BT), Y, c, dc1, dS, dY, dlogit, HS, N, cf_tpw(N));
 }

@@ -488,7 +488,7 @@ def cap_rec_bwd(drec, c, v, reduce_nodes=None):
             return
         _call("gptst_capbig_rec_bwd_dc", _p(drec), _p(v), _p(dc1), BT, HS, N, C)
         _capbig_type1(c, drec, dv, BT, HS, N, C, reduce_nodes)                       # dv = sum_n c drec: a sum over nodes
-    if reduce_nodes is not None:
+    if reduce_nodes is not None or (HS > 16 and capflow_ok(HS, C)):     # HS > 16: the LDS kernel is the VALU first generation (172 vs 64 us at HS = 40)
         stream()
     else:
         _lds_or_stream(lambda: _call("gptst_cap_rec_bwd", _p(drec), _p(c), _p(v), _p(dc1), _p(dv), BT, N, C, HS, nbytes=_nb(drec, c, v, dc1, dv)),
