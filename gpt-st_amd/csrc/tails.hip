@@ -14,7 +14,7 @@
 // ([0] sum |y-p|, [1] kept count: mae tail; [2] KL sum: kl head), which gptst_stats_fold sums in index order into stats: no float
 // atomics, the result does not depend on scheduling.  (Measured: 510 same-address atomics at the end of a launch — the stats
 // themselves, or a "last workgroup folds" ticket — cost ~8 us; one extra 1-workgroup launch costs 2.5.)
-// C = 64, J <= TL_MAXJ; other shapes use the unfused ops.
+// C in {64, 128}, J <= TL_MAXJ; other shapes use the unfused ops.
 #include "common.h"
 
 #define TL_NB 512
@@ -29,9 +29,9 @@ struct TailArgs {
     const float* prob; const float* c; int N; float w;
 };
 
-template <int KIND>      // 0: mae tail, 1: kl head
+template <int KIND, int C>      // KIND 0: mae tail, 1: kl head
 __global__ __launch_bounds__(256) void tail_kernel(TailArgs t) {
-    constexpr int C = 64, LPR = C / 4, RPB = 256 / LPR;
+    constexpr int LPR = C / 4, RPB = 256 / LPR;
     __shared__ __attribute__((aligned(16))) float Ws[TL_MAXJ * C];
     __shared__ float4 red[RPB][LPR];
     __shared__ float redb[RPB];
@@ -58,7 +58,7 @@ __global__ __launch_bounds__(256) void tail_kernel(TailArgs t) {
         const size_t i = i0 + (size_t)u * RPB;
         if (i >= r1) continue;                                        // uniform per 16-lane row group; no barrier inside
         const float4 x = xs[u];
-        // per-row scalars: lane j of the row's 16-lane group loads / computes entry j (J <= 16) and the group shares the results —
+        // per-row scalars: lane j of the row's C/4-lane group loads / computes entry j (J <= 16) and the group shares the results —
         // every lane loading all J entries itself cost 16x the load instructions (42 us for the KL head at the bench shape)
         float a[TL_MAXJ];
         float a_own = 0.f;
@@ -156,7 +156,9 @@ __global__ __launch_bounds__(256) void stats_fold_kernel(const float* __restrict
 
 thread_local int g_tl_nb = TL_NB;       // experiments: gptst_tune(6, nb)
 static void tl_geometry(int rows, int& nb, int& rpb) {
-    rpb = (rows + g_tl_nb - 1) / g_tl_nb; if (rpb < 16) rpb = 16;
+    int want = g_tl_nb;
+    if (g_tl_nb == TL_NB && rows > TL_NB * 512) { want = rows / 512; if (want > 4096) want = 4096; }      // N = 4096: 1.5 M rows -> 3072 chunks
+    rpb = (rows + want - 1) / want; if (rpb < 16) rpb = 16;
     nb = (rows + rpb - 1) / rpb;
 }
 
@@ -175,12 +177,13 @@ extern "C" int gptst_tail_mae(const float* dec, const float* W, const float* b, 
                               float mu, float thresh, float* out, float* d_dec, float* part, float* sws, int rows, int J, int C,
                               void* stream) {
     if (!dec || !W || !src || !mask || !out || !d_dec || !part || !sws || rows <= 0 || J <= 0) return GPTST_EARG;
-    if (C != 64 || J > TL_MAXJ) return GPTST_ESHAPE;
+    if ((C != 64 && C != 128) || J > TL_MAXJ) return GPTST_ESHAPE;
     TailArgs t{};
     t.X = dec; t.W = W; t.b = b; t.dX = d_dec; t.part = part; t.sws = sws; t.rows = rows; t.J = J;
     t.src = src; t.mask = mask; t.out = out; t.lda = lda; t.sigma = sigma; t.mu = mu; t.thresh = thresh;
     int nb; tl_geometry(rows, nb, t.rows_per_block);
-    hipLaunchKernelGGL(tail_kernel<0>, dim3(nb), dim3(256), 0, (hipStream_t)stream, t);
+    if (C == 64) hipLaunchKernelGGL((tail_kernel<0, 64>), dim3(nb), dim3(256), 0, (hipStream_t)stream, t);
+    else hipLaunchKernelGGL((tail_kernel<0, 128>), dim3(nb), dim3(256), 0, (hipStream_t)stream, t);
     GPTST_CHECK_LAUNCH();
     return GPTST_OK;
 }
@@ -188,12 +191,13 @@ extern "C" int gptst_tail_mae(const float* dec, const float* W, const float* b, 
 extern "C" int gptst_tail_kl(const float* h2, const float* W3, const float* prob, const float* c, float w, float* d_h2, float* part,
                              float* sws, int rows, int N, int HS, int C, void* stream) {
     if (!h2 || !W3 || !prob || !c || !d_h2 || !part || !sws || rows <= 0 || HS <= 0 || N <= 0) return GPTST_EARG;
-    if (C != 64 || HS > TL_MAXJ) return GPTST_ESHAPE;
+    if ((C != 64 && C != 128) || HS > TL_MAXJ) return GPTST_ESHAPE;
     TailArgs t{};
     t.X = h2; t.W = W3; t.dX = d_h2; t.part = part; t.sws = sws; t.rows = rows; t.J = HS;
     t.prob = prob; t.c = c; t.N = N; t.w = w;
     int nb; tl_geometry(rows, nb, t.rows_per_block);
-    hipLaunchKernelGGL(tail_kernel<1>, dim3(nb), dim3(256), 0, (hipStream_t)stream, t);
+    if (C == 64) hipLaunchKernelGGL((tail_kernel<1, 64>), dim3(nb), dim3(256), 0, (hipStream_t)stream, t);
+    else hipLaunchKernelGGL((tail_kernel<1, 128>), dim3(nb), dim3(256), 0, (hipStream_t)stream, t);
     GPTST_CHECK_LAUNCH();
     return GPTST_OK;
 }

@@ -462,8 +462,8 @@ def _wb_view(gw, gb):
 
 
 def fused_tails_ok(p, C, base, HS):
-    """The fused loss heads (tails.hip) serve C = 64 and J, HS <= 16 with [weight | bias] adjacent in the flat buffer."""
-    return (C == 64 and base <= ops.TAIL_MAXJ and HS <= ops.TAIL_MAXJ
+    """The fused loss heads (tails.hip) serve C in {64, 128} and J, HS <= 16 with [weight | bias] adjacent in the flat buffer."""
+    return (C in (64, 128) and base <= ops.TAIL_MAXJ and HS <= ops.TAIL_MAXJ
             and _wb_view(p["decoder.dim_flow_out.weight"], p["decoder.dim_flow_out.bias"]) is not None
             and _wb_view(p["encoder.MLP_RL.ln3.weight"], p["encoder.MLP_RL.ln3.bias"]) is not None)
 

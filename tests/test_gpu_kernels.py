@@ -540,13 +540,13 @@ def test_timefeat_jobs_equal_single_launches():
             assert torch.equal(b, c)
 
 
-@pytest.mark.parametrize("J,rows", [(1, 65280), (2, 1000), (1, 37)])
-def test_tail_mae_matches_unfused_ops(J, rows):
+@pytest.mark.parametrize("J,rows,C", [(1, 65280, 64), (2, 1000, 64), (1, 37, 64), (1, 3000, 128), (2, 301, 128)])
+def test_tail_mae_matches_unfused_ops(J, rows, C):
     """tails.hip mae tail == rowdot + mae_fwd + mae_bwd(normalize=False) + lin_in + rowouter, and the statistics of the oracle loss."""
     from gptst_amd import ops
     dev = _dev()
     g = torch.Generator().manual_seed(21)
-    C, lda = 64, J + 2
+    lda = J + 2
     dec, W, b = rnd(rows, C, g=g), rnd(J, C, g=g, scale=0.2), rnd(J, g=g)
     src = rnd(rows, lda, g=g)
     mask = (torch.rand(rows * J, generator=g) > 0.25).float()
@@ -568,12 +568,12 @@ def test_tail_mae_matches_unfused_ops(J, rows):
     close(gwb[J * C:], a.sum(0), what="tail gb")
 
 
-@pytest.mark.parametrize("HS,N,BT", [(10, 170, 48), (5, 20, 7), (16, 33, 5)])
-def test_tail_kl_matches_unfused_ops(HS, N, BT):
+@pytest.mark.parametrize("HS,N,BT,C", [(10, 170, 48, 64), (5, 20, 7, 64), (16, 33, 5, 64), (10, 301, 12, 128), (3, 17, 2, 128)])
+def test_tail_kl_matches_unfused_ops(HS, N, BT, C):
     from gptst_amd import ops
     dev = _dev()
     g = torch.Generator().manual_seed(22)
-    C, rows = 64, BT * N
+    rows = BT * N
     h2, W3 = rnd(rows, C, g=g), rnd(HS, C, g=g, scale=0.2)
     prob = torch.softmax(rnd(rows, HS, g=g), -1)
     c = torch.softmax(rnd(BT, HS, N, g=g), 1).contiguous()

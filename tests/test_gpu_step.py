@@ -213,20 +213,24 @@ def test_unsynced_queue_equals_synced_steps(use_graph):
     assert torch.isfinite(outs[1][1]).all()
 
 
-@pytest.mark.parametrize("use_graph", [False, True])
-def test_deterministic_mode_is_bit_reproducible(use_graph):
+@pytest.mark.parametrize("use_graph,N,over", [(False, 20, {}), (True, 20, {}), (False, 300, dict(hidden_dim=128, HS=10))],
+                         ids=["eager", "graph", "c128_streaming_cap"])
+def test_deterministic_mode_is_bit_reproducible(use_graph, N, over):
     """GPTST_DETERMINISTIC / PretrainStep(deterministic=True): two runs of the same 12 steps (both phases, injected noise, free-running
-    adaptive masks) end in bit-identical parameters and optimiser state — no float atomics are left on the path."""
+    adaptive masks) end in bit-identical parameters and optimiser state — no float atomics are left on the path.  c128_streaming_cap:
+    the C = 128 kernels (apply128 / wgrad128 / tmix_bwd) and the capflow passes (N = 300 does not fit LDS at C = 128)."""
     from gptst_amd.model import GPTST_Model
     from gptst_amd.step import PretrainStep
-    args = _args()
+    args = make_args("PEMS08", **dict(dict(num_nodes=N, embed_dim=8, HS=5, HT=6, num_route=2, scaler_zeros=synth.scaler_zeros(),
+                                           epochs=30, change_epoch=3), **over))
     sd = O.init_state_dict(args, 2)
-    src = [synth.make_batch(4, 12, 20, 1, seed=70 + i).to(DEV) for i in range(12)]
-    M = 4 * 12 * 20
+    Bt = 4 if N == 20 else 2
+    src = [synth.make_batch(Bt, 12, N, 1, seed=70 + i).to(DEV) for i in range(12)]
+    M = Bt * 12 * N
     outs = []
     for rep in range(2):
         model = GPTST_Model(args); model.load_state_dict(sd); model = model.to(DEV)
-        st = PretrainStep(model, args, synth.SCALER_MEAN, synth.SCALER_STD, batch_size=4, use_graph=use_graph, deterministic=True)
+        st = PretrainStep(model, args, synth.SCALER_MEAN, synth.SCALER_STD, batch_size=Bt, use_graph=use_graph, deterministic=True)
         losses = []
         for i in range(12):
             epoch = 1 + i // 2                               # change_epoch = 3: steps 6.. are adaptive + KL
@@ -234,7 +238,7 @@ def test_deterministic_mode_is_bit_reproducible(use_graph):
             if epoch <= args.change_epoch:
                 st.step(src[i], epoch, noise=na)
             else:
-                st.step(src[i], epoch, noise_a=na, noise_r=nr, list_c=synth.class_order(5, i))
+                st.step(src[i], epoch, noise_a=na, noise_r=nr, list_c=synth.class_order(args.HS, i))
             losses.append(st.losses())
         outs.append((model.flat.clone(), st.m.clone(), st.v.clone(), losses))
     assert outs[0][3] == outs[1][3], "losses differ between two deterministic runs"
