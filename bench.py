@@ -239,7 +239,8 @@ def main():
         model.load_state_dict(sd_l)
         model = model.to(dev)
         del gmodel
-        stepper = ShardedPretrainStep(model, largs, N, DistNodeGroup(rank, world), synth.SCALER_MEAN, synth.SCALER_STD, batch_size=B, seed=7)
+        stepper = ShardedPretrainStep(model, largs, N, DistNodeGroup(rank, world), synth.SCALER_MEAN, synth.SCALER_STD, batch_size=B, seed=7,
+                                      use_graph=False if a.no_graph else None)     # None: hipGraph when the collectives are capturable (world = 1)
         gsrc = synth.make_batch(B, T, N, args.input_base_dim, interval=args.interval, seed=2024)
         src = gsrc[:, :, rank * Nl:(rank + 1) * Nl].contiguous().to(dev)
     else:
@@ -302,7 +303,8 @@ def main():
                                    "BASELINE configs[4] shape (unsharded)" if (a.nodes or a.hidden) else
                                    {"PEMS08": "BASELINE configs[1]", "METR_LA": "BASELINE configs[2] shape", "NYC_TAXI": "BASELINE configs[3] shape"}.get(a.dataset, a.dataset),
                                    a.dataset, B, T, N, C, args.input_base_dim, a.epoch,
-                                   "adaptive mask + KL" if a.epoch > args.change_epoch else "random mask", not a.no_graph and a.shard != "nodes"),
+                                   "adaptive mask + KL" if a.epoch > args.change_epoch else "random mask",
+                                   bool(getattr(stepper, "shard_graph", False)) if a.shard == "nodes" else not a.no_graph),
                    "global_batch": gbatch,
                    "parallelism": ("nodes%d" if a.shard == "nodes" else "dp%d") % a.gpus},
         "samples_per_s": steps_s * gbatch,

@@ -12,9 +12,11 @@ norms (one scalar all-reduce).  Masks: the selection runs replicated over the GL
 rank keeps its node columns; the adaptive phase all-gathers the per-cell cluster labels and sums the class counts.
 Loss statistics (sum |e|, kept count, KL sum) travel in the tail of the gradient buffer, as in dist.py.
 
-Eager (no hipGraph: collectives sit between kernels).  The collectives go through a small group object: ``DistNodeGroup``
-(torch.distributed, RCCL on GPUs) or ``ThreadNodeGroup`` (ranks emulated by threads on ONE GPU — how the tests check the
-protocol against the unsharded step).
+The collectives go through a small group object: ``DistNodeGroup`` (torch.distributed, RCCL on GPUs), ``NativeNodeGroup`` (the C-ABI
+communicator of csrc/comm.hip: plain enqueues on the launch stream) or ``ThreadNodeGroup`` (ranks emulated by threads on ONE GPU —
+how the tests check the protocol against the unsharded step).  A group whose collectives are stream-ordered device work
+(``capturable``: world = 1, or NativeNodeGroup) lets the whole step — kernels AND collectives — be captured in ONE hipGraph per phase
+(``use_graph``); otherwise the step is enqueued eagerly, the collectives sitting between the kernels.
 """
 import threading
 
@@ -61,6 +63,7 @@ class DistNodeGroup:
 
     def __init__(self, rank, world):
         self.rank, self.world = rank, world
+        self.capturable = world == 1                     # one rank: the collectives are no-ops / device copies
 
     def all_reduce_(self, t):
         import torch.distributed as dist
@@ -80,9 +83,38 @@ class DistNodeGroup:
         return out.view((self.world,) + tuple(t.shape))
 
 
+class NativeNodeGroup:
+    """The same collectives on the C-ABI communicator (dist.NativeComm: RCCL bound at run time, every call a plain enqueue on torch's
+    current stream), so they can sit INSIDE a captured hipGraph.  The library reduces fp32 only: integer payloads (class counts, cluster
+    labels) travel as exactly representable floats (< 2^24), and the all-gather is an all-reduce of a buffer in which every rank fills its
+    own slot."""
+    capturable = True
+
+    def __init__(self, comm):
+        self.comm, self.rank, self.world = comm, comm.rank, comm.world
+
+    def all_reduce_(self, t):
+        if t.dtype == torch.float32:
+            self.comm.allreduce_(t if t.is_contiguous() else t.contiguous())
+            return t
+        f = t.to(torch.float32)
+        self.comm.allreduce_(f)
+        t.copy_(f.to(t.dtype))
+        return t
+
+    def all_gather(self, t):
+        """-> (world, *t.shape)"""
+        buf = torch.zeros((self.world,) + tuple(t.shape), dtype=torch.float32, device=t.device)
+        buf[self.rank].copy_(t)
+        self.comm.allreduce_(buf)
+        return buf.to(t.dtype)
+
+
 class ThreadNodeGroup:
     """The same collectives between `world` threads of one process sharing one GPU stream (tests).  Kernels of all threads land
     on the same stream in enqueue order, and a barrier separates 'everybody has enqueued its contribution' from the sum."""
+
+    capturable = False
 
     class Shared:
         def __init__(self, world):
@@ -117,8 +149,12 @@ class ThreadNodeGroup:
 class ShardedPretrainStep(PretrainStep):
     """One optimisation step of a rank that owns nodes [n0, n1) of N (all ranks: equal shard sizes)."""
 
-    def __init__(self, model_local, args_local, n_global, group, scaler_mean, scaler_std, batch_size, seed=0):
+    def __init__(self, model_local, args_local, n_global, group, scaler_mean, scaler_std, batch_size, seed=0, use_graph=None):
+        """use_graph: None = capture the step in a hipGraph when the group's collectives are capturable (see the module docstring)."""
         super().__init__(model_local, args_local, scaler_mean, scaler_std, batch_size, use_graph=False, dp=None, seed=seed)
+        self.shard_graph = bool(getattr(group, "capturable", False)) if use_graph is None else bool(use_graph)
+        assert not self.shard_graph or getattr(group, "capturable", False), "this group's collectives cannot be captured"
+        self.fused_tails = False                            # the loss statistics travel in the gradient buffer (one all-reduce)
         self.group, self.Ng = group, n_global
         self.Nl = args_local.num_nodes
         assert self.Nl * group.world == n_global, "equal node shards"
@@ -160,16 +196,47 @@ class ShardedPretrainStep(PretrainStep):
 
     def step(self, source, epoch, noise=None, noise_a=None, noise_r=None, list_c=None):
         """source: this rank's (B,T,Nl,base+2) slice; injected noise (tests) covers the GLOBAL (B,T,N[,base]) cells."""
-        mdl, a, base, dims = self.model, self.args, self.base, self.dims
+        a = self.args
         phase = 0 if epoch <= a.change_epoch else 1
-        self.src.copy_(source, non_blocking=True)
-        self.inject_noise = noise is not None or noise_a is not None
-        if self.inject_noise:
+        if source is not self.src:
+            self.src.copy_(source, non_blocking=True)
+        inject = noise is not None or noise_a is not None
+        if inject:
             if phase == 0:
                 self.noise_g.copy_(noise.reshape(-1))
             else:
                 self.noise_a_g.copy_(noise_a.reshape(-1)); self.noise_r_g.copy_(noise_r.reshape(-1))
         self._host_prepare(phase, epoch, list_c)
+        if not self.shard_graph:
+            self.inject_noise = inject
+            self._sbody(phase)
+            return
+        key = (phase, inject)
+        if key not in self.graphs:
+            self._scapture(key)
+        self.graphs[key].replay()
+
+    def _scapture(self, key):
+        """One hipGraph per (phase, injected noise): warm-up on a side stream, capture, undo the warm-up updates."""
+        phase, self.inject_noise = key
+        keep = (self.model.flat.clone(), self.m.clone(), self.v.clone())
+        s = torch.cuda.Stream()
+        s.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(s):
+            for _ in range(2):
+                self._sbody(phase)
+        torch.cuda.current_stream().wait_stream(s)
+        torch.cuda.synchronize()
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g, capture_error_mode="thread_local"):
+            self._sbody(phase)
+        self.graphs[key] = g
+        self.model.flat.copy_(keep[0]); self.m.copy_(keep[1]); self.v.copy_(keep[2])
+        torch.cuda.synchronize()
+
+    def _sbody(self, phase):
+        """The device side of one step: kernels and collectives in stream order (eager, or inside a capture)."""
+        mdl, a, base, dims = self.model, self.args, self.base, self.dims
         p, g = mdl.param_views(), self.g
         M = self.B * self.T * self.Nl
         self.gbuf.zero_()

@@ -151,3 +151,47 @@ def test_config4_full_size_properties(parity):
             gn, gn_ref = float(out[r][3][i][4]) ** 0.5, float(stats[4]) ** 0.5        # stats[4] = total sum g^2 seen by the optimiser
             parity("gradnorm_sharded_vs_unsharded", abs(gn - gn_ref) / gn_ref)
             assert abs(gn - gn_ref) < 1e-3 * gn_ref, (i, r, gn, gn_ref)
+
+
+@pytest.mark.parametrize("kind", ["dist_world1", "native_comm"])
+def test_sharded_step_in_one_hipgraph(kind, parity):
+    """A group whose collectives are stream-ordered device work lets the whole node-sharded step — kernels and collectives — be ONE
+    hipGraph per phase: world = 1 (collectives are copies) and the C-ABI communicator (RCCL enqueues on the launch stream, here with one
+    rank).  Graph replays reproduce the eager sharded steps: same masks, same losses, same parameters (up to float-atomic order)."""
+    from gptst_amd.model import GPTST_Model
+    from gptst_amd.shard import DistNodeGroup, NativeNodeGroup, ShardedPretrainStep
+    N, B = 40, 2
+    args = _args(N)
+    sd = O.init_state_dict(args, 8)
+    Mg = B * 12 * N
+    steps = [(1, 0), (2, 1), (20, 2), (25, 3)]
+    srcs = [synth.make_batch(B, 12, N, 1, seed=60 + s).to(DEV) for _, s in steps]
+    noise = [tuple(synth.make_noise(Mg, 30 * s + i).to(DEV) for i in range(3)) for _, s in steps]
+    list_c = synth.class_order(args.HS, 3)
+    comm = None
+    if kind == "native_comm":
+        from gptst_amd.dist import NativeComm
+        comm = NativeComm(rank=0, world=1)
+    try:
+        res = []
+        for use_graph in (False, True):
+            group = NativeNodeGroup(comm) if comm is not None else DistNodeGroup(0, 1)
+            m = GPTST_Model(args); m.load_state_dict(sd); m = m.to(DEV)
+            st = ShardedPretrainStep(m, args, N, group, synth.SCALER_MEAN, synth.SCALER_STD, batch_size=B, use_graph=use_graph)
+            assert st.shard_graph == use_graph
+            losses, masks = [], []
+            for (epoch, _), src, (n0, na, nr) in zip(steps, srcs, noise):
+                st.step(src, epoch, noise=n0, noise_a=na, noise_r=nr, list_c=list_c)
+                losses.append(st.losses()); masks.append(st.last_mask_global.clone())
+            res.append((losses, masks, m.flat.detach().clone()))
+    finally:
+        if comm is not None:
+            comm.close()
+    (le, me, pe), (lg, mg, pg) = res
+    for i in range(len(steps)):
+        assert torch.equal(me[i], mg[i]), "mask differs at step %d" % i
+        for a, b in zip(le[i], lg[i]):
+            assert abs(a - b) <= 2e-4 * max(abs(b), 1e-3), (i, le[i], lg[i])
+    err = float((pe - pg).norm() / pe.norm())
+    parity("param_rel_l2_graph_vs_eager", err)
+    assert err < 1e-3
