@@ -141,15 +141,16 @@ __global__ __launch_bounds__(256) void tmix_dgraph_kernel(const float* __restric
 //   dR[t=4kk+s][64hf+4j+e] — rows 4kk+s of the node's (T, C) block as 256-byte coalesced float4 loads, the same rows 4kk+r the lane's
 //   accumulators stand for, so dOut / Y of the residual branch are loaded with the same addressing and the epilogue is register-local;
 //   dG  D[i=t][j=u] = sum_c dR[t,c] X[u,c]:  lane (i,kk) holds row t=i (u=i), channels 16q+4kk..+3 of dR and of X.
-// dR is fetched in both layouts (the second one hits L1/L2): HBM traffic dR + X + dOut + Y + dX instead of 2 dR + X + dOut + Y + dX
+// dR and X change layout through a wave-private LDS tile: HBM traffic dR + X + dOut + Y + dX instead of 2 dR + X + dOut + Y + dX
 // in two launches (N = 4096, C = 128, B = 32: 595 + 482 us -> one launch).
 template <int C>
 __global__ __launch_bounds__(256, 2) void tmix_bwd_dgraph_kernel(const float* __restrict__ dR, const float* __restrict__ X,
                                                                  const float* __restrict__ G, const float* __restrict__ dOut,
                                                                  const float* __restrict__ Y, float* __restrict__ dX,
                                                                  float* __restrict__ dG, int B, int N) {
-    constexpr int Q = C / 16, H2 = C / 64;
+    constexpr int Q = C / 16, H2 = C / 64, P = C + 4;
     __shared__ float red[4][TT2];
+    __shared__ __attribute__((aligned(16))) float tile[4][2][TT][P];     // per wave: the (T, C) blocks of dR and X, to change operand layout
     const int n = blockIdx.x, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int j = lane & 15, kk = lane >> 4;
     const size_t tstride = (size_t)N * C;
@@ -159,26 +160,37 @@ __global__ __launch_bounds__(256, 2) void tmix_bwd_dgraph_kernel(const float* __
     f32x4 g0 = {0.f, 0.f, 0.f, 0.f}, g1 = g0, g2 = g0, g3 = g0;     // dG accumulators (four chains), summed over this wave's samples
     for (int b = wave; b < B; b += 4) {
         const size_t base = ((size_t)b * TT * N + n) * C;
-        float4 drr[Q], xr[Q];                                 // row form: time step j, channels 16q+4kk..
-        float4 drc[4][H2], doc[4][H2], yc[4][H2];             // column form: time steps 4kk+s, channels 64hf+4j..
-#pragma unroll
-        for (int q = 0; q < Q; ++q) {
-            drr[q] = f4zero(); xr[q] = f4zero();
-            if (j < TT) {
-                drr[q] = ld4(dR + base + j * tstride + 16 * q + 4 * kk);
-                xr[q] = ld4(X + base + j * tstride + 16 * q + 4 * kk);
-            }
-        }
+        // every global load in column form (time steps 4kk+s, channels 64hf+4j..: whole 256-byte row pieces); the row form the dG
+        // product needs (time step j, channels 16q+4kk..) is read back from the wave's LDS tile (row-form loads straight from global
+        // memory are 64-byte pieces of 12 rows 2 MB apart: 930 us per launch at N = 4096, B = 32 with them)
+        float4 drc[4][H2], xc[4][H2], doc[4][H2], yc[4][H2];
 #pragma unroll
         for (int s = 0; s < 4; ++s)
 #pragma unroll
             for (int hf = 0; hf < H2; ++hf) {
-                drc[s][hf] = f4zero(); doc[s][hf] = f4zero(); yc[s][hf] = f4zero();
+                drc[s][hf] = f4zero(); xc[s][hf] = f4zero(); doc[s][hf] = f4zero(); yc[s][hf] = f4zero();
                 if (kk < 3) {
                     const size_t o = base + (4 * kk + s) * tstride + 64 * hf + 4 * j;
-                    drc[s][hf] = ld4(dR + o); doc[s][hf] = ld4(dOut + o); yc[s][hf] = ld4(Y + o);
+                    drc[s][hf] = ld4(dR + o); xc[s][hf] = ld4(X + o); doc[s][hf] = ld4(dOut + o); yc[s][hf] = ld4(Y + o);
                 }
             }
+        SB();
+        if (kk < 3) {
+#pragma unroll
+            for (int s = 0; s < 4; ++s)
+#pragma unroll
+                for (int hf = 0; hf < H2; ++hf) {
+                    st4(&tile[wave][0][4 * kk + s][64 * hf + 4 * j], drc[s][hf]);
+                    st4(&tile[wave][1][4 * kk + s][64 * hf + 4 * j], xc[s][hf]);
+                }
+        }
+        SB();
+        float4 drr[Q], xr[Q];                                 // row form: time step j, channels 16q+4kk..  (wave-private tile: program order suffices)
+#pragma unroll
+        for (int q = 0; q < Q; ++q) {
+            drr[q] = f4zero(); xr[q] = f4zero();
+            if (j < TT) { drr[q] = ld4(&tile[wave][0][j][16 * q + 4 * kk]); xr[q] = ld4(&tile[wave][1][j][16 * q + 4 * kk]); }
+        }
         SB();
 #pragma unroll
         for (int q = 0; q < Q; ++q) {
