@@ -182,6 +182,7 @@ __global__ __launch_bounds__(256, 2) void cf_route_kernel(const float* __restric
                                                                          int nparts, int tpw) {
     constexpr int Q = C / 16, H2 = C / 64;
     __shared__ float4 red[4][16][C / 4];
+    __shared__ __attribute__((aligned(16))) float rt[4][16][C + 4];    // per wave: the 16-row tile, to change operand layout
     const int bt = blockIdx.y, chunk = blockIdx.x;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, j = lane & 15, kk = lane >> 4;
     const bool al = (N & 3) == 0;
@@ -205,10 +206,6 @@ __global__ __launch_bounds__(256, 2) void cf_route_kernel(const float* __restric
         if (n0 >= N) break;
         const int n = n0 + 4 * kk;
         float4 a1[Q], a2[4][H2];
-        if (V != nullptr) {
-#pragma unroll
-            for (int q = 0; q < Q; ++q) a1[q] = ld4(rows + ((size_t)bt * N + min(n0 + j, N - 1)) * C + 16 * q + 4 * kk);
-        }
 #pragma unroll
         for (int r = 0; r < 4; ++r)
 #pragma unroll
@@ -223,6 +220,15 @@ __global__ __launch_bounds__(256, 2) void cf_route_kernel(const float* __restric
         }
         SB();
         if (V != nullptr) {
+            // row form of the same tile (row j, channels 16q+4kk..) through the wave's LDS tile: the rows come from HBM once, coalesced
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+#pragma unroll
+                for (int hf = 0; hf < H2; ++hf) st4(&rt[wave][4 * kk + r][64 * hf + 4 * j], a2[r][hf]);
+            SB();
+#pragma unroll
+            for (int q = 0; q < Q; ++q) a1[q] = ld4(&rt[wave][j][16 * q + 4 * kk]);
+            SB();
 #pragma unroll
             for (int ht = 0; ht < NHT; ++ht) {
                 f32x4 L0 = fzero4(), L1 = fzero4(), L2 = fzero4(), L3 = fzero4();      // four independent accumulation chains
