@@ -779,6 +779,8 @@ static void apply128_geometry(const RowMap& rm, bool has_colsum, int& tpw, int& 
     tpw = rm.G == 1 ? 8 : 4;                                     // shared weight: fewer re-stagings of W; else >= ~2 workgroups per CU and group
     if (has_colsum && rm.G == 1) { const int lim = (ntiles + AP128_NW * 128 - 1) / (AP128_NW * 128); if (tpw < lim) tpw = lim; }   // <= 128 partials
     if (tpw * AP128_NW > ntiles) tpw = (ntiles + AP128_NW - 1) / AP128_NW;
+    // few, short groups (one rank's 512-node share of configs[4]: 384 groups x 32 tiles): fewer tiles per wave until ~4 workgroups per CU exist
+    while (tpw > 1 && !(has_colsum && rm.G == 1) && (long)rm.G * ((ntiles + AP128_NW * tpw - 1) / (AP128_NW * tpw)) < 1024) --tpw;
     if (g_apply_tpw > 0) tpw = g_apply_tpw;
     if (tpw < 1) tpw = 1;
     gy = (ntiles + AP128_NW * tpw - 1) / (AP128_NW * tpw);
