@@ -1,5 +1,6 @@
 #!/usr/bin/env python
-"""``python Run.py -dataset PEMS08 -mode pretrain [-key value ...]`` — same flags as the reference model/Run.py for the
+"""``python Run.py -dataset PEMS08 -mode pretrain [-key value ...]`` (and ``-mode eval -model STGCN``: the downstream predictor on the
+enhanced embedding) — same flags as the reference model/Run.py for the
 pretrain mode (reference Run.py:35,49,55-58,63-69,72-74,79-85,115-117,132-143,153-156).  Data: the reference's layout
 ``<root>/<DATASET>/<file>.npz`` with ``['data']`` of shape (L, N, F) under ``-data_root`` (default ../data, as in the reference),
 loaded by gptst_amd.data (time indices, split, windows, z-score: parity-tested against the reference's loader functions);
@@ -23,8 +24,10 @@ def main():
     dev = torch.device("cuda", int(os.environ.get("LOCAL_RANK", "0")) % max(torch.cuda.device_count(), 1))
     torch.cuda.set_device(dev)
     args = parse_args(str(dev))
+    if args.mode == "eval":
+        return main_eval(args, dev)
     if args.mode != "pretrain":
-        raise SystemExit("gpt-st_amd implements -mode pretrain (the encoder is reusable through GPTST_Model(mode='eval'))")
+        raise SystemExit("gpt-st_amd implements -mode pretrain and -mode eval -model STGCN")
     extra = [a for a in sys.argv[1:]]
     data_root = extra[extra.index("-data_root") + 1] if "-data_root" in extra else "../data"
     dp = None
@@ -73,6 +76,45 @@ def main():
         import torch.distributed as dist
         dp.barrier()
         dist.destroy_process_group()
+
+
+def main_eval(args, dev):
+    """``-mode eval -model STGCN``: train the STGCN predictor on the enhanced embedding of the frozen pretrained encoder (reference Run.py
+    mode 'eval', model/Model.py:20-107, model/STGCN/args.py:52-88 with the values of conf/STGCN/<dataset>.conf)."""
+    from types import SimpleNamespace
+    from gptst_amd import graph
+    from gptst_amd.enhance import EnhanceFrontEnd
+    from gptst_amd.eval_trainer import EvalTrainer
+    from gptst_amd.predictors import STGCN
+    if str(args.model) != "STGCN":
+        raise SystemExit("gpt-st_amd -mode eval implements -model STGCN (SURVEY.md §8f rank 4: one baseline predictor)")
+    extra = [a for a in sys.argv[1:]]
+    data_root = extra[extra.index("-data_root") + 1] if "-data_root" in extra else "../data"
+    init_seed(args.seed)
+    args.log_dir = os.path.join(os.path.dirname(os.path.realpath(__file__)), "SAVE", args.dataset)
+    os.makedirs(args.log_dir, exist_ok=True)
+    fname = gdata.DATASETS[args.dataset][0]
+    raw = None
+    if not os.path.exists(os.path.join(data_root, fname)):
+        F = 3 if args.dataset == "PEMS08" else args.input_base_dim
+        raw = synth.make_series(args.num_nodes, F, interval=gdata.DATASETS[args.dataset][2], seed=args.seed)
+        print("gpt-st_amd: %s not found -> synthetic %s-shaped series %s" % (os.path.join(data_root, fname), args.dataset, raw.shape))
+    g = torch.Generator().manual_seed(args.seed)
+    train, val, test, scaler, _, _ = gdata.get_dataloader(args, root=data_root, device=dev, raw=raw, generator=g)
+    args.scaler_zeros = float(scaler.transform(0))
+    csv_path = os.path.join(data_root, args.dataset, args.dataset + ".csv")
+    A = (graph.adjacency_from_distance_csv(csv_path, args.num_nodes) if os.path.exists(csv_path)
+         else graph.synthetic_adjacency(args.num_nodes, seed=args.seed))
+    ap = SimpleNamespace(Ks=3, Kt=3, num_nodes=args.num_nodes, G=graph.stgcn_graph(A), blocks1=[64, 32, 128], drop_prob=0, outputl_ks=3)
+    model = EnhanceFrontEnd(args, predictor=STGCN(ap, dev, args.hidden_dim, args.output_dim)).to(dev)
+    ckpt = args.log_dir + str(args.load_pretrain_path)                           # model/Model.py:92 (plain concatenation: '/GPTST_ada.pth')
+    if os.path.exists(ckpt):
+        model.load_pretrained_model(ckpt)                                        # model/Model.py:91-94
+    else:
+        print("gpt-st_amd: no pretrained encoder at %s -> Xavier-initialised encoder (demo run)" % ckpt)
+        for p_ in model.pretrain_model.parameters():                             # frozen (requires_grad False): xavier_init_ would skip them
+            torch.nn.init.xavier_uniform_(p_) if p_.dim() > 1 else torch.nn.init.uniform_(p_)
+    EvalTrainer(model, args, train, val, test, float(scaler.mean), float(scaler.std)).train()
 
 
 if __name__ == "__main__":

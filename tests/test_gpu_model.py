@@ -137,3 +137,51 @@ def test_enhance_front_end_consumes_pretrain_checkpoint(tmp_path):
     got.square().mean().backward()
     assert fe.fusion.output_fc.weight.grad is not None and fe.lin_test.weight.grad is not None
     assert all(p.grad is None for p in fe.pretrain_model.parameters())
+
+
+def test_eval_mode_trains_stgcn_on_the_enhanced_embedding(tmp_path):
+    """``-mode eval -model STGCN`` end to end on the GPU — frozen HIP encoder (a pretrain checkpoint) -> Fusion -> STGCN
+    predictor trained with the reference's loop (masked MAE on de-normalised values, clip, Adam), validation + per-horizon test report
+    through gptst_metrics_accum.  The predictor's arithmetic is pinned to the reference by tests/test_predictor_stgcn.py; here: the
+    encoder stays frozen, the trainable part learns (loss goes down), the report is finite."""
+    import logging
+    from types import SimpleNamespace
+    from gptst_amd import data as gdata, graph
+    from gptst_amd.enhance import EnhanceFrontEnd
+    from gptst_amd.eval_trainer import EvalTrainer
+    from gptst_amd.predictors import STGCN
+    N = 20
+    pargs = make_args("PEMS08", num_nodes=N, embed_dim=8, HS=5, HT=6, scaler_zeros=synth.scaler_zeros())
+    sd = O.init_state_dict(pargs, 4)
+    torch.save(sd, str(tmp_path / "enc.pth"))
+    eargs = make_args("PEMS08", mode="eval", num_nodes=N, embed_dim=8, HS=5, HT=6, scaler_zeros=synth.scaler_zeros(), batch_size=8,
+                      epochs=3, early_stop=False, log_dir=str(tmp_path), debug=True, model="STGCN_test")
+    raw = synth.make_series(N, 3, days=6, seed=3)
+    train, val, test, scaler, _, _ = gdata.get_dataloader(eargs, device=DEV, raw=raw, generator=torch.Generator().manual_seed(1))
+    ap = SimpleNamespace(Ks=3, Kt=3, num_nodes=N, G=graph.stgcn_graph(graph.synthetic_adjacency(N, 2)), blocks1=[64, 32, 128], drop_prob=0,
+                         outputl_ks=3)
+    torch.manual_seed(0)
+    model = EnhanceFrontEnd(eargs, predictor=STGCN(ap, DEV, eargs.hidden_dim, eargs.output_dim)).to(DEV)
+    model.load_pretrained_model(str(tmp_path / "enc.pth"))
+    enc0 = model.pretrain_model.flat.detach().clone()
+    tr = EvalTrainer(model, eargs, train, val, test, float(scaler.mean), float(scaler.std))
+    tr.logger.setLevel(logging.WARNING)
+    l1 = tr.train_epoch(1)
+    l2 = tr.train_epoch(2)
+    l3 = tr.train_epoch(3)
+    assert l3 < l1 and all(v == v for v in (l1, l2, l3)), (l1, l2, l3)
+    assert torch.equal(model.pretrain_model.flat.detach(), enc0), "the pretrained encoder must stay frozen"
+    v1, v2 = tr.val_epoch(3, val), tr.val_epoch(3, val)
+    assert abs(v1 - v2) < 1e-5 * abs(v1) and v1 == v1
+    rows = tr.test(test)
+    assert rows.shape == (13, 4) and bool(torch.isfinite(rows[:, :3]).all())
+    # the device-side report equals the plain formulas on the concatenated predictions (BasicTrainer.py:232-248, lib/metrics.py:11-43)
+    model.eval()
+    P, Y = [], []
+    with torch.no_grad():
+        for data, target in test:
+            P.append(model(data[..., :3].contiguous(), None)[0]); Y.append(target[..., :1])
+    P, Y = torch.cat(P) * float(scaler.std) + float(scaler.mean), torch.cat(Y) * float(scaler.std) + float(scaler.mean)
+    mae = float((P - Y).abs().mean())
+    assert abs(float(rows[-1, 0]) - mae) < 2e-3 * mae, (float(rows[-1, 0]), mae)
+    assert abs(float(rows[0, 0]) - float((P[:, 0] - Y[:, 0]).abs().mean())) < 2e-3 * mae
