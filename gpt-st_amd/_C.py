@@ -57,6 +57,9 @@ class _Lib:
             setattr(self, "_raw_" + name, fn)
         if self._raw_gptst_abi_version() != 1:
             raise ImportError("gpt-st_amd: ABI version mismatch")
+        for kv in filter(None, os.environ.get("GPTST_TUNE", "").split(",")):      # experiments: GPTST_TUNE="5=1,2=4" -> gptst_tune(id, value)
+            k, v = kv.split("=")
+            self._raw_gptst_tune(int(k), int(v))
 
     def call(self, name, *args):
         rc = getattr(self, "_raw_" + name)(*args)

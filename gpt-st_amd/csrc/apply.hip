@@ -965,8 +965,9 @@ extern "C" int gptst_wgrad_nsplit(int mode, int BT, int N, int C) {
     if (mode == 2) return (rm.M + 255) / 256;          // shared weight: 256-row chunks
     if (mode == 1 && g_wgrad_ns_override > 0) return g_wgrad_ns_override;
     if (mode == 0 && g_wgrad_ns0_override > 0) return g_wgrad_ns0_override;
-    if (C == 128 && !g_wgrad_v1) {                     // MFMA-bound: >= ~4 equal workgroups per CU, splits of >= 128 rows
-        int want = (1024 + rm.G - 1) / rm.G, maxs = (rm.M + 127) / 128;
+    if (C == 128 && !g_wgrad_v1) {                     // MFMA-bound: ~3 equal workgroups per CU, splits of >= 128 rows; every split is a 64 KB
+        // partial per group that the reduction jobs read back (384 groups: 2 splits 126.7, 3 splits 123.6 steps/s at N = 512; equal at N = 4096)
+        int want = (768 + rm.G - 1) / rm.G, maxs = (rm.M + 127) / 128;
         if (want > maxs) want = maxs;
         return want < 1 ? 1 : want;
     }

@@ -30,7 +30,8 @@ int gptst_abi_version(void);
 int gptst_set_deterministic(int on);
 /* launch-geometry knobs for benchmarking, not needed for correctness.  1: rows per block of the poolgen forward; 2 / 5: forced split
  * count of the NODE / TIME weight gradient; 3: 1 = first-generation (LDS-staged) apply for C = 64; 4: tiles per wave of apply64 / apply128;
- * 6: workgroups of the loss-head kernels; 7 / 8: 1 = first-generation weight gradient / apply for C = 128 */
+ * 6: workgroups of the loss-head kernels; 7 / 8: 1 = first-generation weight gradient / apply for C = 128; 10: 0 = VALU forward of the
+ * pool jobs instead of the (bit-identical) MFMA one.  The Python binding applies GPTST_TUNE="id=value,..." from the environment. */
 int gptst_tune(int id, int value);
 
 /* ---- embedding-conditioned parameter generation (poolgen.hip) -----------------------------------------

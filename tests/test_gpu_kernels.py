@@ -659,3 +659,25 @@ def test_linear_bwd_fused(rows):
     close(dX, dY @ Wp + dO * torch.where(out > 0, torch.ones_like(out), torch.full_like(out, 0.01)), what="linear_bwd dX")
     close(dWp.view(ns, C, C).sum(0), dY.t() @ X, what="linear_bwd dWp")
     close(dbp.sum(0), dY.sum(0), what="linear_bwd dbp")
+
+
+@pytest.mark.parametrize("R,K,cols", [(384, 16, 4096), (170, 16, 4096), (384, 4, 1700), (37, 5, 260), (20, 16, 64), (1, 3, 8)])
+def test_poolgen_mfma_bitwise(R, K, cols):
+    """The MFMA forward of the pool jobs reproduces the VALU forward BIT FOR BIT (an fp32 MFMA is the fmaf chain over its k values in
+    order), so switching it on changes no number anywhere downstream — and both match the fp64 product to fp32 accuracy."""
+    from gptst_amd import _C, ops
+    dev = _dev()
+    g = torch.Generator().manual_seed(5)
+    emb, pool = rnd(R, K, g=g).to(dev), rnd(K, cols, g=g).to(dev)
+    outs = []
+    for mfma in (1, 0):
+        _C.lib().call("gptst_tune", 10, mfma)
+        try:
+            J = ops.PoolJobs()
+            o = J.fwd(emb, pool)
+            J.launch()
+            outs.append(o.clone())
+        finally:
+            _C.lib().call("gptst_tune", 10, 1)
+    assert torch.equal(outs[0], outs[1])
+    close(outs[0], emb.double().cpu() @ pool.double().cpu(), what="poolgen fwd")
