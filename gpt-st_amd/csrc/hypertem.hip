@@ -6,6 +6,7 @@
 //   (it is shared by the 11 node tiles of the sample, so no LDS copy and no barrier); (3) bias + residual (from the LDS slab) +
 //   LeakyReLU, stored as whole rows.  Replaces tmix_kernel + apply_kernel<TIME> (11 + 20 us -> one launch) and the R round trip.
 #include "mfma_tile.h"
+#include "wgrad64.h"
 
 #define HT_T 12
 #ifdef GPTST_DEBUG
@@ -23,12 +24,13 @@ static constexpr int g_ht_dbg = 0, g_ht_nt_override = 0;
 // XCD-aware work map: workgroup L runs on XCD L % 8 (observed dispatch order), and all node tiles of one sample should share an
 // XCD so that the sample's twelve W_bt matrices (192 KB) are fetched into ONE L2 instead of eight (PMC: 67 MB -> expected ~23 MB
 // of fabric reads per launch).  L -> xcd = L % 8, slot = L / 8;  sample = xcd + 8 * (slot / ntiles), tile = slot % ntiles.
-__device__ __forceinline__ bool ht_work(int ntiles, int B, int& b, int& tile) {
-    const int L = blockIdx.x, xcd = L & 7, slot = L >> 3;
+__device__ __forceinline__ bool ht_work_at(int L, int ntiles, int B, int& b, int& tile) {
+    const int xcd = L & 7, slot = L >> 3;
     b = xcd + 8 * (slot / ntiles);
     tile = slot % ntiles;
     return b < B;
 }
+__device__ __forceinline__ bool ht_work(int ntiles, int B, int& b, int& tile) { return ht_work_at(blockIdx.x, ntiles, B, b, tile); }
 
 // NT (rows of the 16-row MFMA tile that are real nodes) is a run-time parameter for experiments: at (B, N) = (32, 170) the time
 // is flat for NT = 11..16 (352..512 workgroups) and 35 % worse for NT <= 10 — the MFMA / fragment work per tile does not shrink.
@@ -183,16 +185,16 @@ extern "C" int gptst_hypertem_fwd(const float* X, const float* G, const float* W
 // Scheduling notes (measured): all global loads of a phase are issued as one batch into registers (a copy loop
 // compiles to one L2 round trip per trip); dPre stays in registers for the dX phase instead of being re-read; W_bt fragments of
 // the next time step and the X operands of the dG phase are requested before the stores / atomics of the current phase.
-__global__ __launch_bounds__(256, 2) void hypertem_bwd_kernel(const float* __restrict__ dOut, const float* __restrict__ Y,
-                                                              const float* __restrict__ X, const float* __restrict__ G,
-                                                              const float* __restrict__ Wbt, float* __restrict__ dX,
-                                                              float* __restrict__ dbias, float* __restrict__ dG, int N, int B, int dbg) {
+__device__ __forceinline__ void hypertem_bwd_body(const float* __restrict__ dOut, const float* __restrict__ Y,
+                                                  const float* __restrict__ X, const float* __restrict__ G,
+                                                  const float* __restrict__ Wbt, float* __restrict__ dX,
+                                                  float* __restrict__ dbias, float* __restrict__ dG, int N, int B, int dbg, int L,
+                                                  float* __restrict__ smem) {
     constexpr int C = 64, P = C + 4, GP = 145, NT = 16;
-    extern __shared__ __attribute__((aligned(16))) float smem[];
     float* Ds = smem;                               // [12][16][P]  dPre, then dR
     float* Gs = Ds + HT_T * NT * P;                 // [16][GP]
     int b, tile;
-    if (!ht_work((N + NT - 1) / NT, B, b, tile)) return;
+    if (!ht_work_at(L, (N + NT - 1) / NT, B, b, tile)) return;
     const int n0 = tile * NT;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int nl = tid >> 4, c4 = tid & 15;         // thread = (row, float4 column) of every time slice
@@ -330,6 +332,34 @@ __global__ __launch_bounds__(256, 2) void hypertem_bwd_kernel(const float* __res
     }
 }
 
+__global__ __launch_bounds__(256, 2) void hypertem_bwd_kernel(const float* __restrict__ dOut, const float* __restrict__ Y,
+                                                              const float* __restrict__ X, const float* __restrict__ G,
+                                                              const float* __restrict__ Wbt, float* __restrict__ dX,
+                                                              float* __restrict__ dbias, float* __restrict__ dG, int N, int B, int dbg) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    hypertem_bwd_body(dOut, Y, X, G, Wbt, dX, dbias, dG, N, B, dbg, blockIdx.x, smem);
+}
+
+// ---- hyperTem backward AND its weight gradient side by side in ONE launch ---------------------------------------------------------------
+// Both consume (dOut, out) of the layer and are independent of each other: dR / dX / dG by the slab workgroups above, dW_bt (+ db_bt) by the
+// grouped weight-gradient workgroups of wgrad64.h.  As two launches they cost their fixed dependency chains one after the other
+// (tools/mb_scaling.py: ~10 us of every launch does not scale with the work); here workgroups 0 .. nH-1 take the hyperTem role (they are the
+// longer ones and keep the XCD-aware index map), the rest the weight-gradient role, and the chains overlap.
+template <int U>
+__global__ __launch_bounds__(256, 2) void hypertem_bwd_wgrad_kernel(const float* __restrict__ dOut, const float* __restrict__ Y,
+                                                                    const float* __restrict__ X, const float* __restrict__ G,
+                                                                    const float* __restrict__ Wbt, const float* __restrict__ R,
+                                                                    float* __restrict__ dX, float* __restrict__ dG, float* __restrict__ dWb,
+                                                                    int N, int B, int nH, RowMap rm, int rows_per_split) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    if ((int)blockIdx.x < nH) {
+        hypertem_bwd_body(dOut, Y, X, G, Wbt, dX, nullptr, dG, N, B, 0, blockIdx.x, smem);
+    } else {
+        const int w = blockIdx.x - nH;
+        wgrad64_body<PRO_DPRE, U>(R, dOut, Y, dWb, rm, rows_per_split, 64 * 64 + 64, 2, w % rm.G, w / rm.G, smem);
+    }
+}
+
 // dbias: (gptst_hypertem_ntiles(N) * B*T, C) node-tile partials;  dG: (B * N, T, T) per-sample partials — both fully written here.
 extern "C" int gptst_hypertem_ntiles(int N) { return (N + 15) / 16; }
 
@@ -341,6 +371,33 @@ extern "C" int gptst_hypertem_bwd(const float* dOut, const float* Y, const float
     static int done = 0;
     if (!done) { hipFuncSetAttribute((const void*)hypertem_bwd_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem); done = 1; }
     hipLaunchKernelGGL(hypertem_bwd_kernel, dim3(8 * ((B + 7) / 8) * ((N + 15) / 16)), dim3(256), smem, (hipStream_t)stream, dOut, Y, X, G, Wbt, dX, dbias, dG, N, B, g_ht_dbg);
+    GPTST_CHECK_LAUNCH();
+    return GPTST_OK;
+}
+
+// One launch for the whole backward of a hyperTem layer (C = 64): gptst_hypertem_bwd (without dbias) + gptst_wgrad_colsum(mode 0, pro 1,
+// which 2) on (R, dOut, Y).  dWb: (nsplit * B*T, C*C + C) rows [dW_bt | db_bt] with nsplit = gptst_wgrad_nsplit(0, B*T, N, 64).
+extern "C" int gptst_wgrad_nsplit(int mode, int BT, int N, int C);
+extern "C" int gptst_hypertem_bwd_wgrad(const float* dOut, const float* Y, const float* X, const float* G, const float* Wbt, const float* R,
+                                        float* dX, float* dG, float* dWb, int B, int T, int N, int C, void* stream) {
+    if (!dOut || !Y || !X || !G || !Wbt || !R || !dX || !dG || !dWb || T != HT_T) return GPTST_EARG;
+    if (C != 64) return GPTST_ESHAPE;
+    const size_t smem_h = ht_smem(16), smem_w = WGRAD64_SMEM_FLOATS * sizeof(float), smem = smem_h > smem_w ? smem_h : smem_w;
+    static int done = 0;
+    if (!done) {
+        hipFuncSetAttribute((const void*)hypertem_bwd_wgrad_kernel<4>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+        hipFuncSetAttribute((const void*)hypertem_bwd_wgrad_kernel<6>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+        done = 1;
+    }
+    const RowMap rm = make_rowmap(0, B * T, N);
+    const int ns = gptst_wgrad_nsplit(0, B * T, N, 64);
+    int rps = (rm.M + ns - 1) / ns;
+    rps = (rps + 1) & ~1;
+    const int rows = rps < rm.M ? rps : rm.M, steps = ((rows + 3) / 4 + 3) / 4;          // k-steps per wave (as wgrad_impl, apply.hip)
+    const bool u6 = (steps + 5) / 6 * 6 <= (steps + 3) / 4 * 4;
+    const int nH = 8 * ((B + 7) / 8) * ((N + 15) / 16), nW = rm.G * ns;
+    if (u6) hipLaunchKernelGGL((hypertem_bwd_wgrad_kernel<6>), dim3(nH + nW), dim3(256), smem, (hipStream_t)stream, dOut, Y, X, G, Wbt, R, dX, dG, dWb, N, B, nH, rm, rps);
+    else hipLaunchKernelGGL((hypertem_bwd_wgrad_kernel<4>), dim3(nH + nW), dim3(256), smem, (hipStream_t)stream, dOut, Y, X, G, Wbt, R, dX, dG, dWb, N, B, nH, rm, rps);
     GPTST_CHECK_LAUNCH();
     return GPTST_OK;
 }

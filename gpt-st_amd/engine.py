@@ -195,6 +195,9 @@ def hypertem_core_fwd(x, G, Wbt, bbt, dims):
     return out, (x, R, out, G, Wbt)
 
 
+FUSE_HT_BWD = True         # hyperTem backward + its weight gradient in one launch (False: two launches)
+
+
 def graph_grad_splits(dims):
     """partial graph gradients per layer: the fused C = 64 backward writes one per sample, the unfused path one in total"""
     return dims[0] if dims[3] == 64 else 1
@@ -205,7 +208,13 @@ def hypertem_core_bwd(saved, dout, dG_out, dims):
     B, T, N, C = dims
     x, R, out, G, Wbt = saved
     BT = B * T
-    if C == 64:
+    if C == 64 and CTX.SIDE is None and FUSE_HT_BWD:
+        # data / graph gradients and the weight + bias gradient side by side in one launch: rows [dW_bt | db_bt]
+        dx, dWb, ns, _ = ops.hypertem_bwd_wgrad(dout.view(B, T, N, C), out.view(B, T, N, C), x.view(B, T, N, C), G, Wbt, R.view(B, T, N, C),
+                                                dG=dG_out)
+        dWbt, dbias, nsb = dWb[:, :C * C], dWb[:, C * C:], ns
+        dx = dx.view(-1, C)
+    elif C == 64:
         # the weight-gradient kernel also emits the bias gradient (column sums of dPre per (b,t)): rows [dW_bt | db_bt]
         dWb, ns = _wgrad_async(R, dout, MODE_TIME, BT, N, D2=out, pro=PRO_DPRE, colsum_d=True)
         dWbt, dbias, nsb = dWb[:, :C * C], dWb[:, C * C:], ns

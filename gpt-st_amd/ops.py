@@ -299,6 +299,21 @@ def hypertem_bwd(dOut, Y, X, G, Wbt, dG=None, want_dbias=True):
     return dX, dbias, dG
 
 
+def hypertem_bwd_wgrad(dOut, Y, X, G, Wbt, R, dG=None):
+    """Whole backward of a hyperTem layer in ONE launch (C = 64): -> (dX, dWb (ns*BT, C*C+C) rows [dW_bt | db_bt], ns, dG (B,N,T,T)
+    per-sample partials) — hypertem_bwd(want_dbias=False) and wgrad(R, dOut, MODE_TIME, D2=Y, pro=PRO_DPRE, colsum_d=True) side by side."""
+    _chk(dOut, Y, X, G, Wbt, R, dG)
+    B, T, N, C = X.shape
+    dX = torch.empty_like(X)
+    if dG is None:
+        dG = torch.empty(B, N, T, T, device=X.device, dtype=torch.float32)
+    ns = wgrad_nsplit(MODE_TIME, B * T, N, C)
+    dWb = torch.empty(ns * B * T, C * C + C, device=X.device, dtype=torch.float32)
+    _call("gptst_hypertem_bwd_wgrad", _p(dOut), _p(Y), _p(X), _p(G), _p(Wbt), _p(R), _p(dX), _p(dG), _p(dWb), B, T, N, C,
+          nbytes=_nb(dOut, Y, X, G, Wbt, R, dX, dWb))
+    return dX, dWb, ns, dG
+
+
 def tmix_bwd(dR, X, G, dOut, Y, dG=None):
     """Backward of the temporal mixing in one pass: -> (dX = dOut*lrelu'(Y) + G (*) dR, dG (N,T,T) = sum_b dR X^T)."""
     _chk(dR, X, G, dOut, Y, dG)

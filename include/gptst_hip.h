@@ -133,6 +133,11 @@ int gptst_hypertem_fwd(const float* X, const float* G, const float* Wbt, const f
 int gptst_hypertem_ntiles(int N);
 int gptst_hypertem_bwd(const float* dOut, const float* Y, const float* X, const float* G, const float* Wbt, float* dX, float* dbias,
                        float* dG, int B, int T, int N, int C, void* stream);
+/* gptst_hypertem_bwd (without dbias) AND the layer's weight + bias gradient (gptst_wgrad_colsum mode 0, pro 1, which 2 on R, dOut, Y) side
+ * by side in ONE launch: the two are independent, and as separate launches their fixed dependency chains add up.
+ * dWb: (gptst_wgrad_nsplit(0, B*T, N, 64) * B*T, C*C + C) rows [dW_bt | db_bt].  C = 64. */
+int gptst_hypertem_bwd_wgrad(const float* dOut, const float* Y, const float* X, const float* G, const float* Wbt, const float* R, float* dX,
+                             float* dG, float* dWb, int B, int T, int N, int C, void* stream);
 
 /* ---- cap: node x cluster soft assignment + routing + aggregation (cap.hip, cap_cross.hip), GPTST.py:100-141 ----
  * route_fwd, one workgroup per (b,t):  P = squash(X Wp^T + bp) by MFMA into LDS; dadj (BT,HS,N) = teb.adj (from gptst_poolgen_fwd);

@@ -681,3 +681,27 @@ def test_poolgen_mfma_bitwise(R, K, cols):
             _C.lib().call("gptst_tune", 10, 1)
     assert torch.equal(outs[0], outs[1])
     close(outs[0], emb.double().cpu() @ pool.double().cpu(), what="poolgen fwd")
+
+
+@pytest.mark.parametrize("B,N", [(32, 170), (3, 37), (2, 16), (9, 5)])
+def test_hypertem_bwd_wgrad_one_launch_equals_two(B, N):
+    """gptst_hypertem_bwd_wgrad == gptst_hypertem_bwd + gptst_wgrad_colsum: dX, dG and the weight gradients bit for bit (same device code in
+    one grid); the bias column sums agree to the last bits (the two compilations of the shared body round a handful of entries 1 ulp
+    apart, both equally close to the fp64 sums) and are checked against fp64 as well."""
+    from gptst_amd import ops
+    from gptst_amd.ops import MODE_TIME, PRO_DPRE
+    dev = _dev()
+    g = torch.Generator().manual_seed(41)
+    C, T = 64, 12
+    X, dO = rnd(B, T, N, C, g=g).to(dev), rnd(B, T, N, C, g=g).to(dev)
+    G = (rnd(N, T, T, g=g) * 0.1).to(dev)
+    Wbt, bbt = (rnd(B * T, C, C, g=g) * 0.1).to(dev), rnd(B * T, C, g=g).to(dev)
+    R, out = ops.hypertem_fwd(X, G, Wbt, bbt)
+    dx1, _, dG1 = ops.hypertem_bwd(dO, out, X, G, Wbt, want_dbias=False)
+    dWb1, ns1 = ops.wgrad(R.view(-1, C), dO.view(-1, C), MODE_TIME, B * T, N, D2=out.view(-1, C), pro=PRO_DPRE, colsum_d=True)
+    dx2, dWb2, ns2, dG2 = ops.hypertem_bwd_wgrad(dO, out, X, G, Wbt, R)
+    assert ns1 == ns2
+    assert torch.equal(dx1, dx2) and torch.equal(dG1, dG2) and torch.equal(dWb1[:, :C * C], dWb2[:, :C * C])
+    db_ref = (dO * torch.where(out > 0, 1.0, 0.01)).view(B * T, N, C).double().sum(1).cpu()
+    close(dWb2[:, C * C:], db_ref, what="fused db")
+    assert float((dWb1[:, C * C:] - dWb2[:, C * C:]).abs().max()) <= 4e-7 * float(db_ref.abs().max())

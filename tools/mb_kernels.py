@@ -45,6 +45,7 @@ na, nr = torch.rand(B * T * N, device=dev), torch.rand(B * T * N, device=dev)
 CASES = {
     "hypertem_fwd": lambda: ops.hypertem_fwd(X, G, Wbt, bbt),
     "hypertem_bwd": lambda: ops.hypertem_bwd(dO, out, X, G, Wbt, dG=dGp, want_dbias=False),
+    "hypertem_bwd_wgrad": lambda: ops.hypertem_bwd_wgrad(dO, out, X, G, Wbt, Rr, dG=dGp),
     "wgrad_time_dpre_cs": lambda: ops.wgrad(Rr.view(-1, C), dO2, MODE_TIME, BT, N, D2=out2, pro=PRO_DPRE, colsum_d=True),
     "wgrad_node_dpre": lambda: ops.wgrad(rec, dO2, MODE_NODE, BT, N, D2=out2, pro=PRO_DPRE),
     "wgrad_shared_cs": lambda: ops.wgrad(dO2, X2, MODE_SHARED, BT, N, colsum_a=True),
