@@ -714,11 +714,13 @@ def stats_fold(sws, stats):
 _ADAM_WS = {}
 
 
-def step_begin(z0, z1, src, base):
-    """Zero z0 (and z1, may be None) and gather the time index of node 0: -> tidx (B,T,2).  One launch."""
+def step_begin(z0, z1, src, base, noise=None, rng=None):
+    """Zero z0 (and z1, may be None), gather the time index of node 0 -> tidx (B,T,2), and (noise given) fill `noise` with uniform [0,1)
+    numbers from Philox4x32-10 keyed by the int32 device words rng = [seed, step counter].  One launch."""
     B, T, N, lda = src.shape
     tidx = torch.empty(B, T, 2, device=src.device, dtype=torch.float32)
-    _call("gptst_step_begin", _p(z0), z0.numel(), _p(z1), z1.numel() if z1 is not None else 0, _p(src), _p(tidx), B * T, N, lda, base)
+    _call("gptst_step_begin", _p(z0), z0.numel(), _p(z1), z1.numel() if z1 is not None else 0, _p(src), _p(tidx), B * T, N, lda, base,
+          _p(noise), noise.numel() if noise is not None else 0, _p(rng))
     return tidx
 
 

@@ -42,17 +42,19 @@ class PretrainStep:
         self.noise = torch.zeros(M * self.base, device=self.dev)
         self.noise_ar = torch.zeros(2 * M, device=self.dev)          # adaptive phase: [noise_a | noise_r], drawn by ONE launch
         self.noise_a, self.noise_r = self.noise_ar[:M], self.noise_ar[M:]
-        # per-step host scalars in ONE device buffer / ONE H2D copy: [hyper (16 fp32) | list_c (HS int32) | adaptive_num, random_num]
-        self.hc = torch.zeros(16 + self.HS + 2, dtype=torch.int32, device=self.dev)
+        # per-step host scalars in ONE device buffer / ONE H2D copy: [hyper (16 fp32) | list_c (HS int32) | adaptive_num, random_num | rng seed, step]
+        self.hc = torch.zeros(16 + self.HS + 4, dtype=torch.int32, device=self.dev)
         self.hyper = self.hc[:16].view(torch.float32)
-        self.ctrl = self.hc[16:]
+        self.ctrl = self.hc[16:16 + self.HS + 2]
+        self.rng_words = self.hc[16 + self.HS + 2:]                  # Philox key of the step's mask noise (step_begin)
+        self.noise_seed = 1234567 + seed
         # Per-step host scalars travel through a RING of pinned slots, each guarded by an event recorded behind its H2D copies:
         # step() never synchronises, so with a single pinned buffer the host could rewrite the Adam bias corrections / class
         # order of step k+j before the DMA of step k has read them (hundreds of steps are queued back to back by bench.py).
         self._ring = []
         for _ in range(self.RING):
-            hc = torch.zeros(16 + self.HS + 2, dtype=torch.int32).pin_memory()
-            self._ring.append(dict(hc=hc, hyper=hc[:16].view(torch.float32), ctrl=hc[16:], ev=None))
+            hc = torch.zeros(16 + self.HS + 4, dtype=torch.int32).pin_memory()
+            self._ring.append(dict(hc=hc, hyper=hc[:16].view(torch.float32), ctrl=hc[16:16 + self.HS + 2], rng=hc[16 + self.HS + 2:], ev=None))
         self._ring_i = 0
         self.phase_kl = False                                        # phase of the last enqueued step (losses())
         self.stats_out = torch.zeros(8, device=self.dev)            # snapshot of stats after the step (graph output)
@@ -71,7 +73,6 @@ class PretrainStep:
         self.W = dp.world if dp is not None else 1
         self.gmask = bool(global_mask) and dp is not None and self.W > 1
         if self.gmask:
-            torch.cuda.manual_seed(1234567 + seed)              # every rank draws the same global mask noise
             Mg = M * self.W
             self.noise_g = torch.zeros(Mg * self.base, device=self.dev)
             self.noise_ar_g = torch.zeros(2 * Mg, device=self.dev)
@@ -98,7 +99,10 @@ class PretrainStep:
         engine.CTX.SIDE = self.side
         src = self.src
         # zero_grad + the step's zero scratch + the time index of node 0: one launch
-        tidx = ops.step_begin(self.gbuf, self.arena.begin(zero=False), src, base)
+        noise = None                                              # the step's mask noise is drawn by the same launch (unless injected / forced)
+        if not self.inject_noise and not self.force_mask:
+            noise = (self.noise_g if phase == 0 else self.noise_ar_g) if self.gmask else (self.noise if phase == 0 else self.noise_ar)
+        tidx = ops.step_begin(self.gbuf, self.arena.begin(zero=False), src, base, noise=noise, rng=self.rng_words)
         gen = engine.gen_all(p, tidx, dims)                       # time embeddings + every generated parameter: 3 launches
         red = engine.Reductions(side=self.red_side)
         prob, sv_g = engine.guide_fwd(p, src, tidx, dims, base, gen=gen["guide"])
@@ -116,11 +120,6 @@ class PretrainStep:
         if self.gmask:
             mask = self._global_mask(phase)
         else:
-            if not self.inject_noise:
-                if phase == 0:
-                    self.noise.uniform_()
-                else:
-                    self.noise_ar.uniform_()
             if self.force_mask:
                 mask = self.mask_buf
             elif phase == 0:
@@ -162,11 +161,6 @@ class PretrainStep:
         Mg = M * self.W
         if self.force_mask:
             return self.mask_buf
-        if not self.inject_noise:
-            if phase == 0:
-                self.noise_g.uniform_()
-            else:
-                self.noise_ar_g.uniform_()
         if phase == 0:
             mask_g = ops.mask_random(self.noise_g, int(Mg * base * a.mask_ratio))
         else:                                              # label_g was gathered by _exchange_labels(); class histogram taken inside
@@ -218,6 +212,7 @@ class PretrainStep:
         h[4], h[5], h[6] = b1, b2, 1e-8
         h[7] = float(a.max_grad_norm) if a.grad_norm else 0.0
         h[8] = 1.0 if phase == 1 else 0.0
+        sl["rng"][0], sl["rng"][1] = self.noise_seed & 0x7FFFFFFF, self.tA & 0x7FFFFFFF      # same key on every rank: same global noise
         h[9] = 1.0          # the backward carries the gradient of the SUM loss: the optimiser divides path A by the (global) kept count
         h[10] = 1.0
         if phase == 1:

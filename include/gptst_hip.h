@@ -281,9 +281,10 @@ int gptst_timefeat_jobs(int njobs, int bwd, const void* const* params, const voi
 
 /* start of a step in one launch (stepbegin.hip): zero z0[0..n0) (the [flat gradient | statistics] buffer: optimizer.zero_grad,
  * BasicTrainer.py:79) and z1[0..n1) (the step's zero-initialised scratch; may be NULL), and gather tidx (BT,2) = src[:, 0, base:base+2]
- * from src (BT, N, lda) (GPTST.py:256-257; tidx may be NULL). */
+ * from src (BT, N, lda) (GPTST.py:256-257; tidx may be NULL); noise[0..n_noise) (may be NULL) <- the step's mask noise, uniform [0,1)
+ * (torch.rand_like of GPTST.py:316,367,391) from Philox4x32-10 keyed by the DEVICE words rng[0] = seed, rng[1] = step counter. */
 int gptst_step_begin(float* z0, long n0, float* z1, long n1, const float* src, float* tidx, int BT, int N, int lda, int base,
-                     void* stream);
+                     float* noise, long n_noise, const int* rng, void* stream);
 
 /* ---- loss + optimiser (loss_adam.hip) ---------------------------------------------------------------------
  * stats: device float[8] zeroed once per step: [0] sum|y-p| [1] kept count [2] KL sum [3] extra sum g^2 terms (in; node-sharded

@@ -705,3 +705,38 @@ def test_hypertem_bwd_wgrad_one_launch_equals_two(B, N):
     db_ref = (dO * torch.where(out > 0, 1.0, 0.01)).view(B * T, N, C).double().sum(1).cpu()
     close(dWb2[:, C * C:], db_ref, what="fused db")
     assert float((dWb1[:, C * C:] - dWb2[:, C * C:]).abs().max()) <= 4e-7 * float(db_ref.abs().max())
+
+
+def _philox_ref(i, step, seed):
+    """Philox4x32-10 (Salmon et al. 2011) in plain Python: counter (i_lo, i_hi, step, 0), key (seed, 0x5EED) -> four uniforms in [0,1)"""
+    M0, M1, W0, W1, mask = 0xD2511F53, 0xCD9E8D57, 0x9E3779B9, 0xBB67AE85, 0xFFFFFFFF
+    c, k = [i & mask, (i >> 32) & mask, step, 0], [seed, 0x5EED]
+    for _ in range(10):
+        p0, p1 = M0 * c[0], M1 * c[2]
+        c = [((p1 >> 32) ^ c[1] ^ k[0]) & mask, p1 & mask, ((p0 >> 32) ^ c[3] ^ k[1]) & mask, p0 & mask]
+        k = [(k[0] + W0) & mask, (k[1] + W1) & mask]
+    return [(w >> 8) * 2.0 ** -24 for w in c]
+
+
+def test_step_begin_draws_philox_noise():
+    """gptst_step_begin fills the step's mask noise with Philox4x32-10 uniforms keyed by device words (seed, step): exact against a Python
+    restatement of the published algorithm, in [0,1), uniform, and a different stream per step."""
+    from gptst_amd import ops
+    dev = _dev()
+    src = torch.zeros(2, 12, 5, 3, device=dev)
+    z0 = torch.ones(64, device=dev)
+    n = 65280 * 2 + 3
+    noise = torch.full((n,), -1.0, device=dev)
+    rng = torch.tensor([1234567, 42], dtype=torch.int32, device=dev)
+    ops.step_begin(z0, None, src, 1, noise=noise, rng=rng)
+    u = noise.cpu()
+    assert float(z0.abs().max()) == 0.0
+    for i in (0, 1, 17, n // 4 - 1, n // 4):                       # n // 4: the ragged tail (3 values)
+        ref = _philox_ref(i, 42, 1234567)
+        got = u[4 * i:4 * i + 4].tolist()
+        assert got == [float(torch.tensor(v, dtype=torch.float32)) for v in ref[:len(got)]], (i, got, ref)
+    assert float(u.min()) >= 0.0 and float(u.max()) < 1.0
+    assert abs(float(u.mean()) - 0.5) < 5e-3 and abs(float(u.var()) - 1 / 12) < 2e-3
+    noise2 = torch.empty_like(noise)
+    ops.step_begin(z0, None, src, 1, noise=noise2, rng=torch.tensor([1234567, 43], dtype=torch.int32, device=dev))
+    assert float((noise2.cpu() == u).float().mean()) < 1e-3
