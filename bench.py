@@ -34,6 +34,8 @@ def kernel_flops(name, tag, d):
         return 2.0 * rows * C * C + 2.0 * rows * C * T
     if name == "gptst_hypertem_bwd":                      # dR = dPre W^T, dX = G^T dR, dG = dR X^T
         return 2.0 * rows * C * C + 4.0 * rows * C * T
+    if name == "gptst_hypertem_bwd_wgrad":                # + dW_bt = R^T dPre in the same launch
+        return 4.0 * rows * C * C + 4.0 * rows * C * T
     if name in ("gptst_tmix", "gptst_tmix_dgraph"):
         return 2.0 * rows * C * T
     if name == "gptst_cap_route_fwd":
@@ -51,6 +53,7 @@ def kernel_flops(name, tag, d):
 KERNEL_SYMBOL = {
     "gptst_cap_route_fwd": "void cap_route_fwd2_kernel<64,", "gptst_cap_route_bwd": "void cap_route_bwd2_kernel<64>",
     "gptst_hypertem_fwd": "hypertem_fwd_kernel", "gptst_hypertem_bwd": "hypertem_bwd_kernel", "gptst_wgrad": "void wgrad64_kernel",
+    "gptst_hypertem_bwd_wgrad": "void hypertem_bwd_wgrad_kernel<",
     "gptst_apply": "void apply64_kernel<", "gptst_tmix": "void tmix_kernel<64", "gptst_tmix_dgraph": "void tmix_dgraph_kernel<64>",
     "gptst_cap_rec_bwd": "void cap_rec_bwd2_kernel<64>", "gptst_cap_cross_bwd": "void cap_cross_bwd_kernel<64>",
     "gptst_cap_rec_fwd": "void cap_rec_fwd_kernel<64>",
