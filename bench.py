@@ -18,6 +18,12 @@ import time
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
+# The bench prints exactly ONE line on stdout.  RCCL writes its version banner (and at WARN its warnings) to STDOUT when NCCL_DEBUG is exported
+# (NCCL_DEBUG=VERSION on the GPU boxes; NCCL_DEBUG_FILE does not move the banner), and through C stdio it lands AFTER the JSON line when
+# stdout is a pipe: the variable is dropped for this process and its ranks unless GPTST_KEEP_NCCL_DEBUG=1.
+if os.environ.get("GPTST_KEEP_NCCL_DEBUG", "0") != "1":
+    os.environ.pop("NCCL_DEBUG", None)
+
 import torch  # noqa: E402
 
 HBM_PEAK = 8.0e12          # B/s   (MI355X_MICROARCH.md: 8 TB/s spec)
@@ -192,6 +198,9 @@ def main():
                     help="data parallel only: weak = every rank steps its own batch of --batch (default); strong = ONE global batch of "
                          "--global-batch samples split evenly over the ranks (SURVEY 8d c3: 256 = 32 x 8)")
     ap.add_argument("--global-batch", type=int, default=256, help="global batch of --scaling strong")
+    ap.add_argument("--native-comm", action="store_true",
+                    help="--shard nodes: collectives on the C-ABI communicator (RCCL enqueues on the launch stream), the whole sharded step "
+                         "in ONE hipGraph per phase also with several ranks (default: torch.distributed between eagerly enqueued kernels)")
     ap.add_argument("--no-graph", action="store_true")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-timing", action="store_true")
@@ -242,7 +251,12 @@ def main():
         model.load_state_dict(sd_l)
         model = model.to(dev)
         del gmodel
-        stepper = ShardedPretrainStep(model, largs, N, DistNodeGroup(rank, world), synth.SCALER_MEAN, synth.SCALER_STD, batch_size=B, seed=7,
+        group = DistNodeGroup(rank, world)
+        if a.native_comm:
+            from gptst_amd.dist import NativeComm
+            from gptst_amd.shard import NativeNodeGroup
+            group = NativeNodeGroup(NativeComm(rank=rank, world=world))
+        stepper = ShardedPretrainStep(model, largs, N, group, synth.SCALER_MEAN, synth.SCALER_STD, batch_size=B, seed=7,
                                       use_graph=False if a.no_graph else None)     # None: hipGraph when the collectives are capturable (world = 1)
         gsrc = synth.make_batch(B, T, N, args.input_base_dim, interval=args.interval, seed=2024)
         src = gsrc[:, :, rank * Nl:(rank + 1) * Nl].contiguous().to(dev)
