@@ -70,6 +70,18 @@ def test_bench_rccl_backend():
     assert out["value"] > 0 and out["last_loss"] == out["last_loss"] and out["last_loss"] > 0
 
 
+def test_bench_stdout_is_one_line_with_rccl_banner_enabled():
+    """The GPU boxes export NCCL_DEBUG=VERSION: RCCL then prints a version banner to STDOUT, which (C stdio, pipe) lands behind the JSON
+    line.  The bench drops the variable for itself and its ranks: the RCCL path still prints exactly one line, and it is the JSON."""
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    env.update(GPTST_FORCE_DP="1", GPTST_DIST_BACKEND="nccl", NCCL_DEBUG="VERSION")
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "4", "--warmup", "2", "--batch", "4", "--no-cpu-baseline",
+                        "--no-kernel-timing"], cwd=ROOT, env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = r.stdout.splitlines()
+    assert len(lines) == 1 and json.loads(lines[0])["value"] > 0, r.stdout[-2000:]
+
+
 def test_native_comm_allreduce_inside_a_graph():
     """C-ABI communication entry points (gptst_comm_* / gptst_allreduce_f32: RCCL bound at run time) with one rank: the all-reduce is an
     ordinary stream enqueue — eager and captured in a hipGraph together with a kernel — and leaves a 1-rank sum unchanged."""
