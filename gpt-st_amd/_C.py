@@ -37,6 +37,11 @@ def parse_header(path=HEADER):
     return protos
 
 
+def header_abi_version(path=HEADER):
+    """GPTST_ABI_VERSION of include/gptst_hip.h: bumped whenever an exported signature or a workspace size changes."""
+    return int(re.search(r"#define\s+GPTST_ABI_VERSION\s+(\d+)", open(path).read()).group(1))
+
+
 class GptstError(RuntimeError):
     code = 0
 
@@ -55,8 +60,10 @@ class _Lib:
             fn.argtypes = types
             fn.restype = ctypes.c_int
             setattr(self, "_raw_" + name, fn)
-        if self._raw_gptst_abi_version() != 1:
-            raise ImportError("gpt-st_amd: ABI version mismatch")
+        want, got = header_abi_version(), self._raw_gptst_abi_version()
+        if got != want:             # a stale .so called with this header's prototypes would get shifted arguments, not an error
+            raise ImportError("gpt-st_amd: %s has ABI version %d, include/gptst_hip.h declares %d — rebuild (python -m gptst_amd.build)"
+                              % (LIB_PATH, got, want))
         for kv in filter(None, os.environ.get("GPTST_TUNE", "").split(",")):      # experiments: GPTST_TUNE="5=1,2=4" -> gptst_tune(id, value)
             k, v = kv.split("=")
             self._raw_gptst_tune(int(k), int(v))

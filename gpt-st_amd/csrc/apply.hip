@@ -333,7 +333,10 @@ __global__ __launch_bounds__(256, 2) void wgrad64_kernel(const float* __restrict
 // KIND 0: generated-weight layer (above).  KIND 1: the shared Linear at the entry of `cap` (P = squash(X Wp^T + bp), GPTST.py:102) together
 // with the residual branch of the layer:  dX = dY Wp + dOut*lrelu'(out),  dWp = dY^T X,  dbp = colsum(dY)  — here "dOut" carries dY (no
 // activation), S = X, W = Wp ([out][in], used untransposed), and resid / resid2 = the layer's output gradient and output.
-template <int KIND>
+// CHAIN (the "dPre chain" of include/gptst_hip.h): 0 = the incoming gradient is dOut and the layer's output Y (KIND 1: resid2) gives the sign;
+// 1 = the incoming gradient already is dPre (Y / the layer output are never read);  2 = as 1, and the result is multiplied by lrelu'(S)
+// (S = the layer's input, the output of the LeakyReLU layer below — KIND 1 reads it from resid2 = S in the accumulator layout: an L1/L2 hit).
+template <int KIND, int CHAIN>
 __global__ __launch_bounds__(256, 2) void applywg64_kernel(const float* __restrict__ dOut, const float* __restrict__ Y,
                                                             const float* __restrict__ S, const float* __restrict__ W, long w_gstride,
                                                             const float* __restrict__ resid, const float* __restrict__ resid2,
@@ -356,7 +359,7 @@ __global__ __launch_bounds__(256, 2) void applywg64_kernel(const float* __restri
             const int m = min(t * 16 + 4 * s4 + kk, rm.M - 1);
             const size_t off = ((size_t)g * rm.rs_g + (size_t)m * rm.rs_m) * C + 4 * j;
             d[s4] = ld4(dOut + off); a[s4] = ld4(S + off);
-            if (KIND == 0) y[s4] = ld4(Y + off);
+            if (KIND == 0 && CHAIN == 0) y[s4] = ld4(Y + off);
         }
     };
     if (t0 < t1) fetch(t0);                          // in flight while the weight is staged
@@ -380,8 +383,8 @@ __global__ __launch_bounds__(256, 2) void applywg64_kernel(const float* __restri
 #pragma unroll
         for (int s4 = 0; s4 < 4; ++s4) {
             float4 v = d[s4];
-            if (KIND == 0) v = make_float4(d[s4].x * lrelu_grad_from_out(y[s4].x), d[s4].y * lrelu_grad_from_out(y[s4].y),
-                                           d[s4].z * lrelu_grad_from_out(y[s4].z), d[s4].w * lrelu_grad_from_out(y[s4].w));
+            if (KIND == 0 && CHAIN == 0) v = make_float4(d[s4].x * lrelu_grad_from_out(y[s4].x), d[s4].y * lrelu_grad_from_out(y[s4].y),
+                                                         d[s4].z * lrelu_grad_from_out(y[s4].z), d[s4].w * lrelu_grad_from_out(y[s4].w));
             if (t * 16 + 4 * s4 + kk >= rm.M) v = f4zero();
             d[s4] = v;
             cs = f4add(cs, v);
@@ -406,12 +409,14 @@ __global__ __launch_bounds__(256, 2) void applywg64_kernel(const float* __restri
         const int tcur = t;
         if (KIND == 0 && t + 1 < t1) fetch(t + 1);   // next tile's operands: in flight during the 64 MFMAs below
         float4 rv[4], rv2[4];
-        if (KIND == 1) {                             // residual branch operands of the epilogue, in the D layout
+        if (KIND == 1 || CHAIN == 2) {               // residual branch operands / sign operand of the epilogue, in the D layout
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 const int m = min(tcur * 16 + kk * 4 + r, rm.M - 1);
                 const size_t off = ((size_t)g * rm.rs_g + (size_t)m * rm.rs_m) * C + 4 * j;
-                rv[r] = ld4(resid + off); rv2[r] = ld4(resid2 + off);
+                if (KIND == 1) rv[r] = ld4(resid + off);
+                if (KIND == 1 && CHAIN != 1) rv2[r] = ld4(resid2 + off);
+                if (KIND == 0 && CHAIN == 2) rv2[r] = ld4(S + off);
             }
         }
         SB();
@@ -434,9 +439,14 @@ __global__ __launch_bounds__(256, 2) void applywg64_kernel(const float* __restri
         for (int r = 0; r < 4; ++r) {
             const int m = tcur * 16 + kk * 4 + r;
             float4 o4 = make_float4(acc[0][r], acc[1][r], acc[2][r], acc[3][r]);
-            if (KIND == 1) {
+            if (KIND == 1 && CHAIN == 0) {
                 o4.x = fmaf(rv[r].x, lrelu_grad_from_out(rv2[r].x), o4.x); o4.y = fmaf(rv[r].y, lrelu_grad_from_out(rv2[r].y), o4.y);
                 o4.z = fmaf(rv[r].z, lrelu_grad_from_out(rv2[r].z), o4.z); o4.w = fmaf(rv[r].w, lrelu_grad_from_out(rv2[r].w), o4.w);
+            }
+            if (KIND == 1 && CHAIN != 0) o4 = f4add(o4, rv[r]);
+            if (CHAIN == 2) {
+                o4.x *= lrelu_grad_from_out(rv2[r].x); o4.y *= lrelu_grad_from_out(rv2[r].y);
+                o4.z *= lrelu_grad_from_out(rv2[r].z); o4.w *= lrelu_grad_from_out(rv2[r].w);
             }
             if (m < rm.M) st4(dS + ((size_t)g * rm.rs_g + (size_t)m * rm.rs_m) * C + 4 * j, o4);
         }
@@ -473,21 +483,26 @@ extern "C" int gptst_apply_wgrad_nsplit(int mode, int BT, int N) {
 }
 
 // dS (rows, C), dW (nsplit*G, C, C), colsum (nsplit*G, C) or NULL; W (G, C, C) row-major [in][out] as in the forward.  C = 64.
+// Y == NULL: dOut already is dPre;  premul: dS is multiplied by lrelu'(S) (dPre-chain convention, include/gptst_hip.h) — not with Y.
 extern "C" int gptst_apply_wgrad(const float* dOut, const float* Y, const float* S, const float* W, float* dS, float* dW, float* colsum,
-                                 int mode, int BT, int N, int C, void* stream) {
-    if (!dOut || !Y || !S || !W || !dS || !dW || BT <= 0 || N <= 0 || mode < 0 || mode > 1) return GPTST_EARG;
+                                 int premul, int mode, int BT, int N, int C, void* stream) {
+    if (!dOut || !S || !W || !dS || !dW || BT <= 0 || N <= 0 || mode < 0 || mode > 1 || (Y && premul)) return GPTST_EARG;
     if (C != 64) return GPTST_ESHAPE;
     RowMap rm = make_rowmap(mode, BT, N);
     int tpw, gy;
     apply64_geometry(rm, false, tpw, gy);
-    hipLaunchKernelGGL(applywg64_kernel<0>, dim3(rm.G, gy), dim3(256), 0, (hipStream_t)stream, dOut, Y, S, W, (long)C * C, nullptr, nullptr, dS,
-                       dW, colsum, rm, tpw);
+    const dim3 grid(rm.G, gy);
+    hipStream_t st = (hipStream_t)stream;
+    if (Y) hipLaunchKernelGGL((applywg64_kernel<0, 0>), grid, dim3(256), 0, st, dOut, Y, S, W, (long)C * C, nullptr, nullptr, dS, dW, colsum, rm, tpw);
+    else if (!premul) hipLaunchKernelGGL((applywg64_kernel<0, 1>), grid, dim3(256), 0, st, dOut, Y, S, W, (long)C * C, nullptr, nullptr, dS, dW, colsum, rm, tpw);
+    else hipLaunchKernelGGL((applywg64_kernel<0, 2>), grid, dim3(256), 0, st, dOut, Y, S, W, (long)C * C, nullptr, nullptr, dS, dW, colsum, rm, tpw);
     GPTST_CHECK_LAUNCH();
     return GPTST_OK;
 }
 
 // Backward through the shared Linear at the entry of cap plus the residual branch of the layer (GPTST.py:102,139-141), one pass:
 //   dX = dY Wp + dOut*lrelu'(out);  per row split s < gptst_linear_bwd_nsplit: dWp[s] = dY^T X ([out][in]), dbp[s] = colsum(dY).
+//   out == NULL: dOut already is dPre ->  dX = dY Wp + dPre, and with premul  dX = (dY Wp + dPre) * lrelu'(X).
 // Replaces gptst_apply(mode 2, epi 2) + gptst_wgrad_colsum(mode 2).  rows = BT*N.  C = 64.
 extern "C" int gptst_linear_bwd_nsplit(int rows) {
     RowMap rm = make_rowmap(2, rows, 1);
@@ -497,13 +512,16 @@ extern "C" int gptst_linear_bwd_nsplit(int rows) {
 }
 
 extern "C" int gptst_linear_bwd(const float* dY, const float* X, const float* Wp, const float* dOut, const float* out, float* dX, float* dWp,
-                                float* dbp, int rows, int C, void* stream) {
-    if (!dY || !X || !Wp || !dOut || !out || !dX || !dWp || !dbp || rows <= 0) return GPTST_EARG;
+                                float* dbp, int premul, int rows, int C, void* stream) {
+    if (!dY || !X || !Wp || !dOut || !dX || !dWp || !dbp || rows <= 0 || (out && premul)) return GPTST_EARG;
     if (C != 64) return GPTST_ESHAPE;
     RowMap rm = make_rowmap(2, rows, 1);
     int tpw, gy;
     apply64_geometry(rm, false, tpw, gy);
-    hipLaunchKernelGGL(applywg64_kernel<1>, dim3(1, gy), dim3(256), 0, (hipStream_t)stream, dY, nullptr, X, Wp, 0L, dOut, out, dX, dWp, dbp, rm, tpw);
+    hipStream_t st = (hipStream_t)stream;
+    if (out) hipLaunchKernelGGL((applywg64_kernel<1, 0>), dim3(1, gy), dim3(256), 0, st, dY, nullptr, X, Wp, 0L, dOut, out, dX, dWp, dbp, rm, tpw);
+    else if (!premul) hipLaunchKernelGGL((applywg64_kernel<1, 1>), dim3(1, gy), dim3(256), 0, st, dY, nullptr, X, Wp, 0L, dOut, nullptr, dX, dWp, dbp, rm, tpw);
+    else hipLaunchKernelGGL((applywg64_kernel<1, 2>), dim3(1, gy), dim3(256), 0, st, dY, nullptr, X, Wp, 0L, dOut, X, dX, dWp, dbp, rm, tpw);
     GPTST_CHECK_LAUNCH();
     return GPTST_OK;
 }

@@ -139,7 +139,7 @@ __global__ __launch_bounds__(256, 2) void hypertem_fwd_kernel(const float* __res
         TS();
         // R_t (kept for the weight gradient) is stored only now, together with the output rows: every store of a time step is
         // issued BEHIND the next step's W_bt loads (vmcnt retires in order)
-        if (j < NT && n0 + j < N) {
+        if (R_out != nullptr && j < NT && n0 + j < N) {        // (NULL: the backward rebuilds R from X, see wgrad64_mix_body)
 #pragma unroll
             for (int q = 0; q < C / 16; ++q) st4(R_out + (g * N + n0 + j) * C + 16 * q + 4 * kk, a4[q]);
         }
@@ -161,7 +161,7 @@ static size_t ht_smem(int NT) { return ((size_t)HT_T * NT * 68 + NT * 145) * siz
 
 extern "C" int gptst_hypertem_fwd(const float* X, const float* G, const float* Wbt, const float* bbt, float* R_out, float* out, int B,
                                   int T, int N, int C, void* stream) {
-    if (!X || !G || !Wbt || !bbt || !R_out || !out || T != HT_T) return GPTST_EARG;
+    if (!X || !G || !Wbt || !bbt || !out || T != HT_T) return GPTST_EARG;       // R_out may be NULL
     if (C != 64) return GPTST_ESHAPE;
     static int done = 0;
     if (!done) { hipFuncSetAttribute((const void*)hypertem_fwd_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ht_smem(16)); done = 1; }
@@ -172,12 +172,16 @@ extern "C" int gptst_hypertem_fwd(const float* X, const float* G, const float* W
 }
 
 // =====================================================================================================================
-// hyperTem backward, fused (everything except the weight gradient, which is grouped by (b,t) and stays in wgrad64_kernel):
-//   dPre = dOut * lrelu'(out)                               (LDS slab, 12 x 16 x C per workgroup = (sample, 16 nodes))
+// hyperTem backward, fused (everything except the weight gradient, which is grouped by (b,t): wgrad role below):
+//   dPre = dOut * lrelu'(out)   [Y given]   or   dPre = dOut  [Y == NULL: the producer already multiplied, see PREMUL]
 //   dbias[tile][b,t,:] = sum_{n in tile} dPre               (column sums of the slab: one PARTIAL per node tile, plain stores)
 //   dR_t = dPre_t W_bt^T                                    MFMA 16x16x4 as  dR_t^T = W_bt dPre_t^T  so that W_bt (L2) is the
 //                                                           A operand with coalesced float4 rows; result overwrites the slab
-//   dX_u = dPre_u + sum_t G_n[t,u] dR_t                     VALU from the slab (dPre re-read from L2)
+//   dX_u = dPre_u + sum_t G_n[t,u] dR_t                     VALU from the slab (dPre kept in registers)
+//   PREMUL: dX_u *= lrelu'(X_u)                             X is the OUTPUT of the layer below (a LeakyReLU), so what leaves this kernel is
+//                                                           already that layer's dPre: no backward kernel has to read its own output
+//                                                           only for the sign (one 16.7 MB read per layer and role, r03).  The signs
+//                                                           are taken from X in the first load batch and kept as 48 bits per thread.
 //   dG[b][n][t,u] = sum_c dR_t[n,c] X_u[n,c]                MFMA 16x16x4 per node: one PARTIAL per sample (gram_bwd sums them)
 // No atomics: every output element is written by exactly one lane, so the result does not depend on scheduling.
 // Replaces apply_kernel<TIME, dPre> + tmix_kernel<bwd> + tmix_dgraph_kernel (19 + 14 + 11 us, and the dR round trip).
@@ -185,6 +189,7 @@ extern "C" int gptst_hypertem_fwd(const float* X, const float* G, const float* W
 // Scheduling notes (measured): all global loads of a phase are issued as one batch into registers (a copy loop
 // compiles to one L2 round trip per trip); dPre stays in registers for the dX phase instead of being re-read; W_bt fragments of
 // the next time step and the X operands of the dG phase are requested before the stores / atomics of the current phase.
+template <bool HASY, bool PREMUL>
 __device__ __forceinline__ void hypertem_bwd_body(const float* __restrict__ dOut, const float* __restrict__ Y,
                                                   const float* __restrict__ X, const float* __restrict__ G,
                                                   const float* __restrict__ Wbt, float* __restrict__ dX,
@@ -214,23 +219,32 @@ __device__ __forceinline__ void hypertem_bwd_body(const float* __restrict__ dOut
     // each, and wave w runs its time step 4*group + w right after its group has landed — the dR phase of the first groups overlaps
     // with the arrival of the later ones instead of waiting for the whole 33 MB burst (r02: loads 12 us + time-step loop 12 us were
     // strictly serial; measured gain 30.0 -> 29.3 us: the kernel is bound by the per-workgroup dependency chain, not by this overlap).
+    // yv: the layer's output (HASY: sign of dPre) or its input X (PREMUL: sign of the outgoing gradient) — never both.
+    static_assert(!(HASY && PREMUL), "one sign operand per launch");
+    const float* __restrict__ Sg = HASY ? Y : X;
     float4 yv[HT_T];
     float gv[9];
+    unsigned sb0 = 0u, sb1 = 0u;                    // PREMUL: bit 4*t + e of (sb0 | sb1 << 32) = (X_t[row][4*c4 + e] > 0)
 #pragma unroll
-    for (int t = 0; t < 4; ++t) { dp[t] = ld4(dOut + rowoff + (size_t)t * N * C); yv[t] = ld4(Y + rowoff + (size_t)t * N * C); }
+    for (int t = 0; t < 4; ++t) { dp[t] = ld4(dOut + rowoff + (size_t)t * N * C); if (HASY || PREMUL) yv[t] = ld4(Sg + rowoff + (size_t)t * N * C); }
 #pragma unroll
     for (int k = 0; k < 9; ++k) gv[k] = G[min(n0 * 144 + tid + k * 256, N * 144 - 1)];
     HT_LOAD_WT(wave);
 #pragma unroll
-    for (int t = 4; t < HT_T; ++t) { dp[t] = ld4(dOut + rowoff + (size_t)t * N * C); yv[t] = ld4(Y + rowoff + (size_t)t * N * C); }
+    for (int t = 4; t < HT_T; ++t) { dp[t] = ld4(dOut + rowoff + (size_t)t * N * C); if (HASY || PREMUL) yv[t] = ld4(Sg + rowoff + (size_t)t * N * C); }
     SB();
 #pragma unroll
     for (int grp = 0; grp < HT_T / 4; ++grp) {
 #pragma unroll
         for (int tt = 0; tt < 4; ++tt) {
             const int t = 4 * grp + tt;
-            float4 v = make_float4(dp[t].x * lrelu_grad_from_out(yv[t].x), dp[t].y * lrelu_grad_from_out(yv[t].y),
-                                   dp[t].z * lrelu_grad_from_out(yv[t].z), dp[t].w * lrelu_grad_from_out(yv[t].w));
+            float4 v = dp[t];
+            if (HASY) v = make_float4(dp[t].x * lrelu_grad_from_out(yv[t].x), dp[t].y * lrelu_grad_from_out(yv[t].y),
+                                      dp[t].z * lrelu_grad_from_out(yv[t].z), dp[t].w * lrelu_grad_from_out(yv[t].w));
+            if (PREMUL) {
+                const unsigned m4 = (yv[t].x > 0.f ? 1u : 0u) | (yv[t].y > 0.f ? 2u : 0u) | (yv[t].z > 0.f ? 4u : 0u) | (yv[t].w > 0.f ? 8u : 0u);
+                if (t < 8) sb0 |= m4 << (4 * t); else sb1 |= m4 << (4 * (t - 8));
+            }
             if (!valid) v = f4zero();
             dp[t] = v;
             st4(Ds + (t * NT + nl) * P + 4 * c4, v);
@@ -304,6 +318,11 @@ __device__ __forceinline__ void hypertem_bwd_body(const float* __restrict__ dOut
             float4 acc = dp[u];
 #pragma unroll
             for (int t = 0; t < HT_T; ++t) acc = f4fma(gr[t * HT_T + u], dr[t], acc);
+            if (PREMUL) {
+                const unsigned m4 = (u < 8 ? sb0 >> (4 * u) : sb1 >> (4 * (u - 8))) & 15u;
+                acc.x *= (m4 & 1u) ? 1.f : LRELU_SLOPE; acc.y *= (m4 & 2u) ? 1.f : LRELU_SLOPE;
+                acc.z *= (m4 & 4u) ? 1.f : LRELU_SLOPE; acc.w *= (m4 & 8u) ? 1.f : LRELU_SLOPE;
+            }
             if (!(HT_DBG(dbg) & 8)) st4(dX + rowoff + (size_t)u * N * C, acc);
             SB();
         }
@@ -332,12 +351,90 @@ __device__ __forceinline__ void hypertem_bwd_body(const float* __restrict__ dOut
     }
 }
 
+template <bool HASY, bool PREMUL>
 __global__ __launch_bounds__(256, 2) void hypertem_bwd_kernel(const float* __restrict__ dOut, const float* __restrict__ Y,
                                                               const float* __restrict__ X, const float* __restrict__ G,
                                                               const float* __restrict__ Wbt, float* __restrict__ dX,
                                                               float* __restrict__ dbias, float* __restrict__ dG, int N, int B, int dbg) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
-    hypertem_bwd_body(dOut, Y, X, G, Wbt, dX, dbias, dG, N, B, dbg, blockIdx.x, smem);
+    hypertem_bwd_body<HASY, PREMUL>(dOut, Y, X, G, Wbt, dX, dbias, dG, N, B, dbg, blockIdx.x, smem);
+}
+
+// ---- weight-gradient role WITHOUT a saved R (r03) -----------------------------------------------------------------------------------------
+// dW_bt = sum_n R_t[n,:]^T dPre_t[n,:] needs R_t[n,:] = sum_u G_n[t,u] X_u[n,:].  Keeping R costs a 16.7 MB write in the forward and a 16.7 MB
+// read here; instead the (b,t) workgroup rebuilds its R rows from the sample's X — 12 float4 per (node, 4 channels), straight into the
+// A-operand layout of wgrad64_body — in the summation order of the forward (bit-identical R).  X[b] (522 KB) is read by the slab workgroups of
+// the same launch on the SAME XCD (work map below), so these 12x re-reads are L2 hits, not HBM traffic.  One row split only (N <= ~700).
+template <bool HASY>
+__device__ __forceinline__ void wgrad64_mix_body(const float* __restrict__ X, const float* __restrict__ G, const float* __restrict__ D,
+                                                 const float* __restrict__ D2, float* __restrict__ dW, int N, int b, int t,
+                                                 float* __restrict__ smem) {
+    constexpr int C = 64, U = 2;
+    float (*red)[C * C] = reinterpret_cast<float (*)[C * C]>(smem);
+    float (*csred)[C] = reinterpret_cast<float (*)[C]>(smem + 4 * C * C);
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int j = lane & 15, kk = lane >> 4;
+    const int q = (N + 3) / 4;
+    const int mbeg = wave * q, mend = min(N, mbeg + q);
+    const size_t g = (size_t)b * HT_T + t;
+    f32x4 acc[4][4];
+#pragma unroll
+    for (int ca = 0; ca < 4; ++ca)
+#pragma unroll
+        for (int cb = 0; cb < 4; ++cb) acc[ca][cb] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    float4 sa = f4zero();
+    for (int m0 = mbeg; m0 < mend; m0 += 4 * U) {
+        float4 x[U][HT_T], gq[U][3], d[U], y[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const int m = min(m0 + 4 * u + kk, mend - 1);                            // clamped: out-of-range rows are zeroed below
+#pragma unroll
+            for (int k = 0; k < 3; ++k) gq[u][k] = ld4(G + (size_t)m * 144 + t * HT_T + 4 * k);
+#pragma unroll
+            for (int uu = 0; uu < HT_T; ++uu) x[u][uu] = ld4(X + (((size_t)b * HT_T + uu) * N + m) * C + 4 * j);
+            const size_t off = (g * N + m) * C + 4 * j;
+            d[u] = ld4(D + off);
+            if (HASY) y[u] = ld4(D2 + off);
+        }
+        SB();
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const float gs[HT_T] = {gq[u][0].x, gq[u][0].y, gq[u][0].z, gq[u][0].w, gq[u][1].x, gq[u][1].y, gq[u][1].z, gq[u][1].w,
+                                    gq[u][2].x, gq[u][2].y, gq[u][2].z, gq[u][2].w};
+            float4 a = f4zero();
+#pragma unroll
+            for (int uu = 0; uu < HT_T; ++uu) a = f4fma(gs[uu], x[u][uu], a);            // same order as hypertem_fwd_kernel's mix
+            if (m0 + 4 * u + kk >= mend) a = f4zero();
+            if (HASY) {
+                d[u].x = __fmul_rn(d[u].x, lrelu_grad_from_out(y[u].x)); d[u].y = __fmul_rn(d[u].y, lrelu_grad_from_out(y[u].y));
+                d[u].z = __fmul_rn(d[u].z, lrelu_grad_from_out(y[u].z)); d[u].w = __fmul_rn(d[u].w, lrelu_grad_from_out(y[u].w));
+            }
+            if (m0 + 4 * u + kk < mend) sa = make_float4(__fadd_rn(sa.x, d[u].x), __fadd_rn(sa.y, d[u].y), __fadd_rn(sa.z, d[u].z), __fadd_rn(sa.w, d[u].w));
+            const float av[4] = {a.x, a.y, a.z, a.w}, dv[4] = {d[u].x, d[u].y, d[u].z, d[u].w};
+#pragma unroll
+            for (int ca = 0; ca < 4; ++ca)
+#pragma unroll
+                for (int cb = 0; cb < 4; ++cb) acc[ca][cb] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[ca], dv[cb], acc[ca][cb], 0, 0, 0);
+        }
+        SB();
+    }
+#pragma unroll
+    for (int ca = 0; ca < 4; ++ca)
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+            st4(&red[wave][(4 * (kk * 4 + r) + ca) * C + 4 * j], make_float4(acc[ca][0][r], acc[ca][1][r], acc[ca][2][r], acc[ca][3][r]));
+    sa.x += __shfl_xor(sa.x, 16, 64); sa.y += __shfl_xor(sa.y, 16, 64); sa.z += __shfl_xor(sa.z, 16, 64); sa.w += __shfl_xor(sa.w, 16, 64);
+    sa.x += __shfl_xor(sa.x, 32, 64); sa.y += __shfl_xor(sa.y, 32, 64); sa.z += __shfl_xor(sa.z, 32, 64); sa.w += __shfl_xor(sa.w, 32, 64);
+    if (kk == 0) st4(&csred[wave][4 * j], sa);
+    __syncthreads();
+    float* o = dW + g * (size_t)(C * C + C);
+    if (threadIdx.x < C) o[C * C + threadIdx.x] = csred[0][threadIdx.x] + csred[1][threadIdx.x] + csred[2][threadIdx.x] + csred[3][threadIdx.x];
+#pragma unroll
+    for (int k = 0; k < C * C / 4 / 256; ++k) {
+        const int f = threadIdx.x + k * 256;
+        const float4 s = f4add(f4add(ld4(&red[0][4 * f]), ld4(&red[1][4 * f])), f4add(ld4(&red[2][4 * f]), ld4(&red[3][4 * f])));
+        st4(o + 4 * f, s);
+    }
 }
 
 // ---- hyperTem backward AND its weight gradient side by side in ONE launch ---------------------------------------------------------------
@@ -345,7 +442,8 @@ __global__ __launch_bounds__(256, 2) void hypertem_bwd_kernel(const float* __res
 // grouped weight-gradient workgroups of wgrad64.h.  As two launches they cost their fixed dependency chains one after the other
 // (tools/mb_scaling.py: ~10 us of every launch does not scale with the work); here workgroups 0 .. nH-1 take the hyperTem role (they are the
 // longer ones and keep the XCD-aware index map), the rest the weight-gradient role, and the chains overlap.
-template <int U>
+// MIX: the weight-gradient role rebuilds R from X (R == NULL) and its workgroups follow the same sample -> XCD map as the slab role.
+template <int U, bool HASY, bool PREMUL, bool MIX>
 __global__ __launch_bounds__(256, 2) void hypertem_bwd_wgrad_kernel(const float* __restrict__ dOut, const float* __restrict__ Y,
                                                                     const float* __restrict__ X, const float* __restrict__ G,
                                                                     const float* __restrict__ Wbt, const float* __restrict__ R,
@@ -353,51 +451,76 @@ __global__ __launch_bounds__(256, 2) void hypertem_bwd_wgrad_kernel(const float*
                                                                     int N, int B, int nH, RowMap rm, int rows_per_split) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     if ((int)blockIdx.x < nH) {
-        hypertem_bwd_body(dOut, Y, X, G, Wbt, dX, nullptr, dG, N, B, 0, blockIdx.x, smem);
+        hypertem_bwd_body<HASY, PREMUL>(dOut, Y, X, G, Wbt, dX, nullptr, dG, N, B, 0, blockIdx.x, smem);
+    } else if (MIX) {
+        int b, t;
+        if (!ht_work_at(blockIdx.x - nH, HT_T, B, b, t)) return;      // nH is a multiple of 8: the XCD of this workgroup is (blockIdx.x - nH) % 8
+        wgrad64_mix_body<HASY>(X, G, dOut, Y, dWb, N, b, t, smem);
     } else {
         const int w = blockIdx.x - nH;
-        wgrad64_body<PRO_DPRE, U>(R, dOut, Y, dWb, rm, rows_per_split, 64 * 64 + 64, 2, w % rm.G, w / rm.G, smem);
+        wgrad64_body<HASY ? PRO_DPRE : PRO_NONE, U>(R, dOut, Y, dWb, rm, rows_per_split, 64 * 64 + 64, 2, w % rm.G, w / rm.G, smem);
     }
 }
 
 // dbias: (gptst_hypertem_ntiles(N) * B*T, C) node-tile partials;  dG: (B * N, T, T) per-sample partials — both fully written here.
 extern "C" int gptst_hypertem_ntiles(int N) { return (N + 15) / 16; }
 
+// Y == NULL: dOut already is dPre.  premul != 0: dX is multiplied by lrelu'(X) (X = output of the LeakyReLU layer below) — not together with Y.
 extern "C" int gptst_hypertem_bwd(const float* dOut, const float* Y, const float* X, const float* G, const float* Wbt, float* dX,
-                                  float* dbias, float* dG, int B, int T, int N, int C, void* stream) {
-    if (!dOut || !Y || !X || !G || !Wbt || !dX || !dG || T != HT_T) return GPTST_EARG;      // dbias may be NULL (bias gradient from gptst_wgrad_colsum)
+                                  float* dbias, float* dG, int premul, int B, int T, int N, int C, void* stream) {
+    if (!dOut || !X || !G || !Wbt || !dX || !dG || T != HT_T || (Y && premul)) return GPTST_EARG;      // dbias may be NULL (bias gradient from gptst_wgrad_colsum)
     if (C != 64) return GPTST_ESHAPE;
     const size_t smem = ht_smem(16);
     static int done = 0;
-    if (!done) { hipFuncSetAttribute((const void*)hypertem_bwd_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem); done = 1; }
-    hipLaunchKernelGGL(hypertem_bwd_kernel, dim3(8 * ((B + 7) / 8) * ((N + 15) / 16)), dim3(256), smem, (hipStream_t)stream, dOut, Y, X, G, Wbt, dX, dbias, dG, N, B, g_ht_dbg);
+    if (!done) {
+        hipFuncSetAttribute((const void*)hypertem_bwd_kernel<true, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+        hipFuncSetAttribute((const void*)hypertem_bwd_kernel<false, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+        hipFuncSetAttribute((const void*)hypertem_bwd_kernel<false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+        done = 1;
+    }
+    const dim3 grid(8 * ((B + 7) / 8) * ((N + 15) / 16));
+    if (Y) hipLaunchKernelGGL((hypertem_bwd_kernel<true, false>), grid, dim3(256), smem, (hipStream_t)stream, dOut, Y, X, G, Wbt, dX, dbias, dG, N, B, g_ht_dbg);
+    else if (premul) hipLaunchKernelGGL((hypertem_bwd_kernel<false, true>), grid, dim3(256), smem, (hipStream_t)stream, dOut, Y, X, G, Wbt, dX, dbias, dG, N, B, g_ht_dbg);
+    else hipLaunchKernelGGL((hypertem_bwd_kernel<false, false>), grid, dim3(256), smem, (hipStream_t)stream, dOut, Y, X, G, Wbt, dX, dbias, dG, N, B, g_ht_dbg);
     GPTST_CHECK_LAUNCH();
     return GPTST_OK;
 }
 
 // One launch for the whole backward of a hyperTem layer (C = 64): gptst_hypertem_bwd (without dbias) + gptst_wgrad_colsum(mode 0, pro 1,
 // which 2) on (R, dOut, Y).  dWb: (nsplit * B*T, C*C + C) rows [dW_bt | db_bt] with nsplit = gptst_wgrad_nsplit(0, B*T, N, 64).
+// Y == NULL / premul: as gptst_hypertem_bwd.  R == NULL: the weight-gradient role rebuilds R from X (needs nsplit == 1, else GPTST_ESHAPE).
 extern "C" int gptst_wgrad_nsplit(int mode, int BT, int N, int C);
-extern "C" int gptst_hypertem_bwd_wgrad(const float* dOut, const float* Y, const float* X, const float* G, const float* Wbt, const float* R,
-                                        float* dX, float* dG, float* dWb, int B, int T, int N, int C, void* stream) {
-    if (!dOut || !Y || !X || !G || !Wbt || !R || !dX || !dG || !dWb || T != HT_T) return GPTST_EARG;
-    if (C != 64) return GPTST_ESHAPE;
-    const size_t smem_h = ht_smem(16), smem_w = WGRAD64_SMEM_FLOATS * sizeof(float), smem = smem_h > smem_w ? smem_h : smem_w;
+template <bool HASY, bool PREMUL>
+static void ht_bwd_wgrad_launch(const float* dOut, const float* Y, const float* X, const float* G, const float* Wbt, const float* R, float* dX,
+                                float* dG, float* dWb, int B, int N, bool u6, int nH, int nW, RowMap rm, int rps, size_t smem, hipStream_t st) {
     static int done = 0;
     if (!done) {
-        hipFuncSetAttribute((const void*)hypertem_bwd_wgrad_kernel<4>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
-        hipFuncSetAttribute((const void*)hypertem_bwd_wgrad_kernel<6>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+        hipFuncSetAttribute((const void*)hypertem_bwd_wgrad_kernel<4, HASY, PREMUL, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+        hipFuncSetAttribute((const void*)hypertem_bwd_wgrad_kernel<6, HASY, PREMUL, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+        hipFuncSetAttribute((const void*)hypertem_bwd_wgrad_kernel<4, HASY, PREMUL, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
         done = 1;
     }
+    if (R == nullptr) hipLaunchKernelGGL((hypertem_bwd_wgrad_kernel<4, HASY, PREMUL, true>), dim3(nH + 8 * ((B + 7) / 8) * HT_T), dim3(256), smem, st, dOut, Y, X, G, Wbt, R, dX, dG, dWb, N, B, nH, rm, rps);
+    else if (u6) hipLaunchKernelGGL((hypertem_bwd_wgrad_kernel<6, HASY, PREMUL, false>), dim3(nH + nW), dim3(256), smem, st, dOut, Y, X, G, Wbt, R, dX, dG, dWb, N, B, nH, rm, rps);
+    else hipLaunchKernelGGL((hypertem_bwd_wgrad_kernel<4, HASY, PREMUL, false>), dim3(nH + nW), dim3(256), smem, st, dOut, Y, X, G, Wbt, R, dX, dG, dWb, N, B, nH, rm, rps);
+}
+
+extern "C" int gptst_hypertem_bwd_wgrad(const float* dOut, const float* Y, const float* X, const float* G, const float* Wbt, const float* R,
+                                        float* dX, float* dG, float* dWb, int premul, int B, int T, int N, int C, void* stream) {
+    if (!dOut || !X || !G || !Wbt || !dX || !dG || !dWb || T != HT_T || (Y && premul)) return GPTST_EARG;
+    if (C != 64) return GPTST_ESHAPE;
+    const size_t smem_h = ht_smem(16), smem_w = WGRAD64_SMEM_FLOATS * sizeof(float), smem = smem_h > smem_w ? smem_h : smem_w;
     const RowMap rm = make_rowmap(0, B * T, N);
     const int ns = gptst_wgrad_nsplit(0, B * T, N, 64);
+    if (!R && ns != 1) return GPTST_ESHAPE;
     int rps = (rm.M + ns - 1) / ns;
     rps = (rps + 1) & ~1;
     const int rows = rps < rm.M ? rps : rm.M, steps = ((rows + 3) / 4 + 3) / 4;          // k-steps per wave (as wgrad_impl, apply.hip)
     const bool u6 = (steps + 5) / 6 * 6 <= (steps + 3) / 4 * 4;
     const int nH = 8 * ((B + 7) / 8) * ((N + 15) / 16), nW = rm.G * ns;
-    if (u6) hipLaunchKernelGGL((hypertem_bwd_wgrad_kernel<6>), dim3(nH + nW), dim3(256), smem, (hipStream_t)stream, dOut, Y, X, G, Wbt, R, dX, dG, dWb, N, B, nH, rm, rps);
-    else hipLaunchKernelGGL((hypertem_bwd_wgrad_kernel<4>), dim3(nH + nW), dim3(256), smem, (hipStream_t)stream, dOut, Y, X, G, Wbt, R, dX, dG, dWb, N, B, nH, rm, rps);
+    if (Y) ht_bwd_wgrad_launch<true, false>(dOut, Y, X, G, Wbt, R, dX, dG, dWb, B, N, u6, nH, nW, rm, rps, smem, (hipStream_t)stream);
+    else if (premul) ht_bwd_wgrad_launch<false, true>(dOut, Y, X, G, Wbt, R, dX, dG, dWb, B, N, u6, nH, nW, rm, rps, smem, (hipStream_t)stream);
+    else ht_bwd_wgrad_launch<false, false>(dOut, Y, X, G, Wbt, R, dX, dG, dWb, B, N, u6, nH, nW, rm, rps, smem, (hipStream_t)stream);
     GPTST_CHECK_LAUNCH();
     return GPTST_OK;
 }

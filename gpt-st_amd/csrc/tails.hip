@@ -27,6 +27,7 @@ struct TailArgs {
     const float* src; const float* mask; float* out; int lda; float sigma, mu, thresh;
     // kl head
     const float* prob; const float* c; int N; float w;
+    int premul;          // dPre chain: dX is multiplied by lrelu'(X) (X = the output of a LeakyReLU layer), include/gptst_hip.h
 };
 
 template <int KIND, int C>      // KIND 0: mae tail, 1: kl head
@@ -104,6 +105,9 @@ __global__ __launch_bounds__(256) void tail_kernel(TailArgs t) {
                 accW[j] = f4fma(a[j], x, accW[j]);
                 accb[j] += a[j];
             }
+        if (t.premul) {
+            dx.x *= lrelu_grad_from_out(x.x); dx.y *= lrelu_grad_from_out(x.y); dx.z *= lrelu_grad_from_out(x.z); dx.w *= lrelu_grad_from_out(x.w);
+        }
         st4(t.dX + i * C + 4 * c4, dx);
       }
     }
@@ -174,13 +178,13 @@ extern "C" int gptst_stats_fold(const float* sws, int rows, float* stats, void* 
 }
 
 extern "C" int gptst_tail_mae(const float* dec, const float* W, const float* b, const float* src, int lda, const float* mask, float sigma,
-                              float mu, float thresh, float* out, float* d_dec, float* part, float* sws, int rows, int J, int C,
+                              float mu, float thresh, float* out, float* d_dec, float* part, float* sws, int premul, int rows, int J, int C,
                               void* stream) {
     if (!dec || !W || !src || !mask || !out || !d_dec || !part || !sws || rows <= 0 || J <= 0) return GPTST_EARG;
     if ((C != 64 && C != 128) || J > TL_MAXJ) return GPTST_ESHAPE;
     TailArgs t{};
     t.X = dec; t.W = W; t.b = b; t.dX = d_dec; t.part = part; t.sws = sws; t.rows = rows; t.J = J;
-    t.src = src; t.mask = mask; t.out = out; t.lda = lda; t.sigma = sigma; t.mu = mu; t.thresh = thresh;
+    t.src = src; t.mask = mask; t.out = out; t.lda = lda; t.sigma = sigma; t.mu = mu; t.thresh = thresh; t.premul = premul;
     int nb; tl_geometry(rows, nb, t.rows_per_block);
     if (C == 64) hipLaunchKernelGGL((tail_kernel<0, 64>), dim3(nb), dim3(256), 0, (hipStream_t)stream, t);
     else hipLaunchKernelGGL((tail_kernel<0, 128>), dim3(nb), dim3(256), 0, (hipStream_t)stream, t);
@@ -189,12 +193,12 @@ extern "C" int gptst_tail_mae(const float* dec, const float* W, const float* b, 
 }
 
 extern "C" int gptst_tail_kl(const float* h2, const float* W3, const float* prob, const float* c, float w, float* d_h2, float* part,
-                             float* sws, int rows, int N, int HS, int C, void* stream) {
+                             float* sws, int premul, int rows, int N, int HS, int C, void* stream) {
     if (!h2 || !W3 || !prob || !c || !d_h2 || !part || !sws || rows <= 0 || HS <= 0 || N <= 0) return GPTST_EARG;
     if ((C != 64 && C != 128) || HS > TL_MAXJ) return GPTST_ESHAPE;
     TailArgs t{};
     t.X = h2; t.W = W3; t.dX = d_h2; t.part = part; t.sws = sws; t.rows = rows; t.J = HS;
-    t.prob = prob; t.c = c; t.N = N; t.w = w;
+    t.prob = prob; t.c = c; t.N = N; t.w = w; t.premul = premul;
     int nb; tl_geometry(rows, nb, t.rows_per_block);
     if (C == 64) hipLaunchKernelGGL((tail_kernel<1, 64>), dim3(nb), dim3(256), 0, (hipStream_t)stream, t);
     else hipLaunchKernelGGL((tail_kernel<1, 128>), dim3(nb), dim3(256), 0, (hipStream_t)stream, t);

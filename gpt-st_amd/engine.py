@@ -4,6 +4,7 @@ Every ``*_fwd`` returns ``(outputs..., saved)`` and every ``*_bwd`` ACCUMULATES 
 gradient dict ``g`` (views into one flat buffer) and returns the input gradients.  ``p`` / ``g`` map the reference's
 state_dict keys to tensors.  Citations: reference model/Pretrain_model/GPTST.py.
 """
+import os
 import threading
 
 import torch
@@ -183,12 +184,24 @@ def _tf_job(p, pfx, tidx, spg=False):
 # ---- hyperTem (GPTST.py:154-163) -----------------------------------------------------------------------------------
 # Parameter generation (A, G, W_bt, b_bt) and the gradient reductions into the pools / embeddings are batched per STHCN
 # (sthcn_fwd / sthcn_bwd below): one launch for all four hyperTem layers instead of one per layer.
+# C = 64: the forward may skip writing R = G (*) X and the fused backward rebuild it from X (12 L2-hit float4 per operand).  Measured r03 at the
+# bench shape (scratch/mb_ht5.py): forward 22.2 -> 18.8 us, backward 29.4 -> 37.9 us (the weight-gradient workgroups become the long pole: 565 KB
+# of L2 reads each) — a net loss of 5 us per layer although it removes 33 MB of HBM traffic, so R is kept.  GPTST_DROP_R=1 switches it on.
+DROP_R = os.environ.get("GPTST_DROP_R", "0") == "1"
+
+
+def _ht_fused_bwd(dims):
+    """the one-launch hyperTem backward (hypertem_bwd_wgrad) serves this step"""
+    return dims[3] == 64 and CTX.SIDE is None and FUSE_HT_BWD
+
+
 def hypertem_core_fwd(x, G, Wbt, bbt, dims):
     """x (BTN, C) rows -> out (BTN, C);  G (N,T,T), Wbt (BT,C,C), bbt (BT,C) precomputed."""
     B, T, N, C = dims
     if C == 64:
-        R, out = ops.hypertem_fwd(x.view(B, T, N, C), G, Wbt, bbt)                      # :157-158 + :162-163 fused
-        R, out = R.view(-1, C), out.view(-1, C)
+        keep = not (DROP_R and _ht_fused_bwd(dims) and ops.wgrad_nsplit(MODE_TIME, B * T, N, C) == 1)
+        R, out = ops.hypertem_fwd(x.view(B, T, N, C), G, Wbt, bbt, want_R=keep)         # :157-158 + :162-163 fused
+        R, out = (R.view(-1, C) if keep else None), out.view(-1, C)
     else:
         R = ops.tmix(x.view(B, T, N, C), G).view(-1, C)                                 # :157-158
         out = ops.apply(R, Wbt, MODE_TIME, B * T, N, bias=bbt, resid=x, epi=EPI_RES_LRELU)  # :162-163
@@ -203,15 +216,23 @@ def graph_grad_splits(dims):
     return dims[0] if dims[3] == 64 else 1
 
 
-def hypertem_core_bwd(saved, dout, dG_out, dims):
-    """-> dx, (dWbt, nsplit, (dbias partials, their count)); the graph-gradient partials are written into dG_out (nsG, N, T, T)."""
+def chain_ok(dims):
+    """The "dPre chain" (include/gptst_hip.h, gptst_hypertem_bwd): every backward kernel of the layer chain hands its input gradient down
+    already multiplied by lrelu'(its input), so that no kernel reads its own output only for the sign.  Needs the fused C = 64 kernels."""
+    return _ht_fused_bwd(dims)
+
+
+def hypertem_core_bwd(saved, dout, dG_out, dims, chain=False, premul=False):
+    """-> dx, (dWbt, nsplit, (dbias partials, their count)); the graph-gradient partials are written into dG_out (nsG, N, T, T).
+    chain: dout already is dPre (the layer's output is not read);  premul (chain only): dx is returned multiplied by lrelu'(x)."""
     B, T, N, C = dims
     x, R, out, G, Wbt = saved
     BT = B * T
-    if C == 64 and CTX.SIDE is None and FUSE_HT_BWD:
+    assert not chain or _ht_fused_bwd(dims)
+    if _ht_fused_bwd(dims):
         # data / graph gradients and the weight + bias gradient side by side in one launch: rows [dW_bt | db_bt]
-        dx, dWb, ns, _ = ops.hypertem_bwd_wgrad(dout.view(B, T, N, C), out.view(B, T, N, C), x.view(B, T, N, C), G, Wbt, R.view(B, T, N, C),
-                                                dG=dG_out)
+        dx, dWb, ns, _ = ops.hypertem_bwd_wgrad(dout.view(B, T, N, C), None if chain else out.view(B, T, N, C), x.view(B, T, N, C), G, Wbt,
+                                                R.view(B, T, N, C) if R is not None else None, dG=dG_out, premul=chain and premul)
         dWbt, dbias, nsb = dWb[:, :C * C], dWb[:, C * C:], ns
         dx = dx.view(-1, C)
     elif C == 64:
@@ -241,13 +262,15 @@ def cap_core_fwd(p, pfx, x, dadj, dyn, Wn, bn, dims, num_route, HS, HT):
     return out, c, (x, out, rec, c, s, v, Ht, Rt, dyn, Wn, Y)
 
 
-def cap_core_bwd(p, g, pfx, saved, dout, dims, HS, HT, red):
-    """-> dx and the pieces whose reductions are batched by the caller: (dWn, nsplit, dbn, ddyn, dlogit)."""
+def cap_core_bwd(p, g, pfx, saved, dout, dims, HS, HT, red, chain=False):
+    """-> dx and the pieces whose reductions are batched by the caller: (dWn, nsplit, dbn, ddyn, dlogit).
+    chain: dout already is dPre, and dx is returned multiplied by lrelu'(x) (x is a hyperTem output)."""
     B, T, N, C = dims
     x, out, rec, c, s, v, Ht, Rt, dyn, Wn, Y = saved
     BT, dev = B * T, x.device
+    assert not chain or (C == 64 and CTX.SIDE is None)
     if C == 64 and CTX.SIDE is None:     # data gradient, weight gradient and bias gradient of the node-conditioned layer in one pass
-        drec, dWn, dbn, ns = ops.apply_wgrad(dout, out, rec, Wn, MODE_NODE, BT, N)
+        drec, dWn, dbn, ns = ops.apply_wgrad(dout, None if chain else out, rec, Wn, MODE_NODE, BT, N)
         nsb = ns
     else:
         drec = ops.apply(dout, Wn, MODE_NODE, BT, N, A2=out, transw=True, pro=PRO_DPRE)
@@ -259,7 +282,7 @@ def cap_core_bwd(p, g, pfx, saved, dout, dims, HS, HT, red):
     gw, gb = g[pfx + "ln_p.weight"], g[pfx + "ln_p.bias"]
     if C == 64:
         # dx = dY Wp + dout*lrelu'(out), the ln_p weight gradient and its bias gradient in one pass over dY
-        dx, dWp, dbp, ns2 = ops.linear_bwd(dY, x, p[pfx + "ln_p.weight"], dout, out)
+        dx, dWp, dbp, ns2 = ops.linear_bwd(dY, x, p[pfx + "ln_p.weight"], dout, None if chain else out, premul=chain)
         red.jobs.bwd_pool(_ones(dev, ns2), dWp, gw.view(1, C * C))
         red.jobs.bwd_pool(_ones(dev, ns2), dbp, gb.view(1, C))
     else:
@@ -287,12 +310,14 @@ def condlin_fwd(x, Wg, bg, mode, dims):
     return out, (x, out, Wg)
 
 
-def condlin_bwd(saved, dout, emb, wpool, bpool, g_wpool, g_bpool, d_emb, mode, dims, red):
+def condlin_bwd(saved, dout, emb, wpool, bpool, g_wpool, g_bpool, d_emb, mode, dims, red, chain=False, premul=False):
+    """chain: dout already is dPre;  premul (chain only): dx is returned multiplied by lrelu'(x)."""
     B, T, N, C = dims
     x, out, Wg = saved
     R, K = emb.shape
+    assert not chain or C == 64
     if C == 64:
-        dx, dW, db, ns = ops.apply_wgrad(dout, out, x, Wg, mode, B * T, N)
+        dx, dW, db, ns = ops.apply_wgrad(dout, None if chain else out, x, Wg, mode, B * T, N, premul=chain and premul)
         nsb = ns
     else:
         dx = ops.apply(dout, Wg, mode, B * T, N, A2=out, transw=True, pro=PRO_DPRE)
@@ -399,7 +424,9 @@ def _grad_buffers(red, slot, N, T, HmT, ref, nsG):
     return red._dG[4 * k:4 * k + 4], red._dA[4 * k:4 * k + 4]
 
 
-def sthcn_bwd(p, g, pfx, tidx, sv, dout, dims, red):
+def sthcn_bwd(p, g, pfx, tidx, sv, dout, dims, red, chain=False, premul_in=False):
+    """chain: dout already is dPre of the last layer and every layer hands dPre down;  premul_in (chain only): the returned input gradient
+    is multiplied by lrelu'(input) — True when the STHCN's input is itself a LeakyReLU output (the decoder's: the encoder embedding)."""
     B, T, N, C = dims
     time_eb, teb, tes = sv["emb"]
     A_all, hts, cps, d, Hm, ds, HS, HT = sv["gen"]
@@ -408,12 +435,12 @@ def sthcn_bwd(p, g, pfx, tidx, sv, dout, dims, red):
     d_te, d_teb, d_tes = _zeros(time_eb, *time_eb.shape), _zeros(teb, *teb.shape), _zeros(tes, *tes.shape)
     nsG = graph_grad_splits(dims)
     dG_all, dA_all = _grad_buffers(red, sv.get("slot"), N, T, Hm * T, dout, nsG)
-    dd, hp4 = hypertem_core_bwd(sv["h4"], dout, dG_all[3], dims)
-    dd, cp2 = cap_core_bwd(p, g, cps[1], sv["c2"], dd, dims, HS, HT, red)
-    dd, hp3 = hypertem_core_bwd(sv["h3"], dd, dG_all[2], dims)
-    dd, hp2 = hypertem_core_bwd(sv["h2"], dd, dG_all[1], dims)
-    dd, cp1 = cap_core_bwd(p, g, cps[0], sv["c1"], dd, dims, HS, HT, red)
-    dd, hp1 = hypertem_core_bwd(sv["h1"], dd, dG_all[0], dims)
+    dd, hp4 = hypertem_core_bwd(sv["h4"], dout, dG_all[3], dims, chain, True)
+    dd, cp2 = cap_core_bwd(p, g, cps[1], sv["c2"], dd, dims, HS, HT, red, chain)
+    dd, hp3 = hypertem_core_bwd(sv["h3"], dd, dG_all[2], dims, chain, True)
+    dd, hp2 = hypertem_core_bwd(sv["h2"], dd, dG_all[1], dims, chain, True)
+    dd, cp1 = cap_core_bwd(p, g, cps[0], sv["c1"], dd, dims, HS, HT, red, chain)
+    dd, hp1 = hypertem_core_bwd(sv["h1"], dd, dG_all[0], dims, chain, premul_in)
     _join_side()
     # ---- gradient reductions of all generated parameters: queued, executed by red.flush() ----
     J = red.jobs
@@ -477,27 +504,29 @@ def fused_tails_ok(p, C, base, HS):
             and _wb_view(p["encoder.MLP_RL.ln3.weight"], p["encoder.MLP_RL.ln3.bias"]) is not None)
 
 
-def loss_tail(p, g, dec, source, mask, base, sigma, mu, thresh, sws, red):
+def loss_tail(p, g, dec, source, mask, base, sigma, mu, thresh, sws, red, chain=False):
     """dim_flow_out + masked MAE + their backward in one pass over dec (GPTST.py:455, Run.py:92-100) -> out (BTN, base), d_dec.
-    sws: the step's loss-statistics scratch (ops.tail_sws / arena zeros), folded into stats by ops.stats_fold."""
+    sws: the step's loss-statistics scratch (ops.tail_sws / arena zeros), folded into stats by ops.stats_fold.
+    chain: d_dec is returned multiplied by lrelu'(dec) (the dPre of the decoder's last hyperTem layer)."""
     wo = "decoder.dim_flow_out."
-    out, dd, part = ops.tail_mae(dec, p[wo + "weight"], p[wo + "bias"], source, base + 2, mask, sigma, mu, thresh, sws)
+    out, dd, part = ops.tail_mae(dec, p[wo + "weight"], p[wo + "bias"], source, base + 2, mask, sigma, mu, thresh, sws, premul=chain)
     red.jobs.bwd_pool(_ones(dec.device, part.shape[0]), part, _wb_view(g[wo + "weight"], g[wo + "bias"]))
     red.keep.append((part, dd))
     return out, dd
 
 
-def kl_head(p, g, sv_g, prob, c1, N, w, sws, red):
-    """0.1 KL(eb || prob) and the backward through softmax + MLP_RL.ln3 in one pass over h2 -> d_h2 (guide_bwd(dh2=...))."""
+def kl_head(p, g, sv_g, prob, c1, N, w, sws, red, chain=False):
+    """0.1 KL(eb || prob) and the backward through softmax + MLP_RL.ln3 in one pass over h2 -> d_h2 (guide_bwd(dh2=...));
+    chain: multiplied by lrelu'(h2)."""
     m = "encoder.MLP_RL."
-    dh2, part = ops.tail_kl(sv_g[3], p[m + "ln3.weight"], prob, c1, N, w, sws)
+    dh2, part = ops.tail_kl(sv_g[3], p[m + "ln3.weight"], prob, c1, N, w, sws, premul=chain)
     red.jobs.bwd_pool(_ones(prob.device, part.shape[0]), part, _wb_view(g[m + "ln3.weight"], g[m + "ln3.bias"]))
     red.keep.append((part, dh2))
     return dh2
 
 
-def guide_bwd(p, g, source, tidx, saved, dlogit, dims, base, red, dh2=None):
-    """dlogit (BTN,HS): gradient of the logits — or dh2 (BTN,C) when kl_head already went through ln3."""
+def guide_bwd(p, g, source, tidx, saved, dlogit, dims, base, red, dh2=None, chain=False):
+    """dlogit (BTN,HS): gradient of the logits — or dh2 (BTN,C) when kl_head already went through ln3 (chain: dh2 is dPre)."""
     B, T, N, C = dims
     t4m, s1, s2, h2 = saved[:4]
     m = "encoder.MLP_RL."
@@ -507,9 +536,9 @@ def guide_bwd(p, g, source, tidx, saved, dlogit, dims, base, red, dh2=None):
         ops.rowouter(dlogit, HS, HS, h2, g[m + "ln3.weight"], 1, asum=g[m + "ln3.bias"])
     d_t4m = _zeros(t4m, *t4m.shape)
     dh1 = condlin_bwd(s2, dh2, t4m, p[m + "weights_pool_tem"], p[m + "bias_pool_tem"], g[m + "weights_pool_tem"],
-                      g[m + "bias_pool_tem"], d_t4m, MODE_TIME, dims, red)
+                      g[m + "bias_pool_tem"], d_t4m, MODE_TIME, dims, red, chain, True)
     dh0 = condlin_bwd(s1, dh1, p["encoder.neb4mask"], p[m + "weights_pool_spa"], p[m + "bias_pool_spa"],
-                      g[m + "weights_pool_spa"], g[m + "bias_pool_spa"], g["encoder.neb4mask"], MODE_NODE, dims, red)
+                      g[m + "weights_pool_spa"], g[m + "bias_pool_spa"], g["encoder.neb4mask"], MODE_NODE, dims, red, chain, False)
     _in_proj_grads(source, base, dh0, g[m + "ln1.weight"], g[m + "ln1.bias"], None, 0.0, red)
     red.timefeat(p, g, GUIDE_TF, tidx, d_t4m)
     red.keep.append((saved, dlogit, dh2, dh1, dh0))
@@ -548,19 +577,21 @@ def decoder_fwd(p, tidx, emb, dims, num_route, gen=None, head=True):
     return out, dec, sv_d
 
 
-def model_bwd(p, g, source, mask, tidx, sv_e, sv_d, dec, d_out, d_dec, dims, base, scaler_zeros, red, dd=None):
+def model_bwd(p, g, source, mask, tidx, sv_e, sv_d, dec, d_out, d_dec, dims, base, scaler_zeros, red, dd=None, chain=False):
     """Backward of decoder_fwd . model_fwd given d_out (BTN, base) [and optional d_dec (BTN, C)] — or given dd, the gradient
     w.r.t. the decoder STHCN output, when loss_tail already went through dim_flow_out.  Parameter-gradient reductions are queued
-    on ``red`` (Reductions): the caller runs red.flush(tidx) once the whole backward is enqueued."""
+    on ``red`` (Reductions): the caller runs red.flush(tidx) once the whole backward is enqueued.
+    chain (only with dd from loss_tail(chain=True)): the dPre chain, see chain_ok()."""
     B, T, N, C = dims
     wo = "decoder.dim_flow_out."
+    assert not chain or dd is not None
     if dd is None:
         dd = ops.lin_in(d_out, base, base, p[wo + "weight"], None, C, wlayout=1)
         if d_dec is not None:
             dd = dd + d_dec
         ops.rowouter(d_out, base, base, dec, g[wo + "weight"], 1, asum=g[wo + "bias"])
-    d_emb = sthcn_bwd(p, g, DEC, tidx, sv_d, dd, dims, red)
+    d_emb = sthcn_bwd(p, g, DEC, tidx, sv_d, dd, dims, red, chain, True)     # the decoder's input is the encoder's last LeakyReLU output
     red.flush_async(tidx)                                   # the decoder's reductions overlap with the encoder's backward chain
-    d_x0 = sthcn_bwd(p, g, ENC, tidx, sv_e, d_emb, dims, red)
+    d_x0 = sthcn_bwd(p, g, ENC, tidx, sv_e, d_emb, dims, red, chain, False)  # the encoder's input is a plain Linear: no premultiplication
     red.flush_async(tidx)                                   # ... and the encoder's with the guide's
     _in_proj_grads(source, base, d_x0, g["encoder.dim_in_flow.weight"], g["encoder.dim_in_flow.bias"], mask, scaler_zeros, red)

@@ -199,8 +199,9 @@ def apply(A, W, mode, BT, N, bias=None, resid=None, A2=None, transw=False, pro=P
     return out
 
 
-def apply_wgrad(dOut, Y, S, W, mode, BT, N):
-    """Fused backward of a generated-weight layer (C = 64): -> (dS (rows,C), dW (ns*G, C*C), dbias (ns*G, C), ns)."""
+def apply_wgrad(dOut, Y, S, W, mode, BT, N, premul=False):
+    """Fused backward of a generated-weight layer (C = 64): -> (dS (rows,C), dW (ns*G, C*C), dbias (ns*G, C), ns).
+    Y=None: dOut already is dPre;  premul: dS is returned multiplied by lrelu'(S)."""
     _chk(dOut, Y, S, W)
     C = dOut.shape[-1]
     G = BT if mode == MODE_TIME else N
@@ -208,20 +209,22 @@ def apply_wgrad(dOut, Y, S, W, mode, BT, N):
     dS = torch.empty_like(dOut)
     dW = torch.empty(ns * G, C * C, device=dOut.device, dtype=torch.float32)
     db = torch.empty(ns * G, C, device=dOut.device, dtype=torch.float32)
-    _call("gptst_apply_wgrad", _p(dOut), _p(Y), _p(S), _p(W), _p(dS), _p(dW), _p(db), mode, BT, N, C, tag="mode%d" % mode,
+    _call("gptst_apply_wgrad", _p(dOut), _p(Y), _p(S), _p(W), _p(dS), _p(dW), _p(db), int(premul), mode, BT, N, C, tag="mode%d" % mode,
           nbytes=_nb(dOut, Y, S, W, dS, dW))
     return dS, dW, db, ns
 
 
-def linear_bwd(dY, X, Wp, dOut, out):
-    """Fused backward of cap's entry Linear + the layer's residual branch (C = 64): -> (dX, dWp (ns, C*C), dbp (ns, C), ns)."""
+def linear_bwd(dY, X, Wp, dOut, out, premul=False):
+    """Fused backward of cap's entry Linear + the layer's residual branch (C = 64): -> (dX, dWp (ns, C*C), dbp (ns, C), ns).
+    out=None: dOut already is dPre;  premul: dX is returned multiplied by lrelu'(X)."""
     _chk(dY, X, Wp, dOut, out)
     rows, C = dY.shape
     ns = _C.lib().value("gptst_linear_bwd_nsplit", rows)
     dX = torch.empty_like(dY)
     dWp = torch.empty(ns, C * C, device=dY.device, dtype=torch.float32)
     dbp = torch.empty(ns, C, device=dY.device, dtype=torch.float32)
-    _call("gptst_linear_bwd", _p(dY), _p(X), _p(Wp), _p(dOut), _p(out), _p(dX), _p(dWp), _p(dbp), rows, C, nbytes=_nb(dY, X, dOut, out, dX, dWp))
+    _call("gptst_linear_bwd", _p(dY), _p(X), _p(Wp), _p(dOut), _p(out), _p(dX), _p(dWp), _p(dbp), int(premul), rows, C,
+          nbytes=_nb(dY, X, dOut, out, dX, dWp))
     return dX, dWp, dbp, ns
 
 
@@ -270,11 +273,11 @@ def tmix(X, G, dOut=None, Y=None):
     return out
 
 
-def hypertem_fwd(X, G, Wbt, bbt):
-    """Fused hyperTem forward -> (R, out), both (B,T,N,C)."""
+def hypertem_fwd(X, G, Wbt, bbt, want_R=True):
+    """Fused hyperTem forward -> (R, out), both (B,T,N,C); want_R=False -> (None, out): the backward rebuilds R from X."""
     _chk(X, G, Wbt, bbt)
     B, T, N, C = X.shape
-    R = torch.empty_like(X)
+    R = torch.empty_like(X) if want_R else None
     out = torch.empty_like(X)
     _call("gptst_hypertem_fwd", _p(X), _p(G), _p(Wbt), _p(bbt), _p(R), _p(out), B, T, N, C, nbytes=_nb(X, G, Wbt, bbt, R, out))
     return R, out
@@ -284,9 +287,10 @@ def hypertem_ntiles(N):
     return _C.lib().value("gptst_hypertem_ntiles", N)
 
 
-def hypertem_bwd(dOut, Y, X, G, Wbt, dG=None, want_dbias=True):
+def hypertem_bwd(dOut, Y, X, G, Wbt, dG=None, want_dbias=True, premul=False):
     """Fused hyperTem backward -> (dX, dbias (ntiles*BT, C) node-tile partials or None, dG (B,N,T,T) per-sample partials); dG may
-    be a preallocated (B,N,T,T) buffer.  No atomics: consumers sum the partials (nsplit = ntiles / B)."""
+    be a preallocated (B,N,T,T) buffer.  No atomics: consumers sum the partials (nsplit = ntiles / B).
+    Y=None: dOut already is dPre = dOut*lrelu'(out);  premul: dX is returned multiplied by lrelu'(X) (the dPre of the layer below)."""
     _chk(dOut, Y, X, G, Wbt, dG)
     B, T, N, C = X.shape
     dX = torch.empty_like(X)
@@ -294,14 +298,15 @@ def hypertem_bwd(dOut, Y, X, G, Wbt, dG=None, want_dbias=True):
     dbias = torch.empty(nt * B * T, C, device=X.device, dtype=torch.float32) if want_dbias else None
     if dG is None:
         dG = torch.empty(B, N, T, T, device=X.device, dtype=torch.float32)
-    _call("gptst_hypertem_bwd", _p(dOut), _p(Y), _p(X), _p(G), _p(Wbt), _p(dX), _p(dbias), _p(dG), B, T, N, C,
+    _call("gptst_hypertem_bwd", _p(dOut), _p(Y), _p(X), _p(G), _p(Wbt), _p(dX), _p(dbias), _p(dG), int(premul), B, T, N, C,
           nbytes=_nb(dOut, Y, X, G, Wbt, dX))
     return dX, dbias, dG
 
 
-def hypertem_bwd_wgrad(dOut, Y, X, G, Wbt, R, dG=None):
+def hypertem_bwd_wgrad(dOut, Y, X, G, Wbt, R, dG=None, premul=False):
     """Whole backward of a hyperTem layer in ONE launch (C = 64): -> (dX, dWb (ns*BT, C*C+C) rows [dW_bt | db_bt], ns, dG (B,N,T,T)
-    per-sample partials) — hypertem_bwd(want_dbias=False) and wgrad(R, dOut, MODE_TIME, D2=Y, pro=PRO_DPRE, colsum_d=True) side by side."""
+    per-sample partials) — hypertem_bwd(want_dbias=False) and wgrad(R, dOut, MODE_TIME, D2=Y, pro=PRO_DPRE, colsum_d=True) side by side.
+    Y=None / premul: as hypertem_bwd.  R=None: the weight-gradient role rebuilds R from X (one row split only)."""
     _chk(dOut, Y, X, G, Wbt, R, dG)
     B, T, N, C = X.shape
     dX = torch.empty_like(X)
@@ -309,7 +314,7 @@ def hypertem_bwd_wgrad(dOut, Y, X, G, Wbt, R, dG=None):
         dG = torch.empty(B, N, T, T, device=X.device, dtype=torch.float32)
     ns = wgrad_nsplit(MODE_TIME, B * T, N, C)
     dWb = torch.empty(ns * B * T, C * C + C, device=X.device, dtype=torch.float32)
-    _call("gptst_hypertem_bwd_wgrad", _p(dOut), _p(Y), _p(X), _p(G), _p(Wbt), _p(R), _p(dX), _p(dG), _p(dWb), B, T, N, C,
+    _call("gptst_hypertem_bwd_wgrad", _p(dOut), _p(Y), _p(X), _p(G), _p(Wbt), _p(R), _p(dX), _p(dG), _p(dWb), int(premul), B, T, N, C,
           nbytes=_nb(dOut, Y, X, G, Wbt, R, dX, dWb))
     return dX, dWb, ns, dG
 
@@ -681,7 +686,7 @@ def tail_sws(rows, device):
     return torch.zeros(_C.lib().value("gptst_tail_parts", rows), 4, device=device, dtype=torch.float32)
 
 
-def tail_mae(dec, W, b, src, lda, mask, sigma, mu, thresh, sws):
+def tail_mae(dec, W, b, src, lda, mask, sigma, mu, thresh, sws, premul=False):
     """Fused output head + masked-MAE + its backward (tails.hip) -> out (rows,J), d_dec (rows,C) [gradient of the SUM loss],
     part (nparts, J*C+J) partials of (gW, gb); the workgroups' (sum |y-p|, kept count) go to sws[:, 0:2] (see stats_fold)."""
     rows, C = dec.shape
@@ -691,18 +696,18 @@ def tail_mae(dec, W, b, src, lda, mask, sigma, mu, thresh, sws):
     d_dec = torch.empty_like(dec)
     part = torch.empty(nparts, J * C + J, device=dec.device, dtype=torch.float32)
     _call("gptst_tail_mae", _p(dec), _p(W), _p(b), _p(src), lda, _p(mask), float(sigma), float(mu), float(thresh), _p(out), _p(d_dec),
-          _p(part), _p(sws), rows, J, C, nbytes=_nb(dec, d_dec))
+          _p(part), _p(sws), int(premul), rows, J, C, nbytes=_nb(dec, d_dec))
     return out, d_dec, part
 
 
-def tail_kl(h2, W3, prob, c, N, w, sws):
+def tail_kl(h2, W3, prob, c, N, w, sws, premul=False):
     """Fused KL + softmax/ln3 backward (tails.hip) -> d_h2 (rows,C), part (nparts, HS*C+HS) partials of (gW3, gb3); KL sums -> sws[:, 2]."""
     rows, C = h2.shape
     HS = W3.shape[0]
     nparts = _C.lib().value("gptst_tail_parts", rows)
     d_h2 = torch.empty_like(h2)
     part = torch.empty(nparts, HS * C + HS, device=h2.device, dtype=torch.float32)
-    _call("gptst_tail_kl", _p(h2), _p(W3), _p(prob), _p(c), float(w), _p(d_h2), _p(part), _p(sws), rows, N, HS, C, nbytes=_nb(h2, d_h2))
+    _call("gptst_tail_kl", _p(h2), _p(W3), _p(prob), _p(c), float(w), _p(d_h2), _p(part), _p(sws), int(premul), rows, N, HS, C, nbytes=_nb(h2, d_h2))
     return d_h2, part
 
 

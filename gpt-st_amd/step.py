@@ -134,11 +134,12 @@ class PretrainStep:
             # output head + masked MAE + their backward: one pass over dec (the mean's 1/#kept is applied by the optimiser)
             _, dec, sv_d = engine.decoder_fwd(p, tidx, emb, dims, mdl.num_route, gen=gen[engine.DEC], head=False)
             sws = self.arena.zeros(ops.tail_parts(M), 4)                       # per-workgroup loss statistics of the two heads
-            out, dd = engine.loss_tail(p, g, dec, src, mask, base, self.std, self.mean, a.mape_thresh, sws, red)
-            engine.model_bwd(p, g, src, mask, tidx, sv_e, sv_d, dec, None, None, dims, base, mdl.scaler_zeros, red, dd=dd)
+            chain = engine.chain_ok(dims)                                      # dPre chain: no backward kernel re-reads its layer's output
+            out, dd = engine.loss_tail(p, g, dec, src, mask, base, self.std, self.mean, a.mape_thresh, sws, red, chain=chain)
+            engine.model_bwd(p, g, src, mask, tidx, sv_e, sv_d, dec, None, None, dims, base, mdl.scaler_zeros, red, dd=dd, chain=chain)
             if phase == 1:
-                dh2 = engine.kl_head(p, g, sv_g, prob, c1, self.N, 0.1, sws, red)
-                engine.guide_bwd(p, g, src, tidx, sv_g, None, dims, base, red, dh2=dh2)
+                dh2 = engine.kl_head(p, g, sv_g, prob, c1, self.N, 0.1, sws, red, chain=chain)
+                engine.guide_bwd(p, g, src, tidx, sv_g, None, dims, base, red, dh2=dh2, chain=chain)
             ops.stats_fold(sws, self.stats)                                    # ordered sum -> stats[0..2] (no float atomics)
         else:
             out, dec, sv_d = engine.decoder_fwd(p, tidx, emb, dims, mdl.num_route, gen=gen[engine.DEC])

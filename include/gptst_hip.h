@@ -22,7 +22,7 @@
 extern "C" {
 #endif
 
-#define GPTST_ABI_VERSION 1
+#define GPTST_ABI_VERSION 3
 int gptst_abi_version(void);
 /* 1: bit-reproducible steps — the two reductions that end in float atomics by default (embedding gradients of gptst_pool_jobs kind 2,
  * weight gradients of gptst_timefeat_jobs) run as single-owner kernels with a fixed summation order (slower).  Everything else is
@@ -94,17 +94,19 @@ int gptst_wgrad_colsum(const float* A, const float* D, const float* D2, float* d
  * dPre = dOut*lrelu'(Y); dS = dPre W_g^T; per row split s < gptst_apply_wgrad_nsplit: dW[s][g] = S^T dPre, colsum[s][g] = column sums
  * of dPre (may be NULL).  Replaces gptst_apply(pro=1, transw=1, colsum) + gptst_wgrad(pro=1), which both read dOut and Y.
  * W (G,C,C) as in the forward ([in][out]).  Backward of einsum('btni,nio->btno') / ('btni,btio->btno') + bias + LeakyReLU
- * (GPTST.py:26-27,31-32,139-141). */
+ * (GPTST.py:26-27,31-32,139-141).  dPre chain (see gptst_hypertem_bwd): Y == NULL -> dOut already is dPre; premul != 0 -> dS is
+ * multiplied by lrelu'(S) (S = output of the LeakyReLU layer below). */
 int gptst_apply_wgrad_nsplit(int mode, int BT, int N);
-int gptst_apply_wgrad(const float* dOut, const float* Y, const float* S, const float* W, float* dS, float* dW, float* colsum, int mode,
-                      int BT, int N, int C, void* stream);
+int gptst_apply_wgrad(const float* dOut, const float* Y, const float* S, const float* W, float* dS, float* dW, float* colsum, int premul,
+                      int mode, int BT, int N, int C, void* stream);
 
 /* Backward through the shared Linear at the entry of cap (P = squash(X Wp^T + bp), GPTST.py:102) plus the residual branch of the layer
  * (:139-141) in ONE pass: dX = dY Wp + dOut*lrelu'(out); per row split s < gptst_linear_bwd_nsplit(rows): dWp[s] = dY^T X ([out][in]),
- * dbp[s] = colsum(dY).  Replaces gptst_apply(mode 2, epi 2) + gptst_wgrad_colsum(mode 2).  C = 64. */
+ * dbp[s] = colsum(dY).  Replaces gptst_apply(mode 2, epi 2) + gptst_wgrad_colsum(mode 2).  C = 64.
+ * dPre chain: out == NULL -> dOut already is dPre: dX = dY Wp + dPre, and with premul != 0  dX = (dY Wp + dPre) * lrelu'(X). */
 int gptst_linear_bwd_nsplit(int rows);
 int gptst_linear_bwd(const float* dY, const float* X, const float* Wp, const float* dOut, const float* out, float* dX, float* dWp, float* dbp,
-                     int rows, int C, void* stream);
+                     int premul, int rows, int C, void* stream);
 
 /* ---- per-node temporal hypergraph of hyperTem (tmix.hip), GPTST.py:156-158 -----------------------------
  * A (N,Hm,T) = node_emb . adj (via poolgen);  G[n] = A[n]^T A[n] (T x T);  ret[b,:,n,:] = G[n] X[b,:,n,:]. */
@@ -121,23 +123,32 @@ int gptst_tmix_dgraph(const float* dR, const float* X, float* dG, int B, int T, 
 int gptst_tmix_bwd(const float* dR, const float* X, const float* G, const float* dOut, const float* Y, float* dX, float* dG, int B, int T,
                    int N, int C, void* stream);
 
-/* fused hyperTem forward (hypertem.hip): R = G (*) X (saved for the weight gradient), out = LReLU(R W_bt + b_bt + X);
- * one workgroup per (sample, 16 nodes), MFMA 16x16x4 with W_bt read from L2.  C = 64. */
+/* fused hyperTem forward (hypertem.hip): R = G (*) X, out = LReLU(R W_bt + b_bt + X); one workgroup per (sample, 16 nodes), MFMA 16x16x4
+ * with W_bt read from L2.  R_out: R kept for the weight gradient, or NULL (the backward then rebuilds it from X).  C = 64.
+ * Replaces GPTST.py:157-158 + :162-163. */
 int gptst_hypertem_fwd(const float* X, const float* G, const float* Wbt, const float* bbt, float* R_out, float* out, int B, int T,
                        int N, int C, void* stream);
 
-/* fused hyperTem backward w.r.t. data and graph: dX = dPre + G (*) (dPre W_bt^T), dPre = dOut*lrelu'(Y), and PARTIALS of the bias and
- * graph gradients, plain stores in a fixed order (no atomics): dbias (gptst_hypertem_ntiles(N) * B*T, C) — one partial per 16-node
- * tile — and dG (B*N, T, T) — one per sample; the consumers sum them (pool jobs nsplit, gptst_gram_bwd nsplit).
- * (The weight gradient stays in gptst_wgrad.)  C = 64. */
+/* "dPre chain" convention of the backward kernels (r03): the gradient that travels down the layer chain may be handed over ALREADY multiplied
+ * by the LeakyReLU derivative of the activation it belongs to (dPre = dOut * lrelu'(out)).  A consumer is told so by Y == NULL (it then
+ * takes its incoming gradient as dPre and never reads its own output), and a producer is told to emit that form by premul != 0: it
+ * multiplies its input gradient by lrelu'(X), where X — its input, which it reads anyway — is the output of the LeakyReLU layer below.
+ * Y != NULL together with premul != 0 is rejected (GPTST_EARG).
+ *
+ * fused hyperTem backward w.r.t. data and graph: dX = (dPre + G (*) (dPre W_bt^T)) [* lrelu'(X) if premul], dPre = dOut*lrelu'(Y) or dOut,
+ * and PARTIALS of the bias and graph gradients, plain stores in a fixed order (no atomics): dbias (gptst_hypertem_ntiles(N) * B*T, C) — one
+ * partial per 16-node tile — and dG (B*N, T, T) — one per sample; the consumers sum them (pool jobs nsplit, gptst_gram_bwd nsplit).
+ * (The weight gradient stays in gptst_wgrad.)  C = 64.  Replaces the backward of GPTST.py:157-163. */
 int gptst_hypertem_ntiles(int N);
 int gptst_hypertem_bwd(const float* dOut, const float* Y, const float* X, const float* G, const float* Wbt, float* dX, float* dbias,
-                       float* dG, int B, int T, int N, int C, void* stream);
+                       float* dG, int premul, int B, int T, int N, int C, void* stream);
 /* gptst_hypertem_bwd (without dbias) AND the layer's weight + bias gradient (gptst_wgrad_colsum mode 0, pro 1, which 2 on R, dOut, Y) side
  * by side in ONE launch: the two are independent, and as separate launches their fixed dependency chains add up.
- * dWb: (gptst_wgrad_nsplit(0, B*T, N, 64) * B*T, C*C + C) rows [dW_bt | db_bt].  C = 64. */
+ * dWb: (gptst_wgrad_nsplit(0, B*T, N, 64) * B*T, C*C + C) rows [dW_bt | db_bt].  R == NULL: the weight-gradient workgroups rebuild
+ * R_t[n,:] = sum_u G_n[t,u] X_u[n,:] from the sample's X (L2 hits: the slab workgroups of the same sample run on the same XCD) — needs
+ * gptst_wgrad_nsplit(...) == 1, else GPTST_ESHAPE.  C = 64. */
 int gptst_hypertem_bwd_wgrad(const float* dOut, const float* Y, const float* X, const float* G, const float* Wbt, const float* R, float* dX,
-                             float* dG, float* dWb, int B, int T, int N, int C, void* stream);
+                             float* dG, float* dWb, int premul, int B, int T, int N, int C, void* stream);
 
 /* ---- cap: node x cluster soft assignment + routing + aggregation (cap.hip, cap_cross.hip), GPTST.py:100-141 ----
  * route_fwd, one workgroup per (b,t):  P = squash(X Wp^T + bp) by MFMA into LDS; dadj (BT,HS,N) = teb.adj (from gptst_poolgen_fwd);
@@ -266,12 +277,13 @@ int gptst_timefeat_bwd(const float* wd, const float* bd, const float* ww, const 
  * tail_kl: the backward through softmax + MLP_RL.ln3 (BasicTrainer.py:85, GPTST.py:33): d_h2, the partials of (gW3, gb3), and the
  *   KL sum of the workgroup in sws[blk][2].  prob (rows,HS) row-major, c (BT,HS,N).
  * stats_fold: stats[0..2] += the column sums of sws (rows, 4) in a fixed order (no float atomics anywhere on this path); rows the
- *   tail kernels did not write must be zero.  C = 64 and J / HS <= 16, else GPTST_ESHAPE (use the unfused ops). */
+ *   tail kernels did not write must be zero.  C = 64 and J / HS <= 16, else GPTST_ESHAPE (use the unfused ops).
+ * premul != 0 (dPre chain, see gptst_hypertem_bwd): d_dec / d_h2 are multiplied by lrelu'(dec) / lrelu'(h2). */
 int gptst_tail_parts(int rows);
 int gptst_tail_mae(const float* dec, const float* W, const float* b, const float* src, int lda, const float* mask, float sigma, float mu,
-                   float thresh, float* out, float* d_dec, float* part, float* sws, int rows, int J, int C, void* stream);
+                   float thresh, float* out, float* d_dec, float* part, float* sws, int premul, int rows, int J, int C, void* stream);
 int gptst_tail_kl(const float* h2, const float* W3, const float* prob, const float* c, float w, float* d_h2, float* part, float* sws,
-                  int rows, int N, int HS, int C, void* stream);
+                  int premul, int rows, int N, int HS, int C, void* stream);
 int gptst_stats_fold(const float* sws, int rows, float* stats, void* stream);
 
 /* njobs (<= 16) time-feature instances in ONE launch (a step has seven).  params: njobs x 10 device pointers in the module order

@@ -707,6 +707,107 @@ def test_hypertem_bwd_wgrad_one_launch_equals_two(B, N):
     assert float((dWb1[:, C * C:] - dWb2[:, C * C:]).abs().max()) <= 4e-7 * float(db_ref.abs().max())
 
 
+def _lg(t):
+    return torch.where(t > 0, 1.0, 0.01)
+
+
+@pytest.mark.parametrize("B,N", [(32, 170), (3, 37), (2, 16), (9, 5)])
+def test_hypertem_bwd_dpre_chain_and_rebuilt_R(B, N):
+    """The dPre-chain forms of the fused hyperTem backward (Y = NULL: the incoming gradient already is dOut*lrelu'(out); premul: dX leaves
+    multiplied by lrelu'(X)) and the weight gradient with R rebuilt from X (R = NULL) reproduce the legacy launch: dG / dW bit for bit
+    (same arithmetic, R summed in the forward's order), dX up to the one extra rounding of the premultiplication."""
+    from gptst_amd import ops
+    dev = _dev()
+    g = torch.Generator().manual_seed(43)
+    C, T = 64, 12
+    X, dO = rnd(B, T, N, C, g=g).to(dev), rnd(B, T, N, C, g=g).to(dev)
+    G = (rnd(N, T, T, g=g) * 0.1).to(dev)
+    Wbt, bbt = (rnd(B * T, C, C, g=g) * 0.1).to(dev), rnd(B * T, C, g=g).to(dev)
+    R, out = ops.hypertem_fwd(X, G, Wbt, bbt)
+    R0, out0 = ops.hypertem_fwd(X, G, Wbt, bbt, want_R=False)
+    assert R0 is None and torch.equal(out, out0)
+    dx1, dWb1, ns, dG1 = ops.hypertem_bwd_wgrad(dO, out, X, G, Wbt, R)
+    dpre = dO * _lg(out)
+    for kw in (dict(R=R), dict(R=None)):                      # Y = NULL, with the saved and with the rebuilt R
+        dx2, dWb2, ns2, dG2 = ops.hypertem_bwd_wgrad(dpre, None, X, G, Wbt, kw["R"])
+        assert ns2 == ns and torch.equal(dx1, dx2) and torch.equal(dG1, dG2)
+        assert torch.equal(dWb1[:, :C * C], dWb2[:, :C * C]), kw
+        assert float((dWb1[:, C * C:] - dWb2[:, C * C:]).abs().max()) <= 4e-7 * float(dWb1[:, C * C:].abs().max())
+    dx3, dWb3, _, dG3 = ops.hypertem_bwd_wgrad(dO, out, X, G, Wbt, None)          # legacy sign operand + rebuilt R
+    assert torch.equal(dx1, dx3) and torch.equal(dG1, dG3) and torch.equal(dWb1[:, :C * C], dWb3[:, :C * C])
+    dx4, dWb4, _, dG4 = ops.hypertem_bwd_wgrad(dpre, None, X, G, Wbt, None, premul=True)
+    assert torch.equal(dG1, dG4) and torch.equal(dWb1[:, :C * C], dWb4[:, :C * C])
+    assert torch.equal(dx4, dx1 * _lg(X))
+    dx5, _, dG5 = ops.hypertem_bwd(dpre, None, X, G, Wbt, want_dbias=False, premul=True)
+    assert torch.equal(dx5, dx4) and torch.equal(dG5, dG1)
+    with pytest.raises(Exception):
+        ops.hypertem_bwd_wgrad(dO, out, X, G, Wbt, R, premul=True)               # sign operand AND premultiplication: rejected
+
+
+@pytest.mark.parametrize("mode,BT,N", [(1, 384, 170), (0, 384, 170), (1, 24, 37), (0, 36, 20)])
+def test_apply_wgrad_dpre_chain(mode, BT, N):
+    """gptst_apply_wgrad with Y = NULL (incoming gradient already dPre) and premul (dS * lrelu'(S)) against the legacy call."""
+    from gptst_amd import ops
+    dev = _dev()
+    g = torch.Generator().manual_seed(47)
+    C = 64
+    G_ = BT if mode == 0 else N
+    dO, Y, S = (rnd(BT * N, C, g=g).to(dev) for _ in range(3))
+    W = (rnd(G_, C, C, g=g) * 0.1).to(dev)
+    dS1, dW1, db1, ns = ops.apply_wgrad(dO, Y, S, W, mode, BT, N)
+    dpre = dO * _lg(Y)
+    dS2, dW2, db2, _ = ops.apply_wgrad(dpre, None, S, W, mode, BT, N)
+    assert torch.equal(dS1, dS2) and torch.equal(dW1, dW2) and torch.equal(db1, db2)
+    dS3, dW3, db3, _ = ops.apply_wgrad(dpre, None, S, W, mode, BT, N, premul=True)
+    assert torch.equal(dS3, dS1 * _lg(S)) and torch.equal(dW1, dW3) and torch.equal(db1, db3)
+
+
+@pytest.mark.parametrize("rows", [65280, 1000, 16])
+def test_linear_bwd_dpre_chain(rows):
+    """gptst_linear_bwd with out = NULL: dX = dY Wp + dPre, and with premul (dY Wp + dPre) * lrelu'(X), against the legacy call."""
+    from gptst_amd import ops
+    dev = _dev()
+    g = torch.Generator().manual_seed(53)
+    C = 64
+    dY, X, dO, out = (rnd(rows, C, g=g).to(dev) for _ in range(4))
+    Wp = (rnd(C, C, g=g) * 0.1).to(dev)
+    dX1, dWp1, dbp1, ns = ops.linear_bwd(dY, X, Wp, dO, out)
+    dpre = dO * _lg(out)
+    dX2, dWp2, dbp2, _ = ops.linear_bwd(dY, X, Wp, dpre, None)
+    close(dX2, dX1.cpu(), what="linear_bwd chain dX")          # fmaf(dOut, lrelu', acc) vs acc + dPre: one rounding apart
+    assert torch.equal(dWp1, dWp2) and torch.equal(dbp1, dbp2)
+    dX3, dWp3, _, _ = ops.linear_bwd(dY, X, Wp, dpre, None, premul=True)
+    assert torch.equal(dX3, dX2 * _lg(X)) and torch.equal(dWp1, dWp3)
+
+
+def test_tails_premul():
+    """tail_mae / tail_kl with premul: the data gradient leaves multiplied by lrelu'(input activation); everything else unchanged."""
+    from gptst_amd import ops
+    dev = _dev()
+    g = torch.Generator().manual_seed(59)
+    B, T, N, C, J, HS = 2, 12, 37, 64, 1, 6
+    rows = B * T * N
+    dec = rnd(rows, C, g=g).to(dev)
+    W, b = rnd(J, C, g=g).to(dev), rnd(J, g=g).to(dev)
+    src = rnd(B, T, N, J + 2, g=g).to(dev)
+    mask = (torch.rand(rows * J, generator=g) > 0.3).float().to(dev)
+    res = []
+    for pm in (False, True):
+        sws = ops.tail_sws(rows, dev)
+        res.append(ops.tail_mae(dec, W, b, src, J + 2, mask, 146.0, 230.0, 0.0, sws, premul=pm) + (sws,))
+    assert torch.equal(res[0][0], res[1][0]) and torch.equal(res[0][2], res[1][2]) and torch.equal(res[0][3], res[1][3])
+    assert torch.equal(res[1][1], res[0][1] * _lg(dec))
+    W3 = rnd(HS, C, g=g).to(dev)
+    prob = torch.softmax(rnd(rows, HS, g=g), -1).to(dev)
+    c = torch.softmax(rnd(B * T, HS, N, g=g), 1).to(dev)
+    res = []
+    for pm in (False, True):
+        sws = ops.tail_sws(rows, dev)
+        res.append(ops.tail_kl(dec, W3, prob, c, N, 0.1, sws, premul=pm) + (sws,))
+    assert torch.equal(res[0][1], res[1][1]) and torch.equal(res[0][2], res[1][2])
+    assert torch.equal(res[1][0], res[0][0] * _lg(dec))
+
+
 def _philox_ref(i, step, seed):
     """Philox4x32-10 (Salmon et al. 2011) in plain Python: counter (i_lo, i_hi, step, 0), key (seed, 0x5EED) -> four uniforms in [0,1)"""
     M0, M1, W0, W1, mask = 0xD2511F53, 0xCD9E8D57, 0x9E3779B9, 0xBB67AE85, 0xFFFFFFFF
