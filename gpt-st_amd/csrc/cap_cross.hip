@@ -37,6 +37,7 @@ __global__ __launch_bounds__(CX_NT) void cap_cross_fwd_kernel(const float* __res
     for (int i = tid; i < HT * K::LPR; i += CX_NT) {
         const int j = i / K::LPR, c4 = i % K::LPR;
         float4 acc = f4zero();
+#pragma unroll 8
         for (int k = 0; k < KK; ++k) acc = f4fma(dyns[j * KK + k], ld4(Zs + k * K::PITCH + 4 * c4), acc);
         acc = make_float4(lrelu(acc.x), lrelu(acc.y), lrelu(acc.z), lrelu(acc.w));
         st4(Hs + j * C + 4 * c4, acc);
@@ -48,6 +49,7 @@ __global__ __launch_bounds__(CX_NT) void cap_cross_fwd_kernel(const float* __res
         const bool valid = i < KK * K::LPR;
         const int k = valid ? i / K::LPR : 0, c4 = i % K::LPR;
         float4 acc = f4zero();
+#pragma unroll 8
         for (int j = 0; j < HT; ++j) acc = f4fma(dyns[j * KK + k], ld4(Hs + j * C + 4 * c4), acc);
         const float4 rt = make_float4(lrelu(acc.x), lrelu(acc.y), lrelu(acc.z), lrelu(acc.w));
         const float tm = tmpl[k / HS];
@@ -59,6 +61,91 @@ __global__ __launch_bounds__(CX_NT) void cap_cross_fwd_kernel(const float* __res
             st4(v + ((size_t)b * KK + k) * C + 4 * c4, make_float4(u.x * sc, u.y * sc, u.z * sc, u.w * sc));
         }
     }
+}
+
+// ---- cross-time block + cluster -> node scatter in ONE launch (r03) -------------------------------------------------------------------
+// cap_cross_fwd runs on B workgroups (12 % of the CUs at B = 32) between two (b,t)-grouped kernels, and every launch has a fixed cost of
+// several microseconds.  Here each (b,t) workgroup of the scatter  rec[bt,n,:] = sum_h c[bt,h,n] v[bt,h,:]  (GPTST.py:135)  first rebuilds what
+// it needs of the sample's cross-time block: Ht = LReLU(dyn Z) for the whole sample (16 x C outputs over T*HS tokens — the 12 workgroups of
+// a sample repeat it, 0.25 MFLOP each), then Rt and v for its OWN HS tokens only.  Same arithmetic and summation order as
+// cap_cross_fwd_kernel, so v / Ht / Rt are bit-identical; Rt and v rows are written by their owner, Ht by the t = 0 workgroup.
+template <int C>
+__global__ __launch_bounds__(256) void cap_cross_rec_fwd_kernel(const float* __restrict__ s, const float* __restrict__ dyn,
+                                                                const float* __restrict__ tmpl, const float* __restrict__ c,
+                                                                float* __restrict__ v, float* __restrict__ Ht_out,
+                                                                float* __restrict__ Rt_out, float* __restrict__ rec, int T, int HS, int HT,
+                                                                int N) {
+    using K = CrossCfg<C>;
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    const int KK = T * HS;
+    float* Zs = smem;                         // KK * PITCH
+    float* Hs = Zs + KK * K::PITCH;           // HT * C
+    float* dyns = Hs + HT * C;                // HT * KK
+    float* vs = dyns + HT * KK;               // HS * C      (offset is a multiple of 4 floats: HT*KK = HT*T*HS with T = 12)
+    float* cs = vs + HS * C;                  // HS * N
+    const int bt = blockIdx.x, b = bt / T, t = bt % T, tid = threadIdx.x;
+    for (int i = tid; i < KK * K::LPR; i += 256) {
+        const int k = i / K::LPR, c4 = i % K::LPR;
+        const float tm = tmpl[k / HS];
+        const float4 x = ld4(s + ((size_t)b * KK + k) * C + 4 * c4);
+        st4(Zs + k * K::PITCH + 4 * c4, make_float4(x.x + tm, x.y + tm, x.z + tm, x.w + tm));
+    }
+    for (int i = tid; i < HT * KK; i += 256) dyns[i] = dyn[(size_t)b * HT * KK + i];
+    for (int i = tid; i < HS * N; i += 256) cs[i] = c[(size_t)bt * HS * N + i];
+    __syncthreads();
+    for (int i = tid; i < HT * K::LPR; i += 256) {
+        const int j = i / K::LPR, c4 = i % K::LPR;
+        float4 acc = f4zero();
+#pragma unroll 8
+        for (int k = 0; k < KK; ++k) acc = f4fma(dyns[j * KK + k], ld4(Zs + k * K::PITCH + 4 * c4), acc);
+        acc = make_float4(lrelu(acc.x), lrelu(acc.y), lrelu(acc.z), lrelu(acc.w));
+        st4(Hs + j * C + 4 * c4, acc);
+        if (t == 0) st4(Ht_out + ((size_t)b * HT + j) * C + 4 * c4, acc);
+    }
+    __syncthreads();
+    for (int base = 0; base < HS * K::LPR; base += 256) {           // own tokens k = t*HS + h
+        const int i = base + tid;
+        const bool valid = i < HS * K::LPR;
+        const int h = valid ? i / K::LPR : 0, c4 = i % K::LPR, k = t * HS + h;
+        float4 acc = f4zero();
+#pragma unroll 8
+        for (int j = 0; j < HT; ++j) acc = f4fma(dyns[j * KK + k], ld4(Hs + j * C + 4 * c4), acc);
+        const float4 rt = make_float4(lrelu(acc.x), lrelu(acc.y), lrelu(acc.z), lrelu(acc.w));
+        const float tm = tmpl[k / HS];
+        const float4 z = ld4(Zs + k * K::PITCH + 4 * c4);
+        const float4 u = make_float4(rt.x + (z.x - tm), rt.y + (z.y - tm), rt.z + (z.z - tm), rt.w + (z.w - tm));
+        const float sc = squash_scale(group_sum<K::LPR>(f4dot(u, u)));
+        if (valid) {
+            const float4 vv = make_float4(u.x * sc, u.y * sc, u.z * sc, u.w * sc);
+            st4(Rt_out + ((size_t)b * KK + k) * C + 4 * c4, rt);
+            st4(v + ((size_t)b * KK + k) * C + 4 * c4, vv);
+            st4(vs + h * C + 4 * c4, vv);
+        }
+    }
+    __syncthreads();
+    constexpr int RPP = 256 / K::LPR;
+    const int slot = tid / K::LPR, j = tid % K::LPR;
+    for (int n = slot; n < N; n += RPP) {                            // as cap_rec_fwd_kernel (cap.hip)
+        float4 acc = f4zero();
+        for (int h = 0; h < HS; ++h) acc = f4fma(cs[h * N + n], ld4(vs + h * C + 4 * j), acc);
+        st4(rec + ((size_t)bt * N + n) * C + 4 * j, acc);
+    }
+}
+
+// (s, dyn, tmpl, c) -> v, Ht, Rt, rec.  GPTST_ESHAPE when the sample's tokens + the (b,t) soft assignment do not fit LDS (use the two launches).
+extern "C" int gptst_cap_cross_rec_fwd(const float* s, const float* dyn, const float* tmpl, const float* c, float* v, float* Ht, float* Rt,
+                                       float* rec, int B, int T, int N, int C, int HS, int HT, void* stream) {
+    if (!s || !dyn || !tmpl || !c || !v || !Ht || !Rt || !rec || B <= 0 || T <= 0 || N <= 0 || HS <= 0 || HT <= 0) return GPTST_EARG;
+    if (C != 64 || (T * HS * HT) % 4 != 0) return GPTST_ESHAPE;
+    using K = CrossCfg<64>;
+    const int KK = T * HS;
+    const size_t smem = ((size_t)KK * K::PITCH + (size_t)HT * 64 + (size_t)HT * KK + (size_t)HS * 64 + (size_t)HS * N) * sizeof(float);
+    if (smem > 80 * 1024) return GPTST_ESHAPE;            // two workgroups per CU, as the scatter alone
+    static size_t cur = 0;
+    if (smem > cur) { hipFuncSetAttribute((const void*)cap_cross_rec_fwd_kernel<64>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem); cur = smem; }
+    hipLaunchKernelGGL((cap_cross_rec_fwd_kernel<64>), dim3(B * T), dim3(256), smem, (hipStream_t)stream, s, dyn, tmpl, c, v, Ht, Rt, rec, T, HS, HT, N);
+    GPTST_CHECK_LAUNCH();
+    return GPTST_OK;
 }
 
 // backward: dS (total grad of s) and ddyn from dv
@@ -109,6 +196,7 @@ __global__ __launch_bounds__(CX_NT) void cap_cross_bwd_kernel(const float* __res
     for (int i = tid; i < HT * K::LPR; i += CX_NT) {
         const int j = i / K::LPR, c4 = i % K::LPR;
         float4 acc = f4zero();
+#pragma unroll 8
         for (int k = 0; k < KK; ++k) acc = f4fma(dyns[j * KK + k], ld4(Gs + k * K::PITCH + 4 * c4), acc);
         const float4 h = ld4(Hs + j * K::PITCH + 4 * c4);
         st4(dHs + j * K::PITCH + 4 * c4, make_float4(acc.x * lrelu_grad_from_out(h.x), acc.y * lrelu_grad_from_out(h.y),
@@ -130,6 +218,7 @@ __global__ __launch_bounds__(CX_NT) void cap_cross_bwd_kernel(const float* __res
     for (int i = tid; i < KK * K::LPR; i += CX_NT) {
         const int k = i / K::LPR, c4 = i % K::LPR;
         float4 acc = f4zero();
+#pragma unroll 8
         for (int j = 0; j < HT; ++j) acc = f4fma(dyns[j * KK + k], ld4(dHs + j * K::PITCH + 4 * c4), acc);
         const size_t off = ((size_t)b * KK + k) * C + 4 * c4;
         st4(dS + off, f4add(ld4(dS + off), acc));

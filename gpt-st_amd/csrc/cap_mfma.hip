@@ -403,12 +403,94 @@ extern "C" int gptst_cap_occupancy(int N, int HS) {
 //   U[h,n] = dS[h,:].P[n,:]  (MFMA 16x16x4, P = g(n) Y)  ->  dc = dc1 + U,  dlogit = c (dc - sum_h c dc)
 //   dP[n,:] = sum_h c[h,n] dS[h,:]  (MFMA 16x16x4, K = clusters)  ->  squash backward  dY = g dP + Y (2 g'(q) (Y.dP))
 // =====================================================================================================================
+struct CrossBwdArgs { const float* dv; const float* s; const float* Rt; const float* Ht; const float* dyn; const float* tmpl; float* ddyn; int T, HT; };
+
+// ---- backward of the cross-time block (cap_cross_bwd_kernel, cap_cross.hip) as a PROLOGUE of the (b,t) workgroups below (r03) -----------
+// cap_cross_bwd runs on B workgroups between two (b,t)-grouped kernels.  Folded in, every (b,t) workgroup repeats the part that needs the
+// whole sample — du / dRpre of all T*HS tokens and dHpre (HT x C over the tokens), ~0.3 MFLOP — and then produces only what belongs to its
+// own HS tokens: dS rows (straight into the LDS tile the routing backward reads: no global round trip) and the ddyn columns.
+// Scratch: the Ys / Wl regions of the kernel below (free until its first phase).  Same arithmetic as cap_cross_bwd_kernel.
+template <int C>
+__device__ __forceinline__ void cap_cross_bwd_prologue(const float* __restrict__ dv, const float* __restrict__ s, const float* __restrict__ Rt,
+                                                       const float* __restrict__ Ht, const float* __restrict__ dyn,
+                                                       const float* __restrict__ tmpl, float* __restrict__ ddyn, float* __restrict__ scratch,
+                                                       float* __restrict__ Vs, int b, int t, int T, int HS, int HT) {
+    constexpr int P = Tile<C>::PITCH, LPR = C / 4;
+    const int KK = T * HS, tid = threadIdx.x;
+    float* Gs = scratch;                       // KK * P   dRpre
+    float* Hs = Gs + KK * P;                   // HT * P   Ht
+    float* dHs = Hs + HT * P;                  // HT * P   dHpre
+    float* Zo = dHs + HT * P;                  // HS * P   Z rows of the own tokens
+    float* dyns = Zo + HS * P;                 // HT * KK
+    for (int i = tid; i < HT * KK; i += CM_NT) dyns[i] = dyn[(size_t)b * HT * KK + i];
+    for (int i = tid; i < HT * LPR; i += CM_NT) st4(Hs + (i / LPR) * P + 4 * (i % LPR), ld4(Ht + ((size_t)b * HT) * C + 4 * i));
+    // rows k: u = Rt + s;  du = squash_bwd(u, dv);  dRpre = du * lrelu'(Rt);  own rows: du -> Vs[h], Z -> Zo[h]
+    for (int base = 0; base < KK * LPR; base += CM_NT) {
+        const int i = base + tid;
+        const bool valid = i < KK * LPR;
+        const int k = valid ? i / LPR : 0, c4 = i % LPR;
+        const size_t off = ((size_t)b * KK + k) * C + 4 * c4;
+        float4 sv = f4zero(), rt = f4zero(), g = f4zero();
+        if (valid) { sv = ld4(s + off); rt = ld4(Rt + off); g = ld4(dv + off); }
+        const float4 u = f4add(rt, sv);
+        const float q = group_sum<LPR>(f4dot(u, u));
+        const float udg = group_sum<LPR>(f4dot(u, g));
+        const float r = sqrtf(q), den = (1.f + q) * (r + 1e-8f);
+        const float gq = q / den;
+        float gp = 0.f;
+        if (r > 0.f) gp = (den - q * ((r + 1e-8f) + (1.f + q) * 0.5f / r)) / (den * den);
+        const float k2 = 2.f * gp * udg;
+        const float4 du = make_float4(fmaf(k2, u.x, gq * g.x), fmaf(k2, u.y, gq * g.y), fmaf(k2, u.z, gq * g.z), fmaf(k2, u.w, gq * g.w));
+        if (valid) {
+            st4(Gs + k * P + 4 * c4, make_float4(du.x * lrelu_grad_from_out(rt.x), du.y * lrelu_grad_from_out(rt.y),
+                                                 du.z * lrelu_grad_from_out(rt.z), du.w * lrelu_grad_from_out(rt.w)));
+            if (k / HS == t) {
+                const float tm = tmpl[t];
+                st4(Vs + (k - t * HS) * P + 4 * c4, du);
+                st4(Zo + (k - t * HS) * P + 4 * c4, make_float4(sv.x + tm, sv.y + tm, sv.z + tm, sv.w + tm));
+            }
+        }
+    }
+    __syncthreads();
+    // dHpre[j] = lrelu'(Ht[j]) * sum_k dyn[j][k] dRpre[k]
+    for (int i = tid; i < HT * LPR; i += CM_NT) {
+        const int j = i / LPR, c4 = i % LPR;
+        float4 acc = f4zero();
+#pragma unroll 8
+        for (int k = 0; k < KK; ++k) acc = f4fma(dyns[j * KK + k], ld4(Gs + k * P + 4 * c4), acc);
+        const float4 h = ld4(Hs + j * P + 4 * c4);
+        st4(dHs + j * P + 4 * c4, make_float4(acc.x * lrelu_grad_from_out(h.x), acc.y * lrelu_grad_from_out(h.y),
+                                              acc.z * lrelu_grad_from_out(h.z), acc.w * lrelu_grad_from_out(h.w)));
+    }
+    __syncthreads();
+    // own tokens: ddyn[j][k] = Ht[j].dRpre[k] + dHpre[j].Z[k]
+    for (int i = tid; i < HT * HS; i += CM_NT) {
+        const int j = i / HS, h = i % HS, k = t * HS + h;
+        float acc = 0.f;
+#pragma unroll 4
+        for (int c4 = 0; c4 < LPR; ++c4) {
+            acc += f4dot(ld4(Hs + j * P + 4 * c4), ld4(Gs + k * P + 4 * c4));
+            acc += f4dot(ld4(dHs + j * P + 4 * c4), ld4(Zo + h * P + 4 * c4));
+        }
+        ddyn[((size_t)b * HT + j) * KK + k] = acc;
+    }
+    // own tokens: dS[k] = du[k] + sum_j dyn[j][k] dHpre[j]
+    for (int i = tid; i < HS * LPR; i += CM_NT) {
+        const int h = i / LPR, c4 = i % LPR, k = t * HS + h;
+        float4 acc = f4zero();
+#pragma unroll 8
+        for (int j = 0; j < HT; ++j) acc = f4fma(dyns[j * KK + k], ld4(dHs + j * P + 4 * c4), acc);
+        st4(Vs + h * P + 4 * c4, f4add(ld4(Vs + h * P + 4 * c4), acc));
+    }
+    __syncthreads();
+}
+
 template <int C>
 __global__ __launch_bounds__(CM_NT, 4) void cap_route_bwd2_kernel(const float* __restrict__ X, const float* __restrict__ Wp,
                                                                   const float* __restrict__ bp, const float* __restrict__ c,
                                                                   const float* __restrict__ dc1, const float* __restrict__ dS,
                                                                   float* __restrict__ dY, float* __restrict__ dlogit, int N, int HS,
-                                                                  int region2) {
+                                                                  int region2, CrossBwdArgs cx) {
     using T = Tile<C>;
     constexpr int P = T::PITCH, LPR = C / 4, RPP = CM_NT / LPR;
     extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -422,6 +504,12 @@ __global__ __launch_bounds__(CM_NT, 4) void cap_route_bwd2_kernel(const float* _
     float* qq = gq + NR;                    // NR         squared norm q(n)
     const int bt = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const float* Xbt = X + (size_t)bt * N * C;
+    const bool fold = cx.dv != nullptr;                 // dS comes out of the cross-time backward, computed here (uniform)
+    if (fold) {
+        for (int i = tid; i < HSP * P; i += CM_NT) Vs[i] = 0.f;
+        __syncthreads();
+        cap_cross_bwd_prologue<C>(cx.dv, cx.s, cx.Rt, cx.Ht, cx.dyn, cx.tmpl, cx.ddyn, smem, Vs, bt / cx.T, bt % cx.T, cx.T, HS, cx.HT);
+    }
 
     if constexpr (C == 64) {
         // ---- Y = X Wp^T + bp, q = |Y|^2, g = squash factor: fused MFMA epilogue as in the forward ----
@@ -430,7 +518,7 @@ __global__ __launch_bounds__(CM_NT, 4) void cap_route_bwd2_kernel(const float* _
         cm_fetch_a16(a, Xbt, wave, N, j, kk);
         const float4 b4 = ld4(bp + 4 * j);
         load_w_lds<C, CM_NT>(Wl, Wp, 1, tid);
-        for (int i = tid; i < HSP * P; i += CM_NT) Vs[i] = 0.f;
+        if (!fold) for (int i = tid; i < HSP * P; i += CM_NT) Vs[i] = 0.f;
         __syncthreads();
         float4 bv[4][4];
         cm_load_bfrag(bv, Wl, j, kk);
@@ -454,7 +542,7 @@ __global__ __launch_bounds__(CM_NT, 4) void cap_route_bwd2_kernel(const float* _
     float4 xv[T::F4_PER_LANE];
     cm_fetch_x<C>(xv, Xbt, wave, N, lane);
     load_w_lds<C, CM_NT>(Wl, Wp, 1, tid);
-    for (int i = tid; i < HSP * P; i += CM_NT) Vs[i] = 0.f;
+    if (!fold) for (int i = tid; i < HSP * P; i += CM_NT) Vs[i] = 0.f;
     __syncthreads();
     for (int t = wave; t < (NR + 31) / 32; t += CM_NW) {           // same tiling as the forward
         float* tile = Ys + t * 32 * P;
@@ -529,7 +617,7 @@ __global__ __launch_bounds__(CM_NT, 4) void cap_route_bwd2_kernel(const float* _
             if (i < HS * N) { cs[(i / N) * NP + i % N] = cv[k]; dcs[(i / N) * NP + i % N] = dv[k]; }
         }
     }
-    for (int i = tid; i < HS * LPR; i += CM_NT) st4(Vs + (i / LPR) * P + 4 * (i % LPR), ld4(dS + (size_t)bt * HS * C + 4 * i));
+    if (!fold) for (int i = tid; i < HS * LPR; i += CM_NT) st4(Vs + (i / LPR) * P + 4 * (i % LPR), ld4(dS + (size_t)bt * HS * C + 4 * i));
     __syncthreads();
 
     const int j = lane & 15, kk = lane >> 4;
@@ -614,7 +702,7 @@ __global__ __launch_bounds__(CM_NT, 4) void cap_route_bwd2_kernel(const float* _
 
 template <int C>
 static int launch_route_bwd2(const float* X, const float* Wp, const float* bp, const float* c, const float* dc1, const float* dS,
-                             float* dY, float* dlogit, int BT, int N, int HS, hipStream_t st) {
+                             float* dY, float* dlogit, int BT, int N, int HS, hipStream_t st, CrossBwdArgs cx = CrossBwdArgs{}) {
     if (HS > 64) return GPTST_ESHAPE;
     const int NR = cm_rows(N), NP = cm_np(N), HSP = cm_hsp(HS);
     size_t r2 = (size_t)C * C, need = (size_t)2 * HSP * NP;
@@ -622,9 +710,13 @@ static int launch_route_bwd2(const float* X, const float* Wp, const float* bp, c
     r2 = (r2 + 3) & ~(size_t)3;
     const size_t smem = ((size_t)NR * Tile<C>::PITCH + r2 + (size_t)HSP * Tile<C>::PITCH + 2 * (size_t)NR) * sizeof(float);
     if (smem > 160 * 1024) return GPTST_ESHAPE;
+    if (cx.dv) {                                     // the prologue's scratch must fit the Ys + Wl regions
+        const size_t need_cx = (size_t)(cx.T * HS + 2 * cx.HT + HS) * Tile<C>::PITCH + (size_t)cx.HT * cx.T * HS;
+        if (need_cx > (size_t)NR * Tile<C>::PITCH + r2 || (cx.HT * cx.T * HS) % 4 != 0) return GPTST_ESHAPE;
+    }
     static size_t cur = 0;
     if (smem > cur) { hipFuncSetAttribute((const void*)cap_route_bwd2_kernel<C>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem); cur = smem; }
-    hipLaunchKernelGGL((cap_route_bwd2_kernel<C>), dim3(BT), dim3(CM_NT), smem, st, X, Wp, bp, c, dc1, dS, dY, dlogit, N, HS, (int)r2);
+    hipLaunchKernelGGL((cap_route_bwd2_kernel<C>), dim3(BT), dim3(CM_NT), smem, st, X, Wp, bp, c, dc1, dS, dY, dlogit, N, HS, (int)r2, cx);
     GPTST_CHECK_LAUNCH();
     return GPTST_OK;
 }
@@ -639,6 +731,18 @@ extern "C" int gptst_cap_route_bwd(const float* X, const float* Wp, const float*
     if (C == 64) rc = launch_route_bwd2<64>(X, Wp, bp, c, dc1, dS, dY, dlogit, BT, N, HS, (hipStream_t)stream);
     if (rc == GPTST_ESHAPE) return gptst_cap_route_bwd_v1(X, Wp, bp, c, dc1, dS, dY, dlogit, BT, N, C, HS, stream);
     return rc;
+}
+
+// gptst_cap_cross_bwd + gptst_cap_route_bwd in ONE launch (the cross-time backward as a prologue of every (b,t) workgroup; dS never leaves
+// LDS).  dv (B, T*HS, C) gradient of the cross-time block's output v; -> dY, dlogit, ddyn (B, HT, T*HS).  C = 64 and T*HS tokens within the
+// kernel's LDS scratch, else GPTST_ESHAPE (use the two launches).
+extern "C" int gptst_cap_cross_route_bwd(const float* X, const float* Wp, const float* bp, const float* c, const float* dc1, const float* dv,
+                                         const float* s, const float* Rt, const float* Ht, const float* dyn, const float* tmpl, float* dY,
+                                         float* dlogit, float* ddyn, int B, int T, int N, int C, int HS, int HT, void* stream) {
+    if (!X || !Wp || !bp || !c || !dc1 || !dv || !s || !Rt || !Ht || !dyn || !tmpl || !dY || !dlogit || !ddyn || B <= 0 || T <= 0) return GPTST_EARG;
+    if (C != 64) return GPTST_ESHAPE;
+    return launch_route_bwd2<64>(X, Wp, bp, c, dc1, nullptr, dY, dlogit, B * T, N, HS, (hipStream_t)stream,
+                                 CrossBwdArgs{dv, s, Rt, Ht, dyn, tmpl, ddyn, T, HT});
 }
 
 // =====================================================================================================================

@@ -251,13 +251,20 @@ def hypertem_core_bwd(saved, dout, dG_out, dims, chain=False, premul=False):
 
 
 # ---- cap (GPTST.py:100-141) ----------------------------------------------------------------------------------------
+FUSE_CROSS = os.environ.get("GPTST_FUSE_CROSS", "1") == "1"     # cross-time block folded into its (b,t)-grouped neighbours (r03)
+
+
 def cap_core_fwd(p, pfx, x, dadj, dyn, Wn, bn, dims, num_route, HS, HT):
     """x (BTN,C); dadj (BT,HS*N), dyn (B,HT,T*HS), Wn (N,C,C), bn (N,C) precomputed -> out, c (BT,HS,N), saved."""
     B, T, N, C = dims
     c, s, Y = ops.cap_route_fwd(x.view(B, T, N, C), p[pfx + "ln_p.weight"], p[pfx + "ln_p.bias"], dadj, HS, num_route,
                                 reduce_nodes=CTX.NODE_REDUCE, want_Y=True)                                            # :102-123
-    v, Ht, Rt = ops.cap_cross_fwd(s, dyn, p[pfx + "mask_template"], B, T, HS, HT)                                     # :125-134
-    rec = ops.cap_rec_fwd(c, v, N, C)                                                                                 # :135
+    fused = ops.cap_cross_rec_fwd(s, dyn, p[pfx + "mask_template"], c, B, T, N, HS, HT) if (FUSE_CROSS and CTX.NODE_REDUCE is None) else None
+    if fused is not None:                                                                                             # :125-135, one launch
+        v, Ht, Rt, rec = fused
+    else:
+        v, Ht, Rt = ops.cap_cross_fwd(s, dyn, p[pfx + "mask_template"], B, T, HS, HT)                                 # :125-134
+        rec = ops.cap_rec_fwd(c, v, N, C)                                                                             # :135
     out = ops.apply(rec, Wn, MODE_NODE, B * T, N, bias=bn, resid=x, epi=EPI_RES_LRELU)                                # :139-141
     return out, c, (x, out, rec, c, s, v, Ht, Rt, dyn, Wn, Y)
 
@@ -277,8 +284,15 @@ def cap_core_bwd(p, g, pfx, saved, dout, dims, HS, HT, red, chain=False):
         dWb, ns = _wgrad_async(rec, dout, MODE_NODE, BT, N, D2=out, pro=PRO_DPRE, colsum_d=True)                    # rows [dWn | dbn] per split
         dWn, dbn, nsb = dWb[:, :C * C], dWb[:, C * C:], ns
     dc1, dv = ops.cap_rec_bwd(drec, c, v, reduce_nodes=CTX.NODE_REDUCE)
-    dS, ddyn = ops.cap_cross_bwd(dv, s, Rt, Ht, dyn, p[pfx + "mask_template"], B, T, HS, HT)
-    dY, dlogit = ops.cap_route_bwd(x.view(B, T, N, C), p[pfx + "ln_p.weight"], p[pfx + "ln_p.bias"], c, dc1, dS, Y=Y)
+    fused = None
+    if FUSE_CROSS and CTX.NODE_REDUCE is None and Y is None:
+        fused = ops.cap_cross_route_bwd(x.view(B, T, N, C), p[pfx + "ln_p.weight"], p[pfx + "ln_p.bias"], c, dc1, dv, s, Rt, Ht, dyn,
+                                        p[pfx + "mask_template"], B, T, HS, HT)
+    if fused is not None:
+        dY, dlogit, ddyn = fused
+    else:
+        dS, ddyn = ops.cap_cross_bwd(dv, s, Rt, Ht, dyn, p[pfx + "mask_template"], B, T, HS, HT)
+        dY, dlogit = ops.cap_route_bwd(x.view(B, T, N, C), p[pfx + "ln_p.weight"], p[pfx + "ln_p.bias"], c, dc1, dS, Y=Y)
     gw, gb = g[pfx + "ln_p.weight"], g[pfx + "ln_p.bias"]
     if C == 64:
         # dx = dY Wp + dout*lrelu'(out), the ln_p weight gradient and its bias gradient in one pass over dY
@@ -359,10 +373,13 @@ def _sthcn_gen_jobs(p, pfx, emb, jobs, A_all, dims):
     return dict(emb=emb, gen=(A_all, hts, cps, d, Hm, ds, HS, HT), Wb=Wb, Wn=Wn, dadj=dadj, dyn=dyn)
 
 
-def gen_all(p, tidx, dims, which=(ENC, DEC), guide=True):
+def gen_all(p, tidx, dims, which=(ENC, DEC), guide=True, side=None):
     """Everything of a step that depends only on the time index and the parameters — the seven time embeddings (:256-261, :337)
     and every generated parameter of both STHCNs and of the guide MLP — in THREE launches (one time-feature job table, one
-    poolgen job table, one gram) instead of 23.  -> {prefix: gen dict, "guide": (t4m, Wspa, bspa, Wtem, btem)}"""
+    poolgen job table, one gram) instead of 23.  -> {prefix: gen dict, "guide": (t4m, Wspa, bspa, Wtem, btem)}
+    side (a SideStream): the guide's four generated parameters get their own small job table on the calling stream and the STHCNs' table
+    + gram run on the side stream — the caller joins it (side.join()) before the encoder; they then overlap with the guide classifier and
+    the mask selection, whose launches use a fraction of the chip."""
     B, T, N, C = dims
     tfj = []
     for pfx in which:
@@ -374,6 +391,15 @@ def gen_all(p, tidx, dims, which=(ENC, DEC), guide=True):
     jobs = ops.PoolJobs()
     res = {}
     L = 4 * len(which)
+    split = side is not None and guide and L
+    if guide:
+        gj = ops.PoolJobs() if split else jobs
+        m = "encoder.MLP_RL."
+        t4m = embs[-1]
+        res["guide"] = (t4m, gj.fwd(p["encoder.neb4mask"], p[m + "weights_pool_spa"]), gj.fwd(p["encoder.neb4mask"], p[m + "bias_pool_spa"]),
+                        gj.fwd(t4m, p[m + "weights_pool_tem"]), gj.fwd(t4m, p[m + "bias_pool_tem"]))
+        if split:
+            gj.launch()
     if L:
         adj0 = p[which[0] + "hyperTem1.adj"]
         Hm = adj0.shape[1]
@@ -381,16 +407,20 @@ def gen_all(p, tidx, dims, which=(ENC, DEC), guide=True):
         for k, pfx in enumerate(which):
             res[pfx] = _sthcn_gen_jobs(p, pfx, embs[3 * k:3 * k + 3], jobs, A_all[4 * k:4 * k + 4], dims)
             res[pfx]["slot"] = (k, len(which))
-    if guide:
-        m = "encoder.MLP_RL."
-        t4m = embs[-1]
-        res["guide"] = (t4m, jobs.fwd(p["encoder.neb4mask"], p[m + "weights_pool_spa"]), jobs.fwd(p["encoder.neb4mask"], p[m + "bias_pool_spa"]),
-                        jobs.fwd(t4m, p[m + "weights_pool_tem"]), jobs.fwd(t4m, p[m + "bias_pool_tem"]))
-    jobs.launch()
-    if L:
-        G_all = ops.gram_fwd(A_all.view(L * N, Hm, T)).view(L, N, T, T)
-        for k, pfx in enumerate(which):
-            res[pfx]["G_all"] = G_all[4 * k:4 * k + 4]
+
+    def rest():
+        jobs.launch()
+        if L:
+            G_all = ops.gram_fwd(A_all.view(L * N, Hm, T)).view(L, N, T, T)
+            for k, pfx in enumerate(which):
+                res[pfx]["G_all"] = G_all[4 * k:4 * k + 4]
+            return G_all
+    if split:
+        with side.fork():
+            G_all = rest()
+        side.keep(A_all, G_all, embs, res)
+    else:
+        rest()
     return res
 
 

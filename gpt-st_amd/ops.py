@@ -468,6 +468,25 @@ def cap_cross_fwd(s, dyn, tmpl, B, T, HS, HT):
     return v, Ht, Rt
 
 
+def cap_cross_rec_fwd(s, dyn, tmpl, c, B, T, N, HS, HT):
+    """Cross-time block + cluster -> node scatter in one launch -> (v, Ht, Rt, rec) or None when the shape needs the two-launch path."""
+    _chk(s, dyn, tmpl, c)
+    C = s.shape[-1]
+    if C != 64 or FORCE_CAP_BIG:
+        return None
+    v, Rt = torch.empty_like(s), torch.empty_like(s)
+    Ht = torch.empty(B, HT, C, device=s.device, dtype=torch.float32)
+    rec = torch.empty(B * T * N, C, device=s.device, dtype=torch.float32)
+    try:
+        _call("gptst_cap_cross_rec_fwd", _p(s), _p(dyn), _p(tmpl), _p(c), _p(v), _p(Ht), _p(Rt), _p(rec), B, T, N, C, HS, HT,
+              nbytes=_nb(s, dyn, c, v, Rt, rec))
+    except _C.GptstError as e:
+        if e.code != _C.ESHAPE:
+            raise
+        return None
+    return v, Ht, Rt, rec
+
+
 def cap_cross_bwd(dv, s, Rt, Ht, dyn, tmpl, B, T, HS, HT):
     _chk(dv, s, Rt, Ht, dyn, tmpl)
     C = s.shape[-1]
@@ -534,6 +553,25 @@ def cap_route_bwd(X, Wp, bp, c, dc1, dS, Y=None):
         _lds_or_stream(lambda: _call("gptst_cap_route_bwd", _p(X), _p(Wp), _p(bp), _p(c), _p(dc1), _p(dS), _p(dY), _p(dlogit), B * T, N, C, HS,
                                      nbytes=_nb(X, Wp, bp, c, dc1, dS, dY, dlogit)), stream)
     return dY, dlogit
+
+
+def cap_cross_route_bwd(X, Wp, bp, c, dc1, dv, s, Rt, Ht, dyn, tmpl, B, T, HS, HT):
+    """Cross-time backward + routing backward in one launch -> (dY, dlogit, ddyn) or None when the shape needs the two-launch path."""
+    _chk(X, Wp, bp, c, dc1, dv, s, Rt, Ht, dyn, tmpl)
+    N, C = X.shape[2], X.shape[3]
+    if C != 64 or FORCE_CAP_BIG:
+        return None
+    dY = torch.empty(B * T * N, C, device=X.device, dtype=torch.float32)
+    dlogit = torch.empty_like(c)
+    ddyn = torch.empty_like(dyn)
+    try:
+        _call("gptst_cap_cross_route_bwd", _p(X), _p(Wp), _p(bp), _p(c), _p(dc1), _p(dv), _p(s), _p(Rt), _p(Ht), _p(dyn), _p(tmpl), _p(dY),
+              _p(dlogit), _p(ddyn), B, T, N, C, HS, HT, nbytes=_nb(X, Wp, bp, c, dc1, dv, s, Rt, dY, dlogit))
+    except _C.GptstError as e:
+        if e.code != _C.ESHAPE:
+            raise
+        return None
+    return dY, dlogit, ddyn
 
 
 # ---- mask generation (integer path) -----------------------------------------------------------------------------

@@ -84,6 +84,10 @@ class PretrainStep:
         # opt-in: parameter-gradient reductions of finished layers on a second stream under the rest of the backward chain
         # (measured r02k: 558-579 vs 597 steps/s — the side kernels take CU slots from the chain, as the weight gradients did)
         self.red_side = engine.SideStream() if os.environ.get("GPTST_RED_STREAM", "0") == "1" else None
+        # generation of the STHCNs' parameters under the guide classifier + mask selection (small launches that leave most CUs idle)
+        self.gen_side = engine.SideStream() if os.environ.get("GPTST_GEN_BRANCH", "0") == "1" else None
+        # the guide classifier's backward (KL path) on a branch of its own beside the decoder forward and the whole backward chain
+        self.kl_side = engine.SideStream() if os.environ.get("GPTST_KL_BRANCH", "0") == "1" else None
 
     # ---- the enqueued work ---------------------------------------------------------------------------------------
     # A step is enqueued in two parts: part 1 ends with the guide classifier (the cluster labels of the local rows), part 2 starts
@@ -103,7 +107,7 @@ class PretrainStep:
         if not self.inject_noise and not self.force_mask:
             noise = (self.noise_g if phase == 0 else self.noise_ar_g) if self.gmask else (self.noise if phase == 0 else self.noise_ar)
         tidx = ops.step_begin(self.gbuf, self.arena.begin(zero=False), src, base, noise=noise, rng=self.rng_words)
-        gen = engine.gen_all(p, tidx, dims)                       # time embeddings + every generated parameter: 3 launches
+        gen = engine.gen_all(p, tidx, dims, side=self.gen_side)   # time embeddings + every generated parameter: 3 launches
         red = engine.Reductions(side=self.red_side)
         prob, sv_g = engine.guide_fwd(p, src, tidx, dims, base, gen=gen["guide"])
         if self._needs_exchange(phase):
@@ -129,17 +133,27 @@ class PretrainStep:
                 mask = ops.mask_adaptive(label, counts, self.ctrl[:self.HS], self.ctrl[self.HS:], self.noise_a, self.noise_r,
                                          a.ada_type == "all", base)[2]
         self.last_mask = mask
+        if self.gen_side is not None:
+            self.gen_side.join()
         emb, c1, tidx, sv_e = engine.model_fwd(p, src, mask, dims, base, mdl.num_route, mdl.scaler_zeros, gen=gen[engine.ENC], tidx=tidx)
         if self.fused_tails:
             # output head + masked MAE + their backward: one pass over dec (the mean's 1/#kept is applied by the optimiser)
             _, dec, sv_d = engine.decoder_fwd(p, tidx, emb, dims, mdl.num_route, gen=gen[engine.DEC], head=False)
             sws = self.arena.zeros(ops.tail_parts(M), 4)                       # per-workgroup loss statistics of the two heads
             chain = engine.chain_ok(dims)                                      # dPre chain: no backward kernel re-reads its layer's output
-            out, dd = engine.loss_tail(p, g, dec, src, mask, base, self.std, self.mean, a.mape_thresh, sws, red, chain=chain)
-            engine.model_bwd(p, g, src, mask, tidx, sv_e, sv_d, dec, None, None, dims, base, mdl.scaler_zeros, red, dd=dd, chain=chain)
-            if phase == 1:
+
+            def kl_path():
                 dh2 = engine.kl_head(p, g, sv_g, prob, c1, self.N, 0.1, sws, red, chain=chain)
                 engine.guide_bwd(p, g, src, tidx, sv_g, None, dims, base, red, dh2=dh2, chain=chain)
+            out, dd = engine.loss_tail(p, g, dec, src, mask, base, self.std, self.mean, a.mape_thresh, sws, red, chain=chain)
+            if phase == 1 and self.kl_side is not None:                        # needs only c1 / prob of the forward: beside the backward chain
+                with self.kl_side.fork():
+                    kl_path()
+            engine.model_bwd(p, g, src, mask, tidx, sv_e, sv_d, dec, None, None, dims, base, mdl.scaler_zeros, red, dd=dd, chain=chain)
+            if phase == 1 and self.kl_side is None:
+                kl_path()
+            if self.kl_side is not None:
+                self.kl_side.join()
             ops.stats_fold(sws, self.stats)                                    # ordered sum -> stats[0..2] (no float atomics)
         else:
             out, dec, sv_d = engine.decoder_fwd(p, tidx, emb, dims, mdl.num_route, gen=gen[engine.DEC])

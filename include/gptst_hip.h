@@ -167,12 +167,23 @@ int gptst_cap_cross_bwd(const float* dv, const float* s, const float* Rt, const 
                         float* dS, float* ddyn, float* ws, int B, int T, int C, int HS, int HT, void* stream);
 /* cluster -> node scatter (GPTST.py:135): rec[bt,n,:] = sum_h c[bt,h,n] v[bt,h,:]; and its backward (dc1, dv). */
 int gptst_cap_rec_fwd(const float* c, const float* v, float* rec, int BT, int N, int C, int HS, void* stream);
+/* gptst_cap_cross_fwd + gptst_cap_rec_fwd in ONE launch of B*T workgroups: every (b,t) workgroup rebuilds the sample's Ht (repeated by
+ * the T workgroups of a sample) and Rt / v of its own HS tokens, then scatters rec[bt] = c[bt]^T v[bt].  Bit-identical to the two launches.
+ * C = 64 and the sample's tokens + c[bt] within 80 KB of LDS, else GPTST_ESHAPE.  GPTST.py:125-135. */
+int gptst_cap_cross_rec_fwd(const float* s, const float* dyn, const float* tmpl, const float* c, float* v, float* Ht, float* Rt, float* rec,
+                            int B, int T, int N, int C, int HS, int HT, void* stream);
 int gptst_cap_rec_bwd(const float* drec, const float* c, const float* v, float* dc1, float* dv, int BT, int N, int C, int HS,
                       void* stream);
 /* backward through s = c P, c = softmax_h(b + dadj) (routing logits b are detached, GPTST.py:108-109) and the squash:
  * dY (BT*N,C) = grad of X Wp^T + bp;  dlogit (BT,HS,N) = grad of dadj. */
 int gptst_cap_route_bwd(const float* X, const float* Wp, const float* bp, const float* c, const float* dc1, const float* dS,
                         float* dY, float* dlogit, int BT, int N, int C, int HS, void* stream);
+/* gptst_cap_cross_bwd + gptst_cap_route_bwd in ONE launch of B*T workgroups: the backward of the cross-time block (GPTST.py:125-134) runs as a
+ * prologue of every (b,t) workgroup (the part that needs the whole sample is repeated by its T workgroups), dS stays in LDS.
+ * dv (B, T*HS, C): gradient of v;  -> dY, dlogit as gptst_cap_route_bwd, ddyn (B, HT, T*HS).  C = 64, else GPTST_ESHAPE. */
+int gptst_cap_cross_route_bwd(const float* X, const float* Wp, const float* bp, const float* c, const float* dc1, const float* dv,
+                              const float* s, const float* Rt, const float* Ht, const float* dyn, const float* tmpl, float* dY,
+                              float* dlogit, float* ddyn, int B, int T, int N, int C, int HS, int HT, void* stream);
 
 /* ---- cap for node counts whose (b,t) capsule matrix does not fit LDS (cap_big.hip; BASELINE config 5: N = 4096, C = 128) ----
  * gptst_cap_fits_lds() == 0 -> the host composes the same algebra from these streaming kernels (ops.py: cap_route_fwd/bwd, cap_rec_*):

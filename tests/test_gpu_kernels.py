@@ -819,6 +819,40 @@ def _philox_ref(i, step, seed):
     return [(w >> 8) * 2.0 ** -24 for w in c]
 
 
+@pytest.mark.parametrize("B,N,HS,HT", [(32, 170, 10, 16), (2, 20, 5, 6), (3, 37, 16, 5), (1, 266, 20, 16)])
+def test_cap_cross_folded_into_its_neighbours(B, N, HS, HT):
+    """gptst_cap_cross_rec_fwd == gptst_cap_cross_fwd + gptst_cap_rec_fwd bit for bit, and gptst_cap_cross_route_bwd ==
+    gptst_cap_cross_bwd + gptst_cap_route_bwd (same arithmetic; dS never leaves LDS)."""
+    from gptst_amd import ops
+    dev = _dev()
+    g = torch.Generator().manual_seed(61)
+    C, T = 64, 12
+    s = rnd(B * T, HS, C, g=g).to(dev)
+    dyn = (rnd(B, HT, T * HS, g=g) * 0.3).to(dev)
+    tmpl = (torch.arange(1, T + 1) / 12.0).float().to(dev)
+    c = torch.softmax(rnd(B * T, HS, N, g=g), 1).to(dev).contiguous()
+    v1, Ht1, Rt1 = ops.cap_cross_fwd(s, dyn, tmpl, B, T, HS, HT)
+    rec1 = ops.cap_rec_fwd(c, v1, N, C)
+    fused = ops.cap_cross_rec_fwd(s, dyn, tmpl, c, B, T, N, HS, HT)
+    assert fused is not None or HS * T > 200                 # (HS = 20: 240 tokens + c[bt] exceed the 80 KB the fused launch allows itself)
+    if fused is not None:
+        v2, Ht2, Rt2, rec2 = fused
+        assert torch.equal(v1, v2) and torch.equal(Ht1, Ht2) and torch.equal(Rt1, Rt2) and torch.equal(rec1, rec2)
+    X = rnd(B, T, N, C, g=g).to(dev)
+    Wp, bp = (rnd(C, C, g=g) * 0.1).to(dev), rnd(C, g=g).to(dev)
+    dc1, dv = rnd(B * T, HS, N, g=g).to(dev), rnd(B * T, HS, C, g=g).to(dev)
+    dS, ddyn1 = ops.cap_cross_bwd(dv, s, Rt1, Ht1, dyn, tmpl, B, T, HS, HT)
+    dY1, dl1 = ops.cap_route_bwd(X, Wp, bp, c, dc1, dS)
+    fb = ops.cap_cross_route_bwd(X, Wp, bp, c, dc1, dv, s, Rt1, Ht1, dyn, tmpl, B, T, HS, HT)
+    if fb is None:            # the prologue's scratch (T*HS tokens) must fit the capsule tile of N nodes: small N with many clusters keeps two launches
+        assert (T * HS + 2 * HT + HS) * (C + 4) + HT * T * HS > ((N + 15) // 16 * 16) * (C + 4) + max(C * C, 2 * 16 * (((N + 3) // 4 * 4) | 1))
+        return
+    dY2, dl2, ddyn2 = fb
+    close(ddyn2, ddyn1.cpu(), tol=2e-6, what="folded ddyn")
+    close(dY2, dY1.cpu(), tol=2e-6, what="folded dY")
+    close(dl2, dl1.cpu(), tol=2e-6, what="folded dlogit")
+
+
 def test_step_begin_draws_philox_noise():
     """gptst_step_begin fills the step's mask noise with Philox4x32-10 uniforms keyed by device words (seed, step): exact against a Python
     restatement of the published algorithm, in [0,1), uniform, and a different stream per step."""
