@@ -15,9 +15,26 @@ import numpy as np   # noqa: E402
 import torch         # noqa: E402
 
 from gptst_amd import data as gdata, synth                   # noqa: E402
-from gptst_amd.config import parse_args                      # noqa: E402
+from gptst_amd.config import apply_predictor_overrides, parse_args, predictor_args   # noqa: E402
 from gptst_amd.model import GPTST_Model, init_seed, xavier_init_   # noqa: E402
 from gptst_amd.trainer import Trainer                        # noqa: E402
+
+
+def load_series(args, dev):
+    """-> (data_root, loaders + scalers of gdata.get_dataloader): the dataset under -data_root, or — when its file is absent — a synthetic
+    series of the dataset's shape (METR_LA's file holds (L, N) without a channel axis, lib/load_dataset.py:57-60)."""
+    extra = [a for a in sys.argv[1:]]
+    data_root = extra[extra.index("-data_root") + 1] if "-data_root" in extra else "../data"
+    fname = gdata.DATASETS[args.dataset][0]
+    raw = None
+    if not os.path.exists(os.path.join(data_root, fname)):                       # synthetic stand-in of the dataset's shape
+        F = 3 if args.dataset == "PEMS08" else args.input_base_dim
+        raw = synth.make_series(args.num_nodes, F, interval=gdata.DATASETS[args.dataset][2], seed=args.seed)
+        if args.dataset == "METR_LA":
+            raw = raw[..., 0]
+        print("gpt-st_amd: %s not found -> synthetic %s-shaped series %s" % (os.path.join(data_root, fname), args.dataset, raw.shape))
+    g = torch.Generator().manual_seed(args.seed)
+    return data_root, gdata.get_dataloader(args, root=data_root, device=dev, raw=raw, generator=g)
 
 
 def main():
@@ -28,24 +45,13 @@ def main():
         return main_eval(args, dev)
     if args.mode != "pretrain":
         raise SystemExit("gpt-st_amd implements -mode pretrain and -mode eval -model STGCN")
-    extra = [a for a in sys.argv[1:]]
-    data_root = extra[extra.index("-data_root") + 1] if "-data_root" in extra else "../data"
     dp = None
     if int(os.environ.get("WORLD_SIZE", "1")) > 1:
         from gptst_amd.dist import DataParallel
         dp = DataParallel("nccl")
     init_seed(args.seed)
     args.log_dir = os.path.join(os.path.dirname(os.path.realpath(__file__)), "SAVE", args.dataset)
-    fname = gdata.DATASETS[args.dataset][0]
-    raw = None
-    if not os.path.exists(os.path.join(data_root, fname)):                       # synthetic stand-in of the dataset's shape
-        F = 3 if args.dataset == "PEMS08" else args.input_base_dim
-        raw = synth.make_series(args.num_nodes, F, interval=gdata.DATASETS[args.dataset][2], seed=args.seed)
-        if args.dataset == "METR_LA":
-            raw = raw[..., 0]
-        print("gpt-st_amd: %s not found -> synthetic %s-shaped series %s" % (os.path.join(data_root, fname), args.dataset, raw.shape))
-    g = torch.Generator().manual_seed(args.seed)
-    train, val, test, scaler, _, _ = gdata.get_dataloader(args, root=data_root, device=dev, raw=raw, generator=g)
+    _, (train, val, test, scaler, _, _) = load_series(args, dev)
     mean, std = float(scaler.mean), float(scaler.std)
     args.scaler_zeros = float(scaler.transform(0))                               # Run.py:67
     model = GPTST_Model(args)
@@ -60,10 +66,11 @@ def main():
         rank draws the same permutation and takes every world-th batch (all ranks see the same number of equally sized batches)."""
         full = train.n // args.batch_size                                        # batches of the full size
         usable = full if dp is None else (full // dp.world) * dp.world           # DP: whole groups of `world` full batches
-        for i, x in enumerate(train.iter_x()):
-            if dp is None:
+        if dp is None:
+            for x in train.iter_x():
                 yield x.contiguous()                                             # incl. the ragged last batch
-            elif i < usable and i % dp.world == dp.rank:
+        else:                                     # only this rank's batches are gathered (the permutation itself is drawn by every rank)
+            for x in train.iter_x(rank=dp.rank, world=dp.world, limit=usable):
                 yield x.contiguous()
 
     full = train.n // args.batch_size
@@ -88,28 +95,26 @@ def main_eval(args, dev):
     from gptst_amd.predictors import STGCN
     if str(args.model) != "STGCN":
         raise SystemExit("gpt-st_amd -mode eval implements -model STGCN (SURVEY.md §8f rank 4: one baseline predictor)")
-    extra = [a for a in sys.argv[1:]]
-    data_root = extra[extra.index("-data_root") + 1] if "-data_root" in extra else "../data"
+    pargs = predictor_args(args.dataset, str(args.model), [a for a in sys.argv[1:] if a.startswith("--") or not a.startswith("-")])
+    apply_predictor_overrides(args, pargs)       # reference Run.py:36-43: the predictor's schedule replaces the pretrain conf's (epochs 100, ...)
     init_seed(args.seed)
     args.log_dir = os.path.join(os.path.dirname(os.path.realpath(__file__)), "SAVE", args.dataset)
     os.makedirs(args.log_dir, exist_ok=True)
-    fname = gdata.DATASETS[args.dataset][0]
-    raw = None
-    if not os.path.exists(os.path.join(data_root, fname)):
-        F = 3 if args.dataset == "PEMS08" else args.input_base_dim
-        raw = synth.make_series(args.num_nodes, F, interval=gdata.DATASETS[args.dataset][2], seed=args.seed)
-        print("gpt-st_amd: %s not found -> synthetic %s-shaped series %s" % (os.path.join(data_root, fname), args.dataset, raw.shape))
-    g = torch.Generator().manual_seed(args.seed)
-    train, val, test, scaler, _, _ = gdata.get_dataloader(args, root=data_root, device=dev, raw=raw, generator=g)
+    data_root, (train, val, test, scaler, _, _) = load_series(args, dev)
     args.scaler_zeros = float(scaler.transform(0))
     csv_path = os.path.join(data_root, args.dataset, args.dataset + ".csv")
     A = (graph.adjacency_from_distance_csv(csv_path, args.num_nodes) if os.path.exists(csv_path)
          else graph.synthetic_adjacency(args.num_nodes, seed=args.seed))
-    ap = SimpleNamespace(Ks=3, Kt=3, num_nodes=args.num_nodes, G=graph.stgcn_graph(A), blocks1=[64, 32, 128], drop_prob=0, outputl_ks=3)
+    ap = SimpleNamespace(Ks=pargs.Ks, Kt=pargs.Kt, num_nodes=args.num_nodes, G=graph.stgcn_graph(A), blocks1=list(pargs.blocks1),
+                         drop_prob=pargs.drop_prob, outputl_ks=pargs.outputl_ks)
     model = EnhanceFrontEnd(args, predictor=STGCN(ap, dev, args.hidden_dim, args.output_dim)).to(dev)
     ckpt = args.log_dir + str(args.load_pretrain_path)                           # model/Model.py:92 (plain concatenation: '/GPTST_ada.pth')
     if os.path.exists(ckpt):
         model.load_pretrained_model(ckpt)                                        # model/Model.py:91-94
+    elif "-demo_random_encoder" not in sys.argv and os.environ.get("GPTST_DEMO_RANDOM_ENCODER", "0") != "1":
+        # the reference's load_pretrained_model raises on a missing file: "enhanced" results on a random frozen encoder are meaningless
+        raise FileNotFoundError("no pretrained encoder at %s (run -mode pretrain first; -demo_random_encoder runs the plumbing on a "
+                                "randomly initialised frozen encoder)" % ckpt)
     else:
         print("gpt-st_amd: no pretrained encoder at %s -> Xavier-initialised encoder (demo run)" % ckpt)
         for p_ in model.pretrain_model.parameters():                             # frozen (requires_grad False): xavier_init_ would skip them

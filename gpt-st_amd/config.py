@@ -78,3 +78,45 @@ def make_args(dataset="PEMS08", mode="pretrain", device="cpu", **overrides):
     for k, v in overrides.items():
         setattr(ns, k, v)
     return ns
+
+
+# ---- downstream predictors (-mode eval): reference lib/Params_predictor.py:4-25 + model/STGCN/args.py:52-76 -------------------------
+PRED_CONF = os.path.join(os.path.dirname(CONF_DIR), "GPTST_pretrain", "params_predictors.conf")
+_PRED_TRAIN = [("batch_size", int), ("epochs", int), ("lr_init", float), ("lr_decay", _EVAL), ("lr_decay_rate", float), ("lr_decay_step", str),
+               ("early_stop", _EVAL), ("early_stop_patience", int), ("grad_norm", _EVAL), ("max_grad_norm", int), ("debug", _EVAL),
+               ("real_value", _EVAL)]
+_STGCN_KEYS = [("data", "num_nodes", int), ("data", "input_window", int), ("data", "output_window", int), ("model", "Ks", int),
+               ("model", "Kt", int), ("model", "blocks1", _EVAL), ("model", "drop_prob", int), ("model", "outputl_ks", int),
+               ("train", "seed", int), ("train", "seed_mode", _EVAL), ("train", "xavier", _EVAL), ("train", "loss_func", str)]
+
+
+def predictor_args(dataset, model="STGCN", argv=None):
+    """The predictor's own argument set (double-dash flags as in the reference): the shared training schedule of
+    params_predictors.conf, then conf/<model>/<dataset>.conf.  Only STGCN is built."""
+    if model != "STGCN":
+        raise ValueError("gpt-st_amd builds the STGCN predictor only, got %r" % (model,))
+    cp = configparser.ConfigParser()
+    cp.optionxform = str
+    cp.read(PRED_CONF)
+    ap = argparse.ArgumentParser(prefix_chars="--", description="predictor_based_arguments")
+    for key, typ in _PRED_TRAIN:
+        ap.add_argument("--" + key, default=typ(cp["train"][key]), type=typ)
+    path = os.path.join(os.path.dirname(CONF_DIR), model, "%s.conf" % dataset)
+    if not os.path.isfile(path):
+        raise FileNotFoundError("no %s conf for dataset %r (%s)" % (model, dataset, path))
+    cm = configparser.ConfigParser()
+    cm.optionxform = str
+    cm.read(path)
+    for sec, key, typ in _STGCN_KEYS:
+        ap.add_argument("--" + key, default=typ(cm[sec][key]), type=typ)
+    pargs, _ = ap.parse_known_args([] if argv is None else argv)
+    return pargs
+
+
+def apply_predictor_overrides(args, pargs):
+    """reference Run.py:36-43: outside pretrain mode every attribute the predictor's argument set also has replaces the pretrain
+    conf's value (batch_size 64, epochs 100, lr_decay_step 25,50,75, early_stop_patience 25, debug False, xavier False, seed, ...)."""
+    for attr in list(vars(args)):
+        if hasattr(pargs, attr):
+            setattr(args, attr, getattr(pargs, attr))
+    return args

@@ -157,6 +157,114 @@ __global__ __launch_bounds__(256, 2) void hypertem_fwd_kernel(const float* __res
     }
 }
 
+// ---- 12-wave variant (r03): one time step per wave ------------------------------------------------------------------------------------------
+// The 4-wave kernel above runs three time steps per wave one after the other (mix -> 64 MFMAs -> epilogue, ~2 us each) behind the slab load,
+// and at B = 32 the 352 workgroups make 1.4 rounds of two co-resident workgroups.  Here a workgroup has 12 waves (3 per SIMD = the register
+// budget of 168), each owning ONE time step: the per-workgroup chain is load -> one step -> store, a CU holds one workgroup at a time, and
+// the three waves of a SIMD interleave mix (VALU) and MFMA phases.  NT = 16 only.
+__global__ __launch_bounds__(768, 3) void hypertem_fwd12_kernel(const float* __restrict__ X, const float* __restrict__ G,
+                                                                 const float* __restrict__ Wbt, const float* __restrict__ bbt,
+                                                                 float* __restrict__ R_out, float* __restrict__ out, int N, int B) {
+    constexpr int C = 64, P = C + 4, GP = 145, NT = 16;
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    float* Xs = smem;                               // [12][NT][P]
+    float* Gs = Xs + HT_T * NT * P;                 // [NT][GP]
+    int b, tile;
+#ifdef GPTST_DEBUG
+#define TS12(i) do { if (blockIdx.x == 59 && threadIdx.x == 64 * 5) g_ht_ts[i] = __builtin_readcyclecounter(); if (blockIdx.x == 200 && threadIdx.x == 64 * 5) g_ht_ts[16 + (i)] = __builtin_readcyclecounter(); } while (0)
+#else
+#define TS12(i) do { } while (0)
+#endif
+    TS12(0);
+    if (!ht_work((N + NT - 1) / NT, B, b, tile)) return;
+    const int n0 = tile * NT;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int j = lane & 15, kk = lane >> 4;
+    const int t = wave;
+    const size_t g = (size_t)b * HT_T + t;
+    // this wave's W_bt fragments and bias: requested first, consumed after the mix
+    float4 bv[C / 16][4];
+    {
+        const float* W_ = Wbt + g * C * C;
+#pragma unroll
+        for (int q = 0; q < C / 16; ++q)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) bv[q][e] = ld4(W_ + (size_t)(16 * q + 4 * kk + e) * C + 4 * j);
+    }
+    const float4 b4 = ld4(bbt + g * C + 4 * j);
+    {   // slab staging: thread = (time third, row, float4 column): 4 time slices each
+        const int th = tid >> 8, r = tid & 255, nl = r >> 4, c4 = r & 15;
+        const int n = min(n0 + nl, N - 1);
+        float4 v[4];
+        float gv[3];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) v[i] = ld4(X + (((size_t)b * HT_T + 4 * th + i) * N + n) * C + 4 * c4);
+#pragma unroll
+        for (int k = 0; k < 3; ++k) gv[k] = G[min(n0 * 144 + tid + k * 768, N * 144 - 1)];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) st4(Xs + ((4 * th + i) * NT + nl) * P + 4 * c4, n0 + nl < N ? v[i] : f4zero());
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+            const int i = tid + k * 768;
+            Gs[(i / 144) * GP + i % 144] = (n0 + i / 144 < N) ? gv[k] : 0.f;
+        }
+    }
+    TS12(1);
+    __syncthreads();
+    SB();
+    TS12(2);
+    float4 a4[C / 16];
+#pragma unroll
+    for (int q = 0; q < C / 16; ++q) a4[q] = f4zero();
+    {
+        const float* gr = Gs + j * GP + t * HT_T;
+        const float* xr = Xs + j * P + 4 * kk;
+#pragma unroll
+        for (int u = 0; u < HT_T; ++u) {
+            const float gu = gr[u];
+#pragma unroll
+            for (int q = 0; q < C / 16; ++q) a4[q] = f4fma(gu, ld4(xr + u * NT * P + 16 * q), a4[q]);
+        }
+    }
+    SB();
+    TS12(3);
+    f32x4 acc[C / 16];
+#pragma unroll
+    for (int ct = 0; ct < C / 16; ++ct) acc[ct] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int q = 0; q < C / 16; ++q) {
+        const float av[4] = {a4[q].x, a4[q].y, a4[q].z, a4[q].w};
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            acc[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[e], bv[q][e].x, acc[0], 0, 0, 0);
+            acc[1] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[e], bv[q][e].y, acc[1], 0, 0, 0);
+            acc[2] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[e], bv[q][e].z, acc[2], 0, 0, 0);
+            acc[3] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[e], bv[q][e].w, acc[3], 0, 0, 0);
+        }
+    }
+    SB();
+    TS12(4);
+    if (R_out != nullptr && n0 + j < N) {
+#pragma unroll
+        for (int q = 0; q < C / 16; ++q) st4(R_out + (g * N + n0 + j) * C + 16 * q + 4 * kk, a4[q]);
+    }
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        const int nl = kk * 4 + r;
+        if (n0 + nl < N) {
+            float4 y = f4add(f4add(make_float4(acc[0][r], acc[1][r], acc[2][r], acc[3][r]), b4), ld4(Xs + (t * NT + nl) * P + 4 * j));
+            y.x = lrelu(y.x); y.y = lrelu(y.y); y.z = lrelu(y.z); y.w = lrelu(y.w);
+            st4(out + (g * N + n0 + nl) * C + 4 * j, y);
+        }
+    }
+    TS12(5);
+#ifdef GPTST_DEBUG
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#endif
+    TS12(6);
+}
+
+thread_local int g_ht_fwd12 = 0;          // gptst_tune(12, 1): the 12-wave forward
 static size_t ht_smem(int NT) { return ((size_t)HT_T * NT * 68 + NT * 145) * sizeof(float); }
 
 extern "C" int gptst_hypertem_fwd(const float* X, const float* G, const float* Wbt, const float* bbt, float* R_out, float* out, int B,
@@ -166,6 +274,13 @@ extern "C" int gptst_hypertem_fwd(const float* X, const float* G, const float* W
     static int done = 0;
     if (!done) { hipFuncSetAttribute((const void*)hypertem_fwd_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ht_smem(16)); done = 1; }
     const int NT = ht_pick_nt(B, N);
+    if (g_ht_fwd12) {
+        static int done12 = 0;
+        if (!done12) { hipFuncSetAttribute((const void*)hypertem_fwd12_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ht_smem(16)); done12 = 1; }
+        hipLaunchKernelGGL(hypertem_fwd12_kernel, dim3(8 * ((B + 7) / 8) * ((N + 15) / 16)), dim3(768), ht_smem(16), (hipStream_t)stream, X, G, Wbt, bbt, R_out, out, N, B);
+        GPTST_CHECK_LAUNCH();
+        return GPTST_OK;
+    }
     hipLaunchKernelGGL(hypertem_fwd_kernel, dim3(8 * ((B + 7) / 8) * ((N + NT - 1) / NT)), dim3(256), ht_smem(NT), (hipStream_t)stream, X, G, Wbt, bbt, R_out, out, N, B, NT, g_ht_dbg);
     GPTST_CHECK_LAUNCH();
     return GPTST_OK;

@@ -382,7 +382,9 @@ extern thread_local int g_apply_tpw;
 extern thread_local int g_tl_nb;
 extern thread_local int g_wgrad_v1;
 extern thread_local int g_apply128_v1;
+extern thread_local int g_ht_fwd12;
 extern "C" int gptst_tune(int id, int value) {
+    if (id == 12) g_ht_fwd12 = value;
     if (id == 1 && value > 0 && value <= PG_MAXROWS) g_pg_rows = value;
     if (id == 6 && value > 0) g_tl_nb = value;
     if (id == 2) g_wgrad_ns_override = value;

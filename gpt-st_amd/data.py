@@ -103,10 +103,14 @@ class WindowLoader:
         for i in range(0, self.n, self.bs):
             yield self.windows(order[i:i + self.bs])
 
-    def iter_x(self):
-        """Input windows only (pretraining never reads the y windows, BasicTrainer.py:74-76): one gather per batch instead of two."""
+    def iter_x(self, rank=0, world=1, limit=None):
+        """Input windows only (pretraining never reads the y windows, BasicTrainer.py:74-76): one gather per batch instead of two.
+        rank / world: data parallelism — the permutation of the epoch is drawn in full (every rank draws the same one), but only batches
+        rank, rank + world, ... (of the first `limit`) are gathered; the others cost nothing."""
         order = self._order()
-        for i in range(0, self.n, self.bs):
+        for k, i in enumerate(range(0, self.n, self.bs)):
+            if (limit is not None and k >= limit) or k % world != rank:
+                continue
             idx = order[i:i + self.bs].to(self.series.device)
             yield self.series[idx[:, None] + self._tx[None, :]]
 

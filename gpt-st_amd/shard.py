@@ -95,7 +95,12 @@ class NativeNodeGroup:
 
     def all_reduce_(self, t):
         if t.dtype == torch.float32:
-            self.comm.allreduce_(t if t.is_contiguous() else t.contiguous())
+            if t.is_contiguous():
+                self.comm.allreduce_(t)
+            else:                                   # reduce a contiguous copy and write the sums back (an in-place reduce of the copy would be lost)
+                f = t.contiguous()
+                self.comm.allreduce_(f)
+                t.copy_(f)
             return t
         f = t.to(torch.float32)
         self.comm.allreduce_(f)

@@ -83,7 +83,7 @@ def test_model_vs_reference_golden(tag):
         scale = float(ref.abs().max())
         err = float((val - ref).abs().max()) / max(scale, 1e-6)
         worst = max(worst, err)
-        assert err < 3e-4, (k, err, scale)          # gradients through ~40 fp32 layers vs the REFERENCE's own gradients
+        assert err < 1e-4, (k, err, scale)          # gradients through ~40 fp32 layers vs the REFERENCE's own gradients (north star: 1e-4; measured 1.6e-5)
     from conftest import record_current
     record_current("grad_worst_vs_reference", worst)
     print(tag, "worst grad rel err", worst)

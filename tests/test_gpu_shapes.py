@@ -92,6 +92,6 @@ def test_model_vs_oracle(name, parity):
             continue
         e = rel(pm.grad, gr)
         worst = max(worst, e)
-        assert e < 6e-4, (name, k, e)       # measured worst over all cases 2.6e-4 (c128_rand), typically 2e-5 (profiles/parity_r02.json)
+        assert e < 2e-4, (name, k, e)       # <= 2x the measured worst over all cases: 9.4e-5 (nyc_taxi), typically 2e-5 (profiles/parity_r0*.json)
     parity("grad_worst", worst)
     print(name, "worst grad rel err %.2e" % worst)

@@ -111,7 +111,7 @@ def test_node_shards_equal_unsharded_step(W, N, B, over, parity):
         upd = v - sd[k]
         err = float((got_sd[k] - v).norm() / upd.norm().clamp_min(1e-6))
         worst = max(worst, err)
-        assert err < 2e-3, "%s: update differs, rel-L2 of the update error %.3e" % (k, err)
+        assert err < 1.2e-3, "%s: update differs, rel-L2 of the update error %.3e" % (k, err)
     parity("update_rel_l2_worst", worst)
     print("worst relative update error %.2e" % worst)
 

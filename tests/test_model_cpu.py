@@ -83,3 +83,57 @@ def test_library_exports_exactly_the_header():
     out = subprocess.run([nm, "-D", "--defined-only", _C.LIB_PATH], capture_output=True, text=True, check=True).stdout
     exp = {ln.split()[-1] for ln in out.splitlines() if " T " in ln and ln.split()[-1].startswith("gptst_")}
     assert exp == hdr, (sorted(exp - hdr), sorted(hdr - exp))
+
+
+def test_integration_stub_matches_header():
+    """The ctypes stub a maintainer would copy out of INTEGRATION.md (section 2) declares the prototype include/gptst_hip.h declares: same
+    entry point, same number and kinds of arguments, and the call passes that many values (a stale stub corrupts memory, it does not fail)."""
+    import ctypes
+    from gptst_amd import _C
+    txt = open(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "INTEGRATION.md")).read()
+    blocks = re.findall(r"```python\n(.*?)```", txt, flags=re.S)
+    stub = [b for b in blocks if "argtypes" in b]
+    assert len(stub) == 1
+    stub = stub[0]
+    m = re.search(r"lib\.(gptst_\w+)\.argtypes\s*=\s*(.+)", stub)
+    name, expr = m.group(1), m.group(2)
+    declared = eval(expr, {"ctypes": ctypes})
+    want = _C.parse_header()[name]
+    assert [t is ctypes.c_void_p for t in declared] == [t is ctypes.c_void_p for t in want], (declared, want)
+    assert all(d is w for d, w in zip(declared, want))
+    call = re.search(r"lib\.%s\((.*?)\)\nassert" % name, stub, flags=re.S).group(1)
+    depth, nargs = 0, 1
+    for ch in call:
+        depth += ch in "([{"
+        depth -= ch in ")]}"
+        nargs += (ch == "," and depth == 0)
+    assert nargs == len(want), (nargs, len(want))
+
+
+def test_predictor_conf_overrides_the_pretrain_schedule():
+    """-mode eval (reference Run.py:36-43): every attribute the predictor's argument set also has replaces the pretrain conf's value —
+    epochs 100, lr_decay_step 25,50,75, early_stop_patience 25, batch_size 64, debug / xavier False, seed from conf/STGCN/<dataset>.conf."""
+    from gptst_amd.config import apply_predictor_overrides, predictor_args
+    for ds, seed, n in (("PEMS08", 12, 170), ("METR_LA", 0, 207), ("NYC_TAXI", 12, 266), ("NYC_BIKE", 12, 250)):
+        a = make_args(ds, mode="eval")
+        assert a.epochs == 300 and a.early_stop_patience >= 80                       # the pretrain conf's schedule
+        p = predictor_args(ds, "STGCN", ["--lr_init", "0.01"])
+        apply_predictor_overrides(a, p)
+        assert (a.epochs, a.lr_decay_step, a.early_stop_patience, a.batch_size) == (100, "25, 50, 75", 25, 64)
+        assert (a.debug, a.xavier, a.seed, a.lr_init, a.num_nodes) == (False, False, seed, 0.01, n)
+        assert (p.Ks, p.Kt, p.blocks1, p.drop_prob, p.outputl_ks) == (3, 3, [64, 32, 128], 0, 3)
+    with pytest.raises(ValueError):
+        predictor_args("PEMS08", "GWN")
+
+
+def test_window_loader_rank_slices_partition_the_epoch():
+    """iter_x(rank, world, limit): the ranks' batches are disjoint, together they are the first `limit` batches of the one permutation."""
+    import numpy as np
+    from gptst_amd.data import WindowLoader
+    series = torch.arange(200 * 3, dtype=torch.float32).view(200, 3, 1)
+    mk = lambda: WindowLoader(series, 12, 12, 8, shuffle=True, generator=torch.Generator().manual_seed(5))
+    full = [x for x in mk().iter_x()]
+    parts = [[x for x in mk().iter_x(rank=r, world=3, limit=18)] for r in range(3)]
+    assert [len(p) for p in parts] == [6, 6, 6]
+    for k in range(18):
+        assert torch.equal(parts[k % 3][k // 3], full[k])
