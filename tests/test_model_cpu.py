@@ -3,6 +3,7 @@ import json
 import os
 import re
 
+import pytest
 import torch
 
 from golden_util import GOLDEN
