@@ -198,9 +198,11 @@ def main():
                     help="data parallel only: weak = every rank steps its own batch of --batch (default); strong = ONE global batch of "
                          "--global-batch samples split evenly over the ranks (SURVEY 8d c3: 256 = 32 x 8)")
     ap.add_argument("--global-batch", type=int, default=256, help="global batch of --scaling strong")
-    ap.add_argument("--native-comm", action="store_true",
-                    help="--shard nodes: collectives on the C-ABI communicator (RCCL enqueues on the launch stream), the whole sharded step "
-                         "in ONE hipGraph per phase also with several ranks (default: torch.distributed between eagerly enqueued kernels)")
+    ap.add_argument("--native-comm", dest="native_comm", action="store_true", default=None,
+                    help="per-step collectives on the C-ABI communicator (RCCL enqueues on the launch stream): the whole step incl. its "
+                         "collectives and the optimiser is ONE hipGraph per phase, also with several ranks.  DEFAULT for --gpus N > 1 "
+                         "(data parallel and node-sharded); --torch-comm keeps torch.distributed collectives between graph replays")
+    ap.add_argument("--torch-comm", dest="native_comm", action="store_false")
     ap.add_argument("--no-graph", action="store_true")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-timing", action="store_true")
@@ -225,9 +227,13 @@ def main():
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     dp = None
-    if world > 1 or os.environ.get("GPTST_FORCE_DP") == "1":      # FORCE_DP: exercise the RCCL path with one rank
+    force_dp = os.environ.get("GPTST_FORCE_DP") == "1"            # FORCE_DP: exercise the RCCL path with one rank
+    if a.native_comm is None:                                      # default: the capturable communicator whenever there is communication,
+        a.native_comm = (world > 1 or force_dp) and os.environ.get("GPTST_DIST_BACKEND", "nccl") == "nccl"   # unless ranks share a GPU (gloo tests)
+    if world > 1 or force_dp:
         from gptst_amd.dist import DataParallel
-        dp = DataParallel(os.environ.get("GPTST_DIST_BACKEND", "nccl"))   # nccl = RCCL over xGMI; gloo only to exercise the path on one GPU
+        dp = DataParallel(os.environ.get("GPTST_DIST_BACKEND", "nccl"),   # nccl = RCCL over xGMI; gloo only to exercise the path on one GPU
+                          native=bool(a.native_comm) and a.shard == "batch")
 
     over = {}
     if a.nodes:
@@ -327,6 +333,10 @@ def main():
         "samples_per_s": steps_s * gbatch,
         "steps_per_s_random_mask_phase": rnd_rate,
         "last_loss": loss[0],
+        # evidence that the job's collectives span the ranks it was started with, and how the step is enqueued
+        "rccl_ranks": (group.comm.count() if (a.shard == "nodes" and a.native_comm) else (dp.rccl_ranks() if dp is not None else None)),
+        "comm": (None if (dp is None and world == 1) else ("c-abi rccl, captured in the step graph" if a.native_comm else "torch.distributed between graph replays")),
+        "graph": bool(getattr(stepper, "shard_graph", False)) if a.shard == "nodes" else not a.no_graph,
         "hbm_peak_gb": round(torch.cuda.max_memory_allocated() / 2**30, 2),
         "alloc_retries": int(torch.cuda.memory_stats().get("num_alloc_retries", 0)),
     }

@@ -48,7 +48,8 @@ def main():
     dp = None
     if int(os.environ.get("WORLD_SIZE", "1")) > 1:
         from gptst_amd.dist import DataParallel
-        dp = DataParallel("nccl")
+        # per-step collectives on the C-ABI communicator (captured inside the step's hipGraph); GPTST_NATIVE_COMM=0: torch.distributed
+        dp = DataParallel("nccl", native=os.environ.get("GPTST_NATIVE_COMM", "1") == "1" and os.environ.get("GPTST_DIST_BACKEND", "nccl") == "nccl")
     init_seed(args.seed)
     args.log_dir = os.path.join(os.path.dirname(os.path.realpath(__file__)), "SAVE", args.dataset)
     _, (train, val, test, scaler, _, _) = load_series(args, dev)

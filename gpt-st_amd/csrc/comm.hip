@@ -16,8 +16,9 @@ typedef int (*GetUniqueId_t)(Uid*);
 typedef int (*CommInitRank_t)(void**, int, Uid, int);
 typedef int (*AllReduce_t)(const void*, void*, size_t, int, int, void*, hipStream_t);
 typedef int (*CommDestroy_t)(void*);
-struct Api { void* lib; GetUniqueId_t uid; CommInitRank_t init; AllReduce_t allreduce; CommDestroy_t destroy; };
-Api g_api = {nullptr, nullptr, nullptr, nullptr, nullptr};
+typedef int (*CommCount_t)(void*, int*);
+struct Api { void* lib; GetUniqueId_t uid; CommInitRank_t init; AllReduce_t allreduce; CommDestroy_t destroy; CommCount_t count; };
+Api g_api = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
 void* g_comm = nullptr;
 int g_world = 0;
 
@@ -29,7 +30,7 @@ bool bind() {
     if (!h) for (const char* n : names) { h = dlopen(n, RTLD_NOW | RTLD_GLOBAL); if (h) break; }
     if (!h) return false;
     Api a{h, (GetUniqueId_t)dlsym(h, "ncclGetUniqueId"), (CommInitRank_t)dlsym(h, "ncclCommInitRank"),
-          (AllReduce_t)dlsym(h, "ncclAllReduce"), (CommDestroy_t)dlsym(h, "ncclCommDestroy")};
+          (AllReduce_t)dlsym(h, "ncclAllReduce"), (CommDestroy_t)dlsym(h, "ncclCommDestroy"), (CommCount_t)dlsym(h, "ncclCommCount")};
     if (!a.uid || !a.init || !a.allreduce || !a.destroy) return false;
     g_api = a;
     return true;
@@ -60,6 +61,15 @@ extern "C" int gptst_allreduce_f32(float* buf, long n, void* stream) {
     if (!buf || n <= 0) return GPTST_EARG;
     if (!g_comm) return GPTST_ECOMM;
     const int rc = g_api.allreduce(buf, buf, (size_t)n, 7, 0, g_comm, (hipStream_t)stream);
+    return rc == 0 ? GPTST_OK : 1000 + rc;
+}
+
+// number of ranks RCCL itself reports for the communicator (ncclCommCount) -> *out; lets a launcher verify that the job's collectives really
+// span the ranks it started (bench.py prints it as rccl_ranks)
+extern "C" int gptst_comm_count(int* out) {
+    if (!out) return GPTST_EARG;
+    if (!g_comm || !g_api.count) return GPTST_ECOMM;
+    const int rc = g_api.count(g_comm, out);
     return rc == 0 ? GPTST_OK : 1000 + rc;
 }
 

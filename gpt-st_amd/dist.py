@@ -18,7 +18,11 @@ import torch.distributed as dist
 
 
 class DataParallel:
-    def __init__(self, backend=None):
+    """native=True: the per-step collectives (gradient all-reduce, label gather) run on the C-ABI communicator (NativeComm: RCCL enqueues on
+    torch's current stream) and are therefore CAPTURABLE — the step, its collectives and the optimiser are then ONE hipGraph per phase
+    (step.py).  torch.distributed stays for the rendezvous, the initial weight broadcast and the host-side barrier / max of the bench."""
+
+    def __init__(self, backend=None, native=False):
         self.rank = int(os.environ.get("RANK", "0"))
         self.world = int(os.environ.get("WORLD_SIZE", "1"))
         self.local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -29,16 +33,42 @@ class DataParallel:
             os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
             os.environ.setdefault("MASTER_PORT", "29511")
             dist.init_process_group(backend=backend, rank=self.rank, world_size=self.world)
+        self.native = NativeComm(rank=self.rank, world=self.world) if native else None
+        self._slots = None
+
+    @property
+    def capturable(self):
+        """the per-step collectives are plain stream-ordered enqueues (no torch.distributed call): they can sit inside a hipGraph"""
+        return self.native is not None
+
+    def rccl_ranks(self):
+        """ranks RCCL reports for the native communicator (ncclCommCount), or the torch.distributed world size under nccl; None on gloo"""
+        if self.native is not None:
+            return self.native.count()
+        return dist.get_world_size() if dist.get_backend() == "nccl" else None
 
     def allreduce_(self, buf):
         """In-place sum over ranks of the packed [gradient | statistics] buffer (one collective per step)."""
-        dist.all_reduce(buf, op=dist.ReduceOp.SUM)
+        if self.native is not None:
+            self.native.allreduce_(buf)
+        else:
+            dist.all_reduce(buf, op=dist.ReduceOp.SUM)
         return buf
 
     def gather_labels(self, local, out=None):
         """Concatenate the ranks' label vectors in rank order (= batch-major order of the global batch)."""
         if out is None:
             out = torch.empty(self.world * local.numel(), dtype=local.dtype, device=local.device)
+        if self.native is not None:
+            # all-gather as an all-reduce of a slot buffer: every rank fills its own slot with its labels as exactly representable floats
+            # (the C-ABI communicator reduces fp32 only; labels < HS <= 64)
+            if self._slots is None or self._slots.numel() != out.numel():
+                self._slots = torch.zeros(out.numel(), dtype=torch.float32, device=local.device)
+            self._slots.zero_()
+            self._slots[self.rank * local.numel():(self.rank + 1) * local.numel()].copy_(local)
+            self.native.allreduce_(self._slots)
+            out.copy_(self._slots)
+            return out
         if self.world == 1:
             out.copy_(local)
             return out
@@ -105,6 +135,13 @@ class NativeComm:
         assert buf.is_cuda and buf.dtype == torch.float32 and buf.is_contiguous()
         self.lib.call("gptst_allreduce_f32", buf.data_ptr(), buf.numel(), torch.cuda.current_stream().cuda_stream)
         return buf
+
+    def count(self):
+        """ncclCommCount of the communicator"""
+        import ctypes
+        n = ctypes.c_int(0)
+        self.lib.call("gptst_comm_count", ctypes.byref(n))
+        return int(n.value)
 
     def close(self):
         self.lib.call("gptst_comm_destroy")

@@ -97,6 +97,11 @@ class PretrainStep:
     def _needs_exchange(self, phase):
         return self.gmask and phase == 1 and not self.force_mask
 
+    def _dp_in_graph(self):
+        """Data parallel on a capturable communicator (dist.DataParallel(native=True)): label gather, gradient all-reduce and optimiser are
+        enqueued as part of the step body — one hipGraph per phase holds everything, as in the single-GPU case."""
+        return self.dp is not None and getattr(self.dp, "capturable", False)
+
     def _part1(self, phase):
         p, dims, base = self.model.param_views(), self.dims, self.base
         engine.CTX.ARENA = self.arena
@@ -168,6 +173,9 @@ class PretrainStep:
         engine.CTX.ARENA = None
         engine.CTX.SIDE = None
         if self.dp is None:
+            self._optim()
+        elif self._dp_in_graph():           # gradient all-reduce + optimiser as the last nodes of the step's graph (no host gap behind the replay)
+            self.dp.allreduce_(self.gbuf)
             self._optim()
 
     def _global_mask(self, phase):
@@ -277,7 +285,7 @@ class PretrainStep:
             if g2 is not None:                          # global masks, adaptive phase: labels are exchanged between the two graphs
                 self._exchange_labels()
                 g2.replay()
-        if self.dp is not None:
+        if self.dp is not None and not self._dp_in_graph():
             self.dp.allreduce_(self.gbuf)
             self._optim()
 
@@ -295,7 +303,7 @@ class PretrainStep:
         ops.set_deterministic(self.deterministic)
         try:
             g1 = torch.cuda.CUDAGraph()
-            if self._needs_exchange(phase):
+            if self._needs_exchange(phase) and not self._dp_in_graph():
                 with torch.cuda.graph(g1, capture_error_mode="thread_local"):      # other threads (RCCL watchdog) may call the runtime meanwhile
                     ctx = self._part1(phase)
                 g2 = torch.cuda.CUDAGraph()
@@ -305,7 +313,10 @@ class PretrainStep:
             else:
                 g2 = None
                 with torch.cuda.graph(g1, capture_error_mode="thread_local"):
-                    self._part2(phase, self._part1(phase))
+                    ctx = self._part1(phase)
+                    if self._needs_exchange(phase):                                # capturable communicator: the label gather is a graph node
+                        self._exchange_labels()
+                    self._part2(phase, ctx)
         finally:
             ops.set_deterministic(False)
         self.graphs[key] = (g1, g2)

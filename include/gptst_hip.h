@@ -22,7 +22,7 @@
 extern "C" {
 #endif
 
-#define GPTST_ABI_VERSION 3
+#define GPTST_ABI_VERSION 4
 int gptst_abi_version(void);
 /* 1: bit-reproducible steps — the two reductions that end in float atomics by default (embedding gradients of gptst_pool_jobs kind 2,
  * weight gradients of gptst_timefeat_jobs) run as single-owner kernels with a fixed summation order (slower).  Everything else is
@@ -332,6 +332,7 @@ int gptst_clip_adam(float* p, const float* g, float* m, float* v, long nA, long 
 int gptst_comm_unique_id(void* out128);
 int gptst_comm_init(int rank, int world, const void* unique_id);
 int gptst_allreduce_f32(float* buf, long n, void* stream);      /* in-place sum over the ranks */
+int gptst_comm_count(int* out);                                /* ncclCommCount of the communicator */
 int gptst_comm_destroy(void);
 
 #ifdef __cplusplus

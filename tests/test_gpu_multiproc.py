@@ -68,6 +68,59 @@ def test_bench_rccl_backend():
                          dict(GPTST_FORCE_DP="1", GPTST_DIST_BACKEND="nccl"))
         assert out["n_gpus"] == 1
     assert out["value"] > 0 and out["last_loss"] == out["last_loss"] and out["last_loss"] > 0
+    # the collectives ran on the C-ABI communicator inside the step's hipGraph, and RCCL itself reports the rank count of the job
+    assert out["rccl_ranks"] == out["n_gpus"] and out["graph"] is True and "c-abi" in out["comm"]
+
+
+def test_bench_dp_torch_comm_fallback():
+    """--torch-comm: torch.distributed (RCCL) collectives between graph replays, as before round 3 — still one line, still counts its ranks."""
+    out = _run_plain(["--gpus", "1", "--steps", "4", "--warmup", "2", "--batch", "4", "--no-cpu-baseline", "--no-kernel-timing", "--torch-comm"],
+                     dict(GPTST_FORCE_DP="1", GPTST_DIST_BACKEND="nccl"))
+    assert out["value"] > 0 and out["rccl_ranks"] == 1 and "torch.distributed" in out["comm"]
+
+
+def test_dp_step_in_one_graph_equals_the_plain_step():
+    """Data parallel on the capturable communicator (one rank): label gather, gradient all-reduce and optimiser are nodes of the step's ONE
+    hipGraph; a step sequence crossing both mask phases gives the same losses and weights as the plain single-GPU stepper."""
+    import torch
+    import torch.distributed as dist
+    from gptst_amd import synth
+    from gptst_amd.config import make_args
+    from gptst_amd.dist import DataParallel
+    from gptst_amd.model import GPTST_Model
+    from gptst_amd.step import PretrainStep
+    from oracle import gptst_oracle as O
+    os.environ.update(RANK="0", WORLD_SIZE="1", LOCAL_RANK="0", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(29700 + os.getpid() % 200))
+    args = make_args("PEMS08", num_nodes=24, embed_dim=8, HS=6, HT=8, scaler_zeros=synth.scaler_zeros(), epochs=30, change_epoch=3)
+    sd = O.init_state_dict(args, 3)
+    B, M = 4, 4 * 12 * 24
+    src = synth.make_batch(B, 12, 24, 1, seed=5).to("cuda:0")
+    dp = DataParallel("nccl", native=True)
+    try:
+        assert dp.capturable and dp.rccl_ranks() == 1
+        res = []
+        for d in (None, dp):
+            model = GPTST_Model(args)
+            model.load_state_dict(sd)
+            model = model.to("cuda:0")
+            st = PretrainStep(model, args, synth.SCALER_MEAN, synth.SCALER_STD, batch_size=B, use_graph=True, dp=d, seed=7)
+            losses = []
+            for i, epoch in enumerate((1, 1, 20, 20, 20)):
+                kw = (dict(noise=synth.make_noise(M, 10 + i).to("cuda:0")) if epoch == 1 else
+                      dict(noise_a=synth.make_noise(M, 20 + i).to("cuda:0"), noise_r=synth.make_noise(M, 30 + i).to("cuda:0"),
+                           list_c=synth.class_order(6, 40 + i)))
+                st.step(src, epoch, **kw)
+                losses.append(st.losses())
+            if d is not None:
+                assert all(g2 is None for _, g2 in st.graphs.values()), "one graph per phase, collectives inside"
+            res.append((losses, {k: v.detach().clone() for k, v in model.state_dict().items()}))
+        for a, b in zip(res[0][0], res[1][0]):
+            assert abs(a[0] - b[0]) <= 1e-6 * abs(a[0]), (a, b)
+        worst = max(float((res[0][1][k].float() - res[1][1][k].float()).abs().max()) for k in res[0][1])
+        assert worst < 1e-6, worst
+    finally:
+        dp.native.close()
+        dist.destroy_process_group()
 
 
 def test_bench_stdout_is_one_line_with_rccl_banner_enabled():
