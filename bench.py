@@ -46,8 +46,10 @@ def kernel_flops(name, tag, d):
         return 2.0 * rows * C * T
     if name == "gptst_cap_route_fwd":
         return 2.0 * rows * C * C + (2 * R + 2) * 2.0 * B * T * HS * N * C
-    if name == "gptst_cap_route_bwd":
+    if name in ("gptst_cap_route_bwd", "gptst_cap_cross_route_bwd"):
         return 2.0 * rows * C * C + 2 * 2.0 * B * T * HS * N * C
+    if name in ("gptst_apply_wgrad", "gptst_linear_bwd"):
+        return 4.0 * rows * C * C
     if name in ("gptst_cap_rec_fwd",):
         return 2.0 * B * T * HS * N * C
     if name in ("gptst_cap_rec_bwd",):
@@ -59,20 +61,46 @@ def kernel_flops(name, tag, d):
 KERNEL_SYMBOL = {
     "gptst_cap_route_fwd": "void cap_route_fwd2_kernel<64,", "gptst_cap_route_bwd": "void cap_route_bwd2_kernel<64>",
     "gptst_hypertem_fwd": "hypertem_fwd_kernel", "gptst_hypertem_bwd": "hypertem_bwd_kernel", "gptst_wgrad": "void wgrad64_kernel",
-    "gptst_hypertem_bwd_wgrad": "void hypertem_bwd_wgrad_kernel<",
+    "gptst_hypertem_bwd_wgrad": "void hypertem_bwd_wgrad_kernel<", "gptst_cap_cross_route_bwd": "void cap_route_bwd2_kernel<64>",
+    "gptst_cap_cross_rec_fwd": "void cap_cross_rec_fwd_kernel<64>", "gptst_apply_wgrad": "void applywg64_kernel<0,", "gptst_linear_bwd": "void applywg64_kernel<1,",
     "gptst_apply": "void apply64_kernel<", "gptst_tmix": "void tmix_kernel<64", "gptst_tmix_dgraph": "void tmix_dgraph_kernel<64>",
     "gptst_cap_rec_bwd": "void cap_rec_bwd2_kernel<64>", "gptst_cap_cross_bwd": "void cap_cross_bwd_kernel<64>",
     "gptst_cap_rec_fwd": "void cap_rec_fwd_kernel<64>",
 }
 
 
+def kernel_source_hash():
+    """sha256 over the kernel sources (csrc/*.hip, *.h + the C-ABI header): identifies the code a PMC pass was collected on.  (The snapshot
+    on the GPU box has no .git, so a commit id is not available there; tools/pmc_to_json.py stores this hash next to the counters.)"""
+    import hashlib
+    h = hashlib.sha256()
+    csrc = os.path.join(ROOT, "gpt-st_amd", "csrc")
+    for f in sorted(os.listdir(csrc)):
+        if f.endswith((".hip", ".h")):
+            h.update(f.encode()); h.update(open(os.path.join(csrc, f), "rb").read())
+    h.update(open(os.path.join(ROOT, "include", "gptst_hip.h"), "rb").read())
+    return h.hexdigest()[:16]
+
+
+# SURVEY.md 8(d) algorithmic bytes per launch in units of A = 4*B*T*N*C: a big layer's forward reads X and writes Y (2A), its backward reads
+# dY and the saved X and writes dX (3A).  hyperTem is one launch per direction; a cap layer's 2A / 3A are spread over its launches: X read
+# by the routing kernels, the layer output written by the node-conditioned apply, dOut read by its backward, dX written by the entry-Linear backward.
+ALG_8D_A = {"gptst_hypertem_fwd": 2.0, "gptst_hypertem_bwd": 3.0, "gptst_hypertem_bwd_wgrad": 3.0, "gptst_cap_route_fwd": 1.0,
+            "gptst_cap_cross_route_bwd": 1.0, "gptst_cap_route_bwd": 1.0, "gptst_apply": 1.0, "gptst_apply_wgrad": 1.0, "gptst_linear_bwd": 1.0,
+            "gptst_cap_cross_rec_fwd": 0.0, "gptst_cap_rec_fwd": 0.0, "gptst_cap_rec_bwd": 0.0}
+
+
 def pmc_traffic(name, tag, grid_hint=None):
-    """HBM bytes per launch of the dominant kernel from the committed PMC pass (profiles/pmc_traffic.json), or None."""
+    """HBM bytes per launch of the dominant kernel from the committed PMC pass (profiles/pmc_traffic.json) — or None when there is no pass
+    for this kernel or the pass was collected on different kernel sources (its kernel_src_sha != kernel_source_hash())."""
     path = os.path.join(ROOT, "profiles", "pmc_traffic.json")
     sym = KERNEL_SYMBOL.get(name)
     if sym is None or not os.path.exists(path):
         return None, None
-    ks = json.load(open(path))["kernels"]
+    js = json.load(open(path))
+    if js.get("kernel_src_sha") != kernel_source_hash():
+        return None, "stale: profiles/pmc_traffic.json was collected on kernel sources %s, this run has %s" % (js.get("kernel_src_sha"), kernel_source_hash())
+    ks = js["kernels"]
     if name == "gptst_apply":
         m = {"mode0": None, "mode1": None, "mode2": None}
         pro, epi = tag.split()[1][3:], tag.split()[2][3:]
@@ -363,9 +391,14 @@ def main():
         precise = retime_kernel(dn, dt)
         if precise is not None:
             dv = dict(dv, avg_s=precise)
-        t_h, t_m = dv["bytes"] / HBM_PEAK, fl / MFMA_F32_PEAK
+        # SURVEY 8(d) protocol: achieved = ALGORITHMIC bytes (8d per-layer figure; flops likewise) / measured duration, against the roof
+        # that binds the kernel (the larger of its two floor times); the operand-byte figure (every operand once) is kept beside it
+        A_bytes = 4.0 * B * T * N * C
+        b8d = ALG_8D_A.get(dn, None)
+        b8d = A_bytes * b8d if b8d is not None else float(dv["bytes"])
+        t_h, t_m = b8d / HBM_PEAK, fl / MFMA_F32_PEAK
         if t_h >= t_m:
-            rf = dict(bound="hbm", achieved=dv["bytes"] / dv["avg_s"] / 1e9, peak=HBM_PEAK / 1e9, unit="GB/s")
+            rf = dict(bound="hbm", achieved=b8d / dv["avg_s"] / 1e9, peak=HBM_PEAK / 1e9, unit="GB/s")
         else:
             rf = dict(bound="mfma", achieved=fl / dv["avg_s"] / 1e12, peak=MFMA_F32_PEAK / 1e12, unit="TFLOP/s")
         rf["frac"] = rf["achieved"] / rf["peak"]
@@ -374,7 +407,9 @@ def main():
         rf.update(kernel="%s[%s]" % (dn, dt), avg_us=1e6 * dv["avg_s"], avg_us_single_eager_launch=1e6 * eager_avg,
                   timing="one HIP event pair around 50 back-to-back launches of the recorded call on the launch stream",
                   launches_per_step=dv["launches"],
-                  alg_bytes_per_launch=dv["bytes"], alg_flops_per_launch=fl, share_of_step_kernel_time=dv["total_s"] / tot)
+                  alg_bytes_8d=b8d, alg_flops_per_launch=fl, frac_8d=(b8d / dv["avg_s"]) / HBM_PEAK, mfma_frac=(fl / dv["avg_s"]) / MFMA_F32_PEAK,
+                  operand_bytes_per_launch=dv["bytes"], frac_operand_bytes=(dv["bytes"] / dv["avg_s"]) / HBM_PEAK,
+                  kernel_src_sha=kernel_source_hash(), share_of_step_kernel_time=dv["total_s"] / tot)
         out["roofline"] = rf
         top = sorted(kt.items(), key=lambda kv: -kv[1]["total_s"])[:12]
         out["kernel_breakdown_us_per_step"] = {"%s[%s]" % k: round(1e6 * v["total_s"], 1) for k, v in top}

@@ -23,6 +23,9 @@ res = {}
 for k in sorted(set(f) | set(w)):
     fk, wk = f.get(k, 0.0), w.get(k, 0.0)
     res[k] = {"FETCH_SIZE_KB": fk, "WRITE_SIZE_KB": wk, "hbm_bytes": (2 * fk + wk) * 1024}
-json.dump({"note": "hbm_bytes = (2*FETCH_SIZE + WRITE_SIZE)*1024 per launch; separate --pmc passes of `bench.py --no-graph`", "kernels": res},
-          open(out, "w"), indent=1)
+import os
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from bench import kernel_source_hash  # noqa: E402   (hash of the kernel sources the passes ran on: bench.py reports traffic only when it matches)
+json.dump({"note": "hbm_bytes = (2*FETCH_SIZE + WRITE_SIZE)*1024 per launch; separate --pmc passes of `bench.py --no-graph`",
+           "kernel_src_sha": kernel_source_hash(), "kernels": res}, open(out, "w"), indent=1)
 print("wrote", out, len(res), "kernels")
