@@ -231,6 +231,9 @@ def main():
                          "collectives and the optimiser is ONE hipGraph per phase, also with several ranks.  DEFAULT for --gpus N > 1 "
                          "(data parallel and node-sharded); --torch-comm keeps torch.distributed collectives between graph replays")
     ap.add_argument("--torch-comm", dest="native_comm", action="store_false")
+    ap.add_argument("--repeats", type=int, default=1,
+                    help="SURVEY 8(d) protocol: after the contract's timed region (which `value` reports), time the same K steps this many times "
+                         "in total and report every rate and their median as `repeat_values` / `median_value` (e.g. --warmup 50 --steps 500 --repeats 5)")
     ap.add_argument("--no-graph", action="store_true")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-timing", action="store_true")
@@ -318,6 +321,21 @@ def main():
     if dp is not None:
         el = dp.max_over_ranks(el)
     loss = stepper.losses()
+    rep_rates = [a.steps / el]
+    for _ in range(max(a.repeats, 1) - 1):                       # further repeats of the identical timed region (informative; `value` stays the first)
+        torch.cuda.synchronize()
+        if dp is not None:
+            dp.barrier()
+        t0r = time.perf_counter()
+        for _ in range(a.steps):
+            stepper.step(stepper.src, a.epoch)
+        torch.cuda.synchronize()
+        if dp is not None:
+            dp.barrier()
+        elr = time.perf_counter() - t0r
+        if dp is not None:
+            elr = dp.max_over_ranks(elr)
+        rep_rates.append(a.steps / elr)
 
     # random-mask phase (epochs 1..change_epoch) rate, informative
     rnd_rate = None
@@ -359,6 +377,8 @@ def main():
                    "global_batch": gbatch,
                    "parallelism": ("nodes%d" if a.shard == "nodes" else "dp%d") % a.gpus},
         "samples_per_s": steps_s * gbatch,
+        "repeat_values": [r * b32_per_step for r in rep_rates] if len(rep_rates) > 1 else None,
+        "median_value": (sorted(rep_rates)[len(rep_rates) // 2] * b32_per_step) if len(rep_rates) > 1 else None,
         "steps_per_s_random_mask_phase": rnd_rate,
         "last_loss": loss[0],
         # evidence that the job's collectives span the ranks it was started with, and how the step is enqueued
