@@ -22,7 +22,7 @@
 extern "C" {
 #endif
 
-#define GPTST_ABI_VERSION 4
+#define GPTST_ABI_VERSION 5
 int gptst_abi_version(void);
 /* 1: bit-reproducible steps — the two reductions that end in float atomics by default (embedding gradients of gptst_pool_jobs kind 2,
  * weight gradients of gptst_timefeat_jobs) run as single-owner kernels with a fixed summation order (slower).  Everything else is
@@ -323,6 +323,45 @@ int gptst_kl(const float* prob, const float* c, int rows, int N, int HS, float w
 int gptst_clip_adam_ws_floats(void);   /* scratch floats (ws) of gptst_clip_adam: one gradient-norm partial per workgroup, folded in order */
 int gptst_clip_adam(float* p, const float* g, float* m, float* v, long nA, long nB, const float* hyper, float* stats, float* ws,
                     float* stats_out, void* stream);   /* stats_out (optional float[8]): copy of the final statistics block */
+
+/* ---- layer-level entry points (layers.hip): ONE call per reference layer, forward and backward ---------------------------------------
+ * SURVEY.md 8(b) "minimum set".  Host-side compositions of the kernel entry points above on the caller's stream; `saved` (forward ->
+ * backward) and `scratch` (backward only) are caller-owned device regions of gptst_layer_bytes() bytes; no allocation / sync / host read.
+ * Parameter and embedding gradients are ACCUMULATED (+=: zero them once), data gradients are written.  C = 64 and a (b,t) capsule matrix
+ * that fits LDS (gptst_cap_fits_lds), else GPTST_ESHAPE; GPTST_EWS (-3) when a region is too small.
+ * kind: 0 hyperTem (GPTST.py:154-163; uses d, Hm), 1 cap (:100-141; d, ds, HS, HT), 2 MLP_RL (:21-34; d, HS, base). */
+int gptst_layer_bytes(int kind, int B, int T, int N, int C, int d, int Hm, int ds, int HS, int HT, int base, long* saved_bytes,
+                      long* scratch_bytes);
+/* hyperTem.forward(x, node_embeddings, time_eb) with parameters adj (d,Hm,T), weights_pool (d,C,C), bias_pool (d,C); time_eb (B*T,d). */
+int gptst_hypertem_layer_fwd(const float* x, const float* node_emb, const float* time_eb, const float* adj, const float* wpool,
+                             const float* bpool, float* out, void* saved, long saved_bytes, int B, int T, int N, int C, int d, int Hm,
+                             void* stream);
+int gptst_hypertem_layer_bwd(const float* dout, const float* x, const float* out, const float* node_emb, const float* time_eb,
+                             const float* adj, const float* wpool, const float* bpool, const void* saved, long saved_bytes, float* dx,
+                             float* d_node_emb, float* d_time_eb, float* d_adj, float* d_wpool, float* d_bpool, void* scratch,
+                             long scratch_bytes, int B, int T, int N, int C, int d, int Hm, void* stream);
+/* cap.forward(x, node_embeddings_spg, time_eb_spg (B,ds), teb (B*T,ds)) with ln_p, adj (ds,HS,N), t_adj (ds,HT,T*HS), weights_spa (d,C,C),
+ * bias_spa (d,C), mask_template (T) -> out, c_out (B*T,HS,N) = the returned soft assignment, dyn_out (B,HT,T*HS); R = num_route. */
+int gptst_cap_layer_fwd(const float* x, const float* node_emb_spg, const float* time_eb_spg, const float* teb, const float* ln_p_w,
+                        const float* ln_p_b, const float* adj, const float* t_adj, const float* wspa, const float* bspa,
+                        const float* mask_template, float* out, float* c_out, float* dyn_out, void* saved, long saved_bytes, int B, int T,
+                        int N, int C, int d, int ds, int HS, int HT, int R, void* stream);
+int gptst_cap_layer_bwd(const float* dout, const float* x, const float* out, const float* c, const float* dyn, const float* node_emb_spg,
+                        const float* time_eb_spg, const float* teb, const float* ln_p_w, const float* ln_p_b, const float* adj,
+                        const float* t_adj, const float* wspa, const float* bspa, const float* mask_template, const void* saved,
+                        long saved_bytes, float* dx, float* d_node_emb_spg, float* d_time_eb_spg, float* d_teb, float* d_ln_p_w,
+                        float* d_ln_p_b, float* d_adj, float* d_t_adj, float* d_wspa, float* d_bspa, void* scratch, long scratch_bytes, int B,
+                        int T, int N, int C, int d, int ds, int HS, int HT, void* stream);
+/* MLP_RL.forward(eb = a[:, :base] (rows = B*T*N, row stride lda), time_eb (B*T,d), node_eb (N,d)) -> logits (rows, HS); the input is data: no dx. */
+int gptst_mlprl_layer_fwd(const float* a, int lda, const float* time_eb, const float* node_emb, const float* ln1_w, const float* ln1_b,
+                          const float* wpool_spa, const float* bpool_spa, const float* wpool_tem, const float* bpool_tem, const float* ln3_w,
+                          const float* ln3_b, float* logits, void* saved, long saved_bytes, int B, int T, int N, int C, int d, int base,
+                          int HS, void* stream);
+int gptst_mlprl_layer_bwd(const float* dlogits, const float* a, int lda, const float* time_eb, const float* node_emb, const float* ln1_w,
+                          const float* wpool_spa, const float* bpool_spa, const float* wpool_tem, const float* bpool_tem, const float* ln3_w,
+                          const void* saved, long saved_bytes, float* d_time_eb, float* d_node_emb, float* d_ln1_w, float* d_ln1_b,
+                          float* d_wpool_spa, float* d_bpool_spa, float* d_wpool_tem, float* d_bpool_tem, float* d_ln3_w, float* d_ln3_b,
+                          void* scratch, long scratch_bytes, int B, int T, int N, int C, int d, int base, int HS, void* stream);
 
 /* ---- communication (comm.hip): RCCL over xGMI with an explicit stream — a collective can sit inside a captured hipGraph -------------
  * The reference has no distributed code; these carry the data-parallel gradient exchange (one all-reduce of [flat gradient | statistics])
