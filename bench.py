@@ -383,7 +383,9 @@ def main():
         "last_loss": loss[0],
         # evidence that the job's collectives span the ranks it was started with, and how the step is enqueued
         "rccl_ranks": (group.comm.count() if (a.shard == "nodes" and a.native_comm) else (dp.rccl_ranks() if dp is not None else None)),
-        "comm": (None if (dp is None and world == 1) else ("c-abi rccl, captured in the step graph" if a.native_comm else "torch.distributed between graph replays")),
+        "comm": (None if (dp is None and world == 1) else
+                 ("c-abi rccl, captured in the step graph" if (a.native_comm and not getattr(stepper, "_graph_comm_failed", False)) else
+                  ("c-abi rccl between graph replays (capturing the collectives failed)" if a.native_comm else "torch.distributed between graph replays"))),
         "graph": bool(getattr(stepper, "shard_graph", False)) if a.shard == "nodes" else not a.no_graph,
         "hbm_peak_gb": round(torch.cuda.max_memory_allocated() / 2**30, 2),
         "alloc_retries": int(torch.cuda.memory_stats().get("num_alloc_retries", 0)),

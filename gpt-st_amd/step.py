@@ -100,7 +100,7 @@ class PretrainStep:
     def _dp_in_graph(self):
         """Data parallel on a capturable communicator (dist.DataParallel(native=True)): label gather, gradient all-reduce and optimiser are
         enqueued as part of the step body — one hipGraph per phase holds everything, as in the single-GPU case."""
-        return self.dp is not None and getattr(self.dp, "capturable", False)
+        return self.dp is not None and getattr(self.dp, "capturable", False) and not getattr(self, "_graph_comm_failed", False)
 
     def _part1(self, phase):
         p, dims, base = self.model.param_views(), self.dims, self.base
@@ -290,6 +290,22 @@ class PretrainStep:
             self._optim()
 
     def _capture(self, key):
+        """Capture the step of `key` = (phase, injected noise, forced mask).  If capturing the collectives of a data-parallel step fails
+        (a runtime that cannot record RCCL kernels into a hipGraph raises at capture time, identically on every rank), the step falls back
+        to collectives BETWEEN graph replays — the pre-round-3 form — instead of aborting the run."""
+        try:
+            return self._capture_impl(key)
+        except Exception as e:                                    # noqa: BLE001
+            if not self._dp_in_graph():
+                raise
+            import sys
+            print("gpt-st_amd: capturing the step with its collectives failed (%s: %s) -> collectives between graph replays"
+                  % (type(e).__name__, str(e).splitlines()[0][:200]), file=sys.stderr)
+            self._graph_comm_failed = True
+            torch.cuda.synchronize()
+            return self._capture_impl(key)
+
+    def _capture_impl(self, key):
         phase, inject, forced = key
         self.inject_noise, self.force_mask = inject, forced
         keep = (self.model.flat.clone(), self.m.clone(), self.v.clone())
@@ -319,9 +335,11 @@ class PretrainStep:
                     self._part2(phase, ctx)
         finally:
             ops.set_deterministic(False)
+            engine.CTX.ARENA = None
+            engine.CTX.SIDE = None
+            self.model.flat.copy_(keep[0]); self.m.copy_(keep[1]); self.v.copy_(keep[2])   # undo the warm-up updates (also when the capture failed)
+            torch.cuda.synchronize()
         self.graphs[key] = (g1, g2)
-        self.model.flat.copy_(keep[0]); self.m.copy_(keep[1]); self.v.copy_(keep[2])   # undo the warm-up updates
-        torch.cuda.synchronize()
 
     # ---- results ---------------------------------------------------------------------------------------------------
     def losses(self):
