@@ -86,17 +86,21 @@ __device__ __forceinline__ float seg_scale(const float* hyper, const float* stat
 
 #define GN_NB 256      // workgroups of gradnorm_kernel = partial sums in ws
 
-// ws[blk] = this workgroup's partial of sum (scale g)^2 — no atomics: adam_kernel folds the GN_NB partials in a fixed order
+// ws[2*blk], ws[2*blk+1] = this workgroup's partial of sum g^2 over segment A / B, UNSCALED — adam_kernel applies the squared segment scales and
+// folds the GN_NB partials in a fixed order (no atomics).  sws != NULL: workgroup 0 also folds the step's loss statistics (what
+// gptst_stats_fold does: stats[0..2] += column sums of sws (sws_rows, 4) in a fixed order) — the scales depend on stats[1], which is why the
+// squares stay unscaled here and one launch per step goes away (r03).
 __global__ __launch_bounds__(256) void gradnorm_kernel(const float* __restrict__ g, long nA, long nB, const float* __restrict__ hyper,
-                                                       const float* __restrict__ stats, float* __restrict__ ws) {
+                                                       float* __restrict__ stats, float* __restrict__ ws, const float* __restrict__ sws,
+                                                       int sws_rows) {
     // float4 loads, 4 in flight per thread (tensors are padded to 16 bytes, so nA % 4 == 0 and a float4 never straddles the
     // segment boundary); the first version walked scalars with one load in flight: 15 us for 4 MB whatever the grid size.
-    __shared__ float red[4];
+    __shared__ float red[2][4];
+    __shared__ float reds[3][4];
     const bool actB = hyper[8] != 0.f;
-    const float sa = seg_scale(hyper, stats, true), sb = seg_scale(hyper, stats, false);
     const long n4 = (nA + (actB ? nB : 0)) / 4, nA4 = nA / 4;
     const long stride = (long)gridDim.x * 256;
-    float s = 0.f;
+    float sA = 0.f, sB = 0.f;
     for (long i0 = (long)blockIdx.x * 256 + threadIdx.x; i0 < n4; i0 += 4 * stride) {
         float4 v[4];
 #pragma unroll
@@ -106,15 +110,28 @@ __global__ __launch_bounds__(256) void gradnorm_kernel(const float* __restrict__
         }
 #pragma unroll
         for (int u = 0; u < 4; ++u) {
-            const float sc = (i0 + u * stride) < nA4 ? sa : sb;
-            s = fmaf(v[u].x * sc, v[u].x * sc, s); s = fmaf(v[u].y * sc, v[u].y * sc, s);
-            s = fmaf(v[u].z * sc, v[u].z * sc, s); s = fmaf(v[u].w * sc, v[u].w * sc, s);
+            const float q = fmaf(v[u].x, v[u].x, fmaf(v[u].y, v[u].y, fmaf(v[u].z, v[u].z, v[u].w * v[u].w)));
+            if ((i0 + u * stride) < nA4) sA += q; else sB += q;
         }
     }
-    s = group_sum<64>(s);
-    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
+    sA = group_sum<64>(sA); sB = group_sum<64>(sB);
+    if ((threadIdx.x & 63) == 0) { red[0][threadIdx.x >> 6] = sA; red[1][threadIdx.x >> 6] = sB; }
     __syncthreads();
-    if (threadIdx.x == 0) ws[blockIdx.x] = (red[0] + red[1]) + (red[2] + red[3]);
+    if (threadIdx.x < 2) ws[2 * blockIdx.x + threadIdx.x] = (red[threadIdx.x][0] + red[threadIdx.x][1]) + (red[threadIdx.x][2] + red[threadIdx.x][3]);
+    if (sws != nullptr && blockIdx.x == 0) {                     // == stats_fold_kernel (tails.hip), same order of additions
+        float s[3] = {0.f, 0.f, 0.f};
+        for (int r = threadIdx.x; r < sws_rows; r += 256) {
+            const float4 v = ld4(sws + 4 * (size_t)r);
+            s[0] += v.x; s[1] += v.y; s[2] += v.z;
+        }
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+            s[k] = group_sum<64>(s[k]);
+            if ((threadIdx.x & 63) == 0) reds[k][threadIdx.x >> 6] = s[k];
+        }
+        __syncthreads();
+        if (threadIdx.x < 3) stats[threadIdx.x] += (reds[threadIdx.x][0] + reds[threadIdx.x][1]) + (reds[threadIdx.x][2] + reds[threadIdx.x][3]);
+    }
 }
 
 // stats[3] on entry: squared-norm contributions that are not in g on this rank (node-sharded runs add the other ranks' node-local
@@ -123,13 +140,15 @@ __global__ __launch_bounds__(256) void adam_kernel(float* __restrict__ p, const 
                                                    float* __restrict__ v, long nA, long nB, const float* __restrict__ hyper,
                                                    float* __restrict__ stats, const float* __restrict__ ws, int nws, float* __restrict__ stats_out) {
     __shared__ float red[4];
-    {   // every workgroup folds the gradient-norm partials in the same fixed order
-        float s = (int)threadIdx.x < nws ? ws[threadIdx.x] : 0.f;
-        s = group_sum<64>(s);
-        if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
+    __shared__ float redB[4];
+    {   // every workgroup folds the gradient-norm partials (per segment, unscaled) in the same fixed order
+        float sA = (int)threadIdx.x < nws ? ws[2 * threadIdx.x] : 0.f, sB = (int)threadIdx.x < nws ? ws[2 * threadIdx.x + 1] : 0.f;
+        sA = group_sum<64>(sA); sB = group_sum<64>(sB);
+        if ((threadIdx.x & 63) == 0) { red[threadIdx.x >> 6] = sA; redB[threadIdx.x >> 6] = sB; }
         __syncthreads();
     }
-    const float gsq = stats[3] + ((red[0] + red[1]) + (red[2] + red[3]));
+    const float ua = seg_scale(hyper, stats, true), ub = seg_scale(hyper, stats, false);
+    const float gsq = stats[3] + (ua * ua * ((red[0] + red[1]) + (red[2] + red[3])) + ub * ub * ((redB[0] + redB[1]) + (redB[2] + redB[3])));
     const bool actB = hyper[8] != 0.f;
     const long n = nA + (actB ? nB : 0);
     const float b1 = hyper[4], b2 = hyper[5], eps = hyper[6], maxn = hyper[7];
@@ -180,17 +199,19 @@ extern "C" int gptst_kl(const float* prob, const float* c, int rows, int N, int 
     return GPTST_OK;
 }
 
-extern "C" int gptst_clip_adam_ws_floats(void) { return GN_NB; }
+extern "C" int gptst_clip_adam_ws_floats(void) { return 2 * GN_NB; }
 
 // ws: gptst_clip_adam_ws_floats() floats of scratch.  stats[3]: extra squared-norm terms (0 unless node-sharded), stats[4] <- the
 // total squared gradient norm (after scaling, before clipping).  No atomics: the norm is folded in a fixed order.
+// sws (may be NULL) / sws_rows: the step's per-workgroup loss statistics, folded into stats[0..2] (+=) by the first launch — replaces a
+// separate gptst_stats_fold when nothing (a gradient all-reduce) has to see the folded statistics in between.
 extern "C" int gptst_clip_adam(float* p, const float* g, float* m, float* v, long nA, long nB, const float* hyper, float* stats,
-                               float* ws, float* stats_out, void* stream) {
-    if (!p || !g || !m || !v || !hyper || !stats || !ws) return GPTST_EARG;
+                               float* ws, float* stats_out, const float* sws, int sws_rows, void* stream) {
+    if (!p || !g || !m || !v || !hyper || !stats || !ws || (sws && sws_rows <= 0)) return GPTST_EARG;
     long n = nA + nB;
     int nb = (int)((n + 255) / 256); if (nb > 1024) nb = 1024;
     const int nbn = nb > GN_NB ? GN_NB : nb;
-    hipLaunchKernelGGL(gradnorm_kernel, dim3(nbn), dim3(256), 0, (hipStream_t)stream, g, nA, nB, hyper, (const float*)stats, ws);
+    hipLaunchKernelGGL(gradnorm_kernel, dim3(nbn), dim3(256), 0, (hipStream_t)stream, g, nA, nB, hyper, stats, ws, sws, sws_rows);
     hipLaunchKernelGGL(adam_kernel, dim3(nb), dim3(256), 0, (hipStream_t)stream, p, g, m, v, nA, nB, hyper, stats, (const float*)ws, nbn, stats_out);
     GPTST_CHECK_LAUNCH();
     return GPTST_OK;

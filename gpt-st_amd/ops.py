@@ -767,14 +767,16 @@ def step_begin(z0, z1, src, base, noise=None, rng=None):
     return tidx
 
 
-def clip_adam(p, g, m, v, nA, nB, hyper, stats, ws=None, stats_out=None):
+def clip_adam(p, g, m, v, nA, nB, hyper, stats, ws=None, stats_out=None, sws=None):
     """clip_grad_norm_ + Adam over the flat buffers; stats[3] (in): extra squared-norm terms, stats[4] (out): total squared norm.
-    ws: gptst_clip_adam_ws_floats() floats of scratch (default: one cached buffer per device — stream-ordered reuse)."""
+    ws: gptst_clip_adam_ws_floats() floats of scratch (default: one cached buffer per device — stream-ordered reuse).
+    sws: the step's per-workgroup loss statistics (tail_sws): folded into stats[0..2] by the first launch instead of a separate stats_fold."""
     if ws is None:
         if p.device not in _ADAM_WS:
             _ADAM_WS[p.device] = torch.empty(_C.lib().value("gptst_clip_adam_ws_floats"), device=p.device, dtype=torch.float32)
         ws = _ADAM_WS[p.device]
-    _call("gptst_clip_adam", _p(p), _p(g), _p(m), _p(v), int(nA), int(nB), _p(hyper), _p(stats), _p(ws), _p(stats_out))
+    _call("gptst_clip_adam", _p(p), _p(g), _p(m), _p(v), int(nA), int(nB), _p(hyper), _p(stats), _p(ws), _p(stats_out), _p(sws),
+          sws.shape[0] if sws is not None else 0)
 
 
 # ---- evaluation metrics (Trainer.test) ---------------------------------------------------------------------------------

@@ -159,7 +159,10 @@ class PretrainStep:
                 kl_path()
             if self.kl_side is not None:
                 self.kl_side.join()
-            ops.stats_fold(sws, self.stats)                                    # ordered sum -> stats[0..2] (no float atomics)
+            if self.dp is None and not self.global_count_scale:
+                self._sws = sws                                                # folded by the optimiser's first launch (one launch less)
+            else:
+                ops.stats_fold(sws, self.stats)                                # ordered sum -> stats[0..2]: the all-reduce must see them
         else:
             out, dec, sv_d = engine.decoder_fwd(p, tidx, emb, dims, mdl.num_route, gen=gen[engine.DEC])
             ops.mae_fwd(out, src, base + 2, mask, self.std, self.mean, a.mape_thresh, M, base, self.stats)
@@ -197,8 +200,9 @@ class PretrainStep:
         self.dp.gather_labels(self.label_l, out=self.label_g)
 
     def _optim(self):
+        sws, self._sws = getattr(self, "_sws", None), None
         ops.clip_adam(self.model.flat, self.gflat, self.m, self.v, self.model.nA, self.model.nB, self.hyper, self.stats,
-                      stats_out=self.stats_out)
+                      stats_out=self.stats_out, sws=sws)
 
     def _body(self, phase):
         """eager: part 1 [-> label exchange] -> part 2 (+ optimiser when there is no gradient all-reduce in between)"""

@@ -22,7 +22,7 @@
 extern "C" {
 #endif
 
-#define GPTST_ABI_VERSION 5
+#define GPTST_ABI_VERSION 6
 int gptst_abi_version(void);
 /* 1: bit-reproducible steps — the two reductions that end in float atomics by default (embedding gradients of gptst_pool_jobs kind 2,
  * weight gradients of gptst_timefeat_jobs) run as single-owner kernels with a fixed summation order (slower).  Everything else is
@@ -322,7 +322,7 @@ int gptst_mae_bwd(const float* out, const float* src, int lda, const float* mask
 int gptst_kl(const float* prob, const float* c, int rows, int N, int HS, float w, float* dlogit, float* stats, void* stream);
 int gptst_clip_adam_ws_floats(void);   /* scratch floats (ws) of gptst_clip_adam: one gradient-norm partial per workgroup, folded in order */
 int gptst_clip_adam(float* p, const float* g, float* m, float* v, long nA, long nB, const float* hyper, float* stats, float* ws,
-                    float* stats_out, void* stream);   /* stats_out (optional float[8]): copy of the final statistics block */
+                    float* stats_out, const float* sws, int sws_rows, void* stream);   /* stats_out (optional float[8]): copy of the final statistics block */
 
 /* ---- layer-level entry points (layers.hip): ONE call per reference layer, forward and backward ---------------------------------------
  * SURVEY.md 8(b) "minimum set".  Host-side compositions of the kernel entry points above on the caller's stream; `saved` (forward ->
