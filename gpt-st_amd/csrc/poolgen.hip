@@ -383,7 +383,9 @@ extern thread_local int g_tl_nb;
 extern thread_local int g_wgrad_v1;
 extern thread_local int g_apply128_v1;
 extern thread_local int g_ht_fwd12;
+extern thread_local int g_tl_mfma;
 extern "C" int gptst_tune(int id, int value) {
+    if (id == 15) g_tl_mfma = value;
     if (id == 12) g_ht_fwd12 = value;
     if (id == 1 && value > 0 && value <= PG_MAXROWS) g_pg_rows = value;
     if (id == 6 && value > 0) g_tl_nb = value;
