@@ -84,42 +84,107 @@ __global__ __launch_bounds__(256) void cap_cross_rec_fwd_kernel(const float* __r
     float* vs = dyns + HT * KK;               // HS * C      (offset is a multiple of 4 floats: HT*KK = HT*T*HS with T = 12)
     float* cs = vs + HS * C;                  // HS * N
     const int bt = blockIdx.x, b = bt / T, t = bt % T, tid = threadIdx.x;
-    for (int i = tid; i < KK * K::LPR; i += 256) {
-        const int k = i / K::LPR, c4 = i % K::LPR;
-        const float tm = tmpl[k / HS];
-        const float4 x = ld4(s + ((size_t)b * KK + k) * C + 4 * c4);
-        st4(Zs + k * K::PITCH + 4 * c4, make_float4(x.x + tm, x.y + tm, x.z + tm, x.w + tm));
+    {   // staging: every global load of a batch is issued before the first LDS store (a copy loop `lds[i] = glb[i]` compiles to one
+        // serialised L2 round trip per trip — 21 of them here, most of the former 8 us of this block)
+        const float* sb = s + (size_t)b * KK * C;
+        const float* db = dyn + (size_t)b * HT * KK;
+        const float* cb = c + (size_t)bt * HS * N;
+        const int nz = KK * K::LPR, nd = HT * KK / 4, nc = HS * N;
+        const bool c4ok = (nc & 3) == 0;
+        for (int i0 = 0; i0 < nz; i0 += 8 * 256) {
+            float4 zv[8], dv[2], cv[2];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) { const int i = i0 + u * 256 + tid; zv[u] = ld4(sb + 4 * (size_t)min(i, nz - 1)); }
+            if (i0 == 0) {
+#pragma unroll
+                for (int u = 0; u < 2; ++u) {
+                    dv[u] = ld4(db + 4 * (size_t)min(u * 256 + tid, nd - 1));
+                    cv[u] = c4ok ? ld4(cb + 4 * (size_t)min(u * 256 + tid, nc / 4 - 1)) : f4zero();
+                }
+            }
+            SB();
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const int i = i0 + u * 256 + tid;
+                if (i < nz) {
+                    const int k = i / K::LPR, c4 = i % K::LPR;
+                    const float tm = tmpl[k / HS];
+                    st4(Zs + k * K::PITCH + 4 * c4, make_float4(zv[u].x + tm, zv[u].y + tm, zv[u].z + tm, zv[u].w + tm));
+                }
+            }
+            if (i0 == 0) {
+#pragma unroll
+                for (int u = 0; u < 2; ++u) {
+                    const int i = u * 256 + tid;
+                    if (i < nd) st4(dyns + 4 * i, dv[u]);
+                    if (c4ok && i < nc / 4) st4(cs + 4 * i, cv[u]);
+                }
+            }
+        }
+        for (int i = 2 * 256 + tid; i < nd; i += 256) st4(dyns + 4 * i, ld4(db + 4 * (size_t)i));          // (beyond the bench shape)
+        for (int i = (c4ok ? 2 * 256 * 4 : 0) + tid; i < nc; i += 256) cs[i] = cb[i];
     }
-    for (int i = tid; i < HT * KK; i += 256) dyns[i] = dyn[(size_t)b * HT * KK + i];
-    for (int i = tid; i < HS * N; i += 256) cs[i] = c[(size_t)bt * HS * N + i];
     __syncthreads();
-    for (int i = tid; i < HT * K::LPR; i += 256) {
-        const int j = i / K::LPR, c4 = i % K::LPR;
-        float4 acc = f4zero();
-#pragma unroll 8
-        for (int k = 0; k < KK; ++k) acc = f4fma(dyns[j * KK + k], ld4(Zs + k * K::PITCH + 4 * c4), acc);
-        acc = make_float4(lrelu(acc.x), lrelu(acc.y), lrelu(acc.z), lrelu(acc.w));
-        st4(Hs + j * C + 4 * c4, acc);
-        if (t == 0) st4(Ht_out + ((size_t)b * HT + j) * C + 4 * c4, acc);
+    // Both products on MFMA 16x16x4 (an fp32 MFMA is the fmaf chain over its four k values in order, and the k-steps run in order: the
+    // results are bit-identical to the VALU loops of cap_cross_fwd_kernel, tests/test_gpu_kernels.py::test_cap_cross_folded...).
+    const int lane = tid & 63, wave = tid >> 6, li = lane & 15, kk = lane >> 4;
+    for (int jt = 0; jt < HT; jt += 16) {               // Ht[j][c] = LReLU(sum_k dyn[j][k] Z[k][c]): wave = column tile, 30 dependent steps
+        const int ja = jt + li;
+        f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+        const float* ar = dyns + min(ja, HT - 1) * KK + kk;
+        const float* br = Zs + kk * K::PITCH + 16 * wave + li;
+        const int ns4 = KK / 4;
+        int s4 = 0;
+        for (; s4 + 6 <= ns4; s4 += 6) {                    // six steps' LDS operands in flight ahead of the dependent MFMA chain
+            float av[6], bv[6];
+#pragma unroll
+            for (int u = 0; u < 6; ++u) { av[u] = ja < HT ? ar[4 * (s4 + u)] : 0.f; bv[u] = br[4 * (s4 + u) * K::PITCH]; }
+#pragma unroll
+            for (int u = 0; u < 6; ++u) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(av[u], bv[u], acc, 0, 0, 0);
+        }
+        for (; s4 < ns4; ++s4)
+            acc = __builtin_amdgcn_mfma_f32_16x16x4f32(ja < HT ? ar[4 * s4] : 0.f, br[4 * s4 * K::PITCH], acc, 0, 0, 0);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int jj = jt + 4 * kk + r;
+            if (jj < HT) {
+                const float h = lrelu(acc[r]);
+                Hs[jj * C + 16 * wave + li] = h;
+                if (t == 0) Ht_out[((size_t)b * HT + jj) * C + 16 * wave + li] = h;
+            }
+        }
     }
     __syncthreads();
-    for (int base = 0; base < HS * K::LPR; base += 256) {           // own tokens k = t*HS + h
-        const int i = base + tid;
-        const bool valid = i < HS * K::LPR;
-        const int h = valid ? i / K::LPR : 0, c4 = i % K::LPR, k = t * HS + h;
-        float4 acc = f4zero();
-#pragma unroll 8
-        for (int j = 0; j < HT; ++j) acc = f4fma(dyns[j * KK + k], ld4(Hs + j * C + 4 * c4), acc);
-        const float4 rt = make_float4(lrelu(acc.x), lrelu(acc.y), lrelu(acc.z), lrelu(acc.w));
-        const float tm = tmpl[k / HS];
-        const float4 z = ld4(Zs + k * K::PITCH + 4 * c4);
-        const float4 u = make_float4(rt.x + (z.x - tm), rt.y + (z.y - tm), rt.z + (z.z - tm), rt.w + (z.w - tm));
-        const float sc = squash_scale(group_sum<K::LPR>(f4dot(u, u)));
-        if (valid) {
-            const float4 vv = make_float4(u.x * sc, u.y * sc, u.z * sc, u.w * sc);
-            st4(Rt_out + ((size_t)b * KK + k) * C + 4 * c4, rt);
-            st4(v + ((size_t)b * KK + k) * C + 4 * c4, vv);
-            st4(vs + h * C + 4 * c4, vv);
+    if (wave == 0) {                                    // own tokens k = t*HS + h:  Rt = LReLU(dyn^T Ht), v = squash(Rt + s)
+        for (int ht = 0; ht < HS; ht += 16) {
+            const int h = ht + li;
+            f32x4 acc[4];
+#pragma unroll
+            for (int ct = 0; ct < 4; ++ct) acc[ct] = (f32x4){0.f, 0.f, 0.f, 0.f};
+            for (int s4 = 0; s4 < (HT + 3) / 4; ++s4) {
+                const int jj = 4 * s4 + kk;
+                const float a = (h < HS && jj < HT) ? dyns[jj * KK + t * HS + h] : 0.f;
+                const float4 bq = jj < HT ? ld4(Hs + jj * C + 4 * li) : f4zero();      // channel 4*li + ct <-> column li of tile ct
+                acc[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, bq.x, acc[0], 0, 0, 0);
+                acc[1] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, bq.y, acc[1], 0, 0, 0);
+                acc[2] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, bq.z, acc[2], 0, 0, 0);
+                acc[3] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, bq.w, acc[3], 0, 0, 0);
+            }
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int hh = ht + 4 * kk + r, k = t * HS + min(hh, HS - 1);
+                const float4 rt = make_float4(lrelu(acc[0][r]), lrelu(acc[1][r]), lrelu(acc[2][r]), lrelu(acc[3][r]));
+                const float tm = tmpl[k / HS];
+                const float4 z = ld4(Zs + k * K::PITCH + 4 * li);
+                const float4 u = make_float4(rt.x + (z.x - tm), rt.y + (z.y - tm), rt.z + (z.z - tm), rt.w + (z.w - tm));
+                const float sc = squash_scale(group_sum<16>(f4dot(u, u)));
+                if (hh < HS) {
+                    const float4 vv = make_float4(u.x * sc, u.y * sc, u.z * sc, u.w * sc);
+                    st4(Rt_out + ((size_t)b * KK + k) * C + 4 * li, rt);
+                    st4(v + ((size_t)b * KK + k) * C + 4 * li, vv);
+                    st4(vs + hh * C + 4 * li, vv);
+                }
+            }
         }
     }
     __syncthreads();

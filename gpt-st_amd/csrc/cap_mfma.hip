@@ -422,45 +422,82 @@ __device__ __forceinline__ void cap_cross_bwd_prologue(const float* __restrict__
     float* dHs = Hs + HT * P;                  // HT * P   dHpre
     float* Zo = dHs + HT * P;                  // HS * P   Z rows of the own tokens
     float* dyns = Zo + HS * P;                 // HT * KK
-    for (int i = tid; i < HT * KK; i += CM_NT) dyns[i] = dyn[(size_t)b * HT * KK + i];
-    for (int i = tid; i < HT * LPR; i += CM_NT) st4(Hs + (i / LPR) * P + 4 * (i % LPR), ld4(Ht + ((size_t)b * HT) * C + 4 * i));
-    // rows k: u = Rt + s;  du = squash_bwd(u, dv);  dRpre = du * lrelu'(Rt);  own rows: du -> Vs[h], Z -> Zo[h]
-    for (int base = 0; base < KK * LPR; base += CM_NT) {
-        const int i = base + tid;
-        const bool valid = i < KK * LPR;
-        const int k = valid ? i / LPR : 0, c4 = i % LPR;
-        const size_t off = ((size_t)b * KK + k) * C + 4 * c4;
-        float4 sv = f4zero(), rt = f4zero(), g = f4zero();
-        if (valid) { sv = ld4(s + off); rt = ld4(Rt + off); g = ld4(dv + off); }
-        const float4 u = f4add(rt, sv);
-        const float q = group_sum<LPR>(f4dot(u, u));
-        const float udg = group_sum<LPR>(f4dot(u, g));
-        const float r = sqrtf(q), den = (1.f + q) * (r + 1e-8f);
-        const float gq = q / den;
-        float gp = 0.f;
-        if (r > 0.f) gp = (den - q * ((r + 1e-8f) + (1.f + q) * 0.5f / r)) / (den * den);
-        const float k2 = 2.f * gp * udg;
-        const float4 du = make_float4(fmaf(k2, u.x, gq * g.x), fmaf(k2, u.y, gq * g.y), fmaf(k2, u.z, gq * g.z), fmaf(k2, u.w, gq * g.w));
-        if (valid) {
-            st4(Gs + k * P + 4 * c4, make_float4(du.x * lrelu_grad_from_out(rt.x), du.y * lrelu_grad_from_out(rt.y),
-                                                 du.z * lrelu_grad_from_out(rt.z), du.w * lrelu_grad_from_out(rt.w)));
-            if (k / HS == t) {
-                const float tm = tmpl[t];
-                st4(Vs + (k - t * HS) * P + 4 * c4, du);
-                st4(Zo + (k - t * HS) * P + 4 * c4, make_float4(sv.x + tm, sv.y + tm, sv.z + tm, sv.w + tm));
+    // rows k: u = Rt + s;  du = squash_bwd(u, dv);  dRpre = du * lrelu'(Rt);  own rows: du -> Vs[h], Z -> Zo[h].
+    // All global loads of a batch are issued before the first LDS store / use (a copy loop is one serialised L2 round trip per trip).
+    {
+        const int nz = KK * LPR, nd = HT * KK / 4, nh = HT * LPR;
+        const float* db = dyn + (size_t)b * HT * KK;
+        const float* hb = Ht + (size_t)b * HT * C;
+        for (int i0 = 0; i0 < nz; i0 += 4 * CM_NT) {
+            float4 sv4[4], rt4[4], g4[4], dv1, hv1;
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const size_t off = (size_t)b * KK * C + 4 * (size_t)min(i0 + u * CM_NT + tid, nz - 1);
+                sv4[u] = ld4(s + off); rt4[u] = ld4(Rt + off); g4[u] = ld4(dv + off);
+            }
+            if (i0 == 0) { dv1 = ld4(db + 4 * (size_t)min(tid, nd - 1)); hv1 = ld4(hb + 4 * (size_t)min(tid, nh - 1)); }
+            SB();
+            if (i0 == 0) {
+                if (tid < nd) st4(dyns + 4 * tid, dv1);
+                if (tid < nh) st4(Hs + (tid / LPR) * P + 4 * (tid % LPR), hv1);
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int i = i0 + u * CM_NT + tid;
+                const bool valid = i < nz;
+                const int k = valid ? i / LPR : 0, c4 = i % LPR;
+                const float4 sv = valid ? sv4[u] : f4zero(), rt = valid ? rt4[u] : f4zero(), g = valid ? g4[u] : f4zero();
+                const float4 u_ = f4add(rt, sv);
+                const float q = group_sum<LPR>(f4dot(u_, u_));
+                const float udg = group_sum<LPR>(f4dot(u_, g));
+                const float r = sqrtf(q), den = (1.f + q) * (r + 1e-8f);
+                const float gq = q / den;
+                float gp = 0.f;
+                if (r > 0.f) gp = (den - q * ((r + 1e-8f) + (1.f + q) * 0.5f / r)) / (den * den);
+                const float k2 = 2.f * gp * udg;
+                const float4 du = make_float4(fmaf(k2, u_.x, gq * g.x), fmaf(k2, u_.y, gq * g.y), fmaf(k2, u_.z, gq * g.z), fmaf(k2, u_.w, gq * g.w));
+                if (valid) {
+                    st4(Gs + k * P + 4 * c4, make_float4(du.x * lrelu_grad_from_out(rt.x), du.y * lrelu_grad_from_out(rt.y),
+                                                         du.z * lrelu_grad_from_out(rt.z), du.w * lrelu_grad_from_out(rt.w)));
+                    if (k / HS == t) {
+                        const float tm = tmpl[t];
+                        st4(Vs + (k - t * HS) * P + 4 * c4, du);
+                        st4(Zo + (k - t * HS) * P + 4 * c4, make_float4(sv.x + tm, sv.y + tm, sv.z + tm, sv.w + tm));
+                    }
+                }
             }
         }
+        for (int i = CM_NT + tid; i < nd; i += CM_NT) st4(dyns + 4 * i, ld4(db + 4 * (size_t)i));             // (beyond the bench shape)
+        for (int i = CM_NT + tid; i < nh; i += CM_NT) st4(Hs + (i / LPR) * P + 4 * (i % LPR), ld4(hb + 4 * (size_t)i));
     }
     __syncthreads();
-    // dHpre[j] = lrelu'(Ht[j]) * sum_k dyn[j][k] dRpre[k]
-    for (int i = tid; i < HT * LPR; i += CM_NT) {
-        const int j = i / LPR, c4 = i % LPR;
-        float4 acc = f4zero();
-#pragma unroll 8
-        for (int k = 0; k < KK; ++k) acc = f4fma(dyns[j * KK + k], ld4(Gs + k * P + 4 * c4), acc);
-        const float4 h = ld4(Hs + j * P + 4 * c4);
-        st4(dHs + j * P + 4 * c4, make_float4(acc.x * lrelu_grad_from_out(h.x), acc.y * lrelu_grad_from_out(h.y),
-                                              acc.z * lrelu_grad_from_out(h.z), acc.w * lrelu_grad_from_out(h.w)));
+    // dHpre[j] = lrelu'(Ht[j]) * sum_k dyn[j][k] dRpre[k]   on MFMA 16x16x4: waves 0-3 = column tiles, KK/4 dependent steps (the fmaf chain over k
+    // in order: the same numbers as the VALU loop of cap_cross_bwd_kernel), six steps' LDS operands in flight
+    {
+        const int lane = tid & 63, wave = tid >> 6, li = lane & 15, kk = lane >> 4;
+        if (wave < C / 16) {
+            for (int jt = 0; jt < HT; jt += 16) {
+                const int ja = jt + li;
+                f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+                const float* ar = dyns + min(ja, HT - 1) * KK + kk;
+                const float* br = Gs + kk * P + 16 * wave + li;
+                const int ns4 = KK / 4;
+                int s4 = 0;
+                for (; s4 + 6 <= ns4; s4 += 6) {
+                    float av[6], bv[6];
+#pragma unroll
+                    for (int u = 0; u < 6; ++u) { av[u] = ja < HT ? ar[4 * (s4 + u)] : 0.f; bv[u] = br[4 * (s4 + u) * P]; }
+#pragma unroll
+                    for (int u = 0; u < 6; ++u) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(av[u], bv[u], acc, 0, 0, 0);
+                }
+                for (; s4 < ns4; ++s4) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(ja < HT ? ar[4 * s4] : 0.f, br[4 * s4 * P], acc, 0, 0, 0);
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int jj = jt + 4 * kk + r;
+                    if (jj < HT) dHs[jj * P + 16 * wave + li] = acc[r] * lrelu_grad_from_out(Hs[jj * P + 16 * wave + li]);
+                }
+            }
+        }
     }
     __syncthreads();
     // own tokens: ddyn[j][k] = Ht[j].dRpre[k] + dHpre[j].Z[k]
