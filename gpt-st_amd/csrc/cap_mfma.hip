@@ -88,9 +88,21 @@ __device__ __forceinline__ void cm_type2(const float* __restrict__ Ps, const flo
 // cs[h][n] = softmax_h( use_bl*bl + use_l0*(teb . adj) ): L lanes per node, lane q takes h = q, q+L, ... (at most UB of them);
 // optional copy to global c_out[h*N + n].  The kernel picks (L, UB) = (2, 8) when N <= 256 and HS <= 16 — all nodes in ONE pass of
 // the 512 threads — and the generic (4, 16) otherwise (HS <= 64, several passes).
+// l0r (may be NULL): the thread's logits l0g[h][n] of the FIRST node pass, preloaded into registers by cm_softmax_preload (the global loads
+// inside the loop were eight serialised L2 round trips per call; the kernel calls this twice with use_l0)
+template <int L, int UB>
+__device__ __forceinline__ void cm_softmax_preload(float (&l0r)[UB], const float* __restrict__ l0g, int N, int HS) {
+    const int q = threadIdx.x & (L - 1), n = threadIdx.x / L;
+#pragma unroll
+    for (int u = 0; u < UB; ++u) {
+        const int h = q + L * u;
+        l0r[u] = (L * u < HS && h < HS && n < N) ? l0g[(size_t)h * N + n] : 0.f;
+    }
+}
 template <int L, int UB>
 __device__ __forceinline__ void cm_softmax(const float* __restrict__ bl, float* __restrict__ cs, const float* __restrict__ l0g,
-                                           float* __restrict__ c_out, int N, int NP, int HS, bool use_bl, bool use_l0) {
+                                           float* __restrict__ c_out, int N, int NP, int HS, bool use_bl, bool use_l0,
+                                           const float* l0r = nullptr) {
     const int q = threadIdx.x & (L - 1);
     for (int n0 = 0; n0 < N; n0 += CM_NT / L) {
         const int n = n0 + threadIdx.x / L;
@@ -104,7 +116,7 @@ __device__ __forceinline__ void cm_softmax(const float* __restrict__ bl, float* 
                 const int h = q + L * u;
                 if (h < HS && valid) {
                     float v = use_bl ? bl[h * NP + n] : 0.f;
-                    if (use_l0) v += l0g[(size_t)h * N + n];
+                    if (use_l0) v += (l0r != nullptr && n0 == 0) ? l0r[u] : l0g[(size_t)h * N + n];
                     l[u] = v;
                     m = fmaxf(m, v);
                 }
@@ -225,6 +237,9 @@ __global__ __launch_bounds__(CM_NT, 4) void cap_route_fwd2_kernel(const float* _
     float* S = V0s + HSP * P;               // HSP * C
     const int bt = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const float* Xbt = X + (size_t)bt * N * C;
+    const float* l0g = dadj + (size_t)bt * HS * N;
+    float l0r[SU];
+    cm_softmax_preload<SL, SU>(l0r, l0g, N, HS);                   // in flight during the capsule GEMM
 
     if constexpr (C == 64) {
         // ---- P = squash(X Wp^T + bp): 16-row tiles, register operands, squash fused into the MFMA epilogue (row norm = 16-lane
@@ -318,8 +333,7 @@ __global__ __launch_bounds__(CM_NT, 4) void cap_route_fwd2_kernel(const float* _
     }
     __syncthreads(); TS();
     }
-    const float* l0g = dadj + (size_t)bt * HS * N;
-    cm_softmax<SL, SU>(bl, cs, l0g, nullptr, N, NP, HS, false, true);       // c0 = softmax_h(dadj)      :105
+    cm_softmax<SL, SU>(bl, cs, l0g, nullptr, N, NP, HS, false, true, l0r);  // c0 = softmax_h(dadj)      :105
     __syncthreads(); TS();
     cm_type1<C>(Ps, cs, S, N, NP, HSP);
     __syncthreads(); TS();
@@ -335,7 +349,7 @@ __global__ __launch_bounds__(CM_NT, 4) void cap_route_fwd2_kernel(const float* _
         __syncthreads(); TS();
     }
     if (R > 0) { cm_type2<C>(Ps, Vs, bl, N, NP, HS, HSP); __syncthreads(); TS(); }
-    cm_softmax<SL, SU>(bl, cs, l0g, c_out + (size_t)bt * HS * N, N, NP, HS, true, true);   // c = softmax_h(b + dadj)  :120
+    cm_softmax<SL, SU>(bl, cs, l0g, c_out + (size_t)bt * HS * N, N, NP, HS, true, true, l0r);   // c = softmax_h(b + dadj)  :120
     __syncthreads(); TS();
     cm_type1<C>(Ps, cs, S, N, NP, HSP);
     __syncthreads(); TS();

@@ -116,9 +116,14 @@ __global__ __launch_bounds__(MS_THREADS) void ms_hist_kernel(MsPlan p, unsigned*
     __syncthreads();
     const int sh = ms_shift(dig), nb = ms_bins(dig);
     const unsigned hi_mask = dig == 0 ? 0u : (0xFFFFFFFFu << (sh + (dig == 1 ? 11 : 10)));
-    for (int i = blockIdx.x * MS_THREADS + threadIdx.x; i < p.M; i += MS_BLOCKS * MS_THREADS) {
-        const unsigned key = ms_key(p, cls, i);
-        if ((key & hi_mask) == (prefix & hi_mask)) atomicAdd(&lh[(key >> sh) & (unsigned)(nb - 1)], 1u);
+    // four cells per trip: their (noise, label / gate) loads are issued together (one cell per trip = one serialised L2 round trip per trip)
+    for (int i0 = blockIdx.x * MS_THREADS + threadIdx.x; i0 < p.M; i0 += 4 * MS_BLOCKS * MS_THREADS) {
+        unsigned key[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) { const int i = i0 + u * MS_BLOCKS * MS_THREADS; key[u] = i < p.M ? ms_key(p, cls, i) : 0u; }
+#pragma unroll
+        for (int u = 0; u < 4; ++u)
+            if (i0 + u * MS_BLOCKS * MS_THREADS < p.M && (key[u] & hi_mask) == (prefix & hi_mask)) atomicAdd(&lh[(key[u] >> sh) & (unsigned)(nb - 1)], 1u);
     }
     __syncthreads();
     unsigned* gh = hist + dig * MS_BINS;
@@ -139,16 +144,31 @@ __global__ __launch_bounds__(MS_THREADS) void ms_apply_kernel(MsPlan p, const un
     unsigned thr = 0xFFFFFFFFu, need = 0u, cnt_eq = 0u;
     if (k > 0) ms_prefix(hist, 3, k, sc, thr, need, cnt_eq);
     const bool ties = k > 0 && need != cnt_eq;                   // uniform
-    for (int i = blockIdx.x * MS_THREADS + threadIdx.x; i < p.M; i += MS_BLOCKS * MS_THREADS) {
-        const unsigned key = ms_key(p, cls, i);
-        // a tie straddling rank k: threshold-equal cells belong to workgroup 0 alone (below) — nobody else writes them, so the
-        // result does not depend on the order in which workgroups finish
-        if (ties && key == thr) continue;
-        float vis = 1.f;
-        if (k > 0 && (key > thr || (key == thr && !ties))) vis = 0.f;
-        if (p.mode == 1 && cls.d[p.label[i]]) vis = 0.f;
-        out[i] = vis;
-        if (p.mode == 2) { const float f = p.gate[i] * vis; for (int j = 0; j < base; ++j) final_mask[(size_t)i * base + j] = f; }
+    for (int i0 = blockIdx.x * MS_THREADS + threadIdx.x; i0 < p.M; i0 += 4 * MS_BLOCKS * MS_THREADS) {       // four cells' loads in flight
+        unsigned keys[4];
+        int lab[4];
+        float gat[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int i = min(i0 + u * MS_BLOCKS * MS_THREADS, p.M - 1);
+            keys[u] = ms_key(p, cls, i);
+            lab[u] = p.mode == 1 ? p.label[i] : 0;
+            gat[u] = p.mode == 2 ? p.gate[i] : 0.f;
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int i = i0 + u * MS_BLOCKS * MS_THREADS;
+            if (i >= p.M) break;
+            const unsigned key = keys[u];
+            // a tie straddling rank k: threshold-equal cells belong to workgroup 0 alone (below) — nobody else writes them, so the
+            // result does not depend on the order in which workgroups finish
+            if (ties && key == thr) continue;
+            float vis = 1.f;
+            if (k > 0 && (key > thr || (key == thr && !ties))) vis = 0.f;
+            if (p.mode == 1 && cls.d[lab[u]]) vis = 0.f;
+            out[i] = vis;
+            if (p.mode == 2) { const float f = gat[u] * vis; for (int j = 0; j < base; ++j) final_mask[(size_t)i * base + j] = f; }
+        }
     }
     if (!ties || blockIdx.x != 0) return;
     // rare: a tie straddles rank k.  Workgroup 0 hands the `need` threshold-equal slots out in index order and writes BOTH
