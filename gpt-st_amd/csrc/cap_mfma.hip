@@ -814,14 +814,35 @@ __global__ __launch_bounds__(CM_NT, 4) void cap_rec_bwd2_kernel(const float* __r
     float* Vs = bl + HS * NP;               // HSP * P  v
     float* S = Vs + HSP * P;                // HSP * C  dv
     const int bt = blockIdx.x, tid = threadIdx.x;
-    for (int i = tid; i < NR * LPR; i += CM_NT) {
-        const int n = i / LPR, c4 = i % LPR;
-        st4(Ds + n * P + 4 * c4, n < N ? ld4(drec + ((size_t)bt * N + n) * C + 4 * c4) : f4zero());
+    // Loads are issued in batches ahead of the LDS stores (a copy loop costs one serialised L2 round trip per trip).
+    const int ncn = HS * N, nv = HS * LPR, nD = N * LPR;
+    const float* cb = c + (size_t)bt * ncn;
+    float cr[4];
+    float4 vr;
+#pragma unroll
+    for (int u = 0; u < 4; ++u) cr[u] = cb[min(u * CM_NT + tid, ncn - 1)];
+    vr = ld4(v + (size_t)bt * HS * C + 4 * (size_t)min(tid, nv - 1));
+    for (int i0 = 0; i0 < NR * LPR; i0 += 4 * CM_NT) {
+        float4 d4[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) d4[u] = ld4(drec + (size_t)bt * N * C + 4 * (size_t)min(i0 + u * CM_NT + tid, nD - 1));
+        SB();
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int i = i0 + u * CM_NT + tid;
+            if (i < NR * LPR) st4(Ds + (i / LPR) * P + 4 * (i % LPR), i < nD ? d4[u] : f4zero());
+        }
     }
     for (int i = tid; i < HSP * NP + HS * NP + HSP * P; i += CM_NT) cs[i] = 0.f;      // cs, bl, Vs
     __syncthreads();
-    for (int i = tid; i < HS * N; i += CM_NT) cs[(i / N) * NP + i % N] = c[(size_t)bt * HS * N + i];
-    for (int i = tid; i < HS * LPR; i += CM_NT) st4(Vs + (i / LPR) * P + 4 * (i % LPR), ld4(v + (size_t)bt * HS * C + 4 * i));
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+        const int i = u * CM_NT + tid;
+        if (i < ncn) cs[(i / N) * NP + i % N] = cr[u];
+    }
+    for (int i = 4 * CM_NT + tid; i < ncn; i += CM_NT) cs[(i / N) * NP + i % N] = cb[i];
+    if (tid < nv) st4(Vs + (tid / LPR) * P + 4 * (tid % LPR), vr);
+    for (int i = CM_NT + tid; i < nv; i += CM_NT) st4(Vs + (i / LPR) * P + 4 * (i % LPR), ld4(v + (size_t)bt * HS * C + 4 * i));
     __syncthreads();
     cm_type2<C>(Ds, Vs, bl, N, NP, HS, HSP);
     cm_type1<C>(Ds, cs, S, N, NP, HSP);

@@ -35,3 +35,12 @@ for r in step:
     busy[q] = busy.get(q, 0.0) + (r[5] - r[4]) / 1e3
     print("%9.1f %7.1f gap %6.1f q%-3s s%-3s %s [%d,%d]" % ((r[4] - t0) / 1e3, (r[5] - r[4]) / 1e3, gap, q, s, n, r[1] // max(r[3], 1), r[2]))
 print("# busy us per queue:", {k: round(v, 1) for k, v in busy.items()})
+# inter-step statistics over the whole run: period = marker end -> next marker end; idle = marker end -> next kernel start
+per, idle, span = [], [], []
+for a, b in zip(ends[:-1], ends[1:]):
+    per.append((rows[b][5] - rows[a][5]) / 1e3)
+    idle.append((rows[a + 1][4] - rows[a][5]) / 1e3)
+    span.append((rows[b][5] - rows[a + 1][4]) / 1e3)
+if per:
+    med = lambda v: sorted(v)[len(v) // 2]
+    print("# steps %d: median period %.1f us, median span %.1f us, median idle between steps %.1f us" % (len(per), med(per), med(span), med(idle)))
