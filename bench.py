@@ -234,6 +234,10 @@ def main():
     ap.add_argument("--repeats", type=int, default=1,
                     help="SURVEY 8(d) protocol: after the contract's timed region (which `value` reports), time the same K steps this many times "
                          "in total and report every rate and their median as `repeat_values` / `median_value` (e.g. --warmup 50 --steps 500 --repeats 5)")
+    ap.add_argument("--group", type=int, default=None,
+                    help="optimisation steps per hipGraph replay (PretrainStep.step_group): K consecutive steps, each a full step on its own "
+                         "input buffer with its own optimiser update, behind ONE host-scalar copy and ONE graph launch (default: the trainer's "
+                         "own setting, config.STEPS_PER_REPLAY = 4; 1 = one replay per step)")
     ap.add_argument("--no-graph", action="store_true")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-timing", action="store_true")
@@ -303,16 +307,30 @@ def main():
                                seed=7)          # same seed on every rank: global mask noise and class order must agree (dist.py)
         src = synth.make_batch(B, T, N, args.input_base_dim, interval=args.interval, seed=2024 + rank, start_slot=1000 * rank).to(dev)
     stepper.src.copy_(src)                           # inputs resident in HBM before the timed region
+    G = max(int(a.group if a.group is not None else getattr(args, "steps_per_replay", 1)), 1)
+    if a.shard == "nodes" or a.no_graph or not stepper.group_ok(a.epoch):
+        G = 1
+    if G > 1:
+        gsrcs = stepper.group_sources(G)             # G consecutive steps per graph replay (PretrainStep.step_group): G input buffers
+        for t_ in gsrcs:
+            t_.copy_(src)
 
-    for _ in range(max(a.warmup, 1)):
-        stepper.step(stepper.src, a.epoch)
+    def run(n, epoch):
+        """enqueue exactly n optimisation steps"""
+        for _ in range(n // G if G > 1 else 0):
+            stepper.step_group(gsrcs, epoch)
+        for _ in range(n % G if G > 1 else n):
+            stepper.step(stepper.src, epoch)
+
+    run(max(a.warmup, 1), a.epoch)
+    if G > 1 and a.warmup < G:
+        run(G, a.epoch)                              # the group graph is captured outside the timed region
     torch.cuda.synchronize()
     if dp is not None:
         dp.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
-    for _ in range(a.steps):
-        stepper.step(stepper.src, a.epoch)
+    run(a.steps, a.epoch)
     torch.cuda.synchronize()
     if dp is not None:
         dp.barrier()
@@ -327,8 +345,7 @@ def main():
         if dp is not None:
             dp.barrier()
         t0r = time.perf_counter()
-        for _ in range(a.steps):
-            stepper.step(stepper.src, a.epoch)
+        run(a.steps, a.epoch)
         torch.cuda.synchronize()
         if dp is not None:
             dp.barrier()
@@ -340,12 +357,10 @@ def main():
     # random-mask phase (epochs 1..change_epoch) rate, informative
     rnd_rate = None
     if world == 1 and a.shard != "nodes":
-        for _ in range(5):
-            stepper.step(stepper.src, 1)
+        run(max(5, G), 1)
         torch.cuda.synchronize()
         t1 = time.perf_counter()
-        for _ in range(max(a.steps // 4, 10)):
-            stepper.step(stepper.src, 1)
+        run(max(a.steps // 4, 10), 1)
         torch.cuda.synchronize()
         rnd_rate = max(a.steps // 4, 10) / (time.perf_counter() - t1)
 
@@ -387,6 +402,7 @@ def main():
                  ("c-abi rccl, captured in the step graph" if (a.native_comm and not getattr(stepper, "_graph_comm_failed", False)) else
                   ("c-abi rccl between graph replays (capturing the collectives failed)" if a.native_comm else "torch.distributed between graph replays"))),
         "graph": bool(getattr(stepper, "shard_graph", False)) if a.shard == "nodes" else not a.no_graph,
+        "steps_per_graph_replay": G,
         "hbm_peak_gb": round(torch.cuda.max_memory_allocated() / 2**30, 2),
         "alloc_retries": int(torch.cuda.memory_stats().get("num_alloc_retries", 0)),
     }

@@ -62,9 +62,15 @@ def parse_args(device, argv=None):
     for sec, key, typ in _KEYS:
         ap.add_argument("-" + key, default=typ(cp[sec][key]), type=typ)
     ap.add_argument("-log_dir", default="./", type=str)
+    ap.add_argument("-steps_per_replay", default=STEPS_PER_REPLAY, type=int)      # not a reference option: see STEPS_PER_REPLAY
     args, _ = ap.parse_known_args(argv)
     args.interval, args.week_day = DATASET_TIME.get(args.dataset, (5, 7))
     return args
+
+
+# Optimisation steps enqueued per hipGraph replay by the trainer and bench.py (PretrainStep.step_group): the device idles ~19 us between
+# two graph replays, one replay per 4 steps removes three quarters of that.  1 = one replay per step.  Results do not depend on it.
+STEPS_PER_REPLAY = int(os.environ.get("GPTST_STEPS_PER_REPLAY", "4"))
 
 
 def make_args(dataset="PEMS08", mode="pretrain", device="cpu", **overrides):
@@ -75,6 +81,7 @@ def make_args(dataset="PEMS08", mode="pretrain", device="cpu", **overrides):
         setattr(ns, key, typ(cp[sec][key]))
     ns.interval, ns.week_day = DATASET_TIME.get(dataset, (5, 7))
     ns.scaler_zeros = 0.0
+    ns.steps_per_replay = STEPS_PER_REPLAY
     for k, v in overrides.items():
         setattr(ns, k, v)
     return ns

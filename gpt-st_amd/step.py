@@ -51,10 +51,7 @@ class PretrainStep:
         # Per-step host scalars travel through a RING of pinned slots, each guarded by an event recorded behind its H2D copies:
         # step() never synchronises, so with a single pinned buffer the host could rewrite the Adam bias corrections / class
         # order of step k+j before the DMA of step k has read them (hundreds of steps are queued back to back by bench.py).
-        self._ring = []
-        for _ in range(self.RING):
-            hc = torch.zeros(16 + self.HS + 4, dtype=torch.int32).pin_memory()
-            self._ring.append(dict(hc=hc, hyper=hc[:16].view(torch.float32), ctrl=hc[16:16 + self.HS + 2], rng=hc[16 + self.HS + 2:], ev=None))
+        self._ring = [self._views(torch.zeros(16 + self.HS + 4, dtype=torch.int32).pin_memory()) for _ in range(self.RING)]
         self._ring_i = 0
         self.phase_kl = False                                        # phase of the last enqueued step (losses())
         self.stats_out = torch.zeros(8, device=self.dev)            # snapshot of stats after the step (graph output)
@@ -216,6 +213,12 @@ class PretrainStep:
             ops.set_deterministic(False)
 
     # ---- host side of one step -------------------------------------------------------------------------------------
+    def _views(self, hc):
+        """numpy views of one pinned host-scalar record (written without a torch dispatch per element)"""
+        HS = self.HS
+        n = hc.numpy()
+        return dict(hc=hc, hyper=n[:16].view("float32"), ctrl=n[16:16 + HS + 2], rng=n[16 + HS + 2:], ev=None)
+
     def _slot(self):
         """Next pinned slot of the ring; waits (host side) until the copies that last used it have run."""
         sl = self._ring[self._ring_i]
@@ -225,35 +228,35 @@ class PretrainStep:
         return sl
 
     def _host_prepare(self, phase, epoch, list_c):
+        sl = self._slot()
+        self._fill(sl, phase, epoch, list_c)
+        self.hc.copy_(sl["hc"], non_blocking=True)
+        if sl["ev"] is None:
+            sl["ev"] = torch.cuda.Event()
+        sl["ev"].record()
+
+    def _fill(self, sl, phase, epoch, list_c):
+        """Advance the optimiser counters by one step and write that step's host scalars into the pinned views of `sl`."""
         a = self.args
         self.tA += 1
         if phase == 1:
             self.tB += 1
         self.phase_kl = phase == 1
         b1, b2 = 0.9, 0.999
-        sl = self._slot()
-        h = sl["hyper"]
-        h[0] = self.lr / (1 - b1 ** self.tA); h[1] = math.sqrt(1 - b2 ** self.tA)
-        h[2] = self.lr / (1 - b1 ** self.tB) if self.tB else 0.0
-        h[3] = math.sqrt(1 - b2 ** self.tB) if self.tB else 1.0
-        h[4], h[5], h[6] = b1, b2, 1e-8
-        h[7] = float(a.max_grad_norm) if a.grad_norm else 0.0
-        h[8] = 1.0 if phase == 1 else 0.0
-        sl["rng"][0], sl["rng"][1] = self.noise_seed & 0x7FFFFFFF, self.tA & 0x7FFFFFFF      # same key on every rank: same global noise
-        h[9] = 1.0          # the backward carries the gradient of the SUM loss: the optimiser divides path A by the (global) kept count
-        h[10] = 1.0
+        tA, tB = self.tA, self.tB
+        sl["hyper"][:11] = (self.lr / (1 - b1 ** tA), math.sqrt(1 - b2 ** tA),
+                            self.lr / (1 - b1 ** tB) if tB else 0.0, math.sqrt(1 - b2 ** tB) if tB else 1.0,
+                            b1, b2, 1e-8, float(a.max_grad_norm) if a.grad_norm else 0.0, 1.0 if phase == 1 else 0.0,
+                            1.0,          # the backward carries the gradient of the SUM loss: the optimiser divides path A by the (global) kept count
+                            1.0)
+        sl["rng"][:2] = (self.noise_seed & 0x7FFFFFFF, tA & 0x7FFFFFFF)                      # same key on every rank: same global noise
         if phase == 1:
             if list_c is None:
                 list_c = list(range(self.HS))
                 self.rng.shuffle(list_c)                                   # GPTST.py:357-358
             ada, rnd = self.model.adaptive_counts(self.B * self.T * self.N * (self.W if self.gmask else 1), epoch)
             ada, rnd = self._budgets(ada, rnd, epoch)
-            c = sl["ctrl"]
-            c.copy_(torch.tensor([int(v) for v in list_c] + [int(ada), int(rnd)], dtype=torch.int32))
-        self.hc.copy_(sl["hc"], non_blocking=True)
-        if sl["ev"] is None:
-            sl["ev"] = torch.cuda.Event()
-        sl["ev"].record()
+            sl["ctrl"][:] = [int(v) for v in list_c] + [int(ada), int(rnd)]
 
     def _budgets(self, ada, rnd, epoch):
         """Hook: subclasses whose masks cover more cells than this rank's batch (node sharding) replace the budgets."""
@@ -264,6 +267,7 @@ class PretrainStep:
         ``forced_mask`` (fp32, 1 = visible) teacher-forces the mask: used by loss-curve parity runs in the adaptive phase,
         where an fp32-level argmax flip of the cluster classifier would otherwise change which cells are masked."""
         phase = 0 if epoch <= self.args.change_epoch else 1
+        self._g_last = None
         if source is not self.src:
             self.src.copy_(source, non_blocking=True)
         inject = noise is not None or noise_a is not None
@@ -345,9 +349,124 @@ class PretrainStep:
             torch.cuda.synchronize()
         self.graphs[key] = (g1, g2)
 
+    # ---- several steps per graph replay -----------------------------------------------------------------------------
+    # Between two replays of the step graph the device idles for ~19 us (tools/timeline.py on profiles/r03z: 8.8 us from the optimiser's last
+    # kernel to the H2D copy of the next step's host scalars, 4.1 us for that copy, 5.8 us until the graph's first kernel) — 1.3 % of a
+    # 1.42 ms step.  step_group() enqueues K consecutive optimisation steps (K batches, K optimiser updates, each with its own host
+    # scalars, source buffer and statistics snapshot) as ONE graph replay behind ONE H2D copy: the reference's batch loop
+    # (BasicTrainer.py:72-103) unrolled K times.  Results are those of K step() calls (tests/test_gpu_step.py).
+    def group_ok(self, epoch):
+        """A group runs as one graph when the whole step is one graph (no host-side collective inside the step)."""
+        phase = 0 if epoch <= self.args.change_epoch else 1
+        return self.use_graph and (self.dp is None or self._dp_in_graph()) and not (self._needs_exchange(phase) and not self._dp_in_graph())
+
+    def _group_init(self, K):
+        if getattr(self, "_gK", 0) == K:
+            return
+        W = self.hc.numel()
+        self._gK = K
+        self._g_hc = torch.zeros(K, W, dtype=torch.int32, device=self.dev)
+        self._g_src = [torch.zeros_like(self.src) for _ in range(K)]
+        self._g_stats = torch.zeros(K, 8, device=self.dev)
+        self._g_ring = []
+        for _ in range(self.RING):
+            hc = torch.zeros(K, W, dtype=torch.int32).pin_memory()
+            self._g_ring.append(dict(hc=hc, rows=[self._views(hc[j]) for j in range(K)], ev=None))
+        self._g_ring_i = 0
+        self._g_graphs = {}
+
+    def group_sources(self, K):
+        """The K device input buffers (B,T,N,base+2) of a group: fill them (or pass other tensors to step_group, which copies)."""
+        self._group_init(K)
+        return self._g_src
+
+    def _sub(self, j):
+        """Point the per-step buffers of the body at sub-step j of the group (host scalars, source, statistics snapshot)."""
+        HS = self.HS
+        r = self._g_hc[j]
+        self.src, self.stats_out = self._g_src[j], self._g_stats[j]
+        self.hyper, self.ctrl, self.rng_words = r[:16].view(torch.float32), r[16:16 + HS + 2], r[16 + HS + 2:]
+
+    def step_group(self, sources, epoch, list_cs=None):
+        """Enqueue len(sources) consecutive optimisation steps of the same epoch.  Never synchronises.  Falls back to a loop over step()
+        where a step is not one graph (eager mode, host-side collectives).  losses_group() returns the K loss triples."""
+        K = len(sources)
+        if K == 1 or not self.group_ok(epoch):
+            for j, src in enumerate(sources):
+                self.step(src, epoch, list_c=None if list_cs is None else list_cs[j])
+            self._g_last = None
+            return
+        phase = 0 if epoch <= self.args.change_epoch else 1
+        self._group_init(K)
+        for j, src in enumerate(sources):
+            if src is not self._g_src[j]:
+                self._g_src[j].copy_(src, non_blocking=True)
+        sl = self._g_ring[self._g_ring_i]
+        self._g_ring_i = (self._g_ring_i + 1) % self.RING
+        if sl["ev"] is not None:
+            sl["ev"].synchronize()
+        for j in range(K):
+            self._fill(sl["rows"][j], phase, epoch, None if list_cs is None else list_cs[j])
+        self._g_hc.copy_(sl["hc"], non_blocking=True)
+        if sl["ev"] is None:
+            sl["ev"] = torch.cuda.Event()
+        sl["ev"].record()
+        keep = (self.src, self.stats_out, self.hyper, self.ctrl, self.rng_words)
+        try:
+            if phase not in self._g_graphs:
+                self._capture_group(phase, K)
+            self._g_graphs[phase].replay()
+        finally:
+            self.src, self.stats_out, self.hyper, self.ctrl, self.rng_words = keep
+        self._g_last = (K, phase)
+
+    def _capture_group(self, phase, K):
+        self.inject_noise, self.force_mask = False, False
+        keep = (self.model.flat.clone(), self.m.clone(), self.v.clone())
+        s = torch.cuda.Stream()
+        s.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(s):                      # warm-up on a side stream (allocator, lazy kernel attributes)
+            for j in range(min(K, 2)):
+                self._sub(j)
+                self._body(phase)
+        torch.cuda.current_stream().wait_stream(s)
+        torch.cuda.synchronize()
+        ops.set_deterministic(self.deterministic)
+        try:
+            g = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g, capture_error_mode="thread_local"):
+                for j in range(K):
+                    self._sub(j)
+                    ctx = self._part1(phase)
+                    if self._needs_exchange(phase):
+                        self._exchange_labels()
+                    self._part2(phase, ctx)
+        finally:
+            ops.set_deterministic(False)
+            engine.CTX.ARENA = None
+            engine.CTX.SIDE = None
+            self.model.flat.copy_(keep[0]); self.m.copy_(keep[1]); self.v.copy_(keep[2])   # undo the warm-up updates
+            torch.cuda.synchronize()
+        self._g_graphs[phase] = g
+
+    def losses_group(self):
+        """[(loss, loss_flow, loss_s)] of the steps of the last step_group() — synchronises."""
+        if getattr(self, "_g_last", None) is None:
+            return [self.losses()]
+        K, phase = self._g_last
+        st = self._g_stats.cpu()
+        out = []
+        for j in range(K):
+            lf = float(st[j, 0] / max(float(st[j, 1]), 1.0))
+            ls = float(st[j, 2]) * 0.1 if phase == 1 else 0.0
+            out.append((lf + ls, lf, ls))
+        return out
+
     # ---- results ---------------------------------------------------------------------------------------------------
     def losses(self):
         """(loss, loss_flow, loss_s) of the last step — synchronises (reference BasicTrainer.py:98-103 does so every step)."""
+        if getattr(self, "_g_last", None) is not None:
+            return self.losses_group()[-1]
         st = self.stats_out.cpu()
         lf = float(st[0] / max(float(st[1]), 1.0))
         ls = float(st[2]) * 0.1 if self.tB and self.phase_kl else 0.0

@@ -61,15 +61,50 @@ class Trainer:
         a = self.args
         tot = tot_f = tot_s = 0.0
         nb = 0
-        for bi, src in enumerate(self.batches(epoch)):
-            st = self._stepper_for(src.shape[0])
-            st.step(src, epoch)
-            if st is not self.step:
-                self.step.tA, self.step.tB = st.tA, st.tB
-            loss, lf, ls = st.losses()                   # the reference syncs every step too (BasicTrainer.py:98-103)
+        G = max(int(getattr(a, "steps_per_replay", 1)), 1)
+        if G > 1 and not self.step.group_ok(epoch):
+            G = 1
+        pend = []                                        # (batch index, group input buffer) of full-size batches not yet enqueued
+
+        def account(bi, loss, lf, ls):
+            nonlocal tot, tot_f, tot_s, nb
             tot += loss; tot_f += lf; tot_s += ls; nb += 1
             if bi % a.log_step == 0:
                 self.logger.info("Train Epoch {}: {}/{} Loss: {:.6f}".format(epoch, bi, self.nb_epoch if self.nb_epoch is not None else "?", loss))
+
+        def flush():
+            """G pending batches: ONE graph replay (PretrainStep.step_group); fewer (end of the epoch): single steps.  One host sync per flush."""
+            if not pend:
+                return
+            if len(pend) == G:
+                self.step.step_group([s_ for _, s_ in pend], epoch)
+                ls_ = self.step.losses_group()
+            else:
+                ls_ = []
+                for _, s_ in pend:
+                    self.step.step(s_, epoch)
+                    ls_.append(self.step.losses())
+            for (bi_, _), l_ in zip(pend, ls_):
+                account(bi_, *l_)
+            del pend[:]
+
+        for bi, src in enumerate(self.batches(epoch)):
+            if src.shape[0] != self.step.B:
+                flush()                                  # before the ragged stepper takes over the optimiser counters
+            st = self._stepper_for(src.shape[0])
+            if G > 1 and st is self.step:
+                buf = self.step.group_sources(G)[len(pend)]
+                buf.copy_(src, non_blocking=True)        # the loader may reuse its batch buffer: keep a copy until the group is enqueued
+                pend.append((bi, buf))
+                if len(pend) == G:
+                    flush()
+                continue
+            flush()
+            st.step(src, epoch)
+            if st is not self.step:
+                self.step.tA, self.step.tB = st.tA, st.tB
+            account(bi, *st.losses())                    # the reference syncs every step too (BasicTrainer.py:98-103)
+        flush()
         if nb == 0:
             raise RuntimeError("epoch %d: this rank received no batch (dataset smaller than world_size x batch_size?)" % epoch)
         self.logger.info("**********Train Epoch {}: averaged Loss: {:.6f} averaged Loss_s: {:.6f}".format(epoch, tot_f / nb, tot_s / nb))

@@ -244,3 +244,41 @@ def test_deterministic_mode_is_bit_reproducible(use_graph, N, over):
     assert outs[0][3] == outs[1][3], "losses differ between two deterministic runs"
     for a, b, nm in zip(outs[0][:3], outs[1][:3], ("parameters", "exp_avg", "exp_avg_sq")):
         assert torch.equal(a, b), "%s differ between two deterministic runs" % nm
+
+
+def test_step_group_equals_single_steps():
+    """PretrainStep.step_group: K consecutive steps in ONE graph replay (one H2D copy of the K steps' host scalars) leave the same
+    parameters, optimiser state and per-step losses as K step() calls — bit for bit in deterministic mode, both mask phases, free-running
+    Philox noise (keyed by the step counter, so the two runs draw the same masks)."""
+    from gptst_amd.model import GPTST_Model
+    from gptst_amd.step import PretrainStep
+    args = _args()
+    sd = O.init_state_dict(args, 2)
+    K = 4
+    srcs = [synth.make_batch(4, 12, 20, 1, seed=900 + i).to(DEV) for i in range(4 * K)]
+    orders = [synth.class_order(5, 40 + i) for i in range(4 * K)]
+    outs = []
+    for grouped in (False, True):
+        model = GPTST_Model(args); model.load_state_dict(sd); model = model.to(DEV)
+        st = PretrainStep(model, args, synth.SCALER_MEAN, synth.SCALER_STD, batch_size=4, use_graph=True, deterministic=True)
+        losses = []
+        for blk in range(4):
+            epoch = 2 if blk < 2 else 5                      # change_epoch = 3: two groups per phase (the second replays the captured graph)
+            ss, oo = srcs[blk * K:(blk + 1) * K], orders[blk * K:(blk + 1) * K]
+            if grouped:
+                assert st.group_ok(epoch)
+                st.step_group(ss, epoch, list_cs=oo)
+                losses += st.losses_group()
+                assert st.losses() == losses[-1]
+            else:
+                for s_, o_ in zip(ss, oo):
+                    st.step(s_, epoch, list_c=o_)
+                    losses.append(st.losses())
+        outs.append((model.flat.clone(), st.m.clone(), st.v.clone(), losses, (st.tA, st.tB)))
+    assert outs[0][4] == outs[1][4] == (16, 8)
+    assert outs[0][3] == outs[1][3], (outs[0][3], outs[1][3])
+    for a, b, nm in zip(outs[0][:3], outs[1][:3], ("parameters", "exp_avg", "exp_avg_sq")):
+        assert torch.equal(a, b), "%s differ between grouped and single steps" % nm
+    # a single step after a group continues the same sequence
+    st.step(srcs[0], 5, list_c=orders[0])
+    assert st.losses()[0] > 0
