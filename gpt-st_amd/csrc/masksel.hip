@@ -15,6 +15,7 @@
 #define MS_BLOCKS 64
 #define MS_THREADS 256
 #define MS_BINS 2048
+#define MS_BLK (3 * MS_BINS + 16)      // words of one selection's block: three digit histograms + the prefix memo (9 words)
 // digit d covers bits [SH(d), SH(d)+W(d)):  d0 = 31..21, d1 = 20..10, d2 = 9..0
 __device__ __forceinline__ int ms_shift(int d) { return d == 0 ? 21 : (d == 1 ? 10 : 0); }
 __device__ __forceinline__ int ms_bins(int d) { return d == 2 ? 1024 : 2048; }
@@ -65,12 +66,16 @@ __device__ __forceinline__ int ms_rank(const MsPlan& p, const MsClass& c) {
     return p.mode == 0 ? p.k_const : (p.mode == 1 ? c.ka : p.nums[1]);
 }
 
-// Re-derive (prefix, remaining, cnt_eq) from the finished histograms of digits 0..ndig-1.  Thread-0 serial scan is
-// replaced by a block-parallel suffix scan because 2048 bins x 64 workgroups adds up.
+// (prefix, remaining, cnt_eq) after the finished histograms of digits 0..ndig-1.  Every workgroup scans the NEWEST digit only (a block-
+// parallel suffix scan: 2048 bins x 64 workgroups as a thread-0 loop adds up); the state after the earlier digits comes from `memo`
+// (3 words per digit behind the histograms), written by workgroup 0 of the launch that scanned that digit.
 __device__ void ms_prefix(const unsigned* __restrict__ hist, int ndig, int k, unsigned* sh /* >= MS_BINS+8 */, unsigned& prefix,
                           unsigned& remaining, unsigned& cnt_eq) {
     prefix = 0u; remaining = (unsigned)k; cnt_eq = 0u;
-    for (int d = 0; d < ndig; ++d) {
+    if (ndig <= 0) return;
+    unsigned* memo = const_cast<unsigned*>(hist) + 3 * MS_BINS;
+    if (ndig >= 2) { prefix = memo[3 * (ndig - 2)]; remaining = memo[3 * (ndig - 2) + 1]; cnt_eq = memo[3 * (ndig - 2) + 2]; }
+    for (int d = ndig - 1; d < ndig; ++d) {
         const int nb = ms_bins(d);
         const unsigned* h = hist + d * MS_BINS;
         // each thread owns nb/256 consecutive bins (descending order = ascending "rank from the top")
@@ -100,6 +105,7 @@ __device__ void ms_prefix(const unsigned* __restrict__ hist, int ndig, int k, un
         cnt_eq = sh[MS_THREADS + 2];
         __syncthreads();
     }
+    if (blockIdx.x == 0 && threadIdx.x == 0) { memo[3 * (ndig - 1)] = prefix; memo[3 * (ndig - 1) + 1] = remaining; memo[3 * (ndig - 1) + 2] = cnt_eq; }
 }
 
 // one digit pass: histogram of digit `dig` over the keys that match the prefix of the earlier digits
@@ -134,18 +140,24 @@ __global__ __launch_bounds__(MS_THREADS) void ms_hist_kernel(MsPlan p, unsigned*
 //   mode 0: out = mask (M = B*T*N*base cells)
 //   mode 1: out = m_ada  (also zeroes the fully masked classes, :397)
 //   mode 2: out = m_rnd, final[i*base + j] = gate[i] * m_rnd[i]   (:411-413)
+//   next_noise != NULL (mode 1 only): digit 0 of selection R — whose keys are next_noise gated by THIS launch's output — is histogrammed
+//   here into next_hist (zeroed), so selection R starts at digit 1: one launch less.
 __global__ __launch_bounds__(MS_THREADS) void ms_apply_kernel(MsPlan p, const unsigned* __restrict__ hist, float* __restrict__ out,
-                                                              float* __restrict__ final_mask, int base) {
+                                                              float* __restrict__ final_mask, int base, const float* __restrict__ next_noise,
+                                                              unsigned* __restrict__ next_hist) {
     __shared__ unsigned sc[MS_THREADS + 8];
     __shared__ MsClass cls;
     __shared__ unsigned s_base;
+    __shared__ unsigned lh[MS_BINS];
+    const bool nxt = next_noise != nullptr && p.nums[1] > 0;        // uniform
+    if (nxt) { for (int b = threadIdx.x; b < MS_BINS; b += MS_THREADS) lh[b] = 0u; }
     if (p.mode == 1) ms_classes(p, cls);
     const int k = ms_rank(p, cls);
     unsigned thr = 0xFFFFFFFFu, need = 0u, cnt_eq = 0u;
     if (k > 0) ms_prefix(hist, 3, k, sc, thr, need, cnt_eq);
     const bool ties = k > 0 && need != cnt_eq;                   // uniform
     for (int i0 = blockIdx.x * MS_THREADS + threadIdx.x; i0 < p.M; i0 += 4 * MS_BLOCKS * MS_THREADS) {       // four cells' loads in flight
-        unsigned keys[4];
+        unsigned keys[4], nk[4];
         int lab[4];
         float gat[4];
 #pragma unroll
@@ -154,6 +166,7 @@ __global__ __launch_bounds__(MS_THREADS) void ms_apply_kernel(MsPlan p, const un
             keys[u] = ms_key(p, cls, i);
             lab[u] = p.mode == 1 ? p.label[i] : 0;
             gat[u] = p.mode == 2 ? p.gate[i] : 0.f;
+            nk[u] = nxt ? __float_as_uint(next_noise[i]) : 0u;
         }
 #pragma unroll
         for (int u = 0; u < 4; ++u) {
@@ -168,9 +181,14 @@ __global__ __launch_bounds__(MS_THREADS) void ms_apply_kernel(MsPlan p, const un
             if (p.mode == 1 && cls.d[lab[u]]) vis = 0.f;
             out[i] = vis;
             if (p.mode == 2) { const float f = gat[u] * vis; for (int j = 0; j < base; ++j) final_mask[(size_t)i * base + j] = f; }
+            if (nxt) atomicAdd(&lh[(vis != 0.f ? nk[u] : 0u) >> ms_shift(0)], 1u);
         }
     }
-    if (!ties || blockIdx.x != 0) return;
+    const bool tie_wg = ties && blockIdx.x == 0;
+    if (!tie_wg) {
+        if (nxt) { __syncthreads(); for (int b = threadIdx.x; b < MS_BINS; b += MS_THREADS) if (lh[b]) atomicAdd(next_hist + b, lh[b]); }
+        return;
+    }
     // rare: a tie straddles rank k.  Workgroup 0 hands the `need` threshold-equal slots out in index order and writes BOTH
     // values (0 for the first `need` of them, 1 for the rest).
     if (threadIdx.x == 0) s_base = 0u;
@@ -192,11 +210,13 @@ __global__ __launch_bounds__(MS_THREADS) void ms_apply_kernel(MsPlan p, const un
             if (p.mode == 1 && cls.d[p.label[i]]) vis = 0.f;
             out[i] = vis;
             if (p.mode == 2) { const float f = p.gate[i] * vis; for (int j = 0; j < base; ++j) final_mask[(size_t)i * base + j] = f; }
+            if (nxt) atomicAdd(&lh[(vis != 0.f ? __float_as_uint(next_noise[i]) : 0u) >> ms_shift(0)], 1u);
         }
         __syncthreads();
         if (threadIdx.x == MS_THREADS - 1) s_base += sc[threadIdx.x];
         __syncthreads();
     }
+    if (nxt) { __syncthreads(); for (int b = threadIdx.x; b < MS_BINS; b += MS_THREADS) if (lh[b]) atomicAdd(next_hist + b, lh[b]); }
 }
 
 // ======================================================================================================================
@@ -379,10 +399,12 @@ __global__ __launch_bounds__(256) void ms_zero_kernel(unsigned* __restrict__ p, 
     for (int i = blockIdx.x * 256 + threadIdx.x; i < n; i += gridDim.x * 256) p[i] = 0u;
 }
 
-// one selection on a ZEROED histogram block (3 digit passes + the mask write)
-static int ms_select(const MsPlan& p, unsigned* hist, float* out, float* final_mask, int base, hipStream_t st) {
-    for (int d = 0; d < 3; ++d) hipLaunchKernelGGL(ms_hist_kernel, dim3(MS_BLOCKS), dim3(MS_THREADS), 0, st, p, hist, d);
-    hipLaunchKernelGGL(ms_apply_kernel, dim3(MS_BLOCKS), dim3(MS_THREADS), 0, st, p, (const unsigned*)hist, out, final_mask, base);
+// one selection on a ZEROED histogram block (digit passes d0..2 + the mask write); next_noise / next_hist: see ms_apply_kernel
+static int ms_select(const MsPlan& p, unsigned* hist, float* out, float* final_mask, int base, hipStream_t st, int d0 = 0,
+                     const float* next_noise = nullptr, unsigned* next_hist = nullptr) {
+    for (int d = d0; d < 3; ++d) hipLaunchKernelGGL(ms_hist_kernel, dim3(MS_BLOCKS), dim3(MS_THREADS), 0, st, p, hist, d);
+    hipLaunchKernelGGL(ms_apply_kernel, dim3(MS_BLOCKS), dim3(MS_THREADS), 0, st, p, (const unsigned*)hist, out, final_mask, base, next_noise,
+                       next_hist);
     GPTST_CHECK_LAUNCH();
     return GPTST_OK;
 }
@@ -397,16 +419,16 @@ __global__ __launch_bounds__(256) void ms_count_kernel(const int* __restrict__ l
     for (int h = threadIdx.x; h < HS; h += 256) if (hist[h]) atomicAdd(counts + h, hist[h]);
 }
 
-// ws: device scratch of gptst_mask_ws_bytes() bytes: [histogram block of selection A / the random selection | block of selection R |
-// class counts (256)] — ONE zeroing launch per mask generation covers all of it
-#define MS_WS_WORDS (2 * 3 * MS_BINS + 256)
+// ws: device scratch of gptst_mask_ws_bytes() bytes: [block of selection A / the random selection | block of selection R |
+// class counts (256)] — ONE zeroing launch per mask generation covers all of it (none when the caller hands it over zeroed)
+#define MS_WS_WORDS (2 * MS_BLK + 256)
 extern "C" int gptst_mask_ws_bytes(void) { return (int)(sizeof(unsigned) * MS_WS_WORDS); }
 
 int g_ms_force_multi = 0;       // tests: 1 = take the multi-launch path for every size
 
 extern "C" int gptst_mask_force_multi(int on) { g_ms_force_multi = on; return GPTST_OK; }
 
-extern "C" int gptst_mask_random(const float* noise, int M, int k, float* mask, void* ws, void* stream) {
+extern "C" int gptst_mask_random(const float* noise, int M, int k, float* mask, void* ws, int ws_zeroed, void* stream) {
     if (!noise || !mask || !ws || M <= 0 || k < 0 || k > M) return GPTST_EARG;
     MsPlan p{nullptr, nullptr, nullptr, nullptr, noise, nullptr, 0, 0, 0, M, k};
     if (M <= MSS_MAXM && !g_ms_force_multi) {
@@ -414,7 +436,7 @@ extern "C" int gptst_mask_random(const float* noise, int M, int k, float* mask, 
         GPTST_CHECK_LAUNCH();
         return GPTST_OK;
     }
-    hipLaunchKernelGGL(ms_zero_kernel, dim3(6), dim3(256), 0, (hipStream_t)stream, (unsigned*)ws, 3 * MS_BINS);
+    if (!ws_zeroed) hipLaunchKernelGGL(ms_zero_kernel, dim3(6), dim3(256), 0, (hipStream_t)stream, (unsigned*)ws, MS_BLK);
     return ms_select(p, (unsigned*)ws, mask, nullptr, 1, (hipStream_t)stream);
 }
 
@@ -429,7 +451,7 @@ extern "C" int gptst_mask_labels(const float* prob, int rows, int HS, int* label
 
 extern "C" int gptst_mask_adaptive(const int* label, const int* counts, const int* list_c, const int* nums, const float* noise_a,
                                    const float* noise_r, int ada_all, int M, int HS, int base, float* m_ada, float* m_rnd,
-                                   float* mask, void* ws, void* stream) {
+                                   float* mask, void* ws, int ws_zeroed, void* stream) {
     if (!label || !list_c || !nums || !noise_a || !noise_r || !m_ada || !m_rnd || !mask || !ws || HS > 256) return GPTST_EARG;
     MsPlan a{label, counts, list_c, nums, noise_a, nullptr, 1, ada_all, HS, M, 0};
     if (M <= MSS_MAXM && !g_ms_force_multi) {        // counts may be NULL here: the single-workgroup kernel histograms the labels itself
@@ -438,15 +460,16 @@ extern "C" int gptst_mask_adaptive(const int* label, const int* counts, const in
         return GPTST_OK;
     }
     unsigned* w = (unsigned*)ws;
-    hipLaunchKernelGGL(ms_zero_kernel, dim3(12), dim3(256), 0, (hipStream_t)stream, w, MS_WS_WORDS);       // both histogram blocks + counts
+    if (!ws_zeroed) hipLaunchKernelGGL(ms_zero_kernel, dim3(12), dim3(256), 0, (hipStream_t)stream, w, MS_WS_WORDS);   // both blocks + counts
     if (!counts) {                                         // class histogram from the labels (what gptst_mask_labels would have produced)
         int nb = (M + 255) / 256; if (nb > 64) nb = 64;
-        int* cw = (int*)(w + 2 * 3 * MS_BINS);
+        int* cw = (int*)(w + 2 * MS_BLK);
         hipLaunchKernelGGL(ms_count_kernel, dim3(nb), dim3(256), 0, (hipStream_t)stream, label, M, HS, cw);
         a.counts = cw;
     }
-    int rc = ms_select(a, w, m_ada, nullptr, base, (hipStream_t)stream);                                   // :386-397
+    // selection A's mask write also histograms digit 0 of selection R (whose keys it gates): R starts at digit 1
+    int rc = ms_select(a, w, m_ada, nullptr, base, (hipStream_t)stream, 0, noise_r, w + MS_BLK);           // :386-397
     if (rc) return rc;
     MsPlan r{label, a.counts, list_c, nums, noise_r, m_ada, 2, ada_all, HS, M, 0};
-    return ms_select(r, w + 3 * MS_BINS, m_rnd, mask, base, (hipStream_t)stream);                          // :399-413
+    return ms_select(r, w + MS_BLK, m_rnd, mask, base, (hipStream_t)stream, 1);                            // :399-413
 }

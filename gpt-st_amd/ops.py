@@ -585,10 +585,17 @@ def _mask_ws(dev):
     return _MASK_WS[dev]
 
 
-def mask_random(noise, k):
+def mask_ws_floats():
+    """size (in 4-byte words) of the scratch of mask_random / mask_adaptive: pass a ZEROED fp32 tensor of this size as `ws` to save the
+    zeroing launch (PretrainStep takes it from the step's zero-initialised arena)."""
+    return _C.lib().value("gptst_mask_ws_bytes") // 4
+
+
+def mask_random(noise, k, ws=None):
     _chk(noise)
     mask = torch.empty_like(noise)
-    _call("gptst_mask_random", _p(noise), noise.numel(), int(k), _p(mask), _p(_mask_ws(noise.device)))
+    _call("gptst_mask_random", _p(noise), noise.numel(), int(k), _p(mask), _p(ws if ws is not None else _mask_ws(noise.device)),
+          int(ws is not None))
     return mask
 
 
@@ -611,14 +618,14 @@ def mask_labels(prob):
     return label, counts
 
 
-def mask_adaptive(label, counts, list_c, nums, noise_a, noise_r, ada_all, base):
-    """-> (m_ada (M), m_rnd (M), mask (M*base)) fp32 {0,1}."""
+def mask_adaptive(label, counts, list_c, nums, noise_a, noise_r, ada_all, base, ws=None):
+    """-> (m_ada (M), m_rnd (M), mask (M*base)) fp32 {0,1}.  ws: see mask_ws_floats()."""
     M, HS = label.numel(), list_c.numel()
     m_ada = torch.empty(M, device=label.device, dtype=torch.float32)
     m_rnd = torch.empty_like(m_ada)
     mask = torch.empty(M * base, device=label.device, dtype=torch.float32)
     _call("gptst_mask_adaptive", _p(label), _p(counts), _p(list_c), _p(nums), _p(noise_a), _p(noise_r), int(ada_all), M, HS, base,
-          _p(m_ada), _p(m_rnd), _p(mask), _p(_mask_ws(label.device)))
+          _p(m_ada), _p(m_rnd), _p(mask), _p(ws if ws is not None else _mask_ws(label.device)), int(ws is not None))
     return m_ada, m_rnd, mask
 
 

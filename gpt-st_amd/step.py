@@ -129,11 +129,11 @@ class PretrainStep:
             if self.force_mask:
                 mask = self.mask_buf
             elif phase == 0:
-                mask = ops.mask_random(self.noise, int(M * base * a.mask_ratio))
+                mask = ops.mask_random(self.noise, int(M * base * a.mask_ratio), ws=self._mask_ws())
             else:
                 label, counts = ops.labels_and_counts(prob, sv_g[4])
                 mask = ops.mask_adaptive(label, counts, self.ctrl[:self.HS], self.ctrl[self.HS:], self.noise_a, self.noise_r,
-                                         a.ada_type == "all", base)[2]
+                                         a.ada_type == "all", base, ws=self._mask_ws())[2]
         self.last_mask = mask
         if self.gen_side is not None:
             self.gen_side.join()
@@ -178,6 +178,10 @@ class PretrainStep:
             self.dp.allreduce_(self.gbuf)
             self._optim()
 
+    def _mask_ws(self):
+        """The selections' histogram scratch comes zeroed out of the step's arena (cleared by the step's first launch): no zeroing launch."""
+        return self.arena.zeros(ops.mask_ws_floats())
+
     def _global_mask(self, phase):
         """Mask of this rank's rows cut out of the selection over the global batch (identical on every rank)."""
         a, base, M = self.args, self.base, self.B * self.T * self.N
@@ -185,10 +189,10 @@ class PretrainStep:
         if self.force_mask:
             return self.mask_buf
         if phase == 0:
-            mask_g = ops.mask_random(self.noise_g, int(Mg * base * a.mask_ratio))
+            mask_g = ops.mask_random(self.noise_g, int(Mg * base * a.mask_ratio), ws=self._mask_ws())
         else:                                              # label_g was gathered by _exchange_labels(); class histogram taken inside
             mask_g = ops.mask_adaptive(self.label_g, None, self.ctrl[:self.HS], self.ctrl[self.HS:], self.noise_a_g,
-                                       self.noise_r_g, a.ada_type == "all", base)[2]
+                                       self.noise_r_g, a.ada_type == "all", base, ws=self._mask_ws())[2]
         self.last_mask_global = mask_g
         return self.dp.rows_of(mask_g, M * base)
 

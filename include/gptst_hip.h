@@ -22,7 +22,7 @@
 extern "C" {
 #endif
 
-#define GPTST_ABI_VERSION 6
+#define GPTST_ABI_VERSION 7
 int gptst_abi_version(void);
 /* 1: bit-reproducible steps — the two reductions that end in float atomics by default (embedding gradients of gptst_pool_jobs kind 2,
  * weight gradients of gptst_timefeat_jobs) run as single-owner kernels with a fixed summation order (slower).  Everything else is
@@ -234,9 +234,12 @@ int gptst_metrics_accum(const float* out, const float* src, int lda, const float
 /* ---- mask generation, integer work, bit-exact given noise/labels/class order (masksel.hip), GPTST.py:314-323,344-413 ----
  * Masks are fp32 {0,1} arrays, 1 = visible, 0 = masked.  Top-k = radix select on the float bits, 11/11/10-bit digits (ties at
  * rank k -> lowest index).  Up to 2^13 cells the whole generation (class histogram and roles, both selections, mask writes) is ONE
- * launch of one 1024-thread workgroup; beyond, one launch per digit + one to write the mask, 64 workgroups each. */
+ * launch of one 1024-thread workgroup; beyond, one launch per digit + one to write the mask, 64 workgroups each (the adaptive phase's
+ * first mask write also histograms the first digit of the second selection). */
 int gptst_mask_ws_bytes(void);   /* device scratch (ws) needed by the two selections below */
-int gptst_mask_random(const float* noise, int M, int k, float* mask, void* ws, void* stream);
+/* ws_zeroed != 0: the caller hands ws over all-zero (e.g. as part of a scratch region it clears once per step) — saves the zeroing launch.
+ * ws is left dirty. */
+int gptst_mask_random(const float* noise, int M, int k, float* mask, void* ws, int ws_zeroed, void* stream);
 /* label[i] = argmax_h prob[i,h] (int32), counts[h] (int32, zeroed here) — replaces sort(..)[..., 0] (:344-345). */
 int gptst_mask_labels(const float* prob, int rows, int HS, int* label, int* counts, void* stream);
 /* adaptive phase: device-side class selection (:356-384) + two selections (:386-407) + product (:410-413).
@@ -246,7 +249,7 @@ int gptst_mask_labels(const float* prob, int rows, int HS, int* label, int* coun
  * small launch beyond). */
 int gptst_mask_adaptive(const int* label, const int* counts, const int* list_c, const int* nums, const float* noise_a,
                         const float* noise_r, int ada_all, int M, int HS, int base, float* m_ada, float* m_rnd, float* mask,
-                        void* ws, void* stream);
+                        void* ws, int ws_zeroed, void* stream);
 int gptst_mask_force_multi(int on);   /* tests: 1 = multi-launch path for every size */
 
 /* ---- thin projections (small.hip) ------------------------------------------------------------------------

@@ -333,6 +333,63 @@ def test_mask_adaptive_bit_exact(ada_all, B, N, HS, frac):
         assert int((mask.view(M, base)[:, 0] == 0).sum()) == total
 
 
+@pytest.mark.parametrize("ada_all", [1, 0])
+def test_mask_adaptive_ties_and_caller_zeroed_scratch(ada_all):
+    """Multi-launch adaptive generation with heavily tied noise in BOTH selections (the tie workgroup of selection A's mask write also has
+    to feed selection R's first-digit histogram), scratch handed over zeroed (ws_zeroed: no zeroing launch), several budgets — bit-exact
+    against the oracle; and the random selection with a caller-zeroed scratch."""
+    from gptst_amd import ops, synth
+    dev = _dev()
+    B, T, N, HS = 8, 12, 170, 10
+    M = B * T * N
+    g = torch.Generator().manual_seed(77)
+    label_ref = torch.randint(0, HS, (M,), generator=g)
+    label = label_ref.to(torch.int32).to(dev)
+    list_c = synth.class_order(HS, 9)
+    na = torch.randint(0, 8, (M,), generator=g).float() / 8 + 0.0625
+    nr = torch.randint(0, 8, (M,), generator=g).float() / 8 + 0.0625
+    words = ops.mask_ws_floats()
+    for total, frac in ((int(M * 0.25), 0.5), (int(M * 0.25), 0.93), (int(M * 0.6), 0.3), (37, 0.5)):
+        ada = int(total * frac)
+        rnd_n = total - ada
+        # the oracle's sort is unstable on ties, as the reference's: its restatement with the kernel's documented tie rule (lowest index first)
+        def drop(values, k):
+            m = torch.ones(values.numel(), dtype=torch.int64)
+            m[torch.sort(-values, stable=True)[1][:k]] = 0
+            return m
+        sel_c = torch.zeros(M, dtype=torch.int64)
+        num, i = 0, 0
+        while num < ada:
+            sel_c[label_ref == list_c[i]] = 1
+            num = int(sel_c.sum()); i += 1
+        sel_d, dnum = torch.zeros(M, dtype=torch.int64), 0
+        if ada_all and i >= 2:
+            for k in range(i - 1):
+                sel_d[label_ref == list_c[k]] = 1
+            dnum = int(sel_d.sum())
+            sel_f = (label_ref == list_c[i - 1]).long()
+        else:
+            sel_f = sel_c.clone()
+        m_ada_r = drop(sel_f.float() * na, ada - dnum) * (1 - sel_d)
+        m_rnd_r = drop(m_ada_r.float() * nr, rnd_n)
+        fin_r = m_ada_r * m_rnd_r
+        if len(torch.unique(na)) == M:                       # (never here) without ties the oracle itself must agree
+            assert torch.equal(O.adaptive_mask(label_ref.view(B, T, N), list_c, na, nr, ada, rnd_n, "all" if ada_all else "half")[2], fin_r)
+        with _mask_path(1):
+            for ws in (None, torch.zeros(words, device=dev)):
+                m_ada, m_rnd, mask = ops.mask_adaptive(label, None, torch.tensor(list_c, dtype=torch.int32, device=dev),
+                                                       torch.tensor([ada, rnd_n], dtype=torch.int32, device=dev), na.to(dev), nr.to(dev),
+                                                       ada_all, 1, ws=ws)
+                assert torch.equal(m_ada.cpu().long(), m_ada_r), (total, frac, ws is None)
+                assert torch.equal(m_rnd.cpu().long(), m_rnd_r), (total, frac, ws is None)
+                assert torch.equal(mask.cpu().long(), fin_r.view(-1)), (total, frac, ws is None)
+    noise = synth.make_noise(M, 3)
+    ref = O.random_mask(noise, 0.25)
+    with _mask_path(1):
+        got = ops.mask_random(noise.to(dev), int(M * 0.25), ws=torch.zeros(words, device=dev))
+    assert torch.equal(got.cpu().to(torch.int64), ref)
+
+
 # ---------------------------------------------------------------------------------------------------------------
 def test_small_projections():
     from gptst_amd import ops
