@@ -26,13 +26,13 @@ template <> __device__ __forceinline__ void stv<1>(float* p, float4 v) { *p = v.
 // ~50 generated-parameter problems in the forward and ~90 gradient reductions in the backward, every one of them a few microseconds
 // of work: as one launch per embedding they were ~60 launches of 4-20 us each at the head and the tail of the step (25 % of it,
 // profiles/r02b timeline); as job tables they are a handful.  The table travels in the kernel arguments (<= 4 KB).
-#define PJ_MAX 56      // 56 x 64 B of kernel arguments (limit 4 KB); a pretraining step queues 98 reductions -> 2 launches
-enum { PJ_FWD = 0, PJ_BWD_POOL = 1, PJ_BWD_EMB = 2 };
+#define PJ_MAX 112     // 112 x 64 B = 7 KB of kernel arguments (the AQL kernarg segment is not limited to 4 KB); a pretraining step queues ~100 reductions -> 1 launch
+enum { PJ_FWD = 0, PJ_BWD_POOL = 1, PJ_BWD_EMB = 2, PJ_GRAM = 3 };
 struct PJob {
     const float* emb;      // FWD / BWD_POOL: (R, K)
     const float* x;        // BWD_POOL / BWD_EMB: dW (R * nsplit, cols)
     const float* pool;     // FWD / BWD_EMB: (K, cols)
-    float* out;            // FWD: (R, cols);  BWD_POOL: dpool (K, cols) +=;  BWD_EMB: demb (R, K) +=
+    float* out;            // FWD: (R, cols);  BWD_POOL: dpool (K, cols) +=;  BWD_EMB: demb (R, K) +=;  GRAM: (R, T, T)
     int R, K, cols, nsplit;
     int blk0, kind, nbx, ldx;   // ldx: row stride of x (>= cols: x may be a column window of a wider matrix)
 };
@@ -118,6 +118,40 @@ __device__ __forceinline__ void pj_fwd_mfma(const PJob& a, int bx, int by, int r
                 if (orow < r1) st4(out + (size_t)orow * cols + c, make_float4(acc[0][r], acc[1][r], acc[2][r], acc[3][r]));
             }
         }
+    }
+}
+
+// GRAM: out[r] = A_r^T A_r (T x T, T = 12) of the per-row matrix A_r = (emb . pool)[r] viewed as (cols / 12, 12) — hyperTem's per-node
+// temporal graph G_n = A_n^T A_n (GPTST.py:156-158, tmix.hip) straight from the node embedding and the hyperedge pool, so that it does not
+// have to wait for (and be launched behind) the job that materialises A.  A workgroup takes pj_gram_rows() rows: the pool is staged in LDS,
+// the rows' A are rebuilt there with the forward job's fmaf order over k (bit-identical to reading them from its output), then reduced over
+// the hyperedges in gram_fwd's order.   blocks: ceil(R / pj_gram_rows())
+#define PJ_SCR (4 * PG_MAXK * 65)                  // floats of the kernel's LDS scratch
+__host__ __device__ inline int pj_gram_rows(int K, int cols) {
+    const int nb = (PJ_SCR - K * cols) / cols;
+    return nb > 16 ? 16 : nb;                      // <= 0: the shape does not fit (EARG)
+}
+__device__ __forceinline__ void pj_gram(const PJob& a, int bx, float* __restrict__ scr) {
+    const int K = a.K, cols = a.cols, Hm = cols / 12, NB = pj_gram_rows(K, cols);
+    float* pl = scr;                               // [K][cols]
+    float* As = scr + K * cols;                    // [NB][cols]
+    const int r0 = bx * NB, nr = min(NB, a.R - r0);
+    for (int i = threadIdx.x; i < K * cols; i += 256) pl[i] = a.pool[i];
+    __syncthreads();
+    for (int i = threadIdx.x; i < nr * cols; i += 256) {
+        const int r = i / cols, c = i % cols;
+        const float* __restrict__ e = a.emb + (size_t)(r0 + r) * K;
+        float acc = 0.f;
+        for (int k = 0; k < K; ++k) acc = fmaf(e[k], pl[k * cols + c], acc);
+        As[i] = acc;
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < nr * 144; i += 256) {
+        const int r = i / 144, t = (i % 144) / 12, u = i % 12;
+        const float* ar = As + r * cols;
+        float s = 0.f;
+        for (int h = 0; h < Hm; ++h) s = fmaf(ar[h * 12 + t], ar[h * 12 + u], s);
+        a.out[(size_t)(r0 + r) * 144 + i % 144] = s;
     }
 }
 
@@ -299,6 +333,7 @@ __global__ __launch_bounds__(256) void pool_jobs_kernel(PJobs t, int fwd_rows, i
         else if (v4) pj_fwd<4>(a, bx, by, fwd_rows, &fold[0][0][0]);
         else pj_fwd<1>(a, bx, by, fwd_rows, &fold[0][0][0]);
     }
+    else if (a.kind == PJ_GRAM) pj_gram(a, rel, &fold[0][0][0]);
     else if (a.kind == PJ_BWD_POOL) { if (v4) pj_bwd_pool<4>(a, bx, fold); else pj_bwd_pool<1>(a, bx, fold); }
     else { if (v4) pj_bwd_emb<4>(a, bx, by); else pj_bwd_emb<1>(a, bx, by); }
 }
@@ -310,6 +345,7 @@ static int pj_blocks(PJob& j) {
     const int V = ((j.cols | j.ldx) & 3) ? 1 : 4;
     if (j.kind == PJ_FWD && V == 4 && g_pg_mfma) { j.nbx = (j.cols + 255) / 256; return j.nbx * ((j.R + PG_MFMA_ROWS - 1) / PG_MFMA_ROWS); }
     if (j.kind == PJ_FWD) { j.nbx = ((j.cols + V - 1) / V + 255) / 256; return j.nbx * ((j.R + g_pg_rows - 1) / g_pg_rows); }
+    if (j.kind == PJ_GRAM) { const int nb = pj_gram_rows(j.K, j.cols); j.nbx = (j.R + nb - 1) / nb; return j.nbx; }
     if (j.kind == PJ_BWD_POOL) { j.nbx = (j.cols + 16 * V - 1) / (16 * V); return j.nbx; }
     j.nbx = (j.R + 15) / 16;
     return j.nbx * (((j.cols + 255) / 256 + 3) / 4);
@@ -320,7 +356,8 @@ static int pj_launch(PJobs& t, hipStream_t st) {
     for (int p = 0; p < t.n; ++p) {
         PJob& j = t.j[p];
         if (j.R <= 0 || j.K <= 0 || j.K > PG_MAXK || j.cols <= 0 || j.nsplit <= 0 || !j.out) return GPTST_EARG;
-        if ((j.kind == PJ_FWD || j.kind == PJ_BWD_POOL) && !j.emb) return GPTST_EARG;
+        if ((j.kind == PJ_FWD || j.kind == PJ_BWD_POOL || j.kind == PJ_GRAM) && !j.emb) return GPTST_EARG;
+        if (j.kind == PJ_GRAM && (!j.pool || j.cols % 12 || pj_gram_rows(j.K, j.cols) <= 0)) return GPTST_EARG;
         if ((j.kind == PJ_BWD_POOL || j.kind == PJ_BWD_EMB) && !j.x) return GPTST_EARG;
         if ((j.kind == PJ_FWD || j.kind == PJ_BWD_EMB) && !j.pool) return GPTST_EARG;
         j.blk0 = nb;
@@ -340,7 +377,7 @@ extern "C" int gptst_pool_jobs(int njobs, const int* kind, const void* const* em
                                const void* const* out, const int* R, const int* K, const int* cols, const int* nsplit, const int* ldx,
                                void* stream) {
     if (njobs < 0 || (njobs && (!kind || !emb || !x || !pool || !out || !R || !K || !cols || !nsplit))) return GPTST_EARG;
-    for (int p = 0; p < njobs; ++p) if (kind[p] < PJ_FWD || kind[p] > PJ_BWD_EMB) return GPTST_EARG;
+    for (int p = 0; p < njobs; ++p) if (kind[p] < PJ_FWD || kind[p] > PJ_GRAM) return GPTST_EARG;
     auto job = [&](int p) {
         return PJob{(const float*)emb[p], (const float*)x[p], (const float*)pool[p], (float*)out[p], R[p], K[p], cols[p], nsplit[p],
                     0, kind[p], 0, ldx ? ldx[p] : 0};

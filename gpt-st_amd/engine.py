@@ -354,7 +354,7 @@ def _sthcn_names(pfx):
     return [pfx + "hyperTem%d." % i for i in (1, 2, 3, 4)], [pfx + "cap1.", pfx + "cap2."]
 
 
-def _sthcn_gen_jobs(p, pfx, emb, jobs, A_all, dims):
+def _sthcn_gen_jobs(p, pfx, emb, jobs, A_all, dims, G_all=None):
     """Queue the generated-parameter problems of one STHCN (20 jobs); -> gen dict (tensors are filled by jobs.launch())."""
     B, T, N, C = dims
     time_eb, teb, tes = emb
@@ -366,6 +366,8 @@ def _sthcn_gen_jobs(p, pfx, emb, jobs, A_all, dims):
     ds, HS, HT = cadj.shape[0], cadj.shape[1], tadj.shape[1]
     for i, h in enumerate(hts):
         jobs.fwd(ne, p[h + "adj"].view(d, Hm * T), out=A_all[i])                                          # :156
+        if G_all is not None:
+            jobs.gram(ne, p[h + "adj"].view(d, Hm * T), out=G_all[i])                                     # :156-158 G_n = A_n^T A_n, same launch
     Wb = [jobs.fwd(time_eb, t) for h in hts for t in (p[h + "weights_pool"], p[h + "bias_pool"])]         # :160-161
     Wn = [jobs.fwd(nes, t) for c in cps for t in (p[c + "weights_spa"], p[c + "bias_spa"])]               # :137-138
     dadj = [jobs.fwd(teb, p[c + "adj"].view(ds, HS * N)) for c in cps]                                    # :104
@@ -404,17 +406,15 @@ def gen_all(p, tidx, dims, which=(ENC, DEC), guide=True, side=None):
         adj0 = p[which[0] + "hyperTem1.adj"]
         Hm = adj0.shape[1]
         A_all = torch.empty(L, N, Hm * T, device=tidx.device)
+        G_all = torch.empty(L, N, T, T, device=tidx.device)
         for k, pfx in enumerate(which):
-            res[pfx] = _sthcn_gen_jobs(p, pfx, embs[3 * k:3 * k + 3], jobs, A_all[4 * k:4 * k + 4], dims)
+            res[pfx] = _sthcn_gen_jobs(p, pfx, embs[3 * k:3 * k + 3], jobs, A_all[4 * k:4 * k + 4], dims, G_all[4 * k:4 * k + 4])
             res[pfx]["slot"] = (k, len(which))
+            res[pfx]["G_all"] = G_all[4 * k:4 * k + 4]
 
     def rest():
-        jobs.launch()
-        if L:
-            G_all = ops.gram_fwd(A_all.view(L * N, Hm, T)).view(L, N, T, T)
-            for k, pfx in enumerate(which):
-                res[pfx]["G_all"] = G_all[4 * k:4 * k + 4]
-            return G_all
+        jobs.launch()                                    # generated parameters AND the temporal graphs: one launch
+        return G_all if L else None
     if split:
         with side.fork():
             G_all = rest()

@@ -126,8 +126,8 @@ def poolgen_bwd_emb_multi(dWs, pools, demb, nsplits=None):
 
 class PoolJobs:
     """A list of independent poolgen problems (forward generation and/or gradient reductions, each with its own embedding) that
-    run as ONE launch per 56 jobs (gptst_pool_jobs).  Tensors are kept referenced until launch()."""
-    FWD, BWD_POOL, BWD_EMB = 0, 1, 2
+    run as ONE launch per 112 jobs (gptst_pool_jobs).  Tensors are kept referenced until launch()."""
+    FWD, BWD_POOL, BWD_EMB, GRAM = 0, 1, 2, 3
 
     def __init__(self):
         self.jobs = []
@@ -139,6 +139,15 @@ class PoolJobs:
         if out is None:
             out = torch.empty((R,) + tuple(pool.shape[1:]), device=emb.device, dtype=torch.float32)
         self.jobs.append((self.FWD, emb, None, pool, out, R, K, pool.numel() // K, 1, 0))
+        return out
+
+    def gram(self, emb, pool, out):
+        """out (R,12,12) = A_r^T A_r, A_r = (emb @ pool)[r] viewed (cols/12, 12) — hyperTem's temporal graph (= gram_fwd of the fwd() job's output)"""
+        _chk(emb, pool, out)
+        R, K = emb.shape
+        cols = pool.numel() // K
+        assert cols % 12 == 0 and out.numel() == R * 144 and out.is_contiguous()
+        self.jobs.append((self.GRAM, emb, None, pool, out, R, K, cols, 1, 0))
         return out
 
     @staticmethod

@@ -47,7 +47,7 @@ int gptst_poolgen_bwd_pool(const float* emb, const float* dW, float* dpool, int 
 int gptst_poolgen_bwd_emb(const float* dW, const float* pool, int cols, const float* dW2, const float* pool2, int cols2,
                           float* demb, int R, int nsplit, int K, void* stream);
 
-/* multi-problem forms (<= 56 problems sharing emb; host arrays of device pointers, read at call time): one launch generates /
+/* multi-problem forms (<= 112 problems sharing emb; host arrays of device pointers, read at call time): one launch generates /
  * reduces the generated parameters of several layers (every launch has a ~4-5 us floor on MI355X). */
 int gptst_poolgen_fwd_multi(const float* emb, int nprob, const void* pools, const void* outs, const int* cols, int R, int K,
                             void* stream);
@@ -56,10 +56,12 @@ int gptst_poolgen_bwd_pool_multi(const float* emb, int nprob, const void* dWs, c
 int gptst_poolgen_bwd_emb_multi(int nprob, const void* dWs, const void* pools, const int* cols, const int* nsplit, float* demb, int R,
                                 int K, void* stream);
 
-/* Job table: njobs independent problems of ANY kind, each with its own embedding and shapes, in ceil(njobs / 56) launches
+/* Job table: njobs independent problems of ANY kind, each with its own embedding and shapes, in ceil(njobs / 112) launches
  * (host arrays, read at call time).  kind 0: out (R,cols) = emb (R,K) . pool (K,cols);  kind 1: out = dpool (K,cols) += sum_rr
  * emb[rr % R,:]^T x[rr,:], rr < R*nsplit — owned by ONE workgroup per element (no atomics: two kind-1 jobs of one call must
  * not share `out`);  kind 2: out = demb (R,K) += (sum_s x[s*R + r,:]) . pool^T (atomic: several jobs may add into one demb).
+ * kind 3: out (R,12,12) = A_r^T A_r with A_r = (emb . pool)[r] viewed as (cols/12, 12): hyperTem's per-node temporal graph (what
+ * gptst_gram_fwd computes from a materialised A; bit-identical to it) without a launch of its own.
  * ldx[j]: row stride of x in floats (0 = cols) — a job may read a column window of a wider matrix.
  * Unused pointers of a kind may be NULL.  A whole pretraining step needs 3 calls (forward generation, two backward reductions)
  * where per-embedding launches needed ~50. */

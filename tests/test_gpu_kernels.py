@@ -556,6 +556,23 @@ def test_pool_jobs_mixed_table(det):
         close(got, ref, what=what)
 
 
+@pytest.mark.parametrize("N,d,Hm", [(170, 16, 8), (33, 4, 5), (1, 1, 1), (300, 8, 16)])
+def test_pool_jobs_gram_kind_is_bitwise_gram_of_the_generated_factor(N, d, Hm):
+    """Job kind 3 of gptst_pool_jobs: G_n = A_n^T A_n straight from (node embedding, hyperedge pool), in the SAME launch as the job that
+    materialises A — bit-identical to gptst_gram_fwd of that job's output (same fmaf orders), and close to the fp64 product."""
+    from gptst_amd import ops
+    dev = _dev()
+    g = torch.Generator().manual_seed(N + d)
+    ne, adj = rnd(N, d, g=g), rnd(d, Hm, 12, g=g)
+    J = ops.PoolJobs()
+    A = J.fwd(ne.to(dev), adj.to(dev).view(d, Hm * 12))
+    G = J.gram(ne.to(dev), adj.to(dev).view(d, Hm * 12), torch.empty(N, 12, 12, device=dev))
+    J.launch()
+    assert torch.equal(G, ops.gram_fwd(A.view(N, Hm, 12)))
+    Ad = torch.einsum("nd,dht->nht", ne.double(), adj.double())
+    close(G, torch.einsum("nht,nhu->ntu", Ad, Ad).float(), what="gram job")
+
+
 def test_timefeat_jobs_equal_single_launches():
     from gptst_amd import ops
     dev = _dev()
