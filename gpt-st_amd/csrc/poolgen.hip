@@ -10,6 +10,8 @@
 // when few land on the same address (a same-address atomic serialises at ~80 ns) and when there are few of them overall —
 // so each output element is owned by one thread (or a handful of row chunks), never by hundreds of workgroups.
 #include "common.h"
+#include <algorithm>
+#include <vector>
 
 #define PG_MAXK 16
 #define PG_MFMA_ROWS 64 // rows per block of the MFMA forward (four 16-row tiles per wave and B-fragment load)
@@ -340,6 +342,7 @@ __global__ __launch_bounds__(256) void pool_jobs_kernel(PJobs t, int fwd_rows, i
 
 // Host side: fill one job and its block range; returns the number of blocks.
 thread_local int g_pg_rows = PG_ROWS;            // experiments: gptst_tune(1, rows)
+thread_local int g_pg_sort = 1;                  // gptst_tune(19, 0): keep the caller's job order
 thread_local int g_pg_mfma = 1;                  // gptst_tune(10, 0): VALU forward instead of the MFMA one
 static int pj_blocks(PJob& j) {
     const int V = ((j.cols | j.ldx) & 3) ? 1 : 4;
@@ -383,8 +386,20 @@ extern "C" int gptst_pool_jobs(int njobs, const int* kind, const void* const* em
                     0, kind[p], 0, ldx ? ldx[p] : 0};
     };
     const bool det = g_deterministic != 0;
+    // Workgroups are dispatched in table order: the jobs whose workgroups stream the most bytes go first, so that the launch does not end
+    // with a few long workgroups on an otherwise idle chip (the jobs of a call are independent: any order gives the same result).
+    std::vector<int> ord(njobs);
+    std::vector<long> cost(njobs);
+    for (int p = 0; p < njobs; ++p) {
+        ord[p] = p;
+        const long rr = (long)R[p] * nsplit[p], cc = cols[p];
+        cost[p] = kind[p] == PJ_BWD_POOL ? rr * (cc < 64 ? cc : 64) : kind[p] == PJ_BWD_EMB ? 16L * nsplit[p] * (cc < 1024 ? cc : 1024)
+                : kind[p] == PJ_FWD ? 64L * (cc < 256 ? cc : 256) : 1L;
+    }
+    if (g_pg_sort) std::stable_sort(ord.begin(), ord.end(), [&](int a, int b) { return cost[a] > cost[b]; });
     PJobs t; t.n = 0;
-    for (int p = 0; p < njobs; ++p) {                            // table launches (in deterministic mode: everything but the kind-2 jobs)
+    for (int o = 0; o < njobs; ++o) {                            // table launches (in deterministic mode: everything but the kind-2 jobs)
+        const int p = ord[o];
         if (det && kind[p] == PJ_BWD_EMB) continue;
         t.j[t.n++] = job(p);
         if (t.n == PJ_MAX) { const int rc = pj_launch(t, (hipStream_t)stream); if (rc) return rc; t.n = 0; }
@@ -423,6 +438,7 @@ extern thread_local int g_ht_fwd12;
 extern thread_local int g_tl_mfma;
 extern "C" int gptst_tune(int id, int value) {
     if (id == 15) g_tl_mfma = value;
+    if (id == 19) g_pg_sort = value;
     if (id == 12) g_ht_fwd12 = value;
     if (id == 1 && value > 0 && value <= PG_MAXROWS) g_pg_rows = value;
     if (id == 6 && value > 0) g_tl_nb = value;
