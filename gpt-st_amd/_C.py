@@ -9,7 +9,7 @@ import re
 import torch  # noqa: F401  (loads libamdhip64 first)
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(HERE, "lib", "libgptst_hip.so")
+LIB_PATH = os.environ.get("GPTST_LIB") or os.path.join(HERE, "lib", "libgptst_hip.so")     # GPTST_LIB: another build of the library (A/B runs on one box)
 HEADER = os.path.join(os.path.dirname(HERE), "include", "gptst_hip.h")
 
 _CT = {"int": ctypes.c_int, "long": ctypes.c_long, "float": ctypes.c_float, "double": ctypes.c_double,

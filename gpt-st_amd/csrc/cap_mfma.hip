@@ -144,9 +144,10 @@ __device__ __forceinline__ void cm_softmax(const float* __restrict__ bl, float* 
 }
 
 // consume S: post 0 -> dst_global[h*C+c] = S;  1 -> Vdst = squash(S);  2 -> Vdst = squash(V0 (.) S)
+// sreg != NULL: the thread's S values come from a register (first routing pass, see cap_route_fwd2_kernel; needs HS * C / 4 <= CM_NT)
 template <int C>
 __device__ __forceinline__ void cm_post(const float* __restrict__ S, const float* __restrict__ V0s, float* __restrict__ Vdst,
-                                        float* __restrict__ gdst, int HS, int post) {
+                                        float* __restrict__ gdst, int HS, int post, const float4* sreg = nullptr) {
     constexpr int P = Tile<C>::PITCH, LPR = C / 4;
     for (int base = 0; base < HS * LPR; base += CM_NT) {
         const int pair = base + threadIdx.x;
@@ -154,7 +155,7 @@ __device__ __forceinline__ void cm_post(const float* __restrict__ S, const float
         const int h = valid ? pair / LPR : 0, c4 = pair % LPR;
         float4 v = f4zero();
         if (valid) {
-            v = ld4(S + h * C + 4 * c4);
+            v = sreg ? *sreg : ld4(S + h * C + 4 * c4);
             if (post == 2) { const float4 m = ld4(V0s + h * P + 4 * c4); v = make_float4(v.x * m.x, v.y * m.y, v.z * m.z, v.w * m.w); }
         }
         if (post != 0) {
@@ -240,6 +241,10 @@ __global__ __launch_bounds__(CM_NT, 4) void cap_route_fwd2_kernel(const float* _
     const float* l0g = dadj + (size_t)bt * HS * N;
     float l0r[SU];
     cm_softmax_preload<SL, SU>(l0r, l0g, N, HS);                   // in flight during the capsule GEMM
+    // First routing pass: b = 0 (GPTST.py:112), so c = softmax_h(0) = 1/HS for every node and s[h] = v0[h] (.) (1/HS) sum_n P[n]: no
+    // softmax, no contraction — the column sums of P fall out of the capsule GEMM's epilogue.
+    const bool uni = C == 64 && R > 0 && HS * LPR <= CM_NT;
+    float4 u0 = f4zero();
 
     if constexpr (C == 64) {
         // ---- P = squash(X Wp^T + bp): 16-row tiles, register operands, squash fused into the MFMA epilogue (row norm = 16-lane
@@ -253,6 +258,7 @@ __global__ __launch_bounds__(CM_NT, 4) void cap_route_fwd2_kernel(const float* _
         __syncthreads(); TS();
         float4 bv[4][4];
         cm_load_bfrag(bv, Wl, j, kk);
+        float4 csum = f4zero();                                    // column sums of this wave's rows of P (first routing pass, below)
         for (int tile = wave; tile < NR / 16; tile += CM_NW) {
             if (tile != wave) cm_fetch_a16(a, Xbt, tile, N, j, kk);
             float4 y[4];
@@ -262,12 +268,31 @@ __global__ __launch_bounds__(CM_NT, 4) void cap_route_fwd2_kernel(const float* _
                 const int n = tile * 16 + kk * 4 + r;
                 float4 v = n < N ? y[r] : f4zero();
                 const float sc = squash_scale(group_sum<16>(f4dot(v, v)));
-                st4(Ps + n * P + 4 * j, make_float4(v.x * sc, v.y * sc, v.z * sc, v.w * sc));
+                v = make_float4(v.x * sc, v.y * sc, v.z * sc, v.w * sc);
+                st4(Ps + n * P + 4 * j, v);
+                csum = f4add(csum, v);
             }
         }
+        if (uni) {                                                 // S rows 0..7 <- the waves' partial column sums (S is first written by c0 . P)
+            csum.x += __shfl_xor(csum.x, 16); csum.y += __shfl_xor(csum.y, 16); csum.z += __shfl_xor(csum.z, 16); csum.w += __shfl_xor(csum.w, 16);
+            csum.x += __shfl_xor(csum.x, 32); csum.y += __shfl_xor(csum.y, 32); csum.z += __shfl_xor(csum.z, 32); csum.w += __shfl_xor(csum.w, 32);
+            if (kk == 0) st4(S + wave * 64 + 4 * j, csum);
+        }
         __syncthreads(); TS();                                     // all B fragments are in registers: Wl may be recycled
-        for (int i = tid; i < (HS + HSP) * NP; i += CM_NT) bl[i] = 0.f;
-        __syncthreads(); TS();
+        // b = 0 and the padding of c (rows >= HS, columns >= N) — the cells the softmax below writes are left alone, so that it needs no
+        // barrier in between
+        for (int i = tid; i < (HS + HSP) * NP; i += CM_NT) {
+            const int hc = i / NP - HS, n = i % NP;
+            if (hc < 0 || hc >= HS || n >= N) bl[i] = 0.f;
+        }
+        if (uni && tid < HS * LPR) {                               // this thread's (h, 4 channels) of the first routing pass: (1/HS) sum_n P[n]
+            const int c4 = tid % LPR;
+#pragma unroll
+            for (int w = 0; w < CM_NW; ++w) u0 = f4add(u0, ld4(S + w * 64 + 4 * c4));       // fixed order
+            const float inv = 1.f / (float)HS;
+            u0 = make_float4(u0.x * inv, u0.y * inv, u0.z * inv, u0.w * inv);
+        }
+        TS();
     } else {
     float4 xv[T::F4_PER_LANE];              // this wave's X tile: requested before the weight is staged (one batch, clamped rows)
     cm_fetch_x<C>(xv, Xbt, wave, N, lane);
@@ -341,6 +366,11 @@ __global__ __launch_bounds__(CM_NT, 4) void cap_route_fwd2_kernel(const float* _
     __syncthreads(); TS();
     for (int r = 0; r < R; ++r) {                                                       // routing (no grad)          :113-118
         if (r > 0) { cm_type2<C>(Ps, Vs, bl, N, NP, HS, HSP); __syncthreads(); TS(); }        // b += v . P^T
+        if (r == 0 && uni) {
+            cm_post<C>(S, V0s, Vs, nullptr, HS, 2, &u0);                                // v = squash(v0 (.) mean-over-classes . P)
+            __syncthreads(); TS();
+            continue;
+        }
         cm_softmax<SL, SU>(bl, cs, l0g, nullptr, N, NP, HS, true, false);   // c = softmax_h(b)
         __syncthreads(); TS();
         cm_type1<C>(Ps, cs, S, N, NP, HSP);
