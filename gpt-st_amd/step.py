@@ -362,6 +362,8 @@ class PretrainStep:
     def group_ok(self, epoch):
         """A group runs as one graph when the whole step is one graph (no host-side collective inside the step)."""
         phase = 0 if epoch <= self.args.change_epoch else 1
+        if getattr(self, "_group_failed", False):
+            return False
         return self.use_graph and (self.dp is None or self._dp_in_graph()) and not (self._needs_exchange(phase) and not self._dp_in_graph())
 
     def _group_init(self, K):
@@ -405,6 +407,22 @@ class PretrainStep:
         for j, src in enumerate(sources):
             if src is not self._g_src[j]:
                 self._g_src[j].copy_(src, non_blocking=True)
+        if phase not in self._g_graphs:
+            # capture BEFORE any per-step state is advanced: if the runtime cannot record this group (e.g. collectives of K steps in one
+            # graph), every rank fails alike, the group falls back to K single steps and later groups do not try again
+            keep = (self.src, self.stats_out, self.hyper, self.ctrl, self.rng_words)
+            try:
+                self._capture_group(phase, K, epoch)
+            except Exception as e:                                    # noqa: BLE001
+                import sys
+                print("gpt-st_amd: capturing %d steps in one graph failed (%s: %s) -> one replay per step"
+                      % (K, type(e).__name__, str(e).splitlines()[0][:200] if str(e) else ""), file=sys.stderr)
+                self._group_failed = True
+                torch.cuda.synchronize()
+            finally:
+                self.src, self.stats_out, self.hyper, self.ctrl, self.rng_words = keep
+            if getattr(self, "_group_failed", False):
+                return self.step_group(sources, epoch, list_cs)
         sl = self._g_ring[self._g_ring_i]
         self._g_ring_i = (self._g_ring_i + 1) % self.RING
         if sl["ev"] is not None:
@@ -415,18 +433,20 @@ class PretrainStep:
         if sl["ev"] is None:
             sl["ev"] = torch.cuda.Event()
         sl["ev"].record()
-        keep = (self.src, self.stats_out, self.hyper, self.ctrl, self.rng_words)
-        try:
-            if phase not in self._g_graphs:
-                self._capture_group(phase, K)
-            self._g_graphs[phase].replay()
-        finally:
-            self.src, self.stats_out, self.hyper, self.ctrl, self.rng_words = keep
+        self._g_graphs[phase].replay()
         self._g_last = (K, phase)
 
-    def _capture_group(self, phase, K):
+    def _capture_group(self, phase, K, epoch):
         self.inject_noise, self.force_mask = False, False
         keep = (self.model.flat.clone(), self.m.clone(), self.v.clone())
+        # the warm-up runs need plausible host scalars in the device table: fill it as the first group would, then put the counters back
+        st = (self.tA, self.tB, self.phase_kl, self.rng.getstate())
+        for j in range(K):
+            self._fill(self._g_ring[0]["rows"][j], phase, epoch, None)
+        self._g_hc.copy_(self._g_ring[0]["hc"])
+        torch.cuda.synchronize()
+        self.tA, self.tB, self.phase_kl = st[:3]
+        self.rng.setstate(st[3])
         s = torch.cuda.Stream()
         s.wait_stream(torch.cuda.current_stream())
         with torch.cuda.stream(s):                      # warm-up on a side stream (allocator, lazy kernel attributes)

@@ -282,3 +282,27 @@ def test_step_group_equals_single_steps():
     # a single step after a group continues the same sequence
     st.step(srcs[0], 5, list_c=orders[0])
     assert st.losses()[0] > 0
+
+
+def test_step_group_falls_back_to_single_steps_when_the_capture_fails(monkeypatch):
+    """A runtime that cannot record K steps in one graph (e.g. collectives) raises at capture time: the group then runs as K single steps —
+    counters not advanced twice, later groups do not retry — and gives the results of K step() calls."""
+    from gptst_amd.model import GPTST_Model
+    from gptst_amd.step import PretrainStep
+    args = _args()
+    sd = O.init_state_dict(args, 2)
+    srcs = [synth.make_batch(4, 12, 20, 1, seed=950 + i).to(DEV) for i in range(4)]
+    outs = []
+    for broken in (False, True):
+        model = GPTST_Model(args); model.load_state_dict(sd); model = model.to(DEV)
+        st = PretrainStep(model, args, synth.SCALER_MEAN, synth.SCALER_STD, batch_size=4, use_graph=True, deterministic=True)
+        if broken:
+            def boom(*a, **k):
+                raise RuntimeError("operation not permitted when stream is capturing")
+            monkeypatch.setattr(st, "_capture_group", boom)
+        st.step_group(srcs, 2)
+        st.step_group(srcs, 2)
+        assert st.tA == 8 and bool(getattr(st, "_group_failed", False)) == broken
+        outs.append((model.flat.clone(), st.losses()))
+    assert outs[0][1] == outs[1][1]
+    assert torch.equal(outs[0][0], outs[1][0])
