@@ -402,7 +402,7 @@ def main():
                  ("c-abi rccl, captured in the step graph" if (a.native_comm and not getattr(stepper, "_graph_comm_failed", False)) else
                   ("c-abi rccl between graph replays (capturing the collectives failed)" if a.native_comm else "torch.distributed between graph replays"))),
         "graph": bool(getattr(stepper, "shard_graph", False)) if a.shard == "nodes" else not a.no_graph,
-        "steps_per_graph_replay": G,
+        "steps_per_graph_replay": 1 if getattr(stepper, "_group_failed", False) else G,
         "hbm_peak_gb": round(torch.cuda.max_memory_allocated() / 2**30, 2),
         "alloc_retries": int(torch.cuda.memory_stats().get("num_alloc_retries", 0)),
     }

@@ -419,6 +419,7 @@ class PretrainStep:
                       % (K, type(e).__name__, str(e).splitlines()[0][:200] if str(e) else ""), file=sys.stderr)
                 self._group_failed = True
                 torch.cuda.synchronize()
+                torch.cuda.empty_cache()
             finally:
                 self.src, self.stats_out, self.hyper, self.ctrl, self.rng_words = keep
             if getattr(self, "_group_failed", False):
@@ -449,12 +450,23 @@ class PretrainStep:
         self.rng.setstate(st[3])
         s = torch.cuda.Stream()
         s.wait_stream(torch.cuda.current_stream())
+        torch.cuda.synchronize()
+        base = torch.cuda.memory_allocated()
+        torch.cuda.reset_peak_memory_stats()
         with torch.cuda.stream(s):                      # warm-up on a side stream (allocator, lazy kernel attributes)
             for j in range(min(K, 2)):
                 self._sub(j)
                 self._body(phase)
         torch.cuda.current_stream().wait_stream(s)
         torch.cuda.synchronize()
+        # Activations of the K sub-steps are NOT shared inside one capture (the graph-private pool grew K-fold at N = 4096, C = 128:
+        # 4 x 56 GB): groups are for the shapes where the idle time between replays matters, i.e. small steps
+        per_step = torch.cuda.max_memory_allocated() - base
+        free = torch.cuda.mem_get_info()[0]
+        if per_step * K > 0.4 * free:
+            self.model.flat.copy_(keep[0]); self.m.copy_(keep[1]); self.v.copy_(keep[2])
+            torch.cuda.synchronize()
+            raise RuntimeError("a group of %d steps would need ~%.0f GB of activations (%.0f GB free)" % (K, per_step * K / 2**30, free / 2**30))
         ops.set_deterministic(self.deterministic)
         try:
             g = torch.cuda.CUDAGraph()
