@@ -41,6 +41,41 @@ __global__ __launch_bounds__(256) void lin_in_kernel(const float* __restrict__ a
     }
 }
 
+// J <= 2 (the input projections of the step: J = input_base_dim): the weight columns live in registers (no LDS staging, no barrier), a
+// workgroup takes 4 x (256 / (C/4)) rows and issues every a / mask load before the first store (one round trip per workgroup instead of
+// weight round trip -> barrier -> operand round trip -> store for 16 rows).  Same arithmetic order as lin_in_kernel.
+template <int C, int JJ>
+__global__ __launch_bounds__(256) void lin_in_small_kernel(const float* __restrict__ a, int lda, const float* __restrict__ mask, float fill,
+                                                           const float* __restrict__ W, int wlayout, const float* __restrict__ b,
+                                                           float* __restrict__ Y, int rows) {
+    constexpr int LPR = C / 4, RPB = 256 / LPR, U = 4;
+    const int c4 = threadIdx.x % LPR, r = threadIdx.x / LPR;
+    float4 w[JJ];
+#pragma unroll
+    for (int j = 0; j < JJ; ++j)
+        w[j] = wlayout ? ld4(W + j * C + 4 * c4)
+                       : make_float4(W[(4 * c4) * JJ + j], W[(4 * c4 + 1) * JJ + j], W[(4 * c4 + 2) * JJ + j], W[(4 * c4 + 3) * JJ + j]);
+    const float4 b4 = b ? ld4(b + 4 * c4) : f4zero();
+    const size_t i0 = (size_t)blockIdx.x * RPB * U + r;
+    float av[U][JJ], mv[U][JJ];
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+        const size_t i = min(i0 + (size_t)u * RPB, (size_t)rows - 1);
+#pragma unroll
+        for (int j = 0; j < JJ; ++j) { av[u][j] = a[i * lda + j]; mv[u][j] = mask ? mask[i * JJ + j] : 1.f; }
+    }
+    SB();
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+        const size_t i = i0 + (size_t)u * RPB;
+        if (i >= (size_t)rows) break;
+        float4 acc = b4;
+#pragma unroll
+        for (int j = 0; j < JJ; ++j) acc = f4fma(mv[u][j] != 0.f ? av[u][j] : fill, w[j], acc);
+        st4(Y + i * C + 4 * c4, acc);
+    }
+}
+
 // Z[i,j] = X[i,:].W[j,:] + b[j];  softmax over j when do_softmax.  C/4 lanes per row, butterfly reduce.
 template <int C, bool LOOP>
 __global__ __launch_bounds__(256) void rowdot_kernel(const float* __restrict__ X, const float* __restrict__ W, const float* __restrict__ b,
@@ -258,7 +293,15 @@ extern "C" int gptst_lin_in(const float* a, int lda, const float* mask, float fi
                             float* Y, int rows, int J, int C, void* stream) {
     if (!a || !W || !Y || J <= 0 || J > SM_MAXJ) return GPTST_EARG;
     hipStream_t st = (hipStream_t)stream;
-    if (C == 64) hipLaunchKernelGGL((lin_in_kernel<64>), dim3(sm_grid(rows, 16)), dim3(256), 0, st, a, lda, mask, fill, W, wlayout, b, Y, rows, J);
+    if ((C == 64 || C == 128) && J <= 2) {
+        const int rpb = 4 * 256 / (C / 4);
+        const dim3 g((rows + rpb - 1) / rpb);
+        if (C == 64 && J == 1) hipLaunchKernelGGL((lin_in_small_kernel<64, 1>), g, dim3(256), 0, st, a, lda, mask, fill, W, wlayout, b, Y, rows);
+        else if (C == 64) hipLaunchKernelGGL((lin_in_small_kernel<64, 2>), g, dim3(256), 0, st, a, lda, mask, fill, W, wlayout, b, Y, rows);
+        else if (J == 1) hipLaunchKernelGGL((lin_in_small_kernel<128, 1>), g, dim3(256), 0, st, a, lda, mask, fill, W, wlayout, b, Y, rows);
+        else hipLaunchKernelGGL((lin_in_small_kernel<128, 2>), g, dim3(256), 0, st, a, lda, mask, fill, W, wlayout, b, Y, rows);
+    }
+    else if (C == 64) hipLaunchKernelGGL((lin_in_kernel<64>), dim3(sm_grid(rows, 16)), dim3(256), 0, st, a, lda, mask, fill, W, wlayout, b, Y, rows, J);
     else if (C == 128) hipLaunchKernelGGL((lin_in_kernel<128>), dim3(sm_grid(rows, 8)), dim3(256), 0, st, a, lda, mask, fill, W, wlayout, b, Y, rows, J);
     else return GPTST_ESHAPE;
     GPTST_CHECK_LAUNCH();
