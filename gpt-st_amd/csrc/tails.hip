@@ -181,6 +181,15 @@ __global__ __launch_bounds__(256) void tail64_mfma_kernel(TailArgs t) {
             if (KIND == 0) xa[q] = ld4(t.X + min(tb + j, r1 - 1) * C + 16 * q + 4 * kk);
             xd[q] = ld4(t.X + min(tb + 4 * kk + q, r1 - 1) * C + 4 * j);
         }
+        // the epilogue's per-row operands travel with the X tile (after the MFMAs they were a second, dependent round trip per tile)
+        float o0[4], o1[4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const size_t i = min(tb + 4 * kk + r, r1 - 1);
+            const int jc = min(j, J - 1);
+            if (KIND == 0) { o0[r] = t.mask[i * J + jc]; o1[r] = t.src[i * t.lda + jc]; }
+            else { const size_t bt = i / t.N, n = i % t.N; o0[r] = t.c[(bt * J + jc) * t.N + n]; o1[r] = t.prob[i * J + jc]; }
+        }
         SB();
         float a[4];
         if (KIND == 0) {
@@ -199,9 +208,9 @@ __global__ __launch_bounds__(256) void tail64_mfma_kernel(TailArgs t) {
                 if (i < r1 && j < J) {
                     const float o = acc0[r] + acc1[r] + bj;
                     const size_t e = i * J + j;
-                    const float M = 1.f - t.mask[e];
+                    const float M = 1.f - o0[r];
                     const float p = (o * t.sigma + t.mu) * M;
-                    const float y = (t.src[i * t.lda + j] * t.sigma + t.mu) * M;
+                    const float y = (o1[r] * t.sigma + t.mu) * M;
                     if (y > t.thresh) {
                         const float d = p - y;
                         s0 += fabsf(d); s1 += 1.f;
@@ -216,7 +225,7 @@ __global__ __launch_bounds__(256) void tail64_mfma_kernel(TailArgs t) {
                 const size_t i = tb + 4 * kk + r;
                 const bool ok = i < r1 && j < J;
                 float e_ = 0.f, p_ = 1.f;
-                if (ok) { const size_t bt = i / t.N, n = i % t.N; e_ = t.c[(bt * J + j) * t.N + n]; p_ = t.prob[i * J + j]; }
+                if (ok) { e_ = o0[r]; p_ = o1[r]; }
                 const float se = group_sum<16>(e_);
                 if (ok && e_ > 0.f) s0 += e_ * (logf(e_) - logf(p_));
                 a[r] = ok ? t.w * (p_ * se - e_) : 0.f;
