@@ -202,12 +202,18 @@ def hypertem_core_fwd(x, G, Wbt, bbt, dims):
         keep = not (DROP_R and _ht_fused_bwd(dims) and ops.wgrad_nsplit(MODE_TIME, B * T, N, C) == 1)
         R, out = ops.hypertem_fwd(x.view(B, T, N, C), G, Wbt, bbt, want_R=keep)         # :157-158 + :162-163 fused
         R, out = (R.view(-1, C) if keep else None), out.view(-1, C)
+    elif C == 128 and HT128_FUSED:
+        R, out = ops.hypertem_fwd(x.view(B, T, N, C), G, Wbt, bbt, want_R=True)         # the same fusion at C = 128 (hypertem_fwd128_kernel)
+        R, out = R.view(-1, C), out.view(-1, C)
     else:
         R = ops.tmix(x.view(B, T, N, C), G).view(-1, C)                                 # :157-158
         out = ops.apply(R, Wbt, MODE_TIME, B * T, N, bias=bbt, resid=x, epi=EPI_RES_LRELU)  # :162-163
     return out, (x, R, out, G, Wbt)
 
 
+# C = 128: slab-fused hyperTem forward (hypertem_fwd128_kernel) instead of tmix + apply128.  Built and parity-tested, but measured SLOWER at
+# N = 4096, B = 32 (1086 vs 285 + 587 us per layer: one 101 KB slab per CU, nothing overlaps the staging): opt-in.
+HT128_FUSED = os.environ.get("GPTST_HT128_FUSED", "0") == "1"
 FUSE_HT_BWD = True         # hyperTem backward + its weight gradient in one launch (False: two launches)
 
 

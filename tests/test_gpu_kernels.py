@@ -161,6 +161,35 @@ def _hypertem_case(B, N, C, d, Hm, seed):
     return [x, ne, te, adj, wp, bp], go
 
 
+@pytest.mark.parametrize("B,N", [(2, 20), (3, 170), (9, 33), (1, 300)])
+def test_hypertem_fwd_c128_fused(B, N):
+    """C = 128 fused hyperTem forward (hypertem_fwd128_kernel): R = G_n X and out = LReLU(R W_bt + b_bt + X) against fp64, and against
+    the two-kernel form it replaces (tmix + apply128<TIME>); ragged node tiles, B not a multiple of the 8 XCDs."""
+    from gptst_amd import ops
+    dev = _dev()
+    C, T = 128, 12
+    g = torch.Generator().manual_seed(B * 1000 + N)
+    X = rnd(B, T, N, C, g=g)
+    A = rnd(N, 6, T, g=g, scale=0.4)
+    G = torch.einsum("nht,nhu->ntu", A, A)
+    W = rnd(B * T, C, C, g=g, scale=0.1)
+    bb = rnd(B * T, C, g=g, scale=0.3)
+    Rr = torch.einsum("ntu,bunc->btnc", G.double(), X.double())
+    pre = torch.einsum("btnc,btcd->btnd", Rr, W.double().view(B, T, C, C)) + bb.double().view(B, T, 1, C) + X.double()
+    ref = torch.where(pre > 0, pre, 0.01 * pre)
+    Xd, Gd, Wd, bd = X.to(dev), G.to(dev), W.to(dev), bb.to(dev)
+    R, out = ops.hypertem_fwd(Xd, Gd, Wd, bd, want_R=True)
+    close(R, Rr.float(), what="R (c128)")
+    ok = pre.abs() > 1e-4                      # a pre-activation within fp32 noise of 0 may pick the other LReLU slope
+    close(out.cpu() * ok, (ref * ok).float(), what="out (c128)")
+    R2 = ops.tmix(Xd, Gd)
+    out2 = ops.apply(R2.view(-1, C), Wd, ops.MODE_TIME, B * T, N, bias=bd, resid=Xd.view(-1, C), epi=ops.EPI_RES_LRELU)
+    assert torch.equal(R, R2), "R differs from tmix"
+    close(out.view(-1, C), out2, what="out vs tmix + apply128")
+    out3 = ops.hypertem_fwd(Xd, Gd, Wd, bd, want_R=False)[1]
+    assert torch.equal(out3, out)
+
+
 @pytest.mark.parametrize("B,N,d,Hm", [(2, 20, 8, 8), (3, 170, 16, 8), (1, 33, 4, 5)])
 def test_hypertem_layer(B, N, d, Hm):
     from gptst_amd import layers
