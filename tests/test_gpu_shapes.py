@@ -30,6 +30,10 @@ CASES = {
     "c128_rand": dict(ds="NYC_TAXI", over=dict(hidden_dim=128, num_nodes=23, embed_dim=4), B=1, epoch=2),
     "n600": dict(ds="PEMS08", over=dict(num_nodes=600, embed_dim=8), B=1, epoch=100),                 # capsule matrix beyond LDS: capbig path
     "n260_c128": dict(ds="PEMS08", over=dict(num_nodes=260, hidden_dim=128, embed_dim=8), B=1, epoch=100),   # config-5 style (C = 128)
+    # BASELINE configs[4] at its FULL size (N = 4096, C = 128, d = 16, HS = 10; one sample): streaming cap, apply128 / wgrad128 / tmix
+    # kernels against the oracle's forward, loss and every gradient (the oracle needs ~10 s of CPU for it with materialize_5d=False)
+    # Reference in fp64: at this size the fp32 ORACLE's own gradient of encoder.neb4mask is 1.2e-3 off its fp64 run (4096-node sums).
+    "c5_full_n4096_c128": dict(ds="PEMS08", over=dict(num_nodes=4096, hidden_dim=128), B=1, epoch=100, f64=True),
 }
 
 
@@ -47,10 +51,13 @@ def test_model_vs_oracle(name, parity):
         inj = dict(noise=synth.make_noise(M * base, 5))
     else:
         inj = dict(noise_a=synth.make_noise(M, 5), noise_r=synth.make_noise(M, 6), list_c=synth.class_order(HS, 3))
-    st = O.Stepper(sd, args, synth.SCALER_MEAN, synth.SCALER_STD, materialize_5d=False)
-    outs_r, aux = O.forward_pretrain(st.sd, args, src, epoch, materialize_5d=False, **inj)
-    loss_r, lf_r, ls_r = O.pretrain_loss(outs_r, src, args, epoch, synth.SCALER_MEAN, synth.SCALER_STD)
+    rdt = torch.float64 if c.get("f64") else torch.float32
+    cast = lambda v: v.to(rdt) if torch.is_tensor(v) and v.dtype.is_floating_point else v      # noqa: E731
+    st = O.Stepper({k: cast(v) for k, v in sd.items()}, args, synth.SCALER_MEAN, synth.SCALER_STD, materialize_5d=False)
+    outs_r, aux = O.forward_pretrain(st.sd, args, cast(src), epoch, materialize_5d=False, **{k: cast(v) for k, v in inj.items()})
+    loss_r, lf_r, ls_r = O.pretrain_loss(outs_r, cast(src), args, epoch, synth.SCALER_MEAN, synth.SCALER_STD)
     loss_r.backward()
+    outs_r = tuple(o.float() if torch.is_tensor(o) and o.dtype == torch.float64 else o for o in outs_r)
 
     model = GPTST_Model(args)
     model.load_state_dict(sd)

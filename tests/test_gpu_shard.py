@@ -118,7 +118,8 @@ def test_node_shards_equal_unsharded_step(W, N, B, over, parity):
 
 def test_config4_full_size_properties(parity):
     """BASELINE configs[4] at full size (N = 4096, C = 128, B = 2), 4 node shards of 1024 against the unsharded step: exact mask
-    budget, finite losses that agree, and the same global gradient norm (size-independent properties; the oracle cannot run here)."""
+    budget, finite losses that agree, and the same global gradient norm (size-independent properties; the unsharded step itself is checked
+    against the fp64 oracle at this size by tests/test_gpu_shapes.py::test_model_vs_oracle[c5_full_n4096_c128])."""
     from gptst_amd.model import GPTST_Model
     from gptst_amd.step import PretrainStep
     W, N, B = 4, 4096, 2
