@@ -51,7 +51,8 @@ def test_model_vs_oracle(name, parity):
         inj = dict(noise=synth.make_noise(M * base, 5))
     else:
         inj = dict(noise_a=synth.make_noise(M, 5), noise_r=synth.make_noise(M, 6), list_c=synth.class_order(HS, 3))
-    rdt = torch.float64 if c.get("f64") else torch.float32
+    import os
+    rdt = torch.float64 if (c.get("f64") or os.environ.get("GPTST_TEST_F64") == "1") else torch.float32
     cast = lambda v: v.to(rdt) if torch.is_tensor(v) and v.dtype.is_floating_point else v      # noqa: E731
     st = O.Stepper({k: cast(v) for k, v in sd.items()}, args, synth.SCALER_MEAN, synth.SCALER_STD, materialize_5d=False)
     outs_r, aux = O.forward_pretrain(st.sd, args, cast(src), epoch, materialize_5d=False, **{k: cast(v) for k, v in inj.items()})
