@@ -461,12 +461,14 @@ class PretrainStep:
         torch.cuda.synchronize()
         # Activations of the K sub-steps are NOT shared inside one capture (the graph-private pool grew K-fold at N = 4096, C = 128:
         # 4 x 56 GB): groups are for the shapes where the idle time between replays matters, i.e. small steps
+        # (decided from the device's TOTAL memory, not from what happens to be free: every rank of a data-parallel job must take the same
+        # branch, or their collective sequences diverge)
         per_step = torch.cuda.max_memory_allocated() - base
-        free = torch.cuda.mem_get_info()[0]
-        if per_step * K > 0.4 * free:
+        total = torch.cuda.get_device_properties(self.dev).total_memory
+        if per_step * K > 0.25 * total:
             self.model.flat.copy_(keep[0]); self.m.copy_(keep[1]); self.v.copy_(keep[2])
             torch.cuda.synchronize()
-            raise RuntimeError("a group of %d steps would need ~%.0f GB of activations (%.0f GB free)" % (K, per_step * K / 2**30, free / 2**30))
+            raise RuntimeError("a group of %d steps would need ~%.0f GB of activations (device: %.0f GB)" % (K, per_step * K / 2**30, total / 2**30))
         ops.set_deterministic(self.deterministic)
         try:
             g = torch.cuda.CUDAGraph()
