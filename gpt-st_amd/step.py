@@ -54,6 +54,7 @@ class PretrainStep:
         self._ring = [self._views(torch.zeros(16 + self.HS + 4, dtype=torch.int32).pin_memory()) for _ in range(self.RING)]
         self._ring_i = 0
         self.phase_kl = False                                        # phase of the last enqueued step (losses())
+        self._gK, self._g_last, self._group_failed = 0, None, False  # step_group(): group size set up, (K, phase) of the last group, capture refused
         self.stats_out = torch.zeros(8, device=self.dev)            # snapshot of stats after the step (graph output)
         self.mask_buf = torch.ones(M * self.base, device=self.dev)   # teacher-forced mask (parity runs)
         self.last_mask = None
@@ -362,12 +363,12 @@ class PretrainStep:
     def group_ok(self, epoch):
         """A group runs as one graph when the whole step is one graph (no host-side collective inside the step)."""
         phase = 0 if epoch <= self.args.change_epoch else 1
-        if getattr(self, "_group_failed", False):
+        if self._group_failed:
             return False
         return self.use_graph and (self.dp is None or self._dp_in_graph()) and not (self._needs_exchange(phase) and not self._dp_in_graph())
 
     def _group_init(self, K):
-        if getattr(self, "_gK", 0) == K:
+        if self._gK == K:
             return
         W = self.hc.numel()
         self._gK = K
@@ -422,7 +423,7 @@ class PretrainStep:
                 torch.cuda.empty_cache()
             finally:
                 self.src, self.stats_out, self.hyper, self.ctrl, self.rng_words = keep
-            if getattr(self, "_group_failed", False):
+            if self._group_failed:
                 return self.step_group(sources, epoch, list_cs)
         sl = self._g_ring[self._g_ring_i]
         self._g_ring_i = (self._g_ring_i + 1) % self.RING
@@ -489,7 +490,7 @@ class PretrainStep:
 
     def losses_group(self):
         """[(loss, loss_flow, loss_s)] of the steps of the last step_group() — synchronises."""
-        if getattr(self, "_g_last", None) is None:
+        if self._g_last is None:
             return [self.losses()]
         K, phase = self._g_last
         st = self._g_stats.cpu()
@@ -503,7 +504,7 @@ class PretrainStep:
     # ---- results ---------------------------------------------------------------------------------------------------
     def losses(self):
         """(loss, loss_flow, loss_s) of the last step — synchronises (reference BasicTrainer.py:98-103 does so every step)."""
-        if getattr(self, "_g_last", None) is not None:
+        if self._g_last is not None:
             return self.losses_group()[-1]
         st = self.stats_out.cpu()
         lf = float(st[0] / max(float(st[1]), 1.0))
