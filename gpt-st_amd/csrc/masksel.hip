@@ -12,7 +12,8 @@
 // Masks are fp32 {0,1} arrays (1 = visible, 0 = masked) of B*T*N*base cells — the consumers multiply with them.
 #include "common.h"
 
-#define MS_BLOCKS 64
+#define MS_BLOCKS 64                     // workgroups of a selection launch up to 2^16 cells; more cells: one per 1024 cells, up to MS_BLOCKS_MAX
+#define MS_BLOCKS_MAX 512
 #define MS_THREADS 256
 #define MS_BINS 2048
 #define MS_BLK (3 * MS_BINS + 16)      // words of one selection's block: three digit histograms + the prefix memo (9 words)
@@ -123,13 +124,13 @@ __global__ __launch_bounds__(MS_THREADS) void ms_hist_kernel(MsPlan p, unsigned*
     const int sh = ms_shift(dig), nb = ms_bins(dig);
     const unsigned hi_mask = dig == 0 ? 0u : (0xFFFFFFFFu << (sh + (dig == 1 ? 11 : 10)));
     // four cells per trip: their (noise, label / gate) loads are issued together (one cell per trip = one serialised L2 round trip per trip)
-    for (int i0 = blockIdx.x * MS_THREADS + threadIdx.x; i0 < p.M; i0 += 4 * MS_BLOCKS * MS_THREADS) {
+    for (int i0 = blockIdx.x * MS_THREADS + threadIdx.x; i0 < p.M; i0 += 4 * gridDim.x * MS_THREADS) {
         unsigned key[4];
 #pragma unroll
-        for (int u = 0; u < 4; ++u) { const int i = i0 + u * MS_BLOCKS * MS_THREADS; key[u] = i < p.M ? ms_key(p, cls, i) : 0u; }
+        for (int u = 0; u < 4; ++u) { const int i = i0 + u * gridDim.x * MS_THREADS; key[u] = i < p.M ? ms_key(p, cls, i) : 0u; }
 #pragma unroll
         for (int u = 0; u < 4; ++u)
-            if (i0 + u * MS_BLOCKS * MS_THREADS < p.M && (key[u] & hi_mask) == (prefix & hi_mask)) atomicAdd(&lh[(key[u] >> sh) & (unsigned)(nb - 1)], 1u);
+            if (i0 + u * gridDim.x * MS_THREADS < p.M && (key[u] & hi_mask) == (prefix & hi_mask)) atomicAdd(&lh[(key[u] >> sh) & (unsigned)(nb - 1)], 1u);
     }
     __syncthreads();
     unsigned* gh = hist + dig * MS_BINS;
@@ -156,13 +157,13 @@ __global__ __launch_bounds__(MS_THREADS) void ms_apply_kernel(MsPlan p, const un
     unsigned thr = 0xFFFFFFFFu, need = 0u, cnt_eq = 0u;
     if (k > 0) ms_prefix(hist, 3, k, sc, thr, need, cnt_eq);
     const bool ties = k > 0 && need != cnt_eq;                   // uniform
-    for (int i0 = blockIdx.x * MS_THREADS + threadIdx.x; i0 < p.M; i0 += 4 * MS_BLOCKS * MS_THREADS) {       // four cells' loads in flight
+    for (int i0 = blockIdx.x * MS_THREADS + threadIdx.x; i0 < p.M; i0 += 4 * gridDim.x * MS_THREADS) {       // four cells' loads in flight
         unsigned keys[4], nk[4];
         int lab[4];
         float gat[4];
 #pragma unroll
         for (int u = 0; u < 4; ++u) {
-            const int i = min(i0 + u * MS_BLOCKS * MS_THREADS, p.M - 1);
+            const int i = min(i0 + u * (int)gridDim.x * MS_THREADS, p.M - 1);
             keys[u] = ms_key(p, cls, i);
             lab[u] = p.mode == 1 ? p.label[i] : 0;
             gat[u] = p.mode == 2 ? p.gate[i] : 0.f;
@@ -170,7 +171,7 @@ __global__ __launch_bounds__(MS_THREADS) void ms_apply_kernel(MsPlan p, const un
         }
 #pragma unroll
         for (int u = 0; u < 4; ++u) {
-            const int i = i0 + u * MS_BLOCKS * MS_THREADS;
+            const int i = i0 + u * gridDim.x * MS_THREADS;
             if (i >= p.M) break;
             const unsigned key = keys[u];
             // a tie straddling rank k: threshold-equal cells belong to workgroup 0 alone (below) — nobody else writes them, so the
@@ -191,12 +192,19 @@ __global__ __launch_bounds__(MS_THREADS) void ms_apply_kernel(MsPlan p, const un
     }
     // rare: a tie straddles rank k.  Workgroup 0 hands the `need` threshold-equal slots out in index order and writes BOTH
     // values (0 for the first `need` of them, 1 for the rest).
+    // (A thread takes TPT consecutive cells, so one block scan orders TPT * 256 of them: the scan over all M cells by this one workgroup
+    //  is what the path costs — 1 ms at 2.6e5 cells with one cell per thread, which matters once a data-parallel job selects over
+    //  world x B*T*N cells with 24-bit noise: a straddling tie every ~30 steps at 5e5 cells.)
+    constexpr int TPT = 16;
     if (threadIdx.x == 0) s_base = 0u;
     __syncthreads();
-    for (int i0 = 0; i0 < p.M; i0 += MS_THREADS) {
-        const int i = i0 + threadIdx.x;
-        const bool eq = i < p.M && ms_key(p, cls, i) == thr;
-        sc[threadIdx.x] = eq ? 1u : 0u;
+    for (int i0 = 0; i0 < p.M; i0 += TPT * MS_THREADS) {
+        const int ib = i0 + TPT * threadIdx.x;
+        unsigned eqm = 0u;                                           // bit u: cell ib + u is threshold-equal
+#pragma unroll
+        for (int u = 0; u < TPT; ++u) if (ib + u < p.M && ms_key(p, cls, ib + u) == thr) eqm |= 1u << u;
+        const unsigned cnt = __popc(eqm);
+        sc[threadIdx.x] = cnt;
         __syncthreads();
         for (int off = 1; off < MS_THREADS; off <<= 1) {
             const unsigned v = threadIdx.x >= off ? sc[threadIdx.x - off] : 0u;
@@ -204,8 +212,9 @@ __global__ __launch_bounds__(MS_THREADS) void ms_apply_kernel(MsPlan p, const un
             sc[threadIdx.x] += v;
             __syncthreads();
         }
-        const unsigned rank = s_base + sc[threadIdx.x] - (eq ? 1u : 0u);
-        if (eq) {
+        unsigned rank = s_base + sc[threadIdx.x] - cnt;
+        for (unsigned m = eqm; m; m &= m - 1u, ++rank) {
+            const int i = ib + (__ffs(m) - 1);
             float vis = rank < need ? 0.f : 1.f;
             if (p.mode == 1 && cls.d[p.label[i]]) vis = 0.f;
             out[i] = vis;
@@ -402,8 +411,12 @@ __global__ __launch_bounds__(256) void ms_zero_kernel(unsigned* __restrict__ p, 
 // one selection on a ZEROED histogram block (digit passes d0..2 + the mask write); next_noise / next_hist: see ms_apply_kernel
 static int ms_select(const MsPlan& p, unsigned* hist, float* out, float* final_mask, int base, hipStream_t st, int d0 = 0,
                      const float* next_noise = nullptr, unsigned* next_hist = nullptr) {
-    for (int d = d0; d < 3; ++d) hipLaunchKernelGGL(ms_hist_kernel, dim3(MS_BLOCKS), dim3(MS_THREADS), 0, st, p, hist, d);
-    hipLaunchKernelGGL(ms_apply_kernel, dim3(MS_BLOCKS), dim3(MS_THREADS), 0, st, p, (const unsigned*)hist, out, final_mask, base, next_noise,
+    // one trip of four cells per thread up to MS_BLOCKS_MAX workgroups: a data-parallel job selects over world x B*T*N cells on every rank,
+    // and with a fixed 64 workgroups the generation grew from 50 to 112 us at 8 x 65280 cells (tools/experiments/mb_mask_scaling.py)
+    int nbk = (p.M + 4 * MS_THREADS - 1) / (4 * MS_THREADS);
+    nbk = nbk < MS_BLOCKS ? MS_BLOCKS : (nbk > MS_BLOCKS_MAX ? MS_BLOCKS_MAX : nbk);
+    for (int d = d0; d < 3; ++d) hipLaunchKernelGGL(ms_hist_kernel, dim3(nbk), dim3(MS_THREADS), 0, st, p, hist, d);
+    hipLaunchKernelGGL(ms_apply_kernel, dim3(nbk), dim3(MS_THREADS), 0, st, p, (const unsigned*)hist, out, final_mask, base, next_noise,
                        next_hist);
     GPTST_CHECK_LAUNCH();
     return GPTST_OK;
@@ -414,7 +427,13 @@ __global__ __launch_bounds__(256) void ms_count_kernel(const int* __restrict__ l
     __shared__ int hist[256];
     for (int h = threadIdx.x; h < HS; h += 256) hist[h] = 0;
     __syncthreads();
-    for (int i = blockIdx.x * 256 + threadIdx.x; i < M; i += gridDim.x * 256) atomicAdd(&hist[label[i]], 1);
+    for (int i0 = blockIdx.x * 256 + threadIdx.x; i0 < M; i0 += 8 * gridDim.x * 256) {          // eight labels' loads in flight per trip
+        int lab[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) lab[u] = label[min(i0 + u * (int)gridDim.x * 256, M - 1)];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) if (i0 + u * (int)gridDim.x * 256 < M) atomicAdd(&hist[lab[u]], 1);
+    }
     __syncthreads();
     for (int h = threadIdx.x; h < HS; h += 256) if (hist[h]) atomicAdd(counts + h, hist[h]);
 }
@@ -462,7 +481,7 @@ extern "C" int gptst_mask_adaptive(const int* label, const int* counts, const in
     unsigned* w = (unsigned*)ws;
     if (!ws_zeroed) hipLaunchKernelGGL(ms_zero_kernel, dim3(12), dim3(256), 0, (hipStream_t)stream, w, MS_WS_WORDS);   // both blocks + counts
     if (!counts) {                                         // class histogram from the labels (what gptst_mask_labels would have produced)
-        int nb = (M + 255) / 256; if (nb > 64) nb = 64;
+        int nb = (M + 8 * 256 - 1) / (8 * 256); if (nb > 128) nb = 128;                      // <= 128 same-address atomics per class
         int* cw = (int*)(w + 2 * MS_BLK);
         hipLaunchKernelGGL(ms_count_kernel, dim3(nb), dim3(256), 0, (hipStream_t)stream, label, M, HS, cw);
         a.counts = cw;

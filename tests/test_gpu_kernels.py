@@ -978,3 +978,26 @@ def test_step_begin_draws_philox_noise():
     noise2 = torch.empty_like(noise)
     ops.step_begin(z0, None, src, 1, noise=noise2, rng=torch.tensor([1234567, 43], dtype=torch.int32, device=dev))
     assert float((noise2.cpu() == u).float().mean()) < 1e-3
+
+
+@pytest.mark.parametrize("W", [2, 8])
+def test_mask_generation_over_a_global_batch(W):
+    """Data parallel with global masks: every rank selects over world x B*T*N cells — more selection workgroups than the single-rank 64
+    (one per 1024 cells, up to 512); bit-exact against the oracle for both phases."""
+    from gptst_amd import ops, synth
+    dev = _dev()
+    B, T, N, HS = 4 * W, 12, 170, 10
+    M = B * T * N
+    noise = synth.make_noise(M, 3)
+    assert torch.equal(ops.mask_random(noise.to(dev), int(M * 0.25)).cpu().to(torch.int64), O.random_mask(noise, 0.25))
+    g = torch.Generator().manual_seed(W)
+    label_ref = torch.randint(0, HS, (M,), generator=g)
+    list_c = synth.class_order(HS, 5)
+    na, nr = synth.make_noise(M, 11), synth.make_noise(M, 12)
+    total = int(M * 0.25)
+    ada = total // 2
+    m_ada_r, m_rnd_r, fin_r = O.adaptive_mask(label_ref.view(B, T, N), list_c, na, nr, ada, total - ada, "all")
+    m_ada, m_rnd, mask = ops.mask_adaptive(label_ref.to(torch.int32).to(dev), None, torch.tensor(list_c, dtype=torch.int32, device=dev),
+                                           torch.tensor([ada, total - ada], dtype=torch.int32, device=dev), na.to(dev), nr.to(dev), 1, 1)
+    assert torch.equal(m_ada.cpu().long(), m_ada_r) and torch.equal(m_rnd.cpu().long(), m_rnd_r)
+    assert torch.equal(mask.cpu().long(), fin_r.view(-1))
