@@ -17,8 +17,9 @@ typedef int (*CommInitRank_t)(void**, int, Uid, int);
 typedef int (*AllReduce_t)(const void*, void*, size_t, int, int, void*, hipStream_t);
 typedef int (*CommDestroy_t)(void*);
 typedef int (*CommCount_t)(void*, int*);
-struct Api { void* lib; GetUniqueId_t uid; CommInitRank_t init; AllReduce_t allreduce; CommDestroy_t destroy; CommCount_t count; };
-Api g_api = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
+typedef int (*AllGather_t)(const void*, void*, size_t, int, void*, hipStream_t);
+struct Api { void* lib; GetUniqueId_t uid; CommInitRank_t init; AllReduce_t allreduce; CommDestroy_t destroy; CommCount_t count; AllGather_t allgather; };
+Api g_api = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
 void* g_comm = nullptr;
 int g_world = 0;
 
@@ -30,7 +31,8 @@ bool bind() {
     if (!h) for (const char* n : names) { h = dlopen(n, RTLD_NOW | RTLD_GLOBAL); if (h) break; }
     if (!h) return false;
     Api a{h, (GetUniqueId_t)dlsym(h, "ncclGetUniqueId"), (CommInitRank_t)dlsym(h, "ncclCommInitRank"),
-          (AllReduce_t)dlsym(h, "ncclAllReduce"), (CommDestroy_t)dlsym(h, "ncclCommDestroy"), (CommCount_t)dlsym(h, "ncclCommCount")};
+          (AllReduce_t)dlsym(h, "ncclAllReduce"), (CommDestroy_t)dlsym(h, "ncclCommDestroy"), (CommCount_t)dlsym(h, "ncclCommCount"),
+          (AllGather_t)dlsym(h, "ncclAllGather")};
     if (!a.uid || !a.init || !a.allreduce || !a.destroy) return false;
     g_api = a;
     return true;
@@ -61,6 +63,15 @@ extern "C" int gptst_allreduce_f32(float* buf, long n, void* stream) {
     if (!buf || n <= 0) return GPTST_EARG;
     if (!g_comm) return GPTST_ECOMM;
     const int rc = g_api.allreduce(buf, buf, (size_t)n, 7, 0, g_comm, (hipStream_t)stream);
+    return rc == 0 ? GPTST_OK : 1000 + rc;
+}
+
+// recv[r*n .. (r+1)*n) <- rank r's send[0..n) (32-bit words: labels, indices), enqueued on `stream` (capturable); dtype 2 = ncclInt32.
+// send may be recv + rank*n (in place).  GPTST_ECOMM when the communicator or ncclAllGather is missing (callers fall back to an all-reduce).
+extern "C" int gptst_allgather_i32(const int* send, int* recv, long n, void* stream) {
+    if (!send || !recv || n <= 0) return GPTST_EARG;
+    if (!g_comm || !g_api.allgather) return GPTST_ECOMM;
+    const int rc = g_api.allgather(send, recv, (size_t)n, 2, g_comm, (hipStream_t)stream);
     return rc == 0 ? GPTST_OK : 1000 + rc;
 }
 

@@ -59,8 +59,10 @@ class DataParallel:
         """Concatenate the ranks' label vectors in rank order (= batch-major order of the global batch)."""
         if out is None:
             out = torch.empty(self.world * local.numel(), dtype=local.dtype, device=local.device)
+        if self.native is not None and self.native.allgather_i32(local, out):
+            return out                                  # one RCCL launch on the C-ABI communicator
         if self.native is not None:
-            # all-gather as an all-reduce of a slot buffer: every rank fills its own slot with its labels as exactly representable floats
+            # (ncclAllGather not available) all-gather as an all-reduce of a slot buffer: every rank fills its own slot with its labels as exactly representable floats
             # (the C-ABI communicator reduces fp32 only; labels < HS <= 64)
             if self._slots is None or self._slots.numel() != out.numel():
                 self._slots = torch.zeros(out.numel(), dtype=torch.float32, device=local.device)
@@ -135,6 +137,20 @@ class NativeComm:
         assert buf.is_cuda and buf.dtype == torch.float32 and buf.is_contiguous()
         self.lib.call("gptst_allreduce_f32", buf.data_ptr(), buf.numel(), torch.cuda.current_stream().cuda_stream)
         return buf
+
+    def allgather_i32(self, local, out):
+        """out[r*n:(r+1)*n] <- rank r's int32 `local`, enqueued on torch's current stream; False when the library cannot (no ncclAllGather)"""
+        assert local.is_cuda and local.dtype == torch.int32 and local.is_contiguous() and out.dtype == torch.int32 and out.is_contiguous()
+        assert out.numel() == self.world * local.numel()
+        if getattr(self, "_no_allgather", False):
+            return False
+        rc = self.lib.value("gptst_allgather_i32", local.data_ptr(), out.data_ptr(), local.numel(), torch.cuda.current_stream().cuda_stream)
+        if rc == -4:                                    # GPTST_ECOMM: symbol missing
+            self._no_allgather = True
+            return False
+        if rc != 0:
+            raise RuntimeError("gptst_allgather_i32 failed: %d" % rc)
+        return True
 
     def count(self):
         """ncclCommCount of the communicator"""

@@ -376,6 +376,8 @@ int gptst_mlprl_layer_bwd(const float* dlogits, const float* a, int lda, const f
 int gptst_comm_unique_id(void* out128);
 int gptst_comm_init(int rank, int world, const void* unique_id);
 int gptst_allreduce_f32(float* buf, long n, void* stream);      /* in-place sum over the ranks */
+/* recv[r*n .. (r+1)*n) <- rank r's send[0..n), 32-bit words (the cluster labels of a data-parallel global batch); send may be recv + rank*n */
+int gptst_allgather_i32(const int* send, int* recv, long n, void* stream);
 int gptst_comm_count(int* out);                                /* ncclCommCount of the communicator */
 int gptst_comm_destroy(void);
 

@@ -160,5 +160,23 @@ def test_native_comm_allreduce_inside_a_graph():
         g.replay(); g.replay()
         torch.cuda.synchronize()
         assert torch.equal(x, ref * 4)                               # two replays (capture records, it does not execute)
+        # the label all-gather of a data-parallel global batch (gptst_allgather_i32): eager and inside a graph; with one rank a copy
+        from gptst_amd.dist import DataParallel
+        lab = torch.randint(0, 10, (65280,), device="cuda:0", dtype=torch.int32)
+        out = torch.full((65280,), -1, device="cuda:0", dtype=torch.int32)
+        assert comm.allgather_i32(lab, out)
+        torch.cuda.synchronize()
+        assert torch.equal(out, lab)
+        out.fill_(-1)
+        g2 = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g2, capture_error_mode="thread_local"):
+            comm.allgather_i32(lab, out)
+        g2.replay()
+        torch.cuda.synchronize()
+        assert torch.equal(out, lab)
+        comm._no_allgather = True                                     # a library without ncclAllGather: the slot all-reduce takes over
+        dp = DataParallel.__new__(DataParallel)
+        dp.native, dp.world, dp.rank, dp._slots = comm, 1, 0, None
+        assert torch.equal(dp.gather_labels(lab), lab)
     finally:
         comm.close()
