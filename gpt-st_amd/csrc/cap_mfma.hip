@@ -411,11 +411,14 @@ static int launch_route_fwd2(const float* X, const float* Wp, const float* bp, c
 
 GPTST_INTERNAL int gptst_cap_route_fwd_v1(const float* X, const float* Wp, const float* bp, const float* dadj, float* c_out, float* s_out,
                                       int BT, int N, int C, int HS, int R, void* stream);
+GPTST_INTERNAL int gptst_cap_route_fwd3(const float* X, const float* Wp, const float* bp, const float* dadj, float* c_out, float* s_out,
+                                        int BT, int N, int C, int HS, int R, void* stream);      // cap_route3.hip (one wave per node tile)
 
 extern "C" int gptst_cap_route_fwd(const float* X, const float* Wp, const float* bp, const float* dadj, float* c_out, float* s_out,
                                    int BT, int N, int C, int HS, int R, void* stream) {
     if (!X || !Wp || !bp || !dadj || !c_out || !s_out || HS <= 0 || R < 0) return GPTST_EARG;
-    int rc = GPTST_ESHAPE;
+    int rc = gptst_cap_route_fwd3(X, Wp, bp, dadj, c_out, s_out, BT, N, C, HS, R, stream);
+    if (rc != GPTST_ESHAPE) return rc;
     if (C == 64) rc = launch_route_fwd2<64>(X, Wp, bp, dadj, c_out, s_out, BT, N, HS, R, (hipStream_t)stream);
     else if (C == 128) rc = launch_route_fwd2<128>(X, Wp, bp, dadj, c_out, s_out, BT, N, HS, R, (hipStream_t)stream);
     if (rc == GPTST_ESHAPE) return gptst_cap_route_fwd_v1(X, Wp, bp, dadj, c_out, s_out, BT, N, C, HS, R, stream);

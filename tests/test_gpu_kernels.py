@@ -1001,3 +1001,32 @@ def test_mask_generation_over_a_global_batch(W):
                                            torch.tensor([ada, total - ada], dtype=torch.int32, device=dev), na.to(dev), nr.to(dev), 1, 1)
     assert torch.equal(m_ada.cpu().long(), m_ada_r) and torch.equal(m_rnd.cpu().long(), m_rnd_r)
     assert torch.equal(mask.cpu().long(), fin_r.view(-1))
+
+
+@pytest.mark.parametrize("occ6", [0, 1, 2], ids=["fwd4", "fwd3", "fwd3occ6"])
+@pytest.mark.parametrize("B,N,HS,R", [(32, 170, 10, 2), (2, 207, 10, 2), (1, 256, 16, 3), (2, 20, 5, 0), (2, 20, 5, 1), (1, 100, 3, 4), (1, 250, 7, 2)])
+def test_cap_route_fwd3_matches_second_generation(B, N, HS, R, occ6):
+    """cap_route_fwd4_kernel (8 waves, wave-local routing passes over LDS-resident tiles, two workgroups per CU) and cap_route_fwd3_kernel
+    (one wave per 16-node tile, capsule rows in registers; gptst_tune(21, 1 / 2)) — one fold per routing iteration — against the LDS-resident
+    second generation (gptst_tune(20, 1)) on the same inputs: same algebra, different summation order over the nodes (tile partials folded
+    over the waves) — soft assignment c and cluster aggregate s to 2e-6 of their scale (routing is detached: no gradient flows through it)."""
+    from gptst_amd import ops, _C
+    dev = _dev()
+    g = torch.Generator().manual_seed(71 + N)
+    C, T = 64, 12
+    X = rnd(B, T, N, C, g=g, scale=0.5).to(dev)
+    Wp, bp = (rnd(C, C, g=g) * 0.15).to(dev), (rnd(C, g=g) * 0.3).to(dev)
+    dadj = rnd(B * T, HS * N, g=g).to(dev)
+    lib = _C.lib()
+    try:
+        lib.call("gptst_tune", 20, 1)
+        c2, s2 = ops.cap_route_fwd(X, Wp, bp, dadj, HS, R)
+        lib.call("gptst_tune", 20, 0)
+        lib.call("gptst_tune", 21, occ6)
+        c3, s3 = ops.cap_route_fwd(X, Wp, bp, dadj, HS, R)
+    finally:
+        lib.call("gptst_tune", 20, 0)
+        lib.call("gptst_tune", 21, 0)
+    assert not torch.equal(c2, c3) or N <= 16, "both calls ran the same kernel?"
+    close(c3, c2.cpu(), tol=2e-6, what="route3 c")
+    close(s3, s2.cpu(), tol=2e-6, what="route3 s")

@@ -91,6 +91,19 @@ def bench(fn, n=20):
 
 
 flt = sys.argv[1] if len(sys.argv) > 1 else ""
+if flt == "capgen":           # cap_route_fwd: third generation (default), its <= 80 VGPR variant, the second generation
+    from gptst_amd import _C
+    for lag in (1, 2, 3, 4, 6, 8, 10, 12):
+        _C.lib().call("gptst_tune", 22, lag)
+        print("cap_route_fwd fwd4 lag %2d %7.2f us" % (lag, bench(CASES["cap_route_fwd"])))
+    _C.lib().call("gptst_tune", 22, 0)
+    for nm, kv in (("fwd4", ()), ("fwd3", ((21, 1),)), ("fwd3 occ6", ((21, 2),)), ("fwd2", ((20, 1),))):
+        for k, v in kv:
+            _C.lib().call("gptst_tune", k, v)
+        print("cap_route_fwd %-10s %7.2f us" % (nm, bench(CASES["cap_route_fwd"])))
+        for k, v in kv:
+            _C.lib().call("gptst_tune", k, 0)
+    sys.exit(0)
 if flt == "tailsweep":
     from gptst_amd import _C
     for nb in (256, 512, 1024, 2048, 4080):
