@@ -316,10 +316,16 @@ __global__ __launch_bounds__(64 * CR4_NW, 4) void cap_route_fwd4_kernel(const fl
 #pragma unroll
         for (int q = 0; q < 4; ++q) a[q] = ld4(row + 16 * q);
     }
+    // Weight fragments: fragment (ct, q) of lane (j, kk) is Wp[4j + ct][16q + 4kk ..] — 16 rows x 64 B per wave load.  Every wave needs all 16
+    // fragments; loaded by each wave from global memory they were 128 of these strided loads per workgroup (prologue 5.6 us alone on a CU, 13 us
+    // for a second resident: tools/experiments/cap_route3_phases.hip).  The workgroup fetches each fragment ONCE (two loads per thread) into LDS
+    // in fragment order (the partial-sum region, free until the first pass) and every wave reads its copy back conflict-free.
+    float4 wf[2];
 #pragma unroll
-    for (int ct = 0; ct < 4; ++ct)
-#pragma unroll
-        for (int q = 0; q < 4; ++q) bv[ct][q] = ld4(Wp + (size_t)(4 * j + ct) * C + 16 * q + 4 * kk);
+    for (int u = 0; u < 2; ++u) {
+        const int f = tid + u * NTH, fr = f >> 6, fl = f & 63;          // fragment fr = 4 ct + q, lane fl
+        wf[u] = ld4(Wp + (size_t)(4 * (fl & 15) + (fr >> 2)) * C + 16 * (fr & 3) + 4 * (fl >> 4));
+    }
     const float4 b4 = ld4(bp + 4 * j);
 #pragma unroll
     for (int i = 0; i < TPW; ++i) {
@@ -330,9 +336,16 @@ __global__ __launch_bounds__(64 * CR4_NW, 4) void cap_route_fwd4_kernel(const fl
             bl[i][r] = 0.f;
         }
     }
+#pragma unroll
+    for (int u = 0; u < 2; ++u) st4(red0 + 4 * (tid + u * NTH), wf[u]);
     for (int i = tid; i < 16 * P; i += NTH) Vs[i] = 0.f;
+    __syncthreads();
+#pragma unroll
+    for (int ct = 0; ct < 4; ++ct)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) bv[ct][q] = ld4(red0 + 4 * ((4 * ct + q) * 64 + lane));
+    __syncthreads();                                       // the fragment image is dead: the region turns into the waves' scratch
     SB();
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     CR4_TS(1);
     // ---- capsule tiles P = squash(X_tile Wp^T + bp) -> LDS (rows of a tile are only ever read by the wave that wrote them) ----
     float4 csum = f4zero();
@@ -515,7 +528,7 @@ GPTST_INTERNAL int gptst_cap_route_fwd3(const float* X, const float* Wp, const f
     if (g_cap_route_v2 || C != 64 || N > 256 || HS > 16 || HS <= 0) return GPTST_ESHAPE;
     const int NW = (N + 15) / 16;
     if (g_cap_route_occ6 == 0) {
-        const int redw = (HS + 1) * 64 > 16 * 17 + 16 ? (HS + 1) * 64 : 16 * 17 + 16;
+        const int redw = (HS + 1) * 64 > 512 ? (HS + 1) * 64 : 512;          // >= the c scratch [16][17]; 8 of them >= the 16 KB fragment image
         const size_t smem4 = ((size_t)NW * 16 * CR3_P + (size_t)CR4_NW * redw + 16 * CR3_P) * sizeof(float);
         static size_t cur4[2] = {0, 0};
         if (NW <= CR4_NW) {
