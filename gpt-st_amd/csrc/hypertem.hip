@@ -759,3 +759,296 @@ extern "C" int gptst_hypertem_bwd_wgrad(const float* dOut, const float* Y, const
     GPTST_CHECK_LAUNCH();
     return GPTST_OK;
 }
+
+// =====================================================================================================================
+// hyperTem forward CHAIN (round 4): up to three consecutive hyperTem layers — optionally preceded by the node-conditioned layer that ends a
+// cap (GPTST.py:137-141: x = LReLU(rec W_n + b_n + x_res)) — in ONE launch on the (b, 16-node) slab.
+//
+// Every one of these layers is node-local: a workgroup that owns (sample b, 16 nodes, all 12 time steps) needs nothing from any other
+// workgroup until the next cap (whose sums over the nodes of a (b,t) are the only coupling in an STHCN).  As separate launches each layer pays
+// its own load phase (the 16.7 MB activation comes back from L2 / HBM while every workgroup of the one-round grid waits: 7.6 us of the 22 us,
+// DESIGN.md section 7) and its own fill / drain; here the layer output goes from the accumulators straight back into the LDS slab (and to HBM
+// once, for the backward) and the next layer starts from it.  Chains of the step: [cap1 node layer, hyperTem2, hyperTem3], [cap2 node layer,
+// hyperTem4 (, the decoder's hyperTem1)] (GPTST.py:264-271, :454).
+//
+// Node layer on the slab: a wave takes nodes w, w+4, .. of the tile; per node one 16-row MFMA tile whose rows are the 12 TIME STEPS of the
+// sample (rows 12..15 are padding), A = rec rows straight from global memory, B = W_n fragments from L2 (coalesced float4 rows, as W_bt
+// below), epilogue = bias + residual + LeakyReLU into the slab.  The node-grouped apply64 shares W_n over the 384 (b,t) rows of a node; here
+// every sample re-reads it (B x 2.8 MB of L2 traffic per launch) — the price of staying on the slab.
+struct HtStage { const float* G; const float* Wbt; const float* bbt; float* R_out; float* out; };
+struct HtChain {
+    int nstage;                                                   // hyperTem layers: 1 .. 3
+    const float* X;                                               // slab source when no node layer precedes
+    const float* rec; const float* Wn; const float* bn; const float* xres; float* out0;     // node layer (rec != NULL)
+    HtStage st[3];
+};
+
+// NODE / NSTAGE are compile-time (the run-time form — one kernel, stage loop over ch.nstage — spilled 250-400 registers: the allocator saw
+// the fragments of every path live around the loop)
+template <bool NODE, int NSTAGE>
+__global__ __launch_bounds__(256, 2) void hypertem_chain_fwd_kernel(HtChain ch, int N, int B) {
+    constexpr int C = 64, P = C + 4, GP = 145, NT = 16;
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    float* Xs = smem;                               // [12][NT][P]
+    float* Gs = Xs + HT_T * NT * P;                 // [NT][GP]
+    int b, tile;
+    if (!ht_work((N + NT - 1) / NT, B, b, tile)) return;
+    const int n0 = tile * NT;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int j = lane & 15, kk = lane >> 4;
+    float gv[9];
+#define HTC_LOAD_G(Gp) _Pragma("unroll") for (int k = 0; k < 9; ++k) gv[k] = (Gp)[min(n0 * 144 + tid + k * 256, N * 144 - 1)]
+#define HTC_STORE_G() _Pragma("unroll") for (int k = 0; k < 9; ++k) { const int i = tid + k * 256; \
+        if (i < NT * 144) Gs[(i / 144) * GP + i % 144] = (n0 + i / 144 < N) ? gv[k] : 0.f; }
+    float4 bv[C / 16][4];
+    float4 b4;
+#define HTC_LOAD_W(W0, b0, tt) do {                                                                                \
+        const float* W_ = (W0) + ((size_t)b * HT_T + (tt)) * C * C;                                                \
+        _Pragma("unroll") for (int q = 0; q < C / 16; ++q)                                                         \
+            _Pragma("unroll") for (int e = 0; e < 4; ++e) bv[q][e] = ld4(W_ + (size_t)(16 * q + 4 * kk + e) * C + 4 * j); \
+        b4 = ld4((b0) + ((size_t)b * HT_T + (tt)) * C + 4 * j);                                                    \
+    } while (0)
+
+    if constexpr (NODE) {
+        // ---- node layer: x[t][n][:] = LReLU(rec[b,t,n,:] W_n + b_n + xres[b,t,n,:]) -> slab + out0 ----
+        HTC_LOAD_G(ch.st[0].G);
+        const int tr = min(j, HT_T - 1);                              // A-operand row = time step (rows >= 12: don't-care)
+        float4 a[4], xr[4], bn4;
+#define HTC_LOAD_NODE(nn) do {                                                                                     \
+            const int n_ = (nn);                                                                                   \
+            const float* W_ = ch.Wn + (size_t)n_ * C * C;                                                          \
+            _Pragma("unroll") for (int q = 0; q < 4; ++q) a[q] = ld4(ch.rec + (((size_t)b * HT_T + tr) * N + n_) * C + 16 * q + 4 * kk); \
+            _Pragma("unroll") for (int q = 0; q < 4; ++q)                                                          \
+                _Pragma("unroll") for (int e = 0; e < 4; ++e) bv[q][e] = ld4(W_ + (size_t)(16 * q + 4 * kk + e) * C + 4 * j); \
+            bn4 = ld4(ch.bn + (size_t)n_ * C + 4 * j);                                                             \
+            _Pragma("unroll") for (int r = 0; r < 4; ++r)                                                          \
+                xr[r] = ld4(ch.xres + (((size_t)b * HT_T + min(4 * kk + r, HT_T - 1)) * N + n_) * C + 4 * j);      \
+        } while (0)
+        if (n0 + wave < N) HTC_LOAD_NODE(n0 + wave);
+        for (int nl = wave; nl < NT; nl += 4) {
+            const int n = n0 + nl;
+            if (n < N) {                                              // wave-uniform
+                SB();
+                f32x4 acc[4];
+#pragma unroll
+                for (int ct = 0; ct < 4; ++ct) acc[ct] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const float av[4] = {a[q].x, a[q].y, a[q].z, a[q].w};
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        acc[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[e], bv[q][e].x, acc[0], 0, 0, 0);
+                        acc[1] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[e], bv[q][e].y, acc[1], 0, 0, 0);
+                        acc[2] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[e], bv[q][e].z, acc[2], 0, 0, 0);
+                        acc[3] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[e], bv[q][e].w, acc[3], 0, 0, 0);
+                    }
+                }
+                SB();
+                float4 y[4];
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    y[r] = f4add(f4add(make_float4(acc[0][r], acc[1][r], acc[2][r], acc[3][r]), bn4), xr[r]);
+                    y[r].x = lrelu(y[r].x); y[r].y = lrelu(y[r].y); y[r].z = lrelu(y[r].z); y[r].w = lrelu(y[r].w);
+                }
+                if (nl + 4 < NT && n + 4 < N) HTC_LOAD_NODE(n + 4);   // next node's operands: requested before this node's stores
+                SB();
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int t = 4 * kk + r;
+                    if (t < HT_T) {
+                        st4(ch.out0 + (((size_t)b * HT_T + t) * N + n) * C + 4 * j, y[r]);
+                        st4(Xs + (t * NT + nl) * P + 4 * j, y[r]);
+                    }
+                }
+            } else {
+#pragma unroll
+                for (int r = 0; r < 4; ++r)
+                    if (4 * kk + r < HT_T) st4(Xs + ((4 * kk + r) * NT + nl) * P + 4 * j, f4zero());
+            }
+        }
+#undef HTC_LOAD_NODE
+        HTC_STORE_G();
+    } else {
+        // ---- slab + graph staging: ALL global loads before the first LDS store (as hypertem_fwd_kernel) ----
+        const int nl = tid >> 4, c4 = tid & 15;
+        const int n = min(n0 + nl, N - 1);
+        float4 v[HT_T];
+#pragma unroll
+        for (int t = 0; t < HT_T; ++t) v[t] = ld4(ch.X + (((size_t)b * HT_T + t) * N + n) * C + 4 * c4);
+        HTC_LOAD_G(ch.st[0].G);
+#pragma unroll
+        for (int t = 0; t < HT_T; ++t) st4(Xs + (t * NT + nl) * P + 4 * c4, n0 + nl < N ? v[t] : f4zero());
+        HTC_STORE_G();
+    }
+    // W_bt fragments are never live across the mix phase of a non-final layer (64 registers on top of the three kept mixes): every layer
+    // requests its first fragments itself — the final one at its start, a non-final one right behind its mixes
+    __syncthreads();
+    SB();
+
+#pragma unroll
+    for (int s = 0; s < NSTAGE; ++s) {
+        const HtStage S = ch.st[s];
+        const HtStage S1 = ch.st[s + 1 < 3 ? s + 1 : 2];
+        if (s + 1 < NSTAGE) {
+            // ---- a layer whose output is the next layer's slab: all mixes first (they read every time step of the slab), then — behind a
+            //      barrier — MFMA + epilogue, writing the output rows IN PLACE (time step t of the slab is only touched by its own wave now) ----
+            float4 a4a[C / 16], a4b[C / 16], a4c[C / 16];          // three named arrays: an [3][4] array indexed by the rolled loop below went to scratch
+#pragma unroll
+            for (int q = 0; q < C / 16; ++q) { a4a[q] = f4zero(); a4b[q] = f4zero(); a4c[q] = f4zero(); }
+            {   // the three mixes of this wave share every slab operand: each X_u row piece is read ONCE and feeds the three time steps
+                const float* gr = Gs + j * GP + wave * HT_T;
+                const float* xr = Xs + j * P + 4 * kk;
+#pragma unroll
+                for (int u = 0; u < HT_T; ++u) {
+                    float4 x[C / 16];
+#pragma unroll
+                    for (int q = 0; q < C / 16; ++q) x[q] = ld4(xr + u * NT * P + 16 * q);
+                    const float g0 = gr[u], g1 = gr[4 * HT_T + u], g2 = gr[8 * HT_T + u];
+#pragma unroll
+                    for (int q = 0; q < C / 16; ++q) {
+                        a4a[q] = f4fma(g0, x[q], a4a[q]);
+                        a4b[q] = f4fma(g1, x[q], a4b[q]);
+                        a4c[q] = f4fma(g2, x[q], a4c[q]);
+                    }
+                    if (u % 3 == 2) SB();                      // at most three time steps' operands (48 registers) in flight
+                }
+            }
+            HTC_LOAD_W(S.Wbt, S.bbt, wave);
+            HTC_LOAD_G(S1.G);                                     // next layer's temporal graphs: in flight during the MFMA phase
+            __syncthreads();
+            SB();
+#pragma nounroll
+            for (int ti = 0; ti < 3; ++ti) {                       // rolled: unrolled, the addresses of all three steps' stores / loads were live at once
+                const int t = wave + 4 * ti;
+                const size_t g = (size_t)b * HT_T + t;
+                float4 m4[C / 16];                                 // this step's mix; the kept ones rotate down (register moves: a select by ti
+#pragma unroll                                                     //  turned the three arrays into one scratch array)
+                for (int q = 0; q < C / 16; ++q) { m4[q] = a4a[q]; a4a[q] = a4b[q]; a4b[q] = a4c[q]; }
+                f32x4 acc[C / 16];
+#pragma unroll
+                for (int ct = 0; ct < C / 16; ++ct) acc[ct] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                for (int q = 0; q < C / 16; ++q) {
+                    const float av[4] = {m4[q].x, m4[q].y, m4[q].z, m4[q].w};
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        acc[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[e], bv[q][e].x, acc[0], 0, 0, 0);
+                        acc[1] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[e], bv[q][e].y, acc[1], 0, 0, 0);
+                        acc[2] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[e], bv[q][e].z, acc[2], 0, 0, 0);
+                        acc[3] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[e], bv[q][e].w, acc[3], 0, 0, 0);
+                    }
+                }
+                SB();
+                const float4 bias = b4;
+                if (ti < 2) HTC_LOAD_W(S.Wbt, S.bbt, t + 4);
+                SB();
+                if (S.R_out != nullptr && n0 + j < N) {
+#pragma unroll
+                    for (int q = 0; q < C / 16; ++q) st4(S.R_out + (g * N + n0 + j) * C + 16 * q + 4 * kk, m4[q]);
+                }
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int nl = kk * 4 + r;
+                    float* xs = Xs + (t * NT + nl) * P + 4 * j;
+                    float4 y = f4add(f4add(make_float4(acc[0][r], acc[1][r], acc[2][r], acc[3][r]), bias), ld4(xs));
+                    y.x = lrelu(y.x); y.y = lrelu(y.y); y.z = lrelu(y.z); y.w = lrelu(y.w);
+                    if (n0 + nl < N) st4(S.out + (g * N + n0 + nl) * C + 4 * j, y);
+                    else y = f4zero();
+                    st4(xs, y);
+                }
+                SB();
+            }
+            HTC_STORE_G();
+            __syncthreads();
+            SB();
+        } else {
+            // ---- last layer of the chain: per time step mix -> MFMA -> epilogue, as hypertem_fwd_kernel ----
+            HTC_LOAD_W(S.Wbt, S.bbt, wave);
+            for (int t = wave; t < HT_T; t += 4) {
+                const size_t g = (size_t)b * HT_T + t;
+                SB();
+                float4 a4[C / 16];
+#pragma unroll
+                for (int q = 0; q < C / 16; ++q) a4[q] = f4zero();
+                {
+                    const float* gr = Gs + j * GP + t * HT_T;
+                    const float* xr = Xs + j * P + 4 * kk;
+#pragma unroll
+                    for (int u = 0; u < HT_T; ++u) {
+                        const float gu = gr[u];
+#pragma unroll
+                        for (int q = 0; q < C / 16; ++q) a4[q] = f4fma(gu, ld4(xr + u * NT * P + 16 * q), a4[q]);
+                    }
+                }
+                SB();
+                f32x4 acc[C / 16];
+#pragma unroll
+                for (int ct = 0; ct < C / 16; ++ct) acc[ct] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                for (int q = 0; q < C / 16; ++q) {
+                    const float av[4] = {a4[q].x, a4[q].y, a4[q].z, a4[q].w};
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        acc[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[e], bv[q][e].x, acc[0], 0, 0, 0);
+                        acc[1] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[e], bv[q][e].y, acc[1], 0, 0, 0);
+                        acc[2] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[e], bv[q][e].z, acc[2], 0, 0, 0);
+                        acc[3] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[e], bv[q][e].w, acc[3], 0, 0, 0);
+                    }
+                }
+                SB();
+                const float4 bias = b4;
+                if (t + 4 < HT_T) HTC_LOAD_W(S.Wbt, S.bbt, t + 4);
+                SB();
+                if (S.R_out != nullptr && n0 + j < N) {
+#pragma unroll
+                    for (int q = 0; q < C / 16; ++q) st4(S.R_out + (g * N + n0 + j) * C + 16 * q + 4 * kk, a4[q]);
+                }
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int nl = kk * 4 + r;
+                    if (n0 + nl < N) {
+                        float4 y = f4add(f4add(make_float4(acc[0][r], acc[1][r], acc[2][r], acc[3][r]), bias), ld4(Xs + (t * NT + nl) * P + 4 * j));
+                        y.x = lrelu(y.x); y.y = lrelu(y.y); y.z = lrelu(y.z); y.w = lrelu(y.w);
+                        st4(S.out + (g * N + n0 + nl) * C + 4 * j, y);
+                    }
+                }
+            }
+        }
+    }
+#undef HTC_LOAD_G
+#undef HTC_STORE_G
+#undef HTC_LOAD_W
+}
+
+// X: input of the first hyperTem layer (ignored when rec != NULL);  rec / Wn (N,C,C) / bn (N,C) / xres / out0: the node layer in front
+// (all five or none);  Gs .. outs: HOST arrays of nstage device pointers (G (N,T,T), Wbt (BT,C,C), bbt (BT,C), R_out or NULL, out), read at
+// call time.  C = 64 only (GPTST_ESHAPE otherwise: use the per-layer entry points).
+extern "C" int gptst_hypertem_chain_fwd(const float* X, const float* rec, const float* Wn, const float* bn, const float* xres, float* out0,
+                                        int nstage, const void* Gs, const void* Wbts, const void* bbts, const void* Rs, const void* outs,
+                                        int B, int T, int N, int C, void* stream) {
+    if (nstage < 1 || nstage > 3 || !Gs || !Wbts || !bbts || !Rs || !outs || T != HT_T || B <= 0 || N <= 0) return GPTST_EARG;
+    const bool node = rec != nullptr;
+    if (node ? (!Wn || !bn || !xres || !out0) : !X) return GPTST_EARG;
+    if (C != 64) return GPTST_ESHAPE;
+    HtChain ch;
+    ch.nstage = nstage; ch.X = X; ch.rec = rec; ch.Wn = Wn; ch.bn = bn; ch.xres = xres; ch.out0 = out0;
+    for (int s = 0; s < 3; ++s) {
+        const int k = s < nstage ? s : nstage - 1;
+        ch.st[s] = HtStage{((const float* const*)Gs)[k], ((const float* const*)Wbts)[k], ((const float* const*)bbts)[k],
+                           ((float* const*)Rs)[k], ((float* const*)outs)[k]};
+        if (!ch.st[s].G || !ch.st[s].Wbt || !ch.st[s].bbt || !ch.st[s].out) return GPTST_EARG;
+    }
+    const dim3 grid(8 * ((B + 7) / 8) * ((N + 15) / 16));
+    const int smem = (int)ht_smem(16);
+    hipStream_t st = (hipStream_t)stream;
+#define HTC_LAUNCH(NODE_, NS_) do {                                                                                                   \
+        static int done_ = 0;                                                                                                          \
+        if (!done_) { (void)hipFuncSetAttribute((const void*)hypertem_chain_fwd_kernel<NODE_, NS_>, hipFuncAttributeMaxDynamicSharedMemorySize, smem); done_ = 1; } \
+        hipLaunchKernelGGL((hypertem_chain_fwd_kernel<NODE_, NS_>), grid, dim3(256), smem, st, ch, N, B);                              \
+    } while (0)
+    if (node) { if (nstage == 1) HTC_LAUNCH(true, 1); else if (nstage == 2) HTC_LAUNCH(true, 2); else HTC_LAUNCH(true, 3); }
+    else { if (nstage == 1) HTC_LAUNCH(false, 1); else if (nstage == 2) HTC_LAUNCH(false, 2); else HTC_LAUNCH(false, 3); }
+#undef HTC_LAUNCH
+    GPTST_CHECK_LAUNCH();
+    return GPTST_OK;
+}

@@ -260,8 +260,8 @@ def hypertem_core_bwd(saved, dout, dG_out, dims, chain=False, premul=False):
 FUSE_CROSS = os.environ.get("GPTST_FUSE_CROSS", "1") == "1"     # cross-time block folded into its (b,t)-grouped neighbours (r03)
 
 
-def cap_core_fwd(p, pfx, x, dadj, dyn, Wn, bn, dims, num_route, HS, HT):
-    """x (BTN,C); dadj (BT,HS*N), dyn (B,HT,T*HS), Wn (N,C,C), bn (N,C) precomputed -> out, c (BT,HS,N), saved."""
+def cap_head_fwd(p, pfx, x, dadj, dyn, dims, num_route, HS, HT):
+    """cap up to the cluster -> node scatter (GPTST.py:102-135): x (BTN,C) -> rec (BTN,C), c (BT,HS,N), (s, v, Ht, Rt, Y)."""
     B, T, N, C = dims
     c, s, Y = ops.cap_route_fwd(x.view(B, T, N, C), p[pfx + "ln_p.weight"], p[pfx + "ln_p.bias"], dadj, HS, num_route,
                                 reduce_nodes=CTX.NODE_REDUCE, want_Y=True)                                            # :102-123
@@ -271,8 +271,40 @@ def cap_core_fwd(p, pfx, x, dadj, dyn, Wn, bn, dims, num_route, HS, HT):
     else:
         v, Ht, Rt = ops.cap_cross_fwd(s, dyn, p[pfx + "mask_template"], B, T, HS, HT)                                 # :125-134
         rec = ops.cap_rec_fwd(c, v, N, C)                                                                             # :135
+    return rec, c, (s, v, Ht, Rt, Y)
+
+
+def cap_core_fwd(p, pfx, x, dadj, dyn, Wn, bn, dims, num_route, HS, HT):
+    """x (BTN,C); dadj (BT,HS*N), dyn (B,HT,T*HS), Wn (N,C,C), bn (N,C) precomputed -> out, c (BT,HS,N), saved."""
+    B, T, N, C = dims
+    rec, c, (s, v, Ht, Rt, Y) = cap_head_fwd(p, pfx, x, dadj, dyn, dims, num_route, HS, HT)
     out = ops.apply(rec, Wn, MODE_NODE, B * T, N, bias=bn, resid=x, epi=EPI_RES_LRELU)                                # :139-141
     return out, c, (x, out, rec, c, s, v, Ht, Rt, dyn, Wn, Y)
+
+
+# Forward chains on the (sample, 16-node) slab (r04, gptst_hypertem_chain_fwd): the node-conditioned layer that ends a cap and the hyperTem
+# layers behind it are node-local, so [cap1 node layer, hyperTem2, hyperTem3] and [cap2 node layer, hyperTem4 (, the next STHCN's hyperTem1)]
+# run as ONE launch each — 10 -> 7 launches per STHCN forward, and the chained layers have no load phase of their own.  GPTST_CHAIN_FWD=0: one
+# launch per layer.
+CHAIN_FWD = os.environ.get("GPTST_CHAIN_FWD", "1") == "1"
+
+
+def chain_fwd_ok(dims):
+    return CHAIN_FWD and dims[3] == 64 and CTX.NODE_REDUCE is None and CTX.SIDE is None and not DROP_R
+
+
+def cap_tail_chain_fwd(x, rec, Wn, bn, stages, dims):
+    """node layer of a cap + the hyperTem layers behind it in one launch -> out of the cap, [(saved tuple of each hyperTem layer)], last output.
+    stages: [(G, Wbt, bbt), ...]"""
+    B, T, N, C = dims
+    out0, res = ops.hypertem_chain_fwd(None, stages, node=(rec, Wn, bn, x.view(B, T, N, C)))
+    out0 = out0.view(-1, C)
+    saved, xin = [], out0
+    for (G, Wbt, _), (R, o) in zip(stages, res):
+        o = o.view(-1, C)
+        saved.append((xin, R.view(-1, C), o, G, Wbt))
+        xin = o
+    return out0, saved, xin
 
 
 def cap_core_bwd(p, g, pfx, saved, dout, dims, HS, HT, red, chain=False):
@@ -430,21 +462,44 @@ def gen_all(p, tidx, dims, which=(ENC, DEC), guide=True, side=None):
     return res
 
 
-def sthcn_fwd(p, pfx, tidx, x, dims, num_route, gen=None):
+def sthcn_fwd(p, pfx, tidx, x, dims, num_route, gen=None, head=None, next_gen=None):
+    """head: (x after hyperTem1, its saved tuple) when the previous STHCN's last chain already ran this one's first layer;
+    next_gen: gen dict of the NEXT STHCN — its hyperTem1 then rides on this one's last chain; -> x, c1, saved[, next head]."""
     if gen is None:
         gen = gen_all(p, tidx, dims, which=(pfx,), guide=False)[pfx]
     A_all, hts, cps, d, Hm, ds, HS, HT = gen["gen"]
     G_all, Wb, Wn, dadj, dyn = gen["G_all"], gen["Wb"], gen["Wn"], gen["dadj"], gen["dyn"]
     sv = {}
-    x, sv["h1"] = hypertem_core_fwd(x, G_all[0], Wb[0], Wb[1], dims)
-    x, c1, sv["c1"] = cap_core_fwd(p, cps[0], x, dadj[0], dyn[0], Wn[0], Wn[1], dims, num_route, HS, HT)
-    x, sv["h2"] = hypertem_core_fwd(x, G_all[1], Wb[2], Wb[3], dims)
-    x, sv["h3"] = hypertem_core_fwd(x, G_all[2], Wb[4], Wb[5], dims)
-    x, _, sv["c2"] = cap_core_fwd(p, cps[1], x, dadj[1], dyn[1], Wn[2], Wn[3], dims, num_route, HS, HT)
-    x, sv["h4"] = hypertem_core_fwd(x, G_all[3], Wb[6], Wb[7], dims)
+    nhead = None
+    if head is not None:
+        x, sv["h1"] = head
+    else:
+        x, sv["h1"] = hypertem_core_fwd(x, G_all[0], Wb[0], Wb[1], dims)
+    if chain_fwd_ok(dims):
+        rec, c1, (s, v, Ht, Rt, Y) = cap_head_fwd(p, cps[0], x, dadj[0], dyn[0], dims, num_route, HS, HT)
+        o, (sv["h2"], sv["h3"]), x3 = cap_tail_chain_fwd(x, rec, Wn[0], Wn[1], [(G_all[1], Wb[2], Wb[3]), (G_all[2], Wb[4], Wb[5])], dims)
+        sv["c1"] = (x, o, rec, c1, s, v, Ht, Rt, dyn[0], Wn[0], Y)
+        rec, c2, (s, v, Ht, Rt, Y) = cap_head_fwd(p, cps[1], x3, dadj[1], dyn[1], dims, num_route, HS, HT)
+        stages = [(G_all[3], Wb[6], Wb[7])]
+        if next_gen is not None:
+            stages.append((next_gen["G_all"][0], next_gen["Wb"][0], next_gen["Wb"][1]))
+        o, hs, xl = cap_tail_chain_fwd(x3, rec, Wn[2], Wn[3], stages, dims)
+        sv["c2"] = (x3, o, rec, c2, s, v, Ht, Rt, dyn[1], Wn[2], Y)
+        sv["h4"] = hs[0]
+        x = hs[0][2]
+        if next_gen is not None:
+            nhead = (xl, hs[1])
+    else:
+        x, c1, sv["c1"] = cap_core_fwd(p, cps[0], x, dadj[0], dyn[0], Wn[0], Wn[1], dims, num_route, HS, HT)
+        x, sv["h2"] = hypertem_core_fwd(x, G_all[1], Wb[2], Wb[3], dims)
+        x, sv["h3"] = hypertem_core_fwd(x, G_all[2], Wb[4], Wb[5], dims)
+        x, _, sv["c2"] = cap_core_fwd(p, cps[1], x, dadj[1], dyn[1], Wn[2], Wn[3], dims, num_route, HS, HT)
+        x, sv["h4"] = hypertem_core_fwd(x, G_all[3], Wb[6], Wb[7], dims)
     sv["emb"] = gen["emb"]
     sv["gen"] = gen["gen"]
     sv["slot"] = gen.get("slot")
+    if next_gen is not None:
+        return x, c1, sv, nhead
     return x, c1, sv
 
 
@@ -594,19 +649,24 @@ def _in_proj_grads(source, base, dY, gW, gb, mask, fill, red):
         ops.rowouter(source, base + 2, base, dY, gW, 0, csum=gb, mask=mask, fill=fill)
 
 
-def model_fwd(p, source, mask, dims, base, num_route, scaler_zeros, gen=None, tidx=None):
-    """Masked-autoencoder body — GPTST.py:415-421 + 453-456.  mask (BTN*base) fp32, 1 = visible; None -> no masking (eval)."""
+def model_fwd(p, source, mask, dims, base, num_route, scaler_zeros, gen=None, tidx=None, dec_gen=None):
+    """Masked-autoencoder body — GPTST.py:415-421 + 453-456.  mask (BTN*base) fp32, 1 = visible; None -> no masking (eval).
+    dec_gen: the decoder STHCN's gen dict — its first hyperTem layer then rides on the encoder's last chain launch and the result comes back
+    as a fifth value, to be passed to decoder_fwd(dec_head=...) (None when the chain path does not serve the shape)."""
     B, T, N, C = dims
     if tidx is None:
         tidx = source[:, :, 0, base:base + 2].contiguous()
     x0 = ops.lin_in(source, base + 2, base, p["encoder.dim_in_flow.weight"], p["encoder.dim_in_flow.bias"], C,
                     mask=mask, fill=scaler_zeros)                                                          # :416-418
+    if dec_gen is not None:
+        emb, c1, sv_e, dec_head = sthcn_fwd(p, ENC, tidx, x0, dims, num_route, gen=gen, next_gen=dec_gen)
+        return emb, c1, tidx, sv_e, dec_head
     emb, c1, sv_e = sthcn_fwd(p, ENC, tidx, x0, dims, num_route, gen=gen)                                  # :421
     return emb, c1, tidx, sv_e
 
 
-def decoder_fwd(p, tidx, emb, dims, num_route, gen=None, head=True):
-    dec, _, sv_d = sthcn_fwd(p, DEC, tidx, emb, dims, num_route, gen=gen)                                  # :454
+def decoder_fwd(p, tidx, emb, dims, num_route, gen=None, head=True, dec_head=None):
+    dec, _, sv_d = sthcn_fwd(p, DEC, tidx, emb, dims, num_route, gen=gen, head=dec_head)                   # :454
     if not head:
         return None, dec, sv_d
     out = ops.rowdot(dec, p["decoder.dim_flow_out.weight"], p["decoder.dim_flow_out.bias"])                 # :455

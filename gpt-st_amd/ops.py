@@ -292,6 +292,26 @@ def hypertem_fwd(X, G, Wbt, bbt, want_R=True):
     return R, out
 
 
+def hypertem_chain_fwd(X, stages, node=None, want_R=True):
+    """Consecutive hyperTem layers (and optionally the node-conditioned layer of a cap in front) in ONE launch on the (sample, 16-node)
+    slab (gptst_hypertem_chain_fwd, C = 64).  X (B,T,N,C): input of the first layer, ignored with node;  stages: [(G, Wbt, bbt), ...] (1..3);
+    node: (rec (B*T*N,C), Wn (N,C,C), bn (N,C), xres (B*T*N,C)) -> out0 = LReLU(rec W_n + b_n + xres).
+    -> (out0 or None, [(R or None, out), ...]), all (B,T,N,C)."""
+    ref = X if node is None else node[3]
+    B, T, N, C = ref.shape if ref.dim() == 4 else X.shape
+    _chk(X if node is None else None, *(node or ()), *[t for st in stages for t in st])
+    f = lambda: torch.empty(B, T, N, C, device=ref.device, dtype=torch.float32)
+    out0 = f() if node is not None else None
+    Rs = [f() if want_R else None for _ in stages]
+    outs = [f() for _ in stages]
+    rec, Wn, bn, xres = node if node is not None else (None, None, None, None)
+    _call("gptst_hypertem_chain_fwd", _p(X) if node is None else None, _p(rec), _p(Wn), _p(bn), _p(xres), _p(out0), len(stages),
+          _ptrs0([st[0] for st in stages]), _ptrs0([st[1] for st in stages]), _ptrs0([st[2] for st in stages]),
+          _ptrs0(Rs), _ptrs0(outs), B, T, N, C, tag="node%d x%d" % (node is not None, len(stages)),
+          nbytes=_nb(X if node is None else None, rec, xres, out0, *Rs, *outs))
+    return out0, list(zip(Rs, outs))
+
+
 def hypertem_ntiles(N):
     return _C.lib().value("gptst_hypertem_ntiles", N)
 

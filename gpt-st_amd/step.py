@@ -138,10 +138,15 @@ class PretrainStep:
         self.last_mask = mask
         if self.gen_side is not None:
             self.gen_side.join()
-        emb, c1, tidx, sv_e = engine.model_fwd(p, src, mask, dims, base, mdl.num_route, mdl.scaler_zeros, gen=gen[engine.ENC], tidx=tidx)
+        dec_head = None
+        if engine.chain_fwd_ok(dims):          # the decoder's first hyperTem layer rides on the encoder's last chain launch
+            emb, c1, tidx, sv_e, dec_head = engine.model_fwd(p, src, mask, dims, base, mdl.num_route, mdl.scaler_zeros, gen=gen[engine.ENC], tidx=tidx,
+                                                             dec_gen=gen[engine.DEC])
+        else:
+            emb, c1, tidx, sv_e = engine.model_fwd(p, src, mask, dims, base, mdl.num_route, mdl.scaler_zeros, gen=gen[engine.ENC], tidx=tidx)
         if self.fused_tails:
             # output head + masked MAE + their backward: one pass over dec (the mean's 1/#kept is applied by the optimiser)
-            _, dec, sv_d = engine.decoder_fwd(p, tidx, emb, dims, mdl.num_route, gen=gen[engine.DEC], head=False)
+            _, dec, sv_d = engine.decoder_fwd(p, tidx, emb, dims, mdl.num_route, gen=gen[engine.DEC], head=False, dec_head=dec_head)
             sws = self.arena.zeros(ops.tail_parts(M), 4)                       # per-workgroup loss statistics of the two heads
             chain = engine.chain_ok(dims)                                      # dPre chain: no backward kernel re-reads its layer's output
 
@@ -162,7 +167,7 @@ class PretrainStep:
             else:
                 ops.stats_fold(sws, self.stats)                                # ordered sum -> stats[0..2]: the all-reduce must see them
         else:
-            out, dec, sv_d = engine.decoder_fwd(p, tidx, emb, dims, mdl.num_route, gen=gen[engine.DEC])
+            out, dec, sv_d = engine.decoder_fwd(p, tidx, emb, dims, mdl.num_route, gen=gen[engine.DEC], dec_head=dec_head)
             ops.mae_fwd(out, src, base + 2, mask, self.std, self.mean, a.mape_thresh, M, base, self.stats)
             d_out = ops.mae_bwd(out, src, base + 2, mask, self.std, self.mean, a.mape_thresh, M, base, self.stats, normalize=False)
             engine.model_bwd(p, g, src, mask, tidx, sv_e, sv_d, dec, d_out, None, dims, base, mdl.scaler_zeros, red)

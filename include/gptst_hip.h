@@ -22,7 +22,7 @@
 extern "C" {
 #endif
 
-#define GPTST_ABI_VERSION 7
+#define GPTST_ABI_VERSION 8
 int gptst_abi_version(void);
 /* 1: bit-reproducible steps — the two reductions that end in float atomics by default (embedding gradients of gptst_pool_jobs kind 2,
  * weight gradients of gptst_timefeat_jobs) run as single-owner kernels with a fixed summation order (slower).  Everything else is
@@ -130,6 +130,16 @@ int gptst_tmix_bwd(const float* dR, const float* X, const float* G, const float*
  * Replaces GPTST.py:157-158 + :162-163. */
 int gptst_hypertem_fwd(const float* X, const float* G, const float* Wbt, const float* bbt, float* R_out, float* out, int B, int T,
                        int N, int C, void* stream);
+/* hyperTem forward CHAIN (r04): nstage (1..3) consecutive hyperTem layers in ONE launch on the (sample, 16-node) slab — every one of them is
+ * node-local, so a layer's output goes from the accumulators back into the LDS slab (and to HBM once, for the backward) and the next layer
+ * starts from it: no load phase, no launch boundary in between.  Optionally preceded by the node-conditioned layer that ends a cap,
+ * out0 = LReLU(rec W_n + b_n + xres) (GPTST.py:137-141), computed per (sample, node) with the 12 time steps as MFMA rows: rec, Wn (N,C,C),
+ * bn (N,C), xres, out0 all given, or rec == NULL and X = the first layer's input.  Gs, Wbts, bbts, Rs, outs: HOST arrays of nstage device
+ * pointers (G (N,T,T), W_bt (B*T,C,C), b_bt (B*T,C), R_out or NULL, out), read at call time.  Same results as the per-layer calls up to the
+ * summation order of the node layer.  C = 64 (GPTST_ESHAPE otherwise).  Replaces GPTST.py:139-141 + 2 x (:157-163) per launch. */
+int gptst_hypertem_chain_fwd(const float* X, const float* rec, const float* Wn, const float* bn, const float* xres, float* out0, int nstage,
+                             const void* Gs, const void* Wbts, const void* bbts, const void* Rs, const void* outs, int B, int T, int N, int C,
+                             void* stream);
 
 /* "dPre chain" convention of the backward kernels (r03): the gradient that travels down the layer chain may be handed over ALREADY multiplied
  * by the LeakyReLU derivative of the activation it belongs to (dPre = dOut * lrelu'(out)).  A consumer is told so by Y == NULL (it then

@@ -1030,3 +1030,33 @@ def test_cap_route_fwd3_matches_second_generation(B, N, HS, R, occ6):
     assert not torch.equal(c2, c3) or N <= 16, "both calls ran the same kernel?"
     close(c3, c2.cpu(), tol=2e-6, what="route3 c")
     close(s3, s2.cpu(), tol=2e-6, what="route3 s")
+
+
+@pytest.mark.parametrize("B,N,nstage,node", [(32, 170, 2, True), (32, 170, 1, True), (32, 170, 2, False), (3, 20, 3, True), (2, 37, 3, False),
+                                             (5, 16, 1, False), (1, 250, 2, True)])
+def test_hypertem_chain_fwd_equals_layer_calls(B, N, nstage, node):
+    """gptst_hypertem_chain_fwd (node layer of a cap + up to three hyperTem layers on the LDS slab, one launch) against the per-layer entry
+    points: the hyperTem stages are the same arithmetic in the same order (bit-identical given the same input), the node layer differs from
+    apply64 only in the order of the MFMA k-steps."""
+    from gptst_amd import ops
+    from gptst_amd.ops import MODE_NODE, EPI_RES_LRELU
+    dev = _dev()
+    g = torch.Generator().manual_seed(81 + N)
+    C, T = 64, 12
+    X = rnd(B, T, N, C, g=g, scale=0.7).to(dev)
+    stages = [((rnd(N, T, T, g=g) * 0.2).to(dev), (rnd(B * T, C, C, g=g) * 0.1).to(dev), (rnd(B * T, C, g=g) * 0.3).to(dev)) for _ in range(nstage)]
+    nd = None
+    x = X
+    if node:
+        rec, Wn, bn = rnd(B * T * N, C, g=g).to(dev), (rnd(N, C, C, g=g) * 0.1).to(dev), (rnd(N, C, g=g) * 0.3).to(dev)
+        nd = (rec, Wn, bn, X)
+        x = ops.apply(rec, Wn, MODE_NODE, B * T, N, bias=bn, resid=X.view(-1, C), epi=EPI_RES_LRELU).view(B, T, N, C)
+    out0, res = ops.hypertem_chain_fwd(None if node else X, stages, node=nd)
+    if node:
+        close(out0, x.cpu(), tol=2e-6, what="chain node layer")
+        x = out0                                              # the following layers are compared on the chain's own input
+    for k, ((G, Wbt, bbt), (R, o)) in enumerate(zip(stages, res)):
+        R1, o1 = ops.hypertem_fwd(x, G, Wbt, bbt)
+        assert torch.equal(R, R1), "R of chained layer %d" % k
+        assert torch.equal(o, o1), "out of chained layer %d" % k
+        x = o1

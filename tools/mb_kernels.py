@@ -61,6 +61,10 @@ CASES = {
     "cap_rec_bwd": lambda: ops.cap_rec_bwd(dO2, c, v),
     "cap_cross_bwd": lambda: ops.cap_cross_bwd(dv, s, Rt, Ht, dyn, tmpl, B, T, HS, HT),
     "cap_route_bwd": lambda: ops.cap_route_bwd(X, Wp, bp, c, dc1, dS),
+    "chain_node_ht_ht": lambda: ops.hypertem_chain_fwd(None, [(G, Wbt, bbt), (G, Wbt, bbt)], node=(rec, Wn, bn, X)),
+    "chain_node_ht": lambda: ops.hypertem_chain_fwd(None, [(G, Wbt, bbt)], node=(rec, Wn, bn, X)),
+    "chain_ht_ht": lambda: ops.hypertem_chain_fwd(X, [(G, Wbt, bbt), (G, Wbt, bbt)]),
+    "chain_ht": lambda: ops.hypertem_chain_fwd(X, [(G, Wbt, bbt)]),
     "copy_A": lambda: X2.clone(),
     "tail_mae": lambda: ops.tail_mae(X2, Wo, bo, src, 3, mask, 146.0, 230.0, 0.0, sws),
     "tail_kl": lambda: ops.tail_kl(X2, W3, prob, c, N, 0.1, sws),
