@@ -287,10 +287,23 @@ def cap_core_fwd(p, pfx, x, dadj, dyn, Wn, bn, dims, num_route, HS, HT):
 # run as ONE launch each — 10 -> 7 launches per STHCN forward, and the chained layers have no load phase of their own.  GPTST_CHAIN_FWD=0: one
 # launch per layer.
 CHAIN_FWD = os.environ.get("GPTST_CHAIN_FWD", "1") == "1"
+CHAIN_NODE = os.environ.get("GPTST_CHAIN_NODE", "0") == "1"      # also the caps' node layers inside the chain launches (measured slower: see sthcn_fwd)
 
 
 def chain_fwd_ok(dims):
     return CHAIN_FWD and dims[3] == 64 and CTX.NODE_REDUCE is None and CTX.SIDE is None and not DROP_R
+
+
+def ht_chain_fwd(x, stages, dims):
+    """consecutive hyperTem layers in one launch -> [saved tuple per layer], last output.  stages: [(G, Wbt, bbt), ...]"""
+    B, T, N, C = dims
+    _, res = ops.hypertem_chain_fwd(x.view(B, T, N, C), stages)
+    saved, xin = [], x
+    for (G, Wbt, _b), (R, o) in zip(stages, res):
+        o = o.view(-1, C)
+        saved.append((xin, R.view(-1, C), o, G, Wbt))
+        xin = o
+    return saved, xin
 
 
 def cap_tail_chain_fwd(x, rec, Wn, bn, stages, dims):
@@ -475,7 +488,7 @@ def sthcn_fwd(p, pfx, tidx, x, dims, num_route, gen=None, head=None, next_gen=No
         x, sv["h1"] = head
     else:
         x, sv["h1"] = hypertem_core_fwd(x, G_all[0], Wb[0], Wb[1], dims)
-    if chain_fwd_ok(dims):
+    if chain_fwd_ok(dims) and CHAIN_NODE:
         rec, c1, (s, v, Ht, Rt, Y) = cap_head_fwd(p, cps[0], x, dadj[0], dyn[0], dims, num_route, HS, HT)
         o, (sv["h2"], sv["h3"]), x3 = cap_tail_chain_fwd(x, rec, Wn[0], Wn[1], [(G_all[1], Wb[2], Wb[3]), (G_all[2], Wb[4], Wb[5])], dims)
         sv["c1"] = (x, o, rec, c1, s, v, Ht, Rt, dyn[0], Wn[0], Y)
@@ -489,6 +502,19 @@ def sthcn_fwd(p, pfx, tidx, x, dims, num_route, gen=None, head=None, next_gen=No
         x = hs[0][2]
         if next_gen is not None:
             nhead = (xl, hs[1])
+    elif chain_fwd_ok(dims):
+        # hyperTem PAIRS on the slab; the caps' node layers stay on the node-grouped apply64 (it shares W_n over the 384 (b,t) rows of a node: 12.6 us
+        # against ~18 us for the per-sample form inside the chain launch, tools/mb_kernels.py chain)
+        x, c1, sv["c1"] = cap_core_fwd(p, cps[0], x, dadj[0], dyn[0], Wn[0], Wn[1], dims, num_route, HS, HT)
+        (sv["h2"], sv["h3"]), x = ht_chain_fwd(x, [(G_all[1], Wb[2], Wb[3]), (G_all[2], Wb[4], Wb[5])], dims)
+        x, _, sv["c2"] = cap_core_fwd(p, cps[1], x, dadj[1], dyn[1], Wn[2], Wn[3], dims, num_route, HS, HT)
+        if next_gen is not None:
+            hs, xl = ht_chain_fwd(x, [(G_all[3], Wb[6], Wb[7]), (next_gen["G_all"][0], next_gen["Wb"][0], next_gen["Wb"][1])], dims)
+            sv["h4"] = hs[0]
+            x = hs[0][2]
+            nhead = (xl, hs[1])
+        else:
+            x, sv["h4"] = hypertem_core_fwd(x, G_all[3], Wb[6], Wb[7], dims)
     else:
         x, c1, sv["c1"] = cap_core_fwd(p, cps[0], x, dadj[0], dyn[0], Wn[0], Wn[1], dims, num_route, HS, HT)
         x, sv["h2"] = hypertem_core_fwd(x, G_all[1], Wb[2], Wb[3], dims)

@@ -278,6 +278,7 @@ class PretrainStep:
         where an fp32-level argmax flip of the cluster classifier would otherwise change which cells are masked."""
         phase = 0 if epoch <= self.args.change_epoch else 1
         self._g_last = None
+        self._g_fallback = None
         if source is not self.src:
             self.src.copy_(source, non_blocking=True)
         inject = noise is not None or noise_a is not None
@@ -320,6 +321,8 @@ class PretrainStep:
             print("gpt-st_amd: capturing the step with its collectives failed (%s: %s) -> collectives between graph replays"
                   % (type(e).__name__, str(e).splitlines()[0][:200]), file=sys.stderr)
             self._graph_comm_failed = True
+            self.graphs.clear()                         # graphs captured earlier hold the in-graph all-reduce + optimiser: replaying them next to
+            getattr(self, "_g_graphs", {}).clear()      # the eager collectives would reduce and step twice
             torch.cuda.synchronize()
             return self._capture_impl(key)
 
@@ -404,9 +407,12 @@ class PretrainStep:
         where a step is not one graph (eager mode, host-side collectives).  losses_group() returns the K loss triples."""
         K = len(sources)
         if K == 1 or not self.group_ok(epoch):
+            snaps = []                                  # every step's statistics (device copies, no sync): losses_group() returns K triples here too
             for j, src in enumerate(sources):
                 self.step(src, epoch, list_c=None if list_cs is None else list_cs[j])
+                snaps.append((self.stats_out.clone(), bool(self.tB and self.phase_kl)))
             self._g_last = None
+            self._g_fallback = snaps
             return
         phase = 0 if epoch <= self.args.change_epoch else 1
         self._group_init(K)
@@ -496,6 +502,14 @@ class PretrainStep:
     def losses_group(self):
         """[(loss, loss_flow, loss_s)] of the steps of the last step_group() — synchronises."""
         if self._g_last is None:
+            if getattr(self, "_g_fallback", None):      # step_group() fell back to single steps: one triple per step, as the grouped path
+                out = []
+                for st, kl in self._g_fallback:
+                    st = st.cpu()
+                    lf = float(st[0] / max(float(st[1]), 1.0))
+                    ls = float(st[2]) * 0.1 if kl else 0.0
+                    out.append((lf + ls, lf, ls))
+                return out
             return [self.losses()]
         K, phase = self._g_last
         st = self._g_stats.cpu()

@@ -303,6 +303,8 @@ def test_step_group_falls_back_to_single_steps_when_the_capture_fails(monkeypatc
         st.step_group(srcs, 2)
         st.step_group(srcs, 2)
         assert st.tA == 8 and bool(getattr(st, "_group_failed", False)) == broken
-        outs.append((model.flat.clone(), st.losses()))
+        outs.append((model.flat.clone(), st.losses(), st.losses_group()))
     assert outs[0][1] == outs[1][1]
     assert torch.equal(outs[0][0], outs[1][0])
+    # the fallback reports one loss triple PER STEP, like the grouped path (the trainer's epoch average and best-model selection use them)
+    assert len(outs[1][2]) == 4 and outs[0][2] == outs[1][2]

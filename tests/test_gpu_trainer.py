@@ -115,3 +115,30 @@ def test_trainer_train_saves_reference_format_checkpoint(tmp_path):
     assert all(torch.equal(ck[k], best[k].cpu()) for k in ck)
     last = tr.train_epoch(6)
     assert last < first and last == last
+
+
+def test_epoch_average_counts_every_step_when_a_group_falls_back(monkeypatch):
+    """when PretrainStep.step_group() cannot capture K steps in one graph it runs them one by one — the trainer's flush() must still
+    account K loss triples (it averaged every K-th step before), so the epoch average that feeds best-model selection equals the one of
+    a run with one replay per step."""
+    from gptst_amd.model import GPTST_Model
+    from gptst_amd.trainer import Trainer
+    monkeypatch.setenv("GPTST_DETERMINISTIC", "1")
+    avgs = []
+    for broken in (False, True):
+        args = _args()
+        args.log_dir = "/tmp/gptst_test_fallback"
+        args.steps_per_replay = 4 if broken else 1
+        sd = O.init_state_dict(args, 4)
+        model = GPTST_Model(args); model.load_state_dict(sd); model = model.to(DEV)
+        batches = [synth.make_batch(4, 12, 20, 1, seed=300 + k, start_slot=5 * k).to(DEV) for k in range(8)]
+        tr = Trainer(model, args, lambda e: iter(batches), synth.SCALER_MEAN, synth.SCALER_STD, batch_size=4)
+        tr.logger.setLevel(logging.WARNING)
+        if broken:
+            def boom(*a, **k):
+                raise RuntimeError("operation not permitted when stream is capturing")
+            monkeypatch.setattr(tr.step, "_capture_group", boom)
+        avgs.append(tr.train_epoch(1))
+        assert tr.step.tA == 8
+        assert bool(getattr(tr.step, "_group_failed", False)) == broken
+    assert abs(avgs[0] - avgs[1]) <= 1e-5 * abs(avgs[0]), avgs
