@@ -311,9 +311,10 @@ def main():
     if a.shard == "nodes" or a.no_graph or not stepper.group_ok(a.epoch):
         G = 1
     if G > 1:
-        gsrcs = stepper.group_sources(G)             # G consecutive steps per graph replay (PretrainStep.step_group): G input buffers
-        for t_ in gsrcs:
-            t_.copy_(src)
+        gsrcs = stepper.group_sources(G)             # G consecutive steps per graph replay (PretrainStep.step_group): G input buffers,
+        for j_, t_ in enumerate(gsrcs):              # holding G DIFFERENT synthetic batches (r03 review: they were G copies of one)
+            t_.copy_(src if j_ == 0 else synth.make_batch(B, T, N, args.input_base_dim, interval=args.interval, seed=2024 + rank + 7919 * j_,
+                                                          start_slot=1000 * rank + 37 * j_).to(dev))
 
     def run(n, epoch):
         """enqueue exactly n optimisation steps"""
@@ -383,12 +384,13 @@ def main():
         "n_gpus": a.gpus, "steps": a.steps, "warmup": a.warmup, "ms_per_step": 1e3 * el / a.steps,
         "higher_is_better": True, "scaling": "strong" if strong else "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
         "config": {"workload": "%s: %s-shape synthetic pretrain step, per-GPU B=%d T=%d N=%d C=%d base=%d, epoch %d/300 (%s), "
-                               "fwd+loss+bwd+clip+Adam, hipGraph=%s" % (
+                               "fwd+loss+bwd+clip+Adam, hipGraph=%s, %s" % (
                                    "BASELINE configs[4] shape (unsharded)" if (a.nodes or a.hidden) else
                                    {"PEMS08": "BASELINE configs[1]", "METR_LA": "BASELINE configs[2] shape", "NYC_TAXI": "BASELINE configs[3] shape"}.get(a.dataset, a.dataset),
                                    a.dataset, B, T, N, C, args.input_base_dim, a.epoch,
                                    "adaptive mask + KL" if a.epoch > args.change_epoch else "random mask",
-                                   bool(getattr(stepper, "shard_graph", False)) if a.shard == "nodes" else not a.no_graph),
+                                   bool(getattr(stepper, "shard_graph", False)) if a.shard == "nodes" else not a.no_graph,
+                                   ("%d full optimiser steps on %d different resident batches per graph replay" % (G, G)) if G > 1 else "one step per replay"),
                    "global_batch": gbatch,
                    "parallelism": ("nodes%d" if a.shard == "nodes" else "dp%d") % a.gpus},
         "samples_per_s": steps_s * gbatch,
@@ -454,6 +456,26 @@ def main():
         top = sorted(kt.items(), key=lambda kv: -kv[1]["total_s"])[:12]
         out["kernel_breakdown_us_per_step"] = {"%s[%s]" % k: round(1e6 * v["total_s"], 1) for k, v in top}
         out["kernel_time_sum_us_per_step_eager"] = round(1e6 * tot, 1)
+    if dp is not None and getattr(dp, "native", None) is not None and a.shard != "nodes":
+        # per-collective durations (HIP event pair around each RCCL enqueue of three eager steps, on the launch stream) — with the bucketed
+        # exchange: the decoder bucket (under the encoder's backward), the encoder bucket and [KL | statistics] behind the chain, the label gather
+        from gptst_amd import dist as gdist
+        stepper.use_graph = False
+        stepper.step(stepper.src, a.epoch)
+        torch.cuda.synchronize()
+        gdist.COMM_TIMER = []
+        for _ in range(3):
+            stepper.step(stepper.src, a.epoch)
+        torch.cuda.synchronize()
+        rec, gdist.COMM_TIMER = gdist.COMM_TIMER, None
+        agg = {}
+        for what, nb, e0, e1 in rec:
+            v = agg.setdefault("%s[%.2f MB]" % (what, nb / 1e6), [0.0, 0])
+            v[0] += e0.elapsed_time(e1) * 1e3
+            v[1] += 1
+        out["collectives_us"] = {k: round(v[0] / v[1], 1) for k, v in agg.items()}
+        out["collectives_per_step"] = len(rec) // 3
+        out["dp_overlap"] = bool(getattr(stepper, "dp_overlap", False))
     if not a.no_cpu_baseline and world == 1:
         out["cpu_baseline"] = cpu_baseline(args, B)
     print(json.dumps(out))

@@ -11,6 +11,7 @@ import torch  # noqa: F401  (loads libamdhip64 first)
 HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("GPTST_LIB") or os.path.join(HERE, "lib", "libgptst_hip.so")     # GPTST_LIB: another build of the library (A/B runs on one box)
 HEADER = os.path.join(os.path.dirname(HERE), "include", "gptst_hip.h")
+TESTING_HEADER = os.path.join(os.path.dirname(HERE), "include", "gptst_hip_testing.h")      # test / benchmark hooks, not part of the C ABI
 
 _CT = {"int": ctypes.c_int, "long": ctypes.c_long, "float": ctypes.c_float, "double": ctypes.c_double,
        "int64_t": ctypes.c_int64, "uint64_t": ctypes.c_uint64, "size_t": ctypes.c_size_t}
@@ -55,6 +56,7 @@ class _Lib:
             raise ImportError("gpt-st_amd: %s not built — run `python -m gptst_amd.build` (no CPU fallback exists)" % LIB_PATH)
         self._dll = ctypes.CDLL(LIB_PATH)
         self.protos = parse_header()
+        self.protos.update(parse_header(TESTING_HEADER))
         for name, types in self.protos.items():
             fn = getattr(self._dll, name)          # AttributeError if the header declares a missing symbol
             fn.argtypes = types

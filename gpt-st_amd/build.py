@@ -13,7 +13,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIBDIR = os.path.join(HERE, "lib")
 LIB = os.path.join(LIBDIR, "libgptst_hip.so")
-FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wno-unused-result"] + os.environ.get("GPTST_EXTRA_HIPCC_FLAGS", "").split()
+FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-fvisibility=hidden", "-Wno-unused-result"] + os.environ.get("GPTST_EXTRA_HIPCC_FLAGS", "").split()
 
 
 def _hipcc():
@@ -27,7 +27,7 @@ def build(force=False, verbose=False):
     os.makedirs(LIBDIR, exist_ok=True)
     srcs = sorted(f for f in os.listdir(CSRC) if f.endswith(".hip"))
     hdrs = [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith(".h")]
-    hdrs.append(os.path.join(os.path.dirname(HERE), "include", "gptst_hip.h"))
+    hdrs += [os.path.join(os.path.dirname(HERE), "include", h) for h in ("gptst_hip.h", "gptst_hip_testing.h")]
     newest_hdr = max(os.path.getmtime(h) for h in hdrs if os.path.exists(h))
     cc = _hipcc()
     objs, jobs = [], []
@@ -49,7 +49,12 @@ def build(force=False, verbose=False):
     with ThreadPoolExecutor(max_workers=max(1, min(8, len(jobs) or 1))) as ex:
         list(ex.map(run, jobs))
     if jobs or not os.path.exists(LIB):
-        run([cc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB] + objs + ["-ldl"])
+        # exports: the gptst_* entry points the headers declare and nothing else — -fvisibility=hidden covers functions, but hipcc gives the
+        # kernel handle objects default visibility whatever the flag says (r03: 378 of them next to the API), so the linker drops the rest
+        vmap = os.path.join(LIBDIR, "exports.map")
+        with open(vmap, "w") as f:
+            f.write("{ global: gptst_*; local: *; };\n")
+        run([cc, "--offload-arch=gfx950", "-shared", "-fPIC", "-Wl,--version-script=" + vmap, "-o", LIB] + objs + ["-ldl"])
     return LIB
 
 

@@ -20,8 +20,7 @@ typedef int (*CommCount_t)(void*, int*);
 typedef int (*AllGather_t)(const void*, void*, size_t, int, void*, hipStream_t);
 struct Api { void* lib; GetUniqueId_t uid; CommInitRank_t init; AllReduce_t allreduce; CommDestroy_t destroy; CommCount_t count; AllGather_t allgather; };
 Api g_api = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
-void* g_comm = nullptr;
-int g_world = 0;
+struct Comm { void* nccl; int rank, world; };               // what a gptst communicator handle points to
 
 bool bind() {
     if (g_api.lib) return true;
@@ -47,46 +46,51 @@ extern "C" int gptst_comm_unique_id(void* out) {
     return rc == 0 ? GPTST_OK : 1000 + rc;
 }
 
-// one communicator per process (= per GPU: hipSetDevice first); unique_id: the 128 bytes of gptst_comm_unique_id
-extern "C" int gptst_comm_init(int rank, int world, const void* unique_id) {
-    if (!unique_id || world <= 0 || rank < 0 || rank >= world || g_comm) return GPTST_EARG;
+// A communicator of `world` ranks in which this process (its current device: hipSetDevice first) is `rank`; unique_id: the 128 bytes of
+// gptst_comm_unique_id, created by one rank of THIS communicator.  *comm_out receives the handle every collective takes.  A process may hold
+// several (r04: e.g. the row and the column of a data-parallel x node-shard mesh, SURVEY 8(e) "Combination"); RCCL serialises collectives of
+// different communicators that share a stream in enqueue order.
+extern "C" int gptst_comm_init(int rank, int world, const void* unique_id, void** comm_out) {
+    if (!unique_id || !comm_out || world <= 0 || rank < 0 || rank >= world) return GPTST_EARG;
     if (!bind()) return GPTST_ECOMM;
     Uid u = *(const Uid*)unique_id;
-    const int rc = g_api.init(&g_comm, world, u, rank);
-    if (rc != 0) { g_comm = nullptr; return 1000 + rc; }
-    g_world = world;
+    void* nc = nullptr;
+    const int rc = g_api.init(&nc, world, u, rank);
+    if (rc != 0) return 1000 + rc;
+    *comm_out = new Comm{nc, rank, world};
     return GPTST_OK;
 }
 
 // in-place sum over the ranks of buf[0..n) (fp32), enqueued on `stream` (capturable); dtype 7 = ncclFloat32, op 0 = ncclSum
-extern "C" int gptst_allreduce_f32(float* buf, long n, void* stream) {
+extern "C" int gptst_allreduce_f32(void* comm, float* buf, long n, void* stream) {
     if (!buf || n <= 0) return GPTST_EARG;
-    if (!g_comm) return GPTST_ECOMM;
-    const int rc = g_api.allreduce(buf, buf, (size_t)n, 7, 0, g_comm, (hipStream_t)stream);
+    if (!comm) return GPTST_ECOMM;
+    const int rc = g_api.allreduce(buf, buf, (size_t)n, 7, 0, ((Comm*)comm)->nccl, (hipStream_t)stream);
     return rc == 0 ? GPTST_OK : 1000 + rc;
 }
 
 // recv[r*n .. (r+1)*n) <- rank r's send[0..n) (32-bit words: labels, indices), enqueued on `stream` (capturable); dtype 2 = ncclInt32.
 // send may be recv + rank*n (in place).  GPTST_ECOMM when the communicator or ncclAllGather is missing (callers fall back to an all-reduce).
-extern "C" int gptst_allgather_i32(const int* send, int* recv, long n, void* stream) {
+extern "C" int gptst_allgather_i32(void* comm, const int* send, int* recv, long n, void* stream) {
     if (!send || !recv || n <= 0) return GPTST_EARG;
-    if (!g_comm || !g_api.allgather) return GPTST_ECOMM;
-    const int rc = g_api.allgather(send, recv, (size_t)n, 2, g_comm, (hipStream_t)stream);
+    if (!comm || !g_api.allgather) return GPTST_ECOMM;
+    const int rc = g_api.allgather(send, recv, (size_t)n, 2, ((Comm*)comm)->nccl, (hipStream_t)stream);
     return rc == 0 ? GPTST_OK : 1000 + rc;
 }
 
 // number of ranks RCCL itself reports for the communicator (ncclCommCount) -> *out; lets a launcher verify that the job's collectives really
 // span the ranks it started (bench.py prints it as rccl_ranks)
-extern "C" int gptst_comm_count(int* out) {
+extern "C" int gptst_comm_count(void* comm, int* out) {
     if (!out) return GPTST_EARG;
-    if (!g_comm || !g_api.count) return GPTST_ECOMM;
-    const int rc = g_api.count(g_comm, out);
+    if (!comm || !g_api.count) return GPTST_ECOMM;
+    const int rc = g_api.count(((Comm*)comm)->nccl, out);
     return rc == 0 ? GPTST_OK : 1000 + rc;
 }
 
-extern "C" int gptst_comm_destroy(void) {
-    if (!g_comm) return GPTST_OK;
-    const int rc = g_api.destroy(g_comm);
-    g_comm = nullptr; g_world = 0;
+extern "C" int gptst_comm_destroy(void* comm) {
+    if (!comm) return GPTST_OK;
+    Comm* c = (Comm*)comm;
+    const int rc = g_api.destroy(c->nccl);
+    delete c;
     return rc == 0 ? GPTST_OK : 1000 + rc;
 }

@@ -3,6 +3,8 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include "gptst_hip.h"               // the exported prototypes: default visibility (the build is -fvisibility=hidden) and checked against
+#include "gptst_hip_testing.h"       // the definitions by the compiler
 
 #define GPTST_OK 0
 #define GPTST_EARG (-1)      // bad argument (shape / null pointer)

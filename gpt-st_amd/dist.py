@@ -110,12 +110,29 @@ def combine_local_gradients(local_bufs, nA, nB):
     return g, stats
 
 
+COMM_TIMER = None     # bench.py sets this to a list: (what, bytes, start_event, end_event) per collective enqueued through NativeComm
+
+
+def _timed(what, nbytes, fn):
+    if COMM_TIMER is None:
+        return fn()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    r = fn()
+    e1.record()
+    COMM_TIMER.append((what, nbytes, e0, e1))
+    return r
+
+
 class NativeComm:
     """The C-ABI communicator (csrc/comm.hip: RCCL with an explicit stream).  The 128-byte unique id is created on rank 0 and handed to
     the other ranks through an existing torch.distributed group (any backend) — the only use of torch.distributed here; the collectives
     themselves are plain enqueues on a HIP stream, so they can be captured inside a hipGraph together with the kernels around them."""
 
-    def __init__(self, rank=None, world=None):
+    def __init__(self, rank=None, world=None, group=None, src=0):
+        """rank / world: this process's rank in the communicator and its size (default: the job's RANK / WORLD_SIZE).
+        group / src: a torch.distributed group that holds exactly the communicator's ranks and the GLOBAL rank of its rank 0 — for the
+        sub-communicators of a mesh (mesh_comms below); the 128-byte id travels over that group."""
         import ctypes
         from . import _C
         self.lib = _C.lib()
@@ -126,16 +143,18 @@ class NativeComm:
             self.lib.call("gptst_comm_unique_id", uid)
         if self.world > 1:
             t = torch.tensor(list(bytes(uid)), dtype=torch.uint8)
-            if dist.get_backend() == "nccl":
+            if dist.get_backend(group) == "nccl":
                 t = t.cuda()
-            dist.broadcast(t, src=0)
+            dist.broadcast(t, src=src, group=group)
             uid = (ctypes.c_char * 128).from_buffer_copy(bytes(t.cpu().tolist()))
-        self.lib.call("gptst_comm_init", self.rank, self.world, uid)
+        self.h = ctypes.c_void_p()                       # communicator handle (r04: a process may hold several)
+        self.lib.call("gptst_comm_init", self.rank, self.world, uid, ctypes.byref(self.h))
 
     def allreduce_(self, buf):
         """in-place sum over the ranks, enqueued on torch's current stream"""
         assert buf.is_cuda and buf.dtype == torch.float32 and buf.is_contiguous()
-        self.lib.call("gptst_allreduce_f32", buf.data_ptr(), buf.numel(), torch.cuda.current_stream().cuda_stream)
+        _timed("allreduce_f32", 4 * buf.numel(),
+               lambda: self.lib.call("gptst_allreduce_f32", self.h, buf.data_ptr(), buf.numel(), torch.cuda.current_stream().cuda_stream))
         return buf
 
     def allgather_i32(self, local, out):
@@ -144,7 +163,8 @@ class NativeComm:
         assert out.numel() == self.world * local.numel()
         if getattr(self, "_no_allgather", False):
             return False
-        rc = self.lib.value("gptst_allgather_i32", local.data_ptr(), out.data_ptr(), local.numel(), torch.cuda.current_stream().cuda_stream)
+        rc = _timed("allgather_i32", 4 * out.numel(),
+                    lambda: self.lib.value("gptst_allgather_i32", self.h, local.data_ptr(), out.data_ptr(), local.numel(), torch.cuda.current_stream().cuda_stream))
         if rc == -4:                                    # GPTST_ECOMM: symbol missing
             self._no_allgather = True
             return False
@@ -156,8 +176,40 @@ class NativeComm:
         """ncclCommCount of the communicator"""
         import ctypes
         n = ctypes.c_int(0)
-        self.lib.call("gptst_comm_count", ctypes.byref(n))
+        self.lib.call("gptst_comm_count", self.h, ctypes.byref(n))
         return int(n.value)
 
     def close(self):
-        self.lib.call("gptst_comm_destroy")
+        if self.h:
+            self.lib.call("gptst_comm_destroy", self.h)
+            self.h = None
+
+
+def mesh_shape(world, n_shard):
+    """(data-parallel size, node-shard size) of a world laid out as a row-major (dp, shard) grid: rank = dp_index * n_shard + shard_index."""
+    assert n_shard >= 1 and world % n_shard == 0, (world, n_shard)
+    return world // n_shard, n_shard
+
+
+def mesh_groups(world, n_shard):
+    """The rank lists of the mesh's sub-communicators: ([ranks of each node-shard group (a row)], [ranks of each data-parallel group (a column)])."""
+    n_dp, n_shard = mesh_shape(world, n_shard)
+    rows = [[d * n_shard + s for s in range(n_shard)] for d in range(n_dp)]
+    cols = [[d * n_shard + s for d in range(n_dp)] for s in range(n_shard)]
+    return rows, cols
+
+
+def mesh_comms(n_shard, rank=None, world=None):
+    """SURVEY 8(e) "Combination": a B x N mesh — node shards inside a row (the cluster-aggregation all-reduces of shard.py), batch data
+    parallelism down a column (the gradient all-reduce / label gather of this module).  -> (shard_comm, dp_comm): two C-ABI communicators of
+    this rank (NativeComm), created over torch.distributed sub-groups (every rank calls new_group for every group, as torch requires)."""
+    rank = int(os.environ.get("RANK", "0")) if rank is None else rank
+    world = int(os.environ.get("WORLD_SIZE", "1")) if world is None else world
+    rows, cols = mesh_groups(world, n_shard)
+    mine = [None, None]
+    for k, groups in enumerate((rows, cols)):
+        for ranks in groups:
+            pg = dist.new_group(ranks) if world > 1 else None
+            if rank in ranks:
+                mine[k] = NativeComm(rank=ranks.index(rank), world=len(ranks), group=pg, src=ranks[0])
+    return mine[0], mine[1]

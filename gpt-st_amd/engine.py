@@ -120,6 +120,8 @@ class Reductions:
         self.keep = []
         self.side = side
         self.held = []
+        self.on_bucket = None    # callable(k): gradient bucket k is complete (k = 0: the decoder's) — called INSIDE the side-stream fork, right behind
+        self.nbucket = 0         # the reductions that finish it, so a data-parallel step can enqueue that bucket's all-reduce under the rest of the backward
 
     def gram(self, A, dG, dA, N, nsG):
         """A (L*N,Hm,T), dG (L, nsG, N, T, T) partial graph gradients, dA (L*N,Hm,T) output"""
@@ -131,17 +133,34 @@ class Reductions:
         self.tf.append((_tf_tensors(p, pfx), _tf_tensors(g, pfx), dout, rows, K))
 
     def flush_async(self, tidx):
-        """Run everything queued so far on the side stream (it depends only on finished layers of the backward); no-op without one."""
+        """Run everything queued so far on the side stream (it depends only on finished layers of the backward); no-op without one.
+        bucket_inline (a data-parallel step, GPTST_DP_OVERLAP=1): the reductions run HERE, on the calling stream (a side branch of ~1300
+        bandwidth-bound workgroups slows the chain it runs under by more than it hides: 717 vs 752 steps/s at one rank), and only the
+        bucket's all-reduce — a few RCCL workgroups — is forked under the rest of the backward."""
+        if getattr(self, "bucket_inline", False) and self.on_bucket is not None and self.nbucket == 0 and (self.jobs.jobs or self.grams or self.tf):
+            self._run(tidx)
+            self.fork_side.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(self.fork_side):
+                self.on_bucket(0)
+            self.forked = True
+            self.nbucket += 1
+            return
         if self.side is None or not (self.jobs.jobs or self.grams or self.tf):
             return
         self.held.append((self.keep, list(self.jobs.jobs), list(self.grams), list(self.tf)))      # alive until the join
         with self.side.fork():
             self._run(tidx)
+            if self.on_bucket is not None:
+                self.on_bucket(self.nbucket)
+        self.nbucket += 1
 
     def flush(self, tidx):
         self._run(tidx)
         if self.side is not None:
             self.side.join()
+        if getattr(self, "forked", False):
+            torch.cuda.current_stream().wait_stream(self.fork_side)
+            self.forked = False
         self.held = []
 
     def _run(self, tidx):

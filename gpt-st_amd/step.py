@@ -82,6 +82,18 @@ class PretrainStep:
         # opt-in: parameter-gradient reductions of finished layers on a second stream under the rest of the backward chain
         # (measured r02k: 558-579 vs 597 steps/s — the side kernels take CU slots from the chain, as the weight gradients did)
         self.red_side = engine.SideStream() if os.environ.get("GPTST_RED_STREAM", "0") == "1" else None
+        # r04, data parallel on the capturable communicator: the gradient leaves in BUCKETS — the decoder's parameters are complete when the decoder's
+        # backward ends, so their reductions + all-reduce run on a forked branch UNDER the encoder's backward; only the encoder / KL bucket
+        # is exchanged behind the chain (one 4.15 MB all-reduce behind everything before).  GPTST_DP_OVERLAP=0: the single all-reduce.
+        # GPTST_DP_OVERLAP: 1 (default) = the bucket's reductions on the chain's stream, only its all-reduce forked; 2 = reductions AND all-reduce forked
+        # (measured at one rank: 2 costs 5 % — the branch's ~1300 bandwidth-bound workgroups slow the encoder's backward); 0 = off
+        self.dp_overlap_mode = int(os.environ.get("GPTST_DP_OVERLAP", "1"))
+        self.dp_overlap = (self.dp_overlap_mode > 0 and dp is not None and getattr(dp, "capturable", False)
+                           and (self.W > 1 or os.environ.get("GPTST_FORCE_DP", "0") == "1"))
+        self.dec_lo, self.dec_hi = self._decoder_bucket(model)
+        self.fork_side = torch.cuda.Stream() if self.dp_overlap else None
+        if self.dp_overlap and self.dp_overlap_mode == 2 and self.red_side is None:
+            self.red_side = engine.SideStream()
         # generation of the STHCNs' parameters under the guide classifier + mask selection (small launches that leave most CUs idle)
         self.gen_side = engine.SideStream() if os.environ.get("GPTST_GEN_BRANCH", "0") == "1" else None
         # the guide classifier's backward (KL path) on a branch of its own beside the decoder forward and the whole backward chain
@@ -94,6 +106,23 @@ class PretrainStep:
     # guide forward is computed once and no collective sits inside a graph.  Everything else runs the two parts back to back.
     def _needs_exchange(self, phase):
         return self.gmask and phase == 1 and not self.force_mask
+
+    @staticmethod
+    def _decoder_bucket(model):
+        """[lo, hi) of the decoder's trained parameters in the flat buffer (they are contiguous: segment A is in registration order,
+        encoder first; the decoder's never-trained time features live in the last segment)."""
+        offs = [(o, model.state_dict()[k].numel()) for k, o in model._offs.items() if k.startswith("decoder.") and o < model.nA]
+        lo = min(o for o, _ in offs)
+        hi = max(o + (n + 3) // 4 * 4 for o, n in offs)
+        assert hi == model.nA and all(o >= lo for o, _ in offs), (lo, hi, model.nA)
+        assert not any(lo <= o < hi for k, o in model._offs.items() if not k.startswith("decoder.")), "decoder bucket is not contiguous"
+        return lo, hi
+
+    def _bucket_ready(self, k):
+        """engine.Reductions callback (inside the side-stream fork): bucket 0 = the decoder's gradient is final -> its all-reduce starts now"""
+        if k == 0:
+            self.dp.allreduce_(self.gbuf[self.dec_lo:self.dec_hi])
+            self._dec_reduced = True
 
     def _dp_in_graph(self):
         """Data parallel on a capturable communicator (dist.DataParallel(native=True)): label gather, gradient all-reduce and optimiser are
@@ -112,6 +141,10 @@ class PretrainStep:
         tidx = ops.step_begin(self.gbuf, self.arena.begin(zero=False), src, base, noise=noise, rng=self.rng_words)
         gen = engine.gen_all(p, tidx, dims, side=self.gen_side)   # time embeddings + every generated parameter: 3 launches
         red = engine.Reductions(side=self.red_side)
+        self._dec_reduced = False
+        if self.dp_overlap and self._dp_in_graph():
+            red.on_bucket = self._bucket_ready
+            red.bucket_inline, red.fork_side = self.dp_overlap_mode == 1, self.fork_side
         prob, sv_g = engine.guide_fwd(p, src, tidx, dims, base, gen=gen["guide"])
         if self._needs_exchange(phase):
             self.label_l.copy_(sv_g[4])                           # this rank's cluster labels -> all-gather (_exchange_labels)
@@ -181,7 +214,11 @@ class PretrainStep:
         if self.dp is None:
             self._optim()
         elif self._dp_in_graph():           # gradient all-reduce + optimiser as the last nodes of the step's graph (no host gap behind the replay)
-            self.dp.allreduce_(self.gbuf)
+            if self._dec_reduced:           # the decoder bucket went out under the encoder's backward: what is left is [encoder] and [KL path | never | statistics]
+                self.dp.allreduce_(self.gbuf[:self.dec_lo])
+                self.dp.allreduce_(self.gbuf[self.dec_hi:])
+            else:
+                self.dp.allreduce_(self.gbuf)
             self._optim()
 
     def _mask_ws(self):

@@ -21,6 +21,10 @@
 #ifdef __cplusplus
 extern "C" {
 #endif
+/* The library is built with -fvisibility=hidden: only what is declared between this push and the pop below is exported. */
+#if defined(__GNUC__)
+#pragma GCC visibility push(default)
+#endif
 
 #define GPTST_ABI_VERSION 8
 int gptst_abi_version(void);
@@ -28,11 +32,6 @@ int gptst_abi_version(void);
  * weight gradients of gptst_timefeat_jobs) run as single-owner kernels with a fixed summation order (slower).  Everything else is
  * order-fixed by construction.  Thread-local. */
 int gptst_set_deterministic(int on);
-/* launch-geometry knobs for benchmarking, not needed for correctness.  1: rows per block of the poolgen forward; 2 / 5: forced split
- * count of the NODE / TIME weight gradient; 3: 1 = first-generation (LDS-staged) apply for C = 64; 4: tiles per wave of apply64 / apply128;
- * 6: workgroups of the loss-head kernels; 7 / 8: 1 = first-generation weight gradient / apply for C = 128; 10: 0 = VALU forward of the
- * pool jobs instead of the (bit-identical) MFMA one.  The Python binding applies GPTST_TUNE="id=value,..." from the environment. */
-int gptst_tune(int id, int value);
 
 /* ---- embedding-conditioned parameter generation (poolgen.hip) -----------------------------------------
  * out[r,:] = sum_k emb[r,k] * pool[k,:]   r < R, k < K <= 16.  Optional second problem (pool2/out2/cols2) shares emb.
@@ -262,7 +261,6 @@ int gptst_mask_labels(const float* prob, int rows, int HS, int* label, int* coun
 int gptst_mask_adaptive(const int* label, const int* counts, const int* list_c, const int* nums, const float* noise_a,
                         const float* noise_r, int ada_all, int M, int HS, int base, float* m_ada, float* m_rnd, float* mask,
                         void* ws, int ws_zeroed, void* stream);
-int gptst_mask_force_multi(int on);   /* tests: 1 = multi-launch path for every size */
 
 /* ---- thin projections (small.hip) ------------------------------------------------------------------------
  * lin_in: Y[i,:] = sum_j a'[i,j] W(:,j) + b, a' = mask ? (mask[i,j] ? a[i*lda+j] : fill) : a;  wlayout 0: W[c*J+j], 1: W[j*C+c].
@@ -381,16 +379,20 @@ int gptst_mlprl_layer_bwd(const float* dlogits, const float* a, int lda, const f
 /* ---- communication (comm.hip): RCCL over xGMI with an explicit stream — a collective can sit inside a captured hipGraph -------------
  * The reference has no distributed code; these carry the data-parallel gradient exchange (one all-reduce of [flat gradient | statistics])
  * and the node-sharded cluster aggregations.  RCCL is bound at run time (dlopen): -4 (GPTST_ECOMM) when it is not available or no
- * communicator exists, 1000 + ncclResult_t on an RCCL error.  One communicator per process (= per GPU).
- * unique_id: 128 bytes (ncclUniqueId) created on one rank and distributed by the caller. */
+ * communicator is given, 1000 + ncclResult_t on an RCCL error.  Communicators are HANDLES (r04; a process-global one before): a process may
+ * hold several — the row and the column of a data-parallel x node-shard mesh (SURVEY 8(e) "Combination") — each created by gptst_comm_init
+ * on the ranks that form it.  unique_id: 128 bytes (ncclUniqueId) created on one rank of the communicator and distributed by the caller. */
 int gptst_comm_unique_id(void* out128);
-int gptst_comm_init(int rank, int world, const void* unique_id);
-int gptst_allreduce_f32(float* buf, long n, void* stream);      /* in-place sum over the ranks */
+int gptst_comm_init(int rank, int world, const void* unique_id, void** comm_out);    /* *comm_out: the handle the calls below take */
+int gptst_allreduce_f32(void* comm, float* buf, long n, void* stream);      /* in-place sum over the ranks */
 /* recv[r*n .. (r+1)*n) <- rank r's send[0..n), 32-bit words (the cluster labels of a data-parallel global batch); send may be recv + rank*n */
-int gptst_allgather_i32(const int* send, int* recv, long n, void* stream);
-int gptst_comm_count(int* out);                                /* ncclCommCount of the communicator */
-int gptst_comm_destroy(void);
+int gptst_allgather_i32(void* comm, const int* send, int* recv, long n, void* stream);
+int gptst_comm_count(void* comm, int* out);                    /* ncclCommCount of the communicator */
+int gptst_comm_destroy(void* comm);
 
+#if defined(__GNUC__)
+#pragma GCC visibility pop
+#endif
 #ifdef __cplusplus
 }
 #endif

@@ -132,3 +132,40 @@ def test_dp_label_exchange_protocol():
     for r, lab_g, counts, mine in got:
         assert lab_g == want_lab.tolist() and counts == want_cnt.tolist()
         assert mine == torch.arange(2 * M * 2, dtype=torch.float32)[r * M * 2:(r + 1) * M * 2].tolist()
+
+
+def test_mesh_groups_layout():
+    """SURVEY 8(e) "Combination": world = dp x shard, rank = dp_index * n_shard + shard_index; rows are the node-shard communicators, columns
+    the data-parallel ones; every rank is in exactly one of each."""
+    from gptst_amd.dist import mesh_groups, mesh_shape
+    assert mesh_shape(8, 4) == (2, 4)
+    rows, cols = mesh_groups(8, 4)
+    assert rows == [[0, 1, 2, 3], [4, 5, 6, 7]] and cols == [[0, 4], [1, 5], [2, 6], [3, 7]]
+    for world, ns in ((8, 1), (8, 8), (6, 2)):
+        rows, cols = mesh_groups(world, ns)
+        for r in range(world):
+            assert sum(r in g for g in rows) == 1 and sum(r in g for g in cols) == 1
+
+
+def test_bucketed_allreduce_equals_the_single_allreduce():
+    """r04: the packed [gradient | statistics] buffer leaves in three pieces — the decoder's bucket early (under the encoder's backward), then
+    [encoder] and [KL path | never trained | statistics] — which must reduce to exactly what the one all-reduce gives, and the decoder's
+    trained parameters must be ONE contiguous range of the flat buffer that ends where the reconstruction-path segment ends."""
+    from gptst_amd.config import make_args
+    from gptst_amd.model import GPTST_Model
+    from gptst_amd.step import PretrainStep
+    args = make_args("PEMS08", num_nodes=20, embed_dim=4)
+    m = GPTST_Model(args)
+    lo, hi = PretrainStep._decoder_bucket(m)
+    assert 0 < lo < hi == m.nA
+    inside = {k for k, o in m._offs.items() if lo <= o < hi}
+    assert inside and all(k.startswith("decoder.") for k in inside)
+    assert {k for k in m._offs if k.startswith("decoder.") and not k.startswith("decoder.time_feature")} == inside
+    n = m.flat.numel()
+    g = torch.Generator().manual_seed(3)
+    bufs = [torch.randn(n + 8, generator=g) for _ in range(3)]
+    whole = torch.stack(bufs).sum(0)
+    pieces = torch.zeros(n + 8)
+    for a, b in ((lo, hi), (0, lo), (hi, n + 8)):
+        pieces[a:b] = torch.stack([t[a:b] for t in bufs]).sum(0)
+    assert torch.equal(whole, pieces)

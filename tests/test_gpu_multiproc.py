@@ -99,11 +99,16 @@ def test_dp_step_in_one_graph_equals_the_plain_step():
     try:
         assert dp.capturable and dp.rccl_ranks() == 1
         res = []
-        for d in (None, dp):
+        for d, overlap in ((None, "0"), (dp, "0"), (dp, "1"), (dp, "2")):
+            # overlap "1" / "2" (r04): the decoder's gradient bucket is all-reduced (2: also reduced) on a forked branch under the encoder's
+            # backward, the rest ([encoder] and [KL path | statistics]) behind the chain — three collectives in the graph instead of one
+            os.environ.update(GPTST_FORCE_DP="1", GPTST_DP_OVERLAP=overlap)
             model = GPTST_Model(args)
             model.load_state_dict(sd)
             model = model.to("cuda:0")
             st = PretrainStep(model, args, synth.SCALER_MEAN, synth.SCALER_STD, batch_size=B, use_graph=True, dp=d, seed=7, deterministic=True)
+            assert st.dp_overlap == (d is not None and overlap != "0")
+            assert 0 < st.dec_lo < st.dec_hi == model.nA
             losses = []
             for i, epoch in enumerate((1, 1, 20, 20, 20)):
                 kw = (dict(noise=synth.make_noise(M, 10 + i).to("cuda:0")) if epoch == 1 else
@@ -114,11 +119,13 @@ def test_dp_step_in_one_graph_equals_the_plain_step():
             if d is not None:
                 assert all(g2 is None for _, g2 in st.graphs.values()), "one graph per phase, collectives inside"
             res.append((losses, {k: v.detach().clone() for k, v in model.state_dict().items()}))
-        for a, b in zip(res[0][0], res[1][0]):
-            assert abs(a[0] - b[0]) <= 1e-6 * abs(a[0]), (a, b)
-        worst = max(float((res[0][1][k].float() - res[1][1][k].float()).abs().max()) for k in res[0][1])
-        assert worst < 2e-6, worst              # (fixed-order reductions on both sides: measured 0 .. 1e-6 over five Adam steps at lr 3e-3)
+        for other in res[1:]:
+            for a, b in zip(res[0][0], other[0]):
+                assert abs(a[0] - b[0]) <= 1e-6 * abs(a[0]), (a, b)
+            worst = max(float((res[0][1][k].float() - other[1][k].float()).abs().max()) for k in res[0][1])
+            assert worst < 2e-6, worst              # (fixed-order reductions on both sides: measured 0 .. 1e-6 over five Adam steps at lr 3e-3)
     finally:
+        os.environ.pop("GPTST_FORCE_DP", None); os.environ.pop("GPTST_DP_OVERLAP", None)
         dp.native.close()
         dist.destroy_process_group()
 
@@ -180,3 +187,29 @@ def test_native_comm_allreduce_inside_a_graph():
         assert torch.equal(dp.gather_labels(lab), lab)
     finally:
         comm.close()
+
+
+def test_two_native_communicators_coexist():
+    """r04: communicators are handles (gptst_comm_init -> *comm_out), so one process can hold the row AND the column communicator of a
+    data-parallel x node-shard mesh.  With one rank each: both serve collectives on the same stream, independently destroyed."""
+    import torch
+    from gptst_amd.dist import NativeComm, mesh_comms
+    a, b = NativeComm(rank=0, world=1), NativeComm(rank=0, world=1)
+    try:
+        assert a.h.value != b.h.value and a.count() == 1 and b.count() == 1
+        x = torch.arange(4096, device="cuda:0", dtype=torch.float32)
+        ref = x.clone()
+        a.allreduce_(x); b.allreduce_(x); a.allreduce_(x)
+        torch.cuda.synchronize()
+        assert torch.equal(x, ref)
+        a.close()
+        b.allreduce_(x)                                                # b outlives a
+        torch.cuda.synchronize()
+        assert torch.equal(x, ref)
+    finally:
+        a.close(); b.close()
+    shard, dp = mesh_comms(1, rank=0, world=1)                         # the 1 x 1 mesh: two communicators of one rank
+    try:
+        assert shard.world == 1 and dp.world == 1 and shard.h.value != dp.h.value
+    finally:
+        shard.close(); dp.close()
