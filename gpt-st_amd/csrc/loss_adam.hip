@@ -152,6 +152,9 @@ __global__ __launch_bounds__(256) void adam_kernel(float* __restrict__ p, const 
     const bool actB = hyper[8] != 0.f;
     const long n = nA + (actB ? nB : 0);
     const float b1 = hyper[4], b2 = hyper[5], eps = hyper[6], maxn = hyper[7];
+    // 1 - beta as the HOST rounds it (hyper[11], hyper[12]): torch.optim.Adam passes python's 1 - beta2 (0.001 rounded to fp32); 1.f - 0.999f is
+    // 0.00099998713 — 1.3e-5 low, i.e. every step 6.4e-6 too long (r04: found by the fp64 trajectory test, tests/test_gpu_step.py)
+    const float omb1 = hyper[11] != 0.f ? hyper[11] : 1.f - b1, omb2 = hyper[12] != 0.f ? hyper[12] : 1.f - b2;
     float clip = 1.f;
     if (maxn > 0.f) clip = fminf(1.f, maxn / (sqrtf(gsq) + 1e-6f));               // clip_grad_norm_
     const float sa = seg_scale(hyper, stats, true) * clip, sb = seg_scale(hyper, stats, false) * clip;
@@ -160,8 +163,8 @@ __global__ __launch_bounds__(256) void adam_kernel(float* __restrict__ p, const 
         const float gr = g[i] * (A ? sa : sb);
         const float step = A ? hyper[0] : hyper[2], bc2 = A ? hyper[1] : hyper[3];
         float mi = m[i], vi = v[i];
-        mi = mi + (gr - mi) * (1.f - b1);                      // exp_avg.lerp_(grad, 1-beta1)
-        vi = vi * b2 + (1.f - b2) * gr * gr;                   // exp_avg_sq.mul_(beta2).addcmul_(grad, grad, 1-beta2)
+        mi = mi + (gr - mi) * omb1;                            // exp_avg.lerp_(grad, 1-beta1)
+        vi = vi * b2 + omb2 * gr * gr;                         // exp_avg_sq.mul_(beta2).addcmul_(grad, grad, 1-beta2)
         const float denom = sqrtf(vi) / bc2 + eps;
         p[i] = p[i] - step * (mi / denom);                     // param.addcdiv_(exp_avg, denom, -step_size)
         m[i] = mi; v[i] = vi;

@@ -291,6 +291,7 @@ class PretrainStep:
         self.phase_kl = phase == 1
         b1, b2 = 0.9, 0.999
         tA, tB = self.tA, self.tB
+        sl["hyper"][11:13] = (1 - b1, 1 - b2)           # as the host rounds them (torch passes python's 1 - beta): 1.f - 0.999f is 1.3e-5 low
         sl["hyper"][:11] = (self.lr / (1 - b1 ** tA), math.sqrt(1 - b2 ** tA),
                             self.lr / (1 - b1 ** tB) if tB else 0.0, math.sqrt(1 - b2 ** tB) if tB else 1.0,
                             b1, b2, 1e-8, float(a.max_grad_norm) if a.grad_norm else 0.0, 1.0 if phase == 1 else 0.0,

@@ -202,3 +202,32 @@ def test_step_sequence():
         assert rel < 2e-2, (k, rel)
     steps = [int(st.opt.state[p]["step"]) if p in st.opt.state else 0 for p in st.params]
     assert steps == [int(s) for s in fx["adam_steps"]]
+
+
+def test_trainer_checkpoint_was_accepted_by_the_reference():
+    """Drop-in, consumer side (reference model/Model.py:95-98: torch.load -> GPTST_Model.load_state_dict, strict): the checkpoint FILE the product's
+    trainer wrote on the MI355X (tests/golden/trainer_ckpt.pth, by tests/golden/make_trainer_ckpt.py) was loaded into the REFERENCE module in
+    the build container by tests/golden/check_ckpt_in_reference.py, whose record is committed next to it.  Here: the record belongs to this
+    very file, says strict load + both forwards agree with the oracle, and the file loads into the product's module and the oracle alike."""
+    import hashlib
+    import json
+    import os
+    import torch
+    from gptst_amd.config import make_args
+    from gptst_amd.model import GPTST_Model
+    from gptst_amd import synth
+    here = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+    rec = json.load(open(os.path.join(here, "ckpt_in_reference.json")))
+    meta = json.load(open(os.path.join(here, "trainer_ckpt.json")))
+    path = os.path.join(here, "trainer_ckpt.pth")
+    assert hashlib.sha256(open(path, "rb").read()).hexdigest() == rec["sha256"], "re-run tests/golden/check_ckpt_in_reference.py on the committed file"
+    assert rec["strict_load"] == "ok" and rec["keys"] == 159
+    assert all(v < 2e-6 for v in rec["forward_max_rel_err_vs_oracle"].values())
+    sd = torch.load(path, map_location="cpu")
+    args = make_args("PEMS08", scaler_zeros=meta["scaler_zeros"], **meta["args"])
+    assert list(sd.keys()) == list(O.init_state_dict(args, 1).keys())
+    m = GPTST_Model(args)
+    m.load_state_dict(sd, strict=True)
+    emb = O.forward_eval(sd, args, synth.make_batch(2, 12, meta["args"]["num_nodes"], 1, seed=1))
+    assert torch.isfinite(emb).all() and float(emb.abs().max()) > 0
+    assert meta["steps"] > 100                                   # a trained file, not an initial state
