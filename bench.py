@@ -159,6 +159,48 @@ def retime_kernel(name, tag, reps=50):
     return e0.elapsed_time(e1) * 1e-3 / reps
 
 
+def module_path(args, B, epoch, dev, steps=40, warmup=6):
+    """The OTHER way into the HIP kernels, the one INTEGRATION.md section 1 advertises: the reference's own training loop
+    (model/BasicTrainer.py:72-103) around the drop-in nn.Module — GPTST_Model.forward (one autograd node over the HIP forward / backward),
+    the reference's torch loss closures (Run.py:91-101, lib/metrics.py:11-18, KLDivLoss(sum)), loss.backward(), clip_grad_norm_(5),
+    torch.optim.Adam.step(), loss.item().  No fused step, no hipGraph, per-tensor optimiser: what a maintainer gets from the one-line
+    import swap alone.  -> dict(steps_per_s, ms_per_step, ...)."""
+    from gptst_amd import synth
+    from gptst_amd.model import GPTST_Model, xavier_init_
+    model = xavier_init_(GPTST_Model(args)).to(dev)
+    opt = torch.optim.Adam(model.parameters(), lr=args.lr_init, eps=1.0e-8, weight_decay=0, amsgrad=False)             # Run.py:134
+    kl = torch.nn.KLDivLoss(reduction="sum")                                                                            # Run.py:132
+    src = synth.make_batch(B, 12, args.num_nodes, args.input_base_dim, interval=args.interval, seed=2024).to(dev)
+    mean, std, base = synth.SCALER_MEAN, synth.SCALER_STD, args.input_base_dim
+
+    def mae(pred, true, mask_value):                                                                                    # lib/metrics.py:11-18
+        m = torch.gt(true, mask_value)
+        return torch.mean(torch.abs(torch.masked_select(true, m) - torch.masked_select(pred, m)))
+
+    def one():
+        opt.zero_grad()                                                                                                 # BasicTrainer.py:79
+        out, _, mask, prob, eb = model(src, src, None, epoch)                                                           # :82
+        label = src[..., :base]
+        loss = mae((out * std + mean) * mask, (label * std + mean) * mask, args.mape_thresh)                            # Run.py:92-100
+        if epoch > args.change_epoch:
+            loss = loss + 0.1 * kl(prob.log(), eb)                                                                      # BasicTrainer.py:84-86
+        loss.backward()                                                                                                 # :92
+        torch.nn.utils.clip_grad_norm_(model.parameters(), args.max_grad_norm)                                          # :95-96
+        opt.step()                                                                                                      # :97
+        return loss.item()                                                                                              # :98 (host sync every step)
+    for _ in range(warmup):
+        one()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        last = one()
+    torch.cuda.synchronize()
+    el = time.perf_counter() - t0
+    return dict(steps_per_s=steps / el, ms_per_step=1e3 * el / steps, steps=steps, last_loss=last,
+                what="reference-style loop (BasicTrainer.py:72-103) over the drop-in GPTST_Model: autograd node on the HIP kernels + torch loss + "
+                     "clip_grad_norm_ + torch.optim.Adam, eager, loss.item() every step")
+
+
 def cpu_baseline(args, B, budget_s=12.0):
     """The oracle (op-for-op CPU restatement of the reference step) timed on the host cores — reported, never the target."""
     from gptst_amd import synth
@@ -241,6 +283,9 @@ def main():
     ap.add_argument("--no-graph", action="store_true")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-timing", action="store_true")
+    ap.add_argument("--path", choices=["step", "module"], default="step",
+                    help="step: the fused PretrainStep (headline); module: ONLY the reference-style loop over the drop-in nn.Module (its rate becomes `value`)")
+    ap.add_argument("--no-module-path", action="store_true", help="skip the short module-path measurement reported beside the headline")
     a = ap.parse_args()
 
     from gptst_amd import synth
@@ -476,6 +521,14 @@ def main():
         out["collectives_us"] = {k: round(v[0] / v[1], 1) for k, v in agg.items()}
         out["collectives_per_step"] = len(rec) // 3
         out["dp_overlap"] = bool(getattr(stepper, "dp_overlap", False))
+    if world == 1 and a.shard != "nodes" and (a.path == "module" or not a.no_module_path):
+        stepper = None
+        torch.cuda.empty_cache()
+        out["module_path"] = module_path(args, B, a.epoch, dev, steps=a.steps if a.path == "module" else 40)
+        if a.path == "module":
+            out["value"], out["ms_per_step"] = out["module_path"]["steps_per_s"], out["module_path"]["ms_per_step"]
+            out["optimizer_steps_per_s"] = out["value"]
+            out["config"]["workload"] += "; PATH = module (reference-style loop over the drop-in nn.Module, not the fused step)"
     if not a.no_cpu_baseline and world == 1:
         out["cpu_baseline"] = cpu_baseline(args, B)
     print(json.dumps(out))

@@ -108,12 +108,12 @@ class _PretrainFn(torch.autograd.Function):
     """Whole-network autograd node: forward/backward are the hand-written HIP pipelines of engine.py."""
 
     @staticmethod
-    def forward(ctx, model, source, mask, *params):
+    def forward(ctx, model, source, mask, pre, *params):
         p = model.param_views()
         dims, base = model._dims(source), model.input_base_dim
-        tidx = model._tidx(source)
-        gen = engine.gen_all(p, tidx, dims)
-        prob, sv_g = engine.guide_fwd(p, source, tidx, dims, base, gen=gen["guide"])
+        # pre: (tidx, gen, prob, sv_g) of forward_pretrain — the generated parameters and the guide classifier's forward, which the mask
+        # needed first, are computed ONCE per call (r03 review: the guide ran twice)
+        tidx, gen, prob, sv_g = pre
         emb, c1, tidx, sv_e = engine.model_fwd(p, source, mask, dims, base, model.num_route, model.scaler_zeros, gen=gen[engine.ENC], tidx=tidx)
         out, dec, sv_d = engine.decoder_fwd(p, tidx, emb, dims, model.num_route, gen=gen[engine.DEC])
         ctx.model, ctx.saved = model, (source, mask, tidx, sv_g, sv_e, sv_d, dec, prob, dims)
@@ -128,7 +128,7 @@ class _PretrainFn(torch.autograd.Function):
         B, T, N, C = dims
         base = model.input_base_dim
         p = model.param_views()
-        gflat = torch.zeros_like(model.flat)
+        gflat = model._grad_buffer()
         g = model.views_of(gflat)
         d_out = d_out.contiguous().view(-1, base)
         d_dec2 = None if d_dec is None or not bool(d_dec.any()) else d_dec.contiguous().view(-1, C)
@@ -144,7 +144,7 @@ class _PretrainFn(torch.autograd.Function):
         for k in model.param_keys:
             seg = _segment(k)
             grads.append(g[k] if seg == 0 or (seg == 1 and has_kl) else None)
-        return (None, None, None) + tuple(grads)
+        return (None, None, None, None) + tuple(grads)
 
 
 class GPTST_Model(nn.Module):
@@ -202,6 +202,17 @@ class GPTST_Model(nn.Module):
         r = super().load_state_dict(sd, strict)  # copy_ into the views keeps the flat layout
         self._views = None
         return r
+
+    def _grad_buffer(self):
+        """The flat gradient buffer of the autograd path, zeroed: ONE buffer per model reused across calls (r03 review: a fresh 4 MB
+        allocation per backward) — unless a parameter's .grad still aliases it (gradient accumulation without zero_grad): then a new one."""
+        buf = getattr(self, "_gbuf", None)
+        if buf is not None and buf.numel() == self.flat.numel() and buf.device == self.flat.device:
+            lo, hi = buf.data_ptr(), buf.data_ptr() + 4 * buf.numel()
+            if not any(q.grad is not None and lo <= q.grad.data_ptr() < hi for q in self.parameters()):
+                return buf.zero_()
+        self._gbuf = torch.zeros_like(self.flat)
+        return self._gbuf
 
     def views_of(self, flat):
         named = dict(self.named_parameters())
@@ -272,11 +283,14 @@ class GPTST_Model(nn.Module):
         base = self.input_base_dim
         p = self.param_views()
         with torch.no_grad():
-            # the mask depends on the guide probabilities only through argmax (no gradient), so generate it first
-            prob0, _ = engine.guide_fwd(p, source, self._tidx(source), self._dims(source), base)
+            # the mask depends on the guide probabilities only through argmax (no gradient), so the guide classifier runs first — once: its
+            # outputs and saved activations are handed to the autograd node together with every generated parameter of the step
+            dims, tidx = self._dims(source), self._tidx(source)
+            gen = engine.gen_all(p, tidx, dims)
+            prob0, sv_g = engine.guide_fwd(p, source, tidx, dims, base, gen=gen["guide"])
             mask = self.make_mask(source, prob0, epoch)
         params = [t for _, t in self.named_parameters()]
-        out, dec, prob, c1 = _PretrainFn.apply(self, source, mask, *params)
+        out, dec, prob, c1 = _PretrainFn.apply(self, source, mask, (tidx, gen, prob0, sv_g), *params)
         mask_i = mask.view(B, T, N, base).to(torch.int64)
         hs1 = c1.view(B, T, self.HS, N).transpose(-1, -2)                                                  # :424
         return out, dec, 1 - mask_i, prob, hs1
