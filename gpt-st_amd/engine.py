@@ -576,7 +576,22 @@ def sthcn_bwd(p, g, pfx, tidx, sv, dout, dims, red, chain=False, premul_in=False
     dd, hp3 = hypertem_core_bwd(sv["h3"], dd, dG_all[2], dims, chain, True)
     dd, hp2 = hypertem_core_bwd(sv["h2"], dd, dG_all[1], dims, chain, True)
     dd, cp1 = cap_core_bwd(p, g, cps[0], sv["c1"], dd, dims, HS, HT, red, chain)
-    dd, hp1 = hypertem_core_bwd(sv["h1"], dd, dG_all[0], dims, chain, premul_in)
+    if isinstance(sv["h1"], EncIn):                 # the encoder's first layer on the low-rank input form: no input gradient tensor
+        assert chain
+        e = sv["h1"]
+        w, bi = p["encoder.dim_in_flow.weight"], p["encoder.dim_in_flow.bias"]
+        dWb, _, dinp = ops.encin_ht1_bwd(dd.view(B, T, N, C), e.source, e.mask, e.fill, w, bi, e.Wbt, e.ab, e.wv, dG=dG_all[0])
+        hp1 = (dWb[:, :C * C], 1, (dWb[:, C * C:], 1))
+        wb = _wb_view(g["encoder.dim_in_flow.weight"], g["encoder.dim_in_flow.bias"])
+        if wb is not None:
+            red.jobs.bwd_pool(_ones(dd.device, dinp.shape[0]), dinp, wb)
+        else:
+            g["encoder.dim_in_flow.weight"].add_(dinp[:, :C].sum(0).view(C, 1))
+            g["encoder.dim_in_flow.bias"].add_(dinp[:, C:].sum(0))
+        red.keep.append((dinp, dWb))
+        dd = None
+    else:
+        dd, hp1 = hypertem_core_bwd(sv["h1"], dd, dG_all[0], dims, chain, premul_in)
     _join_side()
     # ---- gradient reductions of all generated parameters: queued, executed by red.flush() ----
     J = red.jobs
@@ -611,6 +626,21 @@ def sthcn_bwd(p, g, pfx, tidx, sv, dout, dims, red, chain=False, premul_in=False
 
 
 # ---- whole model ---------------------------------------------------------------------------------------------------
+class EncIn:
+    """saved state of the encoder's first layer when it ran on the low-rank input form (ops.encin_ht1_fwd) instead of lin_in + hyperTem"""
+
+    def __init__(self, source, mask, fill, Wbt, ab, wv):
+        self.source, self.mask, self.fill, self.Wbt, self.ab, self.wv = source, mask, fill, Wbt, ab, wv
+
+
+ENCIN = os.environ.get("GPTST_ENCIN", "1") == "1"
+
+
+def encin_ok(dims, base):
+    """input projection + encoder hyperTem1 as one rank-2 kernel pair (encin.hip): base = 1 and the dPre chain in the backward"""
+    return ENCIN and base == 1 and dims[3] in (64, 128) and dims[1] == 12 and chain_ok(dims) and CTX.NODE_REDUCE is None
+
+
 def guide_fwd(p, source, tidx, dims, base, gen=None):
     """softmax(MLP_RL(raw flow, teb4mask(t), neb4mask)) — GPTST.py:326-332 / 337-343.  -> prob (BTN,HS), saved."""
     B, T, N, C = dims
@@ -694,19 +724,30 @@ def _in_proj_grads(source, base, dY, gW, gb, mask, fill, red):
         ops.rowouter(source, base + 2, base, dY, gW, 0, csum=gb, mask=mask, fill=fill)
 
 
-def model_fwd(p, source, mask, dims, base, num_route, scaler_zeros, gen=None, tidx=None, dec_gen=None):
+def model_fwd(p, source, mask, dims, base, num_route, scaler_zeros, gen=None, tidx=None, dec_gen=None, lowrank_in=False):
     """Masked-autoencoder body — GPTST.py:415-421 + 453-456.  mask (BTN*base) fp32, 1 = visible; None -> no masking (eval).
     dec_gen: the decoder STHCN's gen dict — its first hyperTem layer then rides on the encoder's last chain launch and the result comes back
-    as a fifth value, to be passed to decoder_fwd(dec_head=...) (None when the chain path does not serve the shape)."""
+    as a fifth value, to be passed to decoder_fwd(dec_head=...) (None when the chain path does not serve the shape).
+    lowrank_in: the caller's backward is the dPre chain (model_bwd(chain=True)) — the input projection + encoder hyperTem1 then run as the
+    rank-2 kernel pair of encin.hip where the shape allows."""
     B, T, N, C = dims
     if tidx is None:
         tidx = source[:, :, 0, base:base + 2].contiguous()
-    x0 = ops.lin_in(source, base + 2, base, p["encoder.dim_in_flow.weight"], p["encoder.dim_in_flow.bias"], C,
-                    mask=mask, fill=scaler_zeros)                                                          # :416-418
+    head = None
+    if lowrank_in and gen is not None and encin_ok(dims, base):
+        # input projection + encoder hyperTem1 on the rank-2 structure of the input: no x0, no GEMM (ops.encin_ht1_fwd)
+        w, bi = p["encoder.dim_in_flow.weight"], p["encoder.dim_in_flow.bias"]
+        G1, Wb = gen["G_all"][0], gen["Wb"]
+        o1, ab, wv = ops.encin_ht1_fwd(source, base, mask, 0.0 if mask is None else scaler_zeros, w, bi, G1, Wb[0], Wb[1])
+        head = (o1.view(-1, C), EncIn(source, mask, 0.0 if mask is None else scaler_zeros, Wb[0], ab, wv))
+        x0 = None
+    else:
+        x0 = ops.lin_in(source, base + 2, base, p["encoder.dim_in_flow.weight"], p["encoder.dim_in_flow.bias"], C,
+                        mask=mask, fill=scaler_zeros)                                                      # :416-418
     if dec_gen is not None:
-        emb, c1, sv_e, dec_head = sthcn_fwd(p, ENC, tidx, x0, dims, num_route, gen=gen, next_gen=dec_gen)
+        emb, c1, sv_e, dec_head = sthcn_fwd(p, ENC, tidx, x0, dims, num_route, gen=gen, next_gen=dec_gen, head=head)
         return emb, c1, tidx, sv_e, dec_head
-    emb, c1, sv_e = sthcn_fwd(p, ENC, tidx, x0, dims, num_route, gen=gen)                                  # :421
+    emb, c1, sv_e = sthcn_fwd(p, ENC, tidx, x0, dims, num_route, gen=gen, head=head)                       # :421
     return emb, c1, tidx, sv_e
 
 
@@ -735,4 +776,5 @@ def model_bwd(p, g, source, mask, tidx, sv_e, sv_d, dec, d_out, d_dec, dims, bas
     red.flush_async(tidx)                                   # the decoder's reductions overlap with the encoder's backward chain
     d_x0 = sthcn_bwd(p, g, ENC, tidx, sv_e, d_emb, dims, red, chain, False)  # the encoder's input is a plain Linear: no premultiplication
     red.flush_async(tidx)                                   # ... and the encoder's with the guide's
-    _in_proj_grads(source, base, d_x0, g["encoder.dim_in_flow.weight"], g["encoder.dim_in_flow.bias"], mask, scaler_zeros, red)
+    if d_x0 is not None:                                    # (None: the low-rank first layer produced the input-projection gradient itself)
+        _in_proj_grads(source, base, d_x0, g["encoder.dim_in_flow.weight"], g["encoder.dim_in_flow.bias"], mask, scaler_zeros, red)

@@ -312,6 +312,33 @@ def hypertem_chain_fwd(X, stages, node=None, want_R=True):
     return out0, list(zip(Rs, outs))
 
 
+def encin_ht1_fwd(source, base, mask, fill, w, bi, G, Wbt, bbt):
+    """Encoder input projection + hyperTem1 on the rank-2 structure of the input (base = 1) -> out (B,T,N,C), (ab, wv) for the backward."""
+    B, T, N, F = source.shape
+    C = Wbt.shape[-1]
+    assert base == 1
+    _chk(source, mask, w, bi, G, Wbt, bbt)
+    f = dict(device=source.device, dtype=torch.float32)
+    out, ab, wv = torch.empty(B, T, N, C, **f), torch.empty(B * T * N, 2, **f), torch.empty(B * T, 2 * C, **f)
+    _call("gptst_encin_ht1_fwd", _p(source), F, _p(mask), float(fill), _p(w), _p(bi), _p(G), _p(Wbt), _p(bbt), _p(out), _p(ab), _p(wv), B, T, N, C,
+          nbytes=_nb(Wbt, out))
+    return out, ab, wv
+
+
+def encin_ht1_bwd(dPre, source, mask, fill, w, bi, Wbt, ab, wv, dG=None):
+    """-> dWb (B*T, C*C + C) rows [dW_bt | db_bt], dG (B,N,T,T) per-sample partials, dinp (B*T, 2C) partials of d(dim_in_flow.weight | bias)."""
+    B, T, N, F = source.shape
+    C = Wbt.shape[-1]
+    _chk(dPre, source, mask, w, bi, Wbt, ab, wv, dG)
+    f = dict(device=source.device, dtype=torch.float32)
+    dWb, dinp = torch.empty(B * T, C * C + C, **f), torch.empty(B * T, 2 * C, **f)
+    if dG is None:
+        dG = torch.empty(B, N, T, T, **f)
+    _call("gptst_encin_ht1_bwd", _p(dPre), _p(source), F, _p(mask), float(fill), _p(w), _p(bi), _p(Wbt), _p(ab), _p(wv), _p(dWb), _p(dG), _p(dinp),
+          B, T, N, C, nbytes=_nb(dPre, Wbt, dWb, dG))
+    return dWb, dG, dinp
+
+
 def hypertem_ntiles(N):
     return _C.lib().value("gptst_hypertem_ntiles", N)
 

@@ -172,11 +172,13 @@ class PretrainStep:
         if self.gen_side is not None:
             self.gen_side.join()
         dec_head = None
+        lowrank = self.fused_tails and engine.chain_ok(dims)      # the backward below is the dPre chain: the low-rank first layer may run
         if engine.chain_fwd_ok(dims):          # the decoder's first hyperTem layer rides on the encoder's last chain launch
             emb, c1, tidx, sv_e, dec_head = engine.model_fwd(p, src, mask, dims, base, mdl.num_route, mdl.scaler_zeros, gen=gen[engine.ENC], tidx=tidx,
-                                                             dec_gen=gen[engine.DEC])
+                                                             dec_gen=gen[engine.DEC], lowrank_in=lowrank)
         else:
-            emb, c1, tidx, sv_e = engine.model_fwd(p, src, mask, dims, base, mdl.num_route, mdl.scaler_zeros, gen=gen[engine.ENC], tidx=tidx)
+            emb, c1, tidx, sv_e = engine.model_fwd(p, src, mask, dims, base, mdl.num_route, mdl.scaler_zeros, gen=gen[engine.ENC], tidx=tidx,
+                                                   lowrank_in=lowrank)
         if self.fused_tails:
             # output head + masked MAE + their backward: one pass over dec (the mean's 1/#kept is applied by the optimiser)
             _, dec, sv_d = engine.decoder_fwd(p, tidx, emb, dims, mdl.num_route, gen=gen[engine.DEC], head=False, dec_head=dec_head)

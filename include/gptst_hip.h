@@ -140,6 +140,21 @@ int gptst_hypertem_chain_fwd(const float* X, const float* rec, const float* Wn, 
                              const void* Gs, const void* Wbts, const void* bbts, const void* Rs, const void* outs, int B, int T, int N, int C,
                              void* stream);
 
+/* Encoder input projection + the encoder's first hyperTem layer on the low-rank structure of the input (encin.hip, r04).  For base = 1 the
+ * first activation is x0 = m w + bi (m = mask ? flow : fill, a scalar per row), so hyperTem1 needs neither x0 nor a GEMM:
+ * out = LReLU(alpha (w W_bt) + beta (bi W_bt) + b_bt + m w + bi) with alpha = sum_u G_n[t,u] m_u, beta = sum_u G_n[t,u]; the backward collapses
+ * the same way (rank-2 weight gradient, graph gradient from two dot products per row, input-projection gradient from per-(b,t) vectors).
+ * fwd: src rows (B*T*N, lda) with the flow in column 0, mask (B*T*N) 1 = visible or NULL, w = dim_in_flow.weight (C,1), bi = its bias ->
+ *      out (B,T,N,C), ab (B*T*N, 2) = (alpha, beta), wv (B*T, 2C) = (w W_bt | bi W_bt), both kept for the backward.
+ * bwd: dPre = dOut * lrelu'(out) (chain form) -> dWb (B*T, C*C + C) rows [dW_bt | db_bt], dG (B,N,T,T) per-sample partials,
+ *      dinp (B*T, 2C) partials of [d weight | d bias] of dim_in_flow (rows summed by the caller).
+ * Replaces GPTST.py:418 + :154-163 of encoder.STHCN_encode.hyperTem1 and their backward.  base = 1, T = 12, C in {64, 128}; else GPTST_ESHAPE. */
+int gptst_encin_ht1_fwd(const float* src, int lda, const float* mask, float fill, const float* w, const float* bi, const float* G,
+                        const float* Wbt, const float* bbt, float* out, float* ab, float* wv, int B, int T, int N, int C, void* stream);
+int gptst_encin_ht1_bwd(const float* dPre, const float* src, int lda, const float* mask, float fill, const float* w, const float* bi,
+                        const float* Wbt, const float* ab, const float* wv, float* dWb, float* dG, float* dinp, int B, int T, int N, int C,
+                        void* stream);
+
 /* "dPre chain" convention of the backward kernels (r03): the gradient that travels down the layer chain may be handed over ALREADY multiplied
  * by the LeakyReLU derivative of the activation it belongs to (dPre = dOut * lrelu'(out)).  A consumer is told so by Y == NULL (it then
  * takes its incoming gradient as dPre and never reads its own output), and a producer is told to emit that form by premul != 0: it

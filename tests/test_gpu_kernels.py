@@ -1069,3 +1069,42 @@ def test_hypertem_chain_fwd_equals_layer_calls(B, N, nstage, node):
         assert torch.equal(R, R1), "R of chained layer %d" % k
         assert torch.equal(o, o1), "out of chained layer %d" % k
         x = o1
+
+
+@pytest.mark.parametrize("B,N,C,masked", [(32, 170, 64, True), (2, 20, 64, True), (3, 37, 64, False), (1, 300, 128, True)])
+def test_encin_ht1_low_rank_pair_equals_lin_in_plus_hypertem(B, N, C, masked):
+    """encin.hip: input projection (base = 1) + the encoder's first hyperTem layer on the rank-2 structure of the input, forward and backward,
+    against the generic kernels (gptst_lin_in + gptst_hypertem_fwd; their backward in chain form + gptst_rowouter for the projection's
+    gradient): same mathematics, sums associated differently."""
+    from gptst_amd import ops
+    dev = _dev()
+    g = torch.Generator().manual_seed(91 + N)
+    T = 12
+    src = rnd(B, T, N, 3, g=g).to(dev)
+    mask = (torch.rand(B * T * N, generator=g) > 0.3).float().to(dev) if masked else None
+    fill = -1.5753
+    w, bi = rnd(C, 1, g=g).to(dev), (rnd(C, g=g) * 0.5).to(dev)
+    G = (rnd(N, T, T, g=g) * 0.3).to(dev)
+    Wbt, bbt = (rnd(B * T, C, C, g=g) * 0.1).to(dev), (rnd(B * T, C, g=g) * 0.3).to(dev)
+    out, ab, wv = ops.encin_ht1_fwd(src, 1, mask, fill if masked else 0.0, w, bi, G, Wbt, bbt)
+    x0 = ops.lin_in(src, 3, 1, w, bi, C, mask=mask, fill=fill)
+    if C == 64:
+        R, ref = ops.hypertem_fwd(x0.view(B, T, N, C), G, Wbt, bbt)
+    else:
+        from gptst_amd.ops import MODE_TIME, EPI_RES_LRELU
+        R = ops.tmix(x0.view(B, T, N, C), G)
+        ref = ops.apply(R.view(-1, C), Wbt, MODE_TIME, B * T, N, bias=bbt, resid=x0, epi=EPI_RES_LRELU).view(B, T, N, C)
+    close(out, ref.cpu(), tol=3e-6, what="encin out")
+    # backward, chain form: dPre = dOut * lrelu'(out)
+    dO = rnd(B, T, N, C, g=g).to(dev)
+    dPre = (dO * torch.where(ref > 0, torch.ones_like(ref), torch.full_like(ref, 0.01))).contiguous()
+    dWb, dG, dinp = ops.encin_ht1_bwd(dPre, src, mask, fill if masked else 0.0, w, bi, Wbt, ab, wv)
+    x0v, Rv, dP = x0.view(B * T, N, C).double(), R.reshape(B * T, N, C).double(), dPre.view(B * T, N, C).double()
+    close(dWb[:, :C * C].view(B * T, C, C), torch.einsum("gni,gno->gio", Rv, dP).cpu(), tol=5e-6, what="encin dW_bt")
+    close(dWb[:, C * C:], dP.sum(1).cpu(), tol=5e-6, what="encin db_bt")
+    dR = torch.einsum("gno,gio->gni", dP, Wbt.double()).view(B, T, N, C)
+    close(dG, torch.einsum("btnc,bunc->bntu", dR, x0v.view(B, T, N, C)).cpu(), tol=5e-6, what="encin dG")
+    dX0 = dP.view(B, T, N, C) + torch.einsum("ntu,btnc->bunc", G.double(), dR)
+    m = (torch.where(mask.view(B, T, N) != 0, src[..., 0], torch.full_like(src[..., 0], fill)) if masked else src[..., 0]).double()
+    close(dinp[:, :C].sum(0), torch.einsum("btn,btnc->c", m, dX0).cpu(), tol=5e-6, what="encin d weight")
+    close(dinp[:, C:].sum(0), dX0.sum((0, 1, 2)).cpu(), tol=5e-6, what="encin d bias")
