@@ -641,15 +641,24 @@ def encin_ok(dims, base):
     return ENCIN and base == 1 and dims[3] in (64, 128) and dims[1] == 12 and chain_ok(dims) and CTX.NODE_REDUCE is None
 
 
-def guide_fwd(p, source, tidx, dims, base, gen=None):
-    """softmax(MLP_RL(raw flow, teb4mask(t), neb4mask)) — GPTST.py:326-332 / 337-343.  -> prob (BTN,HS), saved."""
+GUIDEIN = os.environ.get("GPTST_GUIDEIN", "1") == "1"
+
+
+def guide_fwd(p, source, tidx, dims, base, gen=None, lowrank_in=False):
+    """softmax(MLP_RL(raw flow, teb4mask(t), neb4mask)) — GPTST.py:326-332 / 337-343.  -> prob (BTN,HS), saved.
+    lowrank_in (the caller's backward is the dPre chain): input projection + node-conditioned layer as the elementwise low-rank form of
+    guidein.hip (base = 1): saved[1] is then the tuple ("lowrank", Wspa) instead of the layer's (x, out, W)."""
     B, T, N, C = dims
     if gen is None:
         gen = gen_all(p, tidx, dims, which=(), guide=True)["guide"]
     t4m, Wspa, bspa, Wtem, btem = gen
     m = "encoder.MLP_RL."
-    h0 = ops.lin_in(source, base + 2, base, p[m + "ln1.weight"], p[m + "ln1.bias"], C)                    # :22
-    h1, s1 = condlin_fwd(h0, Wspa, bspa, MODE_NODE, dims)                                                 # :24-27
+    if lowrank_in and GUIDEIN and base == 1 and C in (64, 128):
+        h1 = ops.guide_in_fwd(source, p[m + "ln1.weight"], p[m + "ln1.bias"], Wspa, bspa)                 # :22 + :24-27, elementwise
+        s1 = ("lowrank", Wspa)
+    else:
+        h0 = ops.lin_in(source, base + 2, base, p[m + "ln1.weight"], p[m + "ln1.bias"], C)                # :22
+        h1, s1 = condlin_fwd(h0, Wspa, bspa, MODE_NODE, dims)                                             # :24-27
     h2, s2 = condlin_fwd(h1, Wtem, btem, MODE_TIME, dims)                                                 # :29-32
     prob, label = ops.rowdot(h2, p[m + "ln3.weight"], p[m + "ln3.bias"], softmax=True, want_label=True)   # :33, :332, :344-345
     return prob, (t4m, s1, s2, h2, label)
@@ -703,9 +712,28 @@ def guide_bwd(p, g, source, tidx, saved, dlogit, dims, base, red, dh2=None, chai
     d_t4m = _zeros(t4m, *t4m.shape)
     dh1 = condlin_bwd(s2, dh2, t4m, p[m + "weights_pool_tem"], p[m + "bias_pool_tem"], g[m + "weights_pool_tem"],
                       g[m + "bias_pool_tem"], d_t4m, MODE_TIME, dims, red, chain, True)
-    dh0 = condlin_bwd(s1, dh1, p["encoder.neb4mask"], p[m + "weights_pool_spa"], p[m + "bias_pool_spa"],
-                      g[m + "weights_pool_spa"], g[m + "bias_pool_spa"], g["encoder.neb4mask"], MODE_NODE, dims, red, chain, False)
-    _in_proj_grads(source, base, dh0, g[m + "ln1.weight"], g[m + "ln1.bias"], None, 0.0, red)
+    if isinstance(s1[0], str):      # ("lowrank", Wspa): node layer + input projection on the low-rank form: p_n, q_n per node instead of dh0 / h0
+        assert chain
+        neb, wpool, bpool = p["encoder.neb4mask"], p[m + "weights_pool_spa"], p[m + "bias_pool_spa"]
+        K = neb.shape[1]
+        dWb, dinp = ops.guide_in_bwd(dh1, source, p[m + "ln1.weight"], p[m + "ln1.bias"], s1[1])
+        dW, db = dWb[:, :C * C], dWb[:, C * C:]
+        red.jobs.bwd_pool(neb, dW, g[m + "weights_pool_spa"].view(K, C * C))
+        red.jobs.bwd_pool(neb, db, g[m + "bias_pool_spa"])
+        red.jobs.bwd_emb(dW, wpool.view(K, C * C), g["encoder.neb4mask"])
+        red.jobs.bwd_emb(db, bpool, g["encoder.neb4mask"])
+        wb = _wb_view(g[m + "ln1.weight"], g[m + "ln1.bias"])
+        if wb is not None:
+            red.jobs.bwd_pool(_ones(dh1.device, N), dinp, wb)
+        else:
+            g[m + "ln1.weight"].add_(dinp[:, :C].sum(0).view(C, 1))
+            g[m + "ln1.bias"].add_(dinp[:, C:].sum(0))
+        red.keep.append((dWb, dinp))
+        dh0 = None
+    else:
+        dh0 = condlin_bwd(s1, dh1, p["encoder.neb4mask"], p[m + "weights_pool_spa"], p[m + "bias_pool_spa"],
+                          g[m + "weights_pool_spa"], g[m + "bias_pool_spa"], g["encoder.neb4mask"], MODE_NODE, dims, red, chain, False)
+        _in_proj_grads(source, base, dh0, g[m + "ln1.weight"], g[m + "ln1.bias"], None, 0.0, red)
     red.timefeat(p, g, GUIDE_TF, tidx, d_t4m)
     red.keep.append((saved, dlogit, dh2, dh1, dh0))
 

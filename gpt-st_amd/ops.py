@@ -339,6 +339,27 @@ def encin_ht1_bwd(dPre, source, mask, fill, w, bi, Wbt, ab, wv, dG=None):
     return dWb, dG, dinp
 
 
+def guide_in_fwd(source, w1, b1, Wn, bn):
+    """MLP_RL input projection + node-conditioned layer on the low-rank input form (base = 1) -> h1 (B*T*N, C)."""
+    B, T, N, F = source.shape
+    C = Wn.shape[-1]
+    _chk(source, w1, b1, Wn, bn)
+    h1 = torch.empty(B * T * N, C, device=source.device, dtype=torch.float32)
+    _call("gptst_guide_in_fwd", _p(source), F, _p(w1), _p(b1), _p(Wn), _p(bn), _p(h1), B * T, N, C, nbytes=_nb(Wn, h1))
+    return h1
+
+
+def guide_in_bwd(dPre, source, w1, b1, Wn):
+    """-> dWb (N, C*C + C) rows [dW_n | db_n], dinp (N, 2C) partials of d(ln1.weight | ln1.bias)."""
+    B, T, N, F = source.shape
+    C = Wn.shape[-1]
+    _chk(dPre, source, w1, b1, Wn)
+    f = dict(device=source.device, dtype=torch.float32)
+    dWb, dinp = torch.empty(N, C * C + C, **f), torch.empty(N, 2 * C, **f)
+    _call("gptst_guide_in_bwd", _p(dPre), _p(source), F, _p(w1), _p(b1), _p(Wn), _p(dWb), _p(dinp), B * T, N, C, nbytes=_nb(dPre, Wn, dWb))
+    return dWb, dinp
+
+
 def hypertem_ntiles(N):
     return _C.lib().value("gptst_hypertem_ntiles", N)
 

@@ -87,6 +87,7 @@ class PretrainStep:
         # is exchanged behind the chain (one 4.15 MB all-reduce behind everything before).  GPTST_DP_OVERLAP=0: the single all-reduce.
         # GPTST_DP_OVERLAP: 1 (default) = the bucket's reductions on the chain's stream, only its all-reduce forked; 2 = reductions AND all-reduce forked
         # (measured at one rank: 2 costs 5 % — the branch's ~1300 bandwidth-bound workgroups slow the encoder's backward); 0 = off
+        self.always_guide = os.environ.get("GPTST_ALWAYS_GUIDE", "0") == "1"      # run the guide classifier in the random-mask phase too (as the reference does)
         self.dp_overlap_mode = int(os.environ.get("GPTST_DP_OVERLAP", "1"))
         self.dp_overlap = (self.dp_overlap_mode > 0 and dp is not None and getattr(dp, "capturable", False)
                            and (self.W > 1 or os.environ.get("GPTST_FORCE_DP", "0") == "1"))
@@ -139,13 +140,17 @@ class PretrainStep:
         if not self.inject_noise and not self.force_mask:
             noise = (self.noise_g if phase == 0 else self.noise_ar_g) if self.gmask else (self.noise if phase == 0 else self.noise_ar)
         tidx = ops.step_begin(self.gbuf, self.arena.begin(zero=False), src, base, noise=noise, rng=self.rng_words)
-        gen = engine.gen_all(p, tidx, dims, side=self.gen_side)   # time embeddings + every generated parameter: 3 launches
+        # the guide classifier (GPTST.py:325-332) feeds the adaptive mask and the KL term only: the random-mask phase of the FUSED step neither
+        # generates its parameters nor runs it (the reference computes and discards the logits there; GPTST_Model.forward still returns them)
+        need_guide = phase == 1 or self.always_guide
+        gen = engine.gen_all(p, tidx, dims, side=self.gen_side, guide=need_guide)   # time embeddings + every generated parameter: 3 launches
         red = engine.Reductions(side=self.red_side)
         self._dec_reduced = False
         if self.dp_overlap and self._dp_in_graph():
             red.on_bucket = self._bucket_ready
             red.bucket_inline, red.fork_side = self.dp_overlap_mode == 1, self.fork_side
-        prob, sv_g = engine.guide_fwd(p, src, tidx, dims, base, gen=gen["guide"])
+        lowrank = self.fused_tails and engine.chain_ok(dims)      # the guide's backward (KL path) is the dPre chain: its first layers may run low-rank
+        prob, sv_g = engine.guide_fwd(p, src, tidx, dims, base, gen=gen["guide"], lowrank_in=lowrank) if need_guide else (None, None)
         if self._needs_exchange(phase):
             self.label_l.copy_(sv_g[4])                           # this rank's cluster labels -> all-gather (_exchange_labels)
         return dict(tidx=tidx, gen=gen, red=red, prob=prob, sv_g=sv_g)

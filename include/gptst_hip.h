@@ -155,6 +155,16 @@ int gptst_encin_ht1_bwd(const float* dPre, const float* src, int lda, const floa
                         const float* Wbt, const float* ab, const float* wv, float* dWb, float* dG, float* dinp, int B, int T, int N, int C,
                         void* stream);
 
+/* Guide classifier MLP_RL, input projection + node-conditioned layer on the low-rank structure of the input (guidein.hip, r04): for base = 1
+ * h1 = LReLU((s w1 + b1) W_n + b_n) = LReLU(s u_n + c_n) with u_n = w1 W_n, c_n = b1 W_n + b_n — an elementwise pass; the backward needs
+ * p_n = sum_rows s dPre and q_n = sum_rows dPre only: dW_n = w1^T (x) p_n + b1^T (x) q_n, db_n = q_n, d w1 = sum_n W_n p_n, d b1 = sum_n W_n q_n.
+ * fwd: src rows (BT*N, lda) with the flow in column 0 -> h1 (BT*N, C).   bwd: dPre = dOut * lrelu'(h1) -> dWb (N, C*C + C) rows [dW_n | db_n],
+ * dinp (N, 2C) partials of [d ln1.weight | d ln1.bias].  Replaces GPTST.py:22-27 and its backward.  base = 1, C in {64, 128}. */
+int gptst_guide_in_fwd(const float* src, int lda, const float* w1, const float* b1, const float* Wn, const float* bn, float* h1, int BT, int N,
+                       int C, void* stream);
+int gptst_guide_in_bwd(const float* dPre, const float* src, int lda, const float* w1, const float* b1, const float* Wn, float* dWb, float* dinp,
+                       int BT, int N, int C, void* stream);
+
 /* "dPre chain" convention of the backward kernels (r03): the gradient that travels down the layer chain may be handed over ALREADY multiplied
  * by the LeakyReLU derivative of the activation it belongs to (dPre = dOut * lrelu'(out)).  A consumer is told so by Y == NULL (it then
  * takes its incoming gradient as dPre and never reads its own output), and a producer is told to emit that form by premul != 0: it

@@ -1108,3 +1108,29 @@ def test_encin_ht1_low_rank_pair_equals_lin_in_plus_hypertem(B, N, C, masked):
     m = (torch.where(mask.view(B, T, N) != 0, src[..., 0], torch.full_like(src[..., 0], fill)) if masked else src[..., 0]).double()
     close(dinp[:, :C].sum(0), torch.einsum("btn,btnc->c", m, dX0).cpu(), tol=5e-6, what="encin d weight")
     close(dinp[:, C:].sum(0), dX0.sum((0, 1, 2)).cpu(), tol=5e-6, what="encin d bias")
+
+
+@pytest.mark.parametrize("B,N,C", [(32, 170, 64), (2, 20, 64), (1, 45, 128)])
+def test_guide_in_low_rank_pair_equals_lin_in_plus_node_layer(B, N, C):
+    """guidein.hip: MLP_RL's input projection (base = 1) + node-conditioned layer as an elementwise pass, and their backward from two vectors
+    per node, against gptst_lin_in + gptst_apply(MODE_NODE) and fp64 einsums."""
+    from gptst_amd import ops
+    from gptst_amd.ops import MODE_NODE, EPI_LRELU
+    dev = _dev()
+    g = torch.Generator().manual_seed(93 + N)
+    T = 12
+    src = rnd(B, T, N, 3, g=g).to(dev)
+    w1, b1 = rnd(C, 1, g=g).to(dev), (rnd(C, g=g) * 0.5).to(dev)
+    Wn, bn = (rnd(N, C, C, g=g) * 0.1).to(dev), (rnd(N, C, g=g) * 0.3).to(dev)
+    h1 = ops.guide_in_fwd(src, w1, b1, Wn, bn)
+    h0 = ops.lin_in(src, 3, 1, w1, b1, C)
+    ref = ops.apply(h0, Wn, MODE_NODE, B * T, N, bias=bn, epi=EPI_LRELU)
+    close(h1, ref.cpu(), tol=3e-6, what="guide_in h1")
+    dPre = rnd(B * T * N, C, g=g).to(dev)
+    dWb, dinp = ops.guide_in_bwd(dPre, src, w1, b1, Wn)
+    h0v, dP, s = h0.view(B * T, N, C).double(), dPre.view(B * T, N, C).double(), src[..., 0].reshape(B * T, N).double()
+    close(dWb[:, :C * C].view(N, C, C), torch.einsum("rni,rno->nio", h0v, dP).cpu(), tol=5e-6, what="guide_in dW_n")
+    close(dWb[:, C * C:], dP.sum(0).cpu(), tol=5e-6, what="guide_in db_n")
+    dh0 = torch.einsum("rno,nio->rni", dP, Wn.double())
+    close(dinp[:, :C].sum(0), torch.einsum("rn,rni->i", s, dh0).cpu(), tol=5e-6, what="guide_in d ln1.weight")
+    close(dinp[:, C:].sum(0), dh0.sum((0, 1)).cpu(), tol=5e-6, what="guide_in d ln1.bias")
