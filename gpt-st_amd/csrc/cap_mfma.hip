@@ -18,6 +18,8 @@ extern "C" int gptst_cap_ts(long long* out) { return (int)hipMemcpyFromSymbol(ou
 static constexpr int g_cap_dbg = 0;
 #endif
 
+GPTST_STAMP_TABLES(capmfma)
+
 #define CM_NT 512
 #define CM_NW (CM_NT / 64)
 
@@ -450,26 +452,34 @@ extern "C" int gptst_cap_occupancy(int N, int HS) {
 //   U[h,n] = dS[h,:].P[n,:]  (MFMA 16x16x4, P = g(n) Y)  ->  dc = dc1 + U,  dlogit = c (dc - sum_h c dc)
 //   dP[n,:] = sum_h c[h,n] dS[h,:]  (MFMA 16x16x4, K = clusters)  ->  squash backward  dY = g dP + Y (2 g'(q) (Y.dP))
 // =====================================================================================================================
-struct CrossBwdArgs { const float* dv; const float* s; const float* Rt; const float* Ht; const float* dyn; const float* tmpl; float* ddyn; int T, HT; };
+#define CX_SPLIT 4        // cross-time role: workgroups per sample (each owns 12 / CX_SPLIT time steps; the whole-sample part is repeated by them)
+struct CrossBwdArgs { const float* dv; const float* s; const float* Rt; const float* Ht; const float* dyn; const float* tmpl; float* ddyn; int T, HT;
+                      float* dSg; unsigned* flags; int nB; };     // roles (r04): nB cross-time workgroups publish dS (B*T, HS, C) + one flag per sample
 
 // ---- backward of the cross-time block (cap_cross_bwd_kernel, cap_cross.hip) as a PROLOGUE of the (b,t) workgroups below (r03) -----------
 // cap_cross_bwd runs on B workgroups between two (b,t)-grouped kernels.  Folded in, every (b,t) workgroup repeats the part that needs the
 // whole sample — du / dRpre of all T*HS tokens and dHpre (HT x C over the tokens), ~0.3 MFLOP — and then produces only what belongs to its
 // own HS tokens: dS rows (straight into the LDS tile the routing backward reads: no global round trip) and the ddyn columns.
 // Scratch: the Ys / Wl regions of the kernel below (free until its first phase).  Same arithmetic as cap_cross_bwd_kernel.
-template <int C>
+// GLOBAL (r04, the cross-time ROLE of the kernel below): the workgroup owns the tokens of time steps t0 .. t0 + nt - 1 of the sample (nt = 1 and
+// dS into the LDS tile Vs in the prologue form) and writes their dS rows THROUGH to dSg (sc1 stores: the sample's routing workgroups read them in
+// this launch).  The part that needs the whole sample (du / dRpre of every token, dHpre) is repeated by the workgroups of a sample either way.
+template <int C, bool GLOBAL>
 __device__ __forceinline__ void cap_cross_bwd_prologue(const float* __restrict__ dv, const float* __restrict__ s, const float* __restrict__ Rt,
                                                        const float* __restrict__ Ht, const float* __restrict__ dyn,
                                                        const float* __restrict__ tmpl, float* __restrict__ ddyn, float* __restrict__ scratch,
-                                                       float* __restrict__ Vs, int b, int t, int T, int HS, int HT) {
+                                                       float* __restrict__ Vs, int b, int t0, int nt, int T, int HS, int HT,
+                                                       float* __restrict__ dSg = nullptr) {
     constexpr int P = Tile<C>::PITCH, LPR = C / 4;
     const int KK = T * HS, tid = threadIdx.x;
+    const int k0 = t0 * HS, nown = nt * HS;    // own tokens: k0 .. k0 + nown - 1
     float* Gs = scratch;                       // KK * P   dRpre
     float* Hs = Gs + KK * P;                   // HT * P   Ht
     float* dHs = Hs + HT * P;                  // HT * P   dHpre
-    float* Zo = dHs + HT * P;                  // HS * P   Z rows of the own tokens
-    float* dyns = Zo + HS * P;                 // HT * KK
-    // rows k: u = Rt + s;  du = squash_bwd(u, dv);  dRpre = du * lrelu'(Rt);  own rows: du -> Vs[h], Z -> Zo[h].
+    float* Zo = dHs + HT * P;                  // nown * P Z rows of the own tokens
+    float* Uo = Zo + nown * P;                 // nown * P du rows of the own tokens (GLOBAL; the prologue form keeps them in Vs)
+    float* dyns = Uo + (GLOBAL ? nown * P : 0);   // HT * KK
+    // rows k: u = Rt + s;  du = squash_bwd(u, dv);  dRpre = du * lrelu'(Rt);  own rows: du -> Vs[h] / Uo, Z -> Zo.
     // All global loads of a batch are issued before the first LDS store / use (a copy loop is one serialised L2 round trip per trip).
     {
         const int nz = KK * LPR, nd = HT * KK / 4, nh = HT * LPR;
@@ -506,10 +516,10 @@ __device__ __forceinline__ void cap_cross_bwd_prologue(const float* __restrict__
                 if (valid) {
                     st4(Gs + k * P + 4 * c4, make_float4(du.x * lrelu_grad_from_out(rt.x), du.y * lrelu_grad_from_out(rt.y),
                                                          du.z * lrelu_grad_from_out(rt.z), du.w * lrelu_grad_from_out(rt.w)));
-                    if (k / HS == t) {
-                        const float tm = tmpl[t];
-                        st4(Vs + (k - t * HS) * P + 4 * c4, du);
-                        st4(Zo + (k - t * HS) * P + 4 * c4, make_float4(sv.x + tm, sv.y + tm, sv.z + tm, sv.w + tm));
+                    if (k >= k0 && k < k0 + nown) {
+                        const float tm = tmpl[k / HS];
+                        st4((GLOBAL ? Uo : Vs) + (k - k0) * P + 4 * c4, du);
+                        st4(Zo + (k - k0) * P + 4 * c4, make_float4(sv.x + tm, sv.y + tm, sv.z + tm, sv.w + tm));
                     }
                 }
             }
@@ -548,8 +558,8 @@ __device__ __forceinline__ void cap_cross_bwd_prologue(const float* __restrict__
     }
     __syncthreads();
     // own tokens: ddyn[j][k] = Ht[j].dRpre[k] + dHpre[j].Z[k]
-    for (int i = tid; i < HT * HS; i += CM_NT) {
-        const int j = i / HS, h = i % HS, k = t * HS + h;
+    for (int i = tid; i < HT * nown; i += CM_NT) {
+        const int j = i / nown, h = i % nown, k = k0 + h;
         float acc = 0.f;
 #pragma unroll 4
         for (int c4 = 0; c4 < LPR; ++c4) {
@@ -559,17 +569,26 @@ __device__ __forceinline__ void cap_cross_bwd_prologue(const float* __restrict__
         ddyn[((size_t)b * HT + j) * KK + k] = acc;
     }
     // own tokens: dS[k] = du[k] + sum_j dyn[j][k] dHpre[j]
-    for (int i = tid; i < HS * LPR; i += CM_NT) {
-        const int h = i / LPR, c4 = i % LPR, k = t * HS + h;
+    for (int i = tid; i < nown * LPR; i += CM_NT) {
+        const int h = i / LPR, c4 = i % LPR, k = k0 + h;
         float4 acc = f4zero();
 #pragma unroll 8
         for (int j = 0; j < HT; ++j) acc = f4fma(dyns[j * KK + k], ld4(dHs + j * P + 4 * c4), acc);
-        st4(Vs + h * P + 4 * c4, f4add(ld4(Vs + h * P + 4 * c4), acc));
+        if (GLOBAL) {
+            // write-through (sc1): the routing workgroups of the sample read it in this launch (MI355X_MICROARCH.md, inter-workgroup visibility)
+            typedef int i32x4_ __attribute__((ext_vector_type(4)));
+            const float4 r4 = f4add(ld4(Uo + h * P + 4 * c4), acc);
+            const f32x4 v4 = {r4.x, r4.y, r4.z, r4.w};
+            const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(dSg + ((size_t)b * KK + k0) * C, 0, nown * C * 4, 0x00020000);
+            __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(i32x4_, v4), rs, (h * C + 4 * c4) * 4, 0, 16);
+        } else {
+            st4(Vs + h * P + 4 * c4, f4add(ld4(Vs + h * P + 4 * c4), acc));
+        }
     }
     __syncthreads();
 }
 
-template <int C>
+template <int C, bool ROLES>
 __global__ __launch_bounds__(CM_NT, 4) void cap_route_bwd2_kernel(const float* __restrict__ X, const float* __restrict__ Wp,
                                                                   const float* __restrict__ bp, const float* __restrict__ c,
                                                                   const float* __restrict__ dc1, const float* __restrict__ dS,
@@ -586,14 +605,37 @@ __global__ __launch_bounds__(CM_NT, 4) void cap_route_bwd2_kernel(const float* _
     float* Vs = Wl + region2;               // HSP * P    dS (rows >= HS zero)
     float* gq = Vs + HSP * P;               // NR         squash factor g(n)
     float* qq = gq + NR;                    // NR         squared norm q(n)
-    const int bt = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const float* Xbt = X + (size_t)bt * N * C;
-    const bool fold = cx.dv != nullptr;                 // dS comes out of the cross-time backward, computed here (uniform)
-    if (fold) {
-        for (int i = tid; i < HSP * P; i += CM_NT) Vs[i] = 0.f;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    // ---- ROLES (r04): the backward of the cross-time block needs the whole sample, and as a prologue of every (b,t) workgroup it was repeated
+    // T times and sat IN FRONT of each workgroup's chain (8-13 us of its 27-31, tools/phase_stamps.py).  In the role form the first nB workgroups
+    // do it once per sample and publish dS (write-through stores, then one flag per sample), while the B*T routing workgroups rebuild their
+    // capsule tile first — that GEMM does not depend on dS — and pick dS up behind it.  All nB + B*T workgroups are resident together (two per
+    // CU, checked by the launcher); the wait is bounded (~1 ms): on expiry dS is poisoned with NaN, so a lost hand-off ends the run loudly (NaN
+    // loss / gradient norm) instead of hanging the GPU or training on a wrong gradient.  A separate instantiation: with both forms in one
+    // kernel the register allocator spilled 100 registers.
+    unsigned* s_ok = reinterpret_cast<unsigned*>(qq + NR);
+    GPTST_WG_BEGIN(); GPTST_STAMP(0);
+    if (ROLES && (int)blockIdx.x < cx.nB) {                          // cross-time role: workgroup r = (sample r / CX_SPLIT, time steps of part r % CX_SPLIT)
+        constexpr int TS = 12 / CX_SPLIT;
+        cap_cross_bwd_prologue<C, true>(cx.dv, cx.s, cx.Rt, cx.Ht, cx.dyn, cx.tmpl, cx.ddyn, smem, nullptr, blockIdx.x / CX_SPLIT,
+                                        (blockIdx.x % CX_SPLIT) * TS, TS, cx.T, HS, cx.HT, cx.dSg);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");            // every storing wave drains its write-through stores ...
         __syncthreads();
-        cap_cross_bwd_prologue<C>(cx.dv, cx.s, cx.Rt, cx.Ht, cx.dyn, cx.tmpl, cx.ddyn, smem, Vs, bt / cx.T, bt % cx.T, cx.T, HS, cx.HT);
+        if (tid == 0) __hip_atomic_store(cx.flags + blockIdx.x, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);     // ... before the flag goes up
+        GPTST_STAMP(1); GPTST_WG_END();
+        return;
     }
+    const int bt = ROLES ? (int)blockIdx.x - cx.nB : (int)blockIdx.x;
+    const float* Xbt = X + (size_t)bt * N * C;
+    const bool fold = !ROLES && cx.dv != nullptr;                  // dS out of the cross-time backward computed HERE (uniform)
+    if constexpr (!ROLES) {
+        if (fold) {
+            for (int i = tid; i < HSP * P; i += CM_NT) Vs[i] = 0.f;
+            __syncthreads();
+            cap_cross_bwd_prologue<C, false>(cx.dv, cx.s, cx.Rt, cx.Ht, cx.dyn, cx.tmpl, cx.ddyn, smem, Vs, bt / cx.T, bt % cx.T, 1, cx.T, HS, cx.HT);
+        }
+    }
+    GPTST_STAMP(1);
 
     if constexpr (C == 64) {
         // ---- Y = X Wp^T + bp, q = |Y|^2, g = squash factor: fused MFMA epilogue as in the forward ----
@@ -604,6 +646,7 @@ __global__ __launch_bounds__(CM_NT, 4) void cap_route_bwd2_kernel(const float* _
         load_w_lds<C, CM_NT>(Wl, Wp, 1, tid);
         if (!fold) for (int i = tid; i < HSP * P; i += CM_NT) Vs[i] = 0.f;
         __syncthreads();
+        GPTST_STAMP(2);
         float4 bv[4][4];
         cm_load_bfrag(bv, Wl, j, kk);
         for (int tile = wave; tile < NR / 16; tile += CM_NW) {
@@ -620,6 +663,7 @@ __global__ __launch_bounds__(CM_NT, 4) void cap_route_bwd2_kernel(const float* _
             }
         }
         __syncthreads();
+        GPTST_STAMP(3);
         for (int i = tid; i < 2 * HSP * NP; i += CM_NT) cs[i] = 0.f;
         __syncthreads();
     } else {
@@ -701,8 +745,30 @@ __global__ __launch_bounds__(CM_NT, 4) void cap_route_bwd2_kernel(const float* _
             if (i < HS * N) { cs[(i / N) * NP + i % N] = cv[k]; dcs[(i / N) * NP + i % N] = dv[k]; }
         }
     }
-    if (!fold) for (int i = tid; i < HS * LPR; i += CM_NT) st4(Vs + (i / LPR) * P + 4 * (i % LPR), ld4(dS + (size_t)bt * HS * C + 4 * i));
+    if (!fold && !ROLES) for (int i = tid; i < HS * LPR; i += CM_NT) st4(Vs + (i / LPR) * P + 4 * (i % LPR), ld4(dS + (size_t)bt * HS * C + 4 * i));
+    if constexpr (ROLES) {
+        if (tid == 0) {                                              // ONE lane polls the sample's flag, relaxed, bounded
+            unsigned got = 0u;
+            for (int spin = 0; spin < 4000; ++spin) {
+                got = __hip_atomic_load(cx.flags + (bt / cx.T) * CX_SPLIT + (bt % cx.T) / (12 / CX_SPLIT), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                if (got) break;
+                __builtin_amdgcn_s_sleep(8);
+            }
+            *s_ok = got;
+        }
+        __syncthreads();
+        const bool ok = *s_ok != 0u;
+        typedef int i32x4_ __attribute__((ext_vector_type(4)));
+        const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(cx.dSg) + (size_t)bt * HS * C, 0, HS * C * 4, 0x00020000);
+        for (int i = tid; i < HS * LPR; i += CM_NT) {                // dS rows of this (b,t): sc1 loads (written through by the cross-time role)
+            const i32x4_ v = __builtin_amdgcn_raw_buffer_load_b128(rs, i * 16, 0, 16);
+            const f32x4 f4 = __builtin_bit_cast(f32x4, v);
+            const float nan = __int_as_float(0x7fc00000);
+            st4(Vs + (i / LPR) * P + 4 * (i % LPR), ok ? make_float4(f4[0], f4[1], f4[2], f4[3]) : make_float4(nan, nan, nan, nan));
+        }
+    }
     __syncthreads();
+    GPTST_STAMP(4);
 
     const int j = lane & 15, kk = lane >> 4;
     const int ntiles = (N + 15) / 16;
@@ -782,25 +848,41 @@ __global__ __launch_bounds__(CM_NT, 4) void cap_route_bwd2_kernel(const float* _
             if (nn < N) st4(dY + ((size_t)bt * N + nn) * C + 4 * c4, ld4(Ys + nn * P + 4 * c4));
         }
     }
+    GPTST_STAMP(5);
+    GPTST_WG_END();
 }
+
+thread_local int g_cap_bwd_noroles = 0;       // gptst_tune(23, 1): the cross-time backward as a replicated prologue (r03) also where the role form serves
 
 template <int C>
 static int launch_route_bwd2(const float* X, const float* Wp, const float* bp, const float* c, const float* dc1, const float* dS,
-                             float* dY, float* dlogit, int BT, int N, int HS, hipStream_t st, CrossBwdArgs cx = CrossBwdArgs{}) {
+                             float* dY, float* dlogit, int BT, int N, int HS, hipStream_t st, CrossBwdArgs cx = CrossBwdArgs{nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, 0, 0, nullptr, nullptr, 0}) {
     if (HS > 64) return GPTST_ESHAPE;
     const int NR = cm_rows(N), NP = cm_np(N), HSP = cm_hsp(HS);
     size_t r2 = (size_t)C * C, need = (size_t)2 * HSP * NP;
     if (need > r2) r2 = need;
     r2 = (r2 + 3) & ~(size_t)3;
-    const size_t smem = ((size_t)NR * Tile<C>::PITCH + r2 + (size_t)HSP * Tile<C>::PITCH + 2 * (size_t)NR) * sizeof(float);
+    const size_t smem = ((size_t)NR * Tile<C>::PITCH + r2 + (size_t)HSP * Tile<C>::PITCH + 2 * (size_t)NR + 4) * sizeof(float);
     if (smem > 160 * 1024) return GPTST_ESHAPE;
     if (cx.dv) {                                     // the prologue's scratch must fit the Ys + Wl regions
         const size_t need_cx = (size_t)(cx.T * HS + 2 * cx.HT + HS) * Tile<C>::PITCH + (size_t)cx.HT * cx.T * HS;
         if (need_cx > (size_t)NR * Tile<C>::PITCH + r2 || (cx.HT * cx.T * HS) % 4 != 0) return GPTST_ESHAPE;
     }
+    if (cx.nB > 0) {                                     // roles: every workgroup resident (two per CU), T = 12, the role's scratch within the LDS tile regions
+        const int no = (12 / CX_SPLIT) * HS;
+        const size_t need_r = (size_t)(cx.T * HS + 2 * cx.HT + 2 * no) * Tile<C>::PITCH + (size_t)cx.HT * cx.T * HS;
+        if (smem > 80 * 1024 || BT + cx.nB > 512 || cx.T != 12 || need_r > (size_t)NR * Tile<C>::PITCH + r2) cx.nB = 0;
+    }
+    if (cx.nB > 0) {
+        static size_t curR = 0;
+        if (smem > curR) { (void)hipFuncSetAttribute((const void*)cap_route_bwd2_kernel<C, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem); curR = smem; }
+        hipLaunchKernelGGL((cap_route_bwd2_kernel<C, true>), dim3(BT + cx.nB), dim3(CM_NT), smem, st, X, Wp, bp, c, dc1, dS, dY, dlogit, N, HS, (int)r2, cx);
+        GPTST_CHECK_LAUNCH();
+        return GPTST_OK;
+    }
     static size_t cur = 0;
-    if (smem > cur) { hipFuncSetAttribute((const void*)cap_route_bwd2_kernel<C>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem); cur = smem; }
-    hipLaunchKernelGGL((cap_route_bwd2_kernel<C>), dim3(BT), dim3(CM_NT), smem, st, X, Wp, bp, c, dc1, dS, dY, dlogit, N, HS, (int)r2, cx);
+    if (smem > cur) { (void)hipFuncSetAttribute((const void*)cap_route_bwd2_kernel<C, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem); cur = smem; }
+    hipLaunchKernelGGL((cap_route_bwd2_kernel<C, false>), dim3(BT), dim3(CM_NT), smem, st, X, Wp, bp, c, dc1, dS, dY, dlogit, N, HS, (int)r2, cx);
     GPTST_CHECK_LAUNCH();
     return GPTST_OK;
 }
@@ -820,13 +902,16 @@ extern "C" int gptst_cap_route_bwd(const float* X, const float* Wp, const float*
 // gptst_cap_cross_bwd + gptst_cap_route_bwd in ONE launch (the cross-time backward as a prologue of every (b,t) workgroup; dS never leaves
 // LDS).  dv (B, T*HS, C) gradient of the cross-time block's output v; -> dY, dlogit, ddyn (B, HT, T*HS).  C = 64 and T*HS tokens within the
 // kernel's LDS scratch, else GPTST_ESHAPE (use the two launches).
+// dS_ws (B*T, HS, C) + flags (4 B 32-bit words, ZERO on entry; e.g. a slice of the step's zeroed scratch): both given -> the cross-time backward runs as a
+// ROLE of the launch (B extra workgroups, once per sample, overlapped with the routing workgroups' capsule GEMM); NULL -> every (b,t) workgroup repeats it.
 extern "C" int gptst_cap_cross_route_bwd(const float* X, const float* Wp, const float* bp, const float* c, const float* dc1, const float* dv,
                                          const float* s, const float* Rt, const float* Ht, const float* dyn, const float* tmpl, float* dY,
-                                         float* dlogit, float* ddyn, int B, int T, int N, int C, int HS, int HT, void* stream) {
+                                         float* dlogit, float* ddyn, float* dS_ws, void* flags, int B, int T, int N, int C, int HS, int HT, void* stream) {
     if (!X || !Wp || !bp || !c || !dc1 || !dv || !s || !Rt || !Ht || !dyn || !tmpl || !dY || !dlogit || !ddyn || B <= 0 || T <= 0) return GPTST_EARG;
     if (C != 64) return GPTST_ESHAPE;
+    const bool roles = dS_ws != nullptr && flags != nullptr && !g_cap_bwd_noroles;
     return launch_route_bwd2<64>(X, Wp, bp, c, dc1, nullptr, dY, dlogit, B * T, N, HS, (hipStream_t)stream,
-                                 CrossBwdArgs{dv, s, Rt, Ht, dyn, tmpl, ddyn, T, HT});
+                                 CrossBwdArgs{dv, s, Rt, Ht, dyn, tmpl, ddyn, T, HT, roles ? dS_ws : nullptr, roles ? (unsigned*)flags : nullptr, roles ? B * CX_SPLIT : 0});
 }
 
 // =====================================================================================================================

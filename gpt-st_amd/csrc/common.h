@@ -27,6 +27,32 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
         if (e__ != hipSuccess) return (int)e__;               \
     } while (0)
 
+// ---- per-workgroup phase stamps (-DGPTST_STAMPS builds only: tools/phase_stamps.py) -----------------------------------------------------
+// GPTST_STAMP(i) records the wall clock (100 MHz) of stamp i for a few chosen workgroups (wave 0, lane 0) and, as stamp 0 / 31, every
+// workgroup's start / end goes to a second table — the schedule of a launch (who ran when, next to whom) is what located the prologue
+// bursts of cap_route_fwd.  Each translation unit has its own tables and exports gptst_stamps_<unit>(out).
+#ifdef GPTST_STAMPS
+#define GPTST_STAMP_TABLES(unit)                                                                                       \
+    __device__ long long g_st_ph[8][32];                                                                               \
+    __device__ long long g_st_wg[2048][2];                                                                             \
+    extern "C" __attribute__((visibility("default"))) int gptst_stamps_##unit(long long* ph, long long* wg) {          \
+        if (ph && hipMemcpyFromSymbol(ph, HIP_SYMBOL(g_st_ph), sizeof(long long) * 8 * 32) != hipSuccess) return 1;   \
+        if (wg && hipMemcpyFromSymbol(wg, HIP_SYMBOL(g_st_wg), sizeof(long long) * 2048 * 2) != hipSuccess) return 1; \
+        return 0;                                                                                                      \
+    }
+// slots: workgroups 5, 100, 200, 300 (+ 261, 383 for second residents), first wave
+#define GPTST_STAMP(i) do { if ((threadIdx.x & 63) == 0 && (threadIdx.x >> 6) == 0) { const int b_ = blockIdx.x;               \
+        const int sl_ = b_ == 5 ? 0 : b_ == 100 ? 1 : b_ == 200 ? 2 : b_ == 300 ? 3 : b_ == 261 ? 4 : b_ == 383 ? 5 : -1;        \
+        if (sl_ >= 0) g_st_ph[sl_][i] = wall_clock64(); } } while (0)
+#define GPTST_WG_BEGIN() do { if (threadIdx.x == 0 && blockIdx.x < 2048) g_st_wg[blockIdx.x][0] = wall_clock64(); } while (0)
+#define GPTST_WG_END() do { if (threadIdx.x == 0 && blockIdx.x < 2048) g_st_wg[blockIdx.x][1] = wall_clock64(); } while (0)
+#else
+#define GPTST_STAMP_TABLES(unit)
+#define GPTST_STAMP(i) do { } while (0)
+#define GPTST_WG_BEGIN() do { } while (0)
+#define GPTST_WG_END() do { } while (0)
+#endif
+
 // Phase fence for the machine scheduler: instructions are not moved across it.  The kernels are written as explicit phases (batch
 // of global loads -> LDS / MFMA -> prefetch of the next tile -> stores) and lose 10-40 % when the compiler re-interleaves them.
 #ifdef GPTST_NO_SB

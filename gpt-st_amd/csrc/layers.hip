@@ -172,7 +172,7 @@ extern "C" int gptst_cap_layer_bwd(const float* dout, const float* x, const floa
     if (w.left < 0 || q.left < 0) return GPTST_EWS;
     TRY(gptst_apply_wgrad(dout, out, rec, Wn, drec, dWn, dbn, 0, 1, (int)BT, N, C, stream));                             // :139-141 backward
     TRY(gptst_cap_rec_bwd(drec, c, v, dc1, dv, (int)BT, N, C, HS, stream));                                              // :135
-    int rc = gptst_cap_cross_route_bwd(x, ln_p_w, ln_p_b, c, dc1, dv, s, Rt, Ht, dyn, mask_template, dY, dlogit, ddyn, B, T, N, C, HS, HT, stream);
+    int rc = gptst_cap_cross_route_bwd(x, ln_p_w, ln_p_b, c, dc1, dv, s, Rt, Ht, dyn, mask_template, dY, dlogit, ddyn, nullptr, nullptr, B, T, N, C, HS, HT, stream);   // (no zeroed flag words in the caller-owned scratch: the replicated-prologue form)
     if (rc == GPTST_ESHAPE) {
         TRY(gptst_cap_cross_bwd(dv, s, Rt, Ht, dyn, mask_template, dS, ddyn, cws, B, T, C, HS, HT, stream));             // :125-134
         rc = gptst_cap_route_bwd(x, ln_p_w, ln_p_b, c, dc1, dS, dY, dlogit, (int)BT, N, C, HS, stream);                  // :102-123

@@ -277,6 +277,7 @@ def hypertem_core_bwd(saved, dout, dG_out, dims, chain=False, premul=False):
 
 # ---- cap (GPTST.py:100-141) ----------------------------------------------------------------------------------------
 FUSE_CROSS = os.environ.get("GPTST_FUSE_CROSS", "1") == "1"     # cross-time block folded into its (b,t)-grouped neighbours (r03)
+CROSS_ROLE = os.environ.get("GPTST_CROSS_ROLE", "1") == "1"     # ... its backward as a ROLE of the routing backward's launch (r04; 0: replicated prologue)
 
 
 def cap_head_fwd(p, pfx, x, dadj, dyn, dims, num_route, HS, HT):
@@ -357,7 +358,7 @@ def cap_core_bwd(p, g, pfx, saved, dout, dims, HS, HT, red, chain=False):
     fused = None
     if FUSE_CROSS and CTX.NODE_REDUCE is None and Y is None:
         fused = ops.cap_cross_route_bwd(x.view(B, T, N, C), p[pfx + "ln_p.weight"], p[pfx + "ln_p.bias"], c, dc1, dv, s, Rt, Ht, dyn,
-                                        p[pfx + "mask_template"], B, T, HS, HT)
+                                        p[pfx + "mask_template"], B, T, HS, HT, flags=_zeros(x, 4 * B) if CROSS_ROLE else None)
     if fused is not None:
         dY, dlogit, ddyn = fused
     else:

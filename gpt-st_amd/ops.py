@@ -632,8 +632,10 @@ def cap_route_bwd(X, Wp, bp, c, dc1, dS, Y=None):
     return dY, dlogit
 
 
-def cap_cross_route_bwd(X, Wp, bp, c, dc1, dv, s, Rt, Ht, dyn, tmpl, B, T, HS, HT):
-    """Cross-time backward + routing backward in one launch -> (dY, dlogit, ddyn) or None when the shape needs the two-launch path."""
+def cap_cross_route_bwd(X, Wp, bp, c, dc1, dv, s, Rt, Ht, dyn, tmpl, B, T, HS, HT, flags=None):
+    """Cross-time backward + routing backward in one launch -> (dY, dlogit, ddyn) or None when the shape needs the two-launch path.
+    flags: 4 B ZEROED 32-bit words (a float32 tensor of zeros will do) — the cross-time backward then runs as a role of the launch (once per
+    sample, overlapped with the routing workgroups' capsule GEMM) instead of a prologue repeated by every (b,t) workgroup."""
     _chk(X, Wp, bp, c, dc1, dv, s, Rt, Ht, dyn, tmpl)
     N, C = X.shape[2], X.shape[3]
     if C != 64 or FORCE_CAP_BIG:
@@ -642,8 +644,9 @@ def cap_cross_route_bwd(X, Wp, bp, c, dc1, dv, s, Rt, Ht, dyn, tmpl, B, T, HS, H
     dlogit = torch.empty_like(c)
     ddyn = torch.empty_like(dyn)
     try:
+        dS_ws = torch.empty(B * T, HS, C, device=X.device, dtype=torch.float32) if flags is not None else None
         _call("gptst_cap_cross_route_bwd", _p(X), _p(Wp), _p(bp), _p(c), _p(dc1), _p(dv), _p(s), _p(Rt), _p(Ht), _p(dyn), _p(tmpl), _p(dY),
-              _p(dlogit), _p(ddyn), B, T, N, C, HS, HT, nbytes=_nb(X, Wp, bp, c, dc1, dv, s, Rt, dY, dlogit))
+              _p(dlogit), _p(ddyn), _p(dS_ws), _p(flags), B, T, N, C, HS, HT, nbytes=_nb(X, Wp, bp, c, dc1, dv, s, Rt, dY, dlogit))
     except _C.GptstError as e:
         if e.code != _C.ESHAPE:
             raise

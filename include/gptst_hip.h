@@ -216,10 +216,14 @@ int gptst_cap_route_bwd(const float* X, const float* Wp, const float* bp, const 
                         float* dY, float* dlogit, int BT, int N, int C, int HS, void* stream);
 /* gptst_cap_cross_bwd + gptst_cap_route_bwd in ONE launch of B*T workgroups: the backward of the cross-time block (GPTST.py:125-134) runs as a
  * prologue of every (b,t) workgroup (the part that needs the whole sample is repeated by its T workgroups), dS stays in LDS.
- * dv (B, T*HS, C): gradient of v;  -> dY, dlogit as gptst_cap_route_bwd, ddyn (B, HT, T*HS).  C = 64, else GPTST_ESHAPE. */
+ * dv (B, T*HS, C): gradient of v;  -> dY, dlogit as gptst_cap_route_bwd, ddyn (B, HT, T*HS).  C = 64, else GPTST_ESHAPE.
+ * r04 — dS_ws (B*T, HS, C) scratch + flags (4 B 32-bit words, ZERO on entry): both given -> the cross-time backward is a ROLE of the launch: 4 B extra
+ * workgroups do it (four per sample, three time steps each) and publish dS (write-through stores + one flag per sample) while the B*T routing workgroups rebuild their
+ * capsule tile, which does not depend on dS, and pick dS up behind it (a bounded wait; on expiry the workgroup computes the prologue itself).
+ * Either NULL: every (b,t) workgroup repeats the cross-time backward as a prologue (r03). */
 int gptst_cap_cross_route_bwd(const float* X, const float* Wp, const float* bp, const float* c, const float* dc1, const float* dv,
                               const float* s, const float* Rt, const float* Ht, const float* dyn, const float* tmpl, float* dY,
-                              float* dlogit, float* ddyn, int B, int T, int N, int C, int HS, int HT, void* stream);
+                              float* dlogit, float* ddyn, float* dS_ws, void* flags, int B, int T, int N, int C, int HS, int HT, void* stream);
 
 /* ---- cap for node counts whose (b,t) capsule matrix does not fit LDS (cap_big.hip; BASELINE config 5: N = 4096, C = 128) ----
  * gptst_cap_fits_lds() == 0 -> the host composes the same algebra from these streaming kernels (ops.py: cap_route_fwd/bwd, cap_rec_*):

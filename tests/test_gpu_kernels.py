@@ -963,6 +963,13 @@ def test_cap_cross_folded_into_its_neighbours(B, N, HS, HT):
     close(ddyn2, ddyn1.cpu(), tol=2e-6, what="folded ddyn")
     close(dY2, dY1.cpu(), tol=2e-6, what="folded dY")
     close(dl2, dl1.cpu(), tol=2e-6, what="folded dlogit")
+    # r04: the cross-time backward as a ROLE of the launch (B extra workgroups publish dS per sample: write-through stores + a flag; the routing
+    # workgroups wait for it behind their capsule GEMM) — the same arithmetic: bit-identical to the replicated prologue, call after call
+    for rep in range(3):
+        fr = ops.cap_cross_route_bwd(X, Wp, bp, c, dc1, dv, s, Rt1, Ht1, dyn, tmpl, B, T, HS, HT, flags=torch.zeros(4 * B, device=dev))
+        assert fr is not None
+        for a, b_, nm in zip(fr, fb, ("dY", "dlogit", "ddyn")):
+            assert torch.equal(a, b_), "role form differs from the prologue form in %s (rep %d)" % (nm, rep)
 
 
 def test_step_begin_draws_philox_noise():
