@@ -452,9 +452,79 @@ extern "C" int gptst_cap_occupancy(int N, int HS) {
 //   U[h,n] = dS[h,:].P[n,:]  (MFMA 16x16x4, P = g(n) Y)  ->  dc = dc1 + U,  dlogit = c (dc - sum_h c dc)
 //   dP[n,:] = sum_h c[h,n] dS[h,:]  (MFMA 16x16x4, K = clusters)  ->  squash backward  dY = g dP + Y (2 g'(q) (Y.dP))
 // =====================================================================================================================
+// =====================================================================================================================
+// backward of the cluster -> node scatter rec[n,:] = sum_h c[h,n] v[h,:]  (GPTST.py:135):
+//   dc1[h,n] = drec[n,:] . v[h,:]   (type 2, "V" = v)        dv[h,:] = sum_n c[h,n] drec[n,:]   (type 1, "P" = drec)
+// drec rows of one (b,t) are staged in LDS once; both contractions on MFMA 16x16x4.
+// =====================================================================================================================
+// PUB: dc1 / dv are consumed by OTHER workgroups of the same launch (the roles of cap_route_bwd2_kernel): write-through (agent-scope) stores.
+template <int C, bool PUB>
+__device__ __forceinline__ void cap_rec_bwd2_body(const float* __restrict__ drec, const float* __restrict__ c, const float* __restrict__ v,
+                                                  float* __restrict__ dc1, float* __restrict__ dv, int N, int HS, int bt, float* __restrict__ smem) {
+    constexpr int P = Tile<C>::PITCH, LPR = C / 4;
+    const int NR = cm_rows(N), NP = cm_np(N), HSP = cm_hsp(HS);
+    float* Ds = smem;                       // NR * P   drec rows (rows >= N zero)
+    float* cs = Ds + NR * P;                // HSP * NP
+    float* bl = cs + HSP * NP;              // HS * NP  dc1 accumulator
+    float* Vs = bl + HS * NP;               // HSP * P  v
+    float* S = Vs + HSP * P;                // HSP * C  dv
+    const int tid = threadIdx.x;
+    // Loads are issued in batches ahead of the LDS stores (a copy loop costs one serialised L2 round trip per trip).
+    const int ncn = HS * N, nv = HS * LPR, nD = N * LPR;
+    const float* cb = c + (size_t)bt * ncn;
+    float cr[4];
+    float4 vr;
+#pragma unroll
+    for (int u = 0; u < 4; ++u) cr[u] = cb[min(u * CM_NT + tid, ncn - 1)];
+    vr = ld4(v + (size_t)bt * HS * C + 4 * (size_t)min(tid, nv - 1));
+    for (int i0 = 0; i0 < NR * LPR; i0 += 4 * CM_NT) {
+        float4 d4[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) d4[u] = ld4(drec + (size_t)bt * N * C + 4 * (size_t)min(i0 + u * CM_NT + tid, nD - 1));
+        SB();
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int i = i0 + u * CM_NT + tid;
+            if (i < NR * LPR) st4(Ds + (i / LPR) * P + 4 * (i % LPR), i < nD ? d4[u] : f4zero());
+        }
+    }
+    for (int i = tid; i < HSP * NP + HS * NP + HSP * P; i += CM_NT) cs[i] = 0.f;      // cs, bl, Vs
+    __syncthreads();
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+        const int i = u * CM_NT + tid;
+        if (i < ncn) cs[(i / N) * NP + i % N] = cr[u];
+    }
+    for (int i = 4 * CM_NT + tid; i < ncn; i += CM_NT) cs[(i / N) * NP + i % N] = cb[i];
+    if (tid < nv) st4(Vs + (tid / LPR) * P + 4 * (tid % LPR), vr);
+    for (int i = CM_NT + tid; i < nv; i += CM_NT) st4(Vs + (i / LPR) * P + 4 * (i % LPR), ld4(v + (size_t)bt * HS * C + 4 * i));
+    __syncthreads();
+    cm_type2<C>(Ds, Vs, bl, N, NP, HS, HSP);
+    cm_type1<C>(Ds, cs, S, N, NP, HSP);
+    __syncthreads();
+    if constexpr (PUB) {
+        for (int i = tid; i < HS * N; i += CM_NT) st_agent(dc1 + (size_t)bt * HS * N + i, bl[(i / N) * NP + i % N]);
+        const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(dv + (size_t)bt * HS * C, 0, HS * C * 4, 0x00020000);
+        for (int i = tid; i < HS * LPR; i += CM_NT) st4_sc1(rs, 16 * i, ld4(S + (i / LPR) * C + 4 * (i % LPR)));
+    } else {
+        for (int i = tid; i < HS * N; i += CM_NT) dc1[(size_t)bt * HS * N + i] = bl[(i / N) * NP + i % N];
+        for (int i = tid; i < HS * LPR; i += CM_NT) st4(dv + (size_t)bt * HS * C + 4 * i, ld4(S + (i / LPR) * C + 4 * (i % LPR)));
+    }
+}
+
+template <int C>
+__global__ __launch_bounds__(CM_NT, 4) void cap_rec_bwd2_kernel(const float* __restrict__ drec, const float* __restrict__ c,
+                                                                const float* __restrict__ v, float* __restrict__ dc1,
+                                                                float* __restrict__ dv, int N, int HS) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    cap_rec_bwd2_body<C, false>(drec, c, v, dc1, dv, N, HS, blockIdx.x, smem);
+}
+
+
 #define CX_SPLIT 4        // cross-time role: workgroups per sample (each owns 12 / CX_SPLIT time steps; the whole-sample part is repeated by them)
 struct CrossBwdArgs { const float* dv; const float* s; const float* Rt; const float* Ht; const float* dyn; const float* tmpl; float* ddyn; int T, HT;
-                      float* dSg; unsigned* flags; int nB; };     // roles (r04): nB cross-time workgroups publish dS (B*T, HS, C) + one flag per sample
+                      float* dSg; unsigned* flags; int nB;       // roles (r04): nB cross-time workgroups publish dS (B*T, HS, C) + their flags
+                      const float* drec; const float* v; float* dc1w; float* dvw; int nA, B; };   // + the B*T rec-backward workgroups (three-role form)
 
 // ---- backward of the cross-time block (cap_cross_bwd_kernel, cap_cross.hip) as a PROLOGUE of the (b,t) workgroups below (r03) -----------
 // cap_cross_bwd runs on B workgroups between two (b,t)-grouped kernels.  Folded in, every (b,t) workgroup repeats the part that needs the
@@ -464,7 +534,7 @@ struct CrossBwdArgs { const float* dv; const float* s; const float* Rt; const fl
 // GLOBAL (r04, the cross-time ROLE of the kernel below): the workgroup owns the tokens of time steps t0 .. t0 + nt - 1 of the sample (nt = 1 and
 // dS into the LDS tile Vs in the prologue form) and writes their dS rows THROUGH to dSg (sc1 stores: the sample's routing workgroups read them in
 // this launch).  The part that needs the whole sample (du / dRpre of every token, dHpre) is repeated by the workgroups of a sample either way.
-template <int C, bool GLOBAL>
+template <int C, bool GLOBAL, bool ACQ = false>     // ACQ: dv was produced in THIS launch (three-role form): agent-scope loads
 __device__ __forceinline__ void cap_cross_bwd_prologue(const float* __restrict__ dv, const float* __restrict__ s, const float* __restrict__ Rt,
                                                        const float* __restrict__ Ht, const float* __restrict__ dyn,
                                                        const float* __restrict__ tmpl, float* __restrict__ ddyn, float* __restrict__ scratch,
@@ -485,12 +555,14 @@ __device__ __forceinline__ void cap_cross_bwd_prologue(const float* __restrict__
         const int nz = KK * LPR, nd = HT * KK / 4, nh = HT * LPR;
         const float* db = dyn + (size_t)b * HT * KK;
         const float* hb = Ht + (size_t)b * HT * C;
+        const __amdgpu_buffer_rsrc_t rs_dv = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(dv) + (size_t)b * KK * C, 0, KK * C * 4, 0x00020000);
         for (int i0 = 0; i0 < nz; i0 += 4 * CM_NT) {
             float4 sv4[4], rt4[4], g4[4], dv1, hv1;
 #pragma unroll
             for (int u = 0; u < 4; ++u) {
-                const size_t off = (size_t)b * KK * C + 4 * (size_t)min(i0 + u * CM_NT + tid, nz - 1);
-                sv4[u] = ld4(s + off); rt4[u] = ld4(Rt + off); g4[u] = ld4(dv + off);
+                const int il = min(i0 + u * CM_NT + tid, nz - 1);
+                const size_t off = (size_t)b * KK * C + 4 * (size_t)il;
+                sv4[u] = ld4(s + off); rt4[u] = ld4(Rt + off); g4[u] = ACQ ? ld4_sc1(rs_dv, 16 * il) : ld4(dv + off);
             }
             if (i0 == 0) { dv1 = ld4(db + 4 * (size_t)min(tid, nd - 1)); hv1 = ld4(hb + 4 * (size_t)min(tid, nh - 1)); }
             SB();
@@ -588,7 +660,7 @@ __device__ __forceinline__ void cap_cross_bwd_prologue(const float* __restrict__
     __syncthreads();
 }
 
-template <int C, bool ROLES>
+template <int C, int ROLES>      // 0: one role (dS given, or the cross-time backward as a prologue); 1: + cross-time role; 2: + rec-backward role
 __global__ __launch_bounds__(CM_NT, 4) void cap_route_bwd2_kernel(const float* __restrict__ X, const float* __restrict__ Wp,
                                                                   const float* __restrict__ bp, const float* __restrict__ c,
                                                                   const float* __restrict__ dc1, const float* __restrict__ dS,
@@ -615,17 +687,49 @@ __global__ __launch_bounds__(CM_NT, 4) void cap_route_bwd2_kernel(const float* _
     // kernel the register allocator spilled 100 registers.
     unsigned* s_ok = reinterpret_cast<unsigned*>(qq + NR);
     GPTST_WG_BEGIN(); GPTST_STAMP(0);
-    if (ROLES && (int)blockIdx.x < cx.nB) {                          // cross-time role: workgroup r = (sample r / CX_SPLIT, time steps of part r % CX_SPLIT)
-        constexpr int TS = 12 / CX_SPLIT;
-        cap_cross_bwd_prologue<C, true>(cx.dv, cx.s, cx.Rt, cx.Ht, cx.dyn, cx.tmpl, cx.ddyn, smem, nullptr, blockIdx.x / CX_SPLIT,
-                                        (blockIdx.x % CX_SPLIT) * TS, TS, cx.T, HS, cx.HT, cx.dSg);
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");            // every storing wave drains its write-through stores ...
+    // ---- three roles (ROLES == 2): the launch ALSO holds the B*T workgroups of cap_rec_bwd2 (dc1, dv out of drec), in front.  Block order is
+    // [rec-backward (b,t)] [cross-time (sample, part)] [routing (b,t)] and every wait points to a LOWER block index: cross-time part waits for
+    // its sample's T rec-backward workgroups (a counter), routing waits for its own rec-backward workgroup and its cross-time part.  With the
+    // dispatcher handing out blocks in index order nothing can wait on a workgroup that is not yet on the chip, whatever the residency; all
+    // waits are bounded and end in NaN.
+    if (ROLES == 2 && (int)blockIdx.x < cx.nA) {
+        const int bt = blockIdx.x;
+        cap_rec_bwd2_body<C, true>(cx.drec, c, cx.v, cx.dc1w, cx.dvw, N, HS, bt, smem);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
-        if (tid == 0) __hip_atomic_store(cx.flags + blockIdx.x, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);     // ... before the flag goes up
+        if (tid == 0) {
+            __hip_atomic_store(cx.flags + cx.nB + cx.B + bt, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_fetch_add(cx.flags + cx.nB + bt / cx.T, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
         GPTST_STAMP(1); GPTST_WG_END();
         return;
     }
-    const int bt = ROLES ? (int)blockIdx.x - cx.nB : (int)blockIdx.x;
+    const int blk = ROLES == 2 ? (int)blockIdx.x - cx.nA : (int)blockIdx.x;
+    if (ROLES && blk < cx.nB) {                          // cross-time role: workgroup r = (sample r / CX_SPLIT, time steps of part r % CX_SPLIT)
+        constexpr int TS = 12 / CX_SPLIT;
+        if constexpr (ROLES == 2) {
+            if (tid == 0) {
+                unsigned got = 0u;
+                for (int spin = 0; spin < 4000; ++spin) {
+                    got = __hip_atomic_load(cx.flags + cx.nB + blk / CX_SPLIT, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    if (got >= (unsigned)cx.T) break;
+                    __builtin_amdgcn_s_sleep(8);
+                }
+                *s_ok = got >= (unsigned)cx.T;
+            }
+            __syncthreads();
+            if (*s_ok == 0u) return;                     // no flag: the sample's routing workgroups time out and poison dS
+            __syncthreads();
+        }
+        cap_cross_bwd_prologue<C, true, ROLES == 2>(cx.dv, cx.s, cx.Rt, cx.Ht, cx.dyn, cx.tmpl, cx.ddyn, smem, nullptr, blk / CX_SPLIT,
+                                                    (blk % CX_SPLIT) * TS, TS, cx.T, HS, cx.HT, cx.dSg);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");            // every storing wave drains its write-through stores ...
+        __syncthreads();
+        if (tid == 0) __hip_atomic_store(cx.flags + blk, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);     // ... before the flag goes up
+        GPTST_STAMP(1); GPTST_WG_END();
+        return;
+    }
+    const int bt = ROLES ? blk - cx.nB : blk;
     const float* Xbt = X + (size_t)bt * N * C;
     const bool fold = !ROLES && cx.dv != nullptr;                  // dS out of the cross-time backward computed HERE (uniform)
     if constexpr (!ROLES) {
@@ -732,12 +836,26 @@ __global__ __launch_bounds__(CM_NT, 4) void cap_route_bwd2_kernel(const float* _
     }
     __syncthreads();
     }
+    auto poll = [&]() {                                              // ONE lane polls the flags it depends on, relaxed, bounded
+        if (tid == 0) {
+            unsigned got = 0u;
+            for (int spin = 0; spin < 4000; ++spin) {
+                got = __hip_atomic_load(cx.flags + (bt / cx.T) * CX_SPLIT + (bt % cx.T) / (12 / CX_SPLIT), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                if (ROLES == 2) got &= __hip_atomic_load(cx.flags + cx.nB + cx.B + bt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                if (got) break;
+                __builtin_amdgcn_s_sleep(8);
+            }
+            *s_ok = got;
+        }
+    };
+    if constexpr (ROLES == 2) { poll(); __syncthreads(); }            // dc1 comes out of this launch's rec-backward role
     for (int i0 = 0; i0 < HS * N; i0 += 4 * CM_NT) {             // c, dc1: batches of 4 + 4 loads per thread
         float cv[4], dv[4];
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
             const int i = min(i0 + k * CM_NT + tid, HS * N - 1);
-            cv[k] = c[(size_t)bt * HS * N + i]; dv[k] = dc1[(size_t)bt * HS * N + i];
+            cv[k] = c[(size_t)bt * HS * N + i];
+            dv[k] = ROLES == 2 ? ld_agent(dc1 + (size_t)bt * HS * N + i) : dc1[(size_t)bt * HS * N + i];
         }
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
@@ -746,16 +864,8 @@ __global__ __launch_bounds__(CM_NT, 4) void cap_route_bwd2_kernel(const float* _
         }
     }
     if (!fold && !ROLES) for (int i = tid; i < HS * LPR; i += CM_NT) st4(Vs + (i / LPR) * P + 4 * (i % LPR), ld4(dS + (size_t)bt * HS * C + 4 * i));
-    if constexpr (ROLES) {
-        if (tid == 0) {                                              // ONE lane polls the sample's flag, relaxed, bounded
-            unsigned got = 0u;
-            for (int spin = 0; spin < 4000; ++spin) {
-                got = __hip_atomic_load(cx.flags + (bt / cx.T) * CX_SPLIT + (bt % cx.T) / (12 / CX_SPLIT), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                if (got) break;
-                __builtin_amdgcn_s_sleep(8);
-            }
-            *s_ok = got;
-        }
+    if constexpr (ROLES != 0) {
+        if constexpr (ROLES == 1) poll();
         __syncthreads();
         const bool ok = *s_ok != 0u;
         typedef int i32x4_ __attribute__((ext_vector_type(4)));
@@ -873,16 +983,23 @@ static int launch_route_bwd2(const float* X, const float* Wp, const float* bp, c
         const size_t need_r = (size_t)(cx.T * HS + 2 * cx.HT + 2 * no) * Tile<C>::PITCH + (size_t)cx.HT * cx.T * HS;
         if (smem > 80 * 1024 || BT + cx.nB > 512 || cx.T != 12 || need_r > (size_t)NR * Tile<C>::PITCH + r2) cx.nB = 0;
     }
+    if (cx.nB > 0 && cx.nA > 0) {                        // three roles: the rec-backward workgroups in front (waits point to lower block indices only)
+        static size_t curA = 0;
+        if (smem > curA) { (void)hipFuncSetAttribute((const void*)cap_route_bwd2_kernel<C, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem); curA = smem; }
+        hipLaunchKernelGGL((cap_route_bwd2_kernel<C, 2>), dim3(cx.nA + cx.nB + BT), dim3(CM_NT), smem, st, X, Wp, bp, c, dc1, dS, dY, dlogit, N, HS, (int)r2, cx);
+        GPTST_CHECK_LAUNCH();
+        return GPTST_OK;
+    }
     if (cx.nB > 0) {
         static size_t curR = 0;
-        if (smem > curR) { (void)hipFuncSetAttribute((const void*)cap_route_bwd2_kernel<C, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem); curR = smem; }
-        hipLaunchKernelGGL((cap_route_bwd2_kernel<C, true>), dim3(BT + cx.nB), dim3(CM_NT), smem, st, X, Wp, bp, c, dc1, dS, dY, dlogit, N, HS, (int)r2, cx);
+        if (smem > curR) { (void)hipFuncSetAttribute((const void*)cap_route_bwd2_kernel<C, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem); curR = smem; }
+        hipLaunchKernelGGL((cap_route_bwd2_kernel<C, 1>), dim3(BT + cx.nB), dim3(CM_NT), smem, st, X, Wp, bp, c, dc1, dS, dY, dlogit, N, HS, (int)r2, cx);
         GPTST_CHECK_LAUNCH();
         return GPTST_OK;
     }
     static size_t cur = 0;
-    if (smem > cur) { (void)hipFuncSetAttribute((const void*)cap_route_bwd2_kernel<C, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem); cur = smem; }
-    hipLaunchKernelGGL((cap_route_bwd2_kernel<C, false>), dim3(BT), dim3(CM_NT), smem, st, X, Wp, bp, c, dc1, dS, dY, dlogit, N, HS, (int)r2, cx);
+    if (smem > cur) { (void)hipFuncSetAttribute((const void*)cap_route_bwd2_kernel<C, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem); cur = smem; }
+    hipLaunchKernelGGL((cap_route_bwd2_kernel<C, 0>), dim3(BT), dim3(CM_NT), smem, st, X, Wp, bp, c, dc1, dS, dY, dlogit, N, HS, (int)r2, cx);
     GPTST_CHECK_LAUNCH();
     return GPTST_OK;
 }
@@ -914,61 +1031,38 @@ extern "C" int gptst_cap_cross_route_bwd(const float* X, const float* Wp, const 
                                  CrossBwdArgs{dv, s, Rt, Ht, dyn, tmpl, ddyn, T, HT, roles ? dS_ws : nullptr, roles ? (unsigned*)flags : nullptr, roles ? B * CX_SPLIT : 0});
 }
 
+// gptst_cap_rec_bwd + gptst_cap_cross_route_bwd in ONE launch (three roles, see cap_route_bwd2_kernel): drec (B*T, N, C) gradient of the capsule
+// block's scatter output, v (B*T, HS, C) -> dY, dlogit, ddyn.  Workspaces: dc1_ws (B*T, HS, N), dv_ws (B*T, HS, C), dS_ws (B*T, HS, C), flags
+// ((CX_SPLIT + 1) * B + B*T 32-bit words, ZERO on entry).  GPTST_ESHAPE where the role form does not serve (use the two calls).
+extern "C" int gptst_cap_rec_cross_route_bwd(const float* drec, const float* v, const float* X, const float* Wp, const float* bp, const float* c,
+                                             const float* s, const float* Rt, const float* Ht, const float* dyn, const float* tmpl, float* dY,
+                                             float* dlogit, float* ddyn, float* dc1_ws, float* dv_ws, float* dS_ws, void* flags, int B, int T,
+                                             int N, int C, int HS, int HT, void* stream) {
+    if (!drec || !v || !X || !Wp || !bp || !c || !s || !Rt || !Ht || !dyn || !tmpl || !dY || !dlogit || !ddyn || !dc1_ws || !dv_ws || !dS_ws ||
+        !flags || B <= 0 || T <= 0) return GPTST_EARG;
+    if (C != 64 || T != 12 || g_cap_bwd_noroles) return GPTST_ESHAPE;
+    {                                                    // the rec-backward role's LDS within the routing kernel's, the role form available at all
+        const int NR = cm_rows(N), NP = cm_np(N), HSP = cm_hsp(HS);
+        size_t r2 = (size_t)C * C, need = (size_t)2 * HSP * NP;
+        if (need > r2) r2 = need;
+        r2 = (r2 + 3) & ~(size_t)3;
+        const size_t have = (size_t)NR * Tile<64>::PITCH + r2 + (size_t)HSP * Tile<64>::PITCH + 2 * (size_t)NR;
+        const size_t rec = (size_t)NR * Tile<64>::PITCH + (size_t)(HSP + HS) * NP + (size_t)HSP * Tile<64>::PITCH + (size_t)HSP * 64;
+        const int no = (12 / CX_SPLIT) * HS;
+        const size_t need_r = (size_t)(T * HS + 2 * HT + 2 * no) * Tile<64>::PITCH + (size_t)HT * T * HS;
+        if (HS > 64 || rec > have || (have + 4) * sizeof(float) > 80 * 1024 || B * T + B * CX_SPLIT > 512 ||
+            need_r > (size_t)NR * Tile<64>::PITCH + r2 || (HT * T * HS) % 4 != 0) return GPTST_ESHAPE;
+    }
+    return launch_route_bwd2<64>(X, Wp, bp, c, dc1_ws, nullptr, dY, dlogit, B * T, N, HS, (hipStream_t)stream,
+                                 CrossBwdArgs{dv_ws, s, Rt, Ht, dyn, tmpl, ddyn, T, HT, dS_ws, (unsigned*)flags, B * CX_SPLIT, drec, v, dc1_ws, dv_ws, B * T, B});
+}
+
 // =====================================================================================================================
 // backward of the cluster -> node scatter rec[n,:] = sum_h c[h,n] v[h,:]  (GPTST.py:135):
 //   dc1[h,n] = drec[n,:] . v[h,:]   (type 2, "V" = v)        dv[h,:] = sum_n c[h,n] drec[n,:]   (type 1, "P" = drec)
 // drec rows of one (b,t) are staged in LDS once; both contractions on MFMA 16x16x4.
 // =====================================================================================================================
-template <int C>
-__global__ __launch_bounds__(CM_NT, 4) void cap_rec_bwd2_kernel(const float* __restrict__ drec, const float* __restrict__ c,
-                                                                const float* __restrict__ v, float* __restrict__ dc1,
-                                                                float* __restrict__ dv, int N, int HS) {
-    constexpr int P = Tile<C>::PITCH, LPR = C / 4;
-    extern __shared__ __attribute__((aligned(16))) float smem[];
-    const int NR = cm_rows(N), NP = cm_np(N), HSP = cm_hsp(HS);
-    float* Ds = smem;                       // NR * P   drec rows (rows >= N zero)
-    float* cs = Ds + NR * P;                // HSP * NP
-    float* bl = cs + HSP * NP;              // HS * NP  dc1 accumulator
-    float* Vs = bl + HS * NP;               // HSP * P  v
-    float* S = Vs + HSP * P;                // HSP * C  dv
-    const int bt = blockIdx.x, tid = threadIdx.x;
-    // Loads are issued in batches ahead of the LDS stores (a copy loop costs one serialised L2 round trip per trip).
-    const int ncn = HS * N, nv = HS * LPR, nD = N * LPR;
-    const float* cb = c + (size_t)bt * ncn;
-    float cr[4];
-    float4 vr;
-#pragma unroll
-    for (int u = 0; u < 4; ++u) cr[u] = cb[min(u * CM_NT + tid, ncn - 1)];
-    vr = ld4(v + (size_t)bt * HS * C + 4 * (size_t)min(tid, nv - 1));
-    for (int i0 = 0; i0 < NR * LPR; i0 += 4 * CM_NT) {
-        float4 d4[4];
-#pragma unroll
-        for (int u = 0; u < 4; ++u) d4[u] = ld4(drec + (size_t)bt * N * C + 4 * (size_t)min(i0 + u * CM_NT + tid, nD - 1));
-        SB();
-#pragma unroll
-        for (int u = 0; u < 4; ++u) {
-            const int i = i0 + u * CM_NT + tid;
-            if (i < NR * LPR) st4(Ds + (i / LPR) * P + 4 * (i % LPR), i < nD ? d4[u] : f4zero());
-        }
-    }
-    for (int i = tid; i < HSP * NP + HS * NP + HSP * P; i += CM_NT) cs[i] = 0.f;      // cs, bl, Vs
-    __syncthreads();
-#pragma unroll
-    for (int u = 0; u < 4; ++u) {
-        const int i = u * CM_NT + tid;
-        if (i < ncn) cs[(i / N) * NP + i % N] = cr[u];
-    }
-    for (int i = 4 * CM_NT + tid; i < ncn; i += CM_NT) cs[(i / N) * NP + i % N] = cb[i];
-    if (tid < nv) st4(Vs + (tid / LPR) * P + 4 * (tid % LPR), vr);
-    for (int i = CM_NT + tid; i < nv; i += CM_NT) st4(Vs + (i / LPR) * P + 4 * (i % LPR), ld4(v + (size_t)bt * HS * C + 4 * i));
-    __syncthreads();
-    cm_type2<C>(Ds, Vs, bl, N, NP, HS, HSP);
-    cm_type1<C>(Ds, cs, S, N, NP, HSP);
-    __syncthreads();
-    for (int i = tid; i < HS * N; i += CM_NT) dc1[(size_t)bt * HS * N + i] = bl[(i / N) * NP + i % N];
-    for (int i = tid; i < HS * LPR; i += CM_NT) st4(dv + (size_t)bt * HS * C + 4 * i, ld4(S + (i / LPR) * C + 4 * (i % LPR)));
-}
-
+// (cap_rec_bwd2_kernel: defined above cap_route_bwd2_kernel, which runs the same body as its first ROLE)
 GPTST_INTERNAL int gptst_cap_rec_bwd_v1(const float* drec, const float* c, const float* v, float* dc1, float* dv, int BT, int N, int C,
                                     int HS, void* stream);
 

@@ -73,6 +73,20 @@ extern thread_local int g_deterministic;
 // agent-scope ticket is the cheap valid form (MI355X_MICROARCH.md, inter-workgroup visibility).
 __device__ __forceinline__ void st_agent(float* p, float v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 __device__ __forceinline__ float ld_agent(const float* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+// 16-byte forms over a buffer resource (rs: __builtin_amdgcn_make_buffer_rsrc(base, 0, bytes, 0x00020000) with a WAVE-UNIFORM base; off in
+// bytes): sc1 = agent scope, i.e. the store is written through to memory and the load does not trust another XCD's stale L2 line.  A producer
+// follows its stores with `s_waitcnt vmcnt(0)` + __syncthreads() and one relaxed agent-scope flag store (MI355X_MICROARCH.md, inter-workgroup
+// visibility); the consumer polls the flag with ONE lane, relaxed, BOUNDED, then loads with ld4_sc1.
+typedef int gptst_i32x4 __attribute__((ext_vector_type(4)));
+typedef float gptst_f32x4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ void st4_sc1(__amdgpu_buffer_rsrc_t rs, int off, float4 v) {
+    const gptst_f32x4 f = {v.x, v.y, v.z, v.w};
+    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(gptst_i32x4, f), rs, off, 0, 16);
+}
+__device__ __forceinline__ float4 ld4_sc1(__amdgpu_buffer_rsrc_t rs, int off) {
+    const gptst_f32x4 f = __builtin_bit_cast(gptst_f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs, off, 0, 16));
+    return make_float4(f[0], f[1], f[2], f[3]);
+}
 __device__ __forceinline__ bool last_block_arrives(unsigned* ticket, unsigned nblocks) {
     __shared__ unsigned s_last;
     if (threadIdx.x == 0) {                                          // thread 0 published the partials: drain its stores, then arrive

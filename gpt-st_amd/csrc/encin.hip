@@ -16,6 +16,7 @@
 #include "common.h"
 
 #define EI_T 12
+GPTST_STAMP_TABLES(encin)
 
 template <int C>
 __global__ __launch_bounds__(256) void encin_fwd_kernel(const float* __restrict__ src, int lda, const float* __restrict__ mask, float fill,
@@ -30,6 +31,7 @@ __global__ __launch_bounds__(256) void encin_fwd_kernel(const float* __restrict_
     float* be = al + N;
     float* mm = be + N;
     const int bt = blockIdx.x, b = bt / EI_T, t = bt % EI_T, tid = threadIdx.x;
+    GPTST_WG_BEGIN(); GPTST_STAMP(0);
     {   // w W_bt and bi W_bt: thread (quarter q of the input channels, output channel o)
         const int q = tid / C, o = tid % C;
         const float* W = Wbt + (size_t)bt * C * C;
@@ -43,6 +45,7 @@ __global__ __launch_bounds__(256) void encin_fwd_kernel(const float* __restrict_
         part[(q * 2 + 0) * C + o] = aw;
         part[(q * 2 + 1) * C + o] = abv;
     }
+    GPTST_STAMP(1);
     for (int n = tid; n < N; n += 256) {   // alpha, beta, m_t of node n
         float g[EI_T];
         const float* gr = G + (size_t)n * EI_T * EI_T + t * EI_T;
@@ -68,6 +71,7 @@ __global__ __launch_bounds__(256) void encin_fwd_kernel(const float* __restrict_
         ab[((size_t)bt * N + n) * 2 + 1] = b_;
     }
     __syncthreads();
+    GPTST_STAMP(2);
     if (tid < C) {
         float s0 = 0.f, s1 = 0.f;
 #pragma unroll
@@ -85,6 +89,7 @@ __global__ __launch_bounds__(256) void encin_fwd_kernel(const float* __restrict_
         y.x = lrelu(y.x); y.y = lrelu(y.y); y.z = lrelu(y.z); y.w = lrelu(y.w);
         st4(out + ((size_t)bt * N + n) * C + 4 * c4, y);
     }
+    GPTST_STAMP(3); GPTST_WG_END();
 }
 
 template <int C>
@@ -100,6 +105,7 @@ __global__ __launch_bounds__(256) void encin_bwd_kernel(const float* __restrict_
     float* as_ = vec + 6 * C;              // [N] dPre . (w W_bt),  [N] dPre . (bi W_bt)
     float* cs_ = as_ + N;
     const int bt = blockIdx.x, b = bt / EI_T, t = bt % EI_T, tid = threadIdx.x;
+    GPTST_WG_BEGIN(); GPTST_STAMP(0);
     if (tid < 2 * C) vec[4 * C + tid] = wv[(size_t)bt * 2 * C + tid];
     __syncthreads();
     const int slot = tid / LPR, c4 = tid % LPR;
@@ -126,6 +132,7 @@ __global__ __launch_bounds__(256) void encin_bwd_kernel(const float* __restrict_
             if (ok && c4 == 0) { as_[n] = pa; cs_[n] = pc; }
         }
     }
+    GPTST_STAMP(1);
     st4(red + (slot * 4 + 0) * C + 4 * c4, A); st4(red + (slot * 4 + 1) * C + 4 * c4, Bv);
     st4(red + (slot * 4 + 2) * C + 4 * c4, Cv); st4(red + (slot * 4 + 3) * C + 4 * c4, Mv);
     __syncthreads();
@@ -136,6 +143,7 @@ __global__ __launch_bounds__(256) void encin_bwd_kernel(const float* __restrict_
         vec[i] = s;
     }
     __syncthreads();
+    GPTST_STAMP(2);
     float* row = dWb + (size_t)bt * (C * C + C);
     for (int f = tid; f < C * C / 4; f += 256) {             // dW_bt = w^T (x) A + bi^T (x) Bv
         const int i = f / LPR, o4 = f % LPR;
@@ -161,6 +169,7 @@ __global__ __launch_bounds__(256) void encin_bwd_kernel(const float* __restrict_
             dinp[(size_t)bt * 2 * C + C + i] = vec[2 * C + i] + p2;
         }
     }
+    GPTST_STAMP(3);
     for (int n = tid; n < N; n += 256) {                     // dG_n[t, u] = m_u a + c: the sample's partial, row t
         const float a = as_[n], c = cs_[n];
         float v[EI_T];
@@ -174,6 +183,7 @@ __global__ __launch_bounds__(256) void encin_bwd_kernel(const float* __restrict_
 #pragma unroll
         for (int k = 0; k < EI_T / 4; ++k) st4(o + 4 * k, make_float4(v[4 * k], v[4 * k + 1], v[4 * k + 2], v[4 * k + 3]));
     }
+    GPTST_STAMP(4); GPTST_WG_END();
 }
 
 // out (B,T,N,C) = LReLU(hyperTem1(Linear(base = 1 -> C)(masked flow)));  ab (B*T*N, 2): (alpha, beta) per row;  wv (B*T, 2C): (w W_bt | bi W_bt)

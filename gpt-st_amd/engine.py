@@ -277,7 +277,10 @@ def hypertem_core_bwd(saved, dout, dG_out, dims, chain=False, premul=False):
 
 # ---- cap (GPTST.py:100-141) ----------------------------------------------------------------------------------------
 FUSE_CROSS = os.environ.get("GPTST_FUSE_CROSS", "1") == "1"     # cross-time block folded into its (b,t)-grouped neighbours (r03)
-CROSS_ROLE = os.environ.get("GPTST_CROSS_ROLE", "1") == "1"     # ... its backward as a ROLE of the routing backward's launch (r04; 0: replicated prologue)
+CROSS_ROLE = int(os.environ.get("GPTST_CROSS_ROLE", "1"))       # ... its backward as a ROLE of the routing backward's launch (r04; 0: replicated
+                                                                # prologue; 2: the rec backward as a third role of the same launch — measured
+                                                                # 799 vs 814 steps/s: rec -> cross-time -> routing tail is ONE dependent chain
+                                                                # (16 + 16 + 10 us, profiles/r04_roles3_stamps.txt), so it stays off)
 
 
 def cap_head_fwd(p, pfx, x, dadj, dyn, dims, num_route, HS, HT):
@@ -354,9 +357,13 @@ def cap_core_bwd(p, g, pfx, saved, dout, dims, HS, HT, red, chain=False):
         drec = ops.apply(dout, Wn, MODE_NODE, BT, N, A2=out, transw=True, pro=PRO_DPRE)
         dWb, ns = _wgrad_async(rec, dout, MODE_NODE, BT, N, D2=out, pro=PRO_DPRE, colsum_d=True)                    # rows [dWn | dbn] per split
         dWn, dbn, nsb = dWb[:, :C * C], dWb[:, C * C:], ns
-    dc1, dv = ops.cap_rec_bwd(drec, c, v, reduce_nodes=CTX.NODE_REDUCE)
     fused = None
-    if FUSE_CROSS and CTX.NODE_REDUCE is None and Y is None:
+    if FUSE_CROSS and CROSS_ROLE >= 2 and CTX.NODE_REDUCE is None and Y is None:        # rec backward + cross-time backward + routing backward: 3 roles
+        fused = ops.cap_rec_cross_route_bwd(drec, v, x.view(B, T, N, C), p[pfx + "ln_p.weight"], p[pfx + "ln_p.bias"], c, s, Rt, Ht, dyn,
+                                            p[pfx + "mask_template"], B, T, HS, HT, _zeros(x, 5 * B + B * T))
+    if fused is None:
+        dc1, dv = ops.cap_rec_bwd(drec, c, v, reduce_nodes=CTX.NODE_REDUCE)
+    if fused is None and FUSE_CROSS and CTX.NODE_REDUCE is None and Y is None:
         fused = ops.cap_cross_route_bwd(x.view(B, T, N, C), p[pfx + "ln_p.weight"], p[pfx + "ln_p.bias"], c, dc1, dv, s, Rt, Ht, dyn,
                                         p[pfx + "mask_template"], B, T, HS, HT, flags=_zeros(x, 4 * B) if CROSS_ROLE else None)
     if fused is not None:

@@ -654,6 +654,29 @@ def cap_cross_route_bwd(X, Wp, bp, c, dc1, dv, s, Rt, Ht, dyn, tmpl, B, T, HS, H
     return dY, dlogit, ddyn
 
 
+def cap_rec_cross_route_bwd(drec, v, X, Wp, bp, c, s, Rt, Ht, dyn, tmpl, B, T, HS, HT, flags):
+    """cap_rec_bwd + cap_cross_route_bwd as three roles of ONE launch -> (dY, dlogit, ddyn), or None where the role form does not serve.
+    flags: 5 B + B T ZEROED 32-bit words."""
+    _chk(drec, v, X, Wp, bp, c, s, Rt, Ht, dyn, tmpl, flags)
+    N, C = X.shape[2], X.shape[3]
+    if C != 64 or FORCE_CAP_BIG:
+        return None
+    dY = torch.empty(B * T * N, C, device=X.device, dtype=torch.float32)
+    dlogit = torch.empty_like(c)
+    ddyn = torch.empty_like(dyn)
+    dc1 = torch.empty_like(c)
+    ws = torch.empty(2, B * T, HS, C, device=X.device, dtype=torch.float32)
+    try:
+        _call("gptst_cap_rec_cross_route_bwd", _p(drec), _p(v), _p(X), _p(Wp), _p(bp), _p(c), _p(s), _p(Rt), _p(Ht), _p(dyn), _p(tmpl), _p(dY),
+              _p(dlogit), _p(ddyn), _p(dc1), _p(ws[0]), _p(ws[1]), _p(flags), B, T, N, C, HS, HT,
+              nbytes=_nb(drec, X, Wp, bp, c, v, s, Rt, dY, dlogit))
+    except _C.GptstError as e:
+        if e.code != _C.ESHAPE:
+            raise
+        return None
+    return dY, dlogit, ddyn
+
+
 # ---- mask generation (integer path) -----------------------------------------------------------------------------
 _MASK_WS = {}
 

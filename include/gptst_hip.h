@@ -219,11 +219,19 @@ int gptst_cap_route_bwd(const float* X, const float* Wp, const float* bp, const 
  * dv (B, T*HS, C): gradient of v;  -> dY, dlogit as gptst_cap_route_bwd, ddyn (B, HT, T*HS).  C = 64, else GPTST_ESHAPE.
  * r04 — dS_ws (B*T, HS, C) scratch + flags (4 B 32-bit words, ZERO on entry): both given -> the cross-time backward is a ROLE of the launch: 4 B extra
  * workgroups do it (four per sample, three time steps each) and publish dS (write-through stores + one flag per sample) while the B*T routing workgroups rebuild their
- * capsule tile, which does not depend on dS, and pick dS up behind it (a bounded wait; on expiry the workgroup computes the prologue itself).
+ * capsule tile, which does not depend on dS, and pick dS up behind it (a bounded wait; on expiry dS is poisoned with NaN: a lost hand-off ends the run loudly).
  * Either NULL: every (b,t) workgroup repeats the cross-time backward as a prologue (r03). */
 int gptst_cap_cross_route_bwd(const float* X, const float* Wp, const float* bp, const float* c, const float* dc1, const float* dv,
                               const float* s, const float* Rt, const float* Ht, const float* dyn, const float* tmpl, float* dY,
                               float* dlogit, float* ddyn, float* dS_ws, void* flags, int B, int T, int N, int C, int HS, int HT, void* stream);
+/* gptst_cap_rec_bwd + gptst_cap_cross_route_bwd in ONE launch of three roles (r04): block order [rec backward (b,t)] [cross-time (sample, part)]
+ * [routing (b,t)], every wait points to a lower block index.  drec (B*T, N, C) gradient of the scatter output, v (B*T, HS, C) -> dY, dlogit, ddyn.
+ * Workspaces: dc1_ws (B*T, HS, N), dv_ws (B*T, HS, C), dS_ws (B*T, HS, C), flags (5 B + B*T 32-bit words, ZERO on entry).  GPTST_ESHAPE where
+ * the role form does not serve (C != 64, T != 12, LDS): use the two calls. */
+int gptst_cap_rec_cross_route_bwd(const float* drec, const float* v, const float* X, const float* Wp, const float* bp, const float* c,
+                                  const float* s, const float* Rt, const float* Ht, const float* dyn, const float* tmpl, float* dY,
+                                  float* dlogit, float* ddyn, float* dc1_ws, float* dv_ws, float* dS_ws, void* flags, int B, int T,
+                                  int N, int C, int HS, int HT, void* stream);
 
 /* ---- cap for node counts whose (b,t) capsule matrix does not fit LDS (cap_big.hip; BASELINE config 5: N = 4096, C = 128) ----
  * gptst_cap_fits_lds() == 0 -> the host composes the same algebra from these streaming kernels (ops.py: cap_route_fwd/bwd, cap_rec_*):

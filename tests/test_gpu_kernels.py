@@ -970,6 +970,17 @@ def test_cap_cross_folded_into_its_neighbours(B, N, HS, HT):
         assert fr is not None
         for a, b_, nm in zip(fr, fb, ("dY", "dlogit", "ddyn")):
             assert torch.equal(a, b_), "role form differs from the prologue form in %s (rep %d)" % (nm, rep)
+    # r04: the rec backward as a THIRD role of the same launch (drec -> dc1, dv published to the other two roles): equal to the chain of calls
+    drec = rnd(B * T, N, C, g=g).to(dev)
+    dc1r, dvr = ops.cap_rec_bwd(drec, c, v1)
+    ref = ops.cap_cross_route_bwd(X, Wp, bp, c, dc1r, dvr, s, Rt1, Ht1, dyn, tmpl, B, T, HS, HT)
+    for rep in range(3):
+        f3 = ops.cap_rec_cross_route_bwd(drec, v1, X, Wp, bp, c, s, Rt1, Ht1, dyn, tmpl, B, T, HS, HT, torch.zeros(5 * B + B * T, device=dev))
+        assert f3 is not None or B != 32          # (small N: the cross-time role's scratch does not fit the capsule tile -> two calls)
+        if f3 is None:
+            break
+        for a, b_, nm in zip(f3, ref, ("dY", "dlogit", "ddyn")):
+            assert torch.equal(a, b_), "three-role form differs in %s (rep %d)" % (nm, rep)
 
 
 def test_step_begin_draws_philox_noise():

@@ -24,10 +24,22 @@ tmpl = torch.arange(12, device=dev, dtype=torch.float32) / 12
 c, s = ops.cap_route_fwd(X, Wp, bp, dadj, HS, R)
 v, Ht, Rt = ops.cap_cross_fwd(s, dyn, tmpl, B, T, HS, HT)
 dc1, dv = ops.cap_rec_bwd(dO, c, v)
+src3 = f(B, T, N, 3)
+mask1 = (torch.rand(B * T * N, device=dev) > 0.25).float()
+w_in, b_in = f(C, 1), f(C)
+Gt = f(N, 12, 12) * 0.1
+Wbt, bbt = f(BT, C, C) * 0.1, f(BT, C)
+o_ei, ab_ei, wv_ei = ops.encin_ht1_fwd(src3, 1, mask1, -1.5, w_in, b_in, Gt, Wbt, bbt)
 CASES = {
+    "encin_fwd": ("encin", lambda: ops.encin_ht1_fwd(src3, 1, mask1, -1.5, w_in, b_in, Gt, Wbt, bbt),
+                  ["w W_bt, bi W_bt partials", "alpha / beta / m per node (G rows, flow, mask) + barrier", "rows out"]),
+    "encin_bwd": ("encin", lambda: ops.encin_ht1_bwd(dO, src3, mask1, -1.5, w_in, b_in, Wbt, ab_ei, wv_ei),
+                  ["pass over dPre: A, Bv, Cv, Mv, row dots", "fold slots", "dWb row + projection partials", "dG rows"]),
     "cap_route_bwd_roles": ("capmfma", lambda: ops.cap_cross_route_bwd(X, Wp, bp, c, dc1, dv, s, Rt, Ht, dyn, tmpl, B, T, HS, HT, flags=torch.zeros(4 * B, device=dev)),
                       ["(cross-time role: whole launch) / routing role: -", "stage Wp (+ X tile requested)", "Y = X Wp^T + bp tiles -> LDS", "zero c / dc, stage c, dc1, wait for dS",
                        "node tiles: U, dlogit, dP, squash backward, dY rows out"]),
+    "cap_route_bwd_roles3": ("capmfma", lambda: ops.cap_rec_cross_route_bwd(dO, v, X, Wp, bp, c, s, Rt, Ht, dyn, tmpl, B, T, HS, HT, torch.zeros(5 * B + B * T, device=dev)),
+                      ["(rec-backward role: whole launch; stamped workgroups are of that role)"]),
     "cap_route_bwd": ("capmfma", lambda: ops.cap_cross_route_bwd(X, Wp, bp, c, dc1, dv, s, Rt, Ht, dyn, tmpl, B, T, HS, HT),
                       ["cross-time backward prologue (replicated per (b,t))", "stage Wp (+ X tile requested)", "Y = X Wp^T + bp tiles -> LDS", "zero c / dc, stage c, dc1",
                        "node tiles: U, dlogit, dP, squash backward, dY rows out"]),
@@ -46,13 +58,14 @@ e1.record(); torch.cuda.synchronize()
 ph = (ctypes.c_longlong * (8 * 32))()
 wg = (ctypes.c_longlong * (2048 * 2))()
 assert getattr(dll, "gptst_stamps_" + unit)(ph, wg) == 0
-ph = np.array(ph).reshape(8, 32); wg = np.array(wg).reshape(2048, 2)[:BT + (4 * B if name.endswith('roles') else 0)]
+nwg = BT + (4 * B if name.endswith('roles') else 0) + (BT + 4 * B if name.endswith('roles3') else 0)
+ph = np.array(ph).reshape(8, 32); wg = np.array(wg).reshape(2048, 2)[:nwg]
 t0 = wg[:, 0].min()
 print("%s: %.2f us per launch (50 back to back); workgroups start %.2f .. %.2f us, end %.2f .. %.2f us after the first start; mean duration %.2f us"
       % (name, e0.elapsed_time(e1) * 20, (wg[:, 0].min() - t0) * 0.01, (wg[:, 0].max() - t0) * 0.01, (wg[:, 1].min() - t0) * 0.01, (wg[:, 1].max() - t0) * 0.01,
          (wg[:, 1] - wg[:, 0]).mean() * 0.01))
-for lo, hi in ((0, 128), (128, 256), (256, BT)):
-    if hi > lo and lo < BT:
+for lo, hi in ((0, 128), (128, 256), (256, BT), (BT, BT + 4 * B), (BT + 4 * B, nwg)):
+    if hi > lo and lo < nwg and hi <= nwg:
         w = wg[lo:hi]
         print("   workgroups %3d..%3d: end %.2f us (mean), duration %.2f us" % (lo, hi - 1, (w[:, 1].mean() - t0) * 0.01, (w[:, 1] - w[:, 0]).mean() * 0.01))
 for sl, b in enumerate((5, 100, 200, 300, 261, 383)):
