@@ -424,23 +424,23 @@ extern "C" int gptst_hypertem_fwd(const float* X, const float* G, const float* W
 // Scheduling notes (measured): all global loads of a phase are issued as one batch into registers (a copy loop
 // compiles to one L2 round trip per trip); dPre stays in registers for the dX phase instead of being re-read; W_bt fragments of
 // the next time step and the X operands of the dG phase are requested before the stores / atomics of the current phase.
-template <bool HASY, bool PREMUL>
-__device__ __forceinline__ void hypertem_bwd_body(const float* __restrict__ dOut, const float* __restrict__ Y,
-                                                  const float* __restrict__ X, const float* __restrict__ G,
-                                                  const float* __restrict__ Wbt, float* __restrict__ dX,
-                                                  float* __restrict__ dbias, float* __restrict__ dG, int N, int B, int dbg, int L,
-                                                  float* __restrict__ smem) {
+// PAIR (r04, hypertem_bwd_pair_kernel): two consecutive layers on the slab.  1 = the upper layer: its input gradient (already multiplied by
+// lrelu'(input) = the lower layer's dPre) stays in the thread's dp[] registers for stage 2 AND goes to dX with write-through stores (the lower
+// layer's weight-gradient role reads it in the same launch); 2 = the lower layer: dPre comes in dp[], nothing is read from dOut.
+template <bool HASY, bool PREMUL, int PAIR>
+__device__ __forceinline__ void hypertem_bwd_stage(const float* __restrict__ dOut, const float* __restrict__ Y,
+                                                   const float* __restrict__ X, const float* __restrict__ G,
+                                                   const float* __restrict__ Wbt, float* __restrict__ dX,
+                                                   float* __restrict__ dbias, float* __restrict__ dG, int N, int B, int dbg, int b, int tile,
+                                                   float* __restrict__ smem, float4 (&dp)[HT_T]) {
     constexpr int C = 64, P = C + 4, GP = 145, NT = 16;
     float* Ds = smem;                               // [12][16][P]  dPre, then dR
     float* Gs = Ds + HT_T * NT * P;                 // [16][GP]
-    int b, tile;
-    if (!ht_work_at(L, (N + NT - 1) / NT, B, b, tile)) return;
     const int n0 = tile * NT;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int nl = tid >> 4, c4 = tid & 15;         // thread = (row, float4 column) of every time slice
     const bool valid = n0 + nl < N;
     const size_t rowoff = ((size_t)b * HT_T * N + min(n0 + nl, N - 1)) * C + 4 * c4;     // + t * N * C
-    float4 dp[HT_T];
     const int j = lane & 15, kk = lane >> 4;
     // dR_t^T (C x 16) = W_bt (C x C) dPre_t^T:  A[i][kk=o] = W[i][o] (global float4 rows), B[kk=o][j=n] = dPre_t[n][o] (LDS)
     float4 aq[C / 16][C / 16];
@@ -461,12 +461,12 @@ __device__ __forceinline__ void hypertem_bwd_body(const float* __restrict__ dOut
     float gv[9];
     unsigned sb0 = 0u, sb1 = 0u;                    // PREMUL: bit 4*t + e of (sb0 | sb1 << 32) = (X_t[row][4*c4 + e] > 0)
 #pragma unroll
-    for (int t = 0; t < 4; ++t) { dp[t] = ld4(dOut + rowoff + (size_t)t * N * C); if (HASY || PREMUL) yv[t] = ld4(Sg + rowoff + (size_t)t * N * C); }
+    for (int t = 0; t < 4; ++t) { if (PAIR != 2) dp[t] = ld4(dOut + rowoff + (size_t)t * N * C); if (HASY || PREMUL) yv[t] = ld4(Sg + rowoff + (size_t)t * N * C); }
 #pragma unroll
     for (int k = 0; k < 9; ++k) gv[k] = G[min(n0 * 144 + tid + k * 256, N * 144 - 1)];
     HT_LOAD_WT(wave);
 #pragma unroll
-    for (int t = 4; t < HT_T; ++t) { dp[t] = ld4(dOut + rowoff + (size_t)t * N * C); if (HASY || PREMUL) yv[t] = ld4(Sg + rowoff + (size_t)t * N * C); }
+    for (int t = 4; t < HT_T; ++t) { if (PAIR != 2) dp[t] = ld4(dOut + rowoff + (size_t)t * N * C); if (HASY || PREMUL) yv[t] = ld4(Sg + rowoff + (size_t)t * N * C); }
     SB();
 #pragma unroll
     for (int grp = 0; grp < HT_T / 4; ++grp) {
@@ -558,7 +558,11 @@ __device__ __forceinline__ void hypertem_bwd_body(const float* __restrict__ dOut
                 acc.x *= (m4 & 1u) ? 1.f : LRELU_SLOPE; acc.y *= (m4 & 2u) ? 1.f : LRELU_SLOPE;
                 acc.z *= (m4 & 4u) ? 1.f : LRELU_SLOPE; acc.w *= (m4 & 8u) ? 1.f : LRELU_SLOPE;
             }
-            if (!(HT_DBG(dbg) & 8)) st4(dX + rowoff + (size_t)u * N * C, acc);
+            if (PAIR == 1) {
+                const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(dX + (size_t)b * HT_T * N * C, 0, HT_T * N * C * 4, 0x00020000);
+                st4_sc1(rs, (int)(((size_t)u * N + n0 + nl) * C + 4 * c4) * 4, acc);
+                dp[u] = acc;
+            } else if (!(HT_DBG(dbg) & 8)) st4(dX + rowoff + (size_t)u * N * C, acc);
             SB();
         }
     }
@@ -584,6 +588,18 @@ __device__ __forceinline__ void hypertem_bwd_body(const float* __restrict__ dOut
             if (t < HT_T && u < HT_T && !(HT_DBG(dbg) & 2)) dG[((size_t)b * N + n) * 144 + t * HT_T + u] = acc[r];   // partial of sample b
         }
     }
+}
+
+template <bool HASY, bool PREMUL>
+__device__ __forceinline__ void hypertem_bwd_body(const float* __restrict__ dOut, const float* __restrict__ Y,
+                                                  const float* __restrict__ X, const float* __restrict__ G,
+                                                  const float* __restrict__ Wbt, float* __restrict__ dX,
+                                                  float* __restrict__ dbias, float* __restrict__ dG, int N, int B, int dbg, int L,
+                                                  float* __restrict__ smem) {
+    int b, tile;
+    if (!ht_work_at(L, (N + 15) / 16, B, b, tile)) return;
+    float4 dp[HT_T];
+    hypertem_bwd_stage<HASY, PREMUL, 0>(dOut, Y, X, G, Wbt, dX, dbias, dG, N, B, dbg, b, tile, smem, dp);
 }
 
 template <bool HASY, bool PREMUL>
@@ -756,6 +772,91 @@ extern "C" int gptst_hypertem_bwd_wgrad(const float* dOut, const float* Y, const
     if (Y) ht_bwd_wgrad_launch<true, false>(dOut, Y, X, G, Wbt, R, dX, dG, dWb, B, N, u6, nH, nW, rm, rps, smem, (hipStream_t)stream);
     else if (premul) ht_bwd_wgrad_launch<false, true>(dOut, Y, X, G, Wbt, R, dX, dG, dWb, B, N, u6, nH, nW, rm, rps, smem, (hipStream_t)stream);
     else ht_bwd_wgrad_launch<false, false>(dOut, Y, X, G, Wbt, R, dX, dG, dWb, B, N, u6, nH, nW, rm, rps, smem, (hipStream_t)stream);
+    GPTST_CHECK_LAUNCH();
+    return GPTST_OK;
+}
+
+// ---- TWO consecutive hyperTem layers' backward in ONE launch (r04) --------------------------------------------------------------------------
+// Layers L+1 ("1", the upper one: its dPre is the input) and L ("0") of a chain hyperTem(L) -> hyperTem(L+1) with nothing in between
+// (GPTST.py:267-268 hyperTem2 -> hyperTem3; :271 / :454 the encoder's hyperTem4 -> the decoder's hyperTem1).  The input gradient of layer L+1,
+// multiplied by lrelu'(its input), IS dPre of layer L for the same (b, 16-node, all-t) slab: the slab workgroup keeps it in registers / LDS and
+// runs layer L right away — no launch boundary, no 16.7 MB read-back in front of the second dependency chain.  The weight gradient of layer L
+// needs dPre_L of ALL nodes of a (b,t): its workgroups sit at the END of the grid [slab | wgrad L+1 | wgrad L] and wait for the sample's slab
+// workgroups to have published stage 1 (write-through stores + one counter per sample): every wait points to a lower block index, so with
+// blocks dispatched in index order nothing waits on a workgroup that is not yet on the chip; the wait is bounded and ends in NaN rows of dWb0.
+struct HtPairArgs {
+    const float* dOut1; const float* X1; const float* G1; const float* Wbt1; const float* R1;
+    const float* X0; const float* G0; const float* Wbt0; const float* R0;
+    float* dXmid; float* dX0; float* dG1; float* dG0; float* dWb1; float* dWb0; unsigned* cnt;
+};
+
+template <int U>
+__global__ __launch_bounds__(256, 2) void hypertem_bwd_pair_kernel(HtPairArgs a, int N, int B, int nH, RowMap rm, int rows_per_split) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    const int ntiles = (N + 15) / 16;
+    if ((int)blockIdx.x < nH) {
+        int b, tile;
+        if (!ht_work_at(blockIdx.x, ntiles, B, b, tile)) return;
+        float4 dp[HT_T];
+        hypertem_bwd_stage<false, true, 1>(a.dOut1, nullptr, a.X1, a.G1, a.Wbt1, a.dXmid, nullptr, a.dG1, N, B, 0, b, tile, smem, dp);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");             // this wave's write-through stores of dPre_L have left ...
+        __syncthreads();                                              // ... (all waves; and the dG phase is done with the LDS slab)
+        if (threadIdx.x == 0) __hip_atomic_fetch_add(a.cnt + b, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        hypertem_bwd_stage<false, true, 2>(nullptr, nullptr, a.X0, a.G0, a.Wbt0, a.dX0, nullptr, a.dG0, N, B, 0, b, tile, smem, dp);
+        return;
+    }
+    const int nW = rm.G * ((rm.M + rows_per_split - 1) / rows_per_split);
+    int w = blockIdx.x - nH;
+    if (w < nW) {
+        wgrad64_body<PRO_NONE, U>(a.R1, a.dOut1, nullptr, a.dWb1, rm, rows_per_split, 64 * 64 + 64, 2, w % rm.G, w / rm.G, smem);
+        return;
+    }
+    w -= nW;
+    const int g = w % rm.G, sp = w / rm.G;
+    unsigned* s_ok = reinterpret_cast<unsigned*>(smem);
+    if (threadIdx.x == 0) {
+        unsigned got = 0u;
+        for (int spin = 0; spin < 4000; ++spin) {
+            got = __hip_atomic_load(a.cnt + g / HT_T, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (got >= (unsigned)ntiles) break;
+            __builtin_amdgcn_s_sleep(8);
+        }
+        *s_ok = got >= (unsigned)ntiles;
+    }
+    __syncthreads();
+    const bool ok = *s_ok != 0u;
+    __syncthreads();
+    wgrad64_body<PRO_NONE, U, true>(a.R0, a.dXmid, nullptr, a.dWb0, rm, rows_per_split, 64 * 64 + 64, 2, g, sp, smem);
+    if (!ok) a.dWb0[((size_t)sp * rm.G + g) * (size_t)(64 * 64 + 64) + threadIdx.x] = __int_as_float(0x7fc00000);    // lost hand-off: loud
+}
+
+// dOut1 = dPre of layer L+1; X1 / X0 the layers' inputs (X1 = output of layer L), R1 / R0 their saved mixes; -> dXmid (= dPre of layer L),
+// dX0 (multiplied by lrelu'(X0)), dG1 / dG0 (B*N, T, T) partials, dWb1 / dWb0 (nsplit * B*T, C*C + C) rows [dW_bt | db_bt].
+// cnt: B 32-bit words, ZERO on entry.
+extern "C" int gptst_hypertem_bwd_pair(const float* dOut1, const float* X1, const float* G1, const float* Wbt1, const float* R1, const float* X0,
+                                       const float* G0, const float* Wbt0, const float* R0, float* dXmid, float* dX0, float* dG1, float* dG0,
+                                       float* dWb1, float* dWb0, void* cnt, int B, int T, int N, int C, void* stream) {
+    if (!dOut1 || !X1 || !G1 || !Wbt1 || !R1 || !X0 || !G0 || !Wbt0 || !R0 || !dXmid || !dX0 || !dG1 || !dG0 || !dWb1 || !dWb0 || !cnt || T != HT_T)
+        return GPTST_EARG;
+    if (C != 64 || (size_t)HT_T * N * C * 4 >= ((size_t)1 << 31)) return GPTST_ESHAPE;
+    const size_t smem_h = ht_smem(16), smem_w = WGRAD64_SMEM_FLOATS * sizeof(float), smem = smem_h > smem_w ? smem_h : smem_w;
+    const RowMap rm = make_rowmap(0, B * T, N);
+    const int ns = gptst_wgrad_nsplit(0, B * T, N, 64);
+    int rps = (rm.M + ns - 1) / ns;
+    rps = (rps + 1) & ~1;
+    if ((rm.M + rps - 1) / rps != ns || (size_t)B * T * N * C * 4 >= ((size_t)1 << 31)) return GPTST_ESHAPE;
+    const int rows = rps < rm.M ? rps : rm.M, steps = ((rows + 3) / 4 + 3) / 4;
+    const bool u6 = (steps + 5) / 6 * 6 <= (steps + 3) / 4 * 4;
+    const int nH = 8 * ((B + 7) / 8) * ((N + 15) / 16), nW = rm.G * ns;
+    static int done = 0;
+    if (!done) {
+        hipFuncSetAttribute((const void*)hypertem_bwd_pair_kernel<4>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+        hipFuncSetAttribute((const void*)hypertem_bwd_pair_kernel<6>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+        done = 1;
+    }
+    const HtPairArgs a{dOut1, X1, G1, Wbt1, R1, X0, G0, Wbt0, R0, dXmid, dX0, dG1, dG0, dWb1, dWb0, (unsigned*)cnt};
+    if (u6) hipLaunchKernelGGL((hypertem_bwd_pair_kernel<6>), dim3(nH + 2 * nW), dim3(256), smem, (hipStream_t)stream, a, N, B, nH, rm, rps);
+    else hipLaunchKernelGGL((hypertem_bwd_pair_kernel<4>), dim3(nH + 2 * nW), dim3(256), smem, (hipStream_t)stream, a, N, B, nH, rm, rps);
     GPTST_CHECK_LAUNCH();
     return GPTST_OK;
 }

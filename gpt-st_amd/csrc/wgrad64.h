@@ -24,7 +24,8 @@ __host__ __device__ inline RowMap make_rowmap(int mode, int BT, int N) {
 
 // C = 64 weight gradient on fp32 MFMA 16x16x4, operands straight from global memory as float4 (see apply.hip for the layout notes).
 // Body of wgrad64_kernel for group g, row split sp (of nsplit_groups = rm.G groups per split); smem: 4*C*C + 4*C floats.
-template <int PRO, int U>
+// ACQ: D was produced by other workgroups of THIS launch (write-through stores + a flag the caller has waited for): agent-scope loads.
+template <int PRO, int U, bool ACQ = false>
 __device__ __forceinline__ void wgrad64_body(const float* __restrict__ A, const float* __restrict__ D, const float* __restrict__ D2,
                                              float* __restrict__ dW, RowMap rm, int rows_per_split, int ostride, int csa, int g, int sp,
                                              float* __restrict__ smem) {
@@ -43,6 +44,7 @@ __device__ __forceinline__ void wgrad64_body(const float* __restrict__ A, const 
 #pragma unroll
         for (int cb = 0; cb < 4; ++cb) acc[ca][cb] = (f32x4){0.f, 0.f, 0.f, 0.f};
     float4 sa = f4zero();
+    const __amdgpu_buffer_rsrc_t rsD = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(D), 0, ACQ ? (int)((size_t)rm.G * rm.M * C * 4) : 0, 0x00020000);
     // U = k-steps (of 4 rows) per batch of loads (2-3 float4 per step in flight per lane); the launcher picks 4 or 6 so that the
     // wave's step count divides evenly (measured: TIME 11 steps 13.5 us either way, NODE 6 steps 13.7 vs 16.8, SHARED 16 steps 10.5 vs 13.0).
     // The scheduler fence keeps the whole batch of loads ahead of the MFMA block (18.0 -> 15.1 us on the TIME weight gradient); a
@@ -53,7 +55,7 @@ __device__ __forceinline__ void wgrad64_body(const float* __restrict__ A, const 
         for (int u = 0; u < U; ++u) {
             const int m = min(m0 + 4 * u + kk, mend - 1);                        // clamped: out-of-range rows are zeroed below
             const size_t off = ((size_t)g * rm.rs_g + (size_t)m * rm.rs_m) * C + 4 * j;
-            a[u] = ld4(A + off); d[u] = ld4(D + off);
+            a[u] = ld4(A + off); d[u] = ACQ ? ld4_sc1(rsD, (int)(off * 4)) : ld4(D + off);
             if (PRO == PRO_DPRE) y[u] = ld4(D2 + off);
         }
         SB();

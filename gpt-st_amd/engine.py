@@ -275,6 +275,40 @@ def hypertem_core_bwd(saved, dout, dG_out, dims, chain=False, premul=False):
     return dx, (dWbt, ns, (dbias, nsb))
 
 
+PAIR_BWD = os.environ.get("GPTST_PAIR_BWD", "1") == "1"        # two adjacent hyperTem layers' backward in one launch (r04)
+
+
+def ht_pair_ok(saved1, saved0, dims):
+    return (PAIR_BWD and dims[3] == 64 and not isinstance(saved1, EncIn) and saved1[1] is not None and saved0[1] is not None
+            and CTX.SIDE is None and _ht_fused_bwd(dims))
+
+
+class PendingH1:
+    """the decoder's hyperTem1 backward, deferred into the pair launch with the encoder's hyperTem4 (GPTST.py:271 -> :454): its dPre, saved
+    tensors and the output buffers the decoder's reduction jobs already point at"""
+
+    def __init__(self, saved, dd, dG, dWb):
+        self.saved, self.dd, self.dG, self.dWb = saved, dd, dG, dWb
+
+
+def ht_pair_bwd(saved1, saved0, dout, dG1, dG0, dims, dWb1=None):
+    """dPre-chain backward of hyperTem layers 1 (upper, dout = its dPre) and 0 in ONE launch -> dx0 (times lrelu'(x0)), hp1, hp0 (as
+    hypertem_core_bwd's second result), or None (shape / no saved R)."""
+    B, T, N, C = dims
+    if not ht_pair_ok(saved1, saved0, dims):
+        assert dWb1 is None
+        return None
+    x1, R1, _, G1, Wbt1 = saved1
+    x0, R0, _, G0, Wbt0 = saved0
+    v = lambda a: a.view(B, T, N, C)
+    r = ops.hypertem_bwd_pair(v(dout), v(x1), G1, Wbt1, v(R1), v(x0), G0, Wbt0, v(R0), dG1, dG0, _zeros(dout, B), dWb1=dWb1)
+    assert r is not None or dWb1 is None
+    if r is None:
+        return None
+    dmid, dx0, dWb1, dWb0, ns = r
+    return dx0.view(-1, C), (dWb1[:, :C * C], ns, (dWb1[:, C * C:], ns)), (dWb0[:, :C * C], ns, (dWb0[:, C * C:], ns))
+
+
 # ---- cap (GPTST.py:100-141) ----------------------------------------------------------------------------------------
 FUSE_CROSS = os.environ.get("GPTST_FUSE_CROSS", "1") == "1"     # cross-time block folded into its (b,t)-grouped neighbours (r03)
 CROSS_ROLE = int(os.environ.get("GPTST_CROSS_ROLE", "1"))       # ... its backward as a ROLE of the routing backward's launch (r04; 0: replicated
@@ -568,9 +602,11 @@ def _grad_buffers(red, slot, N, T, HmT, ref, nsG):
     return red._dG[4 * k:4 * k + 4], red._dA[4 * k:4 * k + 4]
 
 
-def sthcn_bwd(p, g, pfx, tidx, sv, dout, dims, red, chain=False, premul_in=False):
+def sthcn_bwd(p, g, pfx, tidx, sv, dout, dims, red, chain=False, premul_in=False, defer_h1=False):
     """chain: dout already is dPre of the last layer and every layer hands dPre down;  premul_in (chain only): the returned input gradient
-    is multiplied by lrelu'(input) — True when the STHCN's input is itself a LeakyReLU output (the decoder's: the encoder embedding)."""
+    is multiplied by lrelu'(input) — True when the STHCN's input is itself a LeakyReLU output (the decoder's: the encoder embedding).
+    defer_h1 (chain, premul_in): hyperTem1's backward is NOT run — a PendingH1 is returned and the STHCN below runs it in the pair launch
+    with its own hyperTem4 (dout: that PendingH1)."""
     B, T, N, C = dims
     time_eb, teb, tes = sv["emb"]
     A_all, hts, cps, d, Hm, ds, HS, HT = sv["gen"]
@@ -579,10 +615,19 @@ def sthcn_bwd(p, g, pfx, tidx, sv, dout, dims, red, chain=False, premul_in=False
     d_te, d_teb, d_tes = _zeros(time_eb, *time_eb.shape), _zeros(teb, *teb.shape), _zeros(tes, *tes.shape)
     nsG = graph_grad_splits(dims)
     dG_all, dA_all = _grad_buffers(red, sv.get("slot"), N, T, Hm * T, dout, nsG)
-    dd, hp4 = hypertem_core_bwd(sv["h4"], dout, dG_all[3], dims, chain, True)
+    if isinstance(dout, PendingH1):                 # the STHCN above left its first layer to the pair launch with this one's last layer
+        up = dout
+        dd, _, hp4 = ht_pair_bwd(up.saved, sv["h4"], up.dd, up.dG, dG_all[3], dims, dWb1=up.dWb)
+        red.keep.append(up)
+    else:
+        dd, hp4 = hypertem_core_bwd(sv["h4"], dout, dG_all[3], dims, chain, True)
     dd, cp2 = cap_core_bwd(p, g, cps[1], sv["c2"], dd, dims, HS, HT, red, chain)
-    dd, hp3 = hypertem_core_bwd(sv["h3"], dd, dG_all[2], dims, chain, True)
-    dd, hp2 = hypertem_core_bwd(sv["h2"], dd, dG_all[1], dims, chain, True)
+    pair = ht_pair_bwd(sv["h3"], sv["h2"], dd, dG_all[2], dG_all[1], dims) if chain and PAIR_BWD else None
+    if pair is not None:                            # hyperTem3 + hyperTem2: nothing in between (GPTST.py:267-268) -> one launch on the slab
+        dd, hp3, hp2 = pair
+    else:
+        dd, hp3 = hypertem_core_bwd(sv["h3"], dd, dG_all[2], dims, chain, True)
+        dd, hp2 = hypertem_core_bwd(sv["h2"], dd, dG_all[1], dims, chain, True)
     dd, cp1 = cap_core_bwd(p, g, cps[0], sv["c1"], dd, dims, HS, HT, red, chain)
     if isinstance(sv["h1"], EncIn):                 # the encoder's first layer on the low-rank input form: no input gradient tensor
         assert chain
@@ -598,6 +643,12 @@ def sthcn_bwd(p, g, pfx, tidx, sv, dout, dims, red, chain=False, premul_in=False
             g["encoder.dim_in_flow.bias"].add_(dinp[:, C:].sum(0))
         red.keep.append((dinp, dWb))
         dd = None
+    elif defer_h1:
+        assert chain and premul_in
+        ns = ops.wgrad_nsplit(MODE_TIME, B * T, N, C)
+        dWb = torch.empty(ns * B * T, C * C + C, device=dd.device, dtype=torch.float32)
+        hp1 = (dWb[:, :C * C], ns, (dWb[:, C * C:], ns))
+        dd = PendingH1(sv["h1"], dd, dG_all[0], dWb)
     else:
         dd, hp1 = hypertem_core_bwd(sv["h1"], dd, dG_all[0], dims, chain, premul_in)
     _join_side()
@@ -808,7 +859,11 @@ def model_bwd(p, g, source, mask, tidx, sv_e, sv_d, dec, d_out, d_dec, dims, bas
         if d_dec is not None:
             dd = dd + d_dec
         ops.rowouter(d_out, base, base, dec, g[wo + "weight"], 1, asum=g[wo + "bias"])
-    d_emb = sthcn_bwd(p, g, DEC, tidx, sv_d, dd, dims, red, chain, True)     # the decoder's input is the encoder's last LeakyReLU output
+    # the decoder's hyperTem1 and the encoder's hyperTem4 are adjacent (GPTST.py:271 -> :454): one pair launch, unless the decoder's gradient
+    # bucket must be complete when its backward ends (data-parallel overlap / a side stream flush the decoder's reductions right here)
+    defer = (chain and red.side is None and red.on_bucket is None and not isinstance(sv_d["h1"], EncIn)
+             and ht_pair_ok(sv_d["h1"], sv_e["h4"], dims))
+    d_emb = sthcn_bwd(p, g, DEC, tidx, sv_d, dd, dims, red, chain, True, defer_h1=defer)     # the decoder's input is the encoder's last LeakyReLU output
     red.flush_async(tidx)                                   # the decoder's reductions overlap with the encoder's backward chain
     d_x0 = sthcn_bwd(p, g, ENC, tidx, sv_e, d_emb, dims, red, chain, False)  # the encoder's input is a plain Linear: no premultiplication
     red.flush_async(tidx)                                   # ... and the encoder's with the guide's

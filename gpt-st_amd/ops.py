@@ -396,6 +396,30 @@ def hypertem_bwd_wgrad(dOut, Y, X, G, Wbt, R, dG=None, premul=False):
     return dX, dWb, ns, dG
 
 
+def hypertem_bwd_pair(dOut1, X1, G1, Wbt1, R1, X0, G0, Wbt0, R0, dG1, dG0, cnt, dWb1=None):
+    """Backward of two consecutive hyperTem layers (1 above 0; dPre chain, both input gradients times lrelu'(input)) in ONE launch ->
+    (dXmid, dX0, dWb1, dWb0, ns) or None where the pair form does not serve.  cnt: B ZEROED 32-bit words;  dWb1: optional output buffer
+    (ns * B*T, C*C + C) of the upper layer's [dW_bt | db_bt] rows."""
+    _chk(dOut1, X1, G1, Wbt1, R1, X0, G0, Wbt0, R0, dG1, dG0, cnt, dWb1)
+    B, T, N, C = X1.shape
+    if C != 64:
+        return None
+    dXmid, dX0 = torch.empty_like(X1), torch.empty_like(X0)
+    ns = wgrad_nsplit(MODE_TIME, B * T, N, C)
+    dWb0 = torch.empty(ns * B * T, C * C + C, device=X1.device, dtype=torch.float32)
+    if dWb1 is None:
+        dWb1 = torch.empty_like(dWb0)
+    assert dWb1.shape == dWb0.shape
+    try:
+        _call("gptst_hypertem_bwd_pair", _p(dOut1), _p(X1), _p(G1), _p(Wbt1), _p(R1), _p(X0), _p(G0), _p(Wbt0), _p(R0), _p(dXmid), _p(dX0),
+              _p(dG1), _p(dG0), _p(dWb1), _p(dWb0), _p(cnt), B, T, N, C, nbytes=_nb(dOut1, X1, R1, X0, R0, dXmid, dX0, dWb0, dWb1))
+    except _C.GptstError as e:
+        if e.code != _C.ESHAPE:
+            raise
+        return None
+    return dXmid, dX0, dWb1, dWb0, ns
+
+
 def tmix_bwd(dR, X, G, dOut, Y, dG=None):
     """Backward of the temporal mixing in one pass: -> (dX = dOut*lrelu'(Y) + G (*) dR, dG (N,T,T) = sum_b dR X^T)."""
     _chk(dR, X, G, dOut, Y, dG)

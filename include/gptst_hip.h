@@ -185,6 +185,14 @@ int gptst_hypertem_bwd(const float* dOut, const float* Y, const float* X, const 
  * gptst_wgrad_nsplit(...) == 1, else GPTST_ESHAPE.  C = 64. */
 int gptst_hypertem_bwd_wgrad(const float* dOut, const float* Y, const float* X, const float* G, const float* Wbt, const float* R, float* dX,
                              float* dG, float* dWb, int premul, int B, int T, int N, int C, void* stream);
+/* The backward of TWO consecutive hyperTem layers (L+1 "1" above L "0", nothing in between: GPTST.py:267-268, :271 -> :454) in ONE launch (r04):
+ * the slab workgroup turns dPre of layer L+1 into the input gradient times lrelu'(input) — dPre of layer L — and runs layer L on it at once;
+ * grid [slab | weight gradient L+1 | weight gradient L], the last role waits (bounded, NaN on expiry) for the sample's slabs to publish dXmid.
+ * dOut1 = dPre of layer L+1; X1 / X0 the layers' inputs (B,T,N,C), R1 / R0 their saved temporal mixes; -> dXmid (dPre of layer L), dX0 (times
+ * lrelu'(X0)), dG1 / dG0 (B*N,T,T) per-sample partials, dWb1 / dWb0 (nsplit * B*T, C*C + C).  cnt: B 32-bit words, ZERO on entry.  C = 64. */
+int gptst_hypertem_bwd_pair(const float* dOut1, const float* X1, const float* G1, const float* Wbt1, const float* R1, const float* X0,
+                            const float* G0, const float* Wbt0, const float* R0, float* dXmid, float* dX0, float* dG1, float* dG0,
+                            float* dWb1, float* dWb0, void* cnt, int B, int T, int N, int C, void* stream);
 
 /* ---- cap: node x cluster soft assignment + routing + aggregation (cap.hip, cap_cross.hip), GPTST.py:100-141 ----
  * route_fwd, one workgroup per (b,t):  P = squash(X Wp^T + bp) by MFMA into LDS; dadj (BT,HS,N) = teb.adj (from gptst_poolgen_fwd);

@@ -983,6 +983,33 @@ def test_cap_cross_folded_into_its_neighbours(B, N, HS, HT):
             assert torch.equal(a, b_), "three-role form differs in %s (rep %d)" % (nm, rep)
 
 
+@pytest.mark.parametrize("B,N", [(32, 170), (3, 37), (9, 16)])
+def test_hypertem_bwd_pair_equals_two_layer_calls(B, N):
+    """gptst_hypertem_bwd_pair (two adjacent hyperTem layers' backward on the slab, the lower layer's weight-gradient role fed by write-through
+    stores + a per-sample counter) == two gptst_hypertem_bwd_wgrad calls in the dPre chain, bit for bit, call after call."""
+    from gptst_amd import ops
+    dev = _dev()
+    g = torch.Generator().manual_seed(77)
+    T, C = 12, 64
+    x0 = rnd(B, T, N, C, g=g).to(dev)
+    G0, G1 = (rnd(N, T, T, g=g) * 0.2).to(dev), (rnd(N, T, T, g=g) * 0.2).to(dev)
+    W0, W1 = (rnd(B * T, C, C, g=g) * 0.1).to(dev), (rnd(B * T, C, C, g=g) * 0.1).to(dev)
+    b0, b1 = rnd(B * T, C, g=g).to(dev), rnd(B * T, C, g=g).to(dev)
+    R0, x1 = ops.hypertem_fwd(x0, G0, W0, b0)
+    R1, x2 = ops.hypertem_fwd(x1, G1, W1, b1)
+    dpre1 = rnd(B, T, N, C, g=g).to(dev)
+    dmid, dWb1, ns, dG1 = ops.hypertem_bwd_wgrad(dpre1, None, x1, G1, W1, R1, premul=True)
+    dx0, dWb0, _, dG0 = ops.hypertem_bwd_wgrad(dmid, None, x0, G0, W0, R0, premul=True)
+    for rep in range(3):
+        pG1, pG0 = torch.empty_like(dG1), torch.empty_like(dG0)
+        r = ops.hypertem_bwd_pair(dpre1, x1, G1, W1, R1, x0, G0, W0, R0, pG1, pG0, torch.zeros(B, device=dev))
+        assert r is not None
+        pmid, px0, pW1, pW0, pns = r
+        assert pns == ns
+        for a, b_, nm in ((pmid, dmid, "dXmid"), (px0, dx0, "dX0"), (pW1, dWb1, "dWb1"), (pW0, dWb0, "dWb0"), (pG1, dG1, "dG1"), (pG0, dG0, "dG0")):
+            assert torch.equal(a, b_), "pair form differs in %s (rep %d)" % (nm, rep)
+
+
 def test_step_begin_draws_philox_noise():
     """gptst_step_begin fills the step's mask noise with Philox4x32-10 uniforms keyed by device words (seed, step): exact against a Python
     restatement of the published algorithm, in [0,1), uniform, and a different stream per step."""
