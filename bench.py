@@ -42,6 +42,11 @@ def kernel_flops(name, tag, d):
         return 2.0 * rows * C * C + 4.0 * rows * C * T
     if name == "gptst_hypertem_bwd_wgrad":                # + dW_bt = R^T dPre in the same launch
         return 4.0 * rows * C * C + 4.0 * rows * C * T
+    if name == "gptst_hypertem_bwd_pair":                 # two layers' backward + weight gradients in one launch (r04)
+        return 2.0 * (4.0 * rows * C * C + 4.0 * rows * C * T)
+    if name == "gptst_hypertem_chain_fwd":                # tag "node<0|1> x<layers>": consecutive hyperTem layers [+ a cap's node layer in front]
+        node, nl = int(tag.split()[0][4:]), int(tag.split()[1][1:])
+        return nl * (2.0 * rows * C * C + 2.0 * rows * C * T) + node * 2.0 * rows * C * C
     if name in ("gptst_tmix", "gptst_tmix_dgraph"):
         return 2.0 * rows * C * T
     if name == "gptst_cap_route_fwd":
@@ -59,9 +64,10 @@ def kernel_flops(name, tag, d):
 
 # C-ABI entry point (+ tag) -> kernel symbol prefix in rocprofv3 traces / profiles/pmc_traffic.json
 KERNEL_SYMBOL = {
-    "gptst_cap_route_fwd": "void cap_route_fwd2_kernel<64,", "gptst_cap_route_bwd": "void cap_route_bwd2_kernel<64>",
+    "gptst_cap_route_fwd": "void cap_route_fwd", "gptst_cap_route_bwd": "void cap_route_bwd2_kernel<64",
     "gptst_hypertem_fwd": "hypertem_fwd_kernel", "gptst_hypertem_bwd": "hypertem_bwd_kernel", "gptst_wgrad": "void wgrad64_kernel",
-    "gptst_hypertem_bwd_wgrad": "void hypertem_bwd_wgrad_kernel<", "gptst_cap_cross_route_bwd": "void cap_route_bwd2_kernel<64>",
+    "gptst_hypertem_bwd_wgrad": "void hypertem_bwd_wgrad_kernel<", "gptst_cap_cross_route_bwd": "void cap_route_bwd2_kernel<64",
+    "gptst_hypertem_bwd_pair": "void hypertem_bwd_pair_kernel<", "gptst_hypertem_chain_fwd": "void hypertem_chain_fwd_kernel<",
     "gptst_cap_cross_rec_fwd": "void cap_cross_rec_fwd_kernel<64>", "gptst_apply_wgrad": "void applywg64_kernel<0,", "gptst_linear_bwd": "void applywg64_kernel<1,",
     "gptst_apply": "void apply64_kernel<", "gptst_tmix": "void tmix_kernel<64", "gptst_tmix_dgraph": "void tmix_dgraph_kernel<64>",
     "gptst_cap_rec_bwd": "void cap_rec_bwd2_kernel<64>", "gptst_cap_cross_bwd": "void cap_cross_bwd_kernel<64>",
@@ -85,7 +91,7 @@ def kernel_source_hash():
 # SURVEY.md 8(d) algorithmic bytes per launch in units of A = 4*B*T*N*C: a big layer's forward reads X and writes Y (2A), its backward reads
 # dY and the saved X and writes dX (3A).  hyperTem is one launch per direction; a cap layer's 2A / 3A are spread over its launches: X read
 # by the routing kernels, the layer output written by the node-conditioned apply, dOut read by its backward, dX written by the entry-Linear backward.
-ALG_8D_A = {"gptst_hypertem_fwd": 2.0, "gptst_hypertem_bwd": 3.0, "gptst_hypertem_bwd_wgrad": 3.0, "gptst_cap_route_fwd": 1.0,
+ALG_8D_A = {"gptst_hypertem_fwd": 2.0, "gptst_hypertem_bwd": 3.0, "gptst_hypertem_bwd_wgrad": 3.0, "gptst_hypertem_bwd_pair": 6.0, "gptst_cap_route_fwd": 1.0,
             "gptst_cap_cross_route_bwd": 1.0, "gptst_cap_route_bwd": 1.0, "gptst_apply": 1.0, "gptst_apply_wgrad": 1.0, "gptst_linear_bwd": 1.0,
             "gptst_cap_cross_rec_fwd": 0.0, "gptst_cap_rec_fwd": 0.0, "gptst_cap_rec_bwd": 0.0}
 
@@ -482,6 +488,8 @@ def main():
         # that binds the kernel (the larger of its two floor times); the operand-byte figure (every operand once) is kept beside it
         A_bytes = 4.0 * B * T * N * C
         b8d = ALG_8D_A.get(dn, None)
+        if dn == "gptst_hypertem_chain_fwd":               # 2A per hyperTem layer of the chain (+ 1A: the cap's layer output, when its node layer is in front)
+            b8d = 2.0 * int(dt.split()[1][1:]) + int(dt.split()[0][4:])
         b8d = A_bytes * b8d if b8d is not None else float(dv["bytes"])
         t_h, t_m = b8d / HBM_PEAK, fl / MFMA_F32_PEAK
         if t_h >= t_m:

@@ -77,6 +77,21 @@ __device__ __forceinline__ float ld_agent(const float* p) { return __hip_atomic_
 // bytes): sc1 = agent scope, i.e. the store is written through to memory and the load does not trust another XCD's stale L2 line.  A producer
 // follows its stores with `s_waitcnt vmcnt(0)` + __syncthreads() and one relaxed agent-scope flag store (MI355X_MICROARCH.md, inter-workgroup
 // visibility); the consumer polls the flag with ONE lane, relaxed, BOUNDED, then loads with ld4_sc1.
+// Bounded wait of ONE lane for a hand-off word written by another workgroup of the same launch: relaxed agent-scope polls, s_sleep between
+// them, and a WALL-CLOCK bound (0.25 s of the 100 MHz counter) — a spin COUNT is not a time: when another process shares the GPU its time
+// slices stall the producer while the consumer's polls keep counting (4000 polls expired about once in four runs of the two-ranks-on-one-GPU
+// test).  false = the hand-off is lost: the caller poisons its output with NaN, so the run ends loudly instead of hanging the GPU.
+__device__ __forceinline__ bool gptst_wait_ge(const unsigned* p, unsigned want) {
+    const long long t0 = wall_clock64();
+    for (;;) {
+#pragma unroll 1
+        for (int i = 0; i < 64; ++i) {
+            if (__hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= want) return true;
+            __builtin_amdgcn_s_sleep(8);
+        }
+        if (wall_clock64() - t0 > 25000000LL) return false;
+    }
+}
 typedef int gptst_i32x4 __attribute__((ext_vector_type(4)));
 typedef float gptst_f32x4 __attribute__((ext_vector_type(4)));
 __device__ __forceinline__ void st4_sc1(__amdgpu_buffer_rsrc_t rs, int off, float4 v) {

@@ -814,15 +814,7 @@ __global__ __launch_bounds__(256, 2) void hypertem_bwd_pair_kernel(HtPairArgs a,
     w -= nW;
     const int g = w % rm.G, sp = w / rm.G;
     unsigned* s_ok = reinterpret_cast<unsigned*>(smem);
-    if (threadIdx.x == 0) {
-        unsigned got = 0u;
-        for (int spin = 0; spin < 4000; ++spin) {
-            got = __hip_atomic_load(a.cnt + g / HT_T, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            if (got >= (unsigned)ntiles) break;
-            __builtin_amdgcn_s_sleep(8);
-        }
-        *s_ok = got >= (unsigned)ntiles;
-    }
+    if (threadIdx.x == 0) *s_ok = gptst_wait_ge(a.cnt + g / HT_T, (unsigned)ntiles) ? 1u : 0u;
     __syncthreads();
     const bool ok = *s_ok != 0u;
     __syncthreads();

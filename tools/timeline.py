@@ -1,14 +1,16 @@
 #!/usr/bin/env python
 """Timeline of ONE step from a rocprofv3 rocpd sqlite database (kernel-trace): per-kernel start offset, duration, and the gap
-to the previous kernel on the same queue, for the last complete step of the run (steps are delimited by `marker` kernel name,
-default adam_kernel).  usage: python tools/timeline.py results.db [marker] [which_from_end] > gpurun_out/timeline.txt"""
+to the previous kernel on the same queue (steps are delimited by `marker` kernel name, default adam_kernel).  Which step: by default the
+MEDIAN one (by span) among the steps with the most launches — the adaptive-mask + KL phase of a bench run, not a random-phase warm-up step
+and not a tie-path outlier; `which_from_end` = an integer picks that step counted from the end instead.
+usage: python tools/timeline.py results.db [marker] [median|which_from_end] > gpurun_out/timeline.txt"""
 import re
 import sqlite3
 import sys
 
 db = sqlite3.connect(sys.argv[1])
 marker = sys.argv[2] if len(sys.argv) > 2 else "adam_kernel"
-which = int(sys.argv[3]) if len(sys.argv) > 3 else 3
+which = sys.argv[3] if len(sys.argv) > 3 else "median"
 cols = [r[1] for r in db.execute("pragma table_info(kernels)")]
 print("# columns:", cols)
 name_c = "name" if "name" in cols else "kernel_name"
@@ -18,12 +20,22 @@ sel = "select %s, grid_x, grid_y, workgroup_x, start, end%s%s from kernels order
     name_c, (", " + qc) if qc else "", (", " + sc) if sc else "")
 rows = db.execute(sel).fetchall()
 ends = [i for i, r in enumerate(rows) if marker in r[0]]
-if len(ends) < which + 1:
+if len(ends) < 5:
     print("not enough steps", len(ends)); sys.exit(0)
-i0, i1 = ends[-which - 1] + 1, ends[-which] + 1
+if which == "median":
+    cand = [(a + 1, b + 1) for a, b in zip(ends[:-1], ends[1:])]
+    cnt = lambda c: sum(1 for r in rows[c[0]:c[1]] if not r[0].startswith("__amd_rocclr"))      # (the replay's H2D copy rides in every 4th step)
+    nmax = max(cnt(c) for c in cand)
+    cand = sorted((c for c in cand if cnt(c) == nmax), key=lambda c: rows[c[1] - 1][5] - rows[c[0]][4])
+    i0, i1 = cand[len(cand) // 2]
+    note = "median by span of the %d steps with %d launches" % (len(cand), nmax)
+else:
+    which = int(which)
+    i0, i1 = ends[-which - 1] + 1, ends[-which] + 1
+    note = "step %d from the end" % which
 step = rows[i0:i1]
 t0 = step[0][4]
-print("# step: %d kernels, span %.1f us" % (len(step), (step[-1][5] - t0) / 1e3))
+print("# step (%s): %d kernels, span %.1f us" % (note, len(step), (step[-1][5] - t0) / 1e3))
 last_end = {}
 busy = {}
 for r in step:
