@@ -17,6 +17,7 @@ def _dev():
 
 
 ELEM_FLOOR = 0.02      # element-wise relative error is taken against |ref| + ELEM_FLOOR * max|ref|
+ELEM_OUTLIERS = {"cap dadj": 1.5e-4, "cap dt_adj": 1.5e-4}      # measured 9.1e-5 / 9.1e-5 (test_cap_layer_streaming_path, N = 1030 / HS = 64), see close()
 
 
 def close(a, b, tol=1e-4, what=""):
@@ -37,8 +38,12 @@ def close(a, b, tol=1e-4, what=""):
               % (what, err, len(bad), d.numel(), bad[:2].tolist(), bad[-2:].tolist(), tuple(d.shape)))
         return err
     assert err < tol, "%s: max err / scale = %.3e (scale %.3e)" % (what, err, float(scale))
-    # measured worst over the whole suite (profiles/parity_r02.json): scaled 1.3e-5, element-wise 7.9e-5
-    assert elem < max(2e-4, 2 * tol), "%s: element-wise rel err = %.3e (floor %.0e x scale)" % (what, elem, ELEM_FLOOR)
+    # r04: the element-wise bound is the north-star 1e-4 too (r03: 2e-4).  Measured over the whole suite (profiles/parity_r04.json, 1882 tensors):
+    # scaled worst 1.3e-5; element-wise worst 9.1e-5, and only the two tensors named below come within 25 % of the bound — both are gradients
+    # of the cap's cluster logits / cross-time graph on the STREAMING path at shapes where a row sums 1030 nodes or 64 clusters in chunk
+    # order (the oracle sums them in one torch.matmul); they keep 1.5e-4 so that a different-but-valid summation order does not flip the test.
+    ebound = max(1e-4, tol) if key not in ELEM_OUTLIERS else max(ELEM_OUTLIERS[key], tol)
+    assert elem < ebound, "%s: element-wise rel err = %.3e (floor %.0e x scale)" % (what, elem, ELEM_FLOOR)
     return err
 
 
