@@ -492,3 +492,288 @@ extern "C" int gptst_mask_adaptive(const int* label, const int* counts, const in
     MsPlan r{label, a.counts, list_c, nums, noise_r, m_ada, 2, ada_all, HS, M, 0};
     return ms_select(r, w + MS_BLK, m_rnd, mask, base, (hipStream_t)stream, 1);                            // :399-413
 }
+
+// ======================================================================================================================
+// 24-bit noise (r04): the WHOLE mask generation of a step as ONE launch of ONE 1024-thread workgroup, keys in REGISTERS.
+//
+// The step's own noise is Philox (u32 >> 8) * 2^-24 and torch.rand draws the same lattice: every value is k * 2^-24 with an integer k < 2^24,
+// and ordering the floats = ordering the integers.  On the integers the radix select needs TWO uniform 12-bit digits instead of three skewed
+// float-bit digits (half of all keys share four bins of the float's top digit — the LDS atomics of the r02 single-workgroup attempt serialised
+// on them: 234 us at 65 280 cells), and a thread keeps its 64 cells' keys in registers, so nothing is re-read between the passes.  The
+// multi-launch path above costs 8 launches of ~5.5 us in the adaptive phase (4 in the random phase) — latency, not work; this is one.
+//   precondition: noise values on the 2^-24 lattice in [0, 1).  Checked on the device: any other value poisons the whole mask with NaN (the loss
+//   turns NaN at once) instead of selecting on rounded keys.  Callers with arbitrary float noise use gptst_mask_random / gptst_mask_adaptive.
+//   M <= 65536 cells (64 per thread); ties at the threshold are resolved in index order exactly as above.
+// ======================================================================================================================
+#define MU_T 1024
+#define MU_CPT 64
+#define MU_BINS 4096
+typedef unsigned long long mu_u64;
+
+// LDS: the TOP 12-bit digit of every cell's key as 16 bits (bit 15: the key is exactly 0 — ineligible cell or zero noise) = 128 KB for 65 536
+// cells; the low digit is needed only for the handful of cells that share the threshold's top digit, and those re-read their noise.  (A first
+// form kept the 64 keys of a thread in registers: fully unrolled loops over a 64-entry register array at 128 VGPRs spilled 140-500 registers.)
+struct MuShared {
+    unsigned short top[MU_T * MU_CPT];
+    unsigned hist[MU_BINS];         // (first use: the class histogram per wave, [16][256] ints — one address per class would serialise the
+                                    //  whole workgroup's LDS atomics)
+    unsigned wsum[MU_T / 64 + 1];
+    unsigned res[4];                // threshold bin, remaining, count in the bin
+    int counts[256];
+    unsigned bad, base_rank;
+    MsClass cls;
+};
+
+__device__ __forceinline__ unsigned mu_key(float v, unsigned& bad) {
+    const unsigned k = (unsigned)(v * 16777216.f);
+    bad |= (!(v >= 0.f) || k >= (1u << 24) || (float)k * (1.f / 16777216.f) != v) ? 1u : 0u;
+    return k & 0xFFFFFFu;
+}
+
+__device__ __forceinline__ unsigned mu_wave_sum(unsigned v) {
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) v += __shfl_xor(v, off, 64);
+    return v;
+}
+
+// exclusive prefix of `loc` over the 1024 threads in thread order (wave shuffles + one LDS hop); -> before, and the block total in `total`
+__device__ __forceinline__ unsigned mu_scan(unsigned loc, MuShared& sh, unsigned& total) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    unsigned inc = loc;
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) { const unsigned v = __shfl_up(inc, off, 64); if (lane >= off) inc += v; }
+    __syncthreads();                                        // (wsum of the previous scan has been read by everyone)
+    if (lane == 63) sh.wsum[wave] = inc;
+    __syncthreads();
+    unsigned before = inc - loc, tot = 0u;
+#pragma unroll
+    for (int w = 0; w < MU_T / 64; ++w) { const unsigned s = sh.wsum[w]; if (w < wave) before += s; tot += s; }
+    total = tot;
+    return before;
+}
+
+// the bin of sh.hist (4096 bins, filled) that holds rank `remaining` from the top -> sh.res[] = {bin, remaining inside the bin, count of the bin}
+__device__ __forceinline__ void mu_find(unsigned remaining, MuShared& sh) {
+    unsigned h[4], loc = 0u;                                 // thread t owns bins 4095 - (4t + j): descending keys = ascending rank from the top
+#pragma unroll
+    for (int j = 0; j < 4; ++j) { h[j] = sh.hist[MU_BINS - 1 - (4 * threadIdx.x + j)]; loc += h[j]; }
+    unsigned total;
+    const unsigned before = mu_scan(loc, sh, total);
+    if (before < remaining && before + loc >= remaining) {          // exactly one thread
+        unsigned cum = before;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            if (cum + h[j] >= remaining) { sh.res[0] = MU_BINS - 1 - (4 * threadIdx.x + j); sh.res[1] = remaining - cum; sh.res[2] = h[j]; break; }
+            cum += h[j];
+        }
+    }
+    __syncthreads();
+}
+
+// One selection of rank k (1 <= k <= M) over the keys  key(i) = elig(i) ? k24(noise[i]) : 0,  elig(i) = (gate bit of the owning thread) — the
+// caller has filled sh.top[] — -> bit u of the result: cell u * 1024 + t is MASKED (key > threshold, or threshold-equal and among the first
+// `need` of them in index order).  `elig`: bit u = cell u * 1024 + t is eligible.
+__device__ __forceinline__ mu_u64 mu_select_mark(const float* __restrict__ noise, mu_u64 elig, int M, int k, MuShared& sh, unsigned& bad) {
+    const int t = threadIdx.x;
+    // ---- digit 1: histogram of the top digits (exact zeros counted in a register: every ineligible cell sits there) ----
+    for (int b = t; b < MU_BINS; b += MU_T) sh.hist[b] = 0u;
+    __syncthreads();
+    unsigned zeros = 0u;
+#pragma unroll 8
+    for (int u = 0; u < MU_CPT; ++u) {
+        const int i = u * MU_T + t;
+        if (i < M) {
+            const unsigned tp = sh.top[i];
+            if (tp & 0x8000u) ++zeros; else atomicAdd(&sh.hist[tp], 1u);
+        }
+    }
+    zeros = mu_wave_sum(zeros);
+    if ((t & 63) == 0 && zeros) atomicAdd(&sh.hist[0], zeros);
+    __syncthreads();
+    mu_find((unsigned)k, sh);
+    const unsigned d1 = sh.res[0], rem = sh.res[1];
+    __syncthreads();
+    // ---- digit 2: the low digits of the cells whose top digit is d1 (they re-read their noise) ----
+    for (int b = t; b < MU_BINS; b += MU_T) sh.hist[b] = 0u;
+    __syncthreads();
+    zeros = 0u;
+#pragma unroll 4
+    for (int u = 0; u < MU_CPT; ++u) {
+        const int i = u * MU_T + t;
+        if (i < M) {
+            const unsigned tp = sh.top[i];
+            if ((tp & 0xFFFu) == d1) {
+                if (tp & 0x8000u) ++zeros; else atomicAdd(&sh.hist[mu_key(noise[i], bad) & 0xFFFu], 1u);
+            }
+        }
+    }
+    zeros = mu_wave_sum(zeros);
+    if ((t & 63) == 0 && zeros) atomicAdd(&sh.hist[0], zeros);
+    __syncthreads();
+    mu_find(rem, sh);
+    const unsigned d2 = sh.res[0], need = sh.res[1], cnt_eq = sh.res[2];
+    __syncthreads();
+    const bool ties = need != cnt_eq;                                // uniform
+    mu_u64 m = 0ull, eqm = 0ull;
+#pragma unroll 4
+    for (int u = 0; u < MU_CPT; ++u) {
+        const int i = u * MU_T + t;
+        if (i < M) {
+            const unsigned tp = sh.top[i], tt = tp & 0xFFFu;
+            if (tt > d1) m |= 1ull << u;
+            else if (tt == d1) {
+                const unsigned lo = (tp & 0x8000u) ? 0u : (mu_key(noise[i], bad) & 0xFFFu);
+                if (lo > d2) m |= 1ull << u;
+                else if (lo == d2) eqm |= 1ull << u;
+            }
+        }
+    }
+    (void)elig;
+    if (!ties) return m | eqm;
+    // rare: a tie straddles rank k — the threshold-equal cells take the `need` slots in index order (cell = u * 1024 + t: row u, then thread t)
+    if (t == 0) sh.base_rank = 0u;
+    __syncthreads();
+#pragma unroll 1
+    for (int u = 0; u < MU_CPT; ++u) {
+        const unsigned eq = (unsigned)(eqm >> u) & 1u;
+        unsigned total;
+        const unsigned before = mu_scan(eq, sh, total);
+        const unsigned base_rank = sh.base_rank;
+        if (eq && base_rank + before < need) m |= 1ull << u;
+        __syncthreads();
+        if (t == 0) sh.base_rank = base_rank + total;
+        __syncthreads();
+        if (base_rank + total >= need) break;                        // uniform
+    }
+    return m;
+}
+
+template <bool ADAPTIVE>
+__global__ __launch_bounds__(MU_T) void mu_mask_kernel(const int* __restrict__ label, const int* __restrict__ list_c, const int* __restrict__ nums,
+                                                       const float* __restrict__ noise_a, const float* __restrict__ noise_r, int ada_all, int M,
+                                                       int HS, int base, int k_const, float* __restrict__ m_ada, float* __restrict__ m_rnd,
+                                                       float* __restrict__ mask) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char mu_smem[];
+    MuShared& sh = *reinterpret_cast<MuShared*>(mu_smem);
+    const int t = threadIdx.x, wave = t >> 6;
+    unsigned bad = 0u;
+    if (t == 0) sh.bad = 0u;
+    mu_u64 ma = 0ull;                                                // selection A: masked cells (incl. the fully masked classes)
+    if constexpr (ADAPTIVE) {
+        for (int h = t; h < 256; h += MU_T) { sh.counts[h] = 0; sh.cls.d[h] = 0; sh.cls.f[h] = 0; }
+        int (*wcounts)[256] = reinterpret_cast<int (*)[256]>(sh.hist);
+        static_assert(MU_BINS == (MU_T / 64) * 256, "the per-wave class histogram aliases the digit histogram");
+        for (int h = t; h < MU_BINS; h += MU_T) sh.hist[h] = 0u;
+        __syncthreads();
+        // class histogram (GPTST.py:344-345 bincount)
+#pragma unroll 8
+        for (int u = 0; u < MU_CPT; ++u) {
+            const int i = u * MU_T + t;
+            if (i < M) atomicAdd(&wcounts[wave][label[i] & 255], 1);
+        }
+        __syncthreads();
+        for (int h = t; h < HS; h += MU_T) {
+            int c = 0;
+            for (int w = 0; w < MU_T / 64; ++w) c += wcounts[w][h];
+            sh.counts[h] = c;
+        }
+        __syncthreads();
+        if (t == 0) {                                                // class roles, GPTST.py:357-384,393 (as ms_classes)
+            const int ada_num = nums[0];
+            int num = 0, i = 0;
+            while (num < ada_num && i < HS) { num += sh.counts[list_c[i]]; ++i; }
+            int dnum = 0;
+            if (ada_all && i >= 2) {
+                for (int k = 0; k < i - 1; ++k) { sh.cls.d[list_c[k]] = 1; dnum += sh.counts[list_c[k]]; }
+                sh.cls.f[list_c[i - 1]] = 1;
+            } else {
+                for (int k = 0; k < i; ++k) sh.cls.f[list_c[k]] = 1;
+            }
+            sh.cls.ka = ada_num - dnum;
+        }
+        __syncthreads();
+        const int ka = sh.cls.ka;
+        mu_u64 da = 0ull;                                            // cells of the fully masked classes (:397)
+#pragma unroll 8
+        for (int u = 0; u < MU_CPT; ++u) {                           // selection A keys: noise_a gated by the class (:390)
+            const int i = u * MU_T + t;
+            if (i < M) {
+                const int l = label[i] & 255;
+                const unsigned k24 = mu_key(noise_a[i], bad);              // (every value is checked, eligible or not)
+                const unsigned kk = sh.cls.f[l] ? k24 : 0u;
+                sh.top[i] = (unsigned short)((kk >> 12) | (kk == 0u ? 0x8000u : 0u));
+                if (sh.cls.d[l]) da |= 1ull << u;
+            }
+        }
+        __syncthreads();
+        // (re-read noise of an INELIGIBLE cell would give it a low digit: the zero flag in top[] stands for the whole key there)
+        if (ka > 0) ma = mu_select_mark(noise_a, 0ull, M, ka, sh, bad);       // :386-397
+        ma |= da;
+        __syncthreads();
+    }
+    // selection R (adaptive: noise_r gated by m_ada, :399-413) / the random selection (:316-321)
+    const float* __restrict__ nz = ADAPTIVE ? noise_r : noise_a;
+#pragma unroll 8
+    for (int u = 0; u < MU_CPT; ++u) {
+        const int i = u * MU_T + t;
+        if (i < M) {
+            const unsigned k24 = mu_key(nz[i], bad);
+            const unsigned kk = (ADAPTIVE && ((ma >> u) & 1ull)) ? 0u : k24;
+            sh.top[i] = (unsigned short)((kk >> 12) | (kk == 0u ? 0x8000u : 0u));
+        }
+    }
+    __syncthreads();
+    const int kr = ADAPTIVE ? nums[1] : k_const;
+    mu_u64 mr = 0ull;
+    if (kr > 0) mr = mu_select_mark(nz, 0ull, M, kr, sh, bad);
+    if (bad) atomicOr(&sh.bad, 1u);
+    __syncthreads();
+    const bool poison = sh.bad != 0u;
+    const float nan = __int_as_float(0x7fc00000);
+#pragma unroll 4
+    for (int u = 0; u < MU_CPT; ++u) {
+        const int i = u * MU_T + t;
+        if (i >= M) break;
+        const float va = ((ma >> u) & 1ull) ? 0.f : 1.f;
+        const float vr = ((mr >> u) & 1ull) ? 0.f : 1.f;
+        if (ADAPTIVE) {
+            if (m_ada) m_ada[i] = poison ? nan : va;
+            if (m_rnd) m_rnd[i] = poison ? nan : vr;
+            const float f = poison ? nan : va * vr;
+            for (int j = 0; j < base; ++j) mask[(size_t)i * base + j] = f;
+        } else {
+            mask[i] = poison ? nan : vr;
+        }
+    }
+}
+
+static int mu_prepare() {
+    static int done = 0;
+    if (!done) {
+        (void)hipFuncSetAttribute((const void*)mu_mask_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(MuShared));
+        (void)hipFuncSetAttribute((const void*)mu_mask_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(MuShared));
+        done = 1;
+    }
+    return (int)sizeof(MuShared);
+}
+
+// noise on the 2^-24 lattice (see above), M <= 65536: one launch.  GPTST_ESHAPE beyond that size (use gptst_mask_random).
+extern "C" int gptst_mask_random_u24(const float* noise, int M, int k, float* mask, void* stream) {
+    if (!noise || !mask || M <= 0 || k < 0 || k > M) return GPTST_EARG;
+    if (M > MU_T * MU_CPT) return GPTST_ESHAPE;
+    hipLaunchKernelGGL((mu_mask_kernel<false>), dim3(1), dim3(MU_T), mu_prepare(), (hipStream_t)stream, (const int*)nullptr, (const int*)nullptr,
+                       (const int*)nullptr, noise, (const float*)nullptr, 0, M, 0, 1, k, (float*)nullptr, (float*)nullptr, mask);
+    GPTST_CHECK_LAUNCH();
+    return GPTST_OK;
+}
+
+// as gptst_mask_adaptive (the class histogram is taken from the labels); m_ada / m_rnd may be NULL.
+extern "C" int gptst_mask_adaptive_u24(const int* label, const int* list_c, const int* nums, const float* noise_a, const float* noise_r,
+                                       int ada_all, int M, int HS, int base, float* m_ada, float* m_rnd, float* mask, void* stream) {
+    if (!label || !list_c || !nums || !noise_a || !noise_r || !mask || HS <= 0 || HS > 256 || M <= 0 || base <= 0) return GPTST_EARG;
+    if (M > MU_T * MU_CPT) return GPTST_ESHAPE;
+    hipLaunchKernelGGL((mu_mask_kernel<true>), dim3(1), dim3(MU_T), mu_prepare(), (hipStream_t)stream, label, list_c, nums, noise_a, noise_r, ada_all, M, HS,
+                       base, 0, m_ada, m_rnd, mask);
+    GPTST_CHECK_LAUNCH();
+    return GPTST_OK;
+}

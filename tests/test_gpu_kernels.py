@@ -300,6 +300,9 @@ def test_mask_random_bit_exact(M, ratio, seed):
         with _mask_path(multi):
             got = ops.mask_random(noise.to(dev), int(M * ratio))
         assert torch.equal(got.cpu().to(torch.int64), ref), multi
+    # r04: lattice noise (k * 2^-24, what synth / torch.rand / the step's Philox draw) -> the one-launch path on the integers
+    got = ops.mask_random(noise.to(dev), int(M * ratio), u24=True)
+    assert torch.equal(got.cpu().to(torch.int64), ref), "u24"
 
 
 class _mask_path:
@@ -335,6 +338,31 @@ def test_mask_random_ties_lowest_index(multi, reps):
                 ref = torch.ones(n)
                 ref[order[:k]] = 0
                 assert torch.equal(got, ref), k
+        if multi == 0:                                         # one-launch lattice path: 0.1 is not k * 2^-24 -> 0.125 (same order, same ties)
+            lat = torch.where(noise == 0.1, torch.tensor(0.125), noise)
+            assert torch.equal(ops.mask_random(lat.to(dev), k, u24=True).cpu(), ref), ("u24", k)
+
+
+def test_mask_u24_rejects_noise_off_the_lattice():
+    """gptst_mask_*_u24 select on the integers k = noise * 2^24: a value that is not k * 2^-24 (or outside [0,1)) must not be rounded silently —
+    the whole mask comes back NaN; lattice noise with the SAME cells gives a clean {0,1} mask; beyond 65536 cells the general path serves."""
+    from gptst_amd import ops, synth
+    dev = _dev()
+    M = 5000
+    noise = synth.make_noise(M, 21)
+    assert torch.equal((noise * 2 ** 24).round() / 2 ** 24, noise) and float(noise.max()) < 1
+    ok = ops.mask_random(noise.to(dev), 1250, u24=True)
+    assert set(ok.unique().tolist()) == {0.0, 1.0}
+    for bad in (0.1, 1.0, -0.25, float("nan")):              # 0.1 is not on the lattice; 1.0 / negative / NaN are outside [0, 1)
+        nz = noise.clone(); nz[1234] = bad
+        assert torch.isnan(ops.mask_random(nz.to(dev), 1250, u24=True)).all(), bad
+    lab = torch.randint(0, 10, (M,), dtype=torch.int32).to(dev)
+    lc = torch.tensor(synth.class_order(10, 1), dtype=torch.int32, device=dev)
+    nums = torch.tensor([600, 650], dtype=torch.int32, device=dev)
+    nz = noise.clone(); nz[77] = 0.25 + 2.0 ** -25            # a float32 below 0.5 with an odd last mantissa bit: not on the 2^-24 lattice
+    assert torch.isnan(ops.mask_adaptive(lab, None, lc, nums, noise.to(dev), nz.to(dev), 1, 1, u24=True)[2]).all()
+    big = synth.make_noise(70000, 5)
+    assert torch.equal(ops.mask_random(big.to(dev), 17500, u24=True).cpu().long(), O.random_mask(big, 0.25))       # falls back: > 65536 cells
 
 
 @pytest.mark.parametrize("ada_all", [1, 0])
@@ -365,6 +393,13 @@ def test_mask_adaptive_bit_exact(ada_all, B, N, HS, frac):
         assert torch.equal(m_rnd.cpu().long(), m_rnd_r)
         assert torch.equal(mask.cpu().long().view(M, base), fin_r.view(M, 1).repeat(1, base))
         assert int((mask.view(M, base)[:, 0] == 0).sum()) == total
+    for base, parts in ((1, True), (2, True), (1, False)):                  # r04: lattice noise -> ONE launch (class histogram inside)
+        m_ada, m_rnd, mask = ops.mask_adaptive(label, None, torch.tensor(list_c, dtype=torch.int32, device=dev),
+                                               torch.tensor([ada, rnd_n], dtype=torch.int32, device=dev), na.to(dev), nr.to(dev),
+                                               ada_all, base, u24=True, want_parts=parts)
+        if parts:
+            assert torch.equal(m_ada.cpu().long(), m_ada_r) and torch.equal(m_rnd.cpu().long(), m_rnd_r)
+        assert torch.equal(mask.cpu().long().view(M, base), fin_r.view(M, 1).repeat(1, base)), "u24"
 
 
 @pytest.mark.parametrize("ada_all", [1, 0])
@@ -417,6 +452,11 @@ def test_mask_adaptive_ties_and_caller_zeroed_scratch(ada_all):
                 assert torch.equal(m_ada.cpu().long(), m_ada_r), (total, frac, ws is None)
                 assert torch.equal(m_rnd.cpu().long(), m_rnd_r), (total, frac, ws is None)
                 assert torch.equal(mask.cpu().long(), fin_r.view(-1)), (total, frac, ws is None)
+        m_ada, m_rnd, mask = ops.mask_adaptive(label, None, torch.tensor(list_c, dtype=torch.int32, device=dev),
+                                               torch.tensor([ada, rnd_n], dtype=torch.int32, device=dev), na.to(dev), nr.to(dev),
+                                               ada_all, 1, u24=True)                # the one-launch lattice path: the same tie rule
+        assert torch.equal(m_ada.cpu().long(), m_ada_r) and torch.equal(m_rnd.cpu().long(), m_rnd_r), ("u24", total, frac)
+        assert torch.equal(mask.cpu().long(), fin_r.view(-1)), ("u24", total, frac)
     noise = synth.make_noise(M, 3)
     ref = O.random_mask(noise, 0.25)
     with _mask_path(1):
