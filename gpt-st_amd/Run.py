@@ -73,12 +73,15 @@ def main():
         else:                                     # only this rank's batches are gathered (the permutation itself is drawn by every rank)
             for x in train.iter_x(rank=dp.rank, world=dp.world, limit=usable):
                 yield x.contiguous()
+            # the tail of the epoch is KEPT (r04; it was dropped): the full batches beyond the last whole group, then the ragged last batch,
+            # as padded rounds — a rank without a batch of its own steps on a copy of the round's first batch with rank weight 0 (its
+            # gradient and loss statistics are zeroed before the all-reduce, trainer.py / step.py::_allreduce)
+            for xs in train.iter_tail(usable, dp.world):
+                k = min(dp.rank, len(xs) - 1)
+                yield (xs[k].contiguous(), 1.0 if dp.rank < len(xs) else 0.0)
 
     full = train.n // args.batch_size
-    nb = len(train) if dp is None else full // dp.world
-    if dp is not None and dp.rank == 0 and len(train) != nb * dp.world:
-        print("gpt-st_amd: data parallel over %d ranks drops %d of %d batches per epoch (ragged tail / incomplete group)"
-              % (dp.world, len(train) - nb * dp.world, len(train)))
+    nb = len(train) if dp is None else full // dp.world + len(list(train.tail_rounds(full // dp.world * dp.world, dp.world)))
     Trainer(model, args, batches, mean, std, args.batch_size, dp=dp, batches_per_epoch=nb).train()
     if dp is not None:
         import torch.distributed as dist

@@ -107,12 +107,32 @@ class WindowLoader:
         """Input windows only (pretraining never reads the y windows, BasicTrainer.py:74-76): one gather per batch instead of two.
         rank / world: data parallelism — the permutation of the epoch is drawn in full (every rank draws the same one), but only batches
         rank, rank + world, ... (of the first `limit`) are gathered; the others cost nothing."""
-        order = self._order()
+        order = self._last_order = self._order()
         for k, i in enumerate(range(0, self.n, self.bs)):
             if (limit is not None and k >= limit) or k % world != rank:
                 continue
             idx = order[i:i + self.bs].to(self.series.device)
             yield self.series[idx[:, None] + self._tx[None, :]]
+
+    def tail_rounds(self, first, world):
+        """Batch indices of the padded rounds behind the first `first` batches under `world`-way data parallelism: the remaining FULL batches
+        as one round (fewer than `world` of them), then the ragged last batch as a round of its own (other batch size)."""
+        full, nb = self.n // self.bs, (self.n + self.bs - 1) // self.bs
+        if first < full:
+            yield list(range(first, full))
+        if nb > full:
+            yield [full]
+
+    def iter_tail(self, first, world):
+        """-> per padded round the list of its batches' input windows (iter_x's permutation: call it BEHIND iter_x of the same epoch, which
+        drew the permutation — the order is cached per epoch)."""
+        order = self._last_order
+        for ks in self.tail_rounds(first, world):
+            out = []
+            for k in ks:
+                idx = order[k * self.bs:(k + 1) * self.bs].to(self.series.device)
+                out.append(self.series[idx[:, None] + self._tx[None, :]])
+            yield out
 
 
 def get_dataloader(args, root="../data", device="cpu", raw=None, single=False, generator=None):

@@ -97,6 +97,7 @@ class PretrainStep:
         self.dp_overlap = (self.dp_overlap_mode > 0 and dp is not None and getattr(dp, "capturable", False)
                            and (self.W > 1 or os.environ.get("GPTST_FORCE_DP", "0") == "1"))
         self.dec_lo, self.dec_hi = self._decoder_bucket(model)
+        self.rank_weight = 1.0                          # 0.0: this rank steps on padding (eager tail round of a data-parallel epoch, see _allreduce)
         self.fork_side = torch.cuda.Stream() if self.dp_overlap else None
         if self.dp_overlap and self.dp_overlap_mode == 2 and self.red_side is None:
             self.red_side = engine.SideStream()
@@ -124,10 +125,19 @@ class PretrainStep:
         assert not any(lo <= o < hi for k, o in model._offs.items() if not k.startswith("decoder.")), "decoder bucket is not contiguous"
         return lo, hi
 
+    def _allreduce(self, sl):
+        """All-reduce of a slice of the packed [gradient | statistics] buffer.  rank_weight = 0 (an eager tail step of a data-parallel epoch:
+        this rank has no batch of its own in the last, incomplete round and steps on padding) zeroes the rank's contribution first — gradient
+        AND statistics, so the global kept-cell count the optimiser divides by does not see the padding either."""
+        if self.rank_weight != 1.0:
+            assert not self.use_graph, "a rank weight is baked into a captured graph: tail rounds use eager steppers"
+            sl.mul_(self.rank_weight)
+        self.dp.allreduce_(sl)
+
     def _bucket_ready(self, k):
         """engine.Reductions callback (inside the side-stream fork): bucket 0 = the decoder's gradient is final -> its all-reduce starts now"""
         if k == 0:
-            self.dp.allreduce_(self.gbuf[self.dec_lo:self.dec_hi])
+            self._allreduce(self.gbuf[self.dec_lo:self.dec_hi])
             self._dec_reduced = True
 
     def _dp_in_graph(self):
@@ -227,10 +237,10 @@ class PretrainStep:
             self._optim()
         elif self._dp_in_graph():           # gradient all-reduce + optimiser as the last nodes of the step's graph (no host gap behind the replay)
             if self._dec_reduced:           # the decoder bucket went out under the encoder's backward: what is left is [encoder] and [KL path | never | statistics]
-                self.dp.allreduce_(self.gbuf[:self.dec_lo])
-                self.dp.allreduce_(self.gbuf[self.dec_hi:])
+                self._allreduce(self.gbuf[:self.dec_lo])
+                self._allreduce(self.gbuf[self.dec_hi:])
             else:
-                self.dp.allreduce_(self.gbuf)
+                self._allreduce(self.gbuf)
             self._optim()
 
     def _mask_ws(self):
@@ -355,7 +365,7 @@ class PretrainStep:
                 self._exchange_labels()
                 g2.replay()
         if self.dp is not None and not self._dp_in_graph():
-            self.dp.allreduce_(self.gbuf)
+            self._allreduce(self.gbuf)
             self._optim()
 
     def _capture(self, key):

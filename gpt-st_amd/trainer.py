@@ -46,8 +46,10 @@ class Trainer:
         self.lr_steps = [int(i) for i in str(args.lr_decay_step).split(",")] if args.lr_decay else []
         self.up_epoch = [int(i) for i in str(args.up_epoch).split(",")]
 
-    def _stepper_for(self, B):
-        if B == self.step.B:
+    def _stepper_for(self, B, tail=False):
+        """tail: an eager stepper even for the full batch size — the rounds of a data-parallel epoch in which some ranks step on padding
+        with rank_weight 0 (a weight cannot change inside a captured graph)."""
+        if B == self.step.B and not tail:
             return self.step
         if B not in self.ragged:                         # drop_last=False in the reference: the last batch is smaller
             s = PretrainStep(self.model, self.args, self.scaler[0], self.scaler[1], B, use_graph=False, dp=self.dp, seed=self.args.seed)
@@ -89,9 +91,16 @@ class Trainer:
             del pend[:]
 
         for bi, src in enumerate(self.batches(epoch)):
-            if src.shape[0] != self.step.B:
+            # (batch, rank weight): a TAIL round of a data-parallel epoch (Run.py batches()) — some rank steps on padding with weight 0.  Every
+            # rank gets the tuple form in such a round (weight 1 for a real batch): all of them take the eager stepper, so the sequence of
+            # collectives stays the same on every rank.
+            weight, tail = 1.0, isinstance(src, tuple)
+            if tail:
+                src, weight = src
+            if src.shape[0] != self.step.B or tail:
                 flush()                                  # before the ragged stepper takes over the optimiser counters
-            st = self._stepper_for(src.shape[0])
+            st = self._stepper_for(src.shape[0], tail=tail)
+            st.rank_weight = weight
             if G > 1 and st is self.step:
                 buf = self.step.group_sources(G)[len(pend)]
                 buf.copy_(src, non_blocking=True)        # the loader may reuse its batch buffer: keep a copy until the group is enqueued
@@ -101,6 +110,7 @@ class Trainer:
                 continue
             flush()
             st.step(src, epoch)
+            st.rank_weight = 1.0
             if st is not self.step:
                 self.step.tA, self.step.tB = st.tA, st.tB
             account(bi, *st.losses())                    # the reference syncs every step too (BasicTrainer.py:98-103)

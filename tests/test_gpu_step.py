@@ -175,6 +175,58 @@ def test_dp_global_mask_equals_single_process_global_batch(use_graph):
                 assert torch.equal(sr.last_mask, mask_ref[r * M:(r + 1) * M]), (epoch, r)
 
 
+class _TailDP(_FakeDP):
+    """Two ranks of a padded tail round, one after the other on this GPU: the first records what it sends into the all-reduce, the second
+    receives it (sum of the two contributions)."""
+
+    def __init__(self, rank, peer_sent=None):
+        super().__init__(rank, 2, None, None)
+        self.sent, self.peer_sent = None, peer_sent
+
+    def allreduce_(self, buf):
+        self.sent = buf.clone()
+        if self.peer_sent is not None:
+            buf.add_(self.peer_sent)
+        return buf
+
+
+@pytest.mark.parametrize("epoch", [1, 20])
+def test_padded_tail_round_of_a_data_parallel_epoch(epoch):
+    """r04 (the tail of a data-parallel epoch is kept): a rank without a batch of its own steps on padding with rank_weight 0 — its gradient
+    AND loss statistics are zeroed before the all-reduce.  With per-rank masks the round must then be exactly the single-process step on the
+    real batch: same losses, same weights on BOTH ranks (the replicas stay identical), whatever the padding rank computed."""
+    from gptst_amd.model import GPTST_Model
+    from gptst_amd.step import PretrainStep
+    args = _args()
+    sd = O.init_state_dict(args, 4)
+    M = 4 * 12 * 20
+    real, pad = synth.make_batch(4, 12, 20, 1, seed=31).to(DEV), synth.make_batch(4, 12, 20, 1, seed=32).to(DEV)
+    kw = dict(noise=synth.make_noise(M, 5).to(DEV)) if epoch == 1 else dict(
+        noise_a=synth.make_noise(M, 6).to(DEV), noise_r=synth.make_noise(M, 7).to(DEV), list_c=[2, 0, 4, 1, 3])
+
+    def run(src, dp, weight):
+        model = GPTST_Model(args); model.load_state_dict(sd); model = model.to(DEV)
+        st = PretrainStep(model, args, synth.SCALER_MEAN, synth.SCALER_STD, batch_size=4, use_graph=False, dp=dp, global_mask=False, deterministic=True)
+        st.rank_weight = weight
+        st.step(src, epoch, **kw)
+        torch.cuda.synchronize()
+        return st.losses(), {k: v.detach().clone() for k, v in model.state_dict().items()}
+
+    l_plain, w_plain = run(real, None, 1.0)
+    dp0 = _TailDP(0)
+    l0, w0 = run(real, dp0, 1.0)
+    assert float(dp0.sent.abs().max()) > 0
+    dp1 = _TailDP(1, peer_sent=dp0.sent)
+    l1, w1 = run(pad, dp1, 0.0)
+    assert float(dp1.sent.abs().max()) == 0.0, "the padding rank must contribute nothing (gradient and statistics)"
+    np.testing.assert_allclose(l0, l_plain, rtol=1e-6)
+    np.testing.assert_allclose(l1, l_plain, rtol=1e-6)                 # the job's loss is the real batch's, on every rank
+    for k in w_plain:
+        assert torch.equal(w1[k], w0[k]), k                            # the replicas stay bit-identical
+        # vs the plain stepper: the data-parallel form sums the loss gradient and divides by the kept-cell count in the optimiser (one rounding apart)
+        assert float((w0[k] - w_plain[k]).abs().max()) <= 2e-6 * max(float(w_plain[k].abs().max()), 1e-3) + 1e-9, k
+
+
 @pytest.mark.parametrize("use_graph", [False, True])
 def test_unsynced_queue_equals_synced_steps(use_graph):
     """50 steps enqueued back to back with NO host sync (what bench.py does) must see the same per-step host scalars (Adam bias

@@ -141,3 +141,26 @@ def test_window_loader_rank_slices_partition_the_epoch():
     assert [len(p) for p in parts] == [6, 6, 6]
     for k in range(18):
         assert torch.equal(parts[k % 3][k // 3], full[k])
+
+
+def test_window_loader_tail_rounds_keep_every_batch():
+    """Data parallelism keeps the tail of an epoch as padded rounds: the batches iter_x hands to the ranks plus the batches of the tail rounds
+    are exactly the batches of the single-process epoch (same permutation), the ragged last batch in a round of its own."""
+    from gptst_amd.data import WindowLoader
+    series = torch.arange(200 * 3, dtype=torch.float32).view(200, 3, 1)
+    for world in (2, 3, 4):
+        mk = lambda: WindowLoader(series, 12, 12, 8, shuffle=True, generator=torch.Generator().manual_seed(5))
+        full_epoch = [x for x in mk().iter_x()]
+        full = mk().n // 8
+        usable = full // world * world
+        ld = mk()
+        per_rank = [[x for x in ld.iter_x(rank=r, world=world, limit=usable)] for r in range(1)]   # (rank 0 draws the permutation of the epoch)
+        rounds = list(ld.tail_rounds(usable, world))
+        assert sum(len(r) for r in rounds) == len(full_epoch) - usable
+        assert all(len(r) < world or len(r) == 1 for r in rounds)
+        got = [x for xs in ld.iter_tail(usable, world) for x in xs]
+        for k, x in zip(range(usable, len(full_epoch)), got):
+            assert torch.equal(x, full_epoch[k])
+        if mk().n % 8:
+            assert got[-1].shape[0] == mk().n % 8 and rounds[-1] == [full]
+        assert torch.equal(per_rank[0][0], full_epoch[0])
