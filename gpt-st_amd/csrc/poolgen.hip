@@ -354,6 +354,10 @@ static int pj_blocks(PJob& j) {
     return j.nbx * (((j.cols + 255) / 256 + 3) / 4);
 }
 
+// rows of a GRAM job one workgroup takes for (K, cols) — <= 0: the pool + one row do not fit the kernel's LDS scratch (e.g. more than 20 hyperedges
+// at embed_dim 16): the caller then runs gptst_gram_fwd on the forward job's output instead (ops.PoolJobs.gram does)
+extern "C" int gptst_pool_jobs_gram_rows(int K, int cols) { return (K <= 0 || K > PG_MAXK || cols <= 0 || cols % 12) ? 0 : pj_gram_rows(K, cols); }
+
 static int pj_launch(PJobs& t, hipStream_t st) {
     int nb = 0;
     for (int p = 0; p < t.n; ++p) {

@@ -479,7 +479,7 @@ def _sthcn_gen_jobs(p, pfx, emb, jobs, A_all, dims, G_all=None):
     for i, h in enumerate(hts):
         jobs.fwd(ne, p[h + "adj"].view(d, Hm * T), out=A_all[i])                                          # :156
         if G_all is not None:
-            jobs.gram(ne, p[h + "adj"].view(d, Hm * T), out=G_all[i])                                     # :156-158 G_n = A_n^T A_n, same launch
+            jobs.gram(ne, p[h + "adj"].view(d, Hm * T), out=G_all[i], A=A_all[i])                         # :156-158 G_n = A_n^T A_n, same launch
     Wb = [jobs.fwd(time_eb, t) for h in hts for t in (p[h + "weights_pool"], p[h + "bias_pool"])]         # :160-161
     Wn = [jobs.fwd(nes, t) for c in cps for t in (p[c + "weights_spa"], p[c + "bias_spa"])]               # :137-138
     dadj = [jobs.fwd(teb, p[c + "adj"].view(ds, HS * N)) for c in cps]                                    # :104

@@ -131,6 +131,7 @@ class PoolJobs:
 
     def __init__(self):
         self.jobs = []
+        self.post = []           # (A, G, rows, Hm): temporal graphs built by gptst_gram_fwd behind the launch (shapes beyond the job kernel)
 
     def fwd(self, emb, pool, out=None):
         """out (R, ...) = emb (R,K) @ pool (K, ...)"""
@@ -141,12 +142,18 @@ class PoolJobs:
         self.jobs.append((self.FWD, emb, None, pool, out, R, K, pool.numel() // K, 1, 0))
         return out
 
-    def gram(self, emb, pool, out):
-        """out (R,12,12) = A_r^T A_r, A_r = (emb @ pool)[r] viewed (cols/12, 12) — hyperTem's temporal graph (= gram_fwd of the fwd() job's output)"""
-        _chk(emb, pool, out)
+    def gram(self, emb, pool, out, A=None):
+        """out (R,12,12) = A_r^T A_r, A_r = (emb @ pool)[r] viewed (cols/12, 12) — hyperTem's temporal graph (= gram_fwd of the fwd() job's output).
+        A: that forward job's output (R, cols) — used when the shape does not fit the job kernel's LDS scratch (more than 20 hyperedges at
+        embed_dim 16): the graph is then built by gptst_gram_fwd right behind the job launch."""
+        _chk(emb, pool, out, A)
         R, K = emb.shape
         cols = pool.numel() // K
         assert cols % 12 == 0 and out.numel() == R * 144 and out.is_contiguous()
+        if _C.lib().value("gptst_pool_jobs_gram_rows", K, cols) <= 0:
+            assert A is not None and A.numel() == R * cols, "gram job does not fit and no forward output was given"
+            self.post.append((A, out, R, cols // 12))
+            return out
         self.jobs.append((self.GRAM, emb, None, pool, out, R, K, cols, 1, 0))
         return out
 
@@ -172,11 +179,13 @@ class PoolJobs:
 
     def launch(self):
         js, self.jobs = self.jobs, []
-        if not js:
-            return
-        col = lambda i: [j[i] for j in js]
-        _call("gptst_pool_jobs", len(js), _ints(col(0)), _ptrs0(col(1)), _ptrs0(col(2)), _ptrs0(col(3)), _ptrs0(col(4)), _ints(col(5)),
-              _ints(col(6)), _ints(col(7)), _ints(col(8)), _ints(col(9)), nbytes=_nb(*[t for j in js for t in j[1:5]]))
+        post, self.post = self.post, []
+        if js:
+            col = lambda i: [j[i] for j in js]
+            _call("gptst_pool_jobs", len(js), _ints(col(0)), _ptrs0(col(1)), _ptrs0(col(2)), _ptrs0(col(3)), _ptrs0(col(4)), _ints(col(5)),
+                  _ints(col(6)), _ints(col(7)), _ints(col(8)), _ints(col(9)), nbytes=_nb(*[t for j in js for t in j[1:5]]))
+        for A, G, rows, Hm in post:                      # temporal graphs whose shape is beyond the job kernel
+            _call("gptst_gram_fwd", _p(A), _p(G), rows, Hm)
 
 
 def _ptrs0(ts):

@@ -494,6 +494,11 @@ class PretrainStep:
                 torch.cuda.empty_cache()
             finally:
                 self.src, self.stats_out, self.hyper, self.ctrl, self.rng_words = keep
+            if self.dp is not None and getattr(self.dp, "world", 1) > 1 and hasattr(self.dp, "max_over_ranks"):
+                # ... and so is the outcome of the capture itself: one rank that could not record the group takes every rank to single steps
+                if self.dp.max_over_ranks(1.0 if self._group_failed else 0.0) > 0 and not self._group_failed:
+                    self._group_failed = True
+                    self._g_graphs.pop(phase, None)
             if self._group_failed:
                 return self.step_group(sources, epoch, list_cs)
         sl = self._g_ring[self._g_ring_i]
@@ -537,6 +542,11 @@ class PretrainStep:
         # branch, or their collective sequences diverge)
         per_step = torch.cuda.max_memory_allocated() - base
         total = torch.cuda.get_device_properties(self.dev).total_memory
+        if self.dp is not None and getattr(self.dp, "world", 1) > 1 and hasattr(self.dp, "max_over_ranks"):
+            # the group / no-group decision is COLLECTIVE: the largest per-step peak any rank measured and the smallest device decide
+            # for all of them — ranks whose allocators differ must not take different branches (their collective sequences would diverge)
+            per_step = int(self.dp.max_over_ranks(per_step))
+            total = -int(self.dp.max_over_ranks(-total))
         if per_step * K > 0.25 * total:
             self.model.flat.copy_(keep[0]); self.m.copy_(keep[1]); self.v.copy_(keep[2])
             torch.cuda.synchronize()

@@ -66,6 +66,9 @@ int gptst_poolgen_bwd_emb_multi(int nprob, const void* dWs, const void* pools, c
  * where per-embedding launches needed ~50. */
 int gptst_pool_jobs(int njobs, const int* kind, const void* const* emb, const void* const* x, const void* const* pool,
                     const void* const* out, const int* R, const int* K, const int* cols, const int* nsplit, const int* ldx, void* stream);
+/* rows per workgroup of a kind-3 (temporal graph) job for (K, cols); <= 0: the shape does not fit the job kernel — use gptst_gram_fwd on the
+ * forward job's output (more than 20 hyperedges at embed_dim 16). */
+int gptst_pool_jobs_gram_rows(int K, int cols);
 
 /* ---- C x C contractions on fp32 MFMA (apply.hip) ------------------------------------------------------
  * out[g,m,:] = epi( pro(A)[g,m,:] @ W[g] (+bias[g]) (+resid) ).   mode: 0 TIME (g=(b,t), rows n), 1 NODE (g=n, rows

@@ -1055,6 +1055,28 @@ def test_hypertem_bwd_pair_equals_two_layer_calls(B, N):
             assert torch.equal(a, b_), "pair form differs in %s (rep %d)" % (nm, rep)
 
 
+def test_temporal_graph_job_falls_back_beyond_its_lds_scratch():
+    """the kind-3 job of gptst_pool_jobs (hyperTem's G_n = A_n^T A_n from node embedding and hyperedge pool) holds pool + rows in
+    4160 LDS floats — 20 hyperedges at embed_dim 16.  Beyond that PoolJobs.gram builds the graph with gptst_gram_fwd behind the launch: same
+    numbers as the job form where both serve, and the large shape equals the torch restatement."""
+    from gptst_amd import ops, _C
+    dev = _dev()
+    g = torch.Generator().manual_seed(9)
+    for N, d, Hm in ((170, 16, 16), (170, 16, 20), (170, 16, 24), (37, 8, 48)):
+        ne, pool = rnd(N, d, g=g).to(dev), (rnd(d, Hm * 12, g=g) * 0.3).to(dev)
+        fits = _C.lib().value("gptst_pool_jobs_gram_rows", d, Hm * 12) > 0
+        assert fits == ((d + 1) * Hm * 12 <= 4160)
+        jobs = ops.PoolJobs()
+        A = jobs.fwd(ne, pool)
+        G = torch.empty(N, 12, 12, device=dev)
+        jobs.gram(ne, pool, out=G, A=A)
+        assert (len(jobs.post) == 0) == fits
+        jobs.launch()
+        Ar = (ne.cpu() @ pool.cpu()).view(N, Hm, 12)
+        close(G, torch.einsum("nht,nhu->ntu", Ar, Ar), what="temporal graph (job or fallback)")
+        assert torch.equal(G, ops.gram_fwd(A.view(N, Hm, 12)))
+
+
 def test_step_begin_draws_philox_noise():
     """gptst_step_begin fills the step's mask noise with Philox4x32-10 uniforms keyed by device words (seed, step): exact against a Python
     restatement of the published algorithm, in [0,1), uniform, and a different stream per step."""
