@@ -784,6 +784,7 @@ extern "C" int gptst_hypertem_bwd_wgrad(const float* dOut, const float* Y, const
 // needs dPre_L of ALL nodes of a (b,t): its workgroups sit at the END of the grid [slab | wgrad L+1 | wgrad L] and wait for the sample's slab
 // workgroups to have published stage 1 (write-through stores + one counter per sample): every wait points to a lower block index, so with
 // blocks dispatched in index order nothing waits on a workgroup that is not yet on the chip; the wait is bounded and ends in NaN rows of dWb0.
+GPTST_STAMP_TABLES(hypertem)
 struct HtPairArgs {
     const float* dOut1; const float* X1; const float* G1; const float* Wbt1; const float* R1;
     const float* X0; const float* G0; const float* Wbt0; const float* R0;
@@ -798,17 +799,23 @@ __global__ __launch_bounds__(256, 2) void hypertem_bwd_pair_kernel(HtPairArgs a,
         int b, tile;
         if (!ht_work_at(blockIdx.x, ntiles, B, b, tile)) return;
         float4 dp[HT_T];
+        GPTST_WG_BEGIN(); GPTST_STAMP(0);
         hypertem_bwd_stage<false, true, 1>(a.dOut1, nullptr, a.X1, a.G1, a.Wbt1, a.dXmid, nullptr, a.dG1, N, B, 0, b, tile, smem, dp);
+        GPTST_STAMP(1);
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");             // this wave's write-through stores of dPre_L have left ...
         __syncthreads();                                              // ... (all waves; and the dG phase is done with the LDS slab)
         if (threadIdx.x == 0) __hip_atomic_fetch_add(a.cnt + b, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        GPTST_STAMP(2);
         hypertem_bwd_stage<false, true, 2>(nullptr, nullptr, a.X0, a.G0, a.Wbt0, a.dX0, nullptr, a.dG0, N, B, 0, b, tile, smem, dp);
+        GPTST_STAMP(3); GPTST_WG_END();
         return;
     }
+    GPTST_WG_BEGIN();
     const int nW = rm.G * ((rm.M + rows_per_split - 1) / rows_per_split);
     int w = blockIdx.x - nH;
     if (w < nW) {
         wgrad64_body<PRO_NONE, U>(a.R1, a.dOut1, nullptr, a.dWb1, rm, rows_per_split, 64 * 64 + 64, 2, w % rm.G, w / rm.G, smem);
+        GPTST_WG_END();
         return;
     }
     w -= nW;
@@ -820,6 +827,7 @@ __global__ __launch_bounds__(256, 2) void hypertem_bwd_pair_kernel(HtPairArgs a,
     __syncthreads();
     wgrad64_body<PRO_NONE, U, true>(a.R0, a.dXmid, nullptr, a.dWb0, rm, rows_per_split, 64 * 64 + 64, 2, g, sp, smem);
     if (!ok) a.dWb0[((size_t)sp * rm.G + g) * (size_t)(64 * 64 + 64) + threadIdx.x] = __int_as_float(0x7fc00000);    // lost hand-off: loud
+    GPTST_WG_END();
 }
 
 // dOut1 = dPre of layer L+1; X1 / X0 the layers' inputs (X1 = output of layer L), R1 / R0 their saved mixes; -> dXmid (= dPre of layer L),

@@ -30,7 +30,22 @@ w_in, b_in = f(C, 1), f(C)
 Gt = f(N, 12, 12) * 0.1
 Wbt, bbt = f(BT, C, C) * 0.1, f(BT, C)
 o_ei, ab_ei, wv_ei = ops.encin_ht1_fwd(src3, 1, mask1, -1.5, w_in, b_in, Gt, Wbt, bbt)
+def _pair_case():
+    g = lambda *sh: torch.randn(*sh, device=dev)
+    x0 = g(B, T, N, C)
+    G0, G1 = g(N, T, T) * 0.2, g(N, T, T) * 0.2
+    W0, W1, b0, b1 = g(BT, C, C) * 0.1, g(BT, C, C) * 0.1, g(BT, C), g(BT, C)
+    R0, x1 = ops.hypertem_fwd(x0, G0, W0, b0)
+    R1, x2 = ops.hypertem_fwd(x1, G1, W1, b1)
+    dpre1 = g(B, T, N, C)
+    dG1, dG0 = torch.empty(B, N, T, T, device=dev), torch.empty(B, N, T, T, device=dev)
+    return lambda: ops.hypertem_bwd_pair(dpre1, x1, G1, W1, R1, x0, G0, W0, R0, dG1, dG0, torch.zeros(B, device=dev))
+
+
 CASES = {
+    "ht_bwd_pair": ("hypertem", _pair_case(),
+                    ["stage 1: layer L+1 on the slab (loads, dR, dX -> dPre_L written through, dG)", "drain the write-through stores, count up",
+                     "stage 2: layer L on the slab"]),
     "encin_fwd": ("encin", lambda: ops.encin_ht1_fwd(src3, 1, mask1, -1.5, w_in, b_in, Gt, Wbt, bbt),
                   ["w W_bt, bi W_bt partials", "alpha / beta / m per node (G rows, flow, mask) + barrier", "rows out"]),
     "encin_bwd": ("encin", lambda: ops.encin_ht1_bwd(dO, src3, mask1, -1.5, w_in, b_in, Wbt, ab_ei, wv_ei),
@@ -59,12 +74,14 @@ ph = (ctypes.c_longlong * (8 * 32))()
 wg = (ctypes.c_longlong * (2048 * 2))()
 assert getattr(dll, "gptst_stamps_" + unit)(ph, wg) == 0
 nwg = BT + (4 * B if name.endswith('roles') else 0) + (BT + 4 * B if name.endswith('roles3') else 0)
+if name == "ht_bwd_pair":
+    nwg = 352 + 2 * BT
 ph = np.array(ph).reshape(8, 32); wg = np.array(wg).reshape(2048, 2)[:nwg]
 t0 = wg[:, 0].min()
 print("%s: %.2f us per launch (50 back to back); workgroups start %.2f .. %.2f us, end %.2f .. %.2f us after the first start; mean duration %.2f us"
       % (name, e0.elapsed_time(e1) * 20, (wg[:, 0].min() - t0) * 0.01, (wg[:, 0].max() - t0) * 0.01, (wg[:, 1].min() - t0) * 0.01, (wg[:, 1].max() - t0) * 0.01,
          (wg[:, 1] - wg[:, 0]).mean() * 0.01))
-for lo, hi in ((0, 128), (128, 256), (256, BT), (BT, BT + 4 * B), (BT + 4 * B, nwg)):
+for lo, hi in (((0, 352), (352, 352 + BT), (352 + BT, nwg)) if name == "ht_bwd_pair" else ((0, 128), (128, 256), (256, BT), (BT, BT + 4 * B), (BT + 4 * B, nwg))):
     if hi > lo and lo < nwg and hi <= nwg:
         w = wg[lo:hi]
         print("   workgroups %3d..%3d: end %.2f us (mean), duration %.2f us" % (lo, hi - 1, (w[:, 1].mean() - t0) * 0.01, (w[:, 1] - w[:, 0]).mean() * 0.01))

@@ -25,7 +25,10 @@ if len(ends) < 5:
 if which == "median":
     cand = [(a + 1, b + 1) for a, b in zip(ends[:-1], ends[1:])]
     cnt = lambda c: sum(1 for r in rows[c[0]:c[1]] if not r[0].startswith("__amd_rocclr"))      # (the replay's H2D copy rides in every 4th step)
-    nmax = max(cnt(c) for c in cand)
+    hist = {}
+    for c in cand:
+        hist[cnt(c)] = hist.get(cnt(c), 0) + 1
+    nmax = max(n for n, k in hist.items() if k >= max(4, len(cand) // 10))        # the largest launch count that is a regular step, not a one-off
     cand = sorted((c for c in cand if cnt(c) == nmax), key=lambda c: rows[c[1] - 1][5] - rows[c[0]][4])
     i0, i1 = cand[len(cand) // 2]
     note = "median by span of the %d steps with %d launches" % (len(cand), nmax)
