@@ -5,7 +5,7 @@
 tag=${1:-r03}
 cd $GRAFT_REPO_ROOT
 mkdir -p gpurun_out
-CMD="python bench.py --steps 60 --warmup 4 --no-cpu-baseline --no-kernel-timing"
+CMD="python bench.py --steps 60 --warmup 4 --no-cpu-baseline --no-kernel-timing --no-module-path"
 PROF_LINES=5 tools/prof.sh ${tag}_trace auto $CMD > /dev/null
 db=$(ls /tmp/prof_${tag}_trace/*.db | head -1)
 python tools/timeline.py $db > gpurun_out/${tag}_timeline.txt
