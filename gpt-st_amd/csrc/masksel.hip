@@ -15,11 +15,21 @@
 #define MS_BLOCKS 64                     // workgroups of a selection launch up to 2^16 cells; more cells: one per 1024 cells, up to MS_BLOCKS_MAX
 #define MS_BLOCKS_MAX 512
 #define MS_THREADS 256
-#define MS_BINS 2048
-#define MS_BLK (3 * MS_BINS + 16)      // words of one selection's block: three digit histograms + the prefix memo (9 words)
-// digit d covers bits [SH(d), SH(d)+W(d)):  d0 = 31..21, d1 = 20..10, d2 = 9..0
-__device__ __forceinline__ int ms_shift(int d) { return d == 0 ? 21 : (d == 1 ? 10 : 0); }
-__device__ __forceinline__ int ms_bins(int d) { return d == 2 ? 1024 : 2048; }
+#define MS_BINS 4096
+#define MS_BLK (3 * MS_BINS + 16)      // words of one selection's block: three digit histograms + the prefix memo (9 words) + [15] the lattice flag
+// float keys: digit d covers bits [SH(d), SH(d)+W(d)):  d0 = 31..21, d1 = 20..10, d2 = 9..0
+// u24 (r04): the noise is on the 2^-24 lattice (Philox / torch.rand): keys are the integers k = noise * 2^24 and TWO uniform 12-bit digits serve —
+// one launch less per selection.  The lattice is checked where a key is formed; a violation sets word 15 of the block's memo and the mask write
+// poisons its output with NaN (see gptst_mask_random_u24).
+__device__ __forceinline__ int ms_ndig(int u24) { return u24 ? 2 : 3; }
+__device__ __forceinline__ int ms_shift(int d, int u24 = 0) { return u24 ? (d == 0 ? 12 : 0) : (d == 0 ? 21 : (d == 1 ? 10 : 0)); }
+__device__ __forceinline__ int ms_bins(int d, int u24 = 0) { return u24 ? 4096 : (d == 2 ? 1024 : 2048); }
+__device__ __forceinline__ unsigned ms_fkey(float v, int u24, unsigned& bad) {
+    if (!u24) return __float_as_uint(v);
+    const unsigned k = (unsigned)(v * 16777216.f);
+    bad |= (!(v >= 0.f) || k >= (1u << 24) || (float)k * (1.f / 16777216.f) != v) ? 1u : 0u;
+    return k & 0xFFFFFFu;
+}
 
 // workspace layout (uint32): hist[3][2048] for selection A/R or the random selection, followed by nothing else.
 struct MsPlan {            // what a selection works on
@@ -31,6 +41,7 @@ struct MsPlan {            // what a selection works on
     const float* gate;     // selection R: m_ada (cells with gate == 0 are not eligible); else null
     int mode;              // 0 random phase, 1 adaptive selection A (class gated), 2 adaptive selection R (m_ada gated)
     int ada_all, HS, M, k_const;
+    int u24;               // keys are noise * 2^24 (two digits) instead of the float bits (three)
 };
 
 struct MsClass {           // class roles of the adaptive phase, derived per workgroup (cheap: <= HS steps)
@@ -57,11 +68,13 @@ __device__ void ms_classes(const MsPlan& p, MsClass& c) {       // GPTST.py:357-
     __syncthreads();
 }
 
-__device__ __forceinline__ unsigned ms_key(const MsPlan& p, const MsClass& c, int i) {
-    if (p.mode == 1) return c.f[p.label[i]] ? __float_as_uint(p.noise[i]) : 0u;          // :390
-    if (p.mode == 2) return p.gate[i] != 0.f ? __float_as_uint(p.noise[i]) : 0u;         // :401
-    return __float_as_uint(p.noise[i]);                                                  // :316-317
+__device__ __forceinline__ unsigned ms_key(const MsPlan& p, const MsClass& c, int i, unsigned& bad) {
+    const unsigned k = ms_fkey(p.noise[i], p.u24, bad);                                  // (every value is checked, eligible or not)
+    if (p.mode == 1) return c.f[p.label[i]] ? k : 0u;                                    // :390
+    if (p.mode == 2) return p.gate[i] != 0.f ? k : 0u;                                   // :401
+    return k;                                                                            // :316-317
 }
+__device__ __forceinline__ unsigned ms_key(const MsPlan& p, const MsClass& c, int i) { unsigned bad = 0u; return ms_key(p, c, i, bad); }
 
 __device__ __forceinline__ int ms_rank(const MsPlan& p, const MsClass& c) {
     return p.mode == 0 ? p.k_const : (p.mode == 1 ? c.ka : p.nums[1]);
@@ -71,13 +84,13 @@ __device__ __forceinline__ int ms_rank(const MsPlan& p, const MsClass& c) {
 // parallel suffix scan: 2048 bins x 64 workgroups as a thread-0 loop adds up); the state after the earlier digits comes from `memo`
 // (3 words per digit behind the histograms), written by workgroup 0 of the launch that scanned that digit.
 __device__ void ms_prefix(const unsigned* __restrict__ hist, int ndig, int k, unsigned* sh /* >= MS_BINS+8 */, unsigned& prefix,
-                          unsigned& remaining, unsigned& cnt_eq) {
+                          unsigned& remaining, unsigned& cnt_eq, int u24 = 0) {
     prefix = 0u; remaining = (unsigned)k; cnt_eq = 0u;
     if (ndig <= 0) return;
     unsigned* memo = const_cast<unsigned*>(hist) + 3 * MS_BINS;
     if (ndig >= 2) { prefix = memo[3 * (ndig - 2)]; remaining = memo[3 * (ndig - 2) + 1]; cnt_eq = memo[3 * (ndig - 2) + 2]; }
     for (int d = ndig - 1; d < ndig; ++d) {
-        const int nb = ms_bins(d);
+        const int nb = ms_bins(d, u24);
         const unsigned* h = hist + d * MS_BINS;
         // each thread owns nb/256 consecutive bins (descending order = ascending "rank from the top")
         const int per = nb / MS_THREADS;
@@ -101,7 +114,7 @@ __device__ void ms_prefix(const unsigned* __restrict__ hist, int ndig, int k, un
             }
         }
         __syncthreads();
-        prefix |= sh[MS_THREADS] << ms_shift(d);
+        prefix |= sh[MS_THREADS] << ms_shift(d, u24);
         remaining = sh[MS_THREADS + 1];
         cnt_eq = sh[MS_THREADS + 2];
         __syncthreads();
@@ -117,17 +130,17 @@ __global__ __launch_bounds__(MS_THREADS) void ms_hist_kernel(MsPlan p, unsigned*
     if (p.mode == 1) ms_classes(p, cls);
     const int k = ms_rank(p, cls);
     if (k <= 0) return;                                          // uniform: nothing to select
-    unsigned prefix, remaining, cnt_eq;
-    ms_prefix(hist, dig, k, sc, prefix, remaining, cnt_eq);
-    for (int b = threadIdx.x; b < MS_BINS; b += MS_THREADS) lh[b] = 0u;
+    unsigned prefix, remaining, cnt_eq, bad = 0u;
+    ms_prefix(hist, dig, k, sc, prefix, remaining, cnt_eq, p.u24);
+    const int sh = ms_shift(dig, p.u24), nb = ms_bins(dig, p.u24);
+    for (int b = threadIdx.x; b < nb; b += MS_THREADS) lh[b] = 0u;
     __syncthreads();
-    const int sh = ms_shift(dig), nb = ms_bins(dig);
-    const unsigned hi_mask = dig == 0 ? 0u : (0xFFFFFFFFu << (sh + (dig == 1 ? 11 : 10)));
+    const unsigned hi_mask = dig == 0 ? 0u : (p.u24 ? 0xFFFFF000u : (0xFFFFFFFFu << (sh + (dig == 1 ? 11 : 10))));
     // four cells per trip: their (noise, label / gate) loads are issued together (one cell per trip = one serialised L2 round trip per trip)
     for (int i0 = blockIdx.x * MS_THREADS + threadIdx.x; i0 < p.M; i0 += 4 * gridDim.x * MS_THREADS) {
         unsigned key[4];
 #pragma unroll
-        for (int u = 0; u < 4; ++u) { const int i = i0 + u * gridDim.x * MS_THREADS; key[u] = i < p.M ? ms_key(p, cls, i) : 0u; }
+        for (int u = 0; u < 4; ++u) { const int i = i0 + u * gridDim.x * MS_THREADS; key[u] = i < p.M ? ms_key(p, cls, i, bad) : 0u; }
 #pragma unroll
         for (int u = 0; u < 4; ++u)
             if (i0 + u * gridDim.x * MS_THREADS < p.M && (key[u] & hi_mask) == (prefix & hi_mask)) atomicAdd(&lh[(key[u] >> sh) & (unsigned)(nb - 1)], 1u);
@@ -135,6 +148,7 @@ __global__ __launch_bounds__(MS_THREADS) void ms_hist_kernel(MsPlan p, unsigned*
     __syncthreads();
     unsigned* gh = hist + dig * MS_BINS;
     for (int b = threadIdx.x; b < nb; b += MS_THREADS) if (lh[b]) atomicAdd(gh + b, lh[b]);
+    if (bad) atomicOr(hist + 3 * MS_BINS + 15, 1u);                  // a noise value off the lattice: the mask write poisons its output
 }
 
 // final launch of a selection: write the {0,1} mask of this selection (and the combined mask for selection R)
@@ -151,12 +165,17 @@ __global__ __launch_bounds__(MS_THREADS) void ms_apply_kernel(MsPlan p, const un
     __shared__ unsigned s_base;
     __shared__ unsigned lh[MS_BINS];
     const bool nxt = next_noise != nullptr && p.nums[1] > 0;        // uniform
-    if (nxt) { for (int b = threadIdx.x; b < MS_BINS; b += MS_THREADS) lh[b] = 0u; }
+    const int nb0 = ms_bins(0, p.u24);
+    if (nxt) { for (int b = threadIdx.x; b < nb0; b += MS_THREADS) lh[b] = 0u; }
     if (p.mode == 1) ms_classes(p, cls);
     const int k = ms_rank(p, cls);
-    unsigned thr = 0xFFFFFFFFu, need = 0u, cnt_eq = 0u;
-    if (k > 0) ms_prefix(hist, 3, k, sc, thr, need, cnt_eq);
+    unsigned thr = 0xFFFFFFFFu, need = 0u, cnt_eq = 0u, bad = 0u, bad2 = 0u;
+    if (k > 0) ms_prefix(hist, ms_ndig(p.u24), k, sc, thr, need, cnt_eq, p.u24);
     const bool ties = k > 0 && need != cnt_eq;                   // uniform
+    // u24: a value off the lattice was seen by a digit pass of this selection (or, selection R: by selection A, whose block sits MS_BLK words
+    // below) -> every output of this launch is NaN
+    const bool poison = p.u24 && (hist[3 * MS_BINS + 15] != 0u || (p.mode == 2 && (hist - MS_BLK)[3 * MS_BINS + 15] != 0u));
+    const float one = poison ? __int_as_float(0x7fc00000) : 1.f, zero = poison ? __int_as_float(0x7fc00000) : 0.f;
     for (int i0 = blockIdx.x * MS_THREADS + threadIdx.x; i0 < p.M; i0 += 4 * gridDim.x * MS_THREADS) {       // four cells' loads in flight
         unsigned keys[4], nk[4];
         int lab[4];
@@ -164,10 +183,10 @@ __global__ __launch_bounds__(MS_THREADS) void ms_apply_kernel(MsPlan p, const un
 #pragma unroll
         for (int u = 0; u < 4; ++u) {
             const int i = min(i0 + u * (int)gridDim.x * MS_THREADS, p.M - 1);
-            keys[u] = ms_key(p, cls, i);
+            keys[u] = ms_key(p, cls, i, bad);
             lab[u] = p.mode == 1 ? p.label[i] : 0;
             gat[u] = p.mode == 2 ? p.gate[i] : 0.f;
-            nk[u] = nxt ? __float_as_uint(next_noise[i]) : 0u;
+            nk[u] = nxt ? ms_fkey(next_noise[i], p.u24, bad2) : 0u;
         }
 #pragma unroll
         for (int u = 0; u < 4; ++u) {
@@ -180,14 +199,16 @@ __global__ __launch_bounds__(MS_THREADS) void ms_apply_kernel(MsPlan p, const un
             float vis = 1.f;
             if (k > 0 && (key > thr || (key == thr && !ties))) vis = 0.f;
             if (p.mode == 1 && cls.d[lab[u]]) vis = 0.f;
-            out[i] = vis;
-            if (p.mode == 2) { const float f = gat[u] * vis; for (int j = 0; j < base; ++j) final_mask[(size_t)i * base + j] = f; }
-            if (nxt) atomicAdd(&lh[(vis != 0.f ? nk[u] : 0u) >> ms_shift(0)], 1u);
+            out[i] = vis != 0.f ? one : zero;
+            if (p.mode == 2) { const float f = gat[u] * (vis != 0.f ? one : zero); for (int j = 0; j < base; ++j) final_mask[(size_t)i * base + j] = f; }
+            if (nxt) atomicAdd(&lh[(vis != 0.f ? nk[u] : 0u) >> ms_shift(0, p.u24)], 1u);
         }
     }
     const bool tie_wg = ties && blockIdx.x == 0;
+    if (p.u24 && bad) atomicOr(const_cast<unsigned*>(hist) + 3 * MS_BINS + 15, 1u);      // (seen only here: the flag serves the launches behind this one)
+    if (p.u24 && bad2 && next_hist) atomicOr(next_hist + 3 * MS_BINS + 15, 1u);
     if (!tie_wg) {
-        if (nxt) { __syncthreads(); for (int b = threadIdx.x; b < MS_BINS; b += MS_THREADS) if (lh[b]) atomicAdd(next_hist + b, lh[b]); }
+        if (nxt) { __syncthreads(); for (int b = threadIdx.x; b < nb0; b += MS_THREADS) if (lh[b]) atomicAdd(next_hist + b, lh[b]); }
         return;
     }
     // rare: a tie straddles rank k.  Workgroup 0 hands the `need` threshold-equal slots out in index order and writes BOTH
@@ -217,15 +238,15 @@ __global__ __launch_bounds__(MS_THREADS) void ms_apply_kernel(MsPlan p, const un
             const int i = ib + (__ffs(m) - 1);
             float vis = rank < need ? 0.f : 1.f;
             if (p.mode == 1 && cls.d[p.label[i]]) vis = 0.f;
-            out[i] = vis;
-            if (p.mode == 2) { const float f = p.gate[i] * vis; for (int j = 0; j < base; ++j) final_mask[(size_t)i * base + j] = f; }
-            if (nxt) atomicAdd(&lh[(vis != 0.f ? __float_as_uint(next_noise[i]) : 0u) >> ms_shift(0)], 1u);
+            out[i] = vis != 0.f ? one : zero;
+            if (p.mode == 2) { const float f = p.gate[i] * (vis != 0.f ? one : zero); for (int j = 0; j < base; ++j) final_mask[(size_t)i * base + j] = f; }
+            if (nxt) { unsigned b3 = 0u; atomicAdd(&lh[(vis != 0.f ? ms_fkey(next_noise[i], p.u24, b3) : 0u) >> ms_shift(0, p.u24)], 1u); }
         }
         __syncthreads();
         if (threadIdx.x == MS_THREADS - 1) s_base += sc[threadIdx.x];
         __syncthreads();
     }
-    if (nxt) { __syncthreads(); for (int b = threadIdx.x; b < MS_BINS; b += MS_THREADS) if (lh[b]) atomicAdd(next_hist + b, lh[b]); }
+    if (nxt) { __syncthreads(); for (int b = threadIdx.x; b < nb0; b += MS_THREADS) if (lh[b]) atomicAdd(next_hist + b, lh[b]); }
 }
 
 // ======================================================================================================================
@@ -415,7 +436,7 @@ static int ms_select(const MsPlan& p, unsigned* hist, float* out, float* final_m
     // and with a fixed 64 workgroups the generation grew from 50 to 112 us at 8 x 65280 cells (tools/experiments/mb_mask_scaling.py)
     int nbk = (p.M + 4 * MS_THREADS - 1) / (4 * MS_THREADS);
     nbk = nbk < MS_BLOCKS ? MS_BLOCKS : (nbk > MS_BLOCKS_MAX ? MS_BLOCKS_MAX : nbk);
-    for (int d = d0; d < 3; ++d) hipLaunchKernelGGL(ms_hist_kernel, dim3(nbk), dim3(MS_THREADS), 0, st, p, hist, d);
+    for (int d = d0; d < (p.u24 ? 2 : 3); ++d) hipLaunchKernelGGL(ms_hist_kernel, dim3(nbk), dim3(MS_THREADS), 0, st, p, hist, d);
     hipLaunchKernelGGL(ms_apply_kernel, dim3(nbk), dim3(MS_THREADS), 0, st, p, (const unsigned*)hist, out, final_mask, base, next_noise,
                        next_hist);
     GPTST_CHECK_LAUNCH();
@@ -447,16 +468,19 @@ int g_ms_force_multi = 0;       // tests: 1 = take the multi-launch path for eve
 
 extern "C" int gptst_mask_force_multi(int on) { g_ms_force_multi = on; return GPTST_OK; }
 
-extern "C" int gptst_mask_random(const float* noise, int M, int k, float* mask, void* ws, int ws_zeroed, void* stream) {
+static int ms_random_impl(const float* noise, int M, int k, float* mask, void* ws, int ws_zeroed, void* stream, int u24) {
     if (!noise || !mask || !ws || M <= 0 || k < 0 || k > M) return GPTST_EARG;
-    MsPlan p{nullptr, nullptr, nullptr, nullptr, noise, nullptr, 0, 0, 0, M, k};
-    if (M <= MSS_MAXM && !g_ms_force_multi) {
+    MsPlan p{nullptr, nullptr, nullptr, nullptr, noise, nullptr, 0, 0, 0, M, k, u24};
+    if (M <= MSS_MAXM && !g_ms_force_multi && !u24) {
         hipLaunchKernelGGL(mss_random_kernel, dim3(1), dim3(MSS_T), 0, (hipStream_t)stream, p, mask);
         GPTST_CHECK_LAUNCH();
         return GPTST_OK;
     }
-    if (!ws_zeroed) hipLaunchKernelGGL(ms_zero_kernel, dim3(6), dim3(256), 0, (hipStream_t)stream, (unsigned*)ws, MS_BLK);
+    if (!ws_zeroed) hipLaunchKernelGGL(ms_zero_kernel, dim3(12), dim3(256), 0, (hipStream_t)stream, (unsigned*)ws, MS_BLK);
     return ms_select(p, (unsigned*)ws, mask, nullptr, 1, (hipStream_t)stream);
+}
+extern "C" int gptst_mask_random(const float* noise, int M, int k, float* mask, void* ws, int ws_zeroed, void* stream) {
+    return ms_random_impl(noise, M, k, mask, ws, ws_zeroed, stream, 0);
 }
 
 extern "C" int gptst_mask_labels(const float* prob, int rows, int HS, int* label, int* counts, void* stream) {
@@ -468,18 +492,18 @@ extern "C" int gptst_mask_labels(const float* prob, int rows, int HS, int* label
     return GPTST_OK;
 }
 
-extern "C" int gptst_mask_adaptive(const int* label, const int* counts, const int* list_c, const int* nums, const float* noise_a,
-                                   const float* noise_r, int ada_all, int M, int HS, int base, float* m_ada, float* m_rnd,
-                                   float* mask, void* ws, int ws_zeroed, void* stream) {
+static int ms_adaptive_impl(const int* label, const int* counts, const int* list_c, const int* nums, const float* noise_a,
+                            const float* noise_r, int ada_all, int M, int HS, int base, float* m_ada, float* m_rnd,
+                            float* mask, void* ws, int ws_zeroed, void* stream, int u24) {
     if (!label || !list_c || !nums || !noise_a || !noise_r || !m_ada || !m_rnd || !mask || !ws || HS > 256) return GPTST_EARG;
-    MsPlan a{label, counts, list_c, nums, noise_a, nullptr, 1, ada_all, HS, M, 0};
-    if (M <= MSS_MAXM && !g_ms_force_multi) {        // counts may be NULL here: the single-workgroup kernel histograms the labels itself
+    MsPlan a{label, counts, list_c, nums, noise_a, nullptr, 1, ada_all, HS, M, 0, u24};
+    if (M <= MSS_MAXM && !g_ms_force_multi && !u24) {        // counts may be NULL here: the single-workgroup kernel histograms the labels itself
         hipLaunchKernelGGL(mss_adaptive_kernel, dim3(1), dim3(MSS_T), 0, (hipStream_t)stream, a, noise_r, counts, m_ada, m_rnd, mask, base);
         GPTST_CHECK_LAUNCH();
         return GPTST_OK;
     }
     unsigned* w = (unsigned*)ws;
-    if (!ws_zeroed) hipLaunchKernelGGL(ms_zero_kernel, dim3(12), dim3(256), 0, (hipStream_t)stream, w, MS_WS_WORDS);   // both blocks + counts
+    if (!ws_zeroed) hipLaunchKernelGGL(ms_zero_kernel, dim3(24), dim3(256), 0, (hipStream_t)stream, w, MS_WS_WORDS);   // both blocks + counts
     if (!counts) {                                         // class histogram from the labels (what gptst_mask_labels would have produced)
         int nb = (M + 8 * 256 - 1) / (8 * 256); if (nb > 128) nb = 128;                      // <= 128 same-address atomics per class
         int* cw = (int*)(w + 2 * MS_BLK);
@@ -489,8 +513,13 @@ extern "C" int gptst_mask_adaptive(const int* label, const int* counts, const in
     // selection A's mask write also histograms digit 0 of selection R (whose keys it gates): R starts at digit 1
     int rc = ms_select(a, w, m_ada, nullptr, base, (hipStream_t)stream, 0, noise_r, w + MS_BLK);           // :386-397
     if (rc) return rc;
-    MsPlan r{label, a.counts, list_c, nums, noise_r, m_ada, 2, ada_all, HS, M, 0};
+    MsPlan r{label, a.counts, list_c, nums, noise_r, m_ada, 2, ada_all, HS, M, 0, u24};
     return ms_select(r, w + MS_BLK, m_rnd, mask, base, (hipStream_t)stream, 1);                            // :399-413
+}
+extern "C" int gptst_mask_adaptive(const int* label, const int* counts, const int* list_c, const int* nums, const float* noise_a,
+                                   const float* noise_r, int ada_all, int M, int HS, int base, float* m_ada, float* m_rnd,
+                                   float* mask, void* ws, int ws_zeroed, void* stream) {
+    return ms_adaptive_impl(label, counts, list_c, nums, noise_a, noise_r, ada_all, M, HS, base, m_ada, m_rnd, mask, ws, ws_zeroed, stream, 0);
 }
 
 // ======================================================================================================================
@@ -757,23 +786,31 @@ static int mu_prepare() {
     return (int)sizeof(MuShared);
 }
 
-// noise on the 2^-24 lattice (see above), M <= 65536: one launch.  GPTST_ESHAPE beyond that size (use gptst_mask_random).
-extern "C" int gptst_mask_random_u24(const float* noise, int M, int k, float* mask, void* stream) {
+// Noise on the 2^-24 lattice (see above).  Up to MSS_MAXM cells: ONE launch of one workgroup (top digits in LDS); beyond: the multi-workgroup
+// radix select above on the integer keys — TWO digit passes per selection instead of three (adaptive phase: 6 launches instead of 8, random
+// phase 3 instead of 4).  gptst_mask_force_multi(2) (tests / A-B): the one-workgroup form up to 65536 cells (measured ~120 us at 65 280 cells
+// against ~35 us: one CU's bandwidth and LDS atomics).  ws / ws_zeroed as gptst_mask_random.
+extern "C" int gptst_mask_random_u24(const float* noise, int M, int k, float* mask, void* ws, int ws_zeroed, void* stream) {
     if (!noise || !mask || M <= 0 || k < 0 || k > M) return GPTST_EARG;
-    if (M > MU_T * MU_CPT) return GPTST_ESHAPE;
-    hipLaunchKernelGGL((mu_mask_kernel<false>), dim3(1), dim3(MU_T), mu_prepare(), (hipStream_t)stream, (const int*)nullptr, (const int*)nullptr,
-                       (const int*)nullptr, noise, (const float*)nullptr, 0, M, 0, 1, k, (float*)nullptr, (float*)nullptr, mask);
-    GPTST_CHECK_LAUNCH();
-    return GPTST_OK;
+    if ((M <= MSS_MAXM && g_ms_force_multi != 1) || (g_ms_force_multi == 2 && M <= MU_T * MU_CPT)) {
+        hipLaunchKernelGGL((mu_mask_kernel<false>), dim3(1), dim3(MU_T), mu_prepare(), (hipStream_t)stream, (const int*)nullptr, (const int*)nullptr,
+                           (const int*)nullptr, noise, (const float*)nullptr, 0, M, 0, 1, k, (float*)nullptr, (float*)nullptr, mask);
+        GPTST_CHECK_LAUNCH();
+        return GPTST_OK;
+    }
+    return ms_random_impl(noise, M, k, mask, ws, ws_zeroed, stream, 1);
 }
 
-// as gptst_mask_adaptive (the class histogram is taken from the labels); m_ada / m_rnd may be NULL.
-extern "C" int gptst_mask_adaptive_u24(const int* label, const int* list_c, const int* nums, const float* noise_a, const float* noise_r,
-                                       int ada_all, int M, int HS, int base, float* m_ada, float* m_rnd, float* mask, void* stream) {
+// as gptst_mask_adaptive (counts may be NULL: the class histogram is taken from the labels); m_ada / m_rnd may be NULL in the one-workgroup form only.
+extern "C" int gptst_mask_adaptive_u24(const int* label, const int* counts, const int* list_c, const int* nums, const float* noise_a,
+                                       const float* noise_r, int ada_all, int M, int HS, int base, float* m_ada, float* m_rnd, float* mask,
+                                       void* ws, int ws_zeroed, void* stream) {
     if (!label || !list_c || !nums || !noise_a || !noise_r || !mask || HS <= 0 || HS > 256 || M <= 0 || base <= 0) return GPTST_EARG;
-    if (M > MU_T * MU_CPT) return GPTST_ESHAPE;
-    hipLaunchKernelGGL((mu_mask_kernel<true>), dim3(1), dim3(MU_T), mu_prepare(), (hipStream_t)stream, label, list_c, nums, noise_a, noise_r, ada_all, M, HS,
-                       base, 0, m_ada, m_rnd, mask);
-    GPTST_CHECK_LAUNCH();
-    return GPTST_OK;
+    if ((M <= MSS_MAXM && g_ms_force_multi != 1) || (g_ms_force_multi == 2 && M <= MU_T * MU_CPT)) {
+        hipLaunchKernelGGL((mu_mask_kernel<true>), dim3(1), dim3(MU_T), mu_prepare(), (hipStream_t)stream, label, list_c, nums, noise_a, noise_r, ada_all,
+                           M, HS, base, 0, m_ada, m_rnd, mask);
+        GPTST_CHECK_LAUNCH();
+        return GPTST_OK;
+    }
+    return ms_adaptive_impl(label, counts, list_c, nums, noise_a, noise_r, ada_all, M, HS, base, m_ada, m_rnd, mask, ws, ws_zeroed, stream, 1);
 }

@@ -727,18 +727,13 @@ def mask_ws_floats():
     return _C.lib().value("gptst_mask_ws_bytes") // 4
 
 
-MASK_U24_MAX = 1 << 16      # cells up to which lattice noise takes the one-launch path (masksel.hip mu_mask_kernel)
-
-
 def mask_random(noise, k, ws=None, u24=False):
-    """u24: every noise value is k * 2^-24 (Philox / torch.rand) — one launch for up to 65536 cells (checked on the device: NaN mask otherwise)."""
+    """u24: every noise value is k * 2^-24 (Philox / torch.rand) — the select runs on the integers with two digit passes instead of three
+    (checked on the device: NaN mask otherwise)."""
     _chk(noise)
     mask = torch.empty_like(noise)
-    if u24 and noise.numel() <= MASK_U24_MAX:
-        _call("gptst_mask_random_u24", _p(noise), noise.numel(), int(k), _p(mask))
-        return mask
-    _call("gptst_mask_random", _p(noise), noise.numel(), int(k), _p(mask), _p(ws if ws is not None else _mask_ws(noise.device)),
-          int(ws is not None))
+    _call("gptst_mask_random_u24" if u24 else "gptst_mask_random", _p(noise), noise.numel(), int(k), _p(mask),
+          _p(ws if ws is not None else _mask_ws(noise.device)), int(ws is not None))
     return mask
 
 
@@ -761,21 +756,14 @@ def mask_labels(prob):
     return label, counts
 
 
-def mask_adaptive(label, counts, list_c, nums, noise_a, noise_r, ada_all, base, ws=None, u24=False, want_parts=True):
-    """-> (m_ada (M), m_rnd (M), mask (M*base)) fp32 {0,1}.  ws: see mask_ws_floats().  u24: lattice noise, see mask_random (counts unused:
-    the launch histograms the labels);  want_parts=False (u24 only): m_ada / m_rnd are not written (None)."""
+def mask_adaptive(label, counts, list_c, nums, noise_a, noise_r, ada_all, base, ws=None, u24=False):
+    """-> (m_ada (M), m_rnd (M), mask (M*base)) fp32 {0,1}.  ws: see mask_ws_floats().  u24: lattice noise, see mask_random."""
     M, HS = label.numel(), list_c.numel()
-    mask = torch.empty(M * base, device=label.device, dtype=torch.float32)
-    if u24 and M <= MASK_U24_MAX:
-        m_ada = torch.empty(M, device=label.device, dtype=torch.float32) if want_parts else None
-        m_rnd = torch.empty_like(m_ada) if want_parts else None
-        _call("gptst_mask_adaptive_u24", _p(label), _p(list_c), _p(nums), _p(noise_a), _p(noise_r), int(ada_all), M, HS, base,
-              _p(m_ada), _p(m_rnd), _p(mask))
-        return m_ada, m_rnd, mask
     m_ada = torch.empty(M, device=label.device, dtype=torch.float32)
     m_rnd = torch.empty_like(m_ada)
-    _call("gptst_mask_adaptive", _p(label), _p(counts), _p(list_c), _p(nums), _p(noise_a), _p(noise_r), int(ada_all), M, HS, base,
-          _p(m_ada), _p(m_rnd), _p(mask), _p(ws if ws is not None else _mask_ws(label.device)), int(ws is not None))
+    mask = torch.empty(M * base, device=label.device, dtype=torch.float32)
+    _call("gptst_mask_adaptive_u24" if u24 else "gptst_mask_adaptive", _p(label), _p(counts), _p(list_c), _p(nums), _p(noise_a), _p(noise_r),
+          int(ada_all), M, HS, base, _p(m_ada), _p(m_rnd), _p(mask), _p(ws if ws is not None else _mask_ws(label.device)), int(ws is not None))
     return m_ada, m_rnd, mask
 
 

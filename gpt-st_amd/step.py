@@ -13,10 +13,10 @@ import torch
 
 from . import engine, ops
 
-# GPTST_MASK_U24=1: mask generation as ONE launch of one workgroup on the 24-bit noise lattice (gptst_mask_*_u24, <= 65536 cells).  Bit-exact, but
-# measured SLOWER at the bench shape: 780 vs 831 steps/s — one CU moves the 1.3 MB of labels / noise / mask at ~16-150 GB/s and its LDS atomics
-# serve 65 k cells per digit, ~120 us against ~45 us for the eight small launches of the multi-workgroup radix select.  Off by default.
-U24 = os.environ.get("GPTST_MASK_U24", "0") == "1"
+# mask generation on the 24-bit noise lattice (gptst_mask_*_u24, r04): the step's Philox noise and torch.rand fixtures are k * 2^-24, so the radix
+# select takes two 12-bit digits on the integers instead of three float-bit digits: 6 launches instead of 8 in the adaptive phase.  (The whole
+# generation as ONE single-workgroup launch was measured too: ~120 us against ~45 us at 65 280 cells — one CU's bandwidth; it serves <= 8192 cells.)
+U24 = os.environ.get("GPTST_MASK_U24", "1") == "1"
 
 
 class PretrainStep:
@@ -187,7 +187,7 @@ class PretrainStep:
             else:
                 label, counts = ops.labels_and_counts(prob, sv_g[4])
                 mask = ops.mask_adaptive(label, counts, self.ctrl[:self.HS], self.ctrl[self.HS:], self.noise_a, self.noise_r,
-                                         a.ada_type == "all", base, ws=self._mask_ws(), u24=U24, want_parts=False)[2]
+                                         a.ada_type == "all", base, ws=self._mask_ws(), u24=U24)[2]
         self.last_mask = mask
         if self.gen_side is not None:
             self.gen_side.join()
@@ -257,7 +257,7 @@ class PretrainStep:
             mask_g = ops.mask_random(self.noise_g, int(Mg * base * a.mask_ratio), ws=self._mask_ws(), u24=U24)
         else:                                              # label_g was gathered by _exchange_labels(); class histogram taken inside
             mask_g = ops.mask_adaptive(self.label_g, None, self.ctrl[:self.HS], self.ctrl[self.HS:], self.noise_a_g,
-                                       self.noise_r_g, a.ada_type == "all", base, ws=self._mask_ws(), u24=U24, want_parts=False)[2]
+                                       self.noise_r_g, a.ada_type == "all", base, ws=self._mask_ws(), u24=U24)[2]
         self.last_mask_global = mask_g
         return self.dp.rows_of(mask_g, M * base)
 

@@ -311,13 +311,13 @@ int gptst_mask_adaptive(const int* label, const int* counts, const int* list_c, 
                         void* ws, int ws_zeroed, void* stream);
 
 /* r04 — mask generation for noise on the 2^-24 lattice (every value k * 2^-24, 0 <= k < 2^24: what the step's Philox draws and torch.rand
- * produce) as ONE launch of one 1024-thread workgroup: two uniform 12-bit radix digits on the integers, the top digit of every cell in LDS.
- * Same results as gptst_mask_random / gptst_mask_adaptive bit for bit (ties at the threshold in index order).  The lattice is CHECKED on the
- * device: any other noise value poisons the whole mask with NaN.  M <= 65536 cells, else GPTST_ESHAPE (use the calls above).
- * gptst_mask_adaptive_u24 takes the class histogram from the labels; m_ada / m_rnd may be NULL. */
-int gptst_mask_random_u24(const float* noise, int M, int k, float* mask, void* stream);
-int gptst_mask_adaptive_u24(const int* label, const int* list_c, const int* nums, const float* noise_a, const float* noise_r,
-                            int ada_all, int M, int HS, int base, float* m_ada, float* m_rnd, float* mask, void* stream);
+ * produce): the radix select runs on the integers k with TWO uniform 12-bit digits instead of three float-bit digits — one launch less per
+ * selection (adaptive phase 6 launches instead of 8); up to 8192 cells the whole generation is ONE launch of one workgroup.  Same results as
+ * gptst_mask_random / gptst_mask_adaptive bit for bit (ties at the threshold in index order).  The lattice is CHECKED on the device: any other
+ * noise value poisons the outputs with NaN.  ws / ws_zeroed / counts as in the calls above; m_ada / m_rnd must be given beyond 8192 cells. */
+int gptst_mask_random_u24(const float* noise, int M, int k, float* mask, void* ws, int ws_zeroed, void* stream);
+int gptst_mask_adaptive_u24(const int* label, const int* counts, const int* list_c, const int* nums, const float* noise_a, const float* noise_r,
+                            int ada_all, int M, int HS, int base, float* m_ada, float* m_rnd, float* mask, void* ws, int ws_zeroed, void* stream);
 
 /* ---- thin projections (small.hip) ------------------------------------------------------------------------
  * lin_in: Y[i,:] = sum_j a'[i,j] W(:,j) + b, a' = mask ? (mask[i,j] ? a[i*lda+j] : fill) : a;  wlayout 0: W[c*J+j], 1: W[j*C+c].

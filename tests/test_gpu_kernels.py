@@ -300,9 +300,12 @@ def test_mask_random_bit_exact(M, ratio, seed):
         with _mask_path(multi):
             got = ops.mask_random(noise.to(dev), int(M * ratio))
         assert torch.equal(got.cpu().to(torch.int64), ref), multi
-    # r04: lattice noise (k * 2^-24, what synth / torch.rand / the step's Philox draw) -> the one-launch path on the integers
-    got = ops.mask_random(noise.to(dev), int(M * ratio), u24=True)
-    assert torch.equal(got.cpu().to(torch.int64), ref), "u24"
+    # r04: lattice noise (k * 2^-24, what synth / torch.rand / the step's Philox draw) -> the select on the integers: two digit passes (multi-
+    # workgroup form; <= 8192 cells: one launch of one workgroup) and (path 2) the one-workgroup form at every size up to 65536 cells
+    for path in (0, 1, 2):
+        with _mask_path(path):
+            got = ops.mask_random(noise.to(dev), int(M * ratio), u24=True)
+        assert torch.equal(got.cpu().to(torch.int64), ref), ("u24", path)
 
 
 class _mask_path:
@@ -338,31 +341,38 @@ def test_mask_random_ties_lowest_index(multi, reps):
                 ref = torch.ones(n)
                 ref[order[:k]] = 0
                 assert torch.equal(got, ref), k
-        if multi == 0:                                         # one-launch lattice path: 0.1 is not k * 2^-24 -> 0.125 (same order, same ties)
-            lat = torch.where(noise == 0.1, torch.tensor(0.125), noise)
-            assert torch.equal(ops.mask_random(lat.to(dev), k, u24=True).cpu(), ref), ("u24", k)
+        lat = torch.where(noise == 0.1, torch.tensor(0.125), noise)     # lattice paths: 0.1 is not k * 2^-24 -> 0.125 (same order, same ties)
+        with _mask_path(multi if multi else 2):                # 1: two digit passes over many workgroups; 2: the one-workgroup form
+            assert torch.equal(ops.mask_random(lat.to(dev), k, u24=True).cpu(), ref), ("u24", multi, k)
 
 
-def test_mask_u24_rejects_noise_off_the_lattice():
+@pytest.mark.parametrize("path", [0, 1, 2])
+def test_mask_u24_rejects_noise_off_the_lattice(path):
     """gptst_mask_*_u24 select on the integers k = noise * 2^24: a value that is not k * 2^-24 (or outside [0,1)) must not be rounded silently —
-    the whole mask comes back NaN; lattice noise with the SAME cells gives a clean {0,1} mask; beyond 65536 cells the general path serves."""
+    the whole mask comes back NaN; lattice noise gives a clean {0,1} mask.  path 0: one workgroup (<= 8192 cells), 1: two digit passes over
+    many workgroups, 2: one workgroup at any size up to 65536."""
     from gptst_amd import ops, synth
     dev = _dev()
-    M = 5000
+    M = 5000 if path == 0 else 40000
     noise = synth.make_noise(M, 21)
     assert torch.equal((noise * 2 ** 24).round() / 2 ** 24, noise) and float(noise.max()) < 1
-    ok = ops.mask_random(noise.to(dev), 1250, u24=True)
-    assert set(ok.unique().tolist()) == {0.0, 1.0}
-    for bad in (0.1, 1.0, -0.25, float("nan")):              # 0.1 is not on the lattice; 1.0 / negative / NaN are outside [0, 1)
-        nz = noise.clone(); nz[1234] = bad
-        assert torch.isnan(ops.mask_random(nz.to(dev), 1250, u24=True)).all(), bad
-    lab = torch.randint(0, 10, (M,), dtype=torch.int32).to(dev)
-    lc = torch.tensor(synth.class_order(10, 1), dtype=torch.int32, device=dev)
-    nums = torch.tensor([600, 650], dtype=torch.int32, device=dev)
-    nz = noise.clone(); nz[77] = 0.25 + 2.0 ** -25            # a float32 below 0.5 with an odd last mantissa bit: not on the 2^-24 lattice
-    assert torch.isnan(ops.mask_adaptive(lab, None, lc, nums, noise.to(dev), nz.to(dev), 1, 1, u24=True)[2]).all()
+    with _mask_path(path):
+        ok = ops.mask_random(noise.to(dev), M // 4, u24=True)
+        assert set(ok.unique().tolist()) == {0.0, 1.0}
+        for bad in (0.1, 1.0, -0.25, float("nan")):              # 0.1 is not on the lattice; 1.0 / negative / NaN are outside [0, 1)
+            nz = noise.clone(); nz[1234] = bad
+            assert torch.isnan(ops.mask_random(nz.to(dev), M // 4, u24=True)).all(), bad
+        lab = torch.randint(0, 10, (M,), dtype=torch.int32).to(dev)
+        lc = torch.tensor(synth.class_order(10, 1), dtype=torch.int32, device=dev)
+        nums = torch.tensor([M // 8, M // 8], dtype=torch.int32, device=dev)
+        for which in (0, 1):
+            nz = noise.clone(); nz[77] = 0.25 + 2.0 ** -25        # a float32 below 0.5 with an odd last mantissa bit: not on the 2^-24 lattice
+            na, nr = (nz, noise) if which == 0 else (noise, nz)
+            assert torch.isnan(ops.mask_adaptive(lab, None, lc, nums, na.to(dev), nr.to(dev), 1, 1, u24=True)[2]).all(), which
+        clean = ops.mask_adaptive(lab, None, lc, nums, noise.to(dev), synth.make_noise(M, 22).to(dev), 1, 1, u24=True)[2]
+        assert set(clean.unique().tolist()) == {0.0, 1.0} and int((clean == 0).sum()) == 2 * (M // 8)
     big = synth.make_noise(70000, 5)
-    assert torch.equal(ops.mask_random(big.to(dev), 17500, u24=True).cpu().long(), O.random_mask(big, 0.25))       # falls back: > 65536 cells
+    assert torch.equal(ops.mask_random(big.to(dev), 17500, u24=True).cpu().long(), O.random_mask(big, 0.25))       # > 65536 cells: the digit passes
 
 
 @pytest.mark.parametrize("ada_all", [1, 0])
@@ -393,13 +403,13 @@ def test_mask_adaptive_bit_exact(ada_all, B, N, HS, frac):
         assert torch.equal(m_rnd.cpu().long(), m_rnd_r)
         assert torch.equal(mask.cpu().long().view(M, base), fin_r.view(M, 1).repeat(1, base))
         assert int((mask.view(M, base)[:, 0] == 0).sum()) == total
-    for base, parts in ((1, True), (2, True), (1, False)):                  # r04: lattice noise -> ONE launch (class histogram inside)
-        m_ada, m_rnd, mask = ops.mask_adaptive(label, None, torch.tensor(list_c, dtype=torch.int32, device=dev),
+    for base, path, cnt in ((1, 0, counts), (2, 1, None), (1, 1, counts), (2, 2, None)):   # r04: lattice noise (0: by size, 1: two digit passes, 2: one workgroup)
+      with _mask_path(path):
+        m_ada, m_rnd, mask = ops.mask_adaptive(label, cnt, torch.tensor(list_c, dtype=torch.int32, device=dev),
                                                torch.tensor([ada, rnd_n], dtype=torch.int32, device=dev), na.to(dev), nr.to(dev),
-                                               ada_all, base, u24=True, want_parts=parts)
-        if parts:
-            assert torch.equal(m_ada.cpu().long(), m_ada_r) and torch.equal(m_rnd.cpu().long(), m_rnd_r)
-        assert torch.equal(mask.cpu().long().view(M, base), fin_r.view(M, 1).repeat(1, base)), "u24"
+                                               ada_all, base, u24=True)
+        assert torch.equal(m_ada.cpu().long(), m_ada_r) and torch.equal(m_rnd.cpu().long(), m_rnd_r), ("u24", path)
+        assert torch.equal(mask.cpu().long().view(M, base), fin_r.view(M, 1).repeat(1, base)), ("u24", path)
 
 
 @pytest.mark.parametrize("ada_all", [1, 0])
@@ -452,11 +462,13 @@ def test_mask_adaptive_ties_and_caller_zeroed_scratch(ada_all):
                 assert torch.equal(m_ada.cpu().long(), m_ada_r), (total, frac, ws is None)
                 assert torch.equal(m_rnd.cpu().long(), m_rnd_r), (total, frac, ws is None)
                 assert torch.equal(mask.cpu().long(), fin_r.view(-1)), (total, frac, ws is None)
-        m_ada, m_rnd, mask = ops.mask_adaptive(label, None, torch.tensor(list_c, dtype=torch.int32, device=dev),
-                                               torch.tensor([ada, rnd_n], dtype=torch.int32, device=dev), na.to(dev), nr.to(dev),
-                                               ada_all, 1, u24=True)                # the one-launch lattice path: the same tie rule
-        assert torch.equal(m_ada.cpu().long(), m_ada_r) and torch.equal(m_rnd.cpu().long(), m_rnd_r), ("u24", total, frac)
-        assert torch.equal(mask.cpu().long(), fin_r.view(-1)), ("u24", total, frac)
+        for path, ws in ((1, None), (1, torch.zeros(words, device=dev)), (2, None)):        # the lattice paths: the same tie rule
+            with _mask_path(path):
+                m_ada, m_rnd, mask = ops.mask_adaptive(label, None, torch.tensor(list_c, dtype=torch.int32, device=dev),
+                                                       torch.tensor([ada, rnd_n], dtype=torch.int32, device=dev), na.to(dev), nr.to(dev),
+                                                       ada_all, 1, ws=ws, u24=True)
+            assert torch.equal(m_ada.cpu().long(), m_ada_r) and torch.equal(m_rnd.cpu().long(), m_rnd_r), ("u24", path, total, frac)
+            assert torch.equal(mask.cpu().long(), fin_r.view(-1)), ("u24", path, total, frac)
     noise = synth.make_noise(M, 3)
     ref = O.random_mask(noise, 0.25)
     with _mask_path(1):

@@ -1,7 +1,7 @@
 #!/bin/bash
 # usage (GPU box, repo root): tools/results_table.sh > gpurun_out/table.txt  -- the rows of BASELINE.md section 7 from one box
 cd $GRAFT_REPO_ROOT
-b() { python bench.py --no-cpu-baseline --no-kernel-timing "$@" 2>/dev/null | tail -1 | python -c "import json,sys; d=json.loads(sys.stdin.read()); print('%8.1f steps/s  %.3f ms  rnd %s' % (d['value'], d['ms_per_step'], d.get('steps_per_s_random_mask_phase')))"; }
+b() { python bench.py --no-cpu-baseline --no-kernel-timing --no-module-path "$@" 2>/dev/null | tail -1 | python -c "import json,sys; d=json.loads(sys.stdin.read()); print('%8.1f steps/s  %.3f ms  rnd %s' % (d['value'], d['ms_per_step'], d.get('steps_per_s_random_mask_phase')))"; }
 echo "c2 default:      $(b --steps 200 --warmup 20)"
 echo "c2 deterministic: $(GPTST_DETERMINISTIC=1 b --steps 200 --warmup 20)"
 echo "c2 shard nodes w1: $(b --steps 200 --warmup 20 --shard nodes)"
