@@ -1134,6 +1134,12 @@ def test_mask_generation_over_a_global_batch(W):
                                            torch.tensor([ada, total - ada], dtype=torch.int32, device=dev), na.to(dev), nr.to(dev), 1, 1)
     assert torch.equal(m_ada.cpu().long(), m_ada_r) and torch.equal(m_rnd.cpu().long(), m_rnd_r)
     assert torch.equal(mask.cpu().long(), fin_r.view(-1))
+    # r04: what the data-parallel step calls — the two-digit select on the 24-bit noise lattice at the global size
+    assert torch.equal(ops.mask_random(noise.to(dev), int(M * 0.25), u24=True).cpu().to(torch.int64), O.random_mask(noise, 0.25))
+    m_ada, m_rnd, mask = ops.mask_adaptive(label_ref.to(torch.int32).to(dev), None, torch.tensor(list_c, dtype=torch.int32, device=dev),
+                                           torch.tensor([ada, total - ada], dtype=torch.int32, device=dev), na.to(dev), nr.to(dev), 1, 1, u24=True)
+    assert torch.equal(m_ada.cpu().long(), m_ada_r) and torch.equal(m_rnd.cpu().long(), m_rnd_r)
+    assert torch.equal(mask.cpu().long(), fin_r.view(-1))
 
 
 @pytest.mark.parametrize("occ6", [0, 1, 2], ids=["fwd4", "fwd3", "fwd3occ6"])
