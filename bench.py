@@ -321,6 +321,8 @@ def main():
         dp = DataParallel(os.environ.get("GPTST_DIST_BACKEND", "nccl"),   # nccl = RCCL over xGMI; gloo only to exercise the path on one GPU
                           native=bool(a.native_comm) and a.shard == "batch")
 
+    if dp is not None and a.shard == "batch" and a.native_comm and dp.native is None:
+        a.native_comm = False                                      # the C-ABI communicator could not be set up on some rank (dist.DataParallel): torch.distributed
     over = {}
     if a.nodes:
         over["num_nodes"] = a.nodes

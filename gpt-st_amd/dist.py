@@ -33,7 +33,30 @@ class DataParallel:
             os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
             os.environ.setdefault("MASTER_PORT", "29511")
             dist.init_process_group(backend=backend, rank=self.rank, world_size=self.world)
-        self.native = NativeComm(rank=self.rank, world=self.world) if native else None
+        self.native = None
+        if native:
+            # The C-ABI communicator binds RCCL at run time.  Whether it can (library found, symbols present) is probed on EVERY rank and the
+            # answer is agreed on with one all-reduce BEFORE the unique id travels: a rank that cannot must not leave the others waiting in
+            # the broadcast / ncclCommInitRank — the job then runs its collectives through torch.distributed between graph replays instead.
+            import ctypes
+            import sys
+            from . import _C
+            ok = 1
+            try:
+                _C.lib().call("gptst_comm_unique_id", (ctypes.c_char * 128)())
+            except Exception as e:                                    # noqa: BLE001
+                ok, why = 0, "%s: %s" % (type(e).__name__, str(e).splitlines()[0][:160] if str(e) else "")
+            if self.world > 1:
+                t = torch.tensor([ok], dtype=torch.int32, device="cuda" if backend == "nccl" else "cpu")
+                dist.all_reduce(t, op=dist.ReduceOp.MIN)
+                agreed = int(t.item())
+            else:
+                agreed = ok
+            if agreed:
+                self.native = NativeComm(rank=self.rank, world=self.world)
+            elif self.rank == 0 or not ok:
+                print("gpt-st_amd: the C-ABI RCCL communicator is not available%s -> torch.distributed collectives between graph replays"
+                      % ((" here (" + why + ")") if not ok else " on another rank"), file=sys.stderr)
         self._slots = None
 
     @property
