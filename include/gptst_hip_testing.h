@@ -17,7 +17,8 @@ extern "C" {
  * workgroups of cap_route_fwd4_kernel (experiment); 23: 1 = cross-time backward as a replicated prologue of
  * cap_route_bwd2_kernel instead of a role.  The Python binding applies GPTST_TUNE="id=value,..." from the environment. */
 int gptst_tune(int id, int value);
-/* mask selection: 1 = the multi-launch radix select for every size (the single-workgroup launch serves M <= 2^18 otherwise) */
+/* mask selection: 1 = the multi-launch radix select for every size (a single-workgroup launch serves M <= 8192 cells otherwise);
+ * 2 (gptst_mask_*_u24 only) = the one-workgroup lattice kernel for every size up to 65536 cells.  Process-wide, not thread-local. */
 int gptst_mask_force_multi(int on);
 #if defined(__GNUC__)
 #pragma GCC visibility pop
