@@ -7,6 +7,7 @@
 //   LeakyReLU, stored as whole rows.  Replaces tmix_kernel + apply_kernel<TIME> (11 + 20 us -> one launch) and the R round trip.
 #include "mfma_tile.h"
 #include "wgrad64.h"
+GPTST_STAMP_TABLES(hypertem)      // -DGPTST_STAMPS: per-phase / per-workgroup wall-clock stamps of the pair launch (tools/phase_stamps.py ht_bwd_pair)
 
 #define HT_T 12
 #ifdef GPTST_DEBUG
@@ -493,6 +494,7 @@ __device__ __forceinline__ void hypertem_bwd_stage(const float* __restrict__ dOu
         }
         __syncthreads();
         SB();
+        if (PAIR != 0 && grp == 0) GPTST_STAMP(PAIR == 2 ? 6 : 1);
         const int t = 4 * grp + wave;
         if (HT_DBG(dbg) & 32) continue;
         const size_t g = (size_t)b * HT_T + t;
@@ -532,6 +534,7 @@ __device__ __forceinline__ void hypertem_bwd_stage(const float* __restrict__ dOu
             st4(dt + j * P + it * 16 + kk * 4, make_float4(acc[it][0], acc[it][1], acc[it][2], acc[it][3]));
     }
     __syncthreads();
+    if (PAIR != 0) GPTST_STAMP(PAIR == 2 ? 7 : 2);
     // X operands of the dG phase (nodes wave, wave+4, ...): requested now, consumed after the dX phase
     float4 xg[NT / 4][C / 16];
 #pragma unroll
@@ -567,6 +570,7 @@ __device__ __forceinline__ void hypertem_bwd_stage(const float* __restrict__ dOu
         }
     }
     SB();
+    if (PAIR != 0) GPTST_STAMP(PAIR == 2 ? 8 : 3);
     // ---- dG_n[t,u] += sum_c dR_t[n,c] X_u[n,c]:  A[i=t][kk=c] = dR (LDS), B[kk=c][j=u] = X (registers) ----
 #pragma unroll
     for (int i = 0; i < NT / 4; ++i) {
@@ -588,6 +592,7 @@ __device__ __forceinline__ void hypertem_bwd_stage(const float* __restrict__ dOu
             if (t < HT_T && u < HT_T && !(HT_DBG(dbg) & 2)) dG[((size_t)b * N + n) * 144 + t * HT_T + u] = acc[r];   // partial of sample b
         }
     }
+    if (PAIR != 0) GPTST_STAMP(PAIR == 2 ? 9 : 4);
 }
 
 template <bool HASY, bool PREMUL>
@@ -784,7 +789,6 @@ extern "C" int gptst_hypertem_bwd_wgrad(const float* dOut, const float* Y, const
 // needs dPre_L of ALL nodes of a (b,t): its workgroups sit at the END of the grid [slab | wgrad L+1 | wgrad L] and wait for the sample's slab
 // workgroups to have published stage 1 (write-through stores + one counter per sample): every wait points to a lower block index, so with
 // blocks dispatched in index order nothing waits on a workgroup that is not yet on the chip; the wait is bounded and ends in NaN rows of dWb0.
-GPTST_STAMP_TABLES(hypertem)
 struct HtPairArgs {
     const float* dOut1; const float* X1; const float* G1; const float* Wbt1; const float* R1;
     const float* X0; const float* G0; const float* Wbt0; const float* R0;
@@ -801,13 +805,12 @@ __global__ __launch_bounds__(256, 2) void hypertem_bwd_pair_kernel(HtPairArgs a,
         float4 dp[HT_T];
         GPTST_WG_BEGIN(); GPTST_STAMP(0);
         hypertem_bwd_stage<false, true, 1>(a.dOut1, nullptr, a.X1, a.G1, a.Wbt1, a.dXmid, nullptr, a.dG1, N, B, 0, b, tile, smem, dp);
-        GPTST_STAMP(1);
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");             // this wave's write-through stores of dPre_L have left ...
         __syncthreads();                                              // ... (all waves; and the dG phase is done with the LDS slab)
         if (threadIdx.x == 0) __hip_atomic_fetch_add(a.cnt + b, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        GPTST_STAMP(2);
+        GPTST_STAMP(5);
         hypertem_bwd_stage<false, true, 2>(nullptr, nullptr, a.X0, a.G0, a.Wbt0, a.dX0, nullptr, a.dG0, N, B, 0, b, tile, smem, dp);
-        GPTST_STAMP(3); GPTST_WG_END();
+        GPTST_WG_END();
         return;
     }
     GPTST_WG_BEGIN();

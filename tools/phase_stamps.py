@@ -44,8 +44,8 @@ def _pair_case():
 
 CASES = {
     "ht_bwd_pair": ("hypertem", _pair_case(),
-                    ["stage 1: layer L+1 on the slab (loads, dR, dX -> dPre_L written through, dG)", "drain the write-through stores, count up",
-                     "stage 2: layer L on the slab"]),
+                    ["stage 1: loads -> first time-step group staged in LDS", "stage 1: dR = dPre W^T (3 groups of 4 time steps, MFMA)", "stage 1: dX (VALU) + write-through stores",
+                     "stage 1: dG (MFMA)", "drain the write-through stores, count up", "stage 2: sign / graph / W loads -> first group staged", "stage 2: dR", "stage 2: dX + stores", "stage 2: dG"]),
     "encin_fwd": ("encin", lambda: ops.encin_ht1_fwd(src3, 1, mask1, -1.5, w_in, b_in, Gt, Wbt, bbt),
                   ["w W_bt, bi W_bt partials", "alpha / beta / m per node (G rows, flow, mask) + barrier", "rows out"]),
     "encin_bwd": ("encin", lambda: ops.encin_ht1_bwd(dO, src3, mask1, -1.5, w_in, b_in, Wbt, ab_ei, wv_ei),
