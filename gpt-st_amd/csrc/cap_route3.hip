@@ -287,14 +287,11 @@ template <int TPW>
 __global__ __launch_bounds__(64 * CR4_NW, 4) void cap_route_fwd4_kernel(const float* __restrict__ X, const float* __restrict__ Wp,
                                                                         const float* __restrict__ bp, const float* __restrict__ dadj,
                                                                         float* __restrict__ c_out, float* __restrict__ s_out, int N, int HS, int R,
-                                                                        int redw, int lag_from, int lag) {
+                                                                        int redw) {
     constexpr int C = 64, P = CR3_P, NTH = 64 * CR4_NW;
-    // Workgroups lag_from .. are the SECOND residents of their CUs (dispatch order fills every CU once before any gets a second workgroup) and
-    // would run in lock step with the first: MFMA phases on top of each other, latency phases side by side.  A start lag of a few microseconds
-    // puts one's capsule GEMM under the other's routing passes.  Speed only: nothing depends on the placement assumption.
+    // (A start lag for the second-resident workgroups of a CU — blocks >= 256, to put one's capsule GEMM under the other's routing passes — was
+    //  measured in r04 here and in the hyperTem pair launch: no gain at any lag, removed.)
     CR4_WG_BEGIN();
-    if ((int)blockIdx.x >= lag_from)
-        for (int i = 0; i < lag; ++i) __builtin_amdgcn_s_sleep(32);
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const int ntiles = (N + 15) >> 4;
     float* Ps = smem;                          // [16 ntiles][P]   capsule rows
@@ -518,7 +515,6 @@ __global__ __launch_bounds__(64 * CR4_NW, 4) void cap_route_fwd4_kernel(const fl
 }
 
 thread_local int g_cap_route_v2 = 0;          // gptst_tune(20, 1): cap_route_fwd2_kernel (second generation) also where this kernel serves
-thread_local int g_cap_route_lag = 0;         // gptst_tune(22, n): start lag of the second-resident workgroups in units of s_sleep(32) (~1 us)
 thread_local int g_cap_route_occ6 = 0;        // gptst_tune(21, v): 0 = cap_route_fwd4_kernel (8 waves, two workgroups per CU); 1 / 2 = cap_route_fwd3_kernel
                                               // (one wave per tile) with <= 128 / <= 80 VGPRs (the latter spills)
 
@@ -533,10 +529,10 @@ GPTST_INTERNAL int gptst_cap_route_fwd3(const float* X, const float* Wp, const f
         static size_t cur4[2] = {0, 0};
         if (NW <= CR4_NW) {
             if (smem4 > cur4[0]) { (void)hipFuncSetAttribute((const void*)cap_route_fwd4_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem4); cur4[0] = smem4; }
-            hipLaunchKernelGGL((cap_route_fwd4_kernel<1>), dim3(BT), dim3(64 * CR4_NW), smem4, (hipStream_t)stream, X, Wp, bp, dadj, c_out, s_out, N, HS, R, redw, 256, g_cap_route_lag);
+            hipLaunchKernelGGL((cap_route_fwd4_kernel<1>), dim3(BT), dim3(64 * CR4_NW), smem4, (hipStream_t)stream, X, Wp, bp, dadj, c_out, s_out, N, HS, R, redw);
         } else {
             if (smem4 > cur4[1]) { (void)hipFuncSetAttribute((const void*)cap_route_fwd4_kernel<2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem4); cur4[1] = smem4; }
-            hipLaunchKernelGGL((cap_route_fwd4_kernel<2>), dim3(BT), dim3(64 * CR4_NW), smem4, (hipStream_t)stream, X, Wp, bp, dadj, c_out, s_out, N, HS, R, redw, 256, g_cap_route_lag);
+            hipLaunchKernelGGL((cap_route_fwd4_kernel<2>), dim3(BT), dim3(64 * CR4_NW), smem4, (hipStream_t)stream, X, Wp, bp, dadj, c_out, s_out, N, HS, R, redw);
         }
         GPTST_CHECK_LAUNCH();
         return GPTST_OK;

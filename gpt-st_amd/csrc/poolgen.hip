@@ -442,13 +442,11 @@ extern thread_local int g_ht_fwd12;
 extern thread_local int g_tl_mfma;
 extern thread_local int g_cap_route_v2;
 extern thread_local int g_cap_route_occ6;
-extern thread_local int g_cap_route_lag;
 extern thread_local int g_cap_bwd_noroles;
 extern "C" int gptst_tune(int id, int value) {
     if (id == 15) g_tl_mfma = value;
     if (id == 20) g_cap_route_v2 = value;
     if (id == 21) g_cap_route_occ6 = value;
-    if (id == 22) g_cap_route_lag = value;
     if (id == 23) g_cap_bwd_noroles = value;
     if (id == 19) g_pg_sort = value;
     if (id == 12) g_ht_fwd12 = value;

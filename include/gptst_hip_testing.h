@@ -13,8 +13,7 @@ extern "C" {
  * count of the NODE / TIME weight gradient; 3: 1 = first-generation (LDS-staged) apply for C = 64; 4: tiles per wave of apply64 / apply128;
  * 6: workgroups of the loss-head kernels; 7 / 8: 1 = first-generation weight gradient / apply for C = 128; 10: 0 = VALU forward of the
  * pool jobs instead of the (bit-identical) MFMA one; 20: 1 = second-generation cap routing forward (cap_route_fwd2_kernel); 21: cap routing
- * forward variant (0 = cap_route_fwd4_kernel, 1 / 2 = cap_route_fwd3_kernel at <= 128 / <= 80 VGPRs); 22: start lag of second-resident
- * workgroups of cap_route_fwd4_kernel (experiment); 23: 1 = cross-time backward as a replicated prologue of
+ * forward variant (0 = cap_route_fwd4_kernel, 1 / 2 = cap_route_fwd3_kernel at <= 128 / <= 80 VGPRs); 23: 1 = cross-time backward as a replicated prologue of
  * cap_route_bwd2_kernel instead of a role.  The Python binding applies GPTST_TUNE="id=value,..." from the environment. */
 int gptst_tune(int id, int value);
 /* mask selection: 1 = the multi-launch radix select for every size (a single-workgroup launch serves M <= 8192 cells otherwise);

@@ -19,8 +19,7 @@ int main(int argc, char** argv) {
     hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
     {   // cap_route_fwd4_kernel: schedule of the workgroups (start / end per workgroup, CU it ran on)
         g_cap_route_occ6 = 0;
-        for (int lag = 0; lag <= 8; lag += 8) {
-            g_cap_route_lag = lag;
+        for (int lag = 0; lag <= 0; ++lag) {      // (the start-lag variant of r04 is gone from the kernel: profiles/r04_cap_route3_phases.txt holds its runs)
             for (int i = 0; i < 5; ++i) gptst_cap_route_fwd3(X, Wp, bp, dadj, c, s, BT, N, C, HS, R, nullptr);
             CK(hipDeviceSynchronize());
             CK(hipEventRecord(e0));
@@ -48,7 +47,6 @@ int main(int argc, char** argv) {
                 for (int i = 1; i <= 13; ++i) printf("     %-52s %6.2f us\n", n4[i - 1], (t4[k][i] - t4[k][i - 1]) * 0.01);
             }
         }
-        g_cap_route_lag = 0;
     }
     for (int occ6 = 1; occ6 < 3; ++occ6) {
         g_cap_route_occ6 = occ6;
