@@ -96,15 +96,20 @@ __device__ void ms_prefix(const unsigned* __restrict__ hist, int ndig, int k, un
         const int per = nb / MS_THREADS;
         unsigned loc = 0u;
         for (int j = 0; j < per; ++j) loc += h[nb - 1 - (threadIdx.x * per + j)];
-        sh[threadIdx.x] = loc;
-        __syncthreads();
-        for (int off = 1; off < MS_THREADS; off <<= 1) {
-            const unsigned v = threadIdx.x >= off ? sh[threadIdx.x - off] : 0u;
+        // exclusive prefix over the 256 threads: shuffles inside a wave + the four wave totals through LDS (two barriers; the Hillis-Steele
+        // scan over LDS this replaces took sixteen — ~1.5 us in each of a step's six selection launches)
+        unsigned inc = loc;
+        {
+            const int lane = threadIdx.x & 63;
+#pragma unroll
+            for (int off = 1; off < 64; off <<= 1) { const unsigned v = __shfl_up(inc, off, 64); if (lane >= off) inc += v; }
+            __syncthreads();                                         // (sh of an earlier use has been read)
+            if (lane == 63) sh[threadIdx.x >> 6] = inc;
             __syncthreads();
-            sh[threadIdx.x] += v;
-            __syncthreads();
+#pragma unroll
+            for (int w = 0; w < MS_THREADS / 64; ++w) if (w < (int)(threadIdx.x >> 6)) inc += sh[w];
         }
-        const unsigned before = sh[threadIdx.x] - loc;           // keys in bins above this thread's range
+        const unsigned before = inc - loc;                       // keys in bins above this thread's range
         if (before < remaining && before + loc >= remaining) {   // the threshold bin is in this thread's range (exactly one thread)
             unsigned cum = before;
             for (int j = 0; j < per; ++j) {
