@@ -142,6 +142,14 @@ def time_kernels(stepper, epoch, nsteps=3):
     return {k: dict(total_s=v[0] / nsteps, launches=v[1] // nsteps, avg_s=v[0] / v[1], bytes=v[2]) for k, v in agg.items()}
 
 
+def _handoff_timeouts():
+    import ctypes
+    from gptst_amd import _C
+    n = ctypes.c_int(0)
+    _C.lib().call("gptst_handoff_timeouts", ctypes.byref(n))
+    return n.value
+
+
 def retime_kernel(name, tag, reps=50):
     """Average duration of ONE launch of (name, tag): its recorded call is enqueued `reps` times back to back on the launch
     stream, bracketed by one HIP event pair (an event pair around a single launch also counts the ~3-5 us dispatch gap, which
@@ -470,6 +478,7 @@ def main():
         "median_value": (sorted(rep_rates)[len(rep_rates) // 2] * b32_per_step) if len(rep_rates) > 1 else None,
         "steps_per_s_random_mask_phase": rnd_rate,
         "last_loss": loss[0],
+        "handoff_timeouts": _handoff_timeouts(),     # in-launch hand-off waits that expired on rank 0 (0 in a healthy run; an expiry turns the loss NaN)
         # evidence that the job's collectives span the ranks it was started with, and how the step is enqueued
         "rccl_ranks": (group.comm.count() if (a.shard == "nodes" and a.native_comm) else (dp.rccl_ranks() if dp is not None else None)),
         "comm": (None if (dp is None and world == 1) else

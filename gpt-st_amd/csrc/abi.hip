@@ -7,3 +7,15 @@ extern "C" int gptst_abi_version(void) { return GPTST_ABI_VERSION; }
 thread_local int g_deterministic = 0;
 // 1: bit-reproducible steps (single-owner reductions in a fixed order where the default path uses float atomics); thread-local.
 extern "C" int gptst_set_deterministic(int on) { g_deterministic = on ? 1 : 0; return GPTST_OK; }
+
+// number of bounded in-launch hand-off waits that expired since the library was loaded (cap_route_bwd2_kernel's roles, hypertem_bwd_pair_kernel's
+// lower weight-gradient role): 0 in a healthy run.  An expiry poisons that launch's output with NaN; this tells such a NaN from numerical trouble.
+GPTST_INTERNAL int gptst_handoff_lost_capmfma(unsigned* out);
+GPTST_INTERNAL int gptst_handoff_lost_hypertem(unsigned* out);
+extern "C" int gptst_handoff_timeouts(int* out) {
+    if (!out) return GPTST_EARG;
+    unsigned a = 0u, b = 0u;
+    if (gptst_handoff_lost_capmfma(&a) || gptst_handoff_lost_hypertem(&b)) return -5;     // (hipMemcpyFromSymbol failed)
+    *out = (int)(a + b);
+    return GPTST_OK;
+}

@@ -19,6 +19,7 @@ static constexpr int g_cap_dbg = 0;
 #endif
 
 GPTST_STAMP_TABLES(capmfma)
+GPTST_HANDOFF_COUNTER(capmfma)
 
 #define CM_NT 512
 #define CM_NW (CM_NT / 64)
@@ -682,7 +683,7 @@ __global__ __launch_bounds__(CM_NT, 4) void cap_route_bwd2_kernel(const float* _
     // T times and sat IN FRONT of each workgroup's chain (8-13 us of its 27-31, tools/phase_stamps.py).  In the role form the first nB workgroups
     // do it once per sample and publish dS (write-through stores, then one flag per sample), while the B*T routing workgroups rebuild their
     // capsule tile first — that GEMM does not depend on dS — and pick dS up behind it.  All nB + B*T workgroups are resident together (two per
-    // CU, checked by the launcher); the wait is bounded (0.25 s wall clock, gptst_wait_ge): on expiry dS is poisoned with NaN, so a lost hand-off ends the run loudly (NaN
+    // CU, checked by the launcher); the wait is bounded (2 s wall clock, gptst_wait_ge): on expiry dS is poisoned with NaN, so a lost hand-off ends the run loudly (NaN
     // loss / gradient norm) instead of hanging the GPU or training on a wrong gradient.  A separate instantiation: with both forms in one
     // kernel the register allocator spilled 100 registers.
     unsigned* s_ok = reinterpret_cast<unsigned*>(qq + NR);
@@ -708,7 +709,7 @@ __global__ __launch_bounds__(CM_NT, 4) void cap_route_bwd2_kernel(const float* _
     if (ROLES && blk < cx.nB) {                          // cross-time role: workgroup r = (sample r / CX_SPLIT, time steps of part r % CX_SPLIT)
         constexpr int TS = 12 / CX_SPLIT;
         if constexpr (ROLES == 2) {
-            if (tid == 0) *s_ok = gptst_wait_ge(cx.flags + cx.nB + blk / CX_SPLIT, (unsigned)cx.T);
+            if (tid == 0) *s_ok = gptst_wait_ge(cx.flags + cx.nB + blk / CX_SPLIT, (unsigned)cx.T, &g_handoff_lost_capmfma);
             __syncthreads();
             if (*s_ok == 0u) return;                     // no flag: the sample's routing workgroups time out and poison dS
             __syncthreads();
@@ -830,8 +831,8 @@ __global__ __launch_bounds__(CM_NT, 4) void cap_route_bwd2_kernel(const float* _
     }
     auto poll = [&]() {                                              // ONE lane polls the flags it depends on, relaxed, bounded
         if (tid == 0) {
-            bool got = gptst_wait_ge(cx.flags + (bt / cx.T) * CX_SPLIT + (bt % cx.T) / (12 / CX_SPLIT), 1u);
-            if (ROLES == 2) got = got && gptst_wait_ge(cx.flags + cx.nB + cx.B + bt, 1u);
+            bool got = gptst_wait_ge(cx.flags + (bt / cx.T) * CX_SPLIT + (bt % cx.T) / (12 / CX_SPLIT), 1u, &g_handoff_lost_capmfma);
+            if (ROLES == 2) got = got && gptst_wait_ge(cx.flags + cx.nB + cx.B + bt, 1u, &g_handoff_lost_capmfma);
             *s_ok = got ? 1u : 0u;
         }
     };

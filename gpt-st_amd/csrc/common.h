@@ -78,10 +78,10 @@ __device__ __forceinline__ float ld_agent(const float* p) { return __hip_atomic_
 // follows its stores with `s_waitcnt vmcnt(0)` + __syncthreads() and one relaxed agent-scope flag store (MI355X_MICROARCH.md, inter-workgroup
 // visibility); the consumer polls the flag with ONE lane, relaxed, BOUNDED, then loads with ld4_sc1.
 // Bounded wait of ONE lane for a hand-off word written by another workgroup of the same launch: relaxed agent-scope polls, s_sleep between
-// them, and a WALL-CLOCK bound (0.25 s of the 100 MHz counter) — a spin COUNT is not a time: when another process shares the GPU its time
+// them, and a WALL-CLOCK bound (2 s of the 100 MHz counter) — a spin COUNT is not a time: when another process shares the GPU its time
 // slices stall the producer while the consumer's polls keep counting (4000 polls expired about once in four runs of the two-ranks-on-one-GPU
 // test).  false = the hand-off is lost: the caller poisons its output with NaN, so the run ends loudly instead of hanging the GPU.
-__device__ __forceinline__ bool gptst_wait_ge(const unsigned* p, unsigned want) {
+__device__ __forceinline__ bool gptst_wait_ge(const unsigned* p, unsigned want, unsigned* lost) {
     const long long t0 = wall_clock64();
     for (;;) {
 #pragma unroll 1
@@ -89,9 +89,16 @@ __device__ __forceinline__ bool gptst_wait_ge(const unsigned* p, unsigned want) 
             if (__hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= want) return true;
             __builtin_amdgcn_s_sleep(8);
         }
-        if (wall_clock64() - t0 > 25000000LL) return false;
+        if (wall_clock64() - t0 > 200000000LL) { atomicAdd(lost, 1u); return false; }      // 2 s
     }
 }
+// Every translation unit with such waits counts its expiries (a __device__ word; gptst_handoff_timeouts() adds them up for the host): a NaN loss
+// can then be told from numerical trouble, and a run without NaN can still prove that no wait ever expired.
+#define GPTST_HANDOFF_COUNTER(unit)                                                                  \
+    __device__ unsigned g_handoff_lost_##unit = 0u;                                                  \
+    GPTST_INTERNAL int gptst_handoff_lost_##unit(unsigned* out) {                                    \
+        return hipMemcpyFromSymbol(out, HIP_SYMBOL(g_handoff_lost_##unit), sizeof(unsigned)) == hipSuccess ? 0 : 1;   \
+    }
 typedef int gptst_i32x4 __attribute__((ext_vector_type(4)));
 typedef float gptst_f32x4 __attribute__((ext_vector_type(4)));
 __device__ __forceinline__ void st4_sc1(__amdgpu_buffer_rsrc_t rs, int off, float4 v) {

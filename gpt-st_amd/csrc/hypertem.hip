@@ -7,7 +7,8 @@
 //   LeakyReLU, stored as whole rows.  Replaces tmix_kernel + apply_kernel<TIME> (11 + 20 us -> one launch) and the R round trip.
 #include "mfma_tile.h"
 #include "wgrad64.h"
-GPTST_STAMP_TABLES(hypertem)      // -DGPTST_STAMPS: per-phase / per-workgroup wall-clock stamps of the pair launch (tools/phase_stamps.py ht_bwd_pair)
+GPTST_STAMP_TABLES(hypertem)
+GPTST_HANDOFF_COUNTER(hypertem)      // -DGPTST_STAMPS: per-phase / per-workgroup wall-clock stamps of the pair launch (tools/phase_stamps.py ht_bwd_pair)
 
 #define HT_T 12
 #ifdef GPTST_DEBUG
@@ -824,7 +825,7 @@ __global__ __launch_bounds__(256, 2) void hypertem_bwd_pair_kernel(HtPairArgs a,
     w -= nW;
     const int g = w % rm.G, sp = w / rm.G;
     unsigned* s_ok = reinterpret_cast<unsigned*>(smem);
-    if (threadIdx.x == 0) *s_ok = gptst_wait_ge(a.cnt + g / HT_T, (unsigned)ntiles) ? 1u : 0u;
+    if (threadIdx.x == 0) *s_ok = gptst_wait_ge(a.cnt + g / HT_T, (unsigned)ntiles, &g_handoff_lost_hypertem) ? 1u : 0u;
     __syncthreads();
     const bool ok = *s_ok != 0u;
     __syncthreads();

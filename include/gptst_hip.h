@@ -32,6 +32,10 @@ int gptst_abi_version(void);
  * weight gradients of gptst_timefeat_jobs) run as single-owner kernels with a fixed summation order (slower).  Everything else is
  * order-fixed by construction.  Thread-local. */
 int gptst_set_deterministic(int on);
+/* Number of bounded in-launch hand-off waits that expired since the library was loaded (the roles of gptst_cap_cross_route_bwd /
+ * gptst_cap_rec_cross_route_bwd, the lower weight-gradient role of gptst_hypertem_bwd_pair: a consumer workgroup waits at most 2 s of wall clock
+ * for its producer and poisons its output with NaN on expiry).  0 in a healthy run; lets a NaN loss be told from numerical trouble.  Synchronises. */
+int gptst_handoff_timeouts(int* out);
 
 /* ---- embedding-conditioned parameter generation (poolgen.hip) -----------------------------------------
  * out[r,:] = sum_k emb[r,k] * pool[k,:]   r < R, k < K <= 16.  Optional second problem (pool2/out2/cols2) shares emb.

@@ -28,6 +28,7 @@ def test_bench_two_ranks(extra, scaling, par):
     out = _run(extra, 29610 + len(extra) * 7 + os.getpid() % 50)
     assert out["n_gpus"] == 2 and out["scaling"] == scaling and out["config"]["parallelism"] == par
     assert out["value"] > 0 and out["steps"] == 4 and out["higher_is_better"] is True
+    assert out["handoff_timeouts"] == 0, "a bounded in-launch hand-off wait expired (two processes share this GPU)"
     assert out["last_loss"] == out["last_loss"] and out["last_loss"] > 0          # finite
 
 
