@@ -62,26 +62,7 @@ def main():
     if dp is not None:
         dp.broadcast_(model.flat)
 
-    def batches(epoch):
-        """This rank's batches of one epoch: shuffle=True, drop_last=False (lib/dataloader.py:152); under data parallelism every
-        rank draws the same permutation and takes every world-th batch (all ranks see the same number of equally sized batches)."""
-        full = train.n // args.batch_size                                        # batches of the full size
-        usable = full if dp is None else (full // dp.world) * dp.world           # DP: whole groups of `world` full batches
-        if dp is None:
-            for x in train.iter_x():
-                yield x.contiguous()                                             # incl. the ragged last batch
-        else:                                     # only this rank's batches are gathered (the permutation itself is drawn by every rank)
-            for x in train.iter_x(rank=dp.rank, world=dp.world, limit=usable):
-                yield x.contiguous()
-            # the tail of the epoch is KEPT (r04; it was dropped): the full batches beyond the last whole group, then the ragged last batch,
-            # as padded rounds — a rank without a batch of its own steps on a copy of the round's first batch with rank weight 0 (its
-            # gradient and loss statistics are zeroed before the all-reduce, trainer.py / step.py::_allreduce)
-            for xs in train.iter_tail(usable, dp.world):
-                k = min(dp.rank, len(xs) - 1)
-                yield (xs[k].contiguous(), 1.0 if dp.rank < len(xs) else 0.0)
-
-    full = train.n // args.batch_size
-    nb = len(train) if dp is None else full // dp.world + len(list(train.tail_rounds(full // dp.world * dp.world, dp.world)))
+    batches, nb = gdata.epoch_batches(train, args.batch_size, dp)      # under data parallelism the epoch's tail is kept as padded rounds
     Trainer(model, args, batches, mean, std, args.batch_size, dp=dp, batches_per_epoch=nb).train()
     if dp is not None:
         import torch.distributed as dist

@@ -156,3 +156,26 @@ def get_dataloader(args, root="../data", device="cpu", raw=None, single=False, g
         ld = WindowLoader(series, args.lag, args.horizon, args.batch_size, shuffle=(k == 0), single=single, generator=generator)
         loaders.append(ld if ld.n > 0 else None)
     return loaders[0], loaders[1], loaders[2], sc[0], sc[1], sc[2]
+
+
+def epoch_batches(train, batch_size, dp=None):
+    """-> (batches, batches_per_epoch): `batches(epoch)` yields THIS rank's batches of one epoch for trainer.Trainer — shuffle=True,
+    drop_last=False (lib/dataloader.py:152).  Under data parallelism (dp: dist.DataParallel) every rank draws the same permutation and takes
+    every world-th batch of the whole groups of `world` full batches; the tail of the epoch is KEPT as padded rounds (r04; it was dropped):
+    the full batches beyond the last whole group, then the ragged last batch, each as a round in which a rank without a batch of its own
+    steps on a copy of a real one with rank weight 0 — yielded as (batch, weight) on EVERY rank of such a round (trainer.py / step.py::_allreduce)."""
+    full = train.n // batch_size
+    if dp is None:
+        def batches(epoch):
+            for x in train.iter_x():
+                yield x.contiguous()                                 # incl. the ragged last batch
+        return batches, len(train)
+    usable = (full // dp.world) * dp.world
+
+    def batches(epoch):
+        for x in train.iter_x(rank=dp.rank, world=dp.world, limit=usable):     # only this rank's batches are gathered
+            yield x.contiguous()
+        for xs in train.iter_tail(usable, dp.world):
+            yield (xs[min(dp.rank, len(xs) - 1)].contiguous(), 1.0 if dp.rank < len(xs) else 0.0)
+    return batches, usable // dp.world + len(list(train.tail_rounds(usable, dp.world)))
+

@@ -214,3 +214,21 @@ def test_two_native_communicators_coexist():
         assert shard.world == 1 and dp.world == 1 and shard.h.value != dp.h.value
     finally:
         shard.close(); dp.close()
+
+
+def test_trainer_keeps_the_tail_of_a_data_parallel_epoch(tmp_path):
+    """r04 (verdict 5e): two ranks (gloo, one GPU) train two epochs — random-mask and adaptive phase — of a series with an ODD number of full
+    batches and a ragged last one.  Every batch of the epoch is stepped on: whole groups through the captured step, the left-over full batch and the
+    ragged batch as padded rounds (the rank without a batch contributes weight 0); both ranks end with bit-identical weights."""
+    port = 29910 + os.getpid() % 50
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.join(ROOT, "tests", "dp_tail_worker.py"), str(tmp_path)]
+    r = subprocess.run(cmd, cwd=ROOT, env=dict(os.environ, GPTST_DIST_BACKEND="gloo"), capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-3000:]
+    out = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1])
+    assert out["full"] % 2 == 1 and out["n"] % 8 != 0, out                 # the epoch HAS a left-over full batch and a ragged one
+    assert out["tail_rounds"] == [1, 1] and out["nb"] == out["full"] // 2 + 2
+    assert out["tA"] == 2 * out["nb"], out                                  # every round of both epochs was an optimiser step
+    assert out["same_weights"], "the replicas diverged"
+    assert all(l == l and l > 0 for l in out["losses"]), out
+
