@@ -1,11 +1,12 @@
 """Downstream consumer of the pretrained encoder: the reference's ``Enhance_model.forward_pretrain`` +
 ``Fusion`` (model/Model.py:5-18, 20-46, 91-107) without the predictor zoo.  The frozen GPT-ST encoder (``mode='eval'``:
-``dim_in_flow`` + one STHCN, no masking) runs on the HIP kernels; ``lin_test`` and the ``Fusion`` gate are the small trainable
-torch modules of the downstream task, exactly as in the reference, so any predictor (an ``nn.Module`` taking the (B,T,N,C)
+``dim_in_flow`` + one STHCN, no masking) runs on the HIP kernels; ``lin_test`` and the ``Fusion`` gate keep the reference's parameters
+(state_dict keys) and run as one fused HIP launch (round 4, fusion.py) with a torch fallback, so any predictor (an ``nn.Module`` taking the (B,T,N,C)
 embedding) can be trained on top with ordinary autograd."""
 import torch
 import torch.nn as nn
 
+from .fusion import fusion_gate
 from .model import GPTST_Model
 
 
@@ -42,8 +43,8 @@ class EnhanceFrontEnd(nn.Module):
 
     def forward(self, source, label=None, batch_seen=None):                # :96-107
         x_pretrain_flow = self.pretrain_model(source, label)[0]
-        x_t1 = self.lin_test(source[..., :self.input_base_dim])
-        eb = self.fusion(x_pretrain_flow, x_t1)
+        # :105-107 lin_test + Fusion: one HIP launch forward (csrc/fusion.hip) where the shape allows, the torch modules otherwise
+        eb = fusion_gate(x_pretrain_flow.detach(), source, self.fusion, self.lin_test, self.input_base_dim)
         if self.predictor is None:
             return eb
         x = self.predictor(eb)

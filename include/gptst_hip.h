@@ -334,6 +334,17 @@ int gptst_lin_in(const float* a, int lda, const float* mask, float fill, const f
 /* label (optional, int32 per row): argmax_j Z[i,j], first maximum — the cluster label of the adaptive mask (GPTST.py:344-345) */
 int gptst_rowdot(const float* X, const float* W, const float* b, float* Z, int rows, int J, int C, int do_softmax, int* label,
                  void* stream);
+/* r04 — the gate of the downstream front end (reference model/Model.py:5-18 Fusion, :106 lin_test) in one launch:
+ *   x_t = flow . Wt^T + bt  (flow: `base` values per row of src at stride lda);  z = sigmoid(F Ws^T + bs + x_t Wh^T + bh);
+ *   out = (z F + (1 - z) x_t) Wo^T + bo.      F, out, z: (rows, C); weights as nn.Linear stores them ([out][in]); z may be NULL (inference).
+ * gptst_fusion_gate_bwd: the backward's data path — dpre = dHm (F - x_t) z (1 - z) with dHm = dOut Wo (gradient of both gate pre-activations),
+ * dxd = dHm (1 - z), and Hm, xt re-formed as operands of the weight gradients (gptst_wgrad_colsum / gptst_apply do those: gpt-st_amd/fusion.py).
+ * C = 64 and base <= 4, else GPTST_ESHAPE. */
+int gptst_fusion_gate_fwd(const float* F, const float* src, int lda, int base, const float* Ws, const float* bs, const float* Wh,
+                          const float* bh, const float* Wo, const float* bo, const float* Wt, const float* bt, float* out, float* z,
+                          int rows, int C, void* stream);
+int gptst_fusion_gate_bwd(const float* dOut, const float* F, const float* z, const float* src, int lda, int base, const float* Wo,
+                          const float* Wt, const float* bt, float* dpre, float* dxd, float* Hm, float* xt, int rows, int C, void* stream);
 int gptst_rowouter_ws_floats(int J, int C);   /* scratch (ws) size of gptst_rowouter */
 /* first stage of gptst_rowouter alone: part (gptst_rowouter_nparts(rows), J*C + C + J) = row-chunk partials [sum a'^T X (j,c) | column
  * sums of X | sums of a'] for the caller to fold (one kind-1 pool job next to the other reductions of a step). */

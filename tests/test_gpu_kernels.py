@@ -1089,6 +1089,37 @@ def test_temporal_graph_job_falls_back_beyond_its_lds_scratch():
         assert torch.equal(G, ops.gram_fwd(A.view(N, Hm, 12)))
 
 
+@pytest.mark.parametrize("shape,base", [((32, 12, 170), 1), ((3, 12, 37), 2), ((1, 5, 7), 1)])
+def test_fusion_gate_equals_the_torch_modules(shape, base):
+    """gptst_fusion_gate_fwd / _bwd (the downstream front end's lin_test + Fusion gate, reference model/Model.py:5-18,:106) against the torch
+    modules on the same parameters: fused embedding and every parameter gradient (fp32, 1e-4 of the tensor scale); inference (no parameter
+    requires grad) takes the same launch without keeping z."""
+    from gptst_amd.enhance import Fusion
+    from gptst_amd.fusion import fusion_gate
+    dev = _dev()
+    torch.manual_seed(5)
+    C = 64
+    fus, lin = Fusion(C), torch.nn.Linear(base, C)
+    F = torch.randn(*shape, C) * 0.7
+    src = torch.randn(*shape, base + 2)
+    go = torch.randn(*shape, C)
+    ref = fus(F, lin(src[..., :base]))
+    (ref * go).sum().backward()
+    want = {n: p.grad.clone() for n, p in list(fus.named_parameters()) + [("lin." + k, v) for k, v in lin.named_parameters()]}
+    fus_d, lin_d = Fusion(C).to(dev), torch.nn.Linear(base, C).to(dev)
+    fus_d.load_state_dict(fus.state_dict()); lin_d.load_state_dict(lin.state_dict())
+    out = fusion_gate(F.to(dev), src.to(dev), fus_d, lin_d, base)
+    close(out, ref.detach(), what="fusion gate out")
+    (out * go.to(dev)).sum().backward()
+    got = {n: p.grad for n, p in list(fus_d.named_parameters()) + [("lin." + k, v) for k, v in lin_d.named_parameters()]}
+    for n in want:
+        close(got[n], want[n], what="fusion gate d" + n)
+    for p_ in list(fus_d.parameters()) + list(lin_d.parameters()):
+        p_.requires_grad_(False)
+    with torch.no_grad():
+        close(fusion_gate(F.to(dev), src.to(dev), fus_d, lin_d, base), ref.detach(), what="fusion gate out (inference)")
+
+
 def test_step_begin_draws_philox_noise():
     """gptst_step_begin fills the step's mask noise with Philox4x32-10 uniforms keyed by device words (seed, step): exact against a Python
     restatement of the published algorithm, in [0,1), uniform, and a different stream per step."""
