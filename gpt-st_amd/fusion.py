@@ -1,6 +1,6 @@
 """The gate of the downstream front end on HIP (reference model/Model.py:5-18 ``Fusion`` + :106 ``lin_test``; csrc/fusion.hip): forward = ONE launch,
 backward = one data-path launch + the library's weight-gradient kernels.  ``fusion_gate(F, flow, fusion, lin_test)`` is a drop-in for
-``fusion(F, lin_test(flow))`` on CUDA fp32 tensors with C = 64 (anything else takes the torch modules); the encoder embedding F is treated as a
+``fusion(F, lin_test(flow))`` on CUDA fp32 tensors with C = 64 (other widths take the torch modules on the GPU; CPU tensors raise); the encoder embedding F is treated as a
 constant (the pretrained encoder is frozen, model/Model.py:93-94)."""
 import torch
 
@@ -49,9 +49,11 @@ class _FusionGateFn(torch.autograd.Function):
 def fusion_gate(F, source, fusion, lin_test, base):
     """F (..., C): encoder embedding; source (..., base + 2): the raw batch (its first `base` channels are the flow) -> fused embedding (..., C)."""
     C = F.shape[-1]
-    ok = (F.is_cuda and F.dtype == torch.float32 and C == 64 and base <= 4 and source.dtype == torch.float32
+    if not (F.is_cuda and source.is_cuda):
+        raise RuntimeError("gpt-st_amd: the downstream gate runs on the GPU only (no CPU path exists, as for the encoder in front of it)")
+    ok = (F.dtype == torch.float32 and C == 64 and base <= 4 and source.dtype == torch.float32
           and not F.requires_grad and source.shape[:-1] == F.shape[:-1])
-    if not ok:
+    if not ok:                                   # other widths (C = 128): the reference's torch modules, on the GPU as before round 4
         return fusion(F, lin_test(source[..., :base]))
     _C.lib()
     Fc, sc = F.contiguous().view(-1, C), source.contiguous()

@@ -164,3 +164,10 @@ def test_window_loader_tail_rounds_keep_every_batch():
         if mk().n % 8:
             assert got[-1].shape[0] == mk().n % 8 and rounds[-1] == [full]
         assert torch.equal(per_rank[0][0], full_epoch[0])
+
+
+def test_downstream_gate_has_no_cpu_path():
+    from gptst_amd.enhance import Fusion
+    from gptst_amd.fusion import fusion_gate
+    with pytest.raises(RuntimeError):
+        fusion_gate(torch.zeros(2, 3, 4, 64), torch.zeros(2, 3, 4, 3), Fusion(64), torch.nn.Linear(1, 64), 1)
