@@ -445,7 +445,37 @@ def main():
         torch.cuda.synchronize()
         rnd_rate = max(a.steps // 4, 10) / (time.perf_counter() - t1)
 
+    # per-collective durations (HIP event pair around each RCCL enqueue of three eager steps, on the launch stream) — with the bucketed
+    # exchange: the decoder bucket (under the encoder's backward), the encoder bucket and [KL | statistics] behind the chain, the label gather.
+    # EVERY rank runs these steps (they hold collectives: a rank that left early would hang the others — ADVICE r04); rank 0 reports.
+    coll = {}
+    if dp is not None and getattr(dp, "native", None) is not None and a.shard != "nodes":
+        from gptst_amd import dist as gdist
+        graph_was = stepper.use_graph
+        stepper.use_graph = False
+        stepper.step(stepper.src, a.epoch)
+        torch.cuda.synchronize()
+        gdist.COMM_TIMER = []
+        for _ in range(3):
+            stepper.step(stepper.src, a.epoch)
+        torch.cuda.synchronize()
+        rec, gdist.COMM_TIMER = gdist.COMM_TIMER, None
+        stepper.use_graph = graph_was
+        agg = {}
+        for what, nb, e0, e1 in rec:
+            v = agg.setdefault("%s[%.2f MB]" % (what, nb / 1e6), [0.0, 0])
+            v[0] += e0.elapsed_time(e1) * 1e3
+            v[1] += 1
+        coll["collectives_us"] = {k: round(v[0] / v[1], 1) for k, v in agg.items()}
+        coll["collectives_per_step"] = len(rec) // 3
+        coll["dp_overlap"] = bool(getattr(stepper, "dp_overlap", False))
+        dp.barrier()
+
     if rank != 0:
+        if dp is not None:
+            import torch.distributed as dist
+            dp.barrier()
+            dist.destroy_process_group()
         return
     steps_s = a.steps / el
     strong = a.shard == "nodes" or a.scaling == "strong"
@@ -539,26 +569,7 @@ def main():
         top = sorted(kt.items(), key=lambda kv: -kv[1]["total_s"])[:12]
         out["kernel_breakdown_us_per_step"] = {"%s[%s]" % k: round(1e6 * v["total_s"], 1) for k, v in top}
         out["kernel_time_sum_us_per_step_eager"] = round(1e6 * tot, 1)
-    if dp is not None and getattr(dp, "native", None) is not None and a.shard != "nodes":
-        # per-collective durations (HIP event pair around each RCCL enqueue of three eager steps, on the launch stream) — with the bucketed
-        # exchange: the decoder bucket (under the encoder's backward), the encoder bucket and [KL | statistics] behind the chain, the label gather
-        from gptst_amd import dist as gdist
-        stepper.use_graph = False
-        stepper.step(stepper.src, a.epoch)
-        torch.cuda.synchronize()
-        gdist.COMM_TIMER = []
-        for _ in range(3):
-            stepper.step(stepper.src, a.epoch)
-        torch.cuda.synchronize()
-        rec, gdist.COMM_TIMER = gdist.COMM_TIMER, None
-        agg = {}
-        for what, nb, e0, e1 in rec:
-            v = agg.setdefault("%s[%.2f MB]" % (what, nb / 1e6), [0.0, 0])
-            v[0] += e0.elapsed_time(e1) * 1e3
-            v[1] += 1
-        out["collectives_us"] = {k: round(v[0] / v[1], 1) for k, v in agg.items()}
-        out["collectives_per_step"] = len(rec) // 3
-        out["dp_overlap"] = bool(getattr(stepper, "dp_overlap", False))
+    out.update(coll)
     if world == 1 and a.shard != "nodes" and (a.path == "module" or not a.no_module_path):
         stepper = None
         torch.cuda.empty_cache()
@@ -569,9 +580,10 @@ def main():
             out["config"]["workload"] += "; PATH = module (reference-style loop over the drop-in nn.Module, not the fused step)"
     if not a.no_cpu_baseline and world == 1:
         out["cpu_baseline"] = cpu_baseline(args, B)
-    print(json.dumps(out))
+    print(json.dumps(out), flush=True)
     if dp is not None:
         import torch.distributed as dist
+        dp.barrier()
         dist.destroy_process_group()
 
 

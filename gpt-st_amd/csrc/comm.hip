@@ -38,6 +38,11 @@ bool bind() {
 }
 }  // namespace
 
+// GPTST_OK when RCCL can be bound in this process (library found, the four mandatory symbols present), GPTST_ECOMM otherwise.  No side effect
+// beyond the dlopen: the probe every rank runs before a communicator is formed (ncclGetUniqueId starts a bootstrap root — a listening socket
+// and a thread — per call, which a mere probe must not leave behind: ADVICE r04).
+extern "C" int gptst_comm_available(void) { return bind() ? GPTST_OK : GPTST_ECOMM; }
+
 // out: 128 bytes (ncclUniqueId) created on ONE rank and handed to every rank of the job by the caller (file, socket, torch.distributed)
 extern "C" int gptst_comm_unique_id(void* out) {
     if (!out) return GPTST_EARG;

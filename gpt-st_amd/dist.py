@@ -43,7 +43,7 @@ class DataParallel:
             from . import _C
             ok = 1
             try:
-                _C.lib().call("gptst_comm_unique_id", (ctypes.c_char * 128)())
+                _C.lib().call("gptst_comm_available")               # side-effect free (binds RCCL; no ncclGetUniqueId bootstrap root)
             except Exception as e:                                    # noqa: BLE001
                 ok, why = 0, "%s: %s" % (type(e).__name__, str(e).splitlines()[0][:160] if str(e) else "")
             if self.world > 1:

@@ -278,9 +278,20 @@ def hypertem_core_bwd(saved, dout, dG_out, dims, chain=False, premul=False):
 PAIR_BWD = os.environ.get("GPTST_PAIR_BWD", "1") == "1"        # two adjacent hyperTem layers' backward in one launch (r04)
 
 
+def _ht_pair_shape_ok(dims):
+    """the launcher's own shape conditions (gptst_hypertem_bwd_pair, hypertem.hip): T = 12, and rounding a split's rows up to even must not
+    change the split count — checked HERE so that a deferred hyperTem1 (PendingH1) is never handed to a launch that would refuse it"""
+    B, T, N, C = dims
+    if T != 12 or C != 64:
+        return False
+    ns = ops.wgrad_nsplit(MODE_TIME, B * T, N, C)
+    rps = (-(-N // ns) + 1) & ~1
+    return -(-N // rps) == ns
+
+
 def ht_pair_ok(saved1, saved0, dims):
     return (PAIR_BWD and dims[3] == 64 and not isinstance(saved1, EncIn) and saved1[1] is not None and saved0[1] is not None
-            and CTX.SIDE is None and _ht_fused_bwd(dims))
+            and CTX.SIDE is None and _ht_fused_bwd(dims) and _ht_pair_shape_ok(dims))
 
 
 class PendingH1:

@@ -204,15 +204,10 @@ class GPTST_Model(nn.Module):
         return r
 
     def _grad_buffer(self):
-        """The flat gradient buffer of the autograd path, zeroed: ONE buffer per model reused across calls (r03 review: a fresh 4 MB
-        allocation per backward) — unless a parameter's .grad still aliases it (gradient accumulation without zero_grad): then a new one."""
-        buf = getattr(self, "_gbuf", None)
-        if buf is not None and buf.numel() == self.flat.numel() and buf.device == self.flat.device:
-            lo, hi = buf.data_ptr(), buf.data_ptr() + 4 * buf.numel()
-            if not any(q.grad is not None and lo <= q.grad.data_ptr() < hi for q in self.parameters()):
-                return buf.zero_()
-        self._gbuf = torch.zeros_like(self.flat)
-        return self._gbuf
+        """A flat gradient buffer for ONE backward node of the autograd path, zeroed.  Fresh per call: the node returns views of it, and autograd
+        may still hold those views (a second forward of the same model inside one backward pass, tensors returned by torch.autograd.grad) when the
+        next node runs — a reused buffer was overwritten under them.  The caching allocator makes this one memset, as zero_() was."""
+        return torch.zeros_like(self.flat)
 
     def views_of(self, flat):
         named = dict(self.named_parameters())

@@ -165,6 +165,10 @@ class Trainer:
         sums = None
         with torch.no_grad():
             for src in batches:
+                if isinstance(src, tuple):               # tail round of a data-parallel epoch (data.epoch_batches): (batch, rank weight)
+                    src, weight = src
+                    if weight == 0.0:                    # padding: a real rank's batch repeated — it is counted where it is real
+                        continue
                 src = src.contiguous()
                 B, T, N, _ = src.shape
                 out, _, masked, _, _ = model(src, None, None, a.epochs)
@@ -175,8 +179,11 @@ class Trainer:
                                   getattr(a, "mae_thresh", None), a.mape_thresh, B, T, N, base, *sums)
         if self.dp is not None and self.dp.world > 1:
             import torch.distributed as dist
+            if sums is None:                             # a rank whose whole share was padding still joins the reduction
+                sums = ops.metrics_new(self.step.T, a.num_nodes, self.step.dev)
             for t_ in sums:                              # float64 sums over this rank's batches -> over the job's
                 dist.all_reduce(t_, op=dist.ReduceOp.SUM)
+        self.eval_samples = float(sums[1][0, 0, 0]) / base      # (batch, channel) entries per (horizon, node) cell = samples evaluated x base
         rows = ops.metrics_report(*sums)
         for t in range(rows.shape[0] - 1):
             mae, rmse, mape, corr = (float(v) for v in rows[t])

@@ -454,6 +454,7 @@ int gptst_mlprl_layer_bwd(const float* dlogits, const float* a, int lda, const f
  * communicator is given, 1000 + ncclResult_t on an RCCL error.  Communicators are HANDLES (r04; a process-global one before): a process may
  * hold several — the row and the column of a data-parallel x node-shard mesh (SURVEY 8(e) "Combination") — each created by gptst_comm_init
  * on the ranks that form it.  unique_id: 128 bytes (ncclUniqueId) created on one rank of the communicator and distributed by the caller. */
+int gptst_comm_available(void);                                /* RCCL can be bound here (no bootstrap, no socket): the probe before a communicator is formed */
 int gptst_comm_unique_id(void* out128);
 int gptst_comm_init(int rank, int world, const void* unique_id, void** comm_out);    /* *comm_out: the handle the calls below take */
 int gptst_allreduce_f32(void* comm, float* buf, long n, void* stream);      /* in-place sum over the ranks */

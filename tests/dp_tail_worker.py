@@ -34,6 +34,10 @@ batches, nb = D.epoch_batches(train, 8, dp)
 tr = Trainer(model, args, batches, float(scaler.mean), float(scaler.std), 8, dp=dp, batches_per_epoch=nb)
 tr.logger.setLevel(logging.WARNING)
 losses = [tr.train_epoch(e) for e in (1, 2)]            # random-mask phase, then adaptive + KL
+extra = {}
+if len(sys.argv) > 2 and sys.argv[2] == "train":        # Trainer.train() end to end — its closing evaluation walks the padded tail rounds too
+    best = tr.train()
+    extra = {"trained": best is not None, "eval_samples": tr.eval_samples}
 torch.cuda.synchronize()
 h = hashlib.sha256(model.flat.detach().cpu().numpy().tobytes()).hexdigest()
 hs = [None, None]
@@ -41,6 +45,6 @@ dist.all_gather_object(hs, h)
 full = train.n // 8
 if dp.rank == 0:
     print(json.dumps({"tA": tr.step.tA, "nb": nb, "full": full, "n": train.n, "same_weights": hs[0] == hs[1], "losses": losses,
-                      "tail_rounds": [len(r) for r in train.tail_rounds(full // 2 * 2, 2)]}))
+                      "tail_rounds": [len(r) for r in train.tail_rounds(full // 2 * 2, 2)], **extra}))
 dp.barrier()
 dist.destroy_process_group()

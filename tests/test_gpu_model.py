@@ -89,6 +89,41 @@ def test_model_vs_reference_golden(tag):
     print(tag, "worst grad rel err", worst)
 
 
+def test_two_forwards_in_one_backward_accumulate():
+    """(loss(model(x1)) + loss(model(x2))).backward() — two backward nodes of ONE model run before AccumulateGrad; each must hand
+    autograd its own gradient storage (a shared buffer made the accumulated gradient 2*g2), and tensors returned by torch.autograd.grad must
+    survive a later backward of the same model."""
+    fx = load("forward_small.npz")
+    tag = "s_rand"
+    args = cfg_args(fx, tag, make_args, scaler_zeros=synth.scaler_zeros())
+    epoch = int(fx[tag + ".epoch"])
+    model = _build(args, O.init_state_dict(args, int(fx[tag + ".sd_seed"])))
+    x1 = t(fx, tag + ".src").to(DEV)
+    x2 = torch.roll(x1, 1, dims=2).contiguous()
+    noise = t(fx, tag + ".noise0")
+
+    def loss_of(x):
+        model.set_mask_inputs(noise=noise)
+        return _loss(model(x, x, None, epoch), x, args, epoch)[0]
+
+    params = [p for p in model.parameters() if p.requires_grad]
+    g1 = torch.autograd.grad(loss_of(x1), params, allow_unused=True)
+    g1_copy = [None if g is None else g.clone() for g in g1]
+    g2 = torch.autograd.grad(loss_of(x2), params, allow_unused=True)
+    for a_, b_ in zip(g1, g1_copy):                      # g1 was not overwritten by the second backward
+        assert a_ is None or torch.equal(a_, b_)
+    model.zero_grad(set_to_none=True)
+    (loss_of(x1) + loss_of(x2)).backward()
+    n = 0
+    for p_, a_, b_ in zip(params, g1, g2):
+        if a_ is None:
+            continue
+        assert float((a_ - b_).abs().max()) > 0 or float(a_.abs().max()) == 0.0
+        torch.testing.assert_close(p_.grad, a_ + b_, rtol=1e-5, atol=1e-6 * float((a_ + b_).abs().max()))
+        n += 1
+    assert n > 100
+
+
 def test_model_full_pems08_forward():
     fx = load("forward_full.npz")
     args = make_args("PEMS08", scaler_zeros=synth.scaler_zeros())

@@ -232,3 +232,17 @@ def test_trainer_keeps_the_tail_of_a_data_parallel_epoch(tmp_path):
     assert out["same_weights"], "the replicas diverged"
     assert all(l == l and l > 0 for l in out["losses"]), out
 
+
+
+def test_trainer_train_end_to_end_under_data_parallelism(tmp_path):
+    """Trainer.train() closes with test() over the epoch's batches, which under data parallelism include the (batch, weight)
+    tuples of the padded tail rounds.  Two gloo ranks on one GPU run train() to the end: the evaluation completes and counts every sample of the
+    training set exactly once (padding — weight 0 — is skipped, the metric sums are all-reduced)."""
+    port = 29960 + os.getpid() % 30
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.join(ROOT, "tests", "dp_tail_worker.py"), str(tmp_path), "train"]
+    r = subprocess.run(cmd, cwd=ROOT, env=dict(os.environ, GPTST_DIST_BACKEND="gloo"), capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stderr[-3000:]
+    out = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1])
+    assert out["trained"] and out["same_weights"], out
+    assert out["eval_samples"] == out["n"], out

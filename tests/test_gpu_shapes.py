@@ -37,6 +37,15 @@ CASES = {
 }
 
 
+# Whole-model gradient bound = the north star's 1e-4 (r04: 2e-4).  Measured worst per case: profiles/parity_r05.json.
+GRAD_TOL = 1e-4
+# Parameters allowed past it, per case, under the fp64 rule at the end of the test.  hs5 (PEMS08-style base = 1, N = 50, HS = 5): the gradient of
+# the cap's time embedding `teb` (GPTST.py:104,260) is the sum over (h, n) of softmax-backward terms that cancel to 1e-5 of their size — |g| ~ 6e-6
+# where the node embeddings have 5e-2 — and the fp32 ORACLE is itself 6.9e-5 off its fp64 run there (HIP: 8.6e-5; every round-4 kernel switch
+# leaves the figure unchanged to three digits — it is the conditioning of the quantity, not a kernel).
+ILL_CONDITIONED = {"hs5": ("encoder.STHCN_encode.time_feature1_.",)}
+
+
 @pytest.mark.parametrize("name", list(CASES))
 def test_model_vs_oracle(name, parity):
     from gptst_amd.model import GPTST_Model
@@ -92,7 +101,7 @@ def test_model_vs_oracle(name, parity):
     parity("loss", abs(float(loss) - float(loss_r)) / abs(float(loss_r)))
     assert abs(float(loss) - float(loss_r)) < 2e-6 * abs(float(loss_r))      # measured <= 1.5e-7
     loss.backward()
-    worst = 0.0
+    worst, over = 0.0, {}
     for k, pm in model.named_parameters():
         gr = st.sd[k].grad
         if gr is None:
@@ -100,6 +109,24 @@ def test_model_vs_oracle(name, parity):
             continue
         e = rel(pm.grad, gr)
         worst = max(worst, e)
-        assert e < 2e-4, (name, k, e)       # <= 2x the measured worst over all cases: 9.4e-5 (nyc_taxi), typically 2e-5 (profiles/parity_r0*.json)
+        if e >= GRAD_TOL:
+            over[k] = e
     parity("grad_worst", worst)
     print(name, "worst grad rel err %.2e" % worst)
+    if over:
+        # A parameter past 1e-4 must be a NAMED ill-conditioned one, and then the yardstick is the fp64 oracle: the HIP gradient may be no
+        # further from it than 1.5x the fp32 ORACLE's own distance (tools/grad_bisect.py, profiles/r05_grad_bisect.txt: for these tensors the
+        # two fp32 implementations err by the same amount in opposite directions, so their mutual distance is the sum)
+        assert rdt == torch.float32
+        assert all(any(k.startswith(pfx) for pfx in ILL_CONDITIONED.get(name, ())) for k in over), (name, over)
+        c64 = lambda v: v.double() if torch.is_tensor(v) and v.dtype.is_floating_point else v      # noqa: E731
+        st64 = O.Stepper({k: c64(v) for k, v in sd.items()}, args, synth.SCALER_MEAN, synth.SCALER_STD, materialize_5d=False)
+        o64, aux64 = O.forward_pretrain(st64.sd, args, c64(src), epoch, materialize_5d=False, **{k: c64(v) for k, v in inj.items()})
+        assert torch.equal(aux64["final_mask"], aux["final_mask"])
+        O.pretrain_loss(o64, c64(src), args, epoch, synth.SCALER_MEAN, synth.SCALER_STD)[0].backward()
+        for k in over:
+            g64 = st64.sd[k].grad
+            e_hip, e_orc = rel(dict(model.named_parameters())[k].grad, g64), rel(st.sd[k].grad, g64)
+            parity("grad_vs_f64:" + k, e_hip)
+            parity("oracle_vs_f64:" + k, e_orc)
+            assert e_hip < GRAD_TOL and e_hip <= 1.5 * e_orc, (name, k, e_hip, e_orc)
