@@ -527,6 +527,14 @@ struct CrossBwdArgs { const float* dv; const float* s; const float* Rt; const fl
                       float* dSg; unsigned* flags; int nB;       // roles (r04): nB cross-time workgroups publish dS (B*T, HS, C) + their flags
                       const float* drec; const float* v; float* dc1w; float* dvw; int nA, B; };   // + the B*T rec-backward workgroups (three-role form)
 
+// r05: the backward of the cap's ENTRY Linear + the layer's residual branch (GPTST.py:102,139-141; gptst_linear_bwd) folded into the routing backward,
+// which holds everything it needs: the X tile (it rebuilds Y from it), dY (in LDS, never written out) and — fetched as fragments — Wp.
+//   dX = dY Wp + dPre             (out == NULL: the incoming gradient already is dPre;  premul: the sum is multiplied by lrelu'(X))
+//   dX = dY Wp + dOut lrelu'(out) (out given)
+//   dWp[bt] = dY^T X ([out][in]), dbp[bt] = colsum(dY): ONE partial per (b,t) workgroup (B*T rows for the reduction job; 510 row splits before)
+// dX == NULL: not folded (dY goes to global memory for gptst_linear_bwd).
+struct LinArgs { const float* dPre; const float* out; float* dX; float* dWp; float* dbp; int premul; };
+
 // ---- backward of the cross-time block (cap_cross_bwd_kernel, cap_cross.hip) as a PROLOGUE of the (b,t) workgroups below (r03) -----------
 // cap_cross_bwd runs on B workgroups between two (b,t)-grouped kernels.  Folded in, every (b,t) workgroup repeats the part that needs the
 // whole sample — du / dRpre of all T*HS tokens and dHpre (HT x C over the tokens), ~0.3 MFLOP — and then produces only what belongs to its
@@ -661,12 +669,12 @@ __device__ __forceinline__ void cap_cross_bwd_prologue(const float* __restrict__
     __syncthreads();
 }
 
-template <int C, int ROLES>      // 0: one role (dS given, or the cross-time backward as a prologue); 1: + cross-time role; 2: + rec-backward role
+template <int C, int ROLES, bool LIN = false>      // ROLES 0: one role (dS given, or the cross-time backward as a prologue); 1: + cross-time role; 2: + rec-backward role
 __global__ __launch_bounds__(CM_NT, 4) void cap_route_bwd2_kernel(const float* __restrict__ X, const float* __restrict__ Wp,
                                                                   const float* __restrict__ bp, const float* __restrict__ c,
                                                                   const float* __restrict__ dc1, const float* __restrict__ dS,
                                                                   float* __restrict__ dY, float* __restrict__ dlogit, int N, int HS,
-                                                                  int region2, CrossBwdArgs cx) {
+                                                                  int region2, CrossBwdArgs cx, LinArgs lin) {
     using T = Tile<C>;
     constexpr int P = T::PITCH, LPR = C / 4, RPP = CM_NT / LPR;
     extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -870,6 +878,9 @@ __global__ __launch_bounds__(CM_NT, 4) void cap_route_bwd2_kernel(const float* _
 
     const int j = lane & 15, kk = lane >> 4;
     const int ntiles = (N + 15) / 16;
+    float csum[C / 16];
+#pragma unroll
+    for (int ct = 0; ct < C / 16; ++ct) csum[ct] = 0.f;
     for (int nt = wave; nt < ntiles; nt += CM_NW) {
         const int n = nt * 16 + j;                          // node of this lane as MFMA column (type 2) / row (dP)
         const float gn = gq[n];
@@ -936,17 +947,142 @@ __global__ __launch_bounds__(CM_NT, 4) void cap_route_bwd2_kernel(const float* _
             if (rt > 0.f) gp = (den - q * ((rt + 1e-8f) + (1.f + q) * 0.5f / rt)) / (den * den);
             const float k2 = 2.f * gp * ydp[r];
 #pragma unroll
-            for (int ct = 0; ct < C / 16; ++ct) Ys[nn * P + 16 * ct + j] = fmaf(k2, yv[ct][r], g * dp[ct][r]);   // dY over Y (own tile)
+            for (int ct = 0; ct < C / 16; ++ct) {
+                const float dy = fmaf(k2, yv[ct][r], g * dp[ct][r]);
+                Ys[nn * P + 16 * ct + j] = dy;                                                                    // dY over Y (own tile)
+                if constexpr (LIN) csum[ct] += dy;                // column sums of dY (the entry Linear's bias gradient): rows beyond N are zero
+            }
         }
-        // coalesced rows out
+        // coalesced rows out (LIN: dY stays in LDS — its only consumer is the Linear backward below)
+        if constexpr (!LIN) {
 #pragma unroll
-        for (int i = 0; i < 16 * LPR / 64; ++i) {
-            const int f = i * 64 + lane, nl = f / LPR, c4 = f % LPR;
-            const int nn = nt * 16 + nl;
-            if (nn < N) st4(dY + ((size_t)bt * N + nn) * C + 4 * c4, ld4(Ys + nn * P + 4 * c4));
+            for (int i = 0; i < 16 * LPR / 64; ++i) {
+                const int f = i * 64 + lane, nl = f / LPR, c4 = f % LPR;
+                const int nn = nt * 16 + nl;
+                if (nn < N) st4(dY + ((size_t)bt * N + nn) * C + 4 * c4, ld4(Ys + nn * P + 4 * c4));
+            }
         }
     }
     GPTST_STAMP(5);
+    if constexpr (LIN && C == 64) {
+        // (lane-derived indices re-derived from an OPAQUE copy of the thread index: otherwise the compiler hoists this block's address arithmetic to the
+        //  top of the kernel and the capsule GEMM above — 112 live registers of fragments — spills under the 128-register budget)
+        int tid_ = threadIdx.x;
+        asm volatile("" : "+v"(tid_));
+        const int lane_ = tid_ & 63, wave_ = __builtin_amdgcn_readfirstlane(tid_ >> 6), j_ = lane_ & 15, kk_ = lane_ >> 4;
+        // ---- (c) dX tile = dY tile . Wp + residual branch.  Same operand scheme as applywg64_kernel<1>: A = dY rows from LDS (lane (j_,kk_): row j_,
+        //      channels 16q+4kk..), B = Wp fragments ([out][in] as stored: row 16q+4kk+e, columns 4j..4j+3 <-> column tile = component), accumulator
+        //      tile ct / register r = row 4kk+r, channel 4j+ct.  Wp is staged in LDS over the cs / dcs region (dead once every wave_ has left (a)/(b):
+        //      one barrier, which also completes dY for (d)); holding the 64 fragment registers next to the residual operands spilled at 128 VGPRs.
+        const float* sgn_src = lin.out != nullptr ? lin.out : X;      // the sign operand: the layer's output, or X with premul
+        float4 rv[4], sv[4];
+#define CRL_LOAD_RES(nt_) _Pragma("unroll") for (int r = 0; r < 4; ++r) {                                                   \
+            const size_t off_ = ((size_t)bt * N + min((nt_) * 16 + kk_ * 4 + r, N - 1)) * 64 + 4 * j_;                         \
+            sv[r] = ld4(sgn_src + off_); rv[r] = ld4(lin.dPre + off_); }
+        CRL_LOAD_RES(wave_);                                      // first tile's residual operands: in flight across the barrier and the staging
+#pragma unroll
+        for (int ct = 0; ct < 4; ++ct) { csum[ct] += __shfl_xor(csum[ct], 16, 64); csum[ct] += __shfl_xor(csum[ct], 32, 64); }
+        __syncthreads();
+        load_w_lds<C, CM_NT>(Wl, Wp, 0, tid_);
+        if (kk_ == 0) {                                          // per-wave column sums of dY -> Vs (free since the barrier), [wave][channel 16ct + j]
+#pragma unroll
+            for (int ct = 0; ct < 4; ++ct) Vs[wave_ * 64 + 16 * ct + j_] = csum[ct];
+        }
+        __syncthreads();
+        if (tid_ < 64) {
+            float t = 0.f;
+#pragma unroll
+            for (int w = 0; w < CM_NW; ++w) t += Vs[w * 64 + tid_];
+            lin.dbp[(size_t)bt * 64 + tid_] = t;
+        }
+        GPTST_STAMP(6);
+        for (int nt = wave_; nt < ntiles; nt += CM_NW) {
+            if (nt != wave_) { CRL_LOAD_RES(nt); }
+            SB();
+            unsigned sgn = 0u;                                   // bit 4r+e: the sign operand of row r / channel 4j+e is positive
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+                sgn |= ((sv[r].x > 0.f ? 1u : 0u) | (sv[r].y > 0.f ? 2u : 0u) | (sv[r].z > 0.f ? 4u : 0u) | (sv[r].w > 0.f ? 8u : 0u)) << (4 * r);
+            float4 ap[4];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) ap[q] = ld4(Ys + (nt * 16 + j_) * P + 16 * q + 4 * kk_);
+            f32x4 acc[4];
+#pragma unroll
+            for (int ct = 0; ct < 4; ++ct) acc[ct] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                float4 bw[4];
+#pragma unroll
+                for (int e = 0; e < 4; ++e) bw[e] = ld4(Wl + (16 * q + 4 * kk_ + e) * 64 + 4 * j_);
+                const float av[4] = {ap[q].x, ap[q].y, ap[q].z, ap[q].w};
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    acc[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[e], bw[e].x, acc[0], 0, 0, 0);
+                    acc[1] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[e], bw[e].y, acc[1], 0, 0, 0);
+                    acc[2] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[e], bw[e].z, acc[2], 0, 0, 0);
+                    acc[3] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[e], bw[e].w, acc[3], 0, 0, 0);
+                }
+            }
+            SB();
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int nn = nt * 16 + kk_ * 4 + r;
+                float4 o4 = make_float4(acc[0][r], acc[1][r], acc[2][r], acc[3][r]);
+                const float g0 = (sgn >> (4 * r)) & 1u ? 1.f : LRELU_SLOPE, g1 = (sgn >> (4 * r)) & 2u ? 1.f : LRELU_SLOPE;
+                const float g2 = (sgn >> (4 * r)) & 4u ? 1.f : LRELU_SLOPE, g3 = (sgn >> (4 * r)) & 8u ? 1.f : LRELU_SLOPE;
+                if (lin.out != nullptr) {                        // dX = dY Wp + dOut lrelu'(out)
+                    o4.x = fmaf(rv[r].x, g0, o4.x); o4.y = fmaf(rv[r].y, g1, o4.y); o4.z = fmaf(rv[r].z, g2, o4.z); o4.w = fmaf(rv[r].w, g3, o4.w);
+                } else {
+                    o4 = f4add(o4, rv[r]);                       // dX = dY Wp + dPre ...
+                    if (lin.premul) { o4.x *= g0; o4.y *= g1; o4.z *= g2; o4.w *= g3; }       // ... times lrelu'(X)
+                }
+                if (nn < N) st4(lin.dX + ((size_t)bt * N + nn) * 64 + 4 * j_, o4);
+            }
+        }
+#undef CRL_LOAD_RES
+        GPTST_STAMP(7);
+        // ---- (d) dWp[o][i] = sum_n dY[n][o] X[n][i], dbp[o] = sum_n dY[n][o]: wave_ w owns output tile (o-tile w/2, i-tiles 2(w%2), 2(w%2)+1) for ALL
+        //      nodes — no cross-wave_ fold, no further barrier (dY is complete since the barrier in front of (c)).  A = dY^T from LDS (lane (j_ = o, kk_ = node of the k-step)), B = X rows from global memory (L1 / L2: this
+        //      workgroup read them at its start).  Padded rows of Ys are zero.  (dbp: column sums gathered in loop (b), folded over the waves above.)
+        {
+            const int ot = wave_ >> 1, it0 = 2 * (wave_ & 1);
+            f32x4 w0 = {0.f, 0.f, 0.f, 0.f}, w1 = {0.f, 0.f, 0.f, 0.f};
+            const float* xcol = Xbt + 16 * it0 + j_;
+            const float* ycol = Ys + 16 * ot + j_;
+            constexpr int UB = 11;                               // k-steps per batch of loads; the next batch is requested before this one's MFMAs
+            const int nsteps = NR / 4;
+            float b0[UB], b1[UB], n0[UB], n1[UB];
+#define CRL_LOADX(d0, d1, s0_) _Pragma("unroll") for (int u = 0; u < UB; ++u) {                          \
+                const int n_ = min(4 * ((s0_) + u) + kk_, N - 1);                                          \
+                d0[u] = xcol[(size_t)n_ * 64]; d1[u] = xcol[(size_t)n_ * 64 + 16]; }
+            CRL_LOADX(b0, b1, 0);
+#pragma unroll 1
+            for (int s0 = 0; s0 < nsteps; s0 += UB) {
+                if (s0 + UB < nsteps) { CRL_LOADX(n0, n1, s0 + UB); }
+                float av[UB];
+#pragma unroll
+                for (int u = 0; u < UB; ++u) av[u] = (s0 + u < nsteps) ? ycol[(4 * (s0 + u) + kk_) * P] : 0.f;
+                SB();
+#pragma unroll
+                for (int u = 0; u < UB; ++u) {
+                    w0 = __builtin_amdgcn_mfma_f32_16x16x4f32(av[u], b0[u], w0, 0, 0, 0);
+                    w1 = __builtin_amdgcn_mfma_f32_16x16x4f32(av[u], b1[u], w1, 0, 0, 0);
+                }
+                SB();
+#pragma unroll
+                for (int u = 0; u < UB; ++u) { b0[u] = n0[u]; b1[u] = n1[u]; }
+            }
+#undef CRL_LOADX
+            float* dw = lin.dWp + (size_t)bt * 64 * 64;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int o = 16 * ot + 4 * kk_ + r;             // D reg r: row o, col i
+                dw[o * 64 + 16 * it0 + j_] = w0[r];
+                dw[o * 64 + 16 * it0 + 16 + j_] = w1[r];
+            }
+        }
+        GPTST_STAMP(8);
+    }
     GPTST_WG_END();
 }
 
@@ -954,8 +1090,10 @@ thread_local int g_cap_bwd_noroles = 0;       // gptst_tune(23, 1): the cross-ti
 
 template <int C>
 static int launch_route_bwd2(const float* X, const float* Wp, const float* bp, const float* c, const float* dc1, const float* dS,
-                             float* dY, float* dlogit, int BT, int N, int HS, hipStream_t st, CrossBwdArgs cx = CrossBwdArgs{nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, 0, 0, nullptr, nullptr, 0}) {
+                             float* dY, float* dlogit, int BT, int N, int HS, hipStream_t st, CrossBwdArgs cx = CrossBwdArgs{nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, 0, 0, nullptr, nullptr, 0},
+                             LinArgs lin = LinArgs{nullptr, nullptr, nullptr, nullptr, nullptr, 0}) {
     if (HS > 64) return GPTST_ESHAPE;
+    if (lin.dX != nullptr && (C != 64 || cx.nA > 0)) return GPTST_ESHAPE;      // the folded Linear backward: C = 64, one- and two-role forms
     const int NR = cm_rows(N), NP = cm_np(N), HSP = cm_hsp(HS);
     size_t r2 = (size_t)C * C, need = (size_t)2 * HSP * NP;
     if (need > r2) r2 = need;
@@ -974,20 +1112,34 @@ static int launch_route_bwd2(const float* X, const float* Wp, const float* bp, c
     if (cx.nB > 0 && cx.nA > 0) {                        // three roles: the rec-backward workgroups in front (waits point to lower block indices only)
         static size_t curA = 0;
         if (smem > curA) { (void)hipFuncSetAttribute((const void*)cap_route_bwd2_kernel<C, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem); curA = smem; }
-        hipLaunchKernelGGL((cap_route_bwd2_kernel<C, 2>), dim3(cx.nA + cx.nB + BT), dim3(CM_NT), smem, st, X, Wp, bp, c, dc1, dS, dY, dlogit, N, HS, (int)r2, cx);
+        hipLaunchKernelGGL((cap_route_bwd2_kernel<C, 2>), dim3(cx.nA + cx.nB + BT), dim3(CM_NT), smem, st, X, Wp, bp, c, dc1, dS, dY, dlogit, N, HS, (int)r2, cx, lin);
+        GPTST_CHECK_LAUNCH();
+        return GPTST_OK;
+    }
+    if (cx.nB > 0 && lin.dX != nullptr) {
+        static size_t curRL = 0;
+        if (smem > curRL) { (void)hipFuncSetAttribute((const void*)cap_route_bwd2_kernel<C, 1, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem); curRL = smem; }
+        hipLaunchKernelGGL((cap_route_bwd2_kernel<C, 1, true>), dim3(BT + cx.nB), dim3(CM_NT), smem, st, X, Wp, bp, c, dc1, dS, dY, dlogit, N, HS, (int)r2, cx, lin);
         GPTST_CHECK_LAUNCH();
         return GPTST_OK;
     }
     if (cx.nB > 0) {
         static size_t curR = 0;
         if (smem > curR) { (void)hipFuncSetAttribute((const void*)cap_route_bwd2_kernel<C, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem); curR = smem; }
-        hipLaunchKernelGGL((cap_route_bwd2_kernel<C, 1>), dim3(BT + cx.nB), dim3(CM_NT), smem, st, X, Wp, bp, c, dc1, dS, dY, dlogit, N, HS, (int)r2, cx);
+        hipLaunchKernelGGL((cap_route_bwd2_kernel<C, 1>), dim3(BT + cx.nB), dim3(CM_NT), smem, st, X, Wp, bp, c, dc1, dS, dY, dlogit, N, HS, (int)r2, cx, lin);
+        GPTST_CHECK_LAUNCH();
+        return GPTST_OK;
+    }
+    if (lin.dX != nullptr) {
+        static size_t curL = 0;
+        if (smem > curL) { (void)hipFuncSetAttribute((const void*)cap_route_bwd2_kernel<C, 0, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem); curL = smem; }
+        hipLaunchKernelGGL((cap_route_bwd2_kernel<C, 0, true>), dim3(BT), dim3(CM_NT), smem, st, X, Wp, bp, c, dc1, dS, dY, dlogit, N, HS, (int)r2, cx, lin);
         GPTST_CHECK_LAUNCH();
         return GPTST_OK;
     }
     static size_t cur = 0;
     if (smem > cur) { (void)hipFuncSetAttribute((const void*)cap_route_bwd2_kernel<C, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem); cur = smem; }
-    hipLaunchKernelGGL((cap_route_bwd2_kernel<C, 0>), dim3(BT), dim3(CM_NT), smem, st, X, Wp, bp, c, dc1, dS, dY, dlogit, N, HS, (int)r2, cx);
+    hipLaunchKernelGGL((cap_route_bwd2_kernel<C, 0>), dim3(BT), dim3(CM_NT), smem, st, X, Wp, bp, c, dc1, dS, dY, dlogit, N, HS, (int)r2, cx, lin);
     GPTST_CHECK_LAUNCH();
     return GPTST_OK;
 }
@@ -1017,6 +1169,23 @@ extern "C" int gptst_cap_cross_route_bwd(const float* X, const float* Wp, const 
     const bool roles = dS_ws != nullptr && flags != nullptr && !g_cap_bwd_noroles;
     return launch_route_bwd2<64>(X, Wp, bp, c, dc1, nullptr, dY, dlogit, B * T, N, HS, (hipStream_t)stream,
                                  CrossBwdArgs{dv, s, Rt, Ht, dyn, tmpl, ddyn, T, HT, roles ? dS_ws : nullptr, roles ? (unsigned*)flags : nullptr, roles ? B * CX_SPLIT : 0});
+}
+
+// gptst_cap_cross_route_bwd + gptst_linear_bwd in ONE launch (r05): the (b,t) workgroup goes on from its dY tile (kept in LDS) to the backward of the
+// cap's entry Linear and the layer's residual branch.  dPre (B*T*N, C): the cap layer's output gradient — already dPre when out == NULL (then premul
+// multiplies dX by lrelu'(X)), else dOut with out (B*T*N, C) the layer's output.  -> dX (B*T*N, C), dWp (B*T, C*C) / dbp (B*T, C): ONE partial per
+// (b,t) (the caller's reduction sums B*T rows), dlogit, ddyn.  No dY tensor exists.  dS_ws / flags as gptst_cap_cross_route_bwd.  C = 64, else GPTST_ESHAPE.
+extern "C" int gptst_cap_cross_route_lin_bwd(const float* X, const float* Wp, const float* bp, const float* c, const float* dc1, const float* dv,
+                                             const float* s, const float* Rt, const float* Ht, const float* dyn, const float* tmpl,
+                                             const float* dPre, const float* out, int premul, float* dX, float* dWp, float* dbp, float* dlogit,
+                                             float* ddyn, float* dS_ws, void* flags, int B, int T, int N, int C, int HS, int HT, void* stream) {
+    if (!X || !Wp || !bp || !c || !dc1 || !dv || !s || !Rt || !Ht || !dyn || !tmpl || !dPre || !dX || !dWp || !dbp || !dlogit || !ddyn || B <= 0 ||
+        T <= 0 || (out && premul)) return GPTST_EARG;
+    if (C != 64) return GPTST_ESHAPE;
+    const bool roles = dS_ws != nullptr && flags != nullptr && !g_cap_bwd_noroles;
+    return launch_route_bwd2<64>(X, Wp, bp, c, dc1, nullptr, nullptr, dlogit, B * T, N, HS, (hipStream_t)stream,
+                                 CrossBwdArgs{dv, s, Rt, Ht, dyn, tmpl, ddyn, T, HT, roles ? dS_ws : nullptr, roles ? (unsigned*)flags : nullptr, roles ? B * CX_SPLIT : 0},
+                                 LinArgs{dPre, out, dX, dWp, dbp, premul});
 }
 
 // gptst_cap_rec_bwd + gptst_cap_cross_route_bwd in ONE launch (three roles, see cap_route_bwd2_kernel): drec (B*T, N, C) gradient of the capsule

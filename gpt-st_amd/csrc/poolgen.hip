@@ -28,6 +28,18 @@ template <> __device__ __forceinline__ void stv<1>(float* p, float4 v) { *p = v.
 // ~50 generated-parameter problems in the forward and ~90 gradient reductions in the backward, every one of them a few microseconds
 // of work: as one launch per embedding they were ~60 launches of 4-20 us each at the head and the tail of the step (25 % of it,
 // profiles/r02b timeline); as job tables they are a handful.  The table travels in the kernel arguments (<= 4 KB).
+// Occupancy of the job kernel (r05): one kernel holds every job kind, so its register count is the maximum over the kinds — 152 VGPRs with
+// UC = 8 column steps per batch in the embedding-gradient jobs, i.e. 3 waves per SIMD, and the reductions stream at 3.8-4.0 TB/s with 48 KB in
+// flight per CU (tools/mb_pooljobs.py).  PJ_OCC = minimum waves per SIMD the compiler must leave room for, PJ_UC / PJ_NU = loads per batch.
+#ifndef PJ_OCC
+#define PJ_OCC 3
+#endif
+#ifndef PJ_UC
+#define PJ_UC 8
+#endif
+#ifndef PJ_NU
+#define PJ_NU 4
+#endif
 #define PJ_MAX 112     // 112 x 64 B = 7 KB of kernel arguments (the AQL kernarg segment is not limited to 4 KB); a pretraining step queues ~100 reductions -> 1 launch
 enum { PJ_FWD = 0, PJ_BWD_POOL = 1, PJ_BWD_EMB = 2, PJ_GRAM = 3 };
 struct PJob {
@@ -185,7 +197,7 @@ __device__ __forceinline__ void pj_bwd_pool(const PJob& a, int bx, float (*fold)
     for (int e = 0; e < V; ++e) acc[e] = (f32x4){0.f, 0.f, 0.f, 0.f};
     // NU k-steps (4 rows each) per batch: all dW / emb loads of a batch are issued before the first MFMA (row and column are
     // clamped instead of predicated; a row beyond the chunk contributes through a zero emb operand).
-    constexpr int NU = 4;
+    constexpr int NU = PJ_NU;
     const int cl = cok ? c : 0;
     for (int rb = r0; rb < r1; rb += 4 * NU) {
         float av[NU];
@@ -242,7 +254,7 @@ __device__ __forceinline__ void pj_emb_accum(const PJob& a, int bx, int chunk, f
     if (cbeg >= cc) return;
     if (V == 4) {
         // UC column steps (16 columns each) per batch, all loads issued before the MFMAs (clamped, not predicated)
-        constexpr int UC = 8;
+        constexpr int UC = PJ_UC;
         const int rowc = min(row, R - 1), ic = min(i, K - 1);
         const bool rok = row < R, kok = i < K;
         for (int c0 = cbeg; c0 < cend; c0 += 16 * UC) {
@@ -323,7 +335,7 @@ __global__ __launch_bounds__(256) void pool_emb_det_kernel(PJobs t) {
     if (orow < R && k < K) t.j[0].out[(size_t)orow * K + k] += (fold[0][rr][k] + fold[1][rr][k]) + (fold[2][rr][k] + fold[3][rr][k]);
 }
 
-__global__ __launch_bounds__(256) void pool_jobs_kernel(PJobs t, int fwd_rows, int fwd_mfma) {
+__global__ __launch_bounds__(256, PJ_OCC) void pool_jobs_kernel(PJobs t, int fwd_rows, int fwd_mfma) {
     __shared__ __attribute__((aligned(16))) float fold[4][PG_MAXK][65];
     int p = 0;
     for (int q = 1; q < t.n; ++q) if ((int)blockIdx.x >= t.j[q].blk0) p = q;      // uniform scan of the (scalar) table

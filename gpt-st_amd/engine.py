@@ -322,6 +322,7 @@ def ht_pair_bwd(saved1, saved0, dout, dG1, dG0, dims, dWb1=None):
 
 # ---- cap (GPTST.py:100-141) ----------------------------------------------------------------------------------------
 FUSE_CROSS = os.environ.get("GPTST_FUSE_CROSS", "1") == "1"     # cross-time block folded into its (b,t)-grouped neighbours (r03)
+CAP_LIN = os.environ.get("GPTST_CAP_LIN", "1") == "1"           # ... and the entry Linear's backward folded into the same launch (r05)
 CROSS_ROLE = int(os.environ.get("GPTST_CROSS_ROLE", "1"))       # ... its backward as a ROLE of the routing backward's launch (r04; 0: replicated
                                                                 # prologue; 2: the rec backward as a third role of the same launch — measured
                                                                 # 799 vs 814 steps/s: rec -> cross-time -> routing tail is ONE dependent chain
@@ -408,6 +409,17 @@ def cap_core_bwd(p, g, pfx, saved, dout, dims, HS, HT, red, chain=False):
                                             p[pfx + "mask_template"], B, T, HS, HT, _zeros(x, 5 * B + B * T))
     if fused is None:
         dc1, dv = ops.cap_rec_bwd(drec, c, v, reduce_nodes=CTX.NODE_REDUCE)
+    gw, gb = g[pfx + "ln_p.weight"], g[pfx + "ln_p.bias"]
+    if fused is None and FUSE_CROSS and CAP_LIN and C == 64 and CTX.NODE_REDUCE is None and Y is None:
+        # r05: cross-time backward (role) + routing backward + the entry Linear's backward and the residual branch in ONE launch; dY never leaves LDS
+        lin = ops.cap_cross_route_lin_bwd(x.view(B, T, N, C), p[pfx + "ln_p.weight"], p[pfx + "ln_p.bias"], c, dc1, dv, s, Rt, Ht, dyn,
+                                          p[pfx + "mask_template"], dout, None if chain else out, chain, B, T, HS, HT,
+                                          flags=_zeros(x, 4 * B) if CROSS_ROLE else None)
+        if lin is not None:
+            dx, dWp, dbp, dlogit, ddyn = lin
+            red.jobs.bwd_pool(_ones(dev, BT), dWp, gw.view(1, C * C))
+            red.jobs.bwd_pool(_ones(dev, BT), dbp, gb.view(1, C))
+            return dx, (dWn, ns, (dbn, nsb), ddyn, dlogit)
     if fused is None and FUSE_CROSS and CTX.NODE_REDUCE is None and Y is None:
         fused = ops.cap_cross_route_bwd(x.view(B, T, N, C), p[pfx + "ln_p.weight"], p[pfx + "ln_p.bias"], c, dc1, dv, s, Rt, Ht, dyn,
                                         p[pfx + "mask_template"], B, T, HS, HT, flags=_zeros(x, 4 * B) if CROSS_ROLE else None)
@@ -416,7 +428,6 @@ def cap_core_bwd(p, g, pfx, saved, dout, dims, HS, HT, red, chain=False):
     else:
         dS, ddyn = ops.cap_cross_bwd(dv, s, Rt, Ht, dyn, p[pfx + "mask_template"], B, T, HS, HT)
         dY, dlogit = ops.cap_route_bwd(x.view(B, T, N, C), p[pfx + "ln_p.weight"], p[pfx + "ln_p.bias"], c, dc1, dS, Y=Y)
-    gw, gb = g[pfx + "ln_p.weight"], g[pfx + "ln_p.bias"]
     if C == 64:
         # dx = dY Wp + dout*lrelu'(out), the ln_p weight gradient and its bias gradient in one pass over dY
         dx, dWp, dbp, ns2 = ops.linear_bwd(dY, x, p[pfx + "ln_p.weight"], dout, None if chain else out, premul=chain)

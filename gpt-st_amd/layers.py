@@ -59,6 +59,9 @@ def hypertem(x, node_emb, time_eb, adj, wpool, bpool):
     return HyperTemFn.apply(x, node_emb, time_eb, adj, wpool, bpool)
 
 
+CAP_BWD_ONE_LAUNCH = False      # tests: CapFn.backward through gptst_cap_cross_route_lin_bwd (the fused step's routing backward) instead of the per-kernel calls
+
+
 class CapFn(torch.autograd.Function):
     """cap.forward (reference GPTST.py:100-141).  Returns (out, c (B,T,HS,N) detached, dyn (B,HT,T*HS) detached)."""
 
@@ -102,19 +105,28 @@ class CapFn(torch.autograd.Function):
         ops.poolgen_bwd_emb(dWn, wspa, dne, dbn, bspa, nsplit=ns)
         # scatter, cross-time, soft assignment
         dc1, dv = ops.cap_rec_bwd(drec, c, v)
-        dS, ddyn = ops.cap_cross_bwd(dv, s, Rt, Ht, dyn, tmpl, B, T, HS, HT)
+        lin = None
+        if CAP_BWD_ONE_LAUNCH and C == 64:
+            # cross-time backward + routing backward + the entry Linear's backward and the residual branch as ONE launch (the step's default, r05)
+            lin = ops.cap_cross_route_lin_bwd(x, lnp_w, lnp_b, c, dc1, dv, s, Rt, Ht, dyn, tmpl, dout, out2, False, B, T, HS, HT,
+                                              flags=torch.zeros(4 * B, device=dev))
+        if lin is not None:
+            dx, dWp, dbp_part, dlogit, ddyn = lin
+            dlnp_w, dbp = dWp.view(BT, C, C).sum(0), dbp_part.sum(0, keepdim=True)
+        else:
+            dS, ddyn = ops.cap_cross_bwd(dv, s, Rt, Ht, dyn, tmpl, B, T, HS, HT)
+            dY, dlogit = ops.cap_route_bwd(x, lnp_w, lnp_b, c, dc1, dS)
+            # Linear ln_p: Y = X Wp^T + bp
+            dbp = torch.zeros(1, C, device=dev)
+            dx = ops.apply(dY, lnp_w, MODE_SHARED, BT, N, resid=dout, resid2=out2, epi=ops.EPI_ADD_DPRE, colsum=dbp)
+            dWp, ns2 = ops.wgrad(dY, x2, MODE_SHARED, BT, N)
+            dlnp_w = dWp.view(ns2, C, C).sum(0)
         dt_adj, dtes = torch.zeros_like(t_adj), torch.zeros_like(tes)
         ops.poolgen_bwd_pool(tes, ddyn, dt_adj)
         ops.poolgen_bwd_emb(ddyn, t_adj, dtes)
-        dY, dlogit = ops.cap_route_bwd(x, lnp_w, lnp_b, c, dc1, dS)
         dadj, dteb = torch.zeros_like(adj), torch.zeros_like(teb2)
         ops.poolgen_bwd_pool(teb2, dlogit, dadj)
         ops.poolgen_bwd_emb(dlogit, adj, dteb)
-        # Linear ln_p: Y = X Wp^T + bp
-        dbp = torch.zeros(1, C, device=dev)
-        dx = ops.apply(dY, lnp_w, MODE_SHARED, BT, N, resid=dout, resid2=out2, epi=ops.EPI_ADD_DPRE, colsum=dbp)
-        dWp, ns2 = ops.wgrad(dY, x2, MODE_SHARED, BT, N)
-        dlnp_w = dWp.view(ns2, C, C).sum(0)
         return (dx.view(B, T, N, C), dne, dtes, dteb.view(B, T, ds), dt_adj, dadj, dwspa, dbspa, dlnp_w, dbp.view(C), None, None)
 
 

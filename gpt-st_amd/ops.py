@@ -687,6 +687,31 @@ def cap_cross_route_bwd(X, Wp, bp, c, dc1, dv, s, Rt, Ht, dyn, tmpl, B, T, HS, H
     return dY, dlogit, ddyn
 
 
+def cap_cross_route_lin_bwd(X, Wp, bp, c, dc1, dv, s, Rt, Ht, dyn, tmpl, dPre, out, premul, B, T, HS, HT, flags=None):
+    """cap_cross_route_bwd + linear_bwd in one launch (r05) -> (dX (B*T*N, C), dWp (B*T, C*C), dbp (B*T, C), dlogit, ddyn), or None when the shape
+    needs the separate launches.  dPre: the cap layer's output gradient (already dPre when out is None; premul: dX times lrelu'(X))."""
+    _chk(X, Wp, bp, c, dc1, dv, s, Rt, Ht, dyn, tmpl, dPre, out)
+    N, C = X.shape[2], X.shape[3]
+    if C != 64 or FORCE_CAP_BIG:
+        return None
+    dev = X.device
+    dX = torch.empty(B * T * N, C, device=dev, dtype=torch.float32)
+    dWp = torch.empty(B * T, C * C, device=dev, dtype=torch.float32)
+    dbp = torch.empty(B * T, C, device=dev, dtype=torch.float32)
+    dlogit = torch.empty_like(c)
+    ddyn = torch.empty_like(dyn)
+    try:
+        dS_ws = torch.empty(B * T, HS, C, device=dev, dtype=torch.float32) if flags is not None else None
+        _call("gptst_cap_cross_route_lin_bwd", _p(X), _p(Wp), _p(bp), _p(c), _p(dc1), _p(dv), _p(s), _p(Rt), _p(Ht), _p(dyn), _p(tmpl),
+              _p(dPre), _p(out), int(bool(premul)), _p(dX), _p(dWp), _p(dbp), _p(dlogit), _p(ddyn), _p(dS_ws), _p(flags), B, T, N, C, HS, HT,
+              nbytes=_nb(X, Wp, bp, c, dc1, dv, s, Rt, dPre, out, dX, dWp, dlogit))
+    except _C.GptstError as e:
+        if e.code != _C.ESHAPE:
+            raise
+        return None
+    return dX, dWp, dbp, dlogit, ddyn
+
+
 def cap_rec_cross_route_bwd(drec, v, X, Wp, bp, c, s, Rt, Ht, dyn, tmpl, B, T, HS, HT, flags):
     """cap_rec_bwd + cap_cross_route_bwd as three roles of ONE launch -> (dY, dlogit, ddyn), or None where the role form does not serve.
     flags: 5 B + B T ZEROED 32-bit words."""

@@ -26,7 +26,7 @@ extern "C" {
 #pragma GCC visibility push(default)
 #endif
 
-#define GPTST_ABI_VERSION 10  /* 9, 10 (r04, late): + gptst_hypertem_bwd_pair, gptst_cap_rec_cross_route_bwd, gptst_mask_*_u24, gptst_pool_jobs_gram_rows, gptst_handoff_timeouts; gptst_fusion_gate_fwd/bwd */
+#define GPTST_ABI_VERSION 11  /* 11 (r05): + gptst_cap_cross_route_lin_bwd, gptst_comm_available; 9, 10 (r04, late): + gptst_hypertem_bwd_pair, gptst_cap_rec_cross_route_bwd, gptst_mask_*_u24, gptst_pool_jobs_gram_rows, gptst_handoff_timeouts; gptst_fusion_gate_fwd/bwd */
 int gptst_abi_version(void);
 /* 1: bit-reproducible steps — the two reductions that end in float atomics by default (embedding gradients of gptst_pool_jobs kind 2,
  * weight gradients of gptst_timefeat_jobs) run as single-owner kernels with a fixed summation order (slower).  Everything else is
@@ -239,6 +239,15 @@ int gptst_cap_route_bwd(const float* X, const float* Wp, const float* bp, const 
 int gptst_cap_cross_route_bwd(const float* X, const float* Wp, const float* bp, const float* c, const float* dc1, const float* dv,
                               const float* s, const float* Rt, const float* Ht, const float* dyn, const float* tmpl, float* dY,
                               float* dlogit, float* ddyn, float* dS_ws, void* flags, int B, int T, int N, int C, int HS, int HT, void* stream);
+/* r05 — gptst_cap_cross_route_bwd + gptst_linear_bwd in ONE launch: each (b,t) workgroup goes on from its dY tile (kept in LDS; no dY tensor exists) to
+ * the backward of cap's entry Linear (GPTST.py:102) and the layer's residual branch (:139-141):
+ *   out == NULL: dX = dY Wp + dPre (the incoming gradient already is dPre), times lrelu'(X) when premul;   out given: dX = dY Wp + dPre*lrelu'(out).
+ *   dWp (B*T, C*C) [out][in] and dbp (B*T, C): ONE partial per (b,t) — the caller's reduction sums B*T rows.
+ * dlogit, ddyn, dS_ws, flags as gptst_cap_cross_route_bwd.  C = 64, else GPTST_ESHAPE (use the two calls). */
+int gptst_cap_cross_route_lin_bwd(const float* X, const float* Wp, const float* bp, const float* c, const float* dc1, const float* dv,
+                                  const float* s, const float* Rt, const float* Ht, const float* dyn, const float* tmpl,
+                                  const float* dPre, const float* out, int premul, float* dX, float* dWp, float* dbp, float* dlogit,
+                                  float* ddyn, float* dS_ws, void* flags, int B, int T, int N, int C, int HS, int HT, void* stream);
 /* gptst_cap_rec_bwd + gptst_cap_cross_route_bwd in ONE launch of three roles (r04): block order [rec backward (b,t)] [cross-time (sample, part)]
  * [routing (b,t)], every wait points to a lower block index.  drec (B*T, N, C) gradient of the scatter output, v (B*T, HS, C) -> dY, dlogit, ddyn.
  * Workspaces: dc1_ws (B*T, HS, N), dv_ws (B*T, HS, C), dS_ws (B*T, HS, C), flags (5 B + B*T 32-bit words, ZERO on entry).  GPTST_ESHAPE where

@@ -226,8 +226,12 @@ def _cap_case(B, N, C, d, ds, HS, HT, seed):
 
 @pytest.mark.parametrize("B,N,d,ds,HS,HT,R", [(2, 20, 8, 4, 5, 6, 3), (2, 170, 16, 4, 10, 16, 2), (1, 33, 4, 3, 16, 5, 0),
                                               (1, 41, 4, 4, 20, 8, 2)])
-def test_cap_layer(B, N, d, ds, HS, HT, R):
+@pytest.mark.parametrize("one_launch", [False, True], ids=["kernels", "route_lin_bwd"])
+def test_cap_layer(B, N, d, ds, HS, HT, R, one_launch, monkeypatch):
+    """one_launch (r05): the backward through gptst_cap_cross_route_lin_bwd — cross-time role + routing backward + the entry Linear's backward in one
+    launch, the fused step's default — against the ORACLE (dx, ln_p weight / bias, cluster-logit and cross-time-graph gradients)."""
     from gptst_amd import layers
+    monkeypatch.setattr(layers, "CAP_BWD_ONE_LAUNCH", one_launch)
     dev = _dev()
     C, T = 64, 12
     ts, go = _cap_case(B, N, C, d, ds, HS, HT, 21)
@@ -1038,6 +1042,42 @@ def test_cap_cross_folded_into_its_neighbours(B, N, HS, HT):
             break
         for a, b_, nm in zip(f3, ref, ("dY", "dlogit", "ddyn")):
             assert torch.equal(a, b_), "three-role form differs in %s (rep %d)" % (nm, rep)
+
+
+@pytest.mark.parametrize("mode", ["out", "dpre", "dpre_premul"])
+@pytest.mark.parametrize("B,N,HS,HT", [(32, 170, 10, 16), (2, 50, 5, 6), (3, 37, 16, 5), (2, 207, 10, 16)])
+def test_cap_route_lin_bwd_equals_route_bwd_plus_linear_bwd(B, N, HS, HT, mode):
+    """r05: gptst_cap_cross_route_lin_bwd == gptst_cap_cross_route_bwd + gptst_linear_bwd.  dX runs the same MFMA chain on the same operands
+    (bit-identical); the weight / bias gradient comes as ONE partial per (b,t) summed over its nodes in order (510 row splits folded over four waves
+    before): compared after the reduction, 2e-6 of the tensor scale."""
+    from gptst_amd import ops
+    dev = _dev()
+    g = torch.Generator().manual_seed(73)
+    C, T = 64, 12
+    s = rnd(B * T, HS, C, g=g).to(dev)
+    dyn = (rnd(B, HT, T * HS, g=g) * 0.3).to(dev)
+    tmpl = (torch.arange(1, T + 1) / 12.0).float().to(dev)
+    c = torch.softmax(rnd(B * T, HS, N, g=g), 1).to(dev).contiguous()
+    _, Ht, Rt = ops.cap_cross_fwd(s, dyn, tmpl, B, T, HS, HT)
+    X = rnd(B, T, N, C, g=g).to(dev)
+    Wp, bp = (rnd(C, C, g=g) * 0.1).to(dev), rnd(C, g=g).to(dev)
+    dc1, dv = rnd(B * T, HS, N, g=g).to(dev), rnd(B * T, HS, C, g=g).to(dev)
+    dout, out = rnd(B * T * N, C, g=g).to(dev), rnd(B * T * N, C, g=g).to(dev)
+    ref = ops.cap_cross_route_bwd(X, Wp, bp, c, dc1, dv, s, Rt, Ht, dyn, tmpl, B, T, HS, HT, flags=torch.zeros(4 * B, device=dev))
+    if ref is None:
+        pytest.skip("the one-launch routing backward does not serve this shape")
+    dY, dl1, ddyn1 = ref
+    o_, pm = (out, False) if mode == "out" else (None, mode == "dpre_premul")
+    dX1, dWp1, dbp1, ns = ops.linear_bwd(dY, X.view(-1, C), Wp, dout, o_, premul=pm)
+    for rep in range(2):
+        for flags in (torch.zeros(4 * B, device=dev), None):          # cross-time backward as a role / as a prologue
+            r = ops.cap_cross_route_lin_bwd(X, Wp, bp, c, dc1, dv, s, Rt, Ht, dyn, tmpl, dout, o_, pm, B, T, HS, HT, flags=flags)
+            assert r is not None
+            dX2, dWp2, dbp2, dl2, ddyn2 = r
+            assert torch.equal(dl2, dl1) and torch.equal(ddyn2, ddyn1)
+            assert torch.equal(dX2, dX1), float((dX2 - dX1).abs().max())
+            close(dWp2.sum(0), dWp1.sum(0).cpu(), tol=2e-6, what="route_lin dWp")
+            close(dbp2.sum(0), dbp1.sum(0).cpu(), tol=2e-6, what="route_lin dbp")
 
 
 @pytest.mark.parametrize("B,N", [(32, 170), (3, 37), (9, 16)])
