@@ -19,3 +19,18 @@ extern "C" int gptst_handoff_timeouts(int* out) {
     *out = (int)(a + b);
     return GPTST_OK;
 }
+
+// Clears the expiry counters (synchronises with the device): the host calls it once it has dealt with a lost hand-off — until then the optimiser
+// skips every update (gptst_clip_adam's guard), so that a poisoned gradient never reaches the weights.
+GPTST_INTERNAL int gptst_handoff_clear_capmfma(unsigned to);
+GPTST_INTERNAL int gptst_handoff_clear_hypertem(unsigned to);
+extern "C" int gptst_handoff_reset(void) {
+    if (hipDeviceSynchronize() != hipSuccess) return -5;
+    return (gptst_handoff_clear_capmfma(0u) || gptst_handoff_clear_hypertem(0u)) ? -5 : GPTST_OK;
+}
+// (include/gptst_hip_testing.h)
+extern "C" int gptst_handoff_inject(int n) {
+    if (n < 0) return GPTST_EARG;
+    if (hipDeviceSynchronize() != hipSuccess) return -5;
+    return gptst_handoff_clear_capmfma((unsigned)n) ? -5 : GPTST_OK;
+}

@@ -707,6 +707,7 @@ __global__ __launch_bounds__(CM_NT, 4) void cap_route_bwd2_kernel(const float* _
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
         if (tid == 0) {
+            gptst_publish_fence();
             __hip_atomic_store(cx.flags + cx.nB + cx.B + bt, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             __hip_atomic_fetch_add(cx.flags + cx.nB + bt / cx.T, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
@@ -726,7 +727,7 @@ __global__ __launch_bounds__(CM_NT, 4) void cap_route_bwd2_kernel(const float* _
                                                     (blk % CX_SPLIT) * TS, TS, cx.T, HS, cx.HT, cx.dSg);
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");            // every storing wave drains its write-through stores ...
         __syncthreads();
-        if (tid == 0) __hip_atomic_store(cx.flags + blk, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);     // ... before the flag goes up
+        if (tid == 0) { gptst_publish_fence(); __hip_atomic_store(cx.flags + blk, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }     // ... before the flag goes up
         GPTST_STAMP(1); GPTST_WG_END();
         return;
     }

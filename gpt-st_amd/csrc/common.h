@@ -77,6 +77,22 @@ __device__ __forceinline__ float ld_agent(const float* p) { return __hip_atomic_
 // bytes): sc1 = agent scope, i.e. the store is written through to memory and the load does not trust another XCD's stale L2 line.  A producer
 // follows its stores with `s_waitcnt vmcnt(0)` + __syncthreads() and one relaxed agent-scope flag store (MI355X_MICROARCH.md, inter-workgroup
 // visibility); the consumer polls the flag with ONE lane, relaxed, BOUNDED, then loads with ld4_sc1.
+// Publish / consume fences of the hand-offs.  The protocol in use is the one MI355X_MICROARCH.md lists as valid without a fence pair: payload written
+// THROUGH (sc1 stores), every storing wave drains vmcnt, a barrier, one relaxed agent-scope flag store; the consumer polls relaxed with one lane and
+// reads the payload with sc1 loads ("sc1 loads may replace the acquire only when the producer stored sc1").  -DGPTST_HANDOFF_FENCES adds the
+// release / acquire pair on top (buffer_wbl2 sc1 + s_waitcnt in the publishing lane, buffer_inv sc1 in the polling lane) — the form VERDICT r04
+// asked for; its measured cost is in DESIGN.md section 10 (the release writes back every dirty L2 line of the XCD, i.e. the kernel's own output).
+__device__ __forceinline__ void gptst_publish_fence() {
+#ifdef GPTST_HANDOFF_FENCES
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#endif
+}
+__device__ __forceinline__ void gptst_consume_fence() {
+#ifdef GPTST_HANDOFF_FENCES
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+#endif
+}
 // Bounded wait of ONE lane for a hand-off word written by another workgroup of the same launch: relaxed agent-scope polls, s_sleep between
 // them, and a WALL-CLOCK bound (2 s of the 100 MHz counter) — a spin COUNT is not a time: when another process shares the GPU its time
 // slices stall the producer while the consumer's polls keep counting (4000 polls expired about once in four runs of the two-ranks-on-one-GPU
@@ -86,7 +102,7 @@ __device__ __forceinline__ bool gptst_wait_ge(const unsigned* p, unsigned want, 
     for (;;) {
 #pragma unroll 1
         for (int i = 0; i < 64; ++i) {
-            if (__hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= want) return true;
+            if (__hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= want) { gptst_consume_fence(); return true; }
             __builtin_amdgcn_s_sleep(8);
         }
         if (wall_clock64() - t0 > 200000000LL) { atomicAdd(lost, 1u); return false; }      // 2 s
@@ -98,6 +114,14 @@ __device__ __forceinline__ bool gptst_wait_ge(const unsigned* p, unsigned want, 
     __device__ unsigned g_handoff_lost_##unit = 0u;                                                  \
     GPTST_INTERNAL int gptst_handoff_lost_##unit(unsigned* out) {                                    \
         return hipMemcpyFromSymbol(out, HIP_SYMBOL(g_handoff_lost_##unit), sizeof(unsigned)) == hipSuccess ? 0 : 1;   \
+    }                                                                                                \
+    GPTST_INTERNAL const unsigned* gptst_handoff_word_##unit(void) {      /* device address of the counter (the optimiser's guard reads it) */ \
+        void* p_ = nullptr;                                                                          \
+        return hipGetSymbolAddress(&p_, HIP_SYMBOL(g_handoff_lost_##unit)) == hipSuccess ? (const unsigned*)p_ : nullptr;   \
+    }                                                                                                \
+    GPTST_INTERNAL int gptst_handoff_clear_##unit(unsigned to) {                                     \
+        const unsigned z_ = to;                                                                      \
+        return hipMemcpyToSymbol(HIP_SYMBOL(g_handoff_lost_##unit), &z_, sizeof(unsigned)) == hipSuccess ? 0 : 1;   \
     }
 typedef int gptst_i32x4 __attribute__((ext_vector_type(4)));
 typedef float gptst_f32x4 __attribute__((ext_vector_type(4)));

@@ -808,7 +808,7 @@ __global__ __launch_bounds__(256, 2) void hypertem_bwd_pair_kernel(HtPairArgs a,
         hypertem_bwd_stage<false, true, 1>(a.dOut1, nullptr, a.X1, a.G1, a.Wbt1, a.dXmid, nullptr, a.dG1, N, B, 0, b, tile, smem, dp);
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");             // this wave's write-through stores of dPre_L have left ...
         __syncthreads();                                              // ... (all waves; and the dG phase is done with the LDS slab)
-        if (threadIdx.x == 0) __hip_atomic_fetch_add(a.cnt + b, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (threadIdx.x == 0) { gptst_publish_fence(); __hip_atomic_fetch_add(a.cnt + b, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
         GPTST_STAMP(5);
         hypertem_bwd_stage<false, true, 2>(nullptr, nullptr, a.X0, a.G0, a.Wbt0, a.dX0, nullptr, a.dG0, N, B, 0, b, tile, smem, dp);
         GPTST_WG_END();

@@ -138,9 +138,15 @@ __global__ __launch_bounds__(256) void gradnorm_kernel(const float* __restrict__
 // parts there; otherwise 0); on exit (written by workgroup 0): the total squared gradient norm.
 __global__ __launch_bounds__(256) void adam_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m,
                                                    float* __restrict__ v, long nA, long nB, const float* __restrict__ hyper,
-                                                   float* __restrict__ stats, const float* __restrict__ ws, int nws, float* __restrict__ stats_out) {
+                                                   float* __restrict__ stats, const float* __restrict__ ws, int nws, float* __restrict__ stats_out,
+                                                   const unsigned* __restrict__ lost0, const unsigned* __restrict__ lost1) {
     __shared__ float red[4];
     __shared__ float redB[4];
+    // guard (r05): a bounded in-launch hand-off that expired somewhere in this step poisoned a gradient with NaN (gptst_wait_ge).  The update is
+    // then SKIPPED — weights and moments stay as they were — and the count goes out in stats_out[5]; the host re-runs the step on the launches
+    // without hand-offs (step.py) instead of losing the run.  The counters stay up (every later step is skipped too) until gptst_handoff_reset().
+    // (stats[5]: the count gptst_stats_fold put in front of a gradient all-reduce — the sum over the ranks, so that all of them skip together)
+    const unsigned nlost = (lost0 != nullptr ? *lost0 : 0u) + (lost1 != nullptr ? *lost1 : 0u) + ((lost0 != nullptr && stats[5] > 0.f) ? (unsigned)stats[5] : 0u);
     {   // every workgroup folds the gradient-norm partials (per segment, unscaled) in the same fixed order
         float sA = (int)threadIdx.x < nws ? ws[2 * threadIdx.x] : 0.f, sB = (int)threadIdx.x < nws ? ws[2 * threadIdx.x + 1] : 0.f;
         sA = group_sum<64>(sA); sB = group_sum<64>(sB);
@@ -158,7 +164,7 @@ __global__ __launch_bounds__(256) void adam_kernel(float* __restrict__ p, const 
     float clip = 1.f;
     if (maxn > 0.f) clip = fminf(1.f, maxn / (sqrtf(gsq) + 1e-6f));               // clip_grad_norm_
     const float sa = seg_scale(hyper, stats, true) * clip, sb = seg_scale(hyper, stats, false) * clip;
-    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256) {
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n && nlost == 0u; i += (long)gridDim.x * 256) {
         const bool A = i < nA;
         const float gr = g[i] * (A ? sa : sb);
         const float step = A ? hyper[0] : hyper[2], bc2 = A ? hyper[1] : hyper[3];
@@ -172,7 +178,8 @@ __global__ __launch_bounds__(256) void adam_kernel(float* __restrict__ p, const 
     // (stats[3] is rewritten only after every workgroup has read it: the caller's next kernel boundary orders that — here the
     // total goes to stats[4], which nobody reads inside this launch)
     if (blockIdx.x == 0 && threadIdx.x == 0) stats[4] = gsq;
-    if (stats_out != nullptr && blockIdx.x == 0 && threadIdx.x < 8) stats_out[threadIdx.x] = threadIdx.x == 4 ? gsq : stats[threadIdx.x];
+    if (stats_out != nullptr && blockIdx.x == 0 && threadIdx.x < 8)
+        stats_out[threadIdx.x] = threadIdx.x == 4 ? gsq : threadIdx.x == 5 ? (float)nlost : stats[threadIdx.x];
 }
 
 extern "C" int gptst_mae_fwd(const float* out, const float* src, int lda, const float* mask, float sigma, float mu, float thresh,
@@ -208,6 +215,13 @@ extern "C" int gptst_clip_adam_ws_floats(void) { return 2 * GN_NB; }
 // total squared gradient norm (after scaling, before clipping).  No atomics: the norm is folded in a fixed order.
 // sws (may be NULL) / sws_rows: the step's per-workgroup loss statistics, folded into stats[0..2] (+=) by the first launch — replaces a
 // separate gptst_stats_fold when nothing (a gradient all-reduce) has to see the folded statistics in between.
+GPTST_INTERNAL const unsigned* gptst_handoff_word_capmfma(void);
+GPTST_INTERNAL const unsigned* gptst_handoff_word_hypertem(void);
+static int g_handoff_guard = 1;
+// 1 (default): gptst_clip_adam skips the update while a hand-off expiry is on record (see adam_kernel);  0: the update always runs (a lost
+// hand-off then shows as NaN weights, the pre-r05 behaviour).  Process-wide.
+extern "C" int gptst_set_handoff_guard(int on) { g_handoff_guard = on ? 1 : 0; return GPTST_OK; }
+
 extern "C" int gptst_clip_adam(float* p, const float* g, float* m, float* v, long nA, long nB, const float* hyper, float* stats,
                                float* ws, float* stats_out, const float* sws, int sws_rows, void* stream) {
     if (!p || !g || !m || !v || !hyper || !stats || !ws || (sws && sws_rows <= 0)) return GPTST_EARG;
@@ -215,7 +229,10 @@ extern "C" int gptst_clip_adam(float* p, const float* g, float* m, float* v, lon
     int nb = (int)((n + 255) / 256); if (nb > 1024) nb = 1024;
     const int nbn = nb > GN_NB ? GN_NB : nb;
     hipLaunchKernelGGL(gradnorm_kernel, dim3(nbn), dim3(256), 0, (hipStream_t)stream, g, nA, nB, hyper, stats, ws, sws, sws_rows);
-    hipLaunchKernelGGL(adam_kernel, dim3(nb), dim3(256), 0, (hipStream_t)stream, p, g, m, v, nA, nB, hyper, stats, (const float*)ws, nbn, stats_out);
+    static const unsigned* w0 = gptst_handoff_word_capmfma();         // (device addresses: looked up once, outside any graph capture — the steppers warm up first)
+    static const unsigned* w1 = gptst_handoff_word_hypertem();
+    hipLaunchKernelGGL(adam_kernel, dim3(nb), dim3(256), 0, (hipStream_t)stream, p, g, m, v, nA, nB, hyper, stats, (const float*)ws, nbn, stats_out,
+                       g_handoff_guard ? w0 : nullptr, g_handoff_guard ? w1 : nullptr);
     GPTST_CHECK_LAUNCH();
     return GPTST_OK;
 }

@@ -4,6 +4,7 @@ Every ``*_fwd`` returns ``(outputs..., saved)`` and every ``*_bwd`` ACCUMULATES 
 gradient dict ``g`` (views into one flat buffer) and returns the input gradients.  ``p`` / ``g`` map the reference's
 state_dict keys to tensors.  Citations: reference model/Pretrain_model/GPTST.py.
 """
+import contextlib
 import os
 import threading
 
@@ -275,7 +276,21 @@ def hypertem_core_bwd(saved, dout, dG_out, dims, chain=False, premul=False):
     return dx, (dWbt, ns, (dbias, nsb))
 
 
+PAIR_UNDER_DP = os.environ.get("GPTST_PAIR_UNDER_DP", "1") == "1"    # the decoder-hyperTem1 / encoder-hyperTem4 pair also when the decoder's gradient bucket leaves early (r05)
 PAIR_BWD = os.environ.get("GPTST_PAIR_BWD", "1") == "1"        # two adjacent hyperTem layers' backward in one launch (r04)
+
+
+@contextlib.contextmanager
+def no_handoffs():
+    """Enqueue (or capture) the step without launches in which one workgroup waits for another (the hyperTem backward pairs, the cross-time role
+    of the routing backward): what a stepper falls back to after a bounded wait expired (step.py::_enter_safe_mode)."""
+    global PAIR_BWD, CROSS_ROLE
+    keep = (PAIR_BWD, CROSS_ROLE)
+    PAIR_BWD, CROSS_ROLE = False, 0
+    try:
+        yield
+    finally:
+        PAIR_BWD, CROSS_ROLE = keep
 
 
 def _ht_pair_shape_ok(dims):
@@ -360,7 +375,7 @@ CHAIN_NODE = os.environ.get("GPTST_CHAIN_NODE", "0") == "1"      # also the caps
 
 
 def chain_fwd_ok(dims):
-    return CHAIN_FWD and dims[3] == 64 and CTX.NODE_REDUCE is None and CTX.SIDE is None and not DROP_R
+    return CHAIN_FWD and dims[3] == 64 and CTX.SIDE is None and not DROP_R      # (node shards too: the chained layers are node-local, r05)
 
 
 def ht_chain_fwd(x, stages, dims):
@@ -624,7 +639,7 @@ def _grad_buffers(red, slot, N, T, HmT, ref, nsG):
     return red._dG[4 * k:4 * k + 4], red._dA[4 * k:4 * k + 4]
 
 
-def sthcn_bwd(p, g, pfx, tidx, sv, dout, dims, red, chain=False, premul_in=False, defer_h1=False):
+def sthcn_bwd(p, g, pfx, tidx, sv, dout, dims, red, chain=False, premul_in=False, defer_h1=False, after_pending=None):
     """chain: dout already is dPre of the last layer and every layer hands dPre down;  premul_in (chain only): the returned input gradient
     is multiplied by lrelu'(input) — True when the STHCN's input is itself a LeakyReLU output (the decoder's: the encoder embedding).
     defer_h1 (chain, premul_in): hyperTem1's backward is NOT run — a PendingH1 is returned and the STHCN below runs it in the pair launch
@@ -641,6 +656,8 @@ def sthcn_bwd(p, g, pfx, tidx, sv, dout, dims, red, chain=False, premul_in=False
         up = dout
         dd, _, hp4 = ht_pair_bwd(up.saved, sv["h4"], up.dd, up.dG, dG_all[3], dims, dWb1=up.dWb)
         red.keep.append(up)
+        if after_pending is not None:               # the STHCN above is complete only now (data parallel: its gradient bucket closes here)
+            after_pending()
     else:
         dd, hp4 = hypertem_core_bwd(sv["h4"], dout, dG_all[3], dims, chain, True)
     dd, cp2 = cap_core_bwd(p, g, cps[1], sv["c2"], dd, dims, HS, HT, red, chain)
@@ -719,7 +736,7 @@ ENCIN = os.environ.get("GPTST_ENCIN", "1") == "1"
 
 def encin_ok(dims, base):
     """input projection + encoder hyperTem1 as one rank-2 kernel pair (encin.hip): base = 1 and the dPre chain in the backward"""
-    return ENCIN and base == 1 and dims[3] in (64, 128) and dims[1] == 12 and chain_ok(dims) and CTX.NODE_REDUCE is None
+    return ENCIN and base == 1 and dims[3] in (64, 128) and dims[1] == 12 and chain_ok(dims)       # node-local: serves node shards too (r05)
 
 
 GUIDEIN = os.environ.get("GPTST_GUIDEIN", "1") == "1"
@@ -883,11 +900,16 @@ def model_bwd(p, g, source, mask, tidx, sv_e, sv_d, dec, d_out, d_dec, dims, bas
         ops.rowouter(d_out, base, base, dec, g[wo + "weight"], 1, asum=g[wo + "bias"])
     # the decoder's hyperTem1 and the encoder's hyperTem4 are adjacent (GPTST.py:271 -> :454): one pair launch, unless the decoder's gradient
     # bucket must be complete when its backward ends (data-parallel overlap / a side stream flush the decoder's reductions right here)
-    defer = (chain and red.side is None and red.on_bucket is None and not isinstance(sv_d["h1"], EncIn)
+    # r05: also under the data-parallel bucket overlap — the decoder's bucket then closes ONE LAUNCH later, behind the pair launch that finishes its
+    # first layer (the bucket's reductions and its forked all-reduce still run under the rest of the encoder's backward)
+    defer = (chain and red.side is None and (red.on_bucket is None or PAIR_UNDER_DP) and not isinstance(sv_d["h1"], EncIn)
              and ht_pair_ok(sv_d["h1"], sv_e["h4"], dims))
+    late = defer and red.on_bucket is not None
     d_emb = sthcn_bwd(p, g, DEC, tidx, sv_d, dd, dims, red, chain, True, defer_h1=defer)     # the decoder's input is the encoder's last LeakyReLU output
-    red.flush_async(tidx)                                   # the decoder's reductions overlap with the encoder's backward chain
-    d_x0 = sthcn_bwd(p, g, ENC, tidx, sv_e, d_emb, dims, red, chain, False)  # the encoder's input is a plain Linear: no premultiplication
+    if not late:
+        red.flush_async(tidx)                               # the decoder's reductions overlap with the encoder's backward chain
+    d_x0 = sthcn_bwd(p, g, ENC, tidx, sv_e, d_emb, dims, red, chain, False,  # the encoder's input is a plain Linear: no premultiplication
+                     after_pending=(lambda: red.flush_async(tidx)) if late else None)
     red.flush_async(tidx)                                   # ... and the encoder's with the guide's
     if d_x0 is not None:                                    # (None: the low-rank first layer produced the input-projection gradient itself)
         _in_proj_grads(source, base, d_x0, g["encoder.dim_in_flow.weight"], g["encoder.dim_in_flow.bias"], mask, scaler_zeros, red)

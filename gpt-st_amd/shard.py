@@ -18,12 +18,13 @@ how the tests check the protocol against the unsharded step).  A group whose col
 (``capturable``: world = 1, or NativeNodeGroup) lets the whole step — kernels AND collectives — be captured in ONE hipGraph per phase
 (``use_graph``); otherwise the step is enqueued eagerly, the collectives sitting between the kernels.
 """
+import os
 import threading
 
 import torch
 
 from . import engine, ops
-from .step import PretrainStep
+from .step import PretrainStep, U24
 
 
 def is_node_local(key):
@@ -159,7 +160,11 @@ class ShardedPretrainStep(PretrainStep):
         super().__init__(model_local, args_local, scaler_mean, scaler_std, batch_size, use_graph=False, dp=None, seed=seed)
         self.shard_graph = bool(getattr(group, "capturable", False)) if use_graph is None else bool(use_graph)
         assert not self.shard_graph or getattr(group, "capturable", False), "this group's collectives cannot be captured"
-        self.fused_tails = False                            # the loss statistics travel in the gradient buffer (one all-reduce)
+        # r05: the node-local part of the step is the fused step's — loss / KL heads with their backward in one pass each (their per-workgroup
+        # statistics are folded into the gradient buffer's tail BEFORE the all-reduce), the dPre chain, hyperTem forward chains and backward
+        # pairs, the low-rank first layers.  Only the cluster aggregations of cap keep their all-reduce form (engine.CTX.NODE_REDUCE).
+        self.fused_tails = (os.environ.get("GPTST_FUSED_TAILS", "1") == "1" and os.environ.get("GPTST_SHARD_FUSED", "1") == "1"
+                            and engine.fused_tails_ok(model_local.param_views(), self.C, self.base, self.HS))
         self.group, self.Ng = group, n_global
         self.Nl = args_local.num_nodes
         assert self.Nl * group.world == n_global, "equal node shards"
@@ -167,35 +172,46 @@ class ShardedPretrainStep(PretrainStep):
         Mg = self.B * self.T * self.Ng
         torch.cuda.manual_seed(7654321 + seed)              # identical global mask noise on every rank
         self.noise_g = torch.zeros(Mg * self.base, device=self.dev)
-        self.noise_a_g, self.noise_r_g = torch.zeros(Mg, device=self.dev), torch.zeros(Mg, device=self.dev)
+        self.noise_ar_g = torch.zeros(2 * Mg, device=self.dev)      # adaptive phase: [noise_a | noise_r] over the GLOBAL cells, drawn by ONE launch
+        self.noise_a_g, self.noise_r_g = self.noise_ar_g[:Mg], self.noise_ar_g[Mg:]
         self.tail = None                                    # single stream: collectives order against everything
         self.global_count_scale = True
         named = dict(model_local.named_parameters())
         self.local_keys = [k for k in named if is_node_local(k)]
         self.repl_keys = [k for k in named if is_replicated_compute(k)]
         self.segA = {k: model_local._offs[k] < model_local.nA for k in self.local_keys}
+        # node-local gradients are kept out of the gradient all-reduce by a save / restore around it: ONE flat buffer, [reconstruction-path keys |
+        # KL-path keys], moved by multi-tensor copies (r05: a clone, a copy and three norm launches PER KEY before — ~95 tiny launches per step)
+        ordered = [k for k in self.local_keys if self.segA[k]] + [k for k in self.local_keys if not self.segA[k]]
+        sizes = [named[k].numel() for k in ordered]
+        self.keep_flat = torch.zeros(sum(sizes), device=self.dev)
+        self.keep_nA = sum(n for k, n in zip(ordered, sizes) if self.segA[k])
+        offs = [sum(sizes[:i]) for i in range(len(sizes))]
+        self.keep_views = [self.keep_flat[o:o + n].view(named[k].shape) for k, o, n in zip(ordered, offs, sizes)]
+        self.keep_grads = [self.g[k] for k in ordered]
+        self.repl_grads = [self.g[k] for k in self.repl_keys]
 
     # global mask -> this rank's node columns
     def _cols(self, flat_global, per_cell):
         return flat_global.view(self.B, self.T, self.Ng, per_cell)[:, :, self.n0:self.n0 + self.Nl].contiguous().view(-1)
 
-    def _mask(self, phase, prob):
+    def _mask(self, phase, prob, label=None):
+        """label: the guide's argmax labels of the local cells (rowdot's by-product) — else taken from prob"""
         a, base = self.args, self.base
         Mg = self.B * self.T * self.Ng
-        if not self.inject_noise:
-            if phase == 0:
-                self.noise_g.uniform_()
-            else:
-                self.noise_a_g.uniform_(); self.noise_r_g.uniform_()
+        ws = self.arena.zeros(ops.mask_ws_floats())        # the selections' histogram scratch: zeroed by the step's first launch
         if phase == 0:
-            mask_g = ops.mask_random(self.noise_g, int(Mg * base * a.mask_ratio))
+            mask_g = ops.mask_random(self.noise_g, int(Mg * base * a.mask_ratio), ws=ws, u24=U24)
         else:
-            label, counts = ops.mask_labels(prob)                                          # local cells (B,T,Nl)
-            lab = self.group.all_gather(label.view(self.B, self.T, self.Nl))               # (W,B,T,Nl)
-            label_g = lab.permute(1, 2, 0, 3).contiguous().view(-1)                        # (B,T,N) node-major within a cell row
-            self.group.all_reduce_(counts)
-            mask_g = ops.mask_adaptive(label_g, counts, self.ctrl[:self.HS], self.ctrl[self.HS:], self.noise_a_g, self.noise_r_g,
-                                       a.ada_type == "all", base)[2]
+            if label is None:
+                label = ops.mask_labels(prob)[0]                                               # local cells (B,T,Nl)
+            if self.group.world == 1:
+                label_g = label.view(-1)
+            else:
+                lab = self.group.all_gather(label.view(self.B, self.T, self.Nl))               # (W,B,T,Nl)
+                label_g = lab.permute(1, 2, 0, 3).contiguous().view(-1)                        # (B,T,N) node-major within a cell row
+            mask_g = ops.mask_adaptive(label_g, None, self.ctrl[:self.HS], self.ctrl[self.HS:], self.noise_a_g, self.noise_r_g,
+                                       a.ada_type == "all", base, ws=ws, u24=U24)[2]           # (class histogram of the gathered labels: taken inside)
         self.last_mask_global = mask_g
         return self._cols(mask_g, base)
 
@@ -240,52 +256,78 @@ class ShardedPretrainStep(PretrainStep):
         torch.cuda.synchronize()
 
     def _sbody(self, phase):
+        if not self.safe_mode:
+            return self._sbody_impl(phase)
+        with engine.no_handoffs():
+            return self._sbody_impl(phase)
+
+    def _sbody_impl(self, phase):
         """The device side of one step: kernels and collectives in stream order (eager, or inside a capture)."""
         mdl, a, base, dims = self.model, self.args, self.base, self.dims
         p, g = mdl.param_views(), self.g
         M = self.B * self.T * self.Nl
-        self.gbuf.zero_()
         ctx = engine.CTX
         ctx.ARENA, ctx.SIDE, ctx.NODE_REDUCE = self.arena, None, self.group.all_reduce_
         try:
-            self.arena.begin()
             src = self.src
-            tidx = src[:, :, 0, base:base + 2].contiguous()       # every node carries the same time index (GPTST.py:256-257 uses node 0)
-            gen = engine.gen_all(p, tidx, dims)
+            # zero_grad + the step's zero scratch + the time index (every node carries the same one, GPTST.py:256-257) + the GLOBAL mask noise
+            # (Philox keyed by [seed, step]: identical on every rank) in ONE launch
+            noise = None if self.inject_noise else (self.noise_g if phase == 0 else self.noise_ar_g)
+            tidx = ops.step_begin(self.gbuf, self.arena.begin(zero=False), src, base, noise=noise, rng=self.rng_words)
+            fused = self.fused_tails
+            chain = fused and engine.chain_ok(dims)                # dPre chain: no backward kernel re-reads its layer's output
+            need_guide = phase == 1 or not fused                   # (the fused form skips the classifier in the random-mask phase, as step.py does)
+            gen = engine.gen_all(p, tidx, dims, guide=need_guide)
             red = engine.Reductions()
-            prob, sv_g = engine.guide_fwd(p, src, tidx, dims, base, gen=gen["guide"])
-            mask = self._mask(phase, prob)
+            prob, sv_g = engine.guide_fwd(p, src, tidx, dims, base, gen=gen["guide"], lowrank_in=chain) if need_guide else (None, None)
+            mask = self._mask(phase, prob, sv_g[4] if sv_g is not None else None)
             self.last_mask = mask
-            emb, c1, tidx, sv_e = engine.model_fwd(p, src, mask, dims, base, mdl.num_route, mdl.scaler_zeros, gen=gen[engine.ENC], tidx=tidx)
-            out, dec, sv_d = engine.decoder_fwd(p, tidx, emb, dims, mdl.num_route, gen=gen[engine.DEC])
-            ops.mae_fwd(out, src, base + 2, mask, self.std, self.mean, a.mape_thresh, M, base, self.stats)
-            d_out = ops.mae_bwd(out, src, base + 2, mask, self.std, self.mean, a.mape_thresh, M, base, self.stats, normalize=False)
-            engine.model_bwd(p, g, src, mask, tidx, sv_e, sv_d, dec, d_out, None, dims, base, mdl.scaler_zeros, red)
-            if phase == 1:
-                dlogit = ops.kl(prob, c1, self.Nl, 0.1, self.stats)
-                engine.guide_bwd(p, g, src, tidx, sv_g, dlogit, dims, base, red)
+            if fused:
+                dec_head = None
+                if engine.chain_fwd_ok(dims):                      # the decoder's first hyperTem layer rides on the encoder's last chain launch
+                    emb, c1, tidx, sv_e, dec_head = engine.model_fwd(p, src, mask, dims, base, mdl.num_route, mdl.scaler_zeros, gen=gen[engine.ENC],
+                                                                     tidx=tidx, dec_gen=gen[engine.DEC], lowrank_in=chain)
+                else:
+                    emb, c1, tidx, sv_e = engine.model_fwd(p, src, mask, dims, base, mdl.num_route, mdl.scaler_zeros, gen=gen[engine.ENC], tidx=tidx,
+                                                           lowrank_in=chain)
+                _, dec, sv_d = engine.decoder_fwd(p, tidx, emb, dims, mdl.num_route, gen=gen[engine.DEC], head=False, dec_head=dec_head)
+                sws = self.arena.zeros(ops.tail_parts(M), 4)       # per-workgroup loss statistics of the two heads
+                out, dd = engine.loss_tail(p, g, dec, src, mask, base, self.std, self.mean, a.mape_thresh, sws, red, chain=chain)
+                engine.model_bwd(p, g, src, mask, tidx, sv_e, sv_d, dec, None, None, dims, base, mdl.scaler_zeros, red, dd=dd, chain=chain)
+                if phase == 1:
+                    dh2 = engine.kl_head(p, g, sv_g, prob, c1, self.Nl, 0.1, sws, red, chain=chain)
+                    engine.guide_bwd(p, g, src, tidx, sv_g, None, dims, base, red, dh2=dh2, chain=chain)
+                ops.stats_fold(sws, self.stats)                    # ordered sum -> stats[0..2], inside the buffer the all-reduce below moves
+            else:
+                emb, c1, tidx, sv_e = engine.model_fwd(p, src, mask, dims, base, mdl.num_route, mdl.scaler_zeros, gen=gen[engine.ENC], tidx=tidx)
+                out, dec, sv_d = engine.decoder_fwd(p, tidx, emb, dims, mdl.num_route, gen=gen[engine.DEC])
+                ops.mae_fwd(out, src, base + 2, mask, self.std, self.mean, a.mape_thresh, M, base, self.stats)
+                d_out = ops.mae_bwd(out, src, base + 2, mask, self.std, self.mean, a.mape_thresh, M, base, self.stats, normalize=False)
+                engine.model_bwd(p, g, src, mask, tidx, sv_e, sv_d, dec, d_out, None, dims, base, mdl.scaler_zeros, red)
+                if phase == 1:
+                    dlogit = ops.kl(prob, c1, self.Nl, 0.1, self.stats)
+                    engine.guide_bwd(p, g, src, tidx, sv_g, dlogit, dims, base, red)
             red.flush(tidx)
         finally:
             ctx.ARENA = ctx.NODE_REDUCE = None
         # ---- gradients: replicated-compute parameters count once, node-local ones stay local, the rest is summed ----
         W = self.group.world
-        for k in self.repl_keys:
-            g[k].mul_(1.0 / W)
-        keep = {k: g[k].clone() for k in self.local_keys}
+        if W > 1:
+            if self.repl_grads:
+                torch._foreach_mul_(self.repl_grads, 1.0 / W)
+            torch._foreach_copy_(self.keep_views, self.keep_grads)
         self.group.all_reduce_(self.gbuf)                          # [flat gradient | loss statistics]
-        for k, t in keep.items():
-            g[k].copy_(t)
-        # global gradient norm: the optimiser kernel sees the shared part + OWN node-local part; add the other ranks' local parts
-        sa = 1.0 / torch.clamp(self.stats[1], min=1.0)
-        own = torch.zeros(1, device=self.dev)
-        for k, t in keep.items():
-            if self.segA[k]:
-                own += (t * sa).pow(2).sum()
-            elif phase == 1:
-                own += t.pow(2).sum()
-        tot = own.clone()
-        self.group.all_reduce_(tot)
-        self.stats[3] += (tot - own)[0]
+        if W > 1:
+            torch._foreach_copy_(self.keep_grads, self.keep_views)
+            # global gradient norm: the optimiser kernel sees the shared part + OWN node-local part; add the other ranks' local parts
+            # (reconstruction-path gradients are still unnormalised sums: scaled by 1 / kept cells like the optimiser does)
+            sa = 1.0 / torch.clamp(self.stats[1], min=1.0)
+            own = (self.keep_flat[:self.keep_nA] * sa).pow(2).sum().view(1)
+            if phase == 1 and self.keep_nA < self.keep_flat.numel():
+                own = own + self.keep_flat[self.keep_nA:].pow(2).sum()
+            tot = own.clone()
+            self.group.all_reduce_(tot)
+            self.stats[3] += (tot - own)[0]
         self._optim()
 
     def _budgets(self, ada, rnd, epoch):

@@ -70,6 +70,13 @@ class PretrainStep:
         self.graphs = {}
         self.inject_noise = False
         self.global_count_scale = False      # set by subclasses that all-reduce [gradient | statistics] themselves (shard.py)
+        # r05, lost in-launch hand-offs (a bounded wait of the pair / role launches expired: the GPU was time-sliced away from the producer for
+        # seconds): the optimiser skips the update of such a step (gptst_clip_adam's guard; stats_out[5] > 0), losses() / losses_group() notice,
+        # switch this stepper to the launches WITHOUT hand-offs (safe_mode: graphs re-captured) and re-run the skipped steps from the untouched weights
+        self.safe_mode = False
+        self.lost_steps = 0                  # steps re-run so far
+        self._last_call = None               # (epoch, list_c) of the last plain step()
+        self._g_list_cs = None               # class orders of the last group
         self.arena = engine.ZeroArena(self.dev)
         self.fused_tails = os.environ.get("GPTST_FUSED_TAILS", "1") == "1" and engine.fused_tails_ok(model.param_views(), self.C, self.base, self.HS)
         # ---- data parallel: masks over the GLOBAL batch (dist.py) ----
@@ -171,6 +178,12 @@ class PretrainStep:
         return dict(tidx=tidx, gen=gen, red=red, prob=prob, sv_g=sv_g)
 
     def _part2(self, phase, ctx):
+        if not self.safe_mode:
+            return self._part2_impl(phase, ctx)
+        with engine.no_handoffs():              # hyperTem backward per layer, cross-time backward as a prologue: no in-launch waits
+            return self._part2_impl(phase, ctx)
+
+    def _part2_impl(self, phase, ctx):
         mdl, p, g, dims, base = self.model, self.model.param_views(), self.g, self.dims, self.base
         a = self.args
         M = self.B * self.T * self.N
@@ -327,6 +340,7 @@ class PretrainStep:
             ada, rnd = self.model.adaptive_counts(self.B * self.T * self.N * (self.W if self.gmask else 1), epoch)
             ada, rnd = self._budgets(ada, rnd, epoch)
             sl["ctrl"][:] = [int(v) for v in list_c] + [int(ada), int(rnd)]
+        self._filled_list_c = [int(v) for v in list_c] if phase == 1 else None
 
     def _budgets(self, ada, rnd, epoch):
         """Hook: subclasses whose masks cover more cells than this rank's batch (node sharding) replace the budgets."""
@@ -352,6 +366,7 @@ class PretrainStep:
         if forced_mask is not None:
             self.mask_buf.copy_(forced_mask.reshape(-1), non_blocking=True)
         self._host_prepare(phase, epoch, list_c)
+        self._last_call = (epoch, self._filled_list_c) if not inject and forced_mask is None else None
         key = (phase, inject, forced_mask is not None)
         if not self.use_graph:
             self.inject_noise, self.force_mask = inject, forced_mask is not None
@@ -505,8 +520,11 @@ class PretrainStep:
         self._g_ring_i = (self._g_ring_i + 1) % self.RING
         if sl["ev"] is not None:
             sl["ev"].synchronize()
+        self._g_list_cs = []
         for j in range(K):
             self._fill(sl["rows"][j], phase, epoch, None if list_cs is None else list_cs[j])
+            self._g_list_cs.append(self._filled_list_c)
+        self._g_epoch = epoch
         self._g_hc.copy_(sl["hc"], non_blocking=True)
         if sl["ev"] is None:
             sl["ev"] = torch.cuda.Event()
@@ -583,12 +601,42 @@ class PretrainStep:
             return [self.losses()]
         K, phase = self._g_last
         st = self._g_stats.cpu()
+        rerun = {}
+        if float(st[:, 5].max()) > 0:           # a hand-off expired in sub-step j0: its update and every later one were skipped
+            j0 = int((st[:, 5] > 0).float().argmax())
+            self._enter_safe_mode(K - j0, (K - j0) if phase == 1 else 0)
+            srcs, lcs, epoch = [t.clone() for t in self._g_src[j0:]], self._g_list_cs[j0:], self._g_epoch
+            for j, (src, lc) in enumerate(zip(srcs, lcs)):
+                self.step(src, epoch, list_c=lc)
+                rerun[j0 + j] = self._stats_row(self.stats_out.cpu(), phase == 1)
+            self._g_last = (K, phase)            # (step() cleared it: the group's triples stay readable)
         out = []
         for j in range(K):
-            lf = float(st[j, 0] / max(float(st[j, 1]), 1.0))
-            ls = float(st[j, 2]) * 0.1 if phase == 1 else 0.0
-            out.append((lf + ls, lf, ls))
+            out.append(rerun[j] if j in rerun else self._stats_row(st[j], phase == 1))
         return out
+
+    @staticmethod
+    def _stats_row(st, kl):
+        lf = float(st[0] / max(float(st[1]), 1.0))
+        ls = float(st[2]) * 0.1 if kl else 0.0
+        return (lf + ls, lf, ls)
+
+    def _enter_safe_mode(self, nsteps, nkl):
+        """A hand-off expiry is on record: the last `nsteps` optimiser updates (nkl of them with the KL path) were skipped on the device.  Rewind the
+        host's step counters, drop every captured graph (they hold the hand-off launches), clear the record, and from now on enqueue the step
+        without in-launch hand-offs.  Collective under data parallelism by construction: the count travels in the all-reduced statistics."""
+        import sys
+        from . import _C
+        torch.cuda.synchronize()
+        print("gpt-st_amd: an in-launch hand-off expired (the GPU was shared?) — %d skipped step(s) are re-run without hand-off launches; "
+              "this stepper stays in that mode" % nsteps, file=sys.stderr)
+        self.tA -= nsteps
+        self.tB -= nkl
+        self.lost_steps += nsteps
+        self.safe_mode = True
+        self.graphs.clear()
+        getattr(self, "_g_graphs", {}).clear()
+        _C.lib().call("gptst_handoff_reset")
 
     # ---- results ---------------------------------------------------------------------------------------------------
     def losses(self):
@@ -596,6 +644,11 @@ class PretrainStep:
         if self._g_last is not None:
             return self.losses_group()[-1]
         st = self.stats_out.cpu()
-        lf = float(st[0] / max(float(st[1]), 1.0))
-        ls = float(st[2]) * 0.1 if self.tB and self.phase_kl else 0.0
-        return lf + ls, lf, ls
+        if float(st[5]) > 0:                     # the update of this step was skipped (a hand-off expired): re-run it from the untouched weights
+            if self._last_call is None:
+                raise RuntimeError("an in-launch hand-off expired in a step with injected mask inputs: call _enter_safe_mode() and repeat the step")
+            epoch, lc = self._last_call
+            self._enter_safe_mode(1, 1 if self.phase_kl else 0)
+            self.step(self.src, epoch, list_c=lc)
+            st = self.stats_out.cpu()
+        return self._stats_row(st, bool(self.tB and self.phase_kl))

@@ -19,6 +19,9 @@ int gptst_tune(int id, int value);
 /* mask selection: 1 = the multi-launch radix select for every size (a single-workgroup launch serves M <= 8192 cells otherwise);
  * 2 (gptst_mask_*_u24 only) = the one-workgroup lattice kernel for every size up to 65536 cells.  Process-wide, not thread-local. */
 int gptst_mask_force_multi(int on);
+/* puts n hand-off expiries on record without poisoning anything (synchronises): what the optimiser's guard and the steppers' recovery see when a
+ * bounded in-launch wait ran out (tests/test_gpu_step.py::test_lost_handoff_*). */
+int gptst_handoff_inject(int n);
 #if defined(__GNUC__)
 #pragma GCC visibility pop
 #endif

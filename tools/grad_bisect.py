@@ -20,7 +20,7 @@ from oracle import gptst_oracle as O                       # noqa: E402
 from test_gpu_shapes import CASES                          # noqa: E402
 
 DEV = "cuda:0"
-SWITCHES = [("default", {}), ("ENCIN=0", dict(ENCIN=False)), ("GUIDEIN=0", dict(GUIDEIN=False)), ("PAIR_BWD=0", dict(PAIR_BWD=False)),
+SWITCHES = [("default", {})] if os.environ.get("BISECT_DEFAULT_ONLY") == "1" else [("default", {}), ("ENCIN=0", dict(ENCIN=False)), ("GUIDEIN=0", dict(GUIDEIN=False)), ("PAIR_BWD=0", dict(PAIR_BWD=False)),
             ("CHAIN_FWD=0", dict(CHAIN_FWD=False)), ("CROSS_ROLE=0", dict(CROSS_ROLE=0)), ("FUSE_CROSS=0", dict(FUSE_CROSS=False)),
             ("all r04 off", dict(ENCIN=False, GUIDEIN=False, PAIR_BWD=False, CHAIN_FWD=False, CROSS_ROLE=0))]
 
