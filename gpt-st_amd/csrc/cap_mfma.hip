@@ -524,8 +524,7 @@ __global__ __launch_bounds__(CM_NT, 4) void cap_rec_bwd2_kernel(const float* __r
 
 #define CX_SPLIT 4        // cross-time role: workgroups per sample (each owns 12 / CX_SPLIT time steps; the whole-sample part is repeated by them)
 struct CrossBwdArgs { const float* dv; const float* s; const float* Rt; const float* Ht; const float* dyn; const float* tmpl; float* ddyn; int T, HT;
-                      float* dSg; unsigned* flags; int nB;       // roles (r04): nB cross-time workgroups publish dS (B*T, HS, C) + their flags
-                      const float* drec; const float* v; float* dc1w; float* dvw; int nA, B; };   // + the B*T rec-backward workgroups (three-role form)
+                      float* dSg; unsigned* flags; int nB; };    // roles (r04): nB cross-time workgroups publish dS (B*T, HS, C) + their flags
 
 // r05: the backward of the cap's ENTRY Linear + the layer's residual branch (GPTST.py:102,139-141; gptst_linear_bwd) folded into the routing backward,
 // which holds everything it needs: the X tile (it rebuilds Y from it), dY (in LDS, never written out) and — fetched as fragments — Wp.
@@ -669,7 +668,8 @@ __device__ __forceinline__ void cap_cross_bwd_prologue(const float* __restrict__
     __syncthreads();
 }
 
-template <int C, int ROLES, bool LIN = false>      // ROLES 0: one role (dS given, or the cross-time backward as a prologue); 1: + cross-time role; 2: + rec-backward role
+template <int C, int ROLES, bool LIN = false>      // ROLES 0: one role (dS given, or the cross-time backward as a prologue); 1: + cross-time role
+                                                   // (r05: the three-role form — + the rec backward — measured slower and left the library: profiles/r04_roles3_stamps.txt)
 __global__ __launch_bounds__(CM_NT, 4) void cap_route_bwd2_kernel(const float* __restrict__ X, const float* __restrict__ Wp,
                                                                   const float* __restrict__ bp, const float* __restrict__ c,
                                                                   const float* __restrict__ dc1, const float* __restrict__ dS,
@@ -696,34 +696,10 @@ __global__ __launch_bounds__(CM_NT, 4) void cap_route_bwd2_kernel(const float* _
     // kernel the register allocator spilled 100 registers.
     unsigned* s_ok = reinterpret_cast<unsigned*>(qq + NR);
     GPTST_WG_BEGIN(); GPTST_STAMP(0);
-    // ---- three roles (ROLES == 2): the launch ALSO holds the B*T workgroups of cap_rec_bwd2 (dc1, dv out of drec), in front.  Block order is
-    // [rec-backward (b,t)] [cross-time (sample, part)] [routing (b,t)] and every wait points to a LOWER block index: cross-time part waits for
-    // its sample's T rec-backward workgroups (a counter), routing waits for its own rec-backward workgroup and its cross-time part.  With the
-    // dispatcher handing out blocks in index order nothing can wait on a workgroup that is not yet on the chip, whatever the residency; all
-    // waits are bounded and end in NaN.
-    if (ROLES == 2 && (int)blockIdx.x < cx.nA) {
-        const int bt = blockIdx.x;
-        cap_rec_bwd2_body<C, true>(cx.drec, c, cx.v, cx.dc1w, cx.dvw, N, HS, bt, smem);
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __syncthreads();
-        if (tid == 0) {
-            gptst_publish_fence();
-            __hip_atomic_store(cx.flags + cx.nB + cx.B + bt, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            __hip_atomic_fetch_add(cx.flags + cx.nB + bt / cx.T, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        }
-        GPTST_STAMP(1); GPTST_WG_END();
-        return;
-    }
-    const int blk = ROLES == 2 ? (int)blockIdx.x - cx.nA : (int)blockIdx.x;
+    const int blk = (int)blockIdx.x;
     if (ROLES && blk < cx.nB) {                          // cross-time role: workgroup r = (sample r / CX_SPLIT, time steps of part r % CX_SPLIT)
         constexpr int TS = 12 / CX_SPLIT;
-        if constexpr (ROLES == 2) {
-            if (tid == 0) *s_ok = gptst_wait_ge(cx.flags + cx.nB + blk / CX_SPLIT, (unsigned)cx.T, &g_handoff_lost_capmfma);
-            __syncthreads();
-            if (*s_ok == 0u) return;                     // no flag: the sample's routing workgroups time out and poison dS
-            __syncthreads();
-        }
-        cap_cross_bwd_prologue<C, true, ROLES == 2>(cx.dv, cx.s, cx.Rt, cx.Ht, cx.dyn, cx.tmpl, cx.ddyn, smem, nullptr, blk / CX_SPLIT,
+        cap_cross_bwd_prologue<C, true>(cx.dv, cx.s, cx.Rt, cx.Ht, cx.dyn, cx.tmpl, cx.ddyn, smem, nullptr, blk / CX_SPLIT,
                                                     (blk % CX_SPLIT) * TS, TS, cx.T, HS, cx.HT, cx.dSg);
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");            // every storing wave drains its write-through stores ...
         __syncthreads();
@@ -841,18 +817,16 @@ __global__ __launch_bounds__(CM_NT, 4) void cap_route_bwd2_kernel(const float* _
     auto poll = [&]() {                                              // ONE lane polls the flags it depends on, relaxed, bounded
         if (tid == 0) {
             bool got = gptst_wait_ge(cx.flags + (bt / cx.T) * CX_SPLIT + (bt % cx.T) / (12 / CX_SPLIT), 1u, &g_handoff_lost_capmfma);
-            if (ROLES == 2) got = got && gptst_wait_ge(cx.flags + cx.nB + cx.B + bt, 1u, &g_handoff_lost_capmfma);
             *s_ok = got ? 1u : 0u;
         }
     };
-    if constexpr (ROLES == 2) { poll(); __syncthreads(); }            // dc1 comes out of this launch's rec-backward role
     for (int i0 = 0; i0 < HS * N; i0 += 4 * CM_NT) {             // c, dc1: batches of 4 + 4 loads per thread
         float cv[4], dv[4];
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
             const int i = min(i0 + k * CM_NT + tid, HS * N - 1);
             cv[k] = c[(size_t)bt * HS * N + i];
-            dv[k] = ROLES == 2 ? ld_agent(dc1 + (size_t)bt * HS * N + i) : dc1[(size_t)bt * HS * N + i];
+            dv[k] = dc1[(size_t)bt * HS * N + i];
         }
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
@@ -862,7 +836,7 @@ __global__ __launch_bounds__(CM_NT, 4) void cap_route_bwd2_kernel(const float* _
     }
     if (!fold && !ROLES) for (int i = tid; i < HS * LPR; i += CM_NT) st4(Vs + (i / LPR) * P + 4 * (i % LPR), ld4(dS + (size_t)bt * HS * C + 4 * i));
     if constexpr (ROLES != 0) {
-        if constexpr (ROLES == 1) poll();
+        poll();
         __syncthreads();
         const bool ok = *s_ok != 0u;
         typedef int i32x4_ __attribute__((ext_vector_type(4)));
@@ -1094,7 +1068,7 @@ static int launch_route_bwd2(const float* X, const float* Wp, const float* bp, c
                              float* dY, float* dlogit, int BT, int N, int HS, hipStream_t st, CrossBwdArgs cx = CrossBwdArgs{nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, 0, 0, nullptr, nullptr, 0},
                              LinArgs lin = LinArgs{nullptr, nullptr, nullptr, nullptr, nullptr, 0}) {
     if (HS > 64) return GPTST_ESHAPE;
-    if (lin.dX != nullptr && (C != 64 || cx.nA > 0)) return GPTST_ESHAPE;      // the folded Linear backward: C = 64, one- and two-role forms
+    if (lin.dX != nullptr && C != 64) return GPTST_ESHAPE;      // the folded Linear backward: C = 64
     const int NR = cm_rows(N), NP = cm_np(N), HSP = cm_hsp(HS);
     size_t r2 = (size_t)C * C, need = (size_t)2 * HSP * NP;
     if (need > r2) r2 = need;
@@ -1109,13 +1083,6 @@ static int launch_route_bwd2(const float* X, const float* Wp, const float* bp, c
         const int no = (12 / CX_SPLIT) * HS;
         const size_t need_r = (size_t)(cx.T * HS + 2 * cx.HT + 2 * no) * Tile<C>::PITCH + (size_t)cx.HT * cx.T * HS;
         if (smem > 80 * 1024 || BT + cx.nB > 512 || cx.T != 12 || need_r > (size_t)NR * Tile<C>::PITCH + r2) cx.nB = 0;
-    }
-    if (cx.nB > 0 && cx.nA > 0) {                        // three roles: the rec-backward workgroups in front (waits point to lower block indices only)
-        static size_t curA = 0;
-        if (smem > curA) { (void)hipFuncSetAttribute((const void*)cap_route_bwd2_kernel<C, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem); curA = smem; }
-        hipLaunchKernelGGL((cap_route_bwd2_kernel<C, 2>), dim3(cx.nA + cx.nB + BT), dim3(CM_NT), smem, st, X, Wp, bp, c, dc1, dS, dY, dlogit, N, HS, (int)r2, cx, lin);
-        GPTST_CHECK_LAUNCH();
-        return GPTST_OK;
     }
     if (cx.nB > 0 && lin.dX != nullptr) {
         static size_t curRL = 0;
@@ -1187,32 +1154,6 @@ extern "C" int gptst_cap_cross_route_lin_bwd(const float* X, const float* Wp, co
     return launch_route_bwd2<64>(X, Wp, bp, c, dc1, nullptr, nullptr, dlogit, B * T, N, HS, (hipStream_t)stream,
                                  CrossBwdArgs{dv, s, Rt, Ht, dyn, tmpl, ddyn, T, HT, roles ? dS_ws : nullptr, roles ? (unsigned*)flags : nullptr, roles ? B * CX_SPLIT : 0},
                                  LinArgs{dPre, out, dX, dWp, dbp, premul});
-}
-
-// gptst_cap_rec_bwd + gptst_cap_cross_route_bwd in ONE launch (three roles, see cap_route_bwd2_kernel): drec (B*T, N, C) gradient of the capsule
-// block's scatter output, v (B*T, HS, C) -> dY, dlogit, ddyn.  Workspaces: dc1_ws (B*T, HS, N), dv_ws (B*T, HS, C), dS_ws (B*T, HS, C), flags
-// ((CX_SPLIT + 1) * B + B*T 32-bit words, ZERO on entry).  GPTST_ESHAPE where the role form does not serve (use the two calls).
-extern "C" int gptst_cap_rec_cross_route_bwd(const float* drec, const float* v, const float* X, const float* Wp, const float* bp, const float* c,
-                                             const float* s, const float* Rt, const float* Ht, const float* dyn, const float* tmpl, float* dY,
-                                             float* dlogit, float* ddyn, float* dc1_ws, float* dv_ws, float* dS_ws, void* flags, int B, int T,
-                                             int N, int C, int HS, int HT, void* stream) {
-    if (!drec || !v || !X || !Wp || !bp || !c || !s || !Rt || !Ht || !dyn || !tmpl || !dY || !dlogit || !ddyn || !dc1_ws || !dv_ws || !dS_ws ||
-        !flags || B <= 0 || T <= 0) return GPTST_EARG;
-    if (C != 64 || T != 12 || g_cap_bwd_noroles) return GPTST_ESHAPE;
-    {                                                    // the rec-backward role's LDS within the routing kernel's, the role form available at all
-        const int NR = cm_rows(N), NP = cm_np(N), HSP = cm_hsp(HS);
-        size_t r2 = (size_t)C * C, need = (size_t)2 * HSP * NP;
-        if (need > r2) r2 = need;
-        r2 = (r2 + 3) & ~(size_t)3;
-        const size_t have = (size_t)NR * Tile<64>::PITCH + r2 + (size_t)HSP * Tile<64>::PITCH + 2 * (size_t)NR;
-        const size_t rec = (size_t)NR * Tile<64>::PITCH + (size_t)(HSP + HS) * NP + (size_t)HSP * Tile<64>::PITCH + (size_t)HSP * 64;
-        const int no = (12 / CX_SPLIT) * HS;
-        const size_t need_r = (size_t)(T * HS + 2 * HT + 2 * no) * Tile<64>::PITCH + (size_t)HT * T * HS;
-        if (HS > 64 || rec > have || (have + 4) * sizeof(float) > 80 * 1024 || B * T + B * CX_SPLIT > 512 ||
-            need_r > (size_t)NR * Tile<64>::PITCH + r2 || (HT * T * HS) % 4 != 0) return GPTST_ESHAPE;
-    }
-    return launch_route_bwd2<64>(X, Wp, bp, c, dc1_ws, nullptr, dY, dlogit, B * T, N, HS, (hipStream_t)stream,
-                                 CrossBwdArgs{dv_ws, s, Rt, Ht, dyn, tmpl, ddyn, T, HT, dS_ws, (unsigned*)flags, B * CX_SPLIT, drec, v, dc1_ws, dv_ws, B * T, B});
 }
 
 // =====================================================================================================================

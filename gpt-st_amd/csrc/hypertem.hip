@@ -11,6 +11,9 @@ GPTST_STAMP_TABLES(hypertem)
 GPTST_HANDOFF_COUNTER(hypertem)      // -DGPTST_STAMPS: per-phase / per-workgroup wall-clock stamps of the pair launch (tools/phase_stamps.py ht_bwd_pair)
 
 #define HT_T 12
+#ifndef HT_OCC
+#define HT_OCC 2        // waves per SIMD the slab kernels leave room for (2 <-> 256 VGPRs; r05 experiment: 3 / 4, tools/kernel_regs.py)
+#endif
 #ifdef GPTST_DEBUG
 __device__ long long g_ht_ts[64];
 static thread_local int g_ht_dbg = 0, g_ht_nt_override = 0;
@@ -42,7 +45,7 @@ static int ht_pick_nt(int B, int N) {
     return 16;     // measured flat for NT = 11..16 at (32, 170): the per-tile MFMA / fragment cost does not shrink with NT
 }
 
-__global__ __launch_bounds__(256, 2) void hypertem_fwd_kernel(const float* __restrict__ X, const float* __restrict__ G,
+__global__ __launch_bounds__(256, HT_OCC) void hypertem_fwd_kernel(const float* __restrict__ X, const float* __restrict__ G,
                                                               const float* __restrict__ Wbt, const float* __restrict__ bbt,
                                                               float* __restrict__ R_out, float* __restrict__ out, int N, int B, int NT,
                                                               int dbg) {
@@ -159,250 +162,15 @@ __global__ __launch_bounds__(256, 2) void hypertem_fwd_kernel(const float* __res
     }
 }
 
-// ---- 12-wave variant (r03): one time step per wave ------------------------------------------------------------------------------------------
-// The 4-wave kernel above runs three time steps per wave one after the other (mix -> 64 MFMAs -> epilogue, ~2 us each) behind the slab load,
-// and at B = 32 the 352 workgroups make 1.4 rounds of two co-resident workgroups.  Here a workgroup has 12 waves (3 per SIMD = the register
-// budget of 168), each owning ONE time step: the per-workgroup chain is load -> one step -> store, a CU holds one workgroup at a time, and
-// the three waves of a SIMD interleave mix (VALU) and MFMA phases.  NT = 16 only.
-__global__ __launch_bounds__(768, 3) void hypertem_fwd12_kernel(const float* __restrict__ X, const float* __restrict__ G,
-                                                                 const float* __restrict__ Wbt, const float* __restrict__ bbt,
-                                                                 float* __restrict__ R_out, float* __restrict__ out, int N, int B) {
-    constexpr int C = 64, P = C + 4, GP = 145, NT = 16;
-    extern __shared__ __attribute__((aligned(16))) float smem[];
-    float* Xs = smem;                               // [12][NT][P]
-    float* Gs = Xs + HT_T * NT * P;                 // [NT][GP]
-    int b, tile;
-#ifdef GPTST_DEBUG
-#define TS12(i) do { if (blockIdx.x == 59 && threadIdx.x == 64 * 5) g_ht_ts[i] = __builtin_readcyclecounter(); if (blockIdx.x == 200 && threadIdx.x == 64 * 5) g_ht_ts[16 + (i)] = __builtin_readcyclecounter(); } while (0)
-#else
-#define TS12(i) do { } while (0)
-#endif
-    TS12(0);
-    if (!ht_work((N + NT - 1) / NT, B, b, tile)) return;
-    const int n0 = tile * NT;
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int j = lane & 15, kk = lane >> 4;
-    const int t = wave;
-    const size_t g = (size_t)b * HT_T + t;
-    // this wave's W_bt fragments and bias: requested first, consumed after the mix
-    float4 bv[C / 16][4];
-    {
-        const float* W_ = Wbt + g * C * C;
-#pragma unroll
-        for (int q = 0; q < C / 16; ++q)
-#pragma unroll
-            for (int e = 0; e < 4; ++e) bv[q][e] = ld4(W_ + (size_t)(16 * q + 4 * kk + e) * C + 4 * j);
-    }
-    const float4 b4 = ld4(bbt + g * C + 4 * j);
-    {   // slab staging: thread = (time third, row, float4 column): 4 time slices each
-        const int th = tid >> 8, r = tid & 255, nl = r >> 4, c4 = r & 15;
-        const int n = min(n0 + nl, N - 1);
-        float4 v[4];
-        float gv[3];
-#pragma unroll
-        for (int i = 0; i < 4; ++i) v[i] = ld4(X + (((size_t)b * HT_T + 4 * th + i) * N + n) * C + 4 * c4);
-#pragma unroll
-        for (int k = 0; k < 3; ++k) gv[k] = G[min(n0 * 144 + tid + k * 768, N * 144 - 1)];
-#pragma unroll
-        for (int i = 0; i < 4; ++i) st4(Xs + ((4 * th + i) * NT + nl) * P + 4 * c4, n0 + nl < N ? v[i] : f4zero());
-#pragma unroll
-        for (int k = 0; k < 3; ++k) {
-            const int i = tid + k * 768;
-            Gs[(i / 144) * GP + i % 144] = (n0 + i / 144 < N) ? gv[k] : 0.f;
-        }
-    }
-    TS12(1);
-    __syncthreads();
-    SB();
-    TS12(2);
-    float4 a4[C / 16];
-#pragma unroll
-    for (int q = 0; q < C / 16; ++q) a4[q] = f4zero();
-    {
-        const float* gr = Gs + j * GP + t * HT_T;
-        const float* xr = Xs + j * P + 4 * kk;
-#pragma unroll
-        for (int u = 0; u < HT_T; ++u) {
-            const float gu = gr[u];
-#pragma unroll
-            for (int q = 0; q < C / 16; ++q) a4[q] = f4fma(gu, ld4(xr + u * NT * P + 16 * q), a4[q]);
-        }
-    }
-    SB();
-    TS12(3);
-    f32x4 acc[C / 16];
-#pragma unroll
-    for (int ct = 0; ct < C / 16; ++ct) acc[ct] = (f32x4){0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-    for (int q = 0; q < C / 16; ++q) {
-        const float av[4] = {a4[q].x, a4[q].y, a4[q].z, a4[q].w};
-#pragma unroll
-        for (int e = 0; e < 4; ++e) {
-            acc[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[e], bv[q][e].x, acc[0], 0, 0, 0);
-            acc[1] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[e], bv[q][e].y, acc[1], 0, 0, 0);
-            acc[2] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[e], bv[q][e].z, acc[2], 0, 0, 0);
-            acc[3] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[e], bv[q][e].w, acc[3], 0, 0, 0);
-        }
-    }
-    SB();
-    TS12(4);
-    if (R_out != nullptr && n0 + j < N) {
-#pragma unroll
-        for (int q = 0; q < C / 16; ++q) st4(R_out + (g * N + n0 + j) * C + 16 * q + 4 * kk, a4[q]);
-    }
-#pragma unroll
-    for (int r = 0; r < 4; ++r) {
-        const int nl = kk * 4 + r;
-        if (n0 + nl < N) {
-            float4 y = f4add(f4add(make_float4(acc[0][r], acc[1][r], acc[2][r], acc[3][r]), b4), ld4(Xs + (t * NT + nl) * P + 4 * j));
-            y.x = lrelu(y.x); y.y = lrelu(y.y); y.z = lrelu(y.z); y.w = lrelu(y.w);
-            st4(out + (g * N + n0 + nl) * C + 4 * j, y);
-        }
-    }
-    TS12(5);
-#ifdef GPTST_DEBUG
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-#endif
-    TS12(6);
-}
-
-// ---- C = 128 (BASELINE configs[4]) ---------------------------------------------------------------------------------------------------------
-// Same fusion at C = 128: out = LReLU((G_n X) W_bt + b_bt + X) with the 12 x 16 x 128 slab of X in LDS (101 KB: one workgroup per CU) and
-// R = G_n X written once for the weight gradient — replaces tmix_kernel + apply128_kernel<TIME> (the R round trip through HBM and a second
-// pass over X for the residual).  W_bt is 64 KB per (b, t): a lane cannot hold a whole matrix as at C = 64, so the unit of work is
-// (time step, half of the output channels): 24 items over 8 waves (two per SIMD: one's W_bt fragment loads from L2 run under the other's
-// MFMAs), each item = mix (A operand, VALU from LDS) -> 128 MFMAs against its 128 x 64 block of W_bt (32 float4 fragments in registers,
-// the next item's requested right behind the MFMAs) -> bias + residual + LeakyReLU from registers.  The two waves that share a time step
-// both compute its mix; the one with the lower half writes R.  Work map: all node tiles of a sample on one XCD (ht_work), so the sample's
-// 768 KB of W_bt are fetched into one L2.
-// MEASURED (N = 4096, B = 32, r03): 1086 us per launch against 285 + 587 us for the two kernels it replaces — with one workgroup per CU the slab
-// staging, the (duplicated) mixes and the MFMA phases of a tile run one after the other (34 us per tile, MFMA alone 11.7) and nothing of the
-// next tile overlaps them; the two-kernel form keeps 2-4 workgroups per CU.  Kept for parity coverage and as the starting point of a
-// pipelined version; the engine uses it only with GPTST_HT128_FUSED=1.
-#define HT128_NT 16
-static size_t ht128_smem() { return ((size_t)HT_T * HT128_NT * 132 + HT128_NT * 145) * sizeof(float); }
-__global__ __launch_bounds__(512, 1) void hypertem_fwd128_kernel(const float* __restrict__ X, const float* __restrict__ G,
-                                                                 const float* __restrict__ Wbt, const float* __restrict__ bbt,
-                                                                 float* __restrict__ R_out, float* __restrict__ out, int N, int B) {
-    constexpr int C = 128, P = C + 4, GP = 145, NT = HT128_NT, NQ = C / 16;
-    extern __shared__ __attribute__((aligned(16))) float smem[];
-    float* Xs = smem;                               // [12][NT][P]
-    float* Gs = Xs + HT_T * NT * P;                 // [NT][GP]
-    int b, tile;
-    if (!ht_work((N + NT - 1) / NT, B, b, tile)) return;
-    const int n0 = tile * NT;
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int j = lane & 15, kk = lane >> 4;
-    float4 bv[NQ][4];
-    float4 b4;
-#define HT128_LOAD_W(item) do {                                                                                    \
-        const size_t g_ = (size_t)b * HT_T + ((item) >> 1);                                                        \
-        const float* W_ = Wbt + g_ * C * C + 64 * ((item) & 1);                                                    \
-        _Pragma("unroll") for (int q = 0; q < NQ; ++q)                                                             \
-            _Pragma("unroll") for (int e = 0; e < 4; ++e) bv[q][e] = ld4(W_ + (size_t)(16 * q + 4 * kk + e) * C + 4 * j); \
-        b4 = ld4(bbt + g_ * C + 64 * ((item) & 1) + 4 * j);                                                        \
-    } while (0)
-    HT128_LOAD_W(wave);                             // in flight during the slab staging
-    {   // slab + graph staging: every global load before the first LDS store
-        const int nl = tid >> 5, c4 = tid & 31;     // thread = (row, float4 column) of every time slice
-        const int n = min(n0 + nl, N - 1);
-        float4 v[HT_T];
-        float gv[5];
-#pragma unroll
-        for (int t = 0; t < HT_T; ++t) v[t] = ld4(X + (((size_t)b * HT_T + t) * N + n) * C + 4 * c4);
-#pragma unroll
-        for (int k = 0; k < 5; ++k) gv[k] = G[min(n0 * 144 + tid + k * 512, N * 144 - 1)];
-#pragma unroll
-        for (int t = 0; t < HT_T; ++t) st4(Xs + (t * NT + nl) * P + 4 * c4, n0 + nl < N ? v[t] : f4zero());
-#pragma unroll
-        for (int k = 0; k < 5; ++k) {
-            const int i = tid + k * 512;
-            if (i < NT * 144) Gs[(i / 144) * GP + i % 144] = (n0 + i / 144 < N) ? gv[k] : 0.f;
-        }
-    }
-    __syncthreads();
-    for (int item = wave; item < 2 * HT_T; item += 8) {
-        const int t = item >> 1, half = item & 1;
-        const size_t g = (size_t)b * HT_T + t;
-        SB();
-        // ---- (1) temporal mix in the MFMA A-operand layout: lane (j, kk) owns R_t[row j][16q + 4kk .. +3] ----
-        float4 a4[NQ];
-#pragma unroll
-        for (int q = 0; q < NQ; ++q) a4[q] = f4zero();
-        {
-            const float* gr = Gs + j * GP + t * HT_T;
-            const float* xr = Xs + j * P + 4 * kk;
-#pragma unroll
-            for (int u = 0; u < HT_T; ++u) {
-                const float gu = gr[u];
-#pragma unroll
-                for (int q = 0; q < NQ; ++q) a4[q] = f4fma(gu, ld4(xr + u * NT * P + 16 * q), a4[q]);
-            }
-        }
-        SB();
-        // ---- (2) R_t @ W_bt[:, 64 half ..]: column tile ct, column j <-> output channel 64 half + 4j + ct ----
-        f32x4 acc[4];
-#pragma unroll
-        for (int ct = 0; ct < 4; ++ct) acc[ct] = (f32x4){0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-        for (int q = 0; q < NQ; ++q) {
-            const float av[4] = {a4[q].x, a4[q].y, a4[q].z, a4[q].w};
-#pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                acc[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[e], bv[q][e].x, acc[0], 0, 0, 0);
-                acc[1] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[e], bv[q][e].y, acc[1], 0, 0, 0);
-                acc[2] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[e], bv[q][e].z, acc[2], 0, 0, 0);
-                acc[3] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[e], bv[q][e].w, acc[3], 0, 0, 0);
-            }
-        }
-        SB();
-        const float4 bias = b4;
-        if (item + 8 < 2 * HT_T) HT128_LOAD_W(item + 8);         // requested before this item's stores (vmcnt retires in order)
-        SB();
-        if (half == 0 && R_out != nullptr && n0 + j < N) {
-#pragma unroll
-            for (int q = 0; q < NQ; ++q) st4(R_out + (g * N + n0 + j) * C + 16 * q + 4 * kk, a4[q]);
-        }
-        // ---- (3) epilogue from registers: lane (j, kk) owns rows kk*4 + r, channels 64 half + 4j .. +3 ----
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            const int nl = kk * 4 + r;
-            if (n0 + nl < N) {
-                float4 y = f4add(f4add(make_float4(acc[0][r], acc[1][r], acc[2][r], acc[3][r]), bias),
-                                 ld4(Xs + (t * NT + nl) * P + 64 * half + 4 * j));
-                y.x = lrelu(y.x); y.y = lrelu(y.y); y.z = lrelu(y.z); y.w = lrelu(y.w);
-                st4(out + (g * N + n0 + nl) * C + 64 * half + 4 * j, y);
-            }
-        }
-    }
-#undef HT128_LOAD_W
-}
-
-thread_local int g_ht_fwd12 = 0;          // gptst_tune(12, 1): the 12-wave forward
 static size_t ht_smem(int NT) { return ((size_t)HT_T * NT * 68 + NT * 145) * sizeof(float); }
 
 extern "C" int gptst_hypertem_fwd(const float* X, const float* G, const float* Wbt, const float* bbt, float* R_out, float* out, int B,
                                   int T, int N, int C, void* stream) {
     if (!X || !G || !Wbt || !bbt || !out || T != HT_T) return GPTST_EARG;       // R_out may be NULL
-    if (C == 128) {
-        static int done128 = 0;
-        if (!done128) { hipFuncSetAttribute((const void*)hypertem_fwd128_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ht128_smem()); done128 = 1; }
-        hipLaunchKernelGGL(hypertem_fwd128_kernel, dim3(8 * ((B + 7) / 8) * ((N + HT128_NT - 1) / HT128_NT)), dim3(512), ht128_smem(), (hipStream_t)stream,
-                           X, G, Wbt, bbt, R_out, out, N, B);
-        GPTST_CHECK_LAUNCH();
-        return GPTST_OK;
-    }
     if (C != 64) return GPTST_ESHAPE;
     static int done = 0;
     if (!done) { hipFuncSetAttribute((const void*)hypertem_fwd_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ht_smem(16)); done = 1; }
     const int NT = ht_pick_nt(B, N);
-    if (g_ht_fwd12) {
-        static int done12 = 0;
-        if (!done12) { hipFuncSetAttribute((const void*)hypertem_fwd12_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ht_smem(16)); done12 = 1; }
-        hipLaunchKernelGGL(hypertem_fwd12_kernel, dim3(8 * ((B + 7) / 8) * ((N + 15) / 16)), dim3(768), ht_smem(16), (hipStream_t)stream, X, G, Wbt, bbt, R_out, out, N, B);
-        GPTST_CHECK_LAUNCH();
-        return GPTST_OK;
-    }
     hipLaunchKernelGGL(hypertem_fwd_kernel, dim3(8 * ((B + 7) / 8) * ((N + NT - 1) / NT)), dim3(256), ht_smem(NT), (hipStream_t)stream, X, G, Wbt, bbt, R_out, out, N, B, NT, g_ht_dbg);
     GPTST_CHECK_LAUNCH();
     return GPTST_OK;
@@ -609,7 +377,7 @@ __device__ __forceinline__ void hypertem_bwd_body(const float* __restrict__ dOut
 }
 
 template <bool HASY, bool PREMUL>
-__global__ __launch_bounds__(256, 2) void hypertem_bwd_kernel(const float* __restrict__ dOut, const float* __restrict__ Y,
+__global__ __launch_bounds__(256, HT_OCC) void hypertem_bwd_kernel(const float* __restrict__ dOut, const float* __restrict__ Y,
                                                               const float* __restrict__ X, const float* __restrict__ G,
                                                               const float* __restrict__ Wbt, float* __restrict__ dX,
                                                               float* __restrict__ dbias, float* __restrict__ dG, int N, int B, int dbg) {
@@ -701,7 +469,7 @@ __device__ __forceinline__ void wgrad64_mix_body(const float* __restrict__ X, co
 // longer ones and keep the XCD-aware index map), the rest the weight-gradient role, and the chains overlap.
 // MIX: the weight-gradient role rebuilds R from X (R == NULL) and its workgroups follow the same sample -> XCD map as the slab role.
 template <int U, bool HASY, bool PREMUL, bool MIX>
-__global__ __launch_bounds__(256, 2) void hypertem_bwd_wgrad_kernel(const float* __restrict__ dOut, const float* __restrict__ Y,
+__global__ __launch_bounds__(256, HT_OCC) void hypertem_bwd_wgrad_kernel(const float* __restrict__ dOut, const float* __restrict__ Y,
                                                                     const float* __restrict__ X, const float* __restrict__ G,
                                                                     const float* __restrict__ Wbt, const float* __restrict__ R,
                                                                     float* __restrict__ dX, float* __restrict__ dG, float* __restrict__ dWb,
@@ -797,7 +565,7 @@ struct HtPairArgs {
 };
 
 template <int U>
-__global__ __launch_bounds__(256, 2) void hypertem_bwd_pair_kernel(HtPairArgs a, int N, int B, int nH, RowMap rm, int rows_per_split) {
+__global__ __launch_bounds__(256, HT_OCC) void hypertem_bwd_pair_kernel(HtPairArgs a, int N, int B, int nH, RowMap rm, int rows_per_split) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const int ntiles = (N + 15) / 16;
     if ((int)blockIdx.x < nH) {
@@ -868,32 +636,26 @@ extern "C" int gptst_hypertem_bwd_pair(const float* dOut1, const float* X1, cons
 }
 
 // =====================================================================================================================
-// hyperTem forward CHAIN (round 4): up to three consecutive hyperTem layers — optionally preceded by the node-conditioned layer that ends a
-// cap (GPTST.py:137-141: x = LReLU(rec W_n + b_n + x_res)) — in ONE launch on the (b, 16-node) slab.
+// hyperTem forward CHAIN (round 4): up to three consecutive hyperTem layers in ONE launch on the (b, 16-node) slab.
 //
 // Every one of these layers is node-local: a workgroup that owns (sample b, 16 nodes, all 12 time steps) needs nothing from any other
 // workgroup until the next cap (whose sums over the nodes of a (b,t) are the only coupling in an STHCN).  As separate launches each layer pays
 // its own load phase (the 16.7 MB activation comes back from L2 / HBM while every workgroup of the one-round grid waits: 7.6 us of the 22 us,
 // DESIGN.md section 7) and its own fill / drain; here the layer output goes from the accumulators straight back into the LDS slab (and to HBM
-// once, for the backward) and the next layer starts from it.  Chains of the step: [cap1 node layer, hyperTem2, hyperTem3], [cap2 node layer,
-// hyperTem4 (, the decoder's hyperTem1)] (GPTST.py:264-271, :454).
-//
-// Node layer on the slab: a wave takes nodes w, w+4, .. of the tile; per node one 16-row MFMA tile whose rows are the 12 TIME STEPS of the
-// sample (rows 12..15 are padding), A = rec rows straight from global memory, B = W_n fragments from L2 (coalesced float4 rows, as W_bt
-// below), epilogue = bias + residual + LeakyReLU into the slab.  The node-grouped apply64 shares W_n over the 384 (b,t) rows of a node; here
-// every sample re-reads it (B x 2.8 MB of L2 traffic per launch) — the price of staying on the slab.
+// once, for the backward) and the next layer starts from it.  Chains of the step: [hyperTem2, hyperTem3], [hyperTem4, the decoder's hyperTem1]
+// (GPTST.py:267-271, :454).  (r04 also ran the cap's node-conditioned layer as a first stage: measured slower than the node-grouped apply64
+// and removed in r05 — tools/experiments/hypertem_chain_node_layer.hip.)
 struct HtStage { const float* G; const float* Wbt; const float* bbt; float* R_out; float* out; };
 struct HtChain {
     int nstage;                                                   // hyperTem layers: 1 .. 3
-    const float* X;                                               // slab source when no node layer precedes
-    const float* rec; const float* Wn; const float* bn; const float* xres; float* out0;     // node layer (rec != NULL)
+    const float* X;                                               // slab source
     HtStage st[3];
 };
 
-// NODE / NSTAGE are compile-time (the run-time form — one kernel, stage loop over ch.nstage — spilled 250-400 registers: the allocator saw
+// NSTAGE is compile-time (the run-time form — one kernel, stage loop over ch.nstage — spilled 250-400 registers: the allocator saw
 // the fragments of every path live around the loop)
-template <bool NODE, int NSTAGE>
-__global__ __launch_bounds__(256, 2) void hypertem_chain_fwd_kernel(HtChain ch, int N, int B) {
+template <int NSTAGE>
+__global__ __launch_bounds__(256, HT_OCC) void hypertem_chain_fwd_kernel(HtChain ch, int N, int B) {
     constexpr int C = 64, P = C + 4, GP = 145, NT = 16;
     extern __shared__ __attribute__((aligned(16))) float smem[];
     float* Xs = smem;                               // [12][NT][P]
@@ -916,66 +678,7 @@ __global__ __launch_bounds__(256, 2) void hypertem_chain_fwd_kernel(HtChain ch, 
         b4 = ld4((b0) + ((size_t)b * HT_T + (tt)) * C + 4 * j);                                                    \
     } while (0)
 
-    if constexpr (NODE) {
-        // ---- node layer: x[t][n][:] = LReLU(rec[b,t,n,:] W_n + b_n + xres[b,t,n,:]) -> slab + out0 ----
-        HTC_LOAD_G(ch.st[0].G);
-        const int tr = min(j, HT_T - 1);                              // A-operand row = time step (rows >= 12: don't-care)
-        float4 a[4], xr[4], bn4;
-#define HTC_LOAD_NODE(nn) do {                                                                                     \
-            const int n_ = (nn);                                                                                   \
-            const float* W_ = ch.Wn + (size_t)n_ * C * C;                                                          \
-            _Pragma("unroll") for (int q = 0; q < 4; ++q) a[q] = ld4(ch.rec + (((size_t)b * HT_T + tr) * N + n_) * C + 16 * q + 4 * kk); \
-            _Pragma("unroll") for (int q = 0; q < 4; ++q)                                                          \
-                _Pragma("unroll") for (int e = 0; e < 4; ++e) bv[q][e] = ld4(W_ + (size_t)(16 * q + 4 * kk + e) * C + 4 * j); \
-            bn4 = ld4(ch.bn + (size_t)n_ * C + 4 * j);                                                             \
-            _Pragma("unroll") for (int r = 0; r < 4; ++r)                                                          \
-                xr[r] = ld4(ch.xres + (((size_t)b * HT_T + min(4 * kk + r, HT_T - 1)) * N + n_) * C + 4 * j);      \
-        } while (0)
-        if (n0 + wave < N) HTC_LOAD_NODE(n0 + wave);
-        for (int nl = wave; nl < NT; nl += 4) {
-            const int n = n0 + nl;
-            if (n < N) {                                              // wave-uniform
-                SB();
-                f32x4 acc[4];
-#pragma unroll
-                for (int ct = 0; ct < 4; ++ct) acc[ct] = (f32x4){0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-                for (int q = 0; q < 4; ++q) {
-                    const float av[4] = {a[q].x, a[q].y, a[q].z, a[q].w};
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) {
-                        acc[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[e], bv[q][e].x, acc[0], 0, 0, 0);
-                        acc[1] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[e], bv[q][e].y, acc[1], 0, 0, 0);
-                        acc[2] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[e], bv[q][e].z, acc[2], 0, 0, 0);
-                        acc[3] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[e], bv[q][e].w, acc[3], 0, 0, 0);
-                    }
-                }
-                SB();
-                float4 y[4];
-#pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    y[r] = f4add(f4add(make_float4(acc[0][r], acc[1][r], acc[2][r], acc[3][r]), bn4), xr[r]);
-                    y[r].x = lrelu(y[r].x); y[r].y = lrelu(y[r].y); y[r].z = lrelu(y[r].z); y[r].w = lrelu(y[r].w);
-                }
-                if (nl + 4 < NT && n + 4 < N) HTC_LOAD_NODE(n + 4);   // next node's operands: requested before this node's stores
-                SB();
-#pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    const int t = 4 * kk + r;
-                    if (t < HT_T) {
-                        st4(ch.out0 + (((size_t)b * HT_T + t) * N + n) * C + 4 * j, y[r]);
-                        st4(Xs + (t * NT + nl) * P + 4 * j, y[r]);
-                    }
-                }
-            } else {
-#pragma unroll
-                for (int r = 0; r < 4; ++r)
-                    if (4 * kk + r < HT_T) st4(Xs + ((4 * kk + r) * NT + nl) * P + 4 * j, f4zero());
-            }
-        }
-#undef HTC_LOAD_NODE
-        HTC_STORE_G();
-    } else {
+    {
         // ---- slab + graph staging: ALL global loads before the first LDS store (as hypertem_fwd_kernel) ----
         const int nl = tid >> 4, c4 = tid & 15;
         const int n = min(n0 + nl, N - 1);
@@ -1127,18 +830,14 @@ __global__ __launch_bounds__(256, 2) void hypertem_chain_fwd_kernel(HtChain ch, 
 #undef HTC_LOAD_W
 }
 
-// X: input of the first hyperTem layer (ignored when rec != NULL);  rec / Wn (N,C,C) / bn (N,C) / xres / out0: the node layer in front
-// (all five or none);  Gs .. outs: HOST arrays of nstage device pointers (G (N,T,T), Wbt (BT,C,C), bbt (BT,C), R_out or NULL, out), read at
-// call time.  C = 64 only (GPTST_ESHAPE otherwise: use the per-layer entry points).
-extern "C" int gptst_hypertem_chain_fwd(const float* X, const float* rec, const float* Wn, const float* bn, const float* xres, float* out0,
-                                        int nstage, const void* Gs, const void* Wbts, const void* bbts, const void* Rs, const void* outs,
-                                        int B, int T, int N, int C, void* stream) {
-    if (nstage < 1 || nstage > 3 || !Gs || !Wbts || !bbts || !Rs || !outs || T != HT_T || B <= 0 || N <= 0) return GPTST_EARG;
-    const bool node = rec != nullptr;
-    if (node ? (!Wn || !bn || !xres || !out0) : !X) return GPTST_EARG;
+// X: input of the first hyperTem layer;  Gs .. outs: HOST arrays of nstage device pointers (G (N,T,T), Wbt (BT,C,C), bbt (BT,C), R_out or NULL,
+// out), read at call time.  C = 64 only (GPTST_ESHAPE otherwise: use the per-layer entry points).
+extern "C" int gptst_hypertem_chain_fwd(const float* X, int nstage, const void* Gs, const void* Wbts, const void* bbts, const void* Rs,
+                                        const void* outs, int B, int T, int N, int C, void* stream) {
+    if (!X || nstage < 1 || nstage > 3 || !Gs || !Wbts || !bbts || !Rs || !outs || T != HT_T || B <= 0 || N <= 0) return GPTST_EARG;
     if (C != 64) return GPTST_ESHAPE;
     HtChain ch;
-    ch.nstage = nstage; ch.X = X; ch.rec = rec; ch.Wn = Wn; ch.bn = bn; ch.xres = xres; ch.out0 = out0;
+    ch.nstage = nstage; ch.X = X;
     for (int s = 0; s < 3; ++s) {
         const int k = s < nstage ? s : nstage - 1;
         ch.st[s] = HtStage{((const float* const*)Gs)[k], ((const float* const*)Wbts)[k], ((const float* const*)bbts)[k],
@@ -1148,13 +847,12 @@ extern "C" int gptst_hypertem_chain_fwd(const float* X, const float* rec, const 
     const dim3 grid(8 * ((B + 7) / 8) * ((N + 15) / 16));
     const int smem = (int)ht_smem(16);
     hipStream_t st = (hipStream_t)stream;
-#define HTC_LAUNCH(NODE_, NS_) do {                                                                                                   \
+#define HTC_LAUNCH(NS_) do {                                                                                                          \
         static int done_ = 0;                                                                                                          \
-        if (!done_) { (void)hipFuncSetAttribute((const void*)hypertem_chain_fwd_kernel<NODE_, NS_>, hipFuncAttributeMaxDynamicSharedMemorySize, smem); done_ = 1; } \
-        hipLaunchKernelGGL((hypertem_chain_fwd_kernel<NODE_, NS_>), grid, dim3(256), smem, st, ch, N, B);                              \
+        if (!done_) { (void)hipFuncSetAttribute((const void*)hypertem_chain_fwd_kernel<NS_>, hipFuncAttributeMaxDynamicSharedMemorySize, smem); done_ = 1; } \
+        hipLaunchKernelGGL((hypertem_chain_fwd_kernel<NS_>), grid, dim3(256), smem, st, ch, N, B);                                     \
     } while (0)
-    if (node) { if (nstage == 1) HTC_LAUNCH(true, 1); else if (nstage == 2) HTC_LAUNCH(true, 2); else HTC_LAUNCH(true, 3); }
-    else { if (nstage == 1) HTC_LAUNCH(false, 1); else if (nstage == 2) HTC_LAUNCH(false, 2); else HTC_LAUNCH(false, 3); }
+    if (nstage == 1) HTC_LAUNCH(1); else if (nstage == 2) HTC_LAUNCH(2); else HTC_LAUNCH(3);
 #undef HTC_LAUNCH
     GPTST_CHECK_LAUNCH();
     return GPTST_OK;

@@ -32,10 +32,10 @@ template <> __device__ __forceinline__ void stv<1>(float* p, float4 v) { *p = v.
 // UC = 8 column steps per batch in the embedding-gradient jobs, i.e. 3 waves per SIMD, and the reductions stream at 3.8-4.0 TB/s with 48 KB in
 // flight per CU (tools/mb_pooljobs.py).  PJ_OCC = minimum waves per SIMD the compiler must leave room for, PJ_UC / PJ_NU = loads per batch.
 #ifndef PJ_OCC
-#define PJ_OCC 3
-#endif
+#define PJ_OCC 6       // r05: 76 VGPRs with PJ_UC = 4 (was 152 / 3 waves per SIMD): the forward table 32.8 -> 28.0 us, the reduction table unchanged at the
+#endif                 // ~4 TB/s a streaming read reaches on this chip (torch.sum: 3.7-4.9 TB/s), profiles/r05_pooljobs_occupancy.txt
 #ifndef PJ_UC
-#define PJ_UC 8
+#define PJ_UC 4
 #endif
 #ifndef PJ_NU
 #define PJ_NU 4
@@ -450,18 +450,14 @@ extern thread_local int g_apply_tpw;
 extern thread_local int g_tl_nb;
 extern thread_local int g_wgrad_v1;
 extern thread_local int g_apply128_v1;
-extern thread_local int g_ht_fwd12;
 extern thread_local int g_tl_mfma;
 extern thread_local int g_cap_route_v2;
-extern thread_local int g_cap_route_occ6;
 extern thread_local int g_cap_bwd_noroles;
 extern "C" int gptst_tune(int id, int value) {
     if (id == 15) g_tl_mfma = value;
     if (id == 20) g_cap_route_v2 = value;
-    if (id == 21) g_cap_route_occ6 = value;
     if (id == 23) g_cap_bwd_noroles = value;
     if (id == 19) g_pg_sort = value;
-    if (id == 12) g_ht_fwd12 = value;
     if (id == 1 && value > 0 && value <= PG_MAXROWS) g_pg_rows = value;
     if (id == 6 && value > 0) g_tl_nb = value;
     if (id == 2) g_wgrad_ns_override = value;

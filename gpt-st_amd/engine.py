@@ -53,56 +53,17 @@ class _Context(threading.local):
     """Per-thread execution context of a step (thread-local so that several shard steppers can run side by side in one process:
     tests emulate the ranks of a node-sharded run with threads).
       ARENA        ZeroArena of the running step (None -> plain torch.zeros)
-      SIDE         optional second stream for the weight gradients (see SideStream; measured slower, opt-in)
       NODE_REDUCE  node-sharded run: callable that completes a sum over nodes across the ranks, in place (None -> single shard)"""
     ARENA = None
-    SIDE = None
     NODE_REDUCE = None
 
 
 CTX = _Context()
 
 
-class SideStream:
-    """Weight-gradient kernels depend only on saved activations and the incoming gradient, and nothing needs their result
-    until the reductions at the end of the backward — so they can run on a second HIP stream, concurrently with the
-    data-gradient chain on the main stream (fork/join with events; works inside hipGraph capture).  Tensors touched on the side
-    stream are kept alive until the join so the caching allocator cannot hand their memory out on the main stream.
-    Measured twice (r01: 364 vs 403, r02: 495 vs 518 steps/s): slower — the side kernels take CU slots from the critical chain."""
-
-    def __init__(self):
-        self.stream = torch.cuda.Stream()
-        self.pending = []
-        self.active = False
-
-    def fork(self):
-        self.stream.wait_stream(torch.cuda.current_stream())
-        self.active = True
-        return torch.cuda.stream(self.stream)
-
-    def keep(self, *ts):
-        self.pending.extend(ts)
-
-    def join(self):
-        if self.active:
-            torch.cuda.current_stream().wait_stream(self.stream)
-            self.active = False
-        self.pending = []
-
-
-def _wgrad_async(*args, **kw):
-    """ops.wgrad on the side stream when one is installed."""
-    if CTX.SIDE is None:
-        return ops.wgrad(*args, **kw)
-    with CTX.SIDE.fork():
-        r = ops.wgrad(*args, **kw)
-    CTX.SIDE.keep(r[0], *[a for a in args if torch.is_tensor(a)], *[v for v in kw.values() if torch.is_tensor(v)])
-    return r
-
-
-def _join_side():
-    if CTX.SIDE is not None:
-        CTX.SIDE.join()
+# (r05: the side-stream modes of rounds 1-3 — weight gradients, reductions, parameter generation and the KL backward on a second stream / graph
+#  branch — were each measured slower than the single chain (DESIGN.md sections 7-8: 364 vs 403, 558-579 vs 597, 651 / 659 vs 675 steps/s) and left
+#  the engine; the one fork that remains is the data-parallel gradient bucket's all-reduce, Reductions.flush_async.)
 
 
 class Reductions:
@@ -112,16 +73,12 @@ class Reductions:
     executed at the end of the backward as THREE launches (gram_bwd, one job table, one time-feature job table) instead of ~20
     small launches per STHCN.  Nothing on the critical chain waits for these results; only the optimiser does."""
 
-    def __init__(self, side=None):
-        """side: optional SideStream — flush_async() then runs what has been queued so far on it, concurrently with the rest of
-        the backward chain (one fork per call, ONE join in flush())."""
+    def __init__(self):
         self.jobs = ops.PoolJobs()
         self.grams = []          # (A (L*N,Hm,T), dG (L*N,T,T), dA out)
         self.tf = []             # (params, grads, dout, rows, K)
         self.keep = []
-        self.side = side
-        self.held = []
-        self.on_bucket = None    # callable(k): gradient bucket k is complete (k = 0: the decoder's) — called INSIDE the side-stream fork, right behind
+        self.on_bucket = None    # callable(k): gradient bucket k is complete (k = 0: the decoder's) — called on the forked stream, right behind
         self.nbucket = 0         # the reductions that finish it, so a data-parallel step can enqueue that bucket's all-reduce under the rest of the backward
 
     def gram(self, A, dG, dA, N, nsG):
@@ -134,10 +91,9 @@ class Reductions:
         self.tf.append((_tf_tensors(p, pfx), _tf_tensors(g, pfx), dout, rows, K))
 
     def flush_async(self, tidx):
-        """Run everything queued so far on the side stream (it depends only on finished layers of the backward); no-op without one.
-        bucket_inline (a data-parallel step, GPTST_DP_OVERLAP=1): the reductions run HERE, on the calling stream (a side branch of ~1300
-        bandwidth-bound workgroups slows the chain it runs under by more than it hides: 717 vs 752 steps/s at one rank), and only the
-        bucket's all-reduce — a few RCCL workgroups — is forked under the rest of the backward."""
+        """A gradient bucket is complete (a data-parallel step, GPTST_DP_OVERLAP=1; no-op otherwise): its reductions run HERE, on the calling
+        stream (as a side branch their ~1300 bandwidth-bound workgroups slowed the chain they ran under by more than they hid: 717 vs 752
+        steps/s at one rank), and only the bucket's all-reduce — a few RCCL workgroups — is forked under the rest of the backward."""
         if getattr(self, "bucket_inline", False) and self.on_bucket is not None and self.nbucket == 0 and (self.jobs.jobs or self.grams or self.tf):
             self._run(tidx)
             self.fork_side.wait_stream(torch.cuda.current_stream())
@@ -145,24 +101,12 @@ class Reductions:
                 self.on_bucket(0)
             self.forked = True
             self.nbucket += 1
-            return
-        if self.side is None or not (self.jobs.jobs or self.grams or self.tf):
-            return
-        self.held.append((self.keep, list(self.jobs.jobs), list(self.grams), list(self.tf)))      # alive until the join
-        with self.side.fork():
-            self._run(tidx)
-            if self.on_bucket is not None:
-                self.on_bucket(self.nbucket)
-        self.nbucket += 1
 
     def flush(self, tidx):
         self._run(tidx)
-        if self.side is not None:
-            self.side.join()
         if getattr(self, "forked", False):
             torch.cuda.current_stream().wait_stream(self.fork_side)
             self.forked = False
-        self.held = []
 
     def _run(self, tidx):
         gr, self.grams = sorted(self.grams, key=lambda t: t[0].data_ptr()), []
@@ -212,7 +156,7 @@ DROP_R = os.environ.get("GPTST_DROP_R", "0") == "1"
 
 def _ht_fused_bwd(dims):
     """the one-launch hyperTem backward (hypertem_bwd_wgrad) serves this step"""
-    return dims[3] == 64 and CTX.SIDE is None and FUSE_HT_BWD
+    return dims[3] == 64 and FUSE_HT_BWD
 
 
 def hypertem_core_fwd(x, G, Wbt, bbt, dims):
@@ -222,18 +166,12 @@ def hypertem_core_fwd(x, G, Wbt, bbt, dims):
         keep = not (DROP_R and _ht_fused_bwd(dims) and ops.wgrad_nsplit(MODE_TIME, B * T, N, C) == 1)
         R, out = ops.hypertem_fwd(x.view(B, T, N, C), G, Wbt, bbt, want_R=keep)         # :157-158 + :162-163 fused
         R, out = (R.view(-1, C) if keep else None), out.view(-1, C)
-    elif C == 128 and HT128_FUSED:
-        R, out = ops.hypertem_fwd(x.view(B, T, N, C), G, Wbt, bbt, want_R=True)         # the same fusion at C = 128 (hypertem_fwd128_kernel)
-        R, out = R.view(-1, C), out.view(-1, C)
     else:
         R = ops.tmix(x.view(B, T, N, C), G).view(-1, C)                                 # :157-158
         out = ops.apply(R, Wbt, MODE_TIME, B * T, N, bias=bbt, resid=x, epi=EPI_RES_LRELU)  # :162-163
     return out, (x, R, out, G, Wbt)
 
 
-# C = 128: slab-fused hyperTem forward (hypertem_fwd128_kernel) instead of tmix + apply128.  Built and parity-tested, but measured SLOWER at
-# N = 4096, B = 32 (1086 vs 285 + 587 us per layer: one 101 KB slab per CU, nothing overlaps the staging): opt-in.
-HT128_FUSED = os.environ.get("GPTST_HT128_FUSED", "0") == "1"
 FUSE_HT_BWD = True         # hyperTem backward + its weight gradient in one launch (False: two launches)
 
 
@@ -263,12 +201,12 @@ def hypertem_core_bwd(saved, dout, dG_out, dims, chain=False, premul=False):
         dx = dx.view(-1, C)
     elif C == 64:
         # the weight-gradient kernel also emits the bias gradient (column sums of dPre per (b,t)): rows [dW_bt | db_bt]
-        dWb, ns = _wgrad_async(R, dout, MODE_TIME, BT, N, D2=out, pro=PRO_DPRE, colsum_d=True)
+        dWb, ns = ops.wgrad(R, dout, MODE_TIME, BT, N, D2=out, pro=PRO_DPRE, colsum_d=True)
         dWbt, dbias, nsb = dWb[:, :C * C], dWb[:, C * C:], ns
         dx, _, _ = ops.hypertem_bwd(dout.view(B, T, N, C), out.view(B, T, N, C), x.view(B, T, N, C), G, Wbt, dG=dG_out, want_dbias=False)
         dx = dx.view(-1, C)
     else:
-        dWb, ns = _wgrad_async(R, dout, MODE_TIME, BT, N, D2=out, pro=PRO_DPRE, colsum_d=True)
+        dWb, ns = ops.wgrad(R, dout, MODE_TIME, BT, N, D2=out, pro=PRO_DPRE, colsum_d=True)
         dWbt, dbias, nsb = dWb[:, :C * C], dWb[:, C * C:], ns
         dR = ops.apply(dout, Wbt, MODE_TIME, BT, N, A2=out, transw=True, pro=PRO_DPRE)
         dx, _ = ops.tmix_bwd(dR.view(B, T, N, C), x.view(B, T, N, C), G, dout.view(B, T, N, C), out.view(B, T, N, C), dG=dG_out[0])
@@ -306,7 +244,7 @@ def _ht_pair_shape_ok(dims):
 
 def ht_pair_ok(saved1, saved0, dims):
     return (PAIR_BWD and dims[3] == 64 and not isinstance(saved1, EncIn) and saved1[1] is not None and saved0[1] is not None
-            and CTX.SIDE is None and _ht_fused_bwd(dims) and _ht_pair_shape_ok(dims))
+            and _ht_fused_bwd(dims) and _ht_pair_shape_ok(dims))
 
 
 class PendingH1:
@@ -338,10 +276,9 @@ def ht_pair_bwd(saved1, saved0, dout, dG1, dG0, dims, dWb1=None):
 # ---- cap (GPTST.py:100-141) ----------------------------------------------------------------------------------------
 FUSE_CROSS = os.environ.get("GPTST_FUSE_CROSS", "1") == "1"     # cross-time block folded into its (b,t)-grouped neighbours (r03)
 CAP_LIN = os.environ.get("GPTST_CAP_LIN", "1") == "1"           # ... and the entry Linear's backward folded into the same launch (r05)
-CROSS_ROLE = int(os.environ.get("GPTST_CROSS_ROLE", "1"))       # ... its backward as a ROLE of the routing backward's launch (r04; 0: replicated
-                                                                # prologue; 2: the rec backward as a third role of the same launch — measured
-                                                                # 799 vs 814 steps/s: rec -> cross-time -> routing tail is ONE dependent chain
-                                                                # (16 + 16 + 10 us, profiles/r04_roles3_stamps.txt), so it stays off)
+CROSS_ROLE = int(os.environ.get("GPTST_CROSS_ROLE", "1"))       # ... its backward as a ROLE of the routing backward's launch (r04; 0: replicated prologue —
+                                                                # what a stepper falls back to after a lost hand-off.  The rec backward as a THIRD role
+                                                                # measured 799 vs 814 steps/s, profiles/r04_roles3_stamps.txt, and left the library in r05)
 
 
 def cap_head_fwd(p, pfx, x, dadj, dyn, dims, num_route, HS, HT):
@@ -366,22 +303,21 @@ def cap_core_fwd(p, pfx, x, dadj, dyn, Wn, bn, dims, num_route, HS, HT):
     return out, c, (x, out, rec, c, s, v, Ht, Rt, dyn, Wn, Y)
 
 
-# Forward chains on the (sample, 16-node) slab (r04, gptst_hypertem_chain_fwd): the node-conditioned layer that ends a cap and the hyperTem
-# layers behind it are node-local, so [cap1 node layer, hyperTem2, hyperTem3] and [cap2 node layer, hyperTem4 (, the next STHCN's hyperTem1)]
-# run as ONE launch each — 10 -> 7 launches per STHCN forward, and the chained layers have no load phase of their own.  GPTST_CHAIN_FWD=0: one
-# launch per layer.
+# Forward chains on the (sample, 16-node) slab (r04, gptst_hypertem_chain_fwd): consecutive hyperTem layers are node-local, so [hyperTem2, hyperTem3]
+# and [hyperTem4, the next STHCN's hyperTem1] run as ONE launch each, and the chained layer has no load phase of its own.  GPTST_CHAIN_FWD=0: one
+# launch per layer.  (The caps' node layers stay on the node-grouped apply64 — it shares W_n over the 384 (b,t) rows of a node: 12.6 us against
+# ~18 us for the per-sample form inside the chain launch, measured in r04 and removed in r05.)
 CHAIN_FWD = os.environ.get("GPTST_CHAIN_FWD", "1") == "1"
-CHAIN_NODE = os.environ.get("GPTST_CHAIN_NODE", "0") == "1"      # also the caps' node layers inside the chain launches (measured slower: see sthcn_fwd)
 
 
 def chain_fwd_ok(dims):
-    return CHAIN_FWD and dims[3] == 64 and CTX.SIDE is None and not DROP_R      # (node shards too: the chained layers are node-local, r05)
+    return CHAIN_FWD and dims[3] == 64 and not DROP_R      # (node shards too: the chained layers are node-local, r05)
 
 
 def ht_chain_fwd(x, stages, dims):
     """consecutive hyperTem layers in one launch -> [saved tuple per layer], last output.  stages: [(G, Wbt, bbt), ...]"""
     B, T, N, C = dims
-    _, res = ops.hypertem_chain_fwd(x.view(B, T, N, C), stages)
+    res = ops.hypertem_chain_fwd(x.view(B, T, N, C), stages)
     saved, xin = [], x
     for (G, Wbt, _b), (R, o) in zip(stages, res):
         o = o.view(-1, C)
@@ -390,40 +326,22 @@ def ht_chain_fwd(x, stages, dims):
     return saved, xin
 
 
-def cap_tail_chain_fwd(x, rec, Wn, bn, stages, dims):
-    """node layer of a cap + the hyperTem layers behind it in one launch -> out of the cap, [(saved tuple of each hyperTem layer)], last output.
-    stages: [(G, Wbt, bbt), ...]"""
-    B, T, N, C = dims
-    out0, res = ops.hypertem_chain_fwd(None, stages, node=(rec, Wn, bn, x.view(B, T, N, C)))
-    out0 = out0.view(-1, C)
-    saved, xin = [], out0
-    for (G, Wbt, _), (R, o) in zip(stages, res):
-        o = o.view(-1, C)
-        saved.append((xin, R.view(-1, C), o, G, Wbt))
-        xin = o
-    return out0, saved, xin
-
-
 def cap_core_bwd(p, g, pfx, saved, dout, dims, HS, HT, red, chain=False):
     """-> dx and the pieces whose reductions are batched by the caller: (dWn, nsplit, dbn, ddyn, dlogit).
     chain: dout already is dPre, and dx is returned multiplied by lrelu'(x) (x is a hyperTem output)."""
     B, T, N, C = dims
     x, out, rec, c, s, v, Ht, Rt, dyn, Wn, Y = saved
     BT, dev = B * T, x.device
-    assert not chain or (C == 64 and CTX.SIDE is None)
-    if C == 64 and CTX.SIDE is None:     # data gradient, weight gradient and bias gradient of the node-conditioned layer in one pass
+    assert not chain or C == 64
+    if C == 64:     # data gradient, weight gradient and bias gradient of the node-conditioned layer in one pass
         drec, dWn, dbn, ns = ops.apply_wgrad(dout, None if chain else out, rec, Wn, MODE_NODE, BT, N)
         nsb = ns
     else:
         drec = ops.apply(dout, Wn, MODE_NODE, BT, N, A2=out, transw=True, pro=PRO_DPRE)
-        dWb, ns = _wgrad_async(rec, dout, MODE_NODE, BT, N, D2=out, pro=PRO_DPRE, colsum_d=True)                    # rows [dWn | dbn] per split
+        dWb, ns = ops.wgrad(rec, dout, MODE_NODE, BT, N, D2=out, pro=PRO_DPRE, colsum_d=True)                    # rows [dWn | dbn] per split
         dWn, dbn, nsb = dWb[:, :C * C], dWb[:, C * C:], ns
     fused = None
-    if FUSE_CROSS and CROSS_ROLE >= 2 and CTX.NODE_REDUCE is None and Y is None:        # rec backward + cross-time backward + routing backward: 3 roles
-        fused = ops.cap_rec_cross_route_bwd(drec, v, x.view(B, T, N, C), p[pfx + "ln_p.weight"], p[pfx + "ln_p.bias"], c, s, Rt, Ht, dyn,
-                                            p[pfx + "mask_template"], B, T, HS, HT, _zeros(x, 5 * B + B * T))
-    if fused is None:
-        dc1, dv = ops.cap_rec_bwd(drec, c, v, reduce_nodes=CTX.NODE_REDUCE)
+    dc1, dv = ops.cap_rec_bwd(drec, c, v, reduce_nodes=CTX.NODE_REDUCE)
     gw, gb = g[pfx + "ln_p.weight"], g[pfx + "ln_p.bias"]
     if fused is None and FUSE_CROSS and CAP_LIN and C == 64 and CTX.NODE_REDUCE is None and Y is None:
         # r05: cross-time backward (role) + routing backward + the entry Linear's backward and the residual branch in ONE launch; dY never leaves LDS
@@ -524,13 +442,10 @@ def _sthcn_gen_jobs(p, pfx, emb, jobs, A_all, dims, G_all=None):
     return dict(emb=emb, gen=(A_all, hts, cps, d, Hm, ds, HS, HT), Wb=Wb, Wn=Wn, dadj=dadj, dyn=dyn)
 
 
-def gen_all(p, tidx, dims, which=(ENC, DEC), guide=True, side=None):
+def gen_all(p, tidx, dims, which=(ENC, DEC), guide=True):
     """Everything of a step that depends only on the time index and the parameters — the seven time embeddings (:256-261, :337)
     and every generated parameter of both STHCNs and of the guide MLP — in THREE launches (one time-feature job table, one
-    poolgen job table, one gram) instead of 23.  -> {prefix: gen dict, "guide": (t4m, Wspa, bspa, Wtem, btem)}
-    side (a SideStream): the guide's four generated parameters get their own small job table on the calling stream and the STHCNs' table
-    + gram run on the side stream — the caller joins it (side.join()) before the encoder; they then overlap with the guide classifier and
-    the mask selection, whose launches use a fraction of the chip."""
+    poolgen job table, one gram) instead of 23.  -> {prefix: gen dict, "guide": (t4m, Wspa, bspa, Wtem, btem)}"""
     B, T, N, C = dims
     tfj = []
     for pfx in which:
@@ -542,15 +457,12 @@ def gen_all(p, tidx, dims, which=(ENC, DEC), guide=True, side=None):
     jobs = ops.PoolJobs()
     res = {}
     L = 4 * len(which)
-    split = side is not None and guide and L
     if guide:
-        gj = ops.PoolJobs() if split else jobs
+        gj = jobs
         m = "encoder.MLP_RL."
         t4m = embs[-1]
         res["guide"] = (t4m, gj.fwd(p["encoder.neb4mask"], p[m + "weights_pool_spa"]), gj.fwd(p["encoder.neb4mask"], p[m + "bias_pool_spa"]),
                         gj.fwd(t4m, p[m + "weights_pool_tem"]), gj.fwd(t4m, p[m + "bias_pool_tem"]))
-        if split:
-            gj.launch()
     if L:
         adj0 = p[which[0] + "hyperTem1.adj"]
         Hm = adj0.shape[1]
@@ -561,15 +473,7 @@ def gen_all(p, tidx, dims, which=(ENC, DEC), guide=True, side=None):
             res[pfx]["slot"] = (k, len(which))
             res[pfx]["G_all"] = G_all[4 * k:4 * k + 4]
 
-    def rest():
-        jobs.launch()                                    # generated parameters AND the temporal graphs: one launch
-        return G_all if L else None
-    if split:
-        with side.fork():
-            G_all = rest()
-        side.keep(A_all, G_all, embs, res)
-    else:
-        rest()
+    jobs.launch()                                        # generated parameters AND the temporal graphs: one launch
     return res
 
 
@@ -586,23 +490,8 @@ def sthcn_fwd(p, pfx, tidx, x, dims, num_route, gen=None, head=None, next_gen=No
         x, sv["h1"] = head
     else:
         x, sv["h1"] = hypertem_core_fwd(x, G_all[0], Wb[0], Wb[1], dims)
-    if chain_fwd_ok(dims) and CHAIN_NODE:
-        rec, c1, (s, v, Ht, Rt, Y) = cap_head_fwd(p, cps[0], x, dadj[0], dyn[0], dims, num_route, HS, HT)
-        o, (sv["h2"], sv["h3"]), x3 = cap_tail_chain_fwd(x, rec, Wn[0], Wn[1], [(G_all[1], Wb[2], Wb[3]), (G_all[2], Wb[4], Wb[5])], dims)
-        sv["c1"] = (x, o, rec, c1, s, v, Ht, Rt, dyn[0], Wn[0], Y)
-        rec, c2, (s, v, Ht, Rt, Y) = cap_head_fwd(p, cps[1], x3, dadj[1], dyn[1], dims, num_route, HS, HT)
-        stages = [(G_all[3], Wb[6], Wb[7])]
-        if next_gen is not None:
-            stages.append((next_gen["G_all"][0], next_gen["Wb"][0], next_gen["Wb"][1]))
-        o, hs, xl = cap_tail_chain_fwd(x3, rec, Wn[2], Wn[3], stages, dims)
-        sv["c2"] = (x3, o, rec, c2, s, v, Ht, Rt, dyn[1], Wn[2], Y)
-        sv["h4"] = hs[0]
-        x = hs[0][2]
-        if next_gen is not None:
-            nhead = (xl, hs[1])
-    elif chain_fwd_ok(dims):
-        # hyperTem PAIRS on the slab; the caps' node layers stay on the node-grouped apply64 (it shares W_n over the 384 (b,t) rows of a node: 12.6 us
-        # against ~18 us for the per-sample form inside the chain launch, tools/mb_kernels.py chain)
+    if chain_fwd_ok(dims):
+        # hyperTem PAIRS on the slab (the caps' node layers stay on the node-grouped apply64)
         x, c1, sv["c1"] = cap_core_fwd(p, cps[0], x, dadj[0], dyn[0], Wn[0], Wn[1], dims, num_route, HS, HT)
         (sv["h2"], sv["h3"]), x = ht_chain_fwd(x, [(G_all[1], Wb[2], Wb[3]), (G_all[2], Wb[4], Wb[5])], dims)
         x, _, sv["c2"] = cap_core_fwd(p, cps[1], x, dadj[1], dyn[1], Wn[2], Wn[3], dims, num_route, HS, HT)
@@ -690,7 +579,6 @@ def sthcn_bwd(p, g, pfx, tidx, sv, dout, dims, red, chain=False, premul_in=False
         dd = PendingH1(sv["h1"], dd, dG_all[0], dWb)
     else:
         dd, hp1 = hypertem_core_bwd(sv["h1"], dd, dG_all[0], dims, chain, premul_in)
-    _join_side()
     # ---- gradient reductions of all generated parameters: queued, executed by red.flush() ----
     J = red.jobs
     CC, BT = C * C, B * T
@@ -902,7 +790,7 @@ def model_bwd(p, g, source, mask, tidx, sv_e, sv_d, dec, d_out, d_dec, dims, bas
     # bucket must be complete when its backward ends (data-parallel overlap / a side stream flush the decoder's reductions right here)
     # r05: also under the data-parallel bucket overlap — the decoder's bucket then closes ONE LAUNCH later, behind the pair launch that finishes its
     # first layer (the bucket's reductions and its forked all-reduce still run under the rest of the encoder's backward)
-    defer = (chain and red.side is None and (red.on_bucket is None or PAIR_UNDER_DP) and not isinstance(sv_d["h1"], EncIn)
+    defer = (chain and (red.on_bucket is None or PAIR_UNDER_DP) and not isinstance(sv_d["h1"], EncIn)
              and ht_pair_ok(sv_d["h1"], sv_e["h4"], dims))
     late = defer and red.on_bucket is not None
     d_emb = sthcn_bwd(p, g, DEC, tidx, sv_d, dd, dims, red, chain, True, defer_h1=defer)     # the decoder's input is the encoder's last LeakyReLU output

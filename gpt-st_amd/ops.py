@@ -301,24 +301,17 @@ def hypertem_fwd(X, G, Wbt, bbt, want_R=True):
     return R, out
 
 
-def hypertem_chain_fwd(X, stages, node=None, want_R=True):
-    """Consecutive hyperTem layers (and optionally the node-conditioned layer of a cap in front) in ONE launch on the (sample, 16-node)
-    slab (gptst_hypertem_chain_fwd, C = 64).  X (B,T,N,C): input of the first layer, ignored with node;  stages: [(G, Wbt, bbt), ...] (1..3);
-    node: (rec (B*T*N,C), Wn (N,C,C), bn (N,C), xres (B*T*N,C)) -> out0 = LReLU(rec W_n + b_n + xres).
-    -> (out0 or None, [(R or None, out), ...]), all (B,T,N,C)."""
-    ref = X if node is None else node[3]
-    B, T, N, C = ref.shape if ref.dim() == 4 else X.shape
-    _chk(X if node is None else None, *(node or ()), *[t for st in stages for t in st])
-    f = lambda: torch.empty(B, T, N, C, device=ref.device, dtype=torch.float32)
-    out0 = f() if node is not None else None
+def hypertem_chain_fwd(X, stages, want_R=True):
+    """Consecutive hyperTem layers in ONE launch on the (sample, 16-node) slab (gptst_hypertem_chain_fwd, C = 64).  X (B,T,N,C): input of the
+    first layer;  stages: [(G, Wbt, bbt), ...] (1..3)  ->  [(R or None, out), ...], all (B,T,N,C)."""
+    B, T, N, C = X.shape
+    _chk(X, *[t for st in stages for t in st])
+    f = lambda: torch.empty(B, T, N, C, device=X.device, dtype=torch.float32)
     Rs = [f() if want_R else None for _ in stages]
     outs = [f() for _ in stages]
-    rec, Wn, bn, xres = node if node is not None else (None, None, None, None)
-    _call("gptst_hypertem_chain_fwd", _p(X) if node is None else None, _p(rec), _p(Wn), _p(bn), _p(xres), _p(out0), len(stages),
-          _ptrs0([st[0] for st in stages]), _ptrs0([st[1] for st in stages]), _ptrs0([st[2] for st in stages]),
-          _ptrs0(Rs), _ptrs0(outs), B, T, N, C, tag="node%d x%d" % (node is not None, len(stages)),
-          nbytes=_nb(X if node is None else None, rec, xres, out0, *Rs, *outs))
-    return out0, list(zip(Rs, outs))
+    _call("gptst_hypertem_chain_fwd", _p(X), len(stages), _ptrs0([st[0] for st in stages]), _ptrs0([st[1] for st in stages]),
+          _ptrs0([st[2] for st in stages]), _ptrs0(Rs), _ptrs0(outs), B, T, N, C, tag="x%d" % len(stages), nbytes=_nb(X, *Rs, *outs))
+    return list(zip(Rs, outs))
 
 
 def encin_ht1_fwd(source, base, mask, fill, w, bi, G, Wbt, bbt):
@@ -710,29 +703,6 @@ def cap_cross_route_lin_bwd(X, Wp, bp, c, dc1, dv, s, Rt, Ht, dyn, tmpl, dPre, o
             raise
         return None
     return dX, dWp, dbp, dlogit, ddyn
-
-
-def cap_rec_cross_route_bwd(drec, v, X, Wp, bp, c, s, Rt, Ht, dyn, tmpl, B, T, HS, HT, flags):
-    """cap_rec_bwd + cap_cross_route_bwd as three roles of ONE launch -> (dY, dlogit, ddyn), or None where the role form does not serve.
-    flags: 5 B + B T ZEROED 32-bit words."""
-    _chk(drec, v, X, Wp, bp, c, s, Rt, Ht, dyn, tmpl, flags)
-    N, C = X.shape[2], X.shape[3]
-    if C != 64 or FORCE_CAP_BIG:
-        return None
-    dY = torch.empty(B * T * N, C, device=X.device, dtype=torch.float32)
-    dlogit = torch.empty_like(c)
-    ddyn = torch.empty_like(dyn)
-    dc1 = torch.empty_like(c)
-    ws = torch.empty(2, B * T, HS, C, device=X.device, dtype=torch.float32)
-    try:
-        _call("gptst_cap_rec_cross_route_bwd", _p(drec), _p(v), _p(X), _p(Wp), _p(bp), _p(c), _p(s), _p(Rt), _p(Ht), _p(dyn), _p(tmpl), _p(dY),
-              _p(dlogit), _p(ddyn), _p(dc1), _p(ws[0]), _p(ws[1]), _p(flags), B, T, N, C, HS, HT,
-              nbytes=_nb(drec, X, Wp, bp, c, v, s, Rt, dY, dlogit))
-    except _C.GptstError as e:
-        if e.code != _C.ESHAPE:
-            raise
-        return None
-    return dY, dlogit, ddyn
 
 
 # ---- mask generation (integer path) -----------------------------------------------------------------------------

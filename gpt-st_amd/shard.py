@@ -267,7 +267,7 @@ class ShardedPretrainStep(PretrainStep):
         p, g = mdl.param_views(), self.g
         M = self.B * self.T * self.Nl
         ctx = engine.CTX
-        ctx.ARENA, ctx.SIDE, ctx.NODE_REDUCE = self.arena, None, self.group.all_reduce_
+        ctx.ARENA, ctx.NODE_REDUCE = self.arena, self.group.all_reduce_
         try:
             src = self.src
             # zero_grad + the step's zero scratch + the time index (every node carries the same one, GPTST.py:256-257) + the GLOBAL mask noise

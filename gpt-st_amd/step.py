@@ -89,29 +89,16 @@ class PretrainStep:
             self.noise_a_g, self.noise_r_g = self.noise_ar_g[:Mg], self.noise_ar_g[Mg:]
             self.label_l = torch.zeros(M, dtype=torch.int32, device=self.dev)
             self.label_g = torch.zeros(Mg, dtype=torch.int32, device=self.dev)
-        # measured: running weight gradients on a second stream slows the step (364 vs 403 steps/s), so opt-in only
-        self.side = engine.SideStream() if os.environ.get("GPTST_SIDE_STREAM", "0") == "1" else None
-        # opt-in: parameter-gradient reductions of finished layers on a second stream under the rest of the backward chain
-        # (measured r02k: 558-579 vs 597 steps/s — the side kernels take CU slots from the chain, as the weight gradients did)
-        self.red_side = engine.SideStream() if os.environ.get("GPTST_RED_STREAM", "0") == "1" else None
         # r04, data parallel on the capturable communicator: the gradient leaves in BUCKETS — the decoder's parameters are complete when the decoder's
         # backward ends, so their reductions + all-reduce run on a forked branch UNDER the encoder's backward; only the encoder / KL bucket
         # is exchanged behind the chain (one 4.15 MB all-reduce behind everything before).  GPTST_DP_OVERLAP=0: the single all-reduce.
-        # GPTST_DP_OVERLAP: 1 (default) = the bucket's reductions on the chain's stream, only its all-reduce forked; 2 = reductions AND all-reduce forked
-        # (measured at one rank: 2 costs 5 % — the branch's ~1300 bandwidth-bound workgroups slow the encoder's backward); 0 = off
+        # (the bucket's reductions stay on the chain's stream, only its all-reduce is forked: forking the reductions too cost 5 % at one rank)
         self.always_guide = os.environ.get("GPTST_ALWAYS_GUIDE", "0") == "1"      # run the guide classifier in the random-mask phase too (as the reference does)
-        self.dp_overlap_mode = int(os.environ.get("GPTST_DP_OVERLAP", "1"))
-        self.dp_overlap = (self.dp_overlap_mode > 0 and dp is not None and getattr(dp, "capturable", False)
+        self.dp_overlap = (os.environ.get("GPTST_DP_OVERLAP", "1") != "0" and dp is not None and getattr(dp, "capturable", False)
                            and (self.W > 1 or os.environ.get("GPTST_FORCE_DP", "0") == "1"))
         self.dec_lo, self.dec_hi = self._decoder_bucket(model)
         self.rank_weight = 1.0                          # 0.0: this rank steps on padding (eager tail round of a data-parallel epoch, see _allreduce)
         self.fork_side = torch.cuda.Stream() if self.dp_overlap else None
-        if self.dp_overlap and self.dp_overlap_mode == 2 and self.red_side is None:
-            self.red_side = engine.SideStream()
-        # generation of the STHCNs' parameters under the guide classifier + mask selection (small launches that leave most CUs idle)
-        self.gen_side = engine.SideStream() if os.environ.get("GPTST_GEN_BRANCH", "0") == "1" else None
-        # the guide classifier's backward (KL path) on a branch of its own beside the decoder forward and the whole backward chain
-        self.kl_side = engine.SideStream() if os.environ.get("GPTST_KL_BRANCH", "0") == "1" else None
 
     # ---- the enqueued work ---------------------------------------------------------------------------------------
     # A step is enqueued in two parts: part 1 ends with the guide classifier (the cluster labels of the local rows), part 2 starts
@@ -155,7 +142,6 @@ class PretrainStep:
     def _part1(self, phase):
         p, dims, base = self.model.param_views(), self.dims, self.base
         engine.CTX.ARENA = self.arena
-        engine.CTX.SIDE = self.side
         src = self.src
         # zero_grad + the step's zero scratch + the time index of node 0: one launch
         noise = None                                              # the step's mask noise is drawn by the same launch (unless injected / forced)
@@ -165,12 +151,12 @@ class PretrainStep:
         # the guide classifier (GPTST.py:325-332) feeds the adaptive mask and the KL term only: the random-mask phase of the FUSED step neither
         # generates its parameters nor runs it (the reference computes and discards the logits there; GPTST_Model.forward still returns them)
         need_guide = phase == 1 or self.always_guide
-        gen = engine.gen_all(p, tidx, dims, side=self.gen_side, guide=need_guide)   # time embeddings + every generated parameter: 3 launches
-        red = engine.Reductions(side=self.red_side)
+        gen = engine.gen_all(p, tidx, dims, guide=need_guide)   # time embeddings + every generated parameter: 3 launches
+        red = engine.Reductions()
         self._dec_reduced = False
         if self.dp_overlap and self._dp_in_graph():
             red.on_bucket = self._bucket_ready
-            red.bucket_inline, red.fork_side = self.dp_overlap_mode == 1, self.fork_side
+            red.bucket_inline, red.fork_side = True, self.fork_side
         lowrank = self.fused_tails and engine.chain_ok(dims)      # the guide's backward (KL path) is the dPre chain: its first layers may run low-rank
         prob, sv_g = engine.guide_fwd(p, src, tidx, dims, base, gen=gen["guide"], lowrank_in=lowrank) if need_guide else (None, None)
         if self._needs_exchange(phase):
@@ -189,7 +175,6 @@ class PretrainStep:
         M = self.B * self.T * self.N
         src, tidx, gen, red, prob, sv_g = self.src, ctx["tidx"], ctx["gen"], ctx["red"], ctx["prob"], ctx["sv_g"]
         engine.CTX.ARENA = self.arena
-        engine.CTX.SIDE = self.side
         if self.gmask:
             mask = self._global_mask(phase)
         else:
@@ -202,8 +187,6 @@ class PretrainStep:
                 mask = ops.mask_adaptive(label, counts, self.ctrl[:self.HS], self.ctrl[self.HS:], self.noise_a, self.noise_r,
                                          a.ada_type == "all", base, ws=self._mask_ws(), u24=U24)[2]
         self.last_mask = mask
-        if self.gen_side is not None:
-            self.gen_side.join()
         dec_head = None
         lowrank = self.fused_tails and engine.chain_ok(dims)      # the backward below is the dPre chain: the low-rank first layer may run
         if engine.chain_fwd_ok(dims):          # the decoder's first hyperTem layer rides on the encoder's last chain launch
@@ -222,14 +205,9 @@ class PretrainStep:
                 dh2 = engine.kl_head(p, g, sv_g, prob, c1, self.N, 0.1, sws, red, chain=chain)
                 engine.guide_bwd(p, g, src, tidx, sv_g, None, dims, base, red, dh2=dh2, chain=chain)
             out, dd = engine.loss_tail(p, g, dec, src, mask, base, self.std, self.mean, a.mape_thresh, sws, red, chain=chain)
-            if phase == 1 and self.kl_side is not None:                        # needs only c1 / prob of the forward: beside the backward chain
-                with self.kl_side.fork():
-                    kl_path()
             engine.model_bwd(p, g, src, mask, tidx, sv_e, sv_d, dec, None, None, dims, base, mdl.scaler_zeros, red, dd=dd, chain=chain)
-            if phase == 1 and self.kl_side is None:
+            if phase == 1:
                 kl_path()
-            if self.kl_side is not None:
-                self.kl_side.join()
             if self.dp is None and not self.global_count_scale:
                 self._sws = sws                                                # folded by the optimiser's first launch (one launch less)
             else:
@@ -242,10 +220,8 @@ class PretrainStep:
             if phase == 1:
                 dlogit = ops.kl(prob, c1, self.N, 0.1, self.stats)
                 engine.guide_bwd(p, g, src, tidx, sv_g, dlogit, dims, base, red)
-        engine._join_side()
         red.flush(tidx)                                           # all parameter-gradient reductions: 3 launches
         engine.CTX.ARENA = None
-        engine.CTX.SIDE = None
         if self.dp is None:
             self._optim()
         elif self._dp_in_graph():           # gradient all-reduce + optimiser as the last nodes of the step's graph (no host gap behind the replay)
@@ -432,7 +408,6 @@ class PretrainStep:
         finally:
             ops.set_deterministic(False)
             engine.CTX.ARENA = None
-            engine.CTX.SIDE = None
             self.model.flat.copy_(keep[0]); self.m.copy_(keep[1]); self.v.copy_(keep[2])   # undo the warm-up updates (also when the capture failed)
             torch.cuda.synchronize()
         self.graphs[key] = (g1, g2)
@@ -582,7 +557,6 @@ class PretrainStep:
         finally:
             ops.set_deterministic(False)
             engine.CTX.ARENA = None
-            engine.CTX.SIDE = None
             self.model.flat.copy_(keep[0]); self.m.copy_(keep[1]); self.v.copy_(keep[2])   # undo the warm-up updates
             torch.cuda.synchronize()
         self._g_graphs[phase] = g

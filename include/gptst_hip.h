@@ -26,14 +26,14 @@ extern "C" {
 #pragma GCC visibility push(default)
 #endif
 
-#define GPTST_ABI_VERSION 11  /* 11 (r05): + gptst_cap_cross_route_lin_bwd, gptst_comm_available, gptst_handoff_reset, gptst_set_handoff_guard (gptst_clip_adam: stats_out[5] = expiries on record); 9, 10 (r04, late): + gptst_hypertem_bwd_pair, gptst_cap_rec_cross_route_bwd, gptst_mask_*_u24, gptst_pool_jobs_gram_rows, gptst_handoff_timeouts; gptst_fusion_gate_fwd/bwd */
+#define GPTST_ABI_VERSION 11  /* 11 (r05): + gptst_cap_cross_route_lin_bwd, gptst_comm_available, gptst_handoff_reset, gptst_set_handoff_guard (gptst_clip_adam: stats_out[5] = expiries on record); - gptst_cap_rec_cross_route_bwd (three-role form, measured slower); 9, 10 (r04, late): + gptst_hypertem_bwd_pair, gptst_cap_rec_cross_route_bwd, gptst_mask_*_u24, gptst_pool_jobs_gram_rows, gptst_handoff_timeouts; gptst_fusion_gate_fwd/bwd */
 int gptst_abi_version(void);
 /* 1: bit-reproducible steps — the two reductions that end in float atomics by default (embedding gradients of gptst_pool_jobs kind 2,
  * weight gradients of gptst_timefeat_jobs) run as single-owner kernels with a fixed summation order (slower).  Everything else is
  * order-fixed by construction.  Thread-local. */
 int gptst_set_deterministic(int on);
 /* Number of bounded in-launch hand-off waits that expired since the library was loaded (the roles of gptst_cap_cross_route_bwd /
- * gptst_cap_rec_cross_route_bwd, the lower weight-gradient role of gptst_hypertem_bwd_pair: a consumer workgroup waits at most 2 s of wall clock
+ * gptst_cap_cross_route_lin_bwd, the lower weight-gradient role of gptst_hypertem_bwd_pair: a consumer workgroup waits at most 2 s of wall clock
  * for its producer and poisons its output with NaN on expiry).  0 in a healthy run; lets a NaN loss be told from numerical trouble.  Synchronises. */
 int gptst_handoff_timeouts(int* out);
 /* r05: while an expiry is on record gptst_clip_adam SKIPS its update (weights and moments untouched; the count goes out in stats_out[5]) — the
@@ -143,14 +143,12 @@ int gptst_hypertem_fwd(const float* X, const float* G, const float* Wbt, const f
                        int N, int C, void* stream);
 /* hyperTem forward CHAIN (r04): nstage (1..3) consecutive hyperTem layers in ONE launch on the (sample, 16-node) slab — every one of them is
  * node-local, so a layer's output goes from the accumulators back into the LDS slab (and to HBM once, for the backward) and the next layer
- * starts from it: no load phase, no launch boundary in between.  Optionally preceded by the node-conditioned layer that ends a cap,
- * out0 = LReLU(rec W_n + b_n + xres) (GPTST.py:137-141), computed per (sample, node) with the 12 time steps as MFMA rows: rec, Wn (N,C,C),
- * bn (N,C), xres, out0 all given, or rec == NULL and X = the first layer's input.  Gs, Wbts, bbts, Rs, outs: HOST arrays of nstage device
- * pointers (G (N,T,T), W_bt (B*T,C,C), b_bt (B*T,C), R_out or NULL, out), read at call time.  Same results as the per-layer calls up to the
- * summation order of the node layer.  C = 64 (GPTST_ESHAPE otherwise).  Replaces GPTST.py:139-141 + 2 x (:157-163) per launch. */
-int gptst_hypertem_chain_fwd(const float* X, const float* rec, const float* Wn, const float* bn, const float* xres, float* out0, int nstage,
-                             const void* Gs, const void* Wbts, const void* bbts, const void* Rs, const void* outs, int B, int T, int N, int C,
-                             void* stream);
+ * starts from it: no load phase, no launch boundary in between.  X: the first layer's input.  Gs, Wbts, bbts, Rs, outs: HOST arrays of nstage
+ * device pointers (G (N,T,T), W_bt (B*T,C,C), b_bt (B*T,C), R_out or NULL, out), read at call time.  Bit-identical to the per-layer calls.
+ * C = 64 (GPTST_ESHAPE otherwise).  Replaces nstage x (GPTST.py:157-163) per launch.  (r05: the optional node-conditioned first stage of r04 —
+ * measured slower than gptst_apply — left the signature.) */
+int gptst_hypertem_chain_fwd(const float* X, int nstage, const void* Gs, const void* Wbts, const void* bbts, const void* Rs, const void* outs,
+                             int B, int T, int N, int C, void* stream);
 
 /* Encoder input projection + the encoder's first hyperTem layer on the low-rank structure of the input (encin.hip, r04).  For base = 1 the
  * first activation is x0 = m w + bi (m = mask ? flow : fill, a scalar per row), so hyperTem1 needs neither x0 nor a GEMM:
@@ -253,14 +251,6 @@ int gptst_cap_cross_route_lin_bwd(const float* X, const float* Wp, const float* 
                                   const float* s, const float* Rt, const float* Ht, const float* dyn, const float* tmpl,
                                   const float* dPre, const float* out, int premul, float* dX, float* dWp, float* dbp, float* dlogit,
                                   float* ddyn, float* dS_ws, void* flags, int B, int T, int N, int C, int HS, int HT, void* stream);
-/* gptst_cap_rec_bwd + gptst_cap_cross_route_bwd in ONE launch of three roles (r04): block order [rec backward (b,t)] [cross-time (sample, part)]
- * [routing (b,t)], every wait points to a lower block index.  drec (B*T, N, C) gradient of the scatter output, v (B*T, HS, C) -> dY, dlogit, ddyn.
- * Workspaces: dc1_ws (B*T, HS, N), dv_ws (B*T, HS, C), dS_ws (B*T, HS, C), flags (5 B + B*T 32-bit words, ZERO on entry).  GPTST_ESHAPE where
- * the role form does not serve (C != 64, T != 12, LDS): use the two calls. */
-int gptst_cap_rec_cross_route_bwd(const float* drec, const float* v, const float* X, const float* Wp, const float* bp, const float* c,
-                                  const float* s, const float* Rt, const float* Ht, const float* dyn, const float* tmpl, float* dY,
-                                  float* dlogit, float* ddyn, float* dc1_ws, float* dv_ws, float* dS_ws, void* flags, int B, int T,
-                                  int N, int C, int HS, int HT, void* stream);
 
 /* ---- cap for node counts whose (b,t) capsule matrix does not fit LDS (cap_big.hip; BASELINE config 5: N = 4096, C = 128) ----
  * gptst_cap_fits_lds() == 0 -> the host composes the same algebra from these streaming kernels (ops.py: cap_route_fwd/bwd, cap_rec_*):

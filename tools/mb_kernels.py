@@ -61,8 +61,6 @@ CASES = {
     "cap_rec_bwd": lambda: ops.cap_rec_bwd(dO2, c, v),
     "cap_cross_bwd": lambda: ops.cap_cross_bwd(dv, s, Rt, Ht, dyn, tmpl, B, T, HS, HT),
     "cap_route_bwd": lambda: ops.cap_route_bwd(X, Wp, bp, c, dc1, dS),
-    "chain_node_ht_ht": lambda: ops.hypertem_chain_fwd(None, [(G, Wbt, bbt), (G, Wbt, bbt)], node=(rec, Wn, bn, X)),
-    "chain_node_ht": lambda: ops.hypertem_chain_fwd(None, [(G, Wbt, bbt)], node=(rec, Wn, bn, X)),
     "chain_ht_ht": lambda: ops.hypertem_chain_fwd(X, [(G, Wbt, bbt), (G, Wbt, bbt)]),
     "chain_ht": lambda: ops.hypertem_chain_fwd(X, [(G, Wbt, bbt)]),
     "copy_A": lambda: X2.clone(),
@@ -101,7 +99,7 @@ if flt == "capgen":           # cap_route_fwd: third generation (default), its <
         _C.lib().call("gptst_tune", 22, lag)
         print("cap_route_fwd fwd4 lag %2d %7.2f us" % (lag, bench(CASES["cap_route_fwd"])))
     _C.lib().call("gptst_tune", 22, 0)
-    for nm, kv in (("fwd4", ()), ("fwd3", ((21, 1),)), ("fwd3 occ6", ((21, 2),)), ("fwd2", ((20, 1),))):
+    for nm, kv in (("fwd4", ()), ("fwd2", ((20, 1),))):
         for k, v in kv:
             _C.lib().call("gptst_tune", k, v)
         print("cap_route_fwd %-10s %7.2f us" % (nm, bench(CASES["cap_route_fwd"])))

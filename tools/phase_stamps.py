@@ -56,8 +56,6 @@ CASES = {
     "cap_route_lin_bwd_roles": ("capmfma", lambda: ops.cap_cross_route_lin_bwd(X, Wp, bp, c, dc1, dv, s, Rt, Ht, dyn, tmpl, dO, None, True, B, T, HS, HT, flags=torch.zeros(4 * B, device=dev)),
                       ["(cross-time role: whole launch) / routing role: -", "stage Wp (+ X tile requested)", "Y = X Wp^T + bp tiles -> LDS", "zero c / dc, stage c, dc1, wait for dS",
                        "node tiles: U, dlogit, dP, squash backward (dY stays in LDS)", "barrier, Wp -> LDS, barrier", "dX tiles = dY Wp + residual branch, rows out", "dWp / dbp partial of the (b,t)"]),
-    "cap_route_bwd_roles3": ("capmfma", lambda: ops.cap_rec_cross_route_bwd(dO, v, X, Wp, bp, c, s, Rt, Ht, dyn, tmpl, B, T, HS, HT, torch.zeros(5 * B + B * T, device=dev)),
-                      ["(rec-backward role: whole launch; stamped workgroups are of that role)"]),
     "cap_route_bwd": ("capmfma", lambda: ops.cap_cross_route_bwd(X, Wp, bp, c, dc1, dv, s, Rt, Ht, dyn, tmpl, B, T, HS, HT),
                       ["cross-time backward prologue (replicated per (b,t))", "stage Wp (+ X tile requested)", "Y = X Wp^T + bp tiles -> LDS", "zero c / dc, stage c, dc1",
                        "node tiles: U, dlogit, dP, squash backward, dY rows out"]),
@@ -76,7 +74,7 @@ e1.record(); torch.cuda.synchronize()
 ph = (ctypes.c_longlong * (8 * 32))()
 wg = (ctypes.c_longlong * (2048 * 2))()
 assert getattr(dll, "gptst_stamps_" + unit)(ph, wg) == 0
-nwg = BT + (4 * B if name.endswith('roles') else 0) + (BT + 4 * B if name.endswith('roles3') else 0)
+nwg = BT + (4 * B if name.endswith('roles') else 0)
 if name == "ht_bwd_pair":
     nwg = 352 + 2 * BT
 ph = np.array(ph).reshape(8, 32); wg = np.array(wg).reshape(2048, 2)[:nwg]
