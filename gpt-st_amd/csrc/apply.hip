@@ -673,8 +673,8 @@ __global__ __launch_bounds__(64 * AP128_NW, 4) void apply128_kernel(const float*
         for (int r = 0; r < 4; ++r) {
             const int m = min(t * 16 + kk * 4 + r, rm.M - 1);
             orow[r] = ((size_t)g * rm.rs_g + (size_t)m * rm.rs_m) * C + 4 * j;
-            if (EPI == EPI_RES_LRELU || EPI == EPI_ADD_DPRE) { rv[r][0] = ld4(resid + orow[r]); rv[r][1] = ld4(resid + orow[r] + 64); }
-            if (EPI == EPI_ADD_DPRE) { rv2[r][0] = ld4(resid2 + orow[r]); rv2[r][1] = ld4(resid2 + orow[r] + 64); }
+            if (EPI == EPI_RES_LRELU || EPI == EPI_ADD_DPRE || EPI == EPI_ADD_PREMUL) { rv[r][0] = ld4(resid + orow[r]); rv[r][1] = ld4(resid + orow[r] + 64); }
+            if (EPI == EPI_ADD_DPRE || EPI == EPI_ADD_PREMUL || EPI == EPI_PREMUL) { rv2[r][0] = ld4(resid2 + orow[r]); rv2[r][1] = ld4(resid2 + orow[r] + 64); }
         }
         constexpr bool EARLY = (EPI == EPI_PLAIN || EPI == EPI_LRELU) && PRO == PRO_NONE;   // no residual / dPre operands: room for the next tile's fragments now
         if (EARLY && t + 1 < t1) fetch(t + 1);
@@ -694,6 +694,15 @@ __global__ __launch_bounds__(64 * AP128_NW, 4) void apply128_kernel(const float*
                         const float4 d = rv[r][hf], o = rv2[r][hf];
                         y.x = fmaf(d.x, lrelu_grad_from_out(o.x), y.x); y.y = fmaf(d.y, lrelu_grad_from_out(o.y), y.y);
                         y.z = fmaf(d.z, lrelu_grad_from_out(o.z), y.z); y.w = fmaf(d.w, lrelu_grad_from_out(o.w), y.w);
+                    }
+                    if (EPI == EPI_ADD_PREMUL) {                     // dPre chain: (dY Wp + dPre) * lrelu'(X)
+                        const float4 d = rv[r][hf], o = rv2[r][hf];
+                        y.x = (y.x + d.x) * lrelu_grad_from_out(o.x); y.y = (y.y + d.y) * lrelu_grad_from_out(o.y);
+                        y.z = (y.z + d.z) * lrelu_grad_from_out(o.z); y.w = (y.w + d.w) * lrelu_grad_from_out(o.w);
+                    }
+                    if (EPI == EPI_PREMUL) {                         // dPre chain, no residual branch: (dPre W^T) * lrelu'(X)
+                        const float4 o = rv2[r][hf];
+                        y.x *= lrelu_grad_from_out(o.x); y.y *= lrelu_grad_from_out(o.y); y.z *= lrelu_grad_from_out(o.z); y.w *= lrelu_grad_from_out(o.w);
                     }
                     st4(out + orow[r] + 64 * hf, y);
                 }
@@ -751,6 +760,8 @@ static int launch_apply128(const float* A, const float* A2, const float* W, long
     else if (pro == PRO_DPRE && epi == EPI_PLAIN) AP128(PRO_DPRE, EPI_PLAIN, false);
     else if (pro == PRO_NONE && epi == EPI_ADD_DPRE) AP128(PRO_NONE, EPI_ADD_DPRE, false);
     else if (pro == PRO_NONE && epi == EPI_LRELU) AP128(PRO_NONE, EPI_LRELU, false);
+    else if (pro == PRO_NONE && epi == EPI_ADD_PREMUL) AP128(PRO_NONE, EPI_ADD_PREMUL, false);
+    else if (pro == PRO_NONE && epi == EPI_PREMUL) AP128(PRO_NONE, EPI_PREMUL, false);
     else return GPTST_EARG;
 #undef AP128
     GPTST_CHECK_LAUNCH();
@@ -879,7 +890,9 @@ extern "C" int gptst_apply(const float* A, const float* A2, const float* W, int 
     if (!A || !W || !out || BT <= 0 || N <= 0) return GPTST_EARG;
     if (pro == PRO_DPRE && !A2) return GPTST_EARG;
     if (epi == EPI_RES_LRELU && !resid) return GPTST_EARG;
-    if (epi == EPI_ADD_DPRE && (!resid || !resid2)) return GPTST_EARG;
+    if ((epi == EPI_ADD_DPRE || epi == EPI_ADD_PREMUL) && (!resid || !resid2)) return GPTST_EARG;
+    if (epi == EPI_PREMUL && !resid2) return GPTST_EARG;
+    if ((epi == EPI_ADD_PREMUL || epi == EPI_PREMUL) && (C != 128 || g_apply128_v1)) return GPTST_ESHAPE;      // (C = 64 has the fused gptst_linear_bwd for this)
     if (!g_smem_attr_done) { raise_smem_limits<64>(); raise_smem_limits<128>(); g_smem_attr_done = 1; }
     RowMap rm = make_rowmap(mode, BT, N);
     const long gs = w_per_group ? (long)C * C : 0;

@@ -143,7 +143,9 @@ __global__ __launch_bounds__(256) void tmix_dgraph_kernel(const float* __restric
 //   dG  D[i=t][j=u] = sum_c dR[t,c] X[u,c]:  lane (i,kk) holds row t=i (u=i), channels 16q+4kk..+3 of dR and of X.
 // dR and X change layout through a wave-private LDS tile: HBM traffic dR + X + dOut + Y + dX instead of 2 dR + X + dOut + Y + dX
 // in two launches (N = 4096, C = 128, B = 32: 595 + 482 us -> one launch).
-template <int C>
+// CH (r05, the dPre chain at C = 128): 0 = dOut with the layer's output Y for the sign; 1 = the incoming gradient already is dPre (Y is not read:
+// one activation-sized read less); 2 = as 1, and dX is returned multiplied by lrelu'(X) — X is in registers for the graph gradient anyway.
+template <int C, int CH = 0>
 __global__ __launch_bounds__(256, 2) void tmix_bwd_dgraph_kernel(const float* __restrict__ dR, const float* __restrict__ X,
                                                                  const float* __restrict__ G, const float* __restrict__ dOut,
                                                                  const float* __restrict__ Y, float* __restrict__ dX,
@@ -171,7 +173,8 @@ __global__ __launch_bounds__(256, 2) void tmix_bwd_dgraph_kernel(const float* __
                 drc[s][hf] = f4zero(); xc[s][hf] = f4zero(); doc[s][hf] = f4zero(); yc[s][hf] = f4zero();
                 if (kk < 3) {
                     const size_t o = base + (4 * kk + s) * tstride + 64 * hf + 4 * j;
-                    drc[s][hf] = ld4(dR + o); xc[s][hf] = ld4(X + o); doc[s][hf] = ld4(dOut + o); yc[s][hf] = ld4(Y + o);
+                    drc[s][hf] = ld4(dR + o); xc[s][hf] = ld4(X + o); doc[s][hf] = ld4(dOut + o);
+                    if (CH == 0) yc[s][hf] = ld4(Y + o);
                 }
             }
         SB();
@@ -217,10 +220,20 @@ __global__ __launch_bounds__(256, 2) void tmix_bwd_dgraph_kernel(const float* __
             for (int r = 0; r < 4; ++r)
 #pragma unroll
                 for (int hf = 0; hf < H2; ++hf) {
-                    const float4 d = doc[r][hf], y = yc[r][hf];
-                    st4(dX + base + (4 * kk + r) * tstride + 64 * hf + 4 * j,
-                        make_float4(fmaf(d.x, lrelu_grad_from_out(y.x), acc[4 * hf + 0][r]), fmaf(d.y, lrelu_grad_from_out(y.y), acc[4 * hf + 1][r]),
-                                    fmaf(d.z, lrelu_grad_from_out(y.z), acc[4 * hf + 2][r]), fmaf(d.w, lrelu_grad_from_out(y.w), acc[4 * hf + 3][r])));
+                    const float4 d = doc[r][hf];
+                    float4 o4;
+                    if (CH == 0) {
+                        const float4 y = yc[r][hf];
+                        o4 = make_float4(fmaf(d.x, lrelu_grad_from_out(y.x), acc[4 * hf + 0][r]), fmaf(d.y, lrelu_grad_from_out(y.y), acc[4 * hf + 1][r]),
+                                         fmaf(d.z, lrelu_grad_from_out(y.z), acc[4 * hf + 2][r]), fmaf(d.w, lrelu_grad_from_out(y.w), acc[4 * hf + 3][r]));
+                    } else {
+                        o4 = make_float4(d.x + acc[4 * hf + 0][r], d.y + acc[4 * hf + 1][r], d.z + acc[4 * hf + 2][r], d.w + acc[4 * hf + 3][r]);
+                        if (CH == 2) {
+                            const float4 x = xc[r][hf];
+                            o4.x *= lrelu_grad_from_out(x.x); o4.y *= lrelu_grad_from_out(x.y); o4.z *= lrelu_grad_from_out(x.z); o4.w *= lrelu_grad_from_out(x.w);
+                        }
+                    }
+                    st4(dX + base + (4 * kk + r) * tstride + 64 * hf + 4 * j, o4);
                 }
         }
     }
@@ -247,6 +260,20 @@ extern "C" int gptst_gram_fwd(const float* A, float* G, int N, int Hm, void* str
 extern "C" int gptst_gram_bwd(const float* A, const float* dG, float* dA, int L, int N, int Hm, int nsplit, void* stream) {
     if (!A || !dG || !dA || L <= 0 || N <= 0 || nsplit <= 0 || Hm * TT > 256) return GPTST_EARG;
     hipLaunchKernelGGL(gram_bwd_kernel, dim3(L * N), dim3(256), 0, (hipStream_t)stream, A, dG, dA, N, Hm, nsplit);
+    GPTST_CHECK_LAUNCH();
+    return GPTST_OK;
+}
+
+// the dPre-chain form (r05): dX = (dPre + G (*) dR) [* lrelu'(X) when premul], dG as above; the layer's output is not read
+extern "C" int gptst_tmix_bwd_chain(const float* dR, const float* X, const float* G, const float* dPre, int premul, float* dX, float* dG,
+                                    int B, int T, int N, int C, void* stream) {
+    if (!dR || !X || !G || !dPre || !dX || !dG || T != TT || B < 1 || N < 1) return GPTST_EARG;
+    hipStream_t st = (hipStream_t)stream;
+    if (C == 64 && premul) hipLaunchKernelGGL((tmix_bwd_dgraph_kernel<64, 2>), dim3(N), dim3(256), 0, st, dR, X, G, dPre, nullptr, dX, dG, B, N);
+    else if (C == 64) hipLaunchKernelGGL((tmix_bwd_dgraph_kernel<64, 1>), dim3(N), dim3(256), 0, st, dR, X, G, dPre, nullptr, dX, dG, B, N);
+    else if (C == 128 && premul) hipLaunchKernelGGL((tmix_bwd_dgraph_kernel<128, 2>), dim3(N), dim3(256), 0, st, dR, X, G, dPre, nullptr, dX, dG, B, N);
+    else if (C == 128) hipLaunchKernelGGL((tmix_bwd_dgraph_kernel<128, 1>), dim3(N), dim3(256), 0, st, dR, X, G, dPre, nullptr, dX, dG, B, N);
+    else return GPTST_ESHAPE;
     GPTST_CHECK_LAUNCH();
     return GPTST_OK;
 }

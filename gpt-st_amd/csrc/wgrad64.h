@@ -4,7 +4,7 @@
 #include "common.h"
 
 enum { PRO_NONE = 0, PRO_DPRE = 1 };          // PRO_DPRE: a = A * lrelu'(A2)   (A = dOut, A2 = layer output)
-enum { EPI_PLAIN = 0, EPI_RES_LRELU = 1, EPI_ADD_DPRE = 2, EPI_LRELU = 3 };   // 1: lrelu(acc+bias+resid)  2: acc + resid*lrelu'(resid2)  3: lrelu(acc+bias)
+enum { EPI_PLAIN = 0, EPI_RES_LRELU = 1, EPI_ADD_DPRE = 2, EPI_LRELU = 3, EPI_ADD_PREMUL = 4, EPI_PREMUL = 5 };   // 1: lrelu(acc+bias+resid)  2: acc + resid*lrelu'(resid2)  3: lrelu(acc+bias)  4 / 5 (apply128, r05): (acc + resid)*lrelu'(resid2) / acc*lrelu'(resid2)
 
 struct RowMap {
     int G, M;

@@ -11,7 +11,7 @@ import threading
 import torch
 
 from . import ops
-from .ops import (EPI_ADD_DPRE, EPI_LRELU, EPI_PLAIN, EPI_RES_LRELU, MODE_NODE, MODE_SHARED, MODE_TIME, PRO_DPRE, PRO_NONE)
+from .ops import (EPI_ADD_DPRE, EPI_ADD_PREMUL, EPI_LRELU, EPI_PREMUL, EPI_PLAIN, EPI_RES_LRELU, MODE_NODE, MODE_SHARED, MODE_TIME, PRO_DPRE, PRO_NONE)
 
 TF_NAMES = ("ln_day", "ln_week", "ln1", "ln2", "ln")
 
@@ -180,10 +180,15 @@ def graph_grad_splits(dims):
     return dims[0] if dims[3] == 64 else 1
 
 
+CHAIN128 = os.environ.get("GPTST_CHAIN128", "1") == "1"
+
+
 def chain_ok(dims):
     """The "dPre chain" (include/gptst_hip.h, gptst_hypertem_bwd): every backward kernel of the layer chain hands its input gradient down
-    already multiplied by lrelu'(its input), so that no kernel reads its own output only for the sign.  Needs the fused C = 64 kernels."""
-    return _ht_fused_bwd(dims)
+    already multiplied by lrelu'(its input), so that no kernel reads its own output only for the sign.  C = 64: the fused kernels; C = 128
+    (r05): the unfused passes in their chain forms (apply128 / wgrad128 without the dPre prologue, gptst_tmix_bwd_chain, epilogue 4) — three
+    activation-sized reads less per hyperTem layer, two per cap (BASELINE configs[4])."""
+    return _ht_fused_bwd(dims) or (CHAIN128 and dims[3] == 128)
 
 
 def hypertem_core_bwd(saved, dout, dG_out, dims, chain=False, premul=False):
@@ -192,7 +197,7 @@ def hypertem_core_bwd(saved, dout, dG_out, dims, chain=False, premul=False):
     B, T, N, C = dims
     x, R, out, G, Wbt = saved
     BT = B * T
-    assert not chain or _ht_fused_bwd(dims)
+    assert not chain or chain_ok(dims)
     if _ht_fused_bwd(dims):
         # data / graph gradients and the weight + bias gradient side by side in one launch: rows [dW_bt | db_bt]
         dx, dWb, ns, _ = ops.hypertem_bwd_wgrad(dout.view(B, T, N, C), None if chain else out.view(B, T, N, C), x.view(B, T, N, C), G, Wbt,
@@ -204,6 +209,12 @@ def hypertem_core_bwd(saved, dout, dG_out, dims, chain=False, premul=False):
         dWb, ns = ops.wgrad(R, dout, MODE_TIME, BT, N, D2=out, pro=PRO_DPRE, colsum_d=True)
         dWbt, dbias, nsb = dWb[:, :C * C], dWb[:, C * C:], ns
         dx, _, _ = ops.hypertem_bwd(dout.view(B, T, N, C), out.view(B, T, N, C), x.view(B, T, N, C), G, Wbt, dG=dG_out, want_dbias=False)
+        dx = dx.view(-1, C)
+    elif chain:                                       # C = 128, dPre chain: no pass reads the layer's output
+        dWb, ns = ops.wgrad(R, dout, MODE_TIME, BT, N, colsum_d=True)
+        dWbt, dbias, nsb = dWb[:, :C * C], dWb[:, C * C:], ns
+        dR = ops.apply(dout, Wbt, MODE_TIME, BT, N, transw=True)
+        dx, _ = ops.tmix_bwd_chain(dR.view(B, T, N, C), x.view(B, T, N, C), G, dout.view(B, T, N, C), premul=premul, dG=dG_out[0])
         dx = dx.view(-1, C)
     else:
         dWb, ns = ops.wgrad(R, dout, MODE_TIME, BT, N, D2=out, pro=PRO_DPRE, colsum_d=True)
@@ -332,10 +343,14 @@ def cap_core_bwd(p, g, pfx, saved, dout, dims, HS, HT, red, chain=False):
     B, T, N, C = dims
     x, out, rec, c, s, v, Ht, Rt, dyn, Wn, Y = saved
     BT, dev = B * T, x.device
-    assert not chain or C == 64
+    assert not chain or chain_ok(dims)
     if C == 64:     # data gradient, weight gradient and bias gradient of the node-conditioned layer in one pass
         drec, dWn, dbn, ns = ops.apply_wgrad(dout, None if chain else out, rec, Wn, MODE_NODE, BT, N)
         nsb = ns
+    elif chain:     # C = 128, dPre chain: neither pass reads the layer's output
+        drec = ops.apply(dout, Wn, MODE_NODE, BT, N, transw=True)
+        dWb, ns = ops.wgrad(rec, dout, MODE_NODE, BT, N, colsum_d=True)                                          # rows [dWn | dbn] per split
+        dWn, dbn, nsb = dWb[:, :C * C], dWb[:, C * C:], ns
     else:
         drec = ops.apply(dout, Wn, MODE_NODE, BT, N, A2=out, transw=True, pro=PRO_DPRE)
         dWb, ns = ops.wgrad(rec, dout, MODE_NODE, BT, N, D2=out, pro=PRO_DPRE, colsum_d=True)                    # rows [dWn | dbn] per split
@@ -367,7 +382,10 @@ def cap_core_bwd(p, g, pfx, saved, dout, dims, HS, HT, red, chain=False):
         red.jobs.bwd_pool(_ones(dev, ns2), dWp, gw.view(1, C * C))
         red.jobs.bwd_pool(_ones(dev, ns2), dbp, gb.view(1, C))
     else:
-        dx = ops.apply(dY, p[pfx + "ln_p.weight"], MODE_SHARED, BT, N, resid=dout, resid2=out, epi=EPI_ADD_DPRE)
+        if chain:   # (dY Wp + dPre) * lrelu'(x): the sign comes from the layer's INPUT, which the weight gradient below reads anyway
+            dx = ops.apply(dY, p[pfx + "ln_p.weight"], MODE_SHARED, BT, N, resid=dout, resid2=x, epi=EPI_ADD_PREMUL)
+        else:
+            dx = ops.apply(dY, p[pfx + "ln_p.weight"], MODE_SHARED, BT, N, resid=dout, resid2=out, epi=EPI_ADD_DPRE)
         dWp, ns2 = ops.wgrad(dY, x, MODE_SHARED, BT, N, colsum_a=True)                     # rows [dWp | colsum dY]
         red.jobs.bwd_pool(_ones(dev, ns2), dWp[:, :C * C], gw.view(1, C * C))
         red.jobs.bwd_pool(_ones(dev, ns2), dWp[:, C * C:], gb.view(1, C))
@@ -396,10 +414,15 @@ def condlin_bwd(saved, dout, emb, wpool, bpool, g_wpool, g_bpool, d_emb, mode, d
     B, T, N, C = dims
     x, out, Wg = saved
     R, K = emb.shape
-    assert not chain or C == 64
+    assert not chain or chain_ok(dims)
     if C == 64:
         dx, dW, db, ns = ops.apply_wgrad(dout, None if chain else out, x, Wg, mode, B * T, N, premul=chain and premul)
         nsb = ns
+    elif chain:     # C = 128, dPre chain
+        dx = (ops.apply(dout, Wg, mode, B * T, N, transw=True, resid2=x, epi=EPI_PREMUL) if premul
+              else ops.apply(dout, Wg, mode, B * T, N, transw=True))
+        dWb, ns = ops.wgrad(x, dout, mode, B * T, N, colsum_d=True)
+        dW, db, nsb = dWb[:, :C * C], dWb[:, C * C:], ns
     else:
         dx = ops.apply(dout, Wg, mode, B * T, N, A2=out, transw=True, pro=PRO_DPRE)
         dWb, ns = ops.wgrad(x, dout, mode, B * T, N, D2=out, pro=PRO_DPRE, colsum_d=True)
@@ -561,7 +584,11 @@ def sthcn_bwd(p, g, pfx, tidx, sv, dout, dims, red, chain=False, premul_in=False
         assert chain
         e = sv["h1"]
         w, bi = p["encoder.dim_in_flow.weight"], p["encoder.dim_in_flow.bias"]
-        dWb, _, dinp = ops.encin_ht1_bwd(dd.view(B, T, N, C), e.source, e.mask, e.fill, w, bi, e.Wbt, e.ab, e.wv, dG=dG_all[0])
+        if nsG == B:
+            dWb, _, dinp = ops.encin_ht1_bwd(dd.view(B, T, N, C), e.source, e.mask, e.fill, w, bi, e.Wbt, e.ab, e.wv, dG=dG_all[0])
+        else:       # (C = 128: the other layers write ONE graph-gradient partial; this kernel writes one per sample)
+            dWb, dGb, dinp = ops.encin_ht1_bwd(dd.view(B, T, N, C), e.source, e.mask, e.fill, w, bi, e.Wbt, e.ab, e.wv)
+            torch.sum(dGb, 0, out=dG_all[0][0])
         hp1 = (dWb[:, :C * C], 1, (dWb[:, C * C:], 1))
         wb = _wb_view(g["encoder.dim_in_flow.weight"], g["encoder.dim_in_flow.bias"])
         if wb is not None:

@@ -9,7 +9,7 @@ from . import _C
 
 MODE_TIME, MODE_NODE, MODE_SHARED = 0, 1, 2
 PRO_NONE, PRO_DPRE = 0, 1
-EPI_PLAIN, EPI_RES_LRELU, EPI_ADD_DPRE, EPI_LRELU = 0, 1, 2, 3
+EPI_PLAIN, EPI_RES_LRELU, EPI_ADD_DPRE, EPI_LRELU, EPI_ADD_PREMUL, EPI_PREMUL = 0, 1, 2, 3, 4, 5
 
 _p = _C.ptr
 
@@ -430,6 +430,17 @@ def tmix_bwd(dR, X, G, dOut, Y, dG=None):
     if dG is None:
         dG = torch.empty(N, T, T, device=X.device, dtype=torch.float32)
     _call("gptst_tmix_bwd", _p(dR), _p(X), _p(G), _p(dOut), _p(Y), _p(dX), _p(dG), B, T, N, C, nbytes=_nb(dR, X, dOut, Y, dX))
+    return dX, dG
+
+
+def tmix_bwd_chain(dR, X, G, dPre, premul=False, dG=None):
+    """dPre-chain form of tmix_bwd: -> (dX = (dPre + G (*) dR) [* lrelu'(X)], dG); the layer's output is not read."""
+    _chk(dR, X, G, dPre, dG)
+    B, T, N, C = X.shape
+    dX = torch.empty_like(X)
+    if dG is None:
+        dG = torch.empty(N, T, T, device=X.device, dtype=torch.float32)
+    _call("gptst_tmix_bwd_chain", _p(dR), _p(X), _p(G), _p(dPre), int(bool(premul)), _p(dX), _p(dG), B, T, N, C, nbytes=_nb(dR, X, dPre, dX))
     return dX, dG
 
 

@@ -83,7 +83,9 @@ int gptst_pool_jobs_gram_rows(int K, int cols);
  * out[g,m,:] = epi( pro(A)[g,m,:] @ W[g] (+bias[g]) (+resid) ).   mode: 0 TIME (g=(b,t), rows n), 1 NODE (g=n, rows
  * (b,t)), 2 SHARED (one weight).  w_per_group: W is (G,C,C) else (C,C).  transw: W[g] stored [out][in].
  * pro: 0 none, 1 A*lrelu'(A2) (A=dOut, A2=layer output).  epi: 0 plain, 1 lrelu(acc+bias+resid),
- * 2 acc + resid*lrelu'(resid2) (adds the residual branch of a layer's backward), 3 lrelu(acc+bias).
+ * 2 acc + resid*lrelu'(resid2) (adds the residual branch of a layer's backward), 3 lrelu(acc+bias),
+ * 4 (C = 128, r05) (acc + resid)*lrelu'(resid2): the dPre-chain form of 2 (resid already is dPre, resid2 = the layer's INPUT);  5 (C = 128)
+ * acc*lrelu'(resid2): the same without a residual branch.
  * colsum (optional): row-split PARTIALS of the bias gradient, colsum[s][g][:] = sum over the rows m of split s of pro(A)[g,m,:],
  *   s < gptst_apply_nsplit(mode, BT, N, C); plain stores in a fixed order (no atomics): the consumer sums the splits.
  * Replaces einsum('btni,btio->btno') / einsum('btni,nio->btno') + bias + residual + LeakyReLU
@@ -135,6 +137,10 @@ int gptst_tmix_dgraph(const float* dR, const float* X, float* dG, int B, int T, 
 /* both of the above in one pass over dR (the unfused hyperTem backward, C = 128): dX = dOut*lrelu'(Y) + G (*) dR, dG = sum_b dR X^T */
 int gptst_tmix_bwd(const float* dR, const float* X, const float* G, const float* dOut, const float* Y, float* dX, float* dG, int B, int T,
                    int N, int C, void* stream);
+/* r05, the dPre-chain form of gptst_tmix_bwd (C = 128 path): dPre is the layer's pre-activation gradient (its output is not read);
+ * dX = (dPre + G (*) dR), times lrelu'(X) when premul;  dG as above. */
+int gptst_tmix_bwd_chain(const float* dR, const float* X, const float* G, const float* dPre, int premul, float* dX, float* dG, int B, int T,
+                         int N, int C, void* stream);
 
 /* fused hyperTem forward (hypertem.hip): R = G (*) X, out = LReLU(R W_bt + b_bt + X); one workgroup per (sample, 16 nodes), MFMA 16x16x4
  * with W_bt read from L2.  R_out: R kept for the weight gradient, or NULL (the backward then rebuilds it from X).  C = 64.
