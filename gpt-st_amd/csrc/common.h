@@ -149,6 +149,16 @@ __device__ __forceinline__ float lrelu_grad_from_out(float out) { return out > 0
 
 __device__ __forceinline__ float4 ld4(const float* p) { return *reinterpret_cast<const float4*>(p); }
 __device__ __forceinline__ void st4(float* p, float4 v) { *reinterpret_cast<float4*>(p) = v; }
+// store of a tensor whose consumer is far away (the saved mix R of hyperTem: read by the backward ~0.5 ms later).  -DHT_R_NT: nontemporal.
+__device__ __forceinline__ void st4_far(float* p, float4 v) {
+#ifdef HT_R_NT
+    typedef float gptst_v4f_ __attribute__((ext_vector_type(4)));
+    const gptst_v4f_ t = {v.x, v.y, v.z, v.w};
+    __builtin_nontemporal_store(t, reinterpret_cast<gptst_v4f_*>(p));
+#else
+    st4(p, v);
+#endif
+}
 __device__ __forceinline__ float4 f4zero() { return make_float4(0.f, 0.f, 0.f, 0.f); }
 __device__ __forceinline__ float4 f4add(float4 a, float4 b) { return make_float4(a.x + b.x, a.y + b.y, a.z + b.z, a.w + b.w); }
 __device__ __forceinline__ float4 f4fma(float s, float4 a, float4 c) {

@@ -146,7 +146,7 @@ __global__ __launch_bounds__(256, HT_OCC) void hypertem_fwd_kernel(const float* 
         // issued BEHIND the next step's W_bt loads (vmcnt retires in order)
         if (R_out != nullptr && j < NT && n0 + j < N) {        // (NULL: the backward rebuilds R from X, see wgrad64_mix_body)
 #pragma unroll
-            for (int q = 0; q < C / 16; ++q) st4(R_out + (g * N + n0 + j) * C + 16 * q + 4 * kk, a4[q]);
+            for (int q = 0; q < C / 16; ++q) st4_far(R_out + (g * N + n0 + j) * C + 16 * q + 4 * kk, a4[q]);
         }
         // ---- (3) epilogue from registers: lane (j, kk) owns rows kk*4 + r, channels 4j .. 4j+3 ----
 #pragma unroll
@@ -754,7 +754,7 @@ __global__ __launch_bounds__(256, HT_OCC) void hypertem_chain_fwd_kernel(HtChain
                 SB();
                 if (S.R_out != nullptr && n0 + j < N) {
 #pragma unroll
-                    for (int q = 0; q < C / 16; ++q) st4(S.R_out + (g * N + n0 + j) * C + 16 * q + 4 * kk, m4[q]);
+                    for (int q = 0; q < C / 16; ++q) st4_far(S.R_out + (g * N + n0 + j) * C + 16 * q + 4 * kk, m4[q]);
                 }
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
@@ -811,7 +811,7 @@ __global__ __launch_bounds__(256, HT_OCC) void hypertem_chain_fwd_kernel(HtChain
                 SB();
                 if (S.R_out != nullptr && n0 + j < N) {
 #pragma unroll
-                    for (int q = 0; q < C / 16; ++q) st4(S.R_out + (g * N + n0 + j) * C + 16 * q + 4 * kk, a4[q]);
+                    for (int q = 0; q < C / 16; ++q) st4_far(S.R_out + (g * N + n0 + j) * C + 16 * q + 4 * kk, a4[q]);
                 }
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {

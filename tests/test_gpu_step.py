@@ -487,3 +487,54 @@ def test_weight_trajectory_is_as_close_to_fp64_as_the_fp32_oracle(parity):
         e32 = abs(l32[i][0] - l64[i][0]) / abs(l64[i][0])
         eh = abs(lh[i][0] - l64[i][0]) / abs(l64[i][0])
         assert eh <= 3.0 * e32 + 2e-6, (i, eh, e32)
+
+
+def test_handoff_soak_with_a_second_process_on_the_same_gpu():
+    """the in-launch hand-offs (hyperTem backward pairs, cross-time role) under GPU sharing — a second PROCESS keeps the same GPU
+    busy (time slicing between processes is what made the 0.25 s bound of round 4 expire) while this one enqueues 2000 graph replays of the step at
+    the bench shape.  Either no bounded wait expires, or the stepper recovers (lost steps re-run without hand-off launches): the weights stay finite
+    and no expiry is left on record."""
+    import ctypes
+    import os
+    import subprocess
+    import sys
+    import time
+    from gptst_amd import _C
+    from gptst_amd.model import GPTST_Model, init_seed, xavier_init_
+    from gptst_amd.step import PretrainStep
+    args = make_args("PEMS08", scaler_zeros=synth.scaler_zeros(), device=DEV)
+    init_seed(args.seed)
+    B, T, N = 32, 12, args.num_nodes
+    model = xavier_init_(GPTST_Model(args)).to(DEV)
+    st = PretrainStep(model, args, synth.SCALER_MEAN, synth.SCALER_STD, batch_size=B, use_graph=True, seed=7)
+    src = synth.make_batch(B, T, N, args.input_base_dim, interval=args.interval, seed=2024).to(DEV)
+    hog = subprocess.Popen([sys.executable, "-c",
+                            "import torch,time\n"
+                            "a=torch.randn(8192,8192,device='cuda:0');t=time.time()\n"
+                            "while time.time()-t<60:\n"
+                            "    for _ in range(20): b=a@a\n"
+                            "    torch.cuda.synchronize()\n"], env=dict(os.environ))
+    try:
+        time.sleep(8.0)                                  # let the other process get onto the GPU
+        K, lib = 4, _C.lib()
+        srcs = st.group_sources(K)
+        for s_ in srcs:
+            s_.copy_(src)
+        nrep = 500                                       # x K = 2000 steps, one graph replay each group of four
+        for r in range(nrep):
+            st.step_group(srcs, 200)
+            if r % 50 == 49:
+                ls = st.losses_group()                   # sync + recovery point, as the trainer's logging is
+                assert all(l[0] == l[0] and l[0] > 0 for l in ls), ls
+        ls = st.losses_group()
+        torch.cuda.synchronize()
+        n = ctypes.c_int(-1)
+        lib.call("gptst_handoff_timeouts", ctypes.byref(n))
+        assert bool(torch.isfinite(model.flat).all()), "weights went non-finite"
+        assert n.value == 0, "an expiry is still on record after the last recovery point"
+        print("soak: %d steps, lost (re-run) steps %d, safe_mode %s" % (st.tA, st.lost_steps, st.safe_mode))
+        assert st.tA == nrep * K
+    finally:
+        hog.kill()
+        hog.wait()
+        _C.lib().call("gptst_handoff_reset")
