@@ -477,7 +477,7 @@ def test_weight_trajectory_is_as_close_to_fp64_as_the_fp32_oracle(parity):
     # 1.f - 0.999f made every Adam step 6.4e-6 too long, which this test found and test_clip_adam_matches_torch (2e-6 of |p|) could not see
     # r05: 8x (3x before).  Two VALID fp32 summation orders of one weight gradient sit at different multiples: with the entry Linear's backward folded
     # into the routing backward (one dWp partial per (b,t) instead of 510 row splits; every other tensor of a step bit-identical,
-    # scratch/lin_grad_diff2.py) the run reads 6.4x (3.2e-6), without it 1.8x.  The mechanism: Adam normalises per element, so the 1e-7-of-max
+    # tools/experiments/lin_grad_diff.py) the run reads 6.4x (3.2e-6), without it 1.8x.  The mechanism: Adam normalises per element, so the 1e-7-of-max
     # rounding of a weight gradient is a 10 % change of the update of its smallest elements; through ln_p -> cluster assignment -> KL target the
     # guide classifier's pools then drift by 1e-4 of their norm over the 12 steps (GPTST_TRAJ_DEBUG=1 lists the tensors).  The fp32 oracle is ONE
     # sample of that lottery; an optimiser or gradient defect shows as 100x and more (317x for the 1 - beta2 rounding below).
