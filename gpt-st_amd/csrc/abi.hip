@@ -9,14 +9,15 @@ thread_local int g_deterministic = 0;
 extern "C" int gptst_set_deterministic(int on) { g_deterministic = on ? 1 : 0; return GPTST_OK; }
 
 // number of bounded in-launch hand-off waits that expired since the library was loaded (cap_route_bwd2_kernel's roles, hypertem_bwd_pair_kernel's
-// lower weight-gradient role): 0 in a healthy run.  An expiry poisons that launch's output with NaN; this tells such a NaN from numerical trouble.
+// lower weight-gradient role, the grid barriers of the cooperative mask launch): 0 in a healthy run.  An expiry poisons that launch's output with NaN; this tells such a NaN from numerical trouble.
 GPTST_INTERNAL int gptst_handoff_lost_capmfma(unsigned* out);
 GPTST_INTERNAL int gptst_handoff_lost_hypertem(unsigned* out);
+GPTST_INTERNAL int gptst_handoff_lost_masksel(unsigned* out);
 extern "C" int gptst_handoff_timeouts(int* out) {
     if (!out) return GPTST_EARG;
-    unsigned a = 0u, b = 0u;
-    if (gptst_handoff_lost_capmfma(&a) || gptst_handoff_lost_hypertem(&b)) return -5;     // (hipMemcpyFromSymbol failed)
-    *out = (int)(a + b);
+    unsigned a = 0u, b = 0u, c = 0u;
+    if (gptst_handoff_lost_capmfma(&a) || gptst_handoff_lost_hypertem(&b) || gptst_handoff_lost_masksel(&c)) return -5;     // (hipMemcpyFromSymbol failed)
+    *out = (int)(a + b + c);
     return GPTST_OK;
 }
 
@@ -24,9 +25,10 @@ extern "C" int gptst_handoff_timeouts(int* out) {
 // skips every update (gptst_clip_adam's guard), so that a poisoned gradient never reaches the weights.
 GPTST_INTERNAL int gptst_handoff_clear_capmfma(unsigned to);
 GPTST_INTERNAL int gptst_handoff_clear_hypertem(unsigned to);
+GPTST_INTERNAL int gptst_handoff_clear_masksel(unsigned to);
 extern "C" int gptst_handoff_reset(void) {
     if (hipDeviceSynchronize() != hipSuccess) return -5;
-    return (gptst_handoff_clear_capmfma(0u) || gptst_handoff_clear_hypertem(0u)) ? -5 : GPTST_OK;
+    return (gptst_handoff_clear_capmfma(0u) || gptst_handoff_clear_hypertem(0u) || gptst_handoff_clear_masksel(0u)) ? -5 : GPTST_OK;
 }
 // (include/gptst_hip_testing.h)
 extern "C" int gptst_handoff_inject(int n) {

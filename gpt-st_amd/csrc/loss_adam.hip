@@ -139,14 +139,15 @@ __global__ __launch_bounds__(256) void gradnorm_kernel(const float* __restrict__
 __global__ __launch_bounds__(256) void adam_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m,
                                                    float* __restrict__ v, long nA, long nB, const float* __restrict__ hyper,
                                                    float* __restrict__ stats, const float* __restrict__ ws, int nws, float* __restrict__ stats_out,
-                                                   const unsigned* __restrict__ lost0, const unsigned* __restrict__ lost1) {
+                                                   const unsigned* __restrict__ lost0, const unsigned* __restrict__ lost1, const unsigned* __restrict__ lost2) {
     __shared__ float red[4];
     __shared__ float redB[4];
     // guard (r05): a bounded in-launch hand-off that expired somewhere in this step poisoned a gradient with NaN (gptst_wait_ge).  The update is
     // then SKIPPED — weights and moments stay as they were — and the count goes out in stats_out[5]; the host re-runs the step on the launches
     // without hand-offs (step.py) instead of losing the run.  The counters stay up (every later step is skipped too) until gptst_handoff_reset().
     // (stats[5]: the count gptst_stats_fold put in front of a gradient all-reduce — the sum over the ranks, so that all of them skip together)
-    const unsigned nlost = (lost0 != nullptr ? *lost0 : 0u) + (lost1 != nullptr ? *lost1 : 0u) + ((lost0 != nullptr && stats[5] > 0.f) ? (unsigned)stats[5] : 0u);
+    const unsigned nlost = (lost0 != nullptr ? *lost0 : 0u) + (lost1 != nullptr ? *lost1 : 0u) + (lost2 != nullptr ? *lost2 : 0u) +
+                           ((lost0 != nullptr && stats[5] > 0.f) ? (unsigned)stats[5] : 0u);
     {   // every workgroup folds the gradient-norm partials (per segment, unscaled) in the same fixed order
         float sA = (int)threadIdx.x < nws ? ws[2 * threadIdx.x] : 0.f, sB = (int)threadIdx.x < nws ? ws[2 * threadIdx.x + 1] : 0.f;
         sA = group_sum<64>(sA); sB = group_sum<64>(sB);
@@ -217,6 +218,7 @@ extern "C" int gptst_clip_adam_ws_floats(void) { return 2 * GN_NB; }
 // separate gptst_stats_fold when nothing (a gradient all-reduce) has to see the folded statistics in between.
 GPTST_INTERNAL const unsigned* gptst_handoff_word_capmfma(void);
 GPTST_INTERNAL const unsigned* gptst_handoff_word_hypertem(void);
+GPTST_INTERNAL const unsigned* gptst_handoff_word_masksel(void);
 static int g_handoff_guard = 1;
 // 1 (default): gptst_clip_adam skips the update while a hand-off expiry is on record (see adam_kernel);  0: the update always runs (a lost
 // hand-off then shows as NaN weights, the pre-r05 behaviour).  Process-wide.
@@ -231,8 +233,9 @@ extern "C" int gptst_clip_adam(float* p, const float* g, float* m, float* v, lon
     hipLaunchKernelGGL(gradnorm_kernel, dim3(nbn), dim3(256), 0, (hipStream_t)stream, g, nA, nB, hyper, stats, ws, sws, sws_rows);
     static const unsigned* w0 = gptst_handoff_word_capmfma();         // (device addresses: looked up once, outside any graph capture — the steppers warm up first)
     static const unsigned* w1 = gptst_handoff_word_hypertem();
+    static const unsigned* w2 = gptst_handoff_word_masksel();
     hipLaunchKernelGGL(adam_kernel, dim3(nb), dim3(256), 0, (hipStream_t)stream, p, g, m, v, nA, nB, hyper, stats, (const float*)ws, nbn, stats_out,
-                       g_handoff_guard ? w0 : nullptr, g_handoff_guard ? w1 : nullptr);
+                       g_handoff_guard ? w0 : nullptr, g_handoff_guard ? w1 : nullptr, g_handoff_guard ? w2 : nullptr);
     GPTST_CHECK_LAUNCH();
     return GPTST_OK;
 }

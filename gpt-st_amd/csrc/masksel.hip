@@ -471,7 +471,14 @@ extern "C" int gptst_mask_ws_bytes(void) { return (int)(sizeof(unsigned) * MS_WS
 
 int g_ms_force_multi = 0;       // tests: 1 = take the multi-launch path for every size
 
+#ifndef MS_COOP_DEFAULT
+#define MS_COOP_DEFAULT 1
+#endif
+extern int g_ms_coop;
+// 0 default; 1: multi-launch path for every size; 2 (u24): the one-workgroup lattice kernel up to 65536 cells; 3 (u24): the multi-launch path where
+// the cooperative launch (r05) would serve, sizes up to 8192 cells still on the one-workgroup kernel
 extern "C" int gptst_mask_force_multi(int on) { g_ms_force_multi = on; return GPTST_OK; }
+extern "C" int gptst_mask_cooperative(int on) { g_ms_coop = on < 0 ? MS_COOP_DEFAULT : (on != 0); return GPTST_OK; }
 
 static int ms_random_impl(const float* noise, int M, int k, float* mask, void* ws, int ws_zeroed, void* stream, int u24) {
     if (!noise || !mask || !ws || M <= 0 || k < 0 || k > M) return GPTST_EARG;
@@ -781,6 +788,196 @@ __global__ __launch_bounds__(MU_T) void mu_mask_kernel(const int* __restrict__ l
     }
 }
 
+// ======================================================================================================================
+// r05: the whole mask generation as ONE COOPERATIVE launch — ceil(M / 1024) <= 64 workgroups of 1024 threads, ONE CELL PER THREAD (its keys live in
+// registers), a grid barrier where the multi-launch path has a kernel boundary.  The six launches of the adaptive phase are ~7.5 us each of launch
+// + two dependent memory round trips on 64 workgroups (45 us per step, three quarters of the chip idle); a barrier of 64 arrivals on one counter is
+// 2-3 us.  Phases: [class histogram] | A digit 1 | A digit 2 | (ties: per-workgroup counts) | mark A, R digit 1 | R digit 2 | (ties) | write.
+// Histograms: per-workgroup in LDS (exact zeros — every ineligible cell — counted with a ballot, not with 1000 same-address atomics), non-empty
+// bins merged into the global histogram with atomics; behind the barrier every workgroup reads the 4096 bins back (agent-scope loads) and finds
+// the threshold bin itself.  Same SET as the multi-launch path and the oracle: ties at rank k go to the lowest cell indices (per-workgroup counts
+// of threshold-equal cells + one more barrier, only when a tie straddles the rank).
+// All workgroups are resident by construction (<= 64 workgroups of 16 waves on 256 CUs); the barrier wait is bounded like every in-launch wait
+// (gptst_wait_ge, 2 s): on expiry the outputs are NaN and the expiry is on record (gptst_handoff_timeouts; the optimiser's guard skips the step).
+// ws words (zeroed): [0, 16384) four histograms (selection s, digit d) | 16384 class counts (256) | 16640 tie counts (2 x 64) | 16768 barrier | 16769 bad
+// ======================================================================================================================
+GPTST_HANDOFF_COUNTER(masksel)
+#define MC_T 1024
+#define MC_MAXWG 64
+struct McShared {
+    unsigned hist[MU_BINS];
+    unsigned wsum[MC_T / 64 + 1];
+    unsigned res[4];
+    int counts[256];
+    unsigned ok, base_rank;
+    MsClass cls;
+};
+
+__device__ __forceinline__ unsigned mc_ld(const unsigned* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+
+// grid barrier number `phase` (1, 2, ..): every thread's global atomics / stores of the phase are out before the workgroup arrives
+__device__ __forceinline__ bool mc_barrier(unsigned* bar, unsigned nwg, unsigned phase, McShared& sh) {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        __hip_atomic_fetch_add(bar, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        sh.ok = gptst_wait_ge(bar, nwg * phase, &g_handoff_lost_masksel) ? 1u : 0u;
+    }
+    __syncthreads();
+    return sh.ok != 0u;
+}
+
+__device__ __forceinline__ unsigned mc_scan(unsigned loc, McShared& sh, unsigned& total) {      // exclusive prefix over the 1024 threads
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    unsigned inc = loc;
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) { const unsigned v = __shfl_up(inc, off, 64); if (lane >= off) inc += v; }
+    __syncthreads();
+    if (lane == 63) sh.wsum[wave] = inc;
+    __syncthreads();
+    unsigned before = inc - loc, tot = 0u;
+#pragma unroll
+    for (int w = 0; w < MC_T / 64; ++w) { const unsigned s_ = sh.wsum[w]; if (w < wave) before += s_; tot += s_; }
+    total = tot;
+    return before;
+}
+
+// merge this workgroup's histogram of `dig` (only keys with match) into gh, zeros through a ballot
+__device__ __forceinline__ void mc_hist(unsigned bin, bool take, unsigned* __restrict__ gh, McShared& sh) {
+    for (int b = threadIdx.x; b < MU_BINS; b += MC_T) sh.hist[b] = 0u;
+    __syncthreads();
+    const bool z = take && bin == 0u;
+    const unsigned long long zb = __ballot(z);
+    if (take && bin != 0u) atomicAdd(&sh.hist[bin], 1u);
+    if ((threadIdx.x & 63) == 0 && zb) atomicAdd(&sh.hist[0], (unsigned)__popcll(zb));
+    __syncthreads();
+    for (int b = threadIdx.x; b < MU_BINS; b += MC_T) { const unsigned v = sh.hist[b]; if (v) atomicAdd(gh + b, v); }
+}
+
+// the bin of the (complete) global histogram gh that holds rank `remaining` from the top -> sh.res = {bin, remaining inside it, its count}
+__device__ __forceinline__ void mc_find(const unsigned* __restrict__ gh, unsigned remaining, McShared& sh) {
+    unsigned h[4], loc = 0u;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) { h[j] = mc_ld(gh + MU_BINS - 1 - (4 * threadIdx.x + j)); loc += h[j]; }
+    unsigned total;
+    const unsigned before = mc_scan(loc, sh, total);
+    if (before < remaining && before + loc >= remaining) {
+        unsigned cum = before;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            if (cum + h[j] >= remaining) { sh.res[0] = MU_BINS - 1 - (4 * threadIdx.x + j); sh.res[1] = remaining - cum; sh.res[2] = h[j]; break; }
+            cum += h[j];
+        }
+    }
+    __syncthreads();
+}
+
+// one selection of rank k over this grid's keys (key of this thread's cell; 0 = ineligible): -> this cell is masked.  `ph`: barrier phases used so far.
+__device__ __forceinline__ bool mc_select(unsigned key, bool valid, int k, unsigned* __restrict__ ws, int s, unsigned nwg, unsigned& ph, McShared& sh, bool& ok) {
+    if (k <= 0) return false;                                        // uniform over the grid
+    unsigned* H0 = ws + (2 * s) * MU_BINS, *H1 = H0 + MU_BINS;
+    unsigned* bar = ws + 16768;
+    mc_hist(key >> 12, valid, H0, sh);
+    ok = mc_barrier(bar, nwg, ++ph, sh) && ok;
+    mc_find(H0, (unsigned)k, sh);
+    const unsigned d1 = sh.res[0], rem = sh.res[1];
+    __syncthreads();
+    mc_hist(key & 0xFFFu, valid && (key >> 12) == d1, H1, sh);
+    ok = mc_barrier(bar, nwg, ++ph, sh) && ok;
+    mc_find(H1, rem, sh);
+    const unsigned thr = (d1 << 12) | sh.res[0], need = sh.res[1], cnt_eq = sh.res[2];
+    __syncthreads();
+    bool m = valid && key > thr;
+    const bool eq = valid && key == thr;
+    if (need == cnt_eq) return m || eq;                              // uniform: no tie straddles the rank
+    // a tie straddles rank k: threshold-equal cells take the `need` slots in CELL-INDEX order = (workgroup, thread) order
+    unsigned total;
+    const unsigned before = mc_scan(eq ? 1u : 0u, sh, total);
+    unsigned* ec = ws + 16640 + 64 * s;
+    if (threadIdx.x == 0) __hip_atomic_store(ec + blockIdx.x, total, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    ok = mc_barrier(bar, nwg, ++ph, sh) && ok;
+    if (threadIdx.x == 0) {
+        unsigned b = 0u;
+        for (unsigned w = 0; w < blockIdx.x; ++w) b += mc_ld(ec + w);
+        sh.base_rank = b;
+    }
+    __syncthreads();
+    if (eq && sh.base_rank + before < need) m = true;
+    __syncthreads();
+    return m;
+}
+
+template <bool ADAPTIVE>
+__global__ __launch_bounds__(MC_T) void mc_mask_kernel(const int* __restrict__ label, const int* __restrict__ list_c, const int* __restrict__ nums,
+                                                       const float* __restrict__ noise_a, const float* __restrict__ noise_r, int ada_all, int M,
+                                                       int HS, int base, int k_const, float* __restrict__ m_ada, float* __restrict__ m_rnd,
+                                                       float* __restrict__ mask, unsigned* __restrict__ ws) {
+    __shared__ McShared sh;
+    const int t = threadIdx.x, i = blockIdx.x * MC_T + t;
+    const bool valid = i < M;
+    const unsigned nwg = gridDim.x;
+    unsigned ph = 0u, bad = 0u;
+    bool ok = true;
+    unsigned* bar = ws + 16768;
+    const int ic = valid ? i : M - 1;
+    const float na = noise_a[ic];
+    const float nr = ADAPTIVE ? noise_r[ic] : 0.f;
+    const int lab = ADAPTIVE ? (label[ic] & 255) : 0;
+    const unsigned ka24 = mu_key(na, bad), kr24 = ADAPTIVE ? mu_key(nr, bad) : 0u;        // (every value is checked, eligible or not)
+    if (bad) atomicOr(ws + 16769, 1u);
+    bool ma = false, mr = false;
+    if constexpr (ADAPTIVE) {
+        // class histogram (GPTST.py:344-345 bincount): LDS per workgroup, one global atomic per class and workgroup
+        for (int h = t; h < 256; h += MC_T) sh.counts[h] = 0;
+        __syncthreads();
+        if (valid) atomicAdd(&sh.counts[lab], 1);
+        __syncthreads();
+        int* gc = reinterpret_cast<int*>(ws + 16384);
+        for (int h = t; h < HS; h += MC_T) if (sh.counts[h]) atomicAdd(gc + h, sh.counts[h]);
+        ok = mc_barrier(bar, nwg, ++ph, sh) && ok;
+        for (int h = t; h < 256; h += MC_T) { sh.counts[h] = h < HS ? (int)mc_ld(ws + 16384 + h) : 0; sh.cls.d[h] = 0; sh.cls.f[h] = 0; }
+        __syncthreads();
+        if (t == 0) {                                                // class roles, GPTST.py:357-384,393 (as ms_classes)
+            const int ada_num = nums[0];
+            int num = 0, c = 0;
+            while (num < ada_num && c < HS) { num += sh.counts[list_c[c]]; ++c; }
+            int dnum = 0;
+            if (ada_all && c >= 2) {
+                for (int k = 0; k < c - 1; ++k) { sh.cls.d[list_c[k]] = 1; dnum += sh.counts[list_c[k]]; }
+                sh.cls.f[list_c[c - 1]] = 1;
+            } else {
+                for (int k = 0; k < c; ++k) sh.cls.f[list_c[k]] = 1;
+            }
+            sh.cls.ka = ada_num - dnum;
+        }
+        __syncthreads();
+        const int ka = sh.cls.ka;
+        const bool da = valid && sh.cls.d[lab] != 0;
+        const unsigned keyA = (valid && sh.cls.f[lab]) ? ka24 : 0u;                        // :390
+        __syncthreads();
+        ma = mc_select(keyA, valid, ka, ws, 0, nwg, ph, sh, ok) || da;                     // :386-397
+        const unsigned keyR = ma ? 0u : kr24;                                              // :401
+        mr = mc_select(keyR, valid, nums[1], ws, 1, nwg, ph, sh, ok);                      // :399-413
+    } else {
+        mr = mc_select(ka24, valid, k_const, ws, 0, nwg, ph, sh, ok);                      // :316-321
+    }
+    // the lattice flag: every workgroup raised it before its first barrier; a launch without any barrier (k = 0 everywhere) reads what is there
+    const bool poison = !ok || mc_ld(ws + 16769) != 0u;
+    const float nan = __int_as_float(0x7fc00000);
+    if (!valid) return;
+    const float va = ma ? 0.f : 1.f, vr = mr ? 0.f : 1.f;
+    if (ADAPTIVE) {
+        if (m_ada) m_ada[i] = poison ? nan : va;
+        if (m_rnd) m_rnd[i] = poison ? nan : vr;
+        const float f = poison ? nan : va * vr;
+        for (int j = 0; j < base; ++j) mask[(size_t)i * base + j] = f;
+    } else {
+        mask[i] = poison ? nan : vr;
+    }
+}
+
+int g_ms_coop = MS_COOP_DEFAULT;              // gptst_mask_cooperative(0): the multi-launch path instead of the cooperative launch (the steppers' fallback after a lost hand-off; A/B; tests)
+
 static int mu_prepare() {
     static int done = 0;
     if (!done) {
@@ -803,6 +1000,13 @@ extern "C" int gptst_mask_random_u24(const float* noise, int M, int k, float* ma
         GPTST_CHECK_LAUNCH();
         return GPTST_OK;
     }
+    if (g_ms_coop && g_ms_force_multi == 0 && ws && M <= MC_T * MC_MAXWG) {          // r05: one cooperative launch, a cell per thread
+        if (!ws_zeroed) hipLaunchKernelGGL(ms_zero_kernel, dim3(24), dim3(256), 0, (hipStream_t)stream, (unsigned*)ws, MS_WS_WORDS);
+        hipLaunchKernelGGL((mc_mask_kernel<false>), dim3((M + MC_T - 1) / MC_T), dim3(MC_T), 0, (hipStream_t)stream, (const int*)nullptr, (const int*)nullptr,
+                           (const int*)nullptr, noise, (const float*)nullptr, 0, M, 0, 1, k, (float*)nullptr, (float*)nullptr, mask, (unsigned*)ws);
+        GPTST_CHECK_LAUNCH();
+        return GPTST_OK;
+    }
     return ms_random_impl(noise, M, k, mask, ws, ws_zeroed, stream, 1);
 }
 
@@ -814,6 +1018,13 @@ extern "C" int gptst_mask_adaptive_u24(const int* label, const int* counts, cons
     if ((M <= MSS_MAXM && g_ms_force_multi != 1) || (g_ms_force_multi == 2 && M <= MU_T * MU_CPT)) {
         hipLaunchKernelGGL((mu_mask_kernel<true>), dim3(1), dim3(MU_T), mu_prepare(), (hipStream_t)stream, label, list_c, nums, noise_a, noise_r, ada_all,
                            M, HS, base, 0, m_ada, m_rnd, mask);
+        GPTST_CHECK_LAUNCH();
+        return GPTST_OK;
+    }
+    if (g_ms_coop && g_ms_force_multi == 0 && ws && M <= MC_T * MC_MAXWG) {          // r05: one cooperative launch (the class histogram is taken inside)
+        if (!ws_zeroed) hipLaunchKernelGGL(ms_zero_kernel, dim3(24), dim3(256), 0, (hipStream_t)stream, (unsigned*)ws, MS_WS_WORDS);
+        hipLaunchKernelGGL((mc_mask_kernel<true>), dim3((M + MC_T - 1) / MC_T), dim3(MC_T), 0, (hipStream_t)stream, label, list_c, nums, noise_a, noise_r,
+                           ada_all, M, HS, base, 0, m_ada, m_rnd, mask, (unsigned*)ws);
         GPTST_CHECK_LAUNCH();
         return GPTST_OK;
     }

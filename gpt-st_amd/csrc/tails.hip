@@ -289,9 +289,10 @@ __global__ __launch_bounds__(256) void tail64_mfma_kernel(TailArgs t) {
 // lost0 / lost1 (may be NULL): the hand-off expiry counters — their sum goes to stats[5], so that a gradient all-reduce carries it to every rank and
 // all of them skip the update together (gptst_clip_adam's guard)
 __global__ __launch_bounds__(256) void stats_fold_kernel(const float* __restrict__ sws, int rows, float* __restrict__ stats,
-                                                         const unsigned* __restrict__ lost0, const unsigned* __restrict__ lost1) {
+                                                         const unsigned* __restrict__ lost0, const unsigned* __restrict__ lost1,
+                                                         const unsigned* __restrict__ lost2) {
     __shared__ float red[3][4];
-    if (threadIdx.x == 255) stats[5] = (float)((lost0 != nullptr ? *lost0 : 0u) + (lost1 != nullptr ? *lost1 : 0u));
+    if (threadIdx.x == 255) stats[5] = (float)((lost0 != nullptr ? *lost0 : 0u) + (lost1 != nullptr ? *lost1 : 0u) + (lost2 != nullptr ? *lost2 : 0u));
     float s[3] = {0.f, 0.f, 0.f};
     for (int r = threadIdx.x; r < rows; r += 256) {
         const float4 v = ld4(sws + 4 * (size_t)r);
@@ -320,12 +321,14 @@ extern "C" int gptst_tail_parts(int rows) { int nb, rpb; tl_geometry(rows, nb, r
 
 GPTST_INTERNAL const unsigned* gptst_handoff_word_capmfma(void);
 GPTST_INTERNAL const unsigned* gptst_handoff_word_hypertem(void);
+GPTST_INTERNAL const unsigned* gptst_handoff_word_masksel(void);
 // sum the per-workgroup loss statistics sws (rows, 4) of the tail kernels into stats[0..2] (+=), in a fixed order; stats[5] <- hand-off expiries on record
 extern "C" int gptst_stats_fold(const float* sws, int rows, float* stats, void* stream) {
     if (!sws || !stats || rows <= 0) return GPTST_EARG;
     static const unsigned* w0 = gptst_handoff_word_capmfma();         // looked up once (the steppers warm up before any capture)
     static const unsigned* w1 = gptst_handoff_word_hypertem();
-    hipLaunchKernelGGL(stats_fold_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, sws, rows, stats, w0, w1);
+    static const unsigned* w2 = gptst_handoff_word_masksel();
+    hipLaunchKernelGGL(stats_fold_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, sws, rows, stats, w0, w1, w2);
     GPTST_CHECK_LAUNCH();
     return GPTST_OK;
 }

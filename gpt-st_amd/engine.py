@@ -232,14 +232,17 @@ PAIR_BWD = os.environ.get("GPTST_PAIR_BWD", "1") == "1"        # two adjacent hy
 @contextlib.contextmanager
 def no_handoffs():
     """Enqueue (or capture) the step without launches in which one workgroup waits for another (the hyperTem backward pairs, the cross-time role
-    of the routing backward): what a stepper falls back to after a bounded wait expired (step.py::_enter_safe_mode)."""
+    of the routing backward, the cooperative mask launch): what a stepper falls back to after a bounded wait expired (step.py::_enter_safe_mode)."""
     global PAIR_BWD, CROSS_ROLE
+    from . import _C
     keep = (PAIR_BWD, CROSS_ROLE)
     PAIR_BWD, CROSS_ROLE = False, 0
+    _C.lib().call("gptst_mask_cooperative", 0)
     try:
         yield
     finally:
         PAIR_BWD, CROSS_ROLE = keep
+        _C.lib().call("gptst_mask_cooperative", -1)
 
 
 def _ht_pair_shape_ok(dims):

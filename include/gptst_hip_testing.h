@@ -17,7 +17,8 @@ extern "C" {
  * cap_route_bwd2_kernel instead of a role.  The Python binding applies GPTST_TUNE="id=value,..." from the environment. */
 int gptst_tune(int id, int value);
 /* mask selection: 1 = the multi-launch radix select for every size (a single-workgroup launch serves M <= 8192 cells otherwise);
- * 2 (gptst_mask_*_u24 only) = the one-workgroup lattice kernel for every size up to 65536 cells.  Process-wide, not thread-local. */
+ * 2 (gptst_mask_*_u24 only) = the one-workgroup lattice kernel for every size up to 65536 cells; either value also keeps the cooperative launch
+ * (gptst_mask_cooperative, gptst_hip.h) out.  Process-wide, not thread-local. */
 int gptst_mask_force_multi(int on);
 /* puts n hand-off expiries on record without poisoning anything (synchronises): what the optimiser's guard and the steppers' recovery see when a
  * bounded in-launch wait ran out (tests/test_gpu_step.py::test_lost_handoff_*). */

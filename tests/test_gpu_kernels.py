@@ -277,25 +277,28 @@ def test_mask_random_bit_exact(M, ratio, seed):
         assert torch.equal(got.cpu().to(torch.int64), ref), multi
     # r04: lattice noise (k * 2^-24, what synth / torch.rand / the step's Philox draw) -> the select on the integers: two digit passes (multi-
     # workgroup form; <= 8192 cells: one launch of one workgroup) and (path 2) the one-workgroup form at every size up to 65536 cells
-    for path in (0, 1, 2):
+    for path in (0, 1, 2, 3):
         with _mask_path(path):
             got = ops.mask_random(noise.to(dev), int(M * ratio), u24=True)
         assert torch.equal(got.cpu().to(torch.int64), ref), ("u24", path)
 
 
 class _mask_path:
-    """force the multi-launch (1) or allow the single-workgroup (0) mask generation path"""
+    """mask generation path: 0 by size (lattice noise: one workgroup <= 8192 cells, the cooperative launch <= 65536, else multi-launch),
+    1 multi-launch, 2 one workgroup at every size it covers, 3 as 0 without the cooperative launch"""
 
     def __init__(self, multi):
         self.multi = multi
 
     def __enter__(self):
         from gptst_amd import _C
-        _C.lib().call("gptst_mask_force_multi", int(self.multi))
+        _C.lib().call("gptst_mask_force_multi", 0 if self.multi == 3 else int(self.multi))
+        _C.lib().call("gptst_mask_cooperative", 0 if self.multi == 3 else -1)
 
     def __exit__(self, *a):
         from gptst_amd import _C
         _C.lib().call("gptst_mask_force_multi", 0)
+        _C.lib().call("gptst_mask_cooperative", -1)
 
 
 @pytest.mark.parametrize("multi", [0, 1])
@@ -317,18 +320,18 @@ def test_mask_random_ties_lowest_index(multi, reps):
                 ref[order[:k]] = 0
                 assert torch.equal(got, ref), k
         lat = torch.where(noise == 0.1, torch.tensor(0.125), noise)     # lattice paths: 0.1 is not k * 2^-24 -> 0.125 (same order, same ties)
-        with _mask_path(multi if multi else 2):                # 1: two digit passes over many workgroups; 2: the one-workgroup form
-            assert torch.equal(ops.mask_random(lat.to(dev), k, u24=True).cpu(), ref), ("u24", multi, k)
+        for path in ((1,) if multi else (2, 0)):               # 1: two digit passes over many workgroups; 2: the one-workgroup form; 0: by size (r05: 32000 cells -> the cooperative launch)
+            with _mask_path(path):
+                assert torch.equal(ops.mask_random(lat.to(dev), k, u24=True).cpu(), ref), ("u24", path, k)
 
 
-@pytest.mark.parametrize("path", [0, 1, 2])
-def test_mask_u24_rejects_noise_off_the_lattice(path):
+@pytest.mark.parametrize("path,M", [(0, 5000), (0, 40000), (1, 40000), (2, 40000), (3, 40000)])
+def test_mask_u24_rejects_noise_off_the_lattice(path, M):
     """gptst_mask_*_u24 select on the integers k = noise * 2^24: a value that is not k * 2^-24 (or outside [0,1)) must not be rounded silently —
     the whole mask comes back NaN; lattice noise gives a clean {0,1} mask.  path 0: one workgroup (<= 8192 cells), 1: two digit passes over
-    many workgroups, 2: one workgroup at any size up to 65536."""
+    many workgroups, 2: one workgroup at any size up to 65536; path 0 at 40000 cells: the cooperative launch (r05), 3: the same size without it."""
     from gptst_amd import ops, synth
     dev = _dev()
-    M = 5000 if path == 0 else 40000
     noise = synth.make_noise(M, 21)
     assert torch.equal((noise * 2 ** 24).round() / 2 ** 24, noise) and float(noise.max()) < 1
     with _mask_path(path):
@@ -378,7 +381,7 @@ def test_mask_adaptive_bit_exact(ada_all, B, N, HS, frac):
         assert torch.equal(m_rnd.cpu().long(), m_rnd_r)
         assert torch.equal(mask.cpu().long().view(M, base), fin_r.view(M, 1).repeat(1, base))
         assert int((mask.view(M, base)[:, 0] == 0).sum()) == total
-    for base, path, cnt in ((1, 0, counts), (2, 1, None), (1, 1, counts), (2, 2, None)):   # r04: lattice noise (0: by size, 1: two digit passes, 2: one workgroup)
+    for base, path, cnt in ((1, 0, counts), (2, 0, None), (2, 1, None), (1, 1, counts), (2, 2, None), (1, 3, counts)):   # lattice noise (0: by size - r05: the cooperative launch at M > 8192, 1: two digit passes, 2: one workgroup, 3: by size without the cooperative launch)
       with _mask_path(path):
         m_ada, m_rnd, mask = ops.mask_adaptive(label, cnt, torch.tensor(list_c, dtype=torch.int32, device=dev),
                                                torch.tensor([ada, rnd_n], dtype=torch.int32, device=dev), na.to(dev), nr.to(dev),
@@ -437,7 +440,7 @@ def test_mask_adaptive_ties_and_caller_zeroed_scratch(ada_all):
                 assert torch.equal(m_ada.cpu().long(), m_ada_r), (total, frac, ws is None)
                 assert torch.equal(m_rnd.cpu().long(), m_rnd_r), (total, frac, ws is None)
                 assert torch.equal(mask.cpu().long(), fin_r.view(-1)), (total, frac, ws is None)
-        for path, ws in ((1, None), (1, torch.zeros(words, device=dev)), (2, None)):        # the lattice paths: the same tie rule
+        for path, ws in ((0, None), (0, torch.zeros(words, device=dev)), (1, None), (1, torch.zeros(words, device=dev)), (2, None)):        # the lattice paths (0: the cooperative launch): the same tie rule
             with _mask_path(path):
                 m_ada, m_rnd, mask = ops.mask_adaptive(label, None, torch.tensor(list_c, dtype=torch.int32, device=dev),
                                                        torch.tensor([ada, rnd_n], dtype=torch.int32, device=dev), na.to(dev), nr.to(dev),
