@@ -309,30 +309,43 @@ __device__ __forceinline__ void pj_bwd_emb(const PJob& a, int bx, int by) {
     }
 }
 
-// Deterministic form (gptst_set_deterministic): ALL jobs of the table add into the same demb; one workgroup owns a 16-row tile of it,
-// walks every 256-column chunk of every job (chunks dealt round-robin to its 4 waves, each accumulating in order), folds the waves in
-// a fixed order and updates demb with a plain read-modify-write.
-__global__ __launch_bounds__(256) void pool_emb_det_kernel(PJobs t) {
-    __shared__ float fold[4][16][17];
+// Deterministic form (gptst_set_deterministic), r05: ONE launch for every embedding gradient of the call.  The table holds the kind-2 jobs grouped
+// by their demb (a group = the jobs that add into one demb, in call order; blk0 / nbx of a job = first workgroup / number of 16-row tiles of its
+// GROUP); one workgroup of 16 waves owns a 16-row tile of a demb, walks every 256-column chunk of every job of the group (chunks dealt round-robin
+// to its waves, each accumulating in order), folds the waves in a fixed order and updates demb with a plain read-modify-write.  (Round 4 ran one
+// 4-wave launch per demb, 11 - 24 workgroups each: 12 launches of 18 - 47 us per step.)
+#define PJ_DET_T 1024
+__global__ __launch_bounds__(PJ_DET_T) void pool_emb_det_kernel(PJobs t) {
+    __shared__ float fold[PJ_DET_T / 64][16][17];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int i = lane & 15, kk = lane >> 4;
+    int q0 = 0;
+    for (int q = 1; q < t.n; ++q) if ((int)blockIdx.x >= t.j[q].blk0) q0 = q;      // last job of the group (uniform scan of the scalar table)
+    const int g0 = t.j[q0].blk0, tile = blockIdx.x - g0;
     f32x4 acc = {0.f, 0.f, 0.f, 0.f};
-    int chunk_id = 0;
-    for (int q = 0; q < t.n; ++q) {
+    int chunk_id = 0, first = q0;
+    for (int q = 0; q <= q0; ++q) {
         const PJob& a = t.j[q];
+        if (a.blk0 != g0) continue;
+        if (q < first) first = q;
         const bool v4 = ((a.cols | a.ldx) & 3) == 0;
         const int nch = (a.cols + 255) / 256;
         for (int ch = 0; ch < nch; ++ch, ++chunk_id) {
-            if ((chunk_id & 3) != wave) continue;
-            if (v4) pj_emb_accum<4>(a, blockIdx.x, ch, acc); else pj_emb_accum<1>(a, blockIdx.x, ch, acc);
+            if ((chunk_id & (PJ_DET_T / 64 - 1)) != wave) continue;
+            if (v4) pj_emb_accum<4>(a, tile, ch, acc); else pj_emb_accum<1>(a, tile, ch, acc);
         }
     }
 #pragma unroll
     for (int r = 0; r < 4; ++r) fold[wave][kk * 4 + r][i] = acc[r];
     __syncthreads();
-    const int R = t.j[0].R, K = t.j[0].K;
-    const int rr = threadIdx.x >> 4, k = threadIdx.x & 15, orow = blockIdx.x * 16 + rr;
-    if (orow < R && k < K) t.j[0].out[(size_t)orow * K + k] += (fold[0][rr][k] + fold[1][rr][k]) + (fold[2][rr][k] + fold[3][rr][k]);
+    if (threadIdx.x < 256) {
+        const int R = t.j[first].R, K = t.j[first].K;
+        const int rr = threadIdx.x >> 4, k = threadIdx.x & 15, orow = tile * 16 + rr;
+        float s = 0.f;
+#pragma unroll
+        for (int w = 0; w < PJ_DET_T / 64; ++w) s += fold[w][rr][k];
+        if (orow < R && k < K) t.j[first].out[(size_t)orow * K + k] += s;
+    }
 }
 
 __global__ __launch_bounds__(256, PJ_OCC) void pool_jobs_kernel(PJobs t, int fwd_rows, int fwd_mfma) {
@@ -422,24 +435,36 @@ extern "C" int gptst_pool_jobs(int njobs, const int* kind, const void* const* em
     }
     if (t.n) { const int rc = pj_launch(t, (hipStream_t)stream); if (rc) return rc; }
     if (!det) return GPTST_OK;
-    // deterministic embedding gradients: one launch per distinct demb, all its jobs in one table, one workgroup per 16-row tile
+    // deterministic embedding gradients: the jobs grouped by demb (call order inside a group), as many whole groups per launch as the table holds
+    PJobs g; g.n = 0;
+    int nb = 0;
+    auto flush = [&]() {
+        if (g.n) { hipLaunchKernelGGL(pool_emb_det_kernel, dim3(nb), dim3(PJ_DET_T), 0, (hipStream_t)stream, g); g.n = 0; nb = 0; }
+    };
     for (int p = 0; p < njobs; ++p) {
         if (kind[p] != PJ_BWD_EMB) continue;
         bool seen = false;
         for (int q = 0; q < p; ++q) if (kind[q] == PJ_BWD_EMB && out[q] == out[p]) seen = true;
         if (seen) continue;
-        PJobs g; g.n = 0;
+        int members = 0;
+        for (int q = p; q < njobs; ++q) if (kind[q] == PJ_BWD_EMB && out[q] == out[p]) ++members;
+        if (members > PJ_MAX) return GPTST_EARG;
+        if (g.n + members > PJ_MAX) flush();
+        const int tiles = (R[p] + 15) / 16;
         for (int q = p; q < njobs; ++q) {
             if (kind[q] != PJ_BWD_EMB || out[q] != out[p]) continue;
-            if (g.n == PJ_MAX || R[q] != R[p] || K[q] != K[p]) return GPTST_EARG;
+            if (R[q] != R[p] || K[q] != K[p]) return GPTST_EARG;
             PJob j = job(q);
             if (!j.x || !j.pool || !j.out || j.R <= 0 || j.K <= 0 || j.K > PG_MAXK || j.cols <= 0 || j.nsplit <= 0) return GPTST_EARG;
             if (j.ldx <= 0) j.ldx = j.cols;
+            if (j.ldx < j.cols) return GPTST_EARG;
+            j.blk0 = nb; j.nbx = tiles;
             g.j[g.n++] = j;
         }
-        hipLaunchKernelGGL(pool_emb_det_kernel, dim3((R[p] + 15) / 16), dim3(256), 0, (hipStream_t)stream, g);
-        GPTST_CHECK_LAUNCH();
+        nb += tiles;
     }
+    flush();
+    GPTST_CHECK_LAUNCH();
     return GPTST_OK;
 }
 

@@ -14,7 +14,7 @@ struct TfGrads {
     float *wd, *bd, *ww, *bw, *w1, *b1, *w2, *b2, *w3, *b3;
 };
 
-template <int E> struct TfCfg { static constexpr int ROWS = 256 / E; };
+template <int E, int NT = 256> struct TfCfg { static constexpr int ROWS = NT / E; };
 
 // y[e] = b[e] + sum_i W[e][i] x[i]  with x in the row's LDS line; lane e keeps W[e][:] in registers
 template <int E>
@@ -64,11 +64,12 @@ __device__ __forceinline__ void tf_fwd_body(const TfParams& p, const float* __re
 
 template <bool DET> __device__ __forceinline__ void tf_add(float* p, float v) { if (DET) *p += v; else atomicAdd(p, v); }
 
-// DET: this workgroup is the only one that touches the job's gradients (it walks all row blocks itself): plain += in a fixed order
-template <int E, bool DET>
+// DET: this workgroup is the only one that touches the job's gradients (it walks all row blocks itself): plain += in a fixed order.
+// NT = threads of the workgroup (NT / E rows per block; the deterministic launch runs 1024 threads: a quarter of the passes)
+template <int E, bool DET, int NT>
 __device__ __forceinline__ void tf_bwd_body(const TfParams& p, const TfGrads& g, const float* __restrict__ tidx,
                                             const float* __restrict__ dout, int rows, int K, int blk, float* __restrict__ shraw) {
-    constexpr int ROWS = TfCfg<E>::ROWS;
+    constexpr int ROWS = TfCfg<E, NT>::ROWS;
     float (*sh)[ROWS][E + 1] = reinterpret_cast<float (*)[ROWS][E + 1]>(shraw);      // h0, h1, h2, d3, z2, z1, z0 per row
     const int tid = threadIdx.x, e = tid % E, rl = tid / E;
     const int r = blk * ROWS + rl;
@@ -101,7 +102,7 @@ __device__ __forceinline__ void tf_bwd_body(const TfParams& p, const TfGrads& g,
     __syncthreads();
     const int nrow = min(ROWS, rows - blk * ROWS);
     // dW3[e][i] = sum_r d3[e] h2[i]; dW2 = z2 (x) h1; dW1 = z1 (x) h0; biases = column sums of d3, z2, z1, z0
-    for (int idx = tid; idx < 3 * E * E; idx += 256) {
+    for (int idx = tid; idx < 3 * E * E; idx += NT) {
         const int which = idx / (E * E), eo = (idx / E) % E, i = idx % E;
         const int ga = which == 0 ? 3 : (which == 1 ? 4 : 5), gb = which == 0 ? 2 : (which == 1 ? 1 : 0);
         float s = 0.f;
@@ -109,7 +110,7 @@ __device__ __forceinline__ void tf_bwd_body(const TfParams& p, const TfGrads& g,
         float* dst = which == 0 ? g.w3 : (which == 1 ? g.w2 : g.w1);
         tf_add<DET>(dst + eo * E + i, s);
     }
-    for (int idx = tid; idx < 4 * E; idx += 256) {
+    for (int idx = tid; idx < 4 * E; idx += NT) {
         const int which = idx / E, eo = idx % E;
         const int ga = which == 0 ? 3 : (which == 1 ? 4 : (which == 2 ? 5 : 6));
         float s = 0.f;
@@ -120,7 +121,7 @@ __device__ __forceinline__ void tf_bwd_body(const TfParams& p, const TfGrads& g,
         else { tf_add<DET>(g.bd + eo, s); tf_add<DET>(g.bw + eo, s); }
     }
     // input Linears: dWd[e][k] = sum_r z0[e] * day[r,k]; dWw likewise
-    for (int idx = tid; idx < 2 * E * K; idx += 256) {
+    for (int idx = tid; idx < 2 * E * K; idx += NT) {
         const int ch = idx / (E * K), eo = (idx / K) % E, k = idx % K;
         float s = 0.f;
         for (int rr = 0; rr < nrow; ++rr)
@@ -134,20 +135,22 @@ __device__ __forceinline__ void tf_bwd_body(const TfParams& p, const TfGrads& g,
 struct TfJob { TfParams p; TfGrads g; const float* tidx; float* out; const float* dout; int rows, K, E, blk0; };
 struct TfJobs { TfJob j[TF_MAXJ]; int n; };
 
-// BWD: 0 forward, 1 backward (workgroup per row block, atomics), 2 deterministic backward (ONE workgroup per job walks its blocks)
+// BWD: 0 forward, 1 backward (workgroup per row block, atomics), 2 deterministic backward (ONE workgroup of 1024 threads per job walks its blocks)
+#define TF_DET_T 1024
 template <int BWD>
-__global__ __launch_bounds__(256) void timefeat_jobs_kernel(TfJobs t) {
-    __shared__ float shraw[TF_SH_FLOATS];
+__global__ __launch_bounds__(BWD == 2 ? TF_DET_T : 256) void timefeat_jobs_kernel(TfJobs t) {
+    constexpr int NT = BWD == 2 ? TF_DET_T : 256;
+    __shared__ float shraw[TF_SH_FLOATS * (NT / 256)];
     int q = 0;
     if (BWD == 2) q = blockIdx.x;
     else for (int i = 1; i < t.n; ++i) if ((int)blockIdx.x >= t.j[i].blk0) q = i;
     const TfJob& a = t.j[q];
     const int blk = blockIdx.x - a.blk0;
-    const int nblk = (a.rows + 256 / a.E - 1) / (256 / a.E);
+    const int nblk = (a.rows + NT / a.E - 1) / (NT / a.E);
 #define TF_CASE(EE)                                                                              \
     case EE:                                                                                     \
-        if (BWD == 2) { for (int b2 = 0; b2 < nblk; ++b2) { tf_bwd_body<EE, true>(a.p, a.g, a.tidx, a.dout, a.rows, a.K, b2, shraw); __syncthreads(); } } \
-        else if (BWD == 1) tf_bwd_body<EE, false>(a.p, a.g, a.tidx, a.dout, a.rows, a.K, blk, shraw); \
+        if (BWD == 2) { for (int b2 = 0; b2 < nblk; ++b2) { tf_bwd_body<EE, true, NT>(a.p, a.g, a.tidx, a.dout, a.rows, a.K, b2, shraw); __syncthreads(); } } \
+        else if (BWD == 1) tf_bwd_body<EE, false, NT>(a.p, a.g, a.tidx, a.dout, a.rows, a.K, blk, shraw); \
         else tf_fwd_body<EE>(a.p, a.tidx, a.out, a.rows, a.K, blk, shraw);                       \
         break;
     switch (a.E) { TF_CASE(2) TF_CASE(4) TF_CASE(8) TF_CASE(16) default: break; }
@@ -164,7 +167,7 @@ static int tf_launch(TfJobs& t, int bwd, hipStream_t st) {
         a.blk0 = nb;
         nb += (a.rows + rows_per - 1) / rows_per;
     }
-    if (bwd && g_deterministic) hipLaunchKernelGGL(timefeat_jobs_kernel<2>, dim3(t.n), dim3(256), 0, st, t);
+    if (bwd && g_deterministic) hipLaunchKernelGGL(timefeat_jobs_kernel<2>, dim3(t.n), dim3(TF_DET_T), 0, st, t);
     else if (bwd) hipLaunchKernelGGL(timefeat_jobs_kernel<1>, dim3(nb), dim3(256), 0, st, t);
     else hipLaunchKernelGGL(timefeat_jobs_kernel<0>, dim3(nb), dim3(256), 0, st, t);
     GPTST_CHECK_LAUNCH();
