@@ -21,6 +21,7 @@ static constexpr int g_ap_dbg = 0;
 #endif
 // launch-geometry knobs of gptst_tune: thread-local (ranks emulated by threads must not see each other's experiments)
 thread_local int g_apply_tpw = 0;                      // gptst_tune(4, n) forces tiles per wave of apply64 / apply128
+thread_local int g_apply128_minwg = 768;                // gptst_tune(24, n): apply128_geometry halves tiles per wave until n workgroups exist
 thread_local int g_apply128_v1 = 0;                    // gptst_tune(8, 1) selects the first-generation apply_kernel for C = 128
 
 template <int C, int PRO, int EPI>
@@ -727,8 +728,10 @@ static void apply128_geometry(const RowMap& rm, bool has_colsum, int& tpw, int& 
     tpw = rm.G == 1 ? 8 : 4;                                     // shared weight: fewer re-stagings of W; else >= ~2 workgroups per CU and group
     if (has_colsum && rm.G == 1) { const int lim = (ntiles + AP128_NW * 128 - 1) / (AP128_NW * 128); if (tpw < lim) tpw = lim; }   // <= 128 partials
     if (tpw * AP128_NW > ntiles) tpw = (ntiles + AP128_NW - 1) / AP128_NW;
-    // few, short groups (one rank's 512-node share of configs[4]: 384 groups x 32 tiles): fewer tiles per wave until ~4 workgroups per CU exist
-    while (tpw > 1 && !(has_colsum && rm.G == 1) && (long)rm.G * ((ntiles + AP128_NW * tpw - 1) / (AP128_NW * tpw)) < 1024) --tpw;
+    // few, short groups (one rank's 512-node share of configs[4]: 384 groups x 32 tiles): tiles per wave halved until ~3 workgroups per CU exist
+    // (r05: 8 -> 4 -> 2 keeps every wave of a workgroup busy; the 1024-workgroup rule of round 4 ended at one tile per wave, i.e. a 64 KB weight
+    // staged per 8 tiles: 148 -> 152.5 steps/s on that share)
+    while (tpw > 1 && !(has_colsum && rm.G == 1) && (long)rm.G * ((ntiles + AP128_NW * tpw - 1) / (AP128_NW * tpw)) < g_apply128_minwg) tpw >>= 1;
     if (g_apply_tpw > 0) tpw = g_apply_tpw;
     if (tpw < 1) tpw = 1;
     gy = (ntiles + AP128_NW * tpw - 1) / (AP128_NW * tpw);
@@ -919,7 +922,8 @@ extern "C" int gptst_wgrad_nsplit(int mode, int BT, int N, int C) {
     if (mode == 0 && g_wgrad_ns0_override > 0) return g_wgrad_ns0_override;
     if (C == 128 && !g_wgrad_v1) {                     // MFMA-bound: ~3 equal workgroups per CU, splits of >= 128 rows; every split is a 64 KB
         // partial per group that the reduction jobs read back (384 groups: 2 splits 126.7, 3 splits 123.6 steps/s at N = 512; equal at N = 4096)
-        int want = (768 + rm.G - 1) / rm.G, maxs = (rm.M + 127) / 128;
+        // r05: rounded DOWN — 512 node groups run one split each (two: 150.8, one: 152.5 steps/s on the N = 512 share; half the partial bytes)
+        int want = 768 / rm.G, maxs = (rm.M + 127) / 128;
         if (want > maxs) want = maxs;
         return want < 1 ? 1 : want;
     }

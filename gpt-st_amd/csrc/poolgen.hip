@@ -475,6 +475,7 @@ extern thread_local int g_apply_tpw;
 extern thread_local int g_tl_nb;
 extern thread_local int g_wgrad_v1;
 extern thread_local int g_apply128_v1;
+extern thread_local int g_apply128_minwg;
 extern thread_local int g_tl_mfma;
 extern thread_local int g_cap_route_v2;
 extern thread_local int g_cap_bwd_noroles;
@@ -491,6 +492,7 @@ extern "C" int gptst_tune(int id, int value) {
     if (id == 4) g_apply_tpw = value;
     if (id == 7) g_wgrad_v1 = value;
     if (id == 8) g_apply128_v1 = value;
+    if (id == 24 && value > 0) g_apply128_minwg = value;
     if (id == 10) g_pg_mfma = value;
     return GPTST_OK;
 }
