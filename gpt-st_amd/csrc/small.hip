@@ -140,25 +140,26 @@ __global__ __launch_bounds__(256) void rowdot_kernel(const float* __restrict__ X
 // lane (j, kk): A = X[row tile*16 + j][16q + 4kk ..] straight from global (float4), B = W[class j][16q + 4kk ..] (zero for j >= J) — so
 // a row costs 1/16 of 16 MFMAs instead of J dot products of 4 FMAs + a 4-step DPP reduction each (the VALU version: 18.8 us for
 // 65 280 rows x 10 classes).  D reg r = Z[row kk*4 + r][class j]: the softmax / arg-max over the classes runs across the 16 lanes of a DPP row.
-__global__ __launch_bounds__(256) void rowdot64_mfma_kernel(const float* __restrict__ X, const float* __restrict__ W, const float* __restrict__ b,
+template <int C>
+__global__ __launch_bounds__(256) void rowdot_mfma_kernel(const float* __restrict__ X, const float* __restrict__ W, const float* __restrict__ b,
                                                             float* __restrict__ Z, int rows, int J, int do_softmax, int* __restrict__ label,
                                                             int tiles_per_wave) {
-    constexpr int C = 64;
+    constexpr int Q = C / 16;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int j = lane & 15, kk = lane >> 4;
-    float4 bw[4];
+    float4 bw[Q];
 #pragma unroll
-    for (int q = 0; q < 4; ++q) bw[q] = j < J ? ld4(W + (size_t)j * C + 16 * q + 4 * kk) : f4zero();
+    for (int q = 0; q < Q; ++q) bw[q] = j < J ? ld4(W + (size_t)j * C + 16 * q + 4 * kk) : f4zero();
     const float bj = (b != nullptr && j < J) ? b[j] : 0.f;
     const int ntiles = (rows + 15) / 16;
     const int t0 = (blockIdx.x * 4 + wave) * tiles_per_wave, t1 = min(ntiles, t0 + tiles_per_wave);
     for (int tb = t0; tb < t1; tb += 2) {                           // two tiles' loads in flight
-        float4 a[2][4];
+        float4 a[2][Q];
 #pragma unroll
         for (int u = 0; u < 2; ++u) {
             const float* row = X + (size_t)min((tb + u) * 16 + j, rows - 1) * C + 4 * kk;
 #pragma unroll
-            for (int q = 0; q < 4; ++q) a[u][q] = ld4(row + 16 * q);
+            for (int q = 0; q < Q; ++q) a[u][q] = ld4(row + 16 * q);
         }
         SB();
 #pragma unroll
@@ -166,7 +167,7 @@ __global__ __launch_bounds__(256) void rowdot64_mfma_kernel(const float* __restr
             if (tb + u >= t1) break;                                 // wave-uniform
             f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-            for (int q = 0; q < 4; ++q) {
+            for (int q = 0; q < Q; ++q) {
                 acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a[u][q].x, bw[q].x, acc0, 0, 0, 0);
                 acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a[u][q].y, bw[q].y, acc1, 0, 0, 0);
                 acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a[u][q].z, bw[q].z, acc0, 0, 0, 0);
@@ -313,11 +314,13 @@ extern "C" int gptst_rowdot(const float* X, const float* W, const float* b, floa
     if (!X || !W || !Z || J <= 0 || J > SM_MAXJ) return GPTST_EARG;
     hipStream_t st = (hipStream_t)stream;
     const bool loop = (long)rows > (long)SM_MAXGRID * (C == 64 ? 16 : 8);
-    if (C == 64 && J <= 16) {
+    if ((C == 64 || C == 128) && J <= 16) {                         // r05: C = 128 too (the VALU form ran 3.5x its memory floor at N = 512 / 4096)
         const int ntiles = (rows + 15) / 16;
         int tpw = (ntiles + 4 * 1024 - 1) / (4 * 1024);            // ~1024 workgroups of 4 waves; an even number of tiles per wave
         tpw = (tpw + 1) & ~1;
-        hipLaunchKernelGGL(rowdot64_mfma_kernel, dim3((ntiles + 4 * tpw - 1) / (4 * tpw)), dim3(256), 0, st, X, W, b, Z, rows, J, do_softmax, label, tpw);
+        const dim3 grid((ntiles + 4 * tpw - 1) / (4 * tpw));
+        if (C == 64) hipLaunchKernelGGL(rowdot_mfma_kernel<64>, grid, dim3(256), 0, st, X, W, b, Z, rows, J, do_softmax, label, tpw);
+        else hipLaunchKernelGGL(rowdot_mfma_kernel<128>, grid, dim3(256), 0, st, X, W, b, Z, rows, J, do_softmax, label, tpw);
     }
     else if (C == 64 && !loop) hipLaunchKernelGGL((rowdot_kernel<64, false>), dim3(sm_grid(rows, 16)), dim3(256), 0, st, X, W, b, Z, rows, J, do_softmax, label);
     else if (C == 64) hipLaunchKernelGGL((rowdot_kernel<64, true>), dim3(sm_grid(rows, 16)), dim3(256), 0, st, X, W, b, Z, rows, J, do_softmax, label);

@@ -149,9 +149,9 @@ __global__ __launch_bounds__(256) void tail_kernel(TailArgs t) {
 //   gW (16 classes x 64)     += a^T . X          A = a in the D layout as it is (step s <-> row 4kk+s), B = X rows in the D layout (float4)
 // D layout of Z / a: lane (j = class, kk), register r <-> row 4kk + r, so the per-row softmax terms run across the 16 lanes of a DPP row.
 // Same outputs as tail_kernel (out, dX, part[blk][J*C + J], sws[blk][4]); sums are accumulated in a different order (tolerance-checked).
-template <int KIND>
-__global__ __launch_bounds__(256) void tail64_mfma_kernel(TailArgs t) {
-    constexpr int C = 64;
+template <int KIND, int C>      // C = 128 (r05): the D-layout operands come in two 64-channel halves hf (channel 64 hf + 4j + ct)
+__global__ __launch_bounds__(256) void tail_mfma_kernel(TailArgs t) {
+    constexpr int Q = C / 16, HF = C / 64;
     __shared__ float at[4][16][17];                     // per wave: a[row][class] (D layout -> A layout)
     __shared__ __attribute__((aligned(16))) float fold[4][16 * C + 16];
     __shared__ float reds[2][4];
@@ -159,28 +159,34 @@ __global__ __launch_bounds__(256) void tail64_mfma_kernel(TailArgs t) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int j = lane & 15, kk = lane >> 4;
     // W as B operand of Z (class j, channels 16q + 4kk ..) and of dX (class 4s + kk, channels 4j .. 4j+3)
-    float4 bz[4], bd[4];
+    float4 bz[Q], bd[HF][4];
 #pragma unroll
-    for (int q = 0; q < 4; ++q) {
-        bz[q] = (KIND == 0 && j < J) ? ld4(t.W + (size_t)j * C + 16 * q + 4 * kk) : f4zero();
-        bd[q] = (4 * q + kk < J) ? ld4(t.W + (size_t)(4 * q + kk) * C + 4 * j) : f4zero();
-    }
+    for (int q = 0; q < Q; ++q) bz[q] = (KIND == 0 && j < J) ? ld4(t.W + (size_t)j * C + 16 * q + 4 * kk) : f4zero();
+#pragma unroll
+    for (int hf = 0; hf < HF; ++hf)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) bd[hf][q] = (4 * q + kk < J) ? ld4(t.W + (size_t)(4 * q + kk) * C + 64 * hf + 4 * j) : f4zero();
     const float bj = (KIND == 0 && t.b != nullptr && j < J) ? t.b[j] : 0.f;
     const int nks = (J + 3) / 4;                        // k-steps of the dX product
-    f32x4 gw[4];
+    f32x4 gw[HF][4];
 #pragma unroll
-    for (int ct = 0; ct < 4; ++ct) gw[ct] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    for (int hf = 0; hf < HF; ++hf)
+#pragma unroll
+        for (int ct = 0; ct < 4; ++ct) gw[hf][ct] = (f32x4){0.f, 0.f, 0.f, 0.f};
     float gb = 0.f, s0 = 0.f, s1 = 0.f;
     const size_t r0 = (size_t)blockIdx.x * t.rows_per_block;
     const size_t r1 = min((size_t)t.rows, r0 + t.rows_per_block);
     for (size_t tb = r0 + 16 * wave; tb < r1; tb += 64) {
         // X tile in both layouts (the second read hits L1): A layout for Z, D layout for gW / the LeakyReLU sign
-        float4 xa[4], xd[4];
+        float4 xa[Q], xd[HF][4];
+        if (KIND == 0) {
 #pragma unroll
-        for (int q = 0; q < 4; ++q) {
-            if (KIND == 0) xa[q] = ld4(t.X + min(tb + j, r1 - 1) * C + 16 * q + 4 * kk);
-            xd[q] = ld4(t.X + min(tb + 4 * kk + q, r1 - 1) * C + 4 * j);
+            for (int q = 0; q < Q; ++q) xa[q] = ld4(t.X + min(tb + j, r1 - 1) * C + 16 * q + 4 * kk);
         }
+#pragma unroll
+        for (int hf = 0; hf < HF; ++hf)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) xd[hf][q] = ld4(t.X + min(tb + 4 * kk + q, r1 - 1) * C + 64 * hf + 4 * j);
         // the epilogue's per-row operands travel with the X tile (after the MFMAs they were a second, dependent round trip per tile)
         float o0[4], o1[4];
 #pragma unroll
@@ -195,7 +201,7 @@ __global__ __launch_bounds__(256) void tail64_mfma_kernel(TailArgs t) {
         if (KIND == 0) {
             f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-            for (int q = 0; q < 4; ++q) {
+            for (int q = 0; q < Q; ++q) {
                 acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(xa[q].x, bz[q].x, acc0, 0, 0, 0);
                 acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(xa[q].y, bz[q].y, acc1, 0, 0, 0);
                 acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(xa[q].z, bz[q].z, acc0, 0, 0, 0);
@@ -235,41 +241,54 @@ __global__ __launch_bounds__(256) void tail64_mfma_kernel(TailArgs t) {
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
             gb += a[r];
-            gw[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[r], xd[r].x, gw[0], 0, 0, 0);
-            gw[1] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[r], xd[r].y, gw[1], 0, 0, 0);
-            gw[2] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[r], xd[r].z, gw[2], 0, 0, 0);
-            gw[3] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[r], xd[r].w, gw[3], 0, 0, 0);
+#pragma unroll
+            for (int hf = 0; hf < HF; ++hf) {
+                gw[hf][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[r], xd[hf][r].x, gw[hf][0], 0, 0, 0);
+                gw[hf][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[r], xd[hf][r].y, gw[hf][1], 0, 0, 0);
+                gw[hf][2] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[r], xd[hf][r].z, gw[hf][2], 0, 0, 0);
+                gw[hf][3] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[r], xd[hf][r].w, gw[hf][3], 0, 0, 0);
+            }
         }
         // ---- dX = a W: a from the D layout into the A layout (lane (i = row, kk): classes 4s + kk) through the wave's tile ----
 #pragma unroll
         for (int r = 0; r < 4; ++r) at[wave][4 * kk + r][j] = a[r];
-        f32x4 dx[4];
+        f32x4 dx[HF][4];
 #pragma unroll
-        for (int ct = 0; ct < 4; ++ct) dx[ct] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        for (int hf = 0; hf < HF; ++hf)
+#pragma unroll
+            for (int ct = 0; ct < 4; ++ct) dx[hf][ct] = (f32x4){0.f, 0.f, 0.f, 0.f};
 #pragma unroll
         for (int s = 0; s < 4; ++s) {
             if (s < nks) {                                           // uniform
                 const float as = at[wave][j][4 * s + kk];
-                dx[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(as, bd[s].x, dx[0], 0, 0, 0);
-                dx[1] = __builtin_amdgcn_mfma_f32_16x16x4f32(as, bd[s].y, dx[1], 0, 0, 0);
-                dx[2] = __builtin_amdgcn_mfma_f32_16x16x4f32(as, bd[s].z, dx[2], 0, 0, 0);
-                dx[3] = __builtin_amdgcn_mfma_f32_16x16x4f32(as, bd[s].w, dx[3], 0, 0, 0);
+#pragma unroll
+                for (int hf = 0; hf < HF; ++hf) {
+                    dx[hf][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(as, bd[hf][s].x, dx[hf][0], 0, 0, 0);
+                    dx[hf][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(as, bd[hf][s].y, dx[hf][1], 0, 0, 0);
+                    dx[hf][2] = __builtin_amdgcn_mfma_f32_16x16x4f32(as, bd[hf][s].z, dx[hf][2], 0, 0, 0);
+                    dx[hf][3] = __builtin_amdgcn_mfma_f32_16x16x4f32(as, bd[hf][s].w, dx[hf][3], 0, 0, 0);
+                }
             }
         }
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
             const size_t i = tb + 4 * kk + r;
-            float4 v = make_float4(dx[0][r], dx[1][r], dx[2][r], dx[3][r]);
-            if (t.premul) {
-                v.x *= lrelu_grad_from_out(xd[r].x); v.y *= lrelu_grad_from_out(xd[r].y);
-                v.z *= lrelu_grad_from_out(xd[r].z); v.w *= lrelu_grad_from_out(xd[r].w);
+#pragma unroll
+            for (int hf = 0; hf < HF; ++hf) {
+                float4 v = make_float4(dx[hf][0][r], dx[hf][1][r], dx[hf][2][r], dx[hf][3][r]);
+                if (t.premul) {
+                    v.x *= lrelu_grad_from_out(xd[hf][r].x); v.y *= lrelu_grad_from_out(xd[hf][r].y);
+                    v.z *= lrelu_grad_from_out(xd[hf][r].z); v.w *= lrelu_grad_from_out(xd[hf][r].w);
+                }
+                if (i < r1) st4(t.dX + i * C + 64 * hf + 4 * j, v);
             }
-            if (i < r1) st4(t.dX + i * C + 4 * j, v);
         }
     }
     // ---- fold the four waves: gW (D reg r of tile ct: class 4kk + r, channel 4j + ct), gb, loss statistics ----
 #pragma unroll
-    for (int r = 0; r < 4; ++r) st4(&fold[wave][(4 * kk + r) * C + 4 * j], make_float4(gw[0][r], gw[1][r], gw[2][r], gw[3][r]));
+    for (int r = 0; r < 4; ++r)
+#pragma unroll
+        for (int hf = 0; hf < HF; ++hf) st4(&fold[wave][(4 * kk + r) * C + 64 * hf + 4 * j], make_float4(gw[hf][0][r], gw[hf][1][r], gw[hf][2][r], gw[hf][3][r]));
     gb += __shfl_xor(gb, 16, 64); gb += __shfl_xor(gb, 32, 64);
     if (kk == 0) fold[wave][16 * C + j] = gb;
     s0 = group_sum<64>(s0); s1 = group_sum<64>(s1);
@@ -308,7 +327,7 @@ __global__ __launch_bounds__(256) void stats_fold_kernel(const float* __restrict
 }
 
 thread_local int g_tl_nb = TL_NB;       // experiments: gptst_tune(6, nb)
-thread_local int g_tl_mfma = 1;         // gptst_tune(15, 0): the VALU loss heads (tail_kernel) also at C = 64
+thread_local int g_tl_mfma = 1;         // gptst_tune(15, 0): the VALU loss heads (tail_kernel) instead of the MFMA ones
 static void tl_geometry(int rows, int& nb, int& rpb) {
     int want = g_tl_nb;
     if (g_tl_nb == TL_NB && rows > TL_NB * 512) { want = rows / 512; if (want > 4096) want = 4096; }      // N = 4096: 1.5 M rows -> 3072 chunks
@@ -342,8 +361,9 @@ extern "C" int gptst_tail_mae(const float* dec, const float* W, const float* b, 
     t.X = dec; t.W = W; t.b = b; t.dX = d_dec; t.part = part; t.sws = sws; t.rows = rows; t.J = J;
     t.src = src; t.mask = mask; t.out = out; t.lda = lda; t.sigma = sigma; t.mu = mu; t.thresh = thresh; t.premul = premul;
     int nb; tl_geometry(rows, nb, t.rows_per_block);
-    if (C == 64 && g_tl_mfma) hipLaunchKernelGGL((tail64_mfma_kernel<0>), dim3(nb), dim3(256), 0, (hipStream_t)stream, t);
+    if (C == 64 && g_tl_mfma) hipLaunchKernelGGL((tail_mfma_kernel<0, 64>), dim3(nb), dim3(256), 0, (hipStream_t)stream, t);
     else if (C == 64) hipLaunchKernelGGL((tail_kernel<0, 64>), dim3(nb), dim3(256), 0, (hipStream_t)stream, t);
+    else if (g_tl_mfma) hipLaunchKernelGGL((tail_mfma_kernel<0, 128>), dim3(nb), dim3(256), 0, (hipStream_t)stream, t);
     else hipLaunchKernelGGL((tail_kernel<0, 128>), dim3(nb), dim3(256), 0, (hipStream_t)stream, t);
     GPTST_CHECK_LAUNCH();
     return GPTST_OK;
@@ -357,8 +377,9 @@ extern "C" int gptst_tail_kl(const float* h2, const float* W3, const float* prob
     t.X = h2; t.W = W3; t.dX = d_h2; t.part = part; t.sws = sws; t.rows = rows; t.J = HS;
     t.prob = prob; t.c = c; t.N = N; t.w = w; t.premul = premul;
     int nb; tl_geometry(rows, nb, t.rows_per_block);
-    if (C == 64 && g_tl_mfma) hipLaunchKernelGGL((tail64_mfma_kernel<1>), dim3(nb), dim3(256), 0, (hipStream_t)stream, t);
+    if (C == 64 && g_tl_mfma) hipLaunchKernelGGL((tail_mfma_kernel<1, 64>), dim3(nb), dim3(256), 0, (hipStream_t)stream, t);
     else if (C == 64) hipLaunchKernelGGL((tail_kernel<1, 64>), dim3(nb), dim3(256), 0, (hipStream_t)stream, t);
+    else if (g_tl_mfma) hipLaunchKernelGGL((tail_mfma_kernel<1, 128>), dim3(nb), dim3(256), 0, (hipStream_t)stream, t);
     else hipLaunchKernelGGL((tail_kernel<1, 128>), dim3(nb), dim3(256), 0, (hipStream_t)stream, t);
     GPTST_CHECK_LAUNCH();
     return GPTST_OK;
