@@ -11,6 +11,8 @@
 // the host, so it is hipGraph-capturable.  Noise is non-negative (uniform [0,1)): uint32 bit order == float order.
 // Masks are fp32 {0,1} arrays (1 = visible, 0 = masked) of B*T*N*base cells — the consumers multiply with them.
 #include "common.h"
+#include "poolgen_dev.h"
+#include <vector>
 
 #define MS_BLOCKS 64                     // workgroups of a selection launch up to 2^16 cells; more cells: one per 1024 cells, up to MS_BLOCKS_MAX
 #define MS_BLOCKS_MAX 512
@@ -907,15 +909,23 @@ __device__ __forceinline__ bool mc_select(unsigned key, bool valid, int k, unsig
     return m;
 }
 
+struct McArgs {
+    const int* label; const int* list_c; const int* nums; const float* noise_a; const float* noise_r;
+    int ada_all, M, HS, base, k_const;
+    float* m_ada; float* m_rnd; float* mask; unsigned* ws;
+};
+
+// the mask role: workgroups 0 .. nwg-1 of the launch (a cell per thread)
 template <bool ADAPTIVE>
-__global__ __launch_bounds__(MC_T) void mc_mask_kernel(const int* __restrict__ label, const int* __restrict__ list_c, const int* __restrict__ nums,
-                                                       const float* __restrict__ noise_a, const float* __restrict__ noise_r, int ada_all, int M,
-                                                       int HS, int base, int k_const, float* __restrict__ m_ada, float* __restrict__ m_rnd,
-                                                       float* __restrict__ mask, unsigned* __restrict__ ws) {
+__device__ __forceinline__ void mc_mask_body(const McArgs& g, unsigned nwg) {
+    const int* __restrict__ label = g.label; const int* __restrict__ list_c = g.list_c; const int* __restrict__ nums = g.nums;
+    const float* __restrict__ noise_a = g.noise_a; const float* __restrict__ noise_r = g.noise_r;
+    const int ada_all = g.ada_all, M = g.M, HS = g.HS, base = g.base, k_const = g.k_const;
+    float* __restrict__ m_ada = g.m_ada; float* __restrict__ m_rnd = g.m_rnd; float* __restrict__ mask = g.mask;
+    unsigned* __restrict__ ws = g.ws;
     __shared__ McShared sh;
     const int t = threadIdx.x, i = blockIdx.x * MC_T + t;
     const bool valid = i < M;
-    const unsigned nwg = gridDim.x;
     unsigned ph = 0u, bad = 0u;
     bool ok = true;
     unsigned* bar = ws + 16768;
@@ -976,6 +986,37 @@ __global__ __launch_bounds__(MC_T) void mc_mask_kernel(const int* __restrict__ l
     }
 }
 
+template <bool ADAPTIVE>
+__global__ __launch_bounds__(MC_T) void mc_mask_kernel(McArgs g) { mc_mask_body<ADAPTIVE>(g, gridDim.x); }
+
+// r05: the same launch also runs a table of forward generation jobs (poolgen_dev.h) on workgroups nmask, nmask+1, ..: each 256-thread quarter of a
+// workgroup takes one 256-thread job block.  The jobs do not depend on the mask nor the mask on them; the 64 mask workgroups are latency-bound
+// (five grid barriers) on 64 CUs, the jobs are write-bound on all of them.  The mask workgroups come FIRST in dispatch order: all resident at once.
+template <bool ADAPTIVE>
+__global__ __launch_bounds__(MC_T) void mc_mask_jobs_kernel(McArgs g, unsigned nmask, PJobs t, int nf, int nvb, int fwd_rows) {
+    if (blockIdx.x >= nmask) {
+        const int nfw = (nvb + MC_T / 256 - 1) / (MC_T / 256);              // workgroups of the forward jobs; behind them one workgroup per graph-job block
+        const int wrel = (int)(blockIdx.x - nmask);
+        if (wrel >= nfw) {                                                 // kind 3 (temporal graphs): the whole workgroup runs one block
+            __shared__ float scr[PJ_GRAM_SCR];
+            const int gb = wrel - nfw;
+            int p = nf;
+            for (int q = nf + 1; q < t.n; ++q) if (gb >= t.j[q].blk0) p = q;
+            pj_gram(t.j[p], gb - t.j[p].blk0, scr, MC_T);
+            return;
+        }
+        const int vb = __builtin_amdgcn_readfirstlane(wrel * (MC_T / 256) + (int)(threadIdx.x >> 8));
+        if (vb >= nvb) return;
+        int p = 0;
+        for (int q = 1; q < nf; ++q) if (vb >= t.j[q].blk0) p = q;
+        const PJob& a = t.j[p];
+        const int rel = vb - a.blk0;
+        pj_fwd_mfma(a, rel % a.nbx, rel / a.nbx, fwd_rows, threadIdx.x & 255);
+        return;
+    }
+    mc_mask_body<ADAPTIVE>(g, nmask);
+}
+
 int g_ms_coop = MS_COOP_DEFAULT;              // gptst_mask_cooperative(0): the multi-launch path instead of the cooperative launch (the steppers' fallback after a lost hand-off; A/B; tests)
 
 static int mu_prepare() {
@@ -1002,8 +1043,8 @@ extern "C" int gptst_mask_random_u24(const float* noise, int M, int k, float* ma
     }
     if (g_ms_coop && g_ms_force_multi == 0 && ws && M <= MC_T * MC_MAXWG) {          // r05: one cooperative launch, a cell per thread
         if (!ws_zeroed) hipLaunchKernelGGL(ms_zero_kernel, dim3(24), dim3(256), 0, (hipStream_t)stream, (unsigned*)ws, MS_WS_WORDS);
-        hipLaunchKernelGGL((mc_mask_kernel<false>), dim3((M + MC_T - 1) / MC_T), dim3(MC_T), 0, (hipStream_t)stream, (const int*)nullptr, (const int*)nullptr,
-                           (const int*)nullptr, noise, (const float*)nullptr, 0, M, 0, 1, k, (float*)nullptr, (float*)nullptr, mask, (unsigned*)ws);
+        const McArgs g{nullptr, nullptr, nullptr, noise, nullptr, 0, M, 0, 1, k, nullptr, nullptr, mask, (unsigned*)ws};
+        hipLaunchKernelGGL((mc_mask_kernel<false>), dim3((M + MC_T - 1) / MC_T), dim3(MC_T), 0, (hipStream_t)stream, g);
         GPTST_CHECK_LAUNCH();
         return GPTST_OK;
     }
@@ -1023,10 +1064,53 @@ extern "C" int gptst_mask_adaptive_u24(const int* label, const int* counts, cons
     }
     if (g_ms_coop && g_ms_force_multi == 0 && ws && M <= MC_T * MC_MAXWG) {          // r05: one cooperative launch (the class histogram is taken inside)
         if (!ws_zeroed) hipLaunchKernelGGL(ms_zero_kernel, dim3(24), dim3(256), 0, (hipStream_t)stream, (unsigned*)ws, MS_WS_WORDS);
-        hipLaunchKernelGGL((mc_mask_kernel<true>), dim3((M + MC_T - 1) / MC_T), dim3(MC_T), 0, (hipStream_t)stream, label, list_c, nums, noise_a, noise_r,
-                           ada_all, M, HS, base, 0, m_ada, m_rnd, mask, (unsigned*)ws);
+        const McArgs g{label, list_c, nums, noise_a, noise_r, ada_all, M, HS, base, 0, m_ada, m_rnd, mask, (unsigned*)ws};
+        hipLaunchKernelGGL((mc_mask_kernel<true>), dim3((M + MC_T - 1) / MC_T), dim3(MC_T), 0, (hipStream_t)stream, g);
         GPTST_CHECK_LAUNCH();
         return GPTST_OK;
     }
     return ms_adaptive_impl(label, counts, list_c, nums, noise_a, noise_r, ada_all, M, HS, base, m_ada, m_rnd, mask, ws, ws_zeroed, stream, 1);
+}
+
+// r05: gptst_pool_jobs (njobs generation jobs — kind 0 forward: out_j (R_j, cols_j) = emb_j (R_j, K_j) @ pool_j (K_j, cols_j), kind 3 temporal graph;
+// kind NULL: all forward) followed by gptst_mask_random_u24
+// (adaptive == 0: noise_a, k) or gptst_mask_adaptive_u24 (adaptive != 0) — as ONE launch when the mask takes the cooperative form and every job the MFMA
+// form (cols % 4 == 0), else as those two calls.  The jobs must not read the mask's outputs nor write its inputs (they are independent work that fills
+// the CUs the 64 latency-bound mask workgroups leave idle).
+GPTST_INTERNAL int gptst_pj_embed_table(PJobs* t, int njobs, const int* kind, const void* const* emb, const void* const* pool, const void* const* out,
+                                        const int* R, const int* K, const int* cols, int* nf, int* nvb, int* ngw);
+extern "C" int gptst_pool_jobs(int njobs, const int* kind, const void* const* emb, const void* const* x, const void* const* pool,
+                               const void* const* out, const int* R, const int* K, const int* cols, const int* nsplit, const int* ldx, void* stream);
+extern "C" int gptst_mask_u24_fwd_jobs(int adaptive, const int* label, const int* counts, const int* list_c, const int* nums, const float* noise_a,
+                                       const float* noise_r, int ada_all, int M, int HS, int base, int k, float* m_ada, float* m_rnd, float* mask,
+                                       void* ws, int ws_zeroed, int njobs, const int* kind, const void* const* emb, const void* const* pool,
+                                       const void* const* out, const int* R, const int* K, const int* cols, void* stream) {
+    if (njobs < 0 || (njobs && (!emb || !pool || !out || !R || !K || !cols))) return GPTST_EARG;
+    if (adaptive ? (!label || !list_c || !nums || !noise_a || !noise_r || !mask || HS <= 0 || HS > 256 || M <= 0 || base <= 0)
+                 : (!noise_a || !mask || M <= 0 || k < 0 || k > M)) return GPTST_EARG;
+    PJobs t;
+    int nf = 0, nvb = 0, ngw = 0;
+    const bool coop = g_ms_coop && g_ms_force_multi == 0 && ws && M > MSS_MAXM && M <= MC_T * MC_MAXWG;
+    if (coop && njobs > 0 && gptst_pj_embed_table(&t, njobs, kind, emb, pool, out, R, K, cols, &nf, &nvb, &ngw) == GPTST_OK) {
+        if (!ws_zeroed) hipLaunchKernelGGL(ms_zero_kernel, dim3(24), dim3(256), 0, (hipStream_t)stream, (unsigned*)ws, MS_WS_WORDS);
+        const unsigned nmask = (unsigned)((M + MC_T - 1) / MC_T);
+        const dim3 grid(nmask + (unsigned)((nvb + MC_T / 256 - 1) / (MC_T / 256)) + (unsigned)ngw);
+        if (adaptive) {
+            const McArgs g{label, list_c, nums, noise_a, noise_r, ada_all, M, HS, base, 0, m_ada, m_rnd, mask, (unsigned*)ws};
+            hipLaunchKernelGGL((mc_mask_jobs_kernel<true>), grid, dim3(MC_T), 0, (hipStream_t)stream, g, nmask, t, nf, nvb, PG_MFMA_ROWS);
+        } else {
+            const McArgs g{nullptr, nullptr, nullptr, noise_a, nullptr, 0, M, 0, 1, k, nullptr, nullptr, mask, (unsigned*)ws};
+            hipLaunchKernelGGL((mc_mask_jobs_kernel<false>), grid, dim3(MC_T), 0, (hipStream_t)stream, g, nmask, t, nf, nvb, PG_MFMA_ROWS);
+        }
+        GPTST_CHECK_LAUNCH();
+        return GPTST_OK;
+    }
+    if (njobs > 0) {
+        std::vector<int> kd(njobs, (int)PJ_FWD), one(njobs, 1);
+        std::vector<const void*> nul(njobs, nullptr);
+        const int rc = gptst_pool_jobs(njobs, kind ? kind : kd.data(), emb, nul.data(), pool, out, R, K, cols, one.data(), nullptr, stream);
+        if (rc) return rc;
+    }
+    return adaptive ? gptst_mask_adaptive_u24(label, counts, list_c, nums, noise_a, noise_r, ada_all, M, HS, base, m_ada, m_rnd, mask, ws, ws_zeroed, stream)
+                    : gptst_mask_random_u24(noise_a, M, k, mask, ws, ws_zeroed, stream);
 }

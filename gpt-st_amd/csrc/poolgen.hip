@@ -10,11 +10,10 @@
 // when few land on the same address (a same-address atomic serialises at ~80 ns) and when there are few of them overall —
 // so each output element is owned by one thread (or a handful of row chunks), never by hundreds of workgroups.
 #include "common.h"
+#include "poolgen_dev.h"
 #include <algorithm>
 #include <vector>
 
-#define PG_MAXK 16
-#define PG_MFMA_ROWS 64 // rows per block of the MFMA forward (four 16-row tiles per wave and B-fragment load)
 #define PG_ROWS 16     // rows per block of the VALU forward: the K pool rows a thread keeps in registers are re-read from L2 once per block
 
 // V = 4: float4 columns (cols % 4 == 0, rows 16-byte aligned);  V = 1: scalar columns (e.g. HS*N = 2070 for METR_LA)
@@ -40,17 +39,7 @@ template <> __device__ __forceinline__ void stv<1>(float* p, float4 v) { *p = v.
 #ifndef PJ_NU
 #define PJ_NU 4
 #endif
-#define PJ_MAX 112     // 112 x 64 B = 7 KB of kernel arguments (the AQL kernarg segment is not limited to 4 KB); a pretraining step queues ~100 reductions -> 1 launch
-enum { PJ_FWD = 0, PJ_BWD_POOL = 1, PJ_BWD_EMB = 2, PJ_GRAM = 3 };
-struct PJob {
-    const float* emb;      // FWD / BWD_POOL: (R, K)
-    const float* x;        // BWD_POOL / BWD_EMB: dW (R * nsplit, cols)
-    const float* pool;     // FWD / BWD_EMB: (K, cols)
-    float* out;            // FWD: (R, cols);  BWD_POOL: dpool (K, cols) +=;  BWD_EMB: demb (R, K) +=;  GRAM: (R, T, T)
-    int R, K, cols, nsplit;
-    int blk0, kind, nbx, ldx;   // ldx: row stride of x (>= cols: x may be a column window of a wider matrix)
-};
-struct PJobs { PJob j[PJ_MAX]; int n; };
+// (PJ_MAX, PJob, PJobs, pj_fwd_mfma: poolgen_dev.h — the cooperative mask launch of masksel.hip carries forward jobs too, r05)
 
 // out[r, :] = sum_k emb[r,k] pool[k, :].   blocks: (ceil(cols/V/256), ceil(R/rows)), rows <= PG_MAXROWS
 // The block's emb rows are staged in LDS (zero-padded to PG_MAXK) BEFORE the store loop: read per row from global memory they
@@ -94,80 +83,14 @@ __device__ __forceinline__ void pj_fwd(const PJob& a, int bx, int by, int rows, 
 // version above reads as many bytes from L2 as it writes), and the result is BIT-IDENTICAL to it: an fp32 MFMA is the fmaf chain over
 // its four k values in order (MI355X_MICROARCH.md), and the k-steps run in order (tests/test_gpu_kernels.py::test_poolgen_mfma_bitwise).
 // blocks: (ceil(cols/256), ceil(R/rows)), rows a multiple of 16.
-__device__ __forceinline__ void pj_fwd_mfma(const PJob& a, int bx, int by, int rows) {
-    const float* __restrict__ emb = a.emb;
-    const float* __restrict__ pool = a.pool;
-    float* __restrict__ out = a.out;
-    const int cols = a.cols, K = a.K, R = a.R;
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, j = lane & 15, kk = lane >> 4;
-    const int c = bx * 256 + wave * 64 + 4 * j;
-    if (bx * 256 + wave * 64 >= cols) return;                      // whole wave beyond the last column
-    const bool cok = c < cols;
-    const int nks = (K + 3) >> 2;                                  // k-steps (K <= 16)
-    float4 bf[4];
-#pragma unroll
-    for (int s = 0; s < 4; ++s) bf[s] = (cok && 4 * s + kk < K) ? ld4(pool + (size_t)(4 * s + kk) * cols + c) : f4zero();
-    const int r0 = by * rows, r1 = min(R, r0 + rows);
-    for (int rt = r0; rt < r1; rt += 16) {
-        float av[4];
-        const int row = rt + j;
-#pragma unroll
-        for (int s = 0; s < 4; ++s) av[s] = (row < r1 && 4 * s + kk < K) ? emb[(size_t)row * K + 4 * s + kk] : 0.f;
-        f32x4 acc[4];
-#pragma unroll
-        for (int ct = 0; ct < 4; ++ct) acc[ct] = (f32x4){0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-        for (int s = 0; s < 4; ++s) {
-            if (s < nks) {                                             // uniform
-                acc[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[s], bf[s].x, acc[0], 0, 0, 0);
-                acc[1] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[s], bf[s].y, acc[1], 0, 0, 0);
-                acc[2] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[s], bf[s].z, acc[2], 0, 0, 0);
-                acc[3] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[s], bf[s].w, acc[3], 0, 0, 0);
-            }
-        }
-        if (cok) {
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const int orow = rt + 4 * kk + r;
-                if (orow < r1) st4(out + (size_t)orow * cols + c, make_float4(acc[0][r], acc[1][r], acc[2][r], acc[3][r]));
-            }
-        }
-    }
-}
+// pj_fwd_mfma(a, bx, by, rows, tid): poolgen_dev.h
 
 // GRAM: out[r] = A_r^T A_r (T x T, T = 12) of the per-row matrix A_r = (emb . pool)[r] viewed as (cols / 12, 12) — hyperTem's per-node
 // temporal graph G_n = A_n^T A_n (GPTST.py:156-158, tmix.hip) straight from the node embedding and the hyperedge pool, so that it does not
 // have to wait for (and be launched behind) the job that materialises A.  A workgroup takes pj_gram_rows() rows: the pool is staged in LDS,
 // the rows' A are rebuilt there with the forward job's fmaf order over k (bit-identical to reading them from its output), then reduced over
 // the hyperedges in gram_fwd's order.   blocks: ceil(R / pj_gram_rows())
-#define PJ_SCR (4 * PG_MAXK * 65)                  // floats of the kernel's LDS scratch
-__host__ __device__ inline int pj_gram_rows(int K, int cols) {
-    const int nb = (PJ_SCR - K * cols) / cols;
-    return nb > 16 ? 16 : nb;                      // <= 0: the shape does not fit (EARG)
-}
-__device__ __forceinline__ void pj_gram(const PJob& a, int bx, float* __restrict__ scr) {
-    const int K = a.K, cols = a.cols, Hm = cols / 12, NB = pj_gram_rows(K, cols);
-    float* pl = scr;                               // [K][cols]
-    float* As = scr + K * cols;                    // [NB][cols]
-    const int r0 = bx * NB, nr = min(NB, a.R - r0);
-    for (int i = threadIdx.x; i < K * cols; i += 256) pl[i] = a.pool[i];
-    __syncthreads();
-    for (int i = threadIdx.x; i < nr * cols; i += 256) {
-        const int r = i / cols, c = i % cols;
-        const float* __restrict__ e = a.emb + (size_t)(r0 + r) * K;
-        float acc = 0.f;
-        for (int k = 0; k < K; ++k) acc = fmaf(e[k], pl[k * cols + c], acc);
-        As[i] = acc;
-    }
-    __syncthreads();
-    for (int i = threadIdx.x; i < nr * 144; i += 256) {
-        const int r = i / 144, t = (i % 144) / 12, u = i % 12;
-        const float* ar = As + r * cols;
-        float s = 0.f;
-        for (int h = 0; h < Hm; ++h) s = fmaf(ar[h * 12 + t], ar[h * 12 + u], s);
-        a.out[(size_t)(r0 + r) * 144 + i % 144] = s;
-    }
-}
+// pj_gram_rows(K, cols), pj_gram(a, bx, scr, nt): poolgen_dev.h
 
 // dpool[k, c] += sum_rr emb[rr % R, k] * dW[rr, c]   (rr < R*nsplit: wgrad's K-splits are summed here)
 // on fp32 MFMA 16x16x4:  D[i = k][j] += A[i][kk] B[kk][j],  A = emb[row][k],  B = dW[row][col];  lane (kk = l>>4, j = l&15).
@@ -356,11 +279,11 @@ __global__ __launch_bounds__(256, PJ_OCC) void pool_jobs_kernel(PJobs t, int fwd
     const int rel = blockIdx.x - a.blk0, bx = rel % a.nbx, by = rel / a.nbx;
     const bool v4 = ((a.cols | a.ldx) & 3) == 0;
     if (a.kind == PJ_FWD) {
-        if (v4 && fwd_mfma) pj_fwd_mfma(a, bx, by, fwd_mfma);
+        if (v4 && fwd_mfma) pj_fwd_mfma(a, bx, by, fwd_mfma, threadIdx.x);
         else if (v4) pj_fwd<4>(a, bx, by, fwd_rows, &fold[0][0][0]);
         else pj_fwd<1>(a, bx, by, fwd_rows, &fold[0][0][0]);
     }
-    else if (a.kind == PJ_GRAM) pj_gram(a, rel, &fold[0][0][0]);
+    else if (a.kind == PJ_GRAM) pj_gram(a, rel, &fold[0][0][0], 256);
     else if (a.kind == PJ_BWD_POOL) { if (v4) pj_bwd_pool<4>(a, bx, fold); else pj_bwd_pool<1>(a, bx, fold); }
     else { if (v4) pj_bwd_emb<4>(a, bx, by); else pj_bwd_emb<1>(a, bx, by); }
 }
@@ -400,6 +323,34 @@ static int pj_launch(PJobs& t, hipStream_t st) {
     if (nb == 0) return GPTST_OK;
     hipLaunchKernelGGL(pool_jobs_kernel, dim3(nb), dim3(256), 0, st, t, g_pg_rows, g_pg_mfma ? PG_MFMA_ROWS : 0);
     GPTST_CHECK_LAUNCH();
+    return GPTST_OK;
+}
+
+// Table of forward (MFMA form) and temporal-graph jobs for a launch that embeds them (masksel.hip, gptst_mask_u24_fwd_jobs): forward jobs first, numbered in
+// 256-thread blocks (*nvb of them), then the kind-3 jobs, numbered in whole workgroups (*ngw); *nf = number of forward jobs.  GPTST_ESHAPE when a job needs
+// another form / the table does not hold them (the caller then runs gptst_pool_jobs).
+GPTST_INTERNAL int gptst_pj_embed_table(PJobs* t, int njobs, const int* kind, const void* const* emb, const void* const* pool, const void* const* out,
+                                        const int* R, const int* K, const int* cols, int* nf, int* nvb, int* ngw) {
+    if (njobs > PJ_MAX || !g_pg_mfma) return GPTST_ESHAPE;
+    t->n = 0;
+    *nf = *nvb = *ngw = 0;
+    for (int pass = 0; pass < 2; ++pass) {
+        for (int p = 0; p < njobs; ++p) {
+            const int kd = kind ? kind[p] : (int)PJ_FWD;
+            if (kd != PJ_FWD && kd != PJ_GRAM) return GPTST_ESHAPE;
+            if ((kd == PJ_GRAM) != (pass == 1)) continue;
+            PJob j{(const float*)emb[p], nullptr, (const float*)pool[p], (float*)out[p], R[p], K[p], cols[p], 1, 0, kd, 0, cols[p]};
+            if (!j.emb || !j.pool || !j.out || j.R <= 0 || j.K <= 0 || j.K > PG_MAXK || j.cols <= 0) return GPTST_EARG;
+            if (kd == PJ_FWD) {
+                if (j.cols & 3) return GPTST_ESHAPE;
+                j.blk0 = *nvb; *nvb += pj_blocks(j); ++*nf;
+            } else {
+                if (j.cols % 12 || pj_gram_rows(j.K, j.cols) <= 0) return GPTST_EARG;
+                j.blk0 = *ngw; *ngw += pj_blocks(j);
+            }
+            t->j[t->n++] = j;
+        }
+    }
     return GPTST_OK;
 }
 

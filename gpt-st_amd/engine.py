@@ -447,8 +447,10 @@ def _sthcn_names(pfx):
     return [pfx + "hyperTem%d." % i for i in (1, 2, 3, 4)], [pfx + "cap1.", pfx + "cap2."]
 
 
-def _sthcn_gen_jobs(p, pfx, emb, jobs, A_all, dims, G_all=None):
-    """Queue the generated-parameter problems of one STHCN (20 jobs); -> gen dict (tensors are filled by jobs.launch())."""
+def _sthcn_gen_jobs(p, pfx, emb, jobs, A_all, dims, G_all=None, gjobs=None):
+    """Queue the generated-parameter problems of one STHCN (20 jobs); -> gen dict (tensors are filled by jobs.launch()).  gjobs: the table the
+    temporal-graph jobs go to (default: jobs)."""
+    gjobs = jobs if gjobs is None else gjobs
     B, T, N, C = dims
     time_eb, teb, tes = emb
     ne, nes = p[pfx + "node_embeddings"], p[pfx + "node_embeddings_spg"]
@@ -460,7 +462,7 @@ def _sthcn_gen_jobs(p, pfx, emb, jobs, A_all, dims, G_all=None):
     for i, h in enumerate(hts):
         jobs.fwd(ne, p[h + "adj"].view(d, Hm * T), out=A_all[i])                                          # :156
         if G_all is not None:
-            jobs.gram(ne, p[h + "adj"].view(d, Hm * T), out=G_all[i], A=A_all[i])                         # :156-158 G_n = A_n^T A_n, same launch
+            gjobs.gram(ne, p[h + "adj"].view(d, Hm * T), out=G_all[i], A=A_all[i])                        # :156-158 G_n = A_n^T A_n, same launch
     Wb = [jobs.fwd(time_eb, t) for h in hts for t in (p[h + "weights_pool"], p[h + "bias_pool"])]         # :160-161
     Wn = [jobs.fwd(nes, t) for c in cps for t in (p[c + "weights_spa"], p[c + "bias_spa"])]               # :137-138
     dadj = [jobs.fwd(teb, p[c + "adj"].view(ds, HS * N)) for c in cps]                                    # :104
@@ -468,10 +470,13 @@ def _sthcn_gen_jobs(p, pfx, emb, jobs, A_all, dims, G_all=None):
     return dict(emb=emb, gen=(A_all, hts, cps, d, Hm, ds, HS, HT), Wb=Wb, Wn=Wn, dadj=dadj, dyn=dyn)
 
 
-def gen_all(p, tidx, dims, which=(ENC, DEC), guide=True):
+def gen_all(p, tidx, dims, which=(ENC, DEC), guide=True, defer=False):
     """Everything of a step that depends only on the time index and the parameters — the seven time embeddings (:256-261, :337)
     and every generated parameter of both STHCNs and of the guide MLP — in THREE launches (one time-feature job table, one
-    poolgen job table, one gram) instead of 23.  -> {prefix: gen dict, "guide": (t4m, Wspa, bspa, Wtem, btem)}"""
+    poolgen job table, one gram) instead of 23.  -> {prefix: gen dict, "guide": (t4m, Wspa, bspa, Wtem, btem)}
+    defer (r05): only the guide's parameters are generated here; the jobs of the STHCNs (parameters and temporal graphs) come back unlaunched as
+    res["pending"] (a PoolJobs) — the stepper hands them to the mask generation, whose cooperative launch runs them on the CUs it leaves idle
+    (ops.mask_random / mask_adaptive jobs=); nothing before the mask reads their outputs."""
     B, T, N, C = dims
     tfj = []
     for pfx in which:
@@ -481,10 +486,11 @@ def gen_all(p, tidx, dims, which=(ENC, DEC), guide=True):
         tfj.append(_tf_job(p, GUIDE_TF, tidx))
     embs = ops.timefeat_jobs_fwd(tfj, tidx)
     jobs = ops.PoolJobs()
+    now = ops.PoolJobs() if defer else jobs
     res = {}
     L = 4 * len(which)
     if guide:
-        gj = jobs
+        gj = now
         m = "encoder.MLP_RL."
         t4m = embs[-1]
         res["guide"] = (t4m, gj.fwd(p["encoder.neb4mask"], p[m + "weights_pool_spa"]), gj.fwd(p["encoder.neb4mask"], p[m + "bias_pool_spa"]),
@@ -499,6 +505,10 @@ def gen_all(p, tidx, dims, which=(ENC, DEC), guide=True):
             res[pfx]["slot"] = (k, len(which))
             res[pfx]["G_all"] = G_all[4 * k:4 * k + 4]
 
+    if defer:                                            # (a temporal graph beyond the job kernel's shapes: jobs.post — the table then launches on its own)
+        now.launch()
+        res["pending"] = jobs
+        return res
     jobs.launch()                                        # generated parameters AND the temporal graphs: one launch
     return res
 

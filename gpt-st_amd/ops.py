@@ -733,11 +733,30 @@ def mask_ws_floats():
     return _C.lib().value("gptst_mask_ws_bytes") // 4
 
 
-def mask_random(noise, k, ws=None, u24=False):
+def _fused_jobs(jobs, u24):
+    """-> the column lists of a PoolJobs table that may ride in the mask launch (gptst_mask_u24_fwd_jobs: forward and temporal-graph jobs), or None after launching
+    it on its own"""
+    if jobs is None or not (jobs.jobs or jobs.post):
+        return None
+    if not u24 or jobs.post or any(j[0] not in (PoolJobs.FWD, PoolJobs.GRAM) for j in jobs.jobs):
+        jobs.launch()
+        return None
+    js, jobs.jobs = jobs.jobs, []
+    col = lambda i: [j[i] for j in js]      # noqa: E731
+    return js, (len(js), _ints(col(0)), _ptrs0(col(1)), _ptrs0(col(3)), _ptrs0(col(4)), _ints(col(5)), _ints(col(6)), _ints(col(7)))
+
+
+def mask_random(noise, k, ws=None, u24=False, jobs=None):
     """u24: every noise value is k * 2^-24 (Philox / torch.rand) — the select runs on the integers with two digit passes instead of three
-    (checked on the device: NaN mask otherwise)."""
+    (checked on the device: NaN mask otherwise).  jobs: a PoolJobs table of forward jobs, independent of the mask, launched here — inside the mask's
+    launch when that is the cooperative one (r05)."""
     _chk(noise)
     mask = torch.empty_like(noise)
+    fj = _fused_jobs(jobs, u24)
+    if fj is not None:
+        _call("gptst_mask_u24_fwd_jobs", 0, None, None, None, None, _p(noise), None, 0, noise.numel(), 0, 1, int(k), None, None, _p(mask),
+              _p(ws if ws is not None else _mask_ws(noise.device)), int(ws is not None), *fj[1])
+        return mask
     _call("gptst_mask_random_u24" if u24 else "gptst_mask_random", _p(noise), noise.numel(), int(k), _p(mask),
           _p(ws if ws is not None else _mask_ws(noise.device)), int(ws is not None))
     return mask
@@ -762,12 +781,17 @@ def mask_labels(prob):
     return label, counts
 
 
-def mask_adaptive(label, counts, list_c, nums, noise_a, noise_r, ada_all, base, ws=None, u24=False):
-    """-> (m_ada (M), m_rnd (M), mask (M*base)) fp32 {0,1}.  ws: see mask_ws_floats().  u24: lattice noise, see mask_random."""
+def mask_adaptive(label, counts, list_c, nums, noise_a, noise_r, ada_all, base, ws=None, u24=False, jobs=None):
+    """-> (m_ada (M), m_rnd (M), mask (M*base)) fp32 {0,1}.  ws: see mask_ws_floats().  u24: lattice noise, jobs: see mask_random."""
     M, HS = label.numel(), list_c.numel()
     m_ada = torch.empty(M, device=label.device, dtype=torch.float32)
     m_rnd = torch.empty_like(m_ada)
     mask = torch.empty(M * base, device=label.device, dtype=torch.float32)
+    fj = _fused_jobs(jobs, u24)
+    if fj is not None:
+        _call("gptst_mask_u24_fwd_jobs", 1, _p(label), _p(counts), _p(list_c), _p(nums), _p(noise_a), _p(noise_r), int(ada_all), M, HS, base, 0,
+              _p(m_ada), _p(m_rnd), _p(mask), _p(ws if ws is not None else _mask_ws(label.device)), int(ws is not None), *fj[1])
+        return m_ada, m_rnd, mask
     _call("gptst_mask_adaptive_u24" if u24 else "gptst_mask_adaptive", _p(label), _p(counts), _p(list_c), _p(nums), _p(noise_a), _p(noise_r),
           int(ada_all), M, HS, base, _p(m_ada), _p(m_rnd), _p(mask), _p(ws if ws is not None else _mask_ws(label.device)), int(ws is not None))
     return m_ada, m_rnd, mask

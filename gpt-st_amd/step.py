@@ -16,6 +16,7 @@ from . import engine, ops
 # mask generation on the 24-bit noise lattice (gptst_mask_*_u24, r04): the step's Philox noise and torch.rand fixtures are k * 2^-24, so the radix
 # select takes two 12-bit digits on the integers instead of three float-bit digits: 6 launches instead of 8 in the adaptive phase.  (The whole
 # generation as ONE single-workgroup launch was measured too: ~120 us against ~45 us at 65 280 cells — one CU's bandwidth; it serves <= 8192 cells.)
+DEFER_GEN = os.environ.get("GPTST_DEFER_GEN", "1") == "1"      # the STHCNs' parameter generation inside the cooperative mask launch (r05)
 U24 = os.environ.get("GPTST_MASK_U24", "1") == "1"
 
 
@@ -151,7 +152,8 @@ class PretrainStep:
         # the guide classifier (GPTST.py:325-332) feeds the adaptive mask and the KL term only: the random-mask phase of the FUSED step neither
         # generates its parameters nor runs it (the reference computes and discards the logits there; GPTST_Model.forward still returns them)
         need_guide = phase == 1 or self.always_guide
-        gen = engine.gen_all(p, tidx, dims, guide=need_guide)   # time embeddings + every generated parameter: 3 launches
+        # time embeddings + every generated parameter: 3 launches; r05: the STHCNs' forward jobs wait for the mask's launch (_part2_impl)
+        gen = engine.gen_all(p, tidx, dims, guide=need_guide, defer=DEFER_GEN)
         red = engine.Reductions()
         self._dec_reduced = False
         if self.dp_overlap and self._dp_in_graph():
@@ -175,17 +177,20 @@ class PretrainStep:
         M = self.B * self.T * self.N
         src, tidx, gen, red, prob, sv_g = self.src, ctx["tidx"], ctx["gen"], ctx["red"], ctx["prob"], ctx["sv_g"]
         engine.CTX.ARENA = self.arena
+        pend = gen.pop("pending", None)        # the STHCNs' generated-parameter jobs: inside the mask's launch where that is the cooperative one
         if self.gmask:
-            mask = self._global_mask(phase)
+            mask = self._global_mask(phase, jobs=pend)
         else:
             if self.force_mask:
                 mask = self.mask_buf
             elif phase == 0:
-                mask = ops.mask_random(self.noise, int(M * base * a.mask_ratio), ws=self._mask_ws(), u24=U24)       # Philox / torch.rand noise: k * 2^-24
+                mask = ops.mask_random(self.noise, int(M * base * a.mask_ratio), ws=self._mask_ws(), u24=U24, jobs=pend)       # Philox / torch.rand noise: k * 2^-24
             else:
                 label, counts = ops.labels_and_counts(prob, sv_g[4])
                 mask = ops.mask_adaptive(label, counts, self.ctrl[:self.HS], self.ctrl[self.HS:], self.noise_a, self.noise_r,
-                                         a.ada_type == "all", base, ws=self._mask_ws(), u24=U24)[2]
+                                         a.ada_type == "all", base, ws=self._mask_ws(), u24=U24, jobs=pend)[2]
+        if pend is not None:
+            pend.launch()                      # (forced mask: nothing carried them; a no-op after a mask call)
         self.last_mask = mask
         dec_head = None
         lowrank = self.fused_tails and engine.chain_ok(dims)      # the backward below is the dPre chain: the low-rank first layer may run
@@ -236,17 +241,17 @@ class PretrainStep:
         """The selections' histogram scratch comes zeroed out of the step's arena (cleared by the step's first launch): no zeroing launch."""
         return self.arena.zeros(ops.mask_ws_floats())
 
-    def _global_mask(self, phase):
+    def _global_mask(self, phase, jobs=None):
         """Mask of this rank's rows cut out of the selection over the global batch (identical on every rank)."""
         a, base, M = self.args, self.base, self.B * self.T * self.N
         Mg = M * self.W
         if self.force_mask:
             return self.mask_buf
         if phase == 0:
-            mask_g = ops.mask_random(self.noise_g, int(Mg * base * a.mask_ratio), ws=self._mask_ws(), u24=U24)
+            mask_g = ops.mask_random(self.noise_g, int(Mg * base * a.mask_ratio), ws=self._mask_ws(), u24=U24, jobs=jobs)
         else:                                              # label_g was gathered by _exchange_labels(); class histogram taken inside
             mask_g = ops.mask_adaptive(self.label_g, None, self.ctrl[:self.HS], self.ctrl[self.HS:], self.noise_a_g,
-                                       self.noise_r_g, a.ada_type == "all", base, ws=self._mask_ws(), u24=U24)[2]
+                                       self.noise_r_g, a.ada_type == "all", base, ws=self._mask_ws(), u24=U24, jobs=jobs)[2]
         self.last_mask_global = mask_g
         return self.dp.rows_of(mask_g, M * base)
 

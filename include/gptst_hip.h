@@ -26,7 +26,7 @@ extern "C" {
 #pragma GCC visibility push(default)
 #endif
 
-#define GPTST_ABI_VERSION 12  /* 12 (r05, late): + gptst_mask_cooperative (gptst_mask_*_u24 with 8192 < M <= 65536 cells and a workspace: ONE cooperative launch); 11 (r05): + gptst_cap_cross_route_lin_bwd, gptst_comm_available, gptst_handoff_reset, gptst_set_handoff_guard (gptst_clip_adam: stats_out[5] = expiries on record); - gptst_cap_rec_cross_route_bwd (three-role form, measured slower); 9, 10 (r04, late): + gptst_hypertem_bwd_pair, gptst_cap_rec_cross_route_bwd, gptst_mask_*_u24, gptst_pool_jobs_gram_rows, gptst_handoff_timeouts; gptst_fusion_gate_fwd/bwd */
+#define GPTST_ABI_VERSION 13  /* 13 (r05, late): + gptst_mask_u24_fwd_jobs (forward generation jobs inside the cooperative mask launch); 12 (r05, late): + gptst_mask_cooperative (gptst_mask_*_u24 with 8192 < M <= 65536 cells and a workspace: ONE cooperative launch); 11 (r05): + gptst_cap_cross_route_lin_bwd, gptst_comm_available, gptst_handoff_reset, gptst_set_handoff_guard (gptst_clip_adam: stats_out[5] = expiries on record); - gptst_cap_rec_cross_route_bwd (three-role form, measured slower); 9, 10 (r04, late): + gptst_hypertem_bwd_pair, gptst_cap_rec_cross_route_bwd, gptst_mask_*_u24, gptst_pool_jobs_gram_rows, gptst_handoff_timeouts; gptst_fusion_gate_fwd/bwd */
 int gptst_abi_version(void);
 /* 1: bit-reproducible steps — the two reductions that end in float atomics by default (embedding gradients of gptst_pool_jobs kind 2,
  * weight gradients of gptst_timefeat_jobs) run as single-owner kernels with a fixed summation order (slower).  Everything else is
@@ -337,6 +337,16 @@ int gptst_mask_adaptive(const int* label, const int* counts, const int* list_c, 
 int gptst_mask_random_u24(const float* noise, int M, int k, float* mask, void* ws, int ws_zeroed, void* stream);
 int gptst_mask_adaptive_u24(const int* label, const int* counts, const int* list_c, const int* nums, const float* noise_a, const float* noise_r,
                             int ada_all, int M, int HS, int base, float* m_ada, float* m_rnd, float* mask, void* ws, int ws_zeroed, void* stream);
+/* r05 — gptst_pool_jobs with njobs generation jobs (kind[j] 0: out_j (R_j, cols_j) = emb_j (R_j, K_j) @ pool_j (K_j, cols_j), or 3: the temporal graphs of
+ * gptst_pool_jobs; kind NULL: all 0; no gradient kinds) followed by gptst_mask_random_u24
+ * (adaptive == 0: noise_a is the noise, k the number of cells to drop) or gptst_mask_adaptive_u24 (adaptive != 0; k unused) — in ONE launch when the mask
+ * takes the cooperative form (gptst_mask_cooperative, 8192 < M <= 65536, ws given) and every forward job has cols % 4 == 0: the 64 mask workgroups are
+ * latency-bound on 64 CUs, the jobs are write-bound on all of them, and neither depends on the other (the steppers: the generated parameters of the
+ * two STHCNs next to the mask that the guide's output selects).  Otherwise exactly those two calls.  Same results bit for bit either way. */
+int gptst_mask_u24_fwd_jobs(int adaptive, const int* label, const int* counts, const int* list_c, const int* nums, const float* noise_a,
+                            const float* noise_r, int ada_all, int M, int HS, int base, int k, float* m_ada, float* m_rnd, float* mask, void* ws,
+                            int ws_zeroed, int njobs, const int* kind, const void* const* emb, const void* const* pool, const void* const* out,
+                            const int* R, const int* K, const int* cols, void* stream);
 
 /* ---- thin projections (small.hip) ------------------------------------------------------------------------
  * lin_in: Y[i,:] = sum_j a'[i,j] W(:,j) + b, a' = mask ? (mask[i,j] ? a[i*lda+j] : fill) : a;  wlayout 0: W[c*J+j], 1: W[j*C+c].

@@ -283,6 +283,14 @@ def test_mask_random_bit_exact(M, ratio, seed):
         assert torch.equal(got.cpu().to(torch.int64), ref), ("u24", path)
 
 
+def _handoff_timeouts():
+    import ctypes
+    from gptst_amd import _C
+    n = ctypes.c_int(0)
+    _C.lib().call("gptst_handoff_timeouts", ctypes.byref(n))
+    return n.value
+
+
 class _mask_path:
     """mask generation path: 0 by size (lattice noise: one workgroup <= 8192 cells, the cooperative launch <= 65536, else multi-launch),
     1 multi-launch, 2 one workgroup at every size it covers, 3 as 0 without the cooperative launch"""
@@ -388,6 +396,59 @@ def test_mask_adaptive_bit_exact(ada_all, B, N, HS, frac):
                                                ada_all, base, u24=True)
         assert torch.equal(m_ada.cpu().long(), m_ada_r) and torch.equal(m_rnd.cpu().long(), m_rnd_r), ("u24", path)
         assert torch.equal(mask.cpu().long().view(M, base), fin_r.view(M, 1).repeat(1, base)), ("u24", path)
+
+
+@pytest.mark.parametrize("adaptive", [0, 1])
+@pytest.mark.parametrize("coop", [1, 0])
+def test_mask_launch_carries_forward_jobs(adaptive, coop):
+    """gptst_mask_u24_fwd_jobs (r05): a table of forward generation jobs rides in the cooperative mask launch (coop = 0: the same call falls back to
+    gptst_pool_jobs + the multi-launch mask).  Masks and job outputs are bit-identical to the separate calls; a job table that is not forward-only or
+    not float4-shaped goes its own way."""
+    from gptst_amd import ops, synth
+    dev = _dev()
+    B, T, N, HS, base = 32, 12, 170, 10, 1
+    M = B * T * N
+    g = torch.Generator().manual_seed(5)
+    label = torch.randint(0, HS, (M,), generator=g).to(torch.int32).to(dev)
+    list_c = torch.tensor(synth.class_order(HS, 2), dtype=torch.int32, device=dev)
+    total = int(M * 0.25)
+    nums = torch.tensor([total // 2, total - total // 2], dtype=torch.int32, device=dev)
+    na, nr = synth.make_noise(M, 31).to(dev), synth.make_noise(M, 32).to(dev)
+    shapes = [(384, 10, 4096), (384, 10, 64), (170, 10, 16 * 12), (170, 5, 4096), (32, 8, 36 * 12), (384, 10, 1700), (33, 3, 8)]
+    embs = [torch.randn(R, K, generator=g).to(dev) for R, K, _ in shapes]
+    pools = [torch.randn(K, c, generator=g).to(dev) for _, K, c in shapes]
+
+    def table(extra=()):
+        pj = ops.PoolJobs()
+        outs = [pj.fwd(e, p_) for e, p_ in zip(embs, pools)]
+        for k in (2, 4):                                   # temporal graphs (kind 3: whole workgroups of the launch) of the two cols % 12 == 0 shapes
+            outs.append(pj.gram(embs[k], pools[k], torch.empty(shapes[k][0], 12, 12, device=dev)))
+        for e, p_ in extra:
+            outs.append(pj.fwd(e, p_))
+        return pj, outs
+
+    pj, ref_out = table()
+    pj.launch()
+    with _mask_path(0 if coop else 3):
+        ref_mask = (ops.mask_adaptive(label, None, list_c, nums, na, nr, 1, base, u24=True) if adaptive else (ops.mask_random(na, total, u24=True),))
+        for rep in range(3):
+            pj, outs = table()
+            got = (ops.mask_adaptive(label, None, list_c, nums, na, nr, 1, base, u24=True, jobs=pj) if adaptive
+                   else (ops.mask_random(na, total, u24=True, jobs=pj),))
+            assert not pj.jobs
+            for a, b in zip(got, ref_mask):
+                assert torch.equal(a, b), rep
+            for k, (a, b) in enumerate(zip(outs, ref_out)):
+                assert torch.equal(a, b), (rep, k)
+        # a scalar-column job (cols % 4 != 0) sends the table down gptst_pool_jobs; results unchanged
+        e7, p7 = torch.randn(50, 4, generator=g).to(dev), torch.randn(4, 2070, generator=g).to(dev)
+        pj, outs = table(extra=[(e7, p7)])
+        got = ops.mask_random(na, total, u24=True, jobs=pj)
+        assert torch.equal(got, ref_mask[-1]) if not adaptive else True
+        assert torch.allclose(outs[-1], e7 @ p7, rtol=1e-5, atol=1e-5)
+        for a, b in zip(outs[:-1], ref_out):
+            assert torch.equal(a, b)
+    assert _handoff_timeouts() == 0
 
 
 @pytest.mark.parametrize("ada_all", [1, 0])
