@@ -654,9 +654,17 @@ struct HtChain {
 
 // NSTAGE is compile-time (the run-time form — one kernel, stage loop over ch.nstage — spilled 250-400 registers: the allocator saw
 // the fragments of every path live around the loop)
+// HTC_NW waves per workgroup share the 12 time steps: 4 (three steps per wave, two waves per SIMD at the LDS-imposed two workgroups per CU).  r05 experiment,
+// -DHTC_NW=6: two steps per wave, 12 waves per CU = three waves per SIMD within 168 VGPRs (15 spilled address registers outside the loops) — the resident-wave
+// lever of VERDICT r04 item 2 without any exchange between workgroups — measured 876 -> 849 steps/s (profiles/r05_ab_chain_six_waves.txt): not adopted.
+#ifndef HTC_NW
+#define HTC_NW 4
+#endif
 template <int NSTAGE>
-__global__ __launch_bounds__(256, HT_OCC) void hypertem_chain_fwd_kernel(HtChain ch, int N, int B) {
-    constexpr int C = 64, P = C + 4, GP = 145, NT = 16;
+__global__ __launch_bounds__(64 * HTC_NW, HTC_NW == 6 ? 3 : HT_OCC) void hypertem_chain_fwd_kernel(HtChain ch, int N, int B) {
+    constexpr int C = 64, P = C + 4, GP = 145, NT = 16, NW = HTC_NW, NTH = 64 * NW, TPW = HT_T / NW;      // TPW time steps per wave
+    static_assert(HT_T % NW == 0 && (HT_T * NT * (C / 4)) % NTH == 0 && (NT * 144) % NTH == 0, "waves must divide the steps and the staging loops");
+    constexpr int GK = NT * 144 / NTH, XK = HT_T * NT * (C / 4) / NTH;                                     // staging trips per thread
     extern __shared__ __attribute__((aligned(16))) float smem[];
     float* Xs = smem;                               // [12][NT][P]
     float* Gs = Xs + HT_T * NT * P;                 // [NT][GP]
@@ -665,10 +673,10 @@ __global__ __launch_bounds__(256, HT_OCC) void hypertem_chain_fwd_kernel(HtChain
     const int n0 = tile * NT;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int j = lane & 15, kk = lane >> 4;
-    float gv[9];
-#define HTC_LOAD_G(Gp) _Pragma("unroll") for (int k = 0; k < 9; ++k) gv[k] = (Gp)[min(n0 * 144 + tid + k * 256, N * 144 - 1)]
-#define HTC_STORE_G() _Pragma("unroll") for (int k = 0; k < 9; ++k) { const int i = tid + k * 256; \
-        if (i < NT * 144) Gs[(i / 144) * GP + i % 144] = (n0 + i / 144 < N) ? gv[k] : 0.f; }
+    float gv[GK];
+#define HTC_LOAD_G(Gp) _Pragma("unroll") for (int k = 0; k < GK; ++k) gv[k] = (Gp)[min(n0 * 144 + tid + k * NTH, N * 144 - 1)]
+#define HTC_STORE_G() _Pragma("unroll") for (int k = 0; k < GK; ++k) { const int i = tid + k * NTH; \
+        Gs[(i / 144) * GP + i % 144] = (n0 + i / 144 < N) ? gv[k] : 0.f; }
     float4 bv[C / 16][4];
     float4 b4;
 #define HTC_LOAD_W(W0, b0, tt) do {                                                                                \
@@ -680,14 +688,19 @@ __global__ __launch_bounds__(256, HT_OCC) void hypertem_chain_fwd_kernel(HtChain
 
     {
         // ---- slab + graph staging: ALL global loads before the first LDS store (as hypertem_fwd_kernel) ----
-        const int nl = tid >> 4, c4 = tid & 15;
-        const int n = min(n0 + nl, N - 1);
-        float4 v[HT_T];
+        // trip k of thread tid: float4 i = tid + k * NTH of the (12, NT, 16) slab -> (time step i / 256, row (i % 256) / 16, column i % 16)
+        float4 v[XK];
 #pragma unroll
-        for (int t = 0; t < HT_T; ++t) v[t] = ld4(ch.X + (((size_t)b * HT_T + t) * N + n) * C + 4 * c4);
+        for (int k = 0; k < XK; ++k) {
+            const int i = tid + k * NTH, t = i >> 8, nl = (i & 255) >> 4, c4 = i & 15;
+            v[k] = ld4(ch.X + (((size_t)b * HT_T + t) * N + min(n0 + nl, N - 1)) * C + 4 * c4);
+        }
         HTC_LOAD_G(ch.st[0].G);
 #pragma unroll
-        for (int t = 0; t < HT_T; ++t) st4(Xs + (t * NT + nl) * P + 4 * c4, n0 + nl < N ? v[t] : f4zero());
+        for (int k = 0; k < XK; ++k) {
+            const int i = tid + k * NTH, t = i >> 8, nl = (i & 255) >> 4, c4 = i & 15;
+            st4(Xs + (t * NT + nl) * P + 4 * c4, n0 + nl < N ? v[k] : f4zero());
+        }
         HTC_STORE_G();
     }
     // W_bt fragments are never live across the mix phase of a non-final layer (64 registers on top of the three kept mixes): every layer
@@ -702,7 +715,7 @@ __global__ __launch_bounds__(256, HT_OCC) void hypertem_chain_fwd_kernel(HtChain
         if (s + 1 < NSTAGE) {
             // ---- a layer whose output is the next layer's slab: all mixes first (they read every time step of the slab), then — behind a
             //      barrier — MFMA + epilogue, writing the output rows IN PLACE (time step t of the slab is only touched by its own wave now) ----
-            float4 a4a[C / 16], a4b[C / 16], a4c[C / 16];          // three named arrays: an [3][4] array indexed by the rolled loop below went to scratch
+            float4 a4a[C / 16], a4b[C / 16], a4c[C / 16];          // named arrays: an [3][4] array indexed by the rolled loop below went to scratch (a4c: TPW = 3 only)
 #pragma unroll
             for (int q = 0; q < C / 16; ++q) { a4a[q] = f4zero(); a4b[q] = f4zero(); a4c[q] = f4zero(); }
             {   // the three mixes of this wave share every slab operand: each X_u row piece is read ONCE and feeds the three time steps
@@ -713,14 +726,14 @@ __global__ __launch_bounds__(256, HT_OCC) void hypertem_chain_fwd_kernel(HtChain
                     float4 x[C / 16];
 #pragma unroll
                     for (int q = 0; q < C / 16; ++q) x[q] = ld4(xr + u * NT * P + 16 * q);
-                    const float g0 = gr[u], g1 = gr[4 * HT_T + u], g2 = gr[8 * HT_T + u];
+                    const float g0 = gr[u], g1 = gr[NW * HT_T + u], g2 = TPW == 3 ? gr[2 * NW * HT_T + u] : 0.f;
 #pragma unroll
                     for (int q = 0; q < C / 16; ++q) {
                         a4a[q] = f4fma(g0, x[q], a4a[q]);
                         a4b[q] = f4fma(g1, x[q], a4b[q]);
-                        a4c[q] = f4fma(g2, x[q], a4c[q]);
+                        if (TPW == 3) a4c[q] = f4fma(g2, x[q], a4c[q]);
                     }
-                    if (u % 3 == 2) SB();                      // at most three time steps' operands (48 registers) in flight
+                    if (TPW == 3 ? u % 3 == 2 : u % 2 == 1) SB();   // at most three (two) time steps' operands (48 / 32 registers) in flight
                 }
             }
             HTC_LOAD_W(S.Wbt, S.bbt, wave);
@@ -728,8 +741,8 @@ __global__ __launch_bounds__(256, HT_OCC) void hypertem_chain_fwd_kernel(HtChain
             __syncthreads();
             SB();
 #pragma nounroll
-            for (int ti = 0; ti < 3; ++ti) {                       // rolled: unrolled, the addresses of all three steps' stores / loads were live at once
-                const int t = wave + 4 * ti;
+            for (int ti = 0; ti < TPW; ++ti) {                     // rolled: unrolled, the addresses of all three steps' stores / loads were live at once
+                const int t = wave + NW * ti;
                 const size_t g = (size_t)b * HT_T + t;
                 float4 m4[C / 16];                                 // this step's mix; the kept ones rotate down (register moves: a select by ti
 #pragma unroll                                                     //  turned the three arrays into one scratch array)
@@ -750,7 +763,7 @@ __global__ __launch_bounds__(256, HT_OCC) void hypertem_chain_fwd_kernel(HtChain
                 }
                 SB();
                 const float4 bias = b4;
-                if (ti < 2) HTC_LOAD_W(S.Wbt, S.bbt, t + 4);
+                if (ti < TPW - 1) HTC_LOAD_W(S.Wbt, S.bbt, t + NW);
                 SB();
                 if (S.R_out != nullptr && n0 + j < N) {
 #pragma unroll
@@ -774,7 +787,7 @@ __global__ __launch_bounds__(256, HT_OCC) void hypertem_chain_fwd_kernel(HtChain
         } else {
             // ---- last layer of the chain: per time step mix -> MFMA -> epilogue, as hypertem_fwd_kernel ----
             HTC_LOAD_W(S.Wbt, S.bbt, wave);
-            for (int t = wave; t < HT_T; t += 4) {
+            for (int t = wave; t < HT_T; t += NW) {
                 const size_t g = (size_t)b * HT_T + t;
                 SB();
                 float4 a4[C / 16];
@@ -807,7 +820,7 @@ __global__ __launch_bounds__(256, HT_OCC) void hypertem_chain_fwd_kernel(HtChain
                 }
                 SB();
                 const float4 bias = b4;
-                if (t + 4 < HT_T) HTC_LOAD_W(S.Wbt, S.bbt, t + 4);
+                if (t + NW < HT_T) HTC_LOAD_W(S.Wbt, S.bbt, t + NW);
                 SB();
                 if (S.R_out != nullptr && n0 + j < N) {
 #pragma unroll
@@ -850,7 +863,7 @@ extern "C" int gptst_hypertem_chain_fwd(const float* X, int nstage, const void* 
 #define HTC_LAUNCH(NS_) do {                                                                                                          \
         static int done_ = 0;                                                                                                          \
         if (!done_) { (void)hipFuncSetAttribute((const void*)hypertem_chain_fwd_kernel<NS_>, hipFuncAttributeMaxDynamicSharedMemorySize, smem); done_ = 1; } \
-        hipLaunchKernelGGL((hypertem_chain_fwd_kernel<NS_>), grid, dim3(256), smem, st, ch, N, B);                                     \
+        hipLaunchKernelGGL((hypertem_chain_fwd_kernel<NS_>), grid, dim3(64 * HTC_NW), smem, st, ch, N, B);                                     \
     } while (0)
     if (nstage == 1) HTC_LAUNCH(1); else if (nstage == 2) HTC_LAUNCH(2); else HTC_LAUNCH(3);
 #undef HTC_LAUNCH
