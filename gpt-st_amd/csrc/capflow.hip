@@ -174,15 +174,20 @@ __global__ __launch_bounds__(256) void cf_squash_kernel(const float* __restrict_
 //   L = V ? rows . V^T : 0;   b = L + (bl_in ? bl_in : 0);   bl_out <- b (if given)
 //   cs = c_in ? c_in : softmax_h(b + (l0 ? l0 : 0));   c_out <- cs (if given);   part <- partial of cs^T . rows
 // routing iteration r >= 1:  (P, v, b -> b);   last step:  (P, v, b, l0 = dadj -> c);   backward of rec = c^T v:  (drec, v -> dc1 = bl_out; c_in = c -> dv)
+#ifndef CF_ROUTE_OCC
+#define CF_ROUTE_OCC 2      // 3 (168 VGPRs, 34 spilled at C = 128) measured slower: configs[4] 23.2 -> 22.9, N = 512 share 154.5 -> 151.0
+#endif
 template <int C, int NHT>
-__global__ __launch_bounds__(256, 2) void cf_route_kernel(const float* __restrict__ rows, const float* __restrict__ V,
+__global__ __launch_bounds__(256, (NHT == 1 ? CF_ROUTE_OCC : 2)) void cf_route_kernel(const float* __restrict__ rows, const float* __restrict__ V,
                                                                          const float* __restrict__ bl_in, float* __restrict__ bl_out,
                                                                          const float* __restrict__ l0, const float* __restrict__ c_in,
                                                                          float* __restrict__ c_out, float* __restrict__ part, int HS, int N,
                                                                          int nparts, int tpw) {
     constexpr int Q = C / 16, H2 = C / 64;
-    __shared__ float4 red[4][16][C / 4];
-    __shared__ __attribute__((aligned(16))) float rt[4][16][C + 4];    // per wave: the 16-row tile, to change operand layout
+    // per wave: the 16-row tile, to change operand layout; the end-of-kernel fold of the partials reuses the same LDS (r05: 66 -> 34 KB at C = 128, so that
+    // LDS no longer caps the kernel at two workgroups per CU; the register budget still does — CF_ROUTE_OCC = 3 spills, measured slower)
+    __shared__ __attribute__((aligned(16))) float rt[4][16][C + 4];
+    float4 (*red)[16][C / 4] = reinterpret_cast<float4 (*)[16][C / 4]>(&rt[0][0][0]);
     const int bt = blockIdx.y, chunk = blockIdx.x;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, j = lane & 15, kk = lane >> 4;
     const bool al = (N & 3) == 0;
@@ -281,6 +286,7 @@ __global__ __launch_bounds__(256, 2) void cf_route_kernel(const float* __restric
                     acc[ht][4 * hf + 3] = mfma4(cs[ht][r], a2[r][hf].w, acc[ht][4 * hf + 3]);
                 }
     }
+    __syncthreads();                                                  // every wave is done with its row tile: the fold takes the LDS over
     store_partial<C, NHT, 0>(red, acc, part + ((size_t)bt * nparts + chunk) * HS * C, HS, wave, j, kk);
 }
 
