@@ -1017,6 +1017,20 @@ __global__ __launch_bounds__(MC_T) void mc_mask_jobs_kernel(McArgs g, unsigned n
     mc_mask_body<ADAPTIVE>(g, nmask);
 }
 
+// The grid barriers need every mask workgroup resident at once: workgroups the device can hold = CUs x occupancy of the kernel (queried once per kernel;
+// a partitioned or CU-masked device simply takes the multi-launch path)
+template <typename K>
+static bool mc_fits(K kernel, int nwg) {
+    static int cap = -1;
+    if (cap < 0) {
+        int dev = 0, ncu = 0, per = 0;
+        if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess ||
+            hipOccupancyMaxActiveBlocksPerMultiprocessor(&per, (const void*)kernel, MC_T, 0) != hipSuccess) { ncu = 0; per = 0; }
+        cap = ncu * per;
+    }
+    return nwg <= cap;
+}
+
 int g_ms_coop = MS_COOP_DEFAULT;              // gptst_mask_cooperative(0): the multi-launch path instead of the cooperative launch (the steppers' fallback after a lost hand-off; A/B; tests)
 
 static int mu_prepare() {
@@ -1041,7 +1055,7 @@ extern "C" int gptst_mask_random_u24(const float* noise, int M, int k, float* ma
         GPTST_CHECK_LAUNCH();
         return GPTST_OK;
     }
-    if (g_ms_coop && g_ms_force_multi == 0 && ws && M <= MC_T * MC_MAXWG) {          // r05: one cooperative launch, a cell per thread
+    if (g_ms_coop && g_ms_force_multi == 0 && ws && M <= MC_T * MC_MAXWG && mc_fits(mc_mask_kernel<false>, (M + MC_T - 1) / MC_T)) {   // r05: one cooperative launch, a cell per thread
         if (!ws_zeroed) hipLaunchKernelGGL(ms_zero_kernel, dim3(24), dim3(256), 0, (hipStream_t)stream, (unsigned*)ws, MS_WS_WORDS);
         const McArgs g{nullptr, nullptr, nullptr, noise, nullptr, 0, M, 0, 1, k, nullptr, nullptr, mask, (unsigned*)ws};
         hipLaunchKernelGGL((mc_mask_kernel<false>), dim3((M + MC_T - 1) / MC_T), dim3(MC_T), 0, (hipStream_t)stream, g);
@@ -1062,7 +1076,7 @@ extern "C" int gptst_mask_adaptive_u24(const int* label, const int* counts, cons
         GPTST_CHECK_LAUNCH();
         return GPTST_OK;
     }
-    if (g_ms_coop && g_ms_force_multi == 0 && ws && M <= MC_T * MC_MAXWG) {          // r05: one cooperative launch (the class histogram is taken inside)
+    if (g_ms_coop && g_ms_force_multi == 0 && ws && M <= MC_T * MC_MAXWG && mc_fits(mc_mask_kernel<true>, (M + MC_T - 1) / MC_T)) {    // r05: one cooperative launch (the class histogram is taken inside)
         if (!ws_zeroed) hipLaunchKernelGGL(ms_zero_kernel, dim3(24), dim3(256), 0, (hipStream_t)stream, (unsigned*)ws, MS_WS_WORDS);
         const McArgs g{label, list_c, nums, noise_a, noise_r, ada_all, M, HS, base, 0, m_ada, m_rnd, mask, (unsigned*)ws};
         hipLaunchKernelGGL((mc_mask_kernel<true>), dim3((M + MC_T - 1) / MC_T), dim3(MC_T), 0, (hipStream_t)stream, g);
@@ -1090,7 +1104,8 @@ extern "C" int gptst_mask_u24_fwd_jobs(int adaptive, const int* label, const int
                  : (!noise_a || !mask || M <= 0 || k < 0 || k > M)) return GPTST_EARG;
     PJobs t;
     int nf = 0, nvb = 0, ngw = 0;
-    const bool coop = g_ms_coop && g_ms_force_multi == 0 && ws && M > MSS_MAXM && M <= MC_T * MC_MAXWG;
+    const bool coop = g_ms_coop && g_ms_force_multi == 0 && ws && M > MSS_MAXM && M <= MC_T * MC_MAXWG &&
+                      (adaptive ? mc_fits(mc_mask_jobs_kernel<true>, (M + MC_T - 1) / MC_T) : mc_fits(mc_mask_jobs_kernel<false>, (M + MC_T - 1) / MC_T));
     if (coop && njobs > 0 && gptst_pj_embed_table(&t, njobs, kind, emb, pool, out, R, K, cols, &nf, &nvb, &ngw) == GPTST_OK) {
         if (!ws_zeroed) hipLaunchKernelGGL(ms_zero_kernel, dim3(24), dim3(256), 0, (hipStream_t)stream, (unsigned*)ws, MS_WS_WORDS);
         const unsigned nmask = (unsigned)((M + MC_T - 1) / MC_T);
