@@ -801,11 +801,12 @@ __global__ __launch_bounds__(MU_T) void mu_mask_kernel(const int* __restrict__ l
 // of threshold-equal cells + one more barrier, only when a tie straddles the rank).
 // All workgroups are resident by construction (<= 64 workgroups of 16 waves on 256 CUs); the barrier wait is bounded like every in-launch wait
 // (gptst_wait_ge, 2 s): on expiry the outputs are NaN and the expiry is on record (gptst_handoff_timeouts; the optimiser's guard skips the step).
-// ws words (zeroed): [0, 16384) four histograms (selection s, digit d) | 16384 class counts (256) | 16640 tie counts (2 x 64) | 16768 barrier | 16769 bad
+// ws words (zeroed): [0, 16384) four histograms (selection s, digit d) | 16384 class counts (256) | 16768 barrier | 16769 bad | 16800 tie counts (2 x MC_MAXWG)
 // ======================================================================================================================
 GPTST_HANDOFF_COUNTER(masksel)
 #define MC_T 1024
-#define MC_MAXWG 64
+#define MC_MAXWG 128     // 131072 cells (METR_LA / NYC_TAXI at B = 32 too)
+static_assert(16800 + 2 * MC_MAXWG <= MS_WS_WORDS, "tie counts beyond the mask workspace");
 struct McShared {
     unsigned hist[MU_BINS];
     unsigned wsum[MC_T / 64 + 1];
@@ -895,7 +896,7 @@ __device__ __forceinline__ bool mc_select(unsigned key, bool valid, int k, unsig
     // a tie straddles rank k: threshold-equal cells take the `need` slots in CELL-INDEX order = (workgroup, thread) order
     unsigned total;
     const unsigned before = mc_scan(eq ? 1u : 0u, sh, total);
-    unsigned* ec = ws + 16640 + 64 * s;
+    unsigned* ec = ws + 16800 + MC_MAXWG * s;
     if (threadIdx.x == 0) __hip_atomic_store(ec + blockIdx.x, total, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     ok = mc_barrier(bar, nwg, ++ph, sh) && ok;
     if (threadIdx.x == 0) {

@@ -265,7 +265,7 @@ def test_cap_layer_streaming_path(B, N, C, d, ds, HS, HT, R, force, flow):
 # ---------------------------------------------------------------------------------------------------------------
 # integer path: mask generation, bit-exact vs the oracle's sort/scatter restatement
 # ---------------------------------------------------------------------------------------------------------------
-@pytest.mark.parametrize("M,ratio,seed", [(65280, 0.25, 1), (5000, 0.25, 2), (1234, 0.9, 3), (777, 0.0, 4), (300, 1.0, 5)])
+@pytest.mark.parametrize("M,ratio,seed", [(65280, 0.25, 1), (102144, 0.25, 6), (5000, 0.25, 2), (1234, 0.9, 3), (777, 0.0, 4), (300, 1.0, 5)])
 def test_mask_random_bit_exact(M, ratio, seed):
     from gptst_amd import ops, synth
     dev = _dev()
@@ -292,7 +292,7 @@ def _handoff_timeouts():
 
 
 class _mask_path:
-    """mask generation path: 0 by size (lattice noise: one workgroup <= 8192 cells, the cooperative launch <= 65536, else multi-launch),
+    """mask generation path: 0 by size (lattice noise: one workgroup <= 8192 cells, the cooperative launch <= 131072, else multi-launch),
     1 multi-launch, 2 one workgroup at every size it covers, 3 as 0 without the cooperative launch"""
 
     def __init__(self, multi):
@@ -310,7 +310,7 @@ class _mask_path:
 
 
 @pytest.mark.parametrize("multi", [0, 1])
-@pytest.mark.parametrize("reps", [40, 4000])
+@pytest.mark.parametrize("reps", [40, 4000, 12500])
 def test_mask_random_ties_lowest_index(multi, reps):
     """Duplicated values straddling rank k: exactly k cells are dropped, larger values first, ties -> lowest index.  reps = 4000
     spreads the tied cells over all 64 workgroups of the multi-launch path (tied cells are written by ONE workgroup)."""
@@ -357,12 +357,13 @@ def test_mask_u24_rejects_noise_off_the_lattice(path, M):
             assert torch.isnan(ops.mask_adaptive(lab, None, lc, nums, na.to(dev), nr.to(dev), 1, 1, u24=True)[2]).all(), which
         clean = ops.mask_adaptive(lab, None, lc, nums, noise.to(dev), synth.make_noise(M, 22).to(dev), 1, 1, u24=True)[2]
         assert set(clean.unique().tolist()) == {0.0, 1.0} and int((clean == 0).sum()) == 2 * (M // 8)
-    big = synth.make_noise(70000, 5)
-    assert torch.equal(ops.mask_random(big.to(dev), 17500, u24=True).cpu().long(), O.random_mask(big, 0.25))       # > 65536 cells: the digit passes
+    for n_big in (70000, 140000):            # 70000: the cooperative launch on 69 workgroups (path 0) / the digit passes; 140000: beyond the cooperative form
+        big = synth.make_noise(n_big, 5)
+        assert torch.equal(ops.mask_random(big.to(dev), n_big // 4, u24=True).cpu().long(), O.random_mask(big, 0.25)), n_big
 
 
 @pytest.mark.parametrize("ada_all", [1, 0])
-@pytest.mark.parametrize("B,N,HS,frac", [(32, 170, 10, 0.5), (4, 20, 5, 0.9), (3, 17, 10, 0.01), (2, 33, 16, 0.0)])
+@pytest.mark.parametrize("B,N,HS,frac", [(32, 170, 10, 0.5), (32, 266, 10, 0.4), (4, 20, 5, 0.9), (3, 17, 10, 0.01), (2, 33, 16, 0.0)])
 def test_mask_adaptive_bit_exact(ada_all, B, N, HS, frac):
     from gptst_amd import ops, synth
     dev = _dev()
