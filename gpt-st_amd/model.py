@@ -192,6 +192,10 @@ class GPTST_Model(nn.Module):
         self.flat, self._offs = flat, offs
         self.nA, self.nB = seg_end[0], seg_end[1] - seg_end[0]
         self._views = None
+        # the parameter objects in module order, walked ONCE: named_parameters() traverses ~640 modules, and the eager path asked for it four times per
+        # step (1.2 ms of the reference-style loop's 6.7 ms, tools/experiments/prof_module_path.py)
+        self._named = list(named.items())
+        self._shapes = {k: (t.numel(), t.shape) for k, t in self._named}
 
     def _apply(self, fn, *a, **k):               # .to(device) / .cuda(): re-establish the flat views afterwards
         super()._apply(fn, *a, **k)
@@ -210,12 +214,12 @@ class GPTST_Model(nn.Module):
         return torch.zeros_like(self.flat)
 
     def views_of(self, flat):
-        named = dict(self.named_parameters())
-        return {k: flat[o:o + named[k].numel()].view(named[k].shape) for k, o in self._offs.items()}
+        return {k: flat[o:o + self._shapes[k][0]].view(self._shapes[k][1]) for k, o in self._offs.items()}
 
     def param_views(self):
-        if self._views is None or any(v.data_ptr() != dict(self.named_parameters())[k].data_ptr() for k, v in list(self._views.items())[:1]):
-            v = {k: t.data for k, t in self.named_parameters()}
+        k0, t0 = self._named[0]
+        if self._views is None or self._views[k0].data_ptr() != t0.data_ptr():
+            v = {k: t.data for k, t in self._named}
             for k, b in self.named_buffers():
                 v[k] = b
             self._views = v
@@ -284,7 +288,7 @@ class GPTST_Model(nn.Module):
             gen = engine.gen_all(p, tidx, dims)
             prob0, sv_g = engine.guide_fwd(p, source, tidx, dims, base, gen=gen["guide"])
             mask = self.make_mask(source, prob0, epoch)
-        params = [t for _, t in self.named_parameters()]
+        params = [t for _, t in self._named]
         out, dec, prob, c1 = _PretrainFn.apply(self, source, mask, (tidx, gen, prob0, sv_g), *params)
         mask_i = mask.view(B, T, N, base).to(torch.int64)
         hs1 = c1.view(B, T, self.HS, N).transpose(-1, -2)                                                  # :424

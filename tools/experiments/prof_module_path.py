@@ -1,0 +1,13 @@
+import cProfile, pstats, sys, os, io
+sys.path.insert(0, '/root/repo')
+import torch, bench
+from gptst_amd.config import make_args
+from gptst_amd import synth
+args = make_args("PEMS08", scaler_zeros=synth.scaler_zeros(), device="cuda:0")
+dev = torch.device("cuda", 0)
+bench.module_path(args, 32, 200, dev, steps=10)
+pr = cProfile.Profile(); pr.enable()
+r = bench.module_path(args, 32, 200, dev, steps=40)
+pr.disable()
+print(r["steps_per_s"], r["ms_per_step"])
+s = io.StringIO(); pstats.Stats(pr, stream=s).sort_stats("tottime").print_stats(28); print(s.getvalue()[:6000])
