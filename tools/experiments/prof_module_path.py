@@ -10,4 +10,4 @@ pr = cProfile.Profile(); pr.enable()
 r = bench.module_path(args, 32, 200, dev, steps=40)
 pr.disable()
 print(r["steps_per_s"], r["ms_per_step"])
-s = io.StringIO(); pstats.Stats(pr, stream=s).sort_stats("tottime").print_stats(28); print(s.getvalue()[:6000])
+s = io.StringIO(); pstats.Stats(pr, stream=s).sort_stats("cumtime").print_stats(45); print(s.getvalue()[:6000])
