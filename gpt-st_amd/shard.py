@@ -24,7 +24,7 @@ import threading
 import torch
 
 from . import engine, ops
-from .step import PretrainStep, U24
+from .step import PretrainStep, U24, DEFER_GEN
 
 
 def is_node_local(key):
@@ -195,13 +195,14 @@ class ShardedPretrainStep(PretrainStep):
     def _cols(self, flat_global, per_cell):
         return flat_global.view(self.B, self.T, self.Ng, per_cell)[:, :, self.n0:self.n0 + self.Nl].contiguous().view(-1)
 
-    def _mask(self, phase, prob, label=None):
-        """label: the guide's argmax labels of the local cells (rowdot's by-product) — else taken from prob"""
+    def _mask(self, phase, prob, label=None, jobs=None):
+        """label: the guide's argmax labels of the local cells (rowdot's by-product) — else taken from prob;  jobs: the STHCNs' generation table
+        (engine.gen_all(defer=True)), launched by the mask call — inside its launch where that is the cooperative one"""
         a, base = self.args, self.base
         Mg = self.B * self.T * self.Ng
         ws = self.arena.zeros(ops.mask_ws_floats())        # the selections' histogram scratch: zeroed by the step's first launch
         if phase == 0:
-            mask_g = ops.mask_random(self.noise_g, int(Mg * base * a.mask_ratio), ws=ws, u24=U24)
+            mask_g = ops.mask_random(self.noise_g, int(Mg * base * a.mask_ratio), ws=ws, u24=U24, jobs=jobs)
         else:
             if label is None:
                 label = ops.mask_labels(prob)[0]                                               # local cells (B,T,Nl)
@@ -211,7 +212,7 @@ class ShardedPretrainStep(PretrainStep):
                 lab = self.group.all_gather(label.view(self.B, self.T, self.Nl))               # (W,B,T,Nl)
                 label_g = lab.permute(1, 2, 0, 3).contiguous().view(-1)                        # (B,T,N) node-major within a cell row
             mask_g = ops.mask_adaptive(label_g, None, self.ctrl[:self.HS], self.ctrl[self.HS:], self.noise_a_g, self.noise_r_g,
-                                       a.ada_type == "all", base, ws=ws, u24=U24)[2]           # (class histogram of the gathered labels: taken inside)
+                                       a.ada_type == "all", base, ws=ws, u24=U24, jobs=jobs)[2]  # (class histogram of the gathered labels: taken inside)
         self.last_mask_global = mask_g
         return self._cols(mask_g, base)
 
@@ -277,10 +278,10 @@ class ShardedPretrainStep(PretrainStep):
             fused = self.fused_tails
             chain = fused and engine.chain_ok(dims)                # dPre chain: no backward kernel re-reads its layer's output
             need_guide = phase == 1 or not fused                   # (the fused form skips the classifier in the random-mask phase, as step.py does)
-            gen = engine.gen_all(p, tidx, dims, guide=need_guide)
+            gen = engine.gen_all(p, tidx, dims, guide=need_guide, defer=DEFER_GEN)
             red = engine.Reductions()
             prob, sv_g = engine.guide_fwd(p, src, tidx, dims, base, gen=gen["guide"], lowrank_in=chain) if need_guide else (None, None)
-            mask = self._mask(phase, prob, sv_g[4] if sv_g is not None else None)
+            mask = self._mask(phase, prob, sv_g[4] if sv_g is not None else None, jobs=gen.pop("pending", None))
             self.last_mask = mask
             if fused:
                 dec_head = None

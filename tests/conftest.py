@@ -62,3 +62,12 @@ def pytest_sessionfinish(session, exitstatus):
             old = {}
     old.update(_PARITY)
     json.dump(old, open(path, "w"), indent=1, sort_keys=True)
+
+
+def free_port():
+    """a TCP port nobody is listening on right now (bind to 0, read it back): rendezvous ports derived from the pid collided now and then with a
+    socket of the previous test still in TIME_WAIT"""
+    import socket
+    with socket.socket(socket.AF_INET, socket.SOCK_STREAM) as sk:
+        sk.bind(("127.0.0.1", 0))
+        return sk.getsockname()[1]

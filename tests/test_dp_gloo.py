@@ -6,6 +6,9 @@ import sys
 
 import pytest
 import torch
+
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+from conftest import free_port  # noqa: E402
 import torch.multiprocessing as mp
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -61,7 +64,7 @@ def test_dp_allreduce_equals_global_batch_gradient():
     from oracle import gptst_oracle as O
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
-    port = 29600 + os.getpid() % 300
+    port = free_port()
     procs = [ctx.Process(target=_worker, args=(r, 2, port, q)) for r in range(2)]
     for p in procs:
         p.start()
@@ -117,7 +120,7 @@ def test_dp_label_exchange_protocol():
     class counts are summed, and a rank's rows of a global vector are its contiguous slice."""
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
-    port = 29900 + os.getpid() % 90
+    port = free_port()
     procs = [ctx.Process(target=_worker_labels, args=(r, 2, port, q)) for r in range(2)]
     for p in procs:
         p.start()

@@ -8,6 +8,9 @@ import sys
 
 import pytest
 
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+from conftest import free_port  # noqa: E402
+
 pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
@@ -25,7 +28,7 @@ def _run(extra, port):
 
 @pytest.mark.parametrize("extra,scaling,par", [([], "weak", "dp2"), (["--epoch", "1"], "weak", "dp2"), (["--shard", "nodes"], "strong", "nodes2")])
 def test_bench_two_ranks(extra, scaling, par):
-    out = _run(extra, 29610 + len(extra) * 7 + os.getpid() % 50)
+    out = _run(extra, free_port())
     assert out["n_gpus"] == 2 and out["scaling"] == scaling and out["config"]["parallelism"] == par
     assert out["value"] > 0 and out["steps"] == 4 and out["higher_is_better"] is True
     assert out["handoff_timeouts"] == 0, "a bounded in-launch hand-off wait expired (two processes share this GPU)"
@@ -91,7 +94,7 @@ def test_dp_step_in_one_graph_equals_the_plain_step():
     from gptst_amd.model import GPTST_Model
     from gptst_amd.step import PretrainStep
     from oracle import gptst_oracle as O
-    os.environ.update(RANK="0", WORLD_SIZE="1", LOCAL_RANK="0", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(29700 + os.getpid() % 200))
+    os.environ.update(RANK="0", WORLD_SIZE="1", LOCAL_RANK="0", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(free_port()))
     args = make_args("PEMS08", num_nodes=24, embed_dim=8, HS=6, HT=8, scaler_zeros=synth.scaler_zeros(), epochs=30, change_epoch=3)
     sd = O.init_state_dict(args, 3)
     B, M = 4, 4 * 12 * 24
@@ -220,7 +223,7 @@ def test_trainer_keeps_the_tail_of_a_data_parallel_epoch(tmp_path):
     """r04 (verdict 5e): two ranks (gloo, one GPU) train two epochs — random-mask and adaptive phase — of a series with an ODD number of full
     batches and a ragged last one.  Every batch of the epoch is stepped on: whole groups through the captured step, the left-over full batch and the
     ragged batch as padded rounds (the rank without a batch contributes weight 0); both ranks end with bit-identical weights."""
-    port = 29910 + os.getpid() % 50
+    port = free_port()
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
            "--master-port", str(port), os.path.join(ROOT, "tests", "dp_tail_worker.py"), str(tmp_path)]
     r = subprocess.run(cmd, cwd=ROOT, env=dict(os.environ, GPTST_DIST_BACKEND="gloo"), capture_output=True, text=True, timeout=600)
@@ -238,7 +241,7 @@ def test_trainer_train_end_to_end_under_data_parallelism(tmp_path):
     """Trainer.train() closes with test() over the epoch's batches, which under data parallelism include the (batch, weight)
     tuples of the padded tail rounds.  Two gloo ranks on one GPU run train() to the end: the evaluation completes and counts every sample of the
     training set exactly once (padding — weight 0 — is skipped, the metric sums are all-reduced)."""
-    port = 29960 + os.getpid() % 30
+    port = free_port()
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
            "--master-port", str(port), os.path.join(ROOT, "tests", "dp_tail_worker.py"), str(tmp_path), "train"]
     r = subprocess.run(cmd, cwd=ROOT, env=dict(os.environ, GPTST_DIST_BACKEND="gloo"), capture_output=True, text=True, timeout=900)

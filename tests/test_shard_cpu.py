@@ -4,6 +4,9 @@ import os
 import sys
 
 import torch
+
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+from conftest import free_port  # noqa: E402
 import torch.multiprocessing as mp
 
 from gptst_amd import synth
@@ -54,7 +57,7 @@ def _worker(rank, world, port, q):
 def test_label_gather_restores_node_order_over_gloo():
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
-    port = 29750 + os.getpid() % 200
+    port = free_port()
     procs = [ctx.Process(target=_worker, args=(r, 2, port, q)) for r in range(2)]
     for p in procs:
         p.start()
