@@ -1,0 +1,54 @@
+#!/usr/bin/env python
+"""Per-kernel roofline table of the step from the committed evidence: launch durations from the rocprofv3 kernel-trace summary of the graph replay
+(profiles/<tag>_graph_kernel_trace.txt), HBM bytes per launch from the PMC passes (profiles/pmc_traffic.json, (2 FETCH_SIZE + WRITE_SIZE) * 1024, calibrated:
+profiles/r05_pmc_calibration.txt), algorithmic FLOPs from bench.kernel_flops (SURVEY 8d formulas).  For every kernel of the median step: us per step,
+bytes, achieved TB/s on its ACTUAL traffic, time that traffic takes at the ~4.5 TB/s a streaming kernel reaches on this chip (tools/experiments/stream_rates.py),
+fp32-MFMA time at 157.3 TFLOP/s, and which of the two floors is the higher one.
+    python tools/roofline_table.py r05f > profiles/r05f_roofline_table.txt"""
+import json
+import os
+import re
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import bench  # noqa: E402
+
+tag = sys.argv[1] if len(sys.argv) > 1 else "r05f"
+STREAM_TBS, MFMA_TF = 4.5, 157.3
+d = dict(B=32, T=12, N=170, C=64, HS=10, R=3)
+pm = json.load(open(os.path.join(ROOT, "profiles", "pmc_traffic.json")))["kernels"]
+SYM2ENTRY = {
+    "void cap_route_bwd2_kernel<64, 1, true>": ("gptst_cap_cross_route_lin_bwd", ""), "void hypertem_bwd_pair_kernel<6>": ("gptst_hypertem_bwd_pair", ""),
+    "void hypertem_chain_fwd_kernel<2>": ("gptst_hypertem_chain_fwd", "x2"), "void cap_route_fwd4_kernel<2>": ("gptst_cap_route_fwd", ""),
+    "void applywg64_kernel<0, 1>": ("gptst_apply_wgrad", ""), "void applywg64_kernel<0, 2>": ("gptst_apply_wgrad", ""),
+    "void apply64_kernel<0, 1>": ("gptst_apply", ""), "void apply64_kernel<0, 3>": ("gptst_apply", ""),
+    "void cap_cross_rec_fwd_kernel<64>": ("gptst_cap_rec_fwd", ""), "void cap_rec_bwd2_kernel<64>": ("gptst_cap_rec_bwd", ""),
+    "void hypertem_bwd_wgrad_kernel<6, false, true, false": ("gptst_hypertem_bwd_wgrad", ""), "hypertem_fwd_kernel": ("gptst_hypertem_fwd", ""),
+}
+rows = []
+tl = open(os.path.join(ROOT, "profiles", "%s_step_timeline_median_adaptive.txt" % tag)).read().splitlines()
+per = {}
+for l in tl:
+    m = re.match(r"\s+[\d.]+\s+([\d.]+) gap\s+[\d.]+ q\d+\s+s\d+\s+(.*)$", l)
+    if m:
+        nm = m.group(2).strip()
+        e = per.setdefault(nm, [0, 0.0])
+        e[0] += 1; e[1] += float(m.group(1))
+tot_us = sum(v[1] for v in per.values())
+tot_b = tot_t = tot_m = 0.0
+print("# %s: median adaptive step, %d launches, %.1f us; floors: traffic at %.1f TB/s (what a streaming kernel reaches here), fp32 MFMA at %.1f TFLOP/s" % (
+    tag, sum(v[0] for v in per.values()), tot_us, STREAM_TBS, MFMA_TF))
+print("%-58s %3s %8s %8s %7s %8s %8s  %s" % ("kernel [grid]", "n", "us/step", "MB/step", "TB/s", "t_hbm us", "t_mfma", "higher floor / time"))
+for nm, (n, us) in sorted(per.items(), key=lambda kv: -kv[1][1]):
+    key = [k for k in pm if k.startswith(nm[:40]) and k.endswith(nm[-8:])]
+    by = pm[key[0]]["hbm_bytes"] * n if key else 0.0
+    sym = nm.rsplit(" [", 1)[0]
+    ent = SYM2ENTRY.get(sym)
+    fl = bench.kernel_flops(ent[0], ent[1], d) * n if ent else 0.0
+    t_h, t_m = by / (STREAM_TBS * 1e6), fl / (MFMA_TF * 1e6)
+    tot_b += by; tot_t += t_h; tot_m += t_m
+    print("%-58s %3d %8.1f %8.1f %7.2f %8.1f %8.1f  %4.0f %%" % (nm[:58], n, us, by / 1e6, by / us / 1e6 if us else 0, t_h, t_m, 100 * max(t_h, t_m) / us if us else 0))
+print("%-58s %3s %8.1f %8.1f %7.2f %8.1f %8.1f" % ("sum", "", tot_us, tot_b / 1e6, tot_b / tot_us / 1e6, tot_t, tot_m))
+print("# the step moves %.2f GB (%.2fx the 1.13 GB of SURVEY 8d) = %.0f us at %.1f TB/s = %.0f %% of its %.0f us; the named kernels' MFMA work is %.0f us (%.0f %%)" % (
+    tot_b / 1e9, tot_b / 1.131e9, tot_t, STREAM_TBS, 100 * tot_t / tot_us, tot_us, tot_m, 100 * tot_m / tot_us))
