@@ -4,7 +4,7 @@
 profiles/r05_pmc_calibration.txt), algorithmic FLOPs from bench.kernel_flops (SURVEY 8d formulas).  For every kernel of the median step: us per step,
 bytes, achieved TB/s on its ACTUAL traffic, time that traffic takes at the ~4.5 TB/s a streaming kernel reaches on this chip (tools/experiments/stream_rates.py),
 fp32-MFMA time at 157.3 TFLOP/s, and which of the two floors is the higher one.
-    python tools/roofline_table.py r05f > profiles/r05f_roofline_table.txt"""
+    python tools/roofline_table.py r05g > profiles/r05g_roofline_table.txt"""
 import json
 import os
 import re
@@ -14,7 +14,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 import bench  # noqa: E402
 
-tag = sys.argv[1] if len(sys.argv) > 1 else "r05f"
+tag = sys.argv[1] if len(sys.argv) > 1 else "r05g"
 STREAM_TBS, MFMA_TF = 4.5, 157.3
 d = dict(B=32, T=12, N=170, C=64, HS=10, R=3)
 pm = json.load(open(os.path.join(ROOT, "profiles", "pmc_traffic.json")))["kernels"]
@@ -30,7 +30,7 @@ rows = []
 tl = open(os.path.join(ROOT, "profiles", "%s_step_timeline_median_adaptive.txt" % tag)).read().splitlines()
 per = {}
 for l in tl:
-    m = re.match(r"\s+[\d.]+\s+([\d.]+) gap\s+[\d.]+ q\d+\s+s\d+\s+(.*)$", l)
+    m = re.match(r"\s+[\d.]+\s+([\d.]+) gap\s+[-\d.]+ q\d+\s+s\d+\s+(.*)$", l)
     if m:
         nm = m.group(2).strip()
         e = per.setdefault(nm, [0, 0.0])
