@@ -9,6 +9,8 @@
 // both took ~90 us: every phase was a serial latency chain (ds_add_f32 with 8-way bank conflicts, one thread per node doing
 // 30 dependent LDS round trips, 2 waves per SIMD).  LDS at N=170, HS=10, C=64: 78.7 KB -> two workgroups per CU.
 #include "mfma_tile.h"
+#include "poolgen_dev.h"
+#include <vector>
 #ifdef GPTST_DEBUG
 __device__ long long g_cap_ts[64];     // per-phase s_memtime stamps of workgroup 5 (enabled by gptst_tune2(99))
 static thread_local int g_cap_dbg = 0;
@@ -668,13 +670,49 @@ __device__ __forceinline__ void cap_cross_bwd_prologue(const float* __restrict__
     __syncthreads();
 }
 
-template <int C, int ROLES, bool LIN = false>      // ROLES 0: one role (dS given, or the cross-time backward as a prologue); 1: + cross-time role
+// r05, late: REDUCTION JOBS as a further role.  The weight-gradient reductions of the layers ALREADY behind the step's backward (gptst_pool_jobs kinds 1 / 2: their
+// inputs were written by earlier launches, so nothing is waited for) ride behind the routing workgroups: this launch runs 384 routing workgroups on 256 CUs at
+// ~2.3 TB/s, the CUs whose cross-time role has finished and the spare HBM bandwidth take the jobs, and the 69-us reduction launch at the end of the step shrinks
+// by what was carried.  A job workgroup = two 256-thread job blocks of the SAME kind (a pool-gradient block has one barrier: both halves reach it).
+template <bool JOBS> struct RouteJobs { };
+template <> struct RouteJobs<true> { PJobs t; int npool, npb, neb, first; };      // jobs [0, npool): kind 1 (npb blocks), the rest kind 2 (neb blocks); first job workgroup
+
+template <int C, int ROLES, bool LIN = false, bool JOBS = false>      // ROLES 0: one role (dS given, or the cross-time backward as a prologue); 1: + cross-time role
                                                    // (r05: the three-role form — + the rec backward — measured slower and left the library: profiles/r04_roles3_stamps.txt)
 __global__ __launch_bounds__(CM_NT, 4) void cap_route_bwd2_kernel(const float* __restrict__ X, const float* __restrict__ Wp,
                                                                   const float* __restrict__ bp, const float* __restrict__ c,
                                                                   const float* __restrict__ dc1, const float* __restrict__ dS,
                                                                   float* __restrict__ dY, float* __restrict__ dlogit, int N, int HS,
-                                                                  int region2, CrossBwdArgs cx, LinArgs lin) {
+                                                                  int region2, CrossBwdArgs cx, LinArgs lin, RouteJobs<JOBS> jr) {
+    if constexpr (JOBS) {
+        if ((int)blockIdx.x >= jr.first) {
+            extern __shared__ __attribute__((aligned(16))) float jsmem[];
+            const int half = (int)(threadIdx.x >> 8), tid_ = (int)(threadIdx.x & 255);
+            float (*fold)[PG_MAXK][65] = reinterpret_cast<float (*)[PG_MAXK][65]>(jsmem + half * (4 * PG_MAXK * 65));
+            const int w = (int)blockIdx.x - jr.first, wp = (jr.npb + 1) >> 1;
+            if (w < wp) {                                            // two pool-gradient blocks (or one and a half that only keeps the barrier)
+                const int vb = __builtin_amdgcn_readfirstlane(2 * w + half);
+                if (vb < jr.npb) {
+                    int p = 0;
+                    for (int q = 1; q < jr.npool; ++q) if (vb >= jr.t.j[q].blk0) p = q;
+                    const PJob& a = jr.t.j[p];
+                    if (((a.cols | a.ldx) & 3) == 0) pj_bwd_pool<4>(a, vb - a.blk0, fold, tid_); else pj_bwd_pool<1>(a, vb - a.blk0, fold, tid_);
+                } else {
+                    __syncthreads();
+                }
+            } else {
+                const int vb = __builtin_amdgcn_readfirstlane(2 * (w - wp) + half);
+                if (vb < jr.neb) {
+                    int p = jr.npool;
+                    for (int q = jr.npool + 1; q < jr.t.n; ++q) if (vb >= jr.t.j[q].blk0) p = q;
+                    const PJob& a = jr.t.j[p];
+                    const int rel = vb - a.blk0;
+                    if (((a.cols | a.ldx) & 3) == 0) pj_bwd_emb<4>(a, rel % a.nbx, rel / a.nbx, tid_); else pj_bwd_emb<1>(a, rel % a.nbx, rel / a.nbx, tid_);
+                }
+            }
+            return;
+        }
+    }
     using T = Tile<C>;
     constexpr int P = T::PITCH, LPR = C / 4, RPP = CM_NT / LPR;
     extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -1066,7 +1104,7 @@ thread_local int g_cap_bwd_noroles = 0;       // gptst_tune(23, 1): the cross-ti
 template <int C>
 static int launch_route_bwd2(const float* X, const float* Wp, const float* bp, const float* c, const float* dc1, const float* dS,
                              float* dY, float* dlogit, int BT, int N, int HS, hipStream_t st, CrossBwdArgs cx = CrossBwdArgs{nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, 0, 0, nullptr, nullptr, 0},
-                             LinArgs lin = LinArgs{nullptr, nullptr, nullptr, nullptr, nullptr, 0}) {
+                             LinArgs lin = LinArgs{nullptr, nullptr, nullptr, nullptr, nullptr, 0}, RouteJobs<true>* jobs = nullptr) {
     if (HS > 64) return GPTST_ESHAPE;
     if (lin.dX != nullptr && C != 64) return GPTST_ESHAPE;      // the folded Linear backward: C = 64
     const int NR = cm_rows(N), NP = cm_np(N), HSP = cm_hsp(HS);
@@ -1084,30 +1122,40 @@ static int launch_route_bwd2(const float* X, const float* Wp, const float* bp, c
         const size_t need_r = (size_t)(cx.T * HS + 2 * cx.HT + 2 * no) * Tile<C>::PITCH + (size_t)cx.HT * cx.T * HS;
         if (smem > 80 * 1024 || BT + cx.nB > 512 || cx.T != 12 || need_r > (size_t)NR * Tile<C>::PITCH + r2) cx.nB = 0;
     }
+    if (jobs != nullptr && !(cx.nB > 0 && lin.dX != nullptr && smem >= 2 * (4 * PG_MAXK * 65) * sizeof(float))) return GPTST_ESHAPE;   // (the caller then runs the jobs on their own)
+    if (jobs != nullptr) {
+        static size_t curJ = 0;
+        if (smem > curJ) { (void)hipFuncSetAttribute((const void*)cap_route_bwd2_kernel<C, 1, true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem); curJ = smem; }
+        jobs->first = BT + cx.nB;
+        const int njw = ((jobs->npb + 1) >> 1) + ((jobs->neb + 1) >> 1);
+        hipLaunchKernelGGL((cap_route_bwd2_kernel<C, 1, true, true>), dim3(BT + cx.nB + njw), dim3(CM_NT), smem, st, X, Wp, bp, c, dc1, dS, dY, dlogit, N, HS, (int)r2, cx, lin, *jobs);
+        GPTST_CHECK_LAUNCH();
+        return GPTST_OK;
+    }
     if (cx.nB > 0 && lin.dX != nullptr) {
         static size_t curRL = 0;
         if (smem > curRL) { (void)hipFuncSetAttribute((const void*)cap_route_bwd2_kernel<C, 1, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem); curRL = smem; }
-        hipLaunchKernelGGL((cap_route_bwd2_kernel<C, 1, true>), dim3(BT + cx.nB), dim3(CM_NT), smem, st, X, Wp, bp, c, dc1, dS, dY, dlogit, N, HS, (int)r2, cx, lin);
+        hipLaunchKernelGGL((cap_route_bwd2_kernel<C, 1, true>), dim3(BT + cx.nB), dim3(CM_NT), smem, st, X, Wp, bp, c, dc1, dS, dY, dlogit, N, HS, (int)r2, cx, lin, RouteJobs<false>{});
         GPTST_CHECK_LAUNCH();
         return GPTST_OK;
     }
     if (cx.nB > 0) {
         static size_t curR = 0;
         if (smem > curR) { (void)hipFuncSetAttribute((const void*)cap_route_bwd2_kernel<C, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem); curR = smem; }
-        hipLaunchKernelGGL((cap_route_bwd2_kernel<C, 1>), dim3(BT + cx.nB), dim3(CM_NT), smem, st, X, Wp, bp, c, dc1, dS, dY, dlogit, N, HS, (int)r2, cx, lin);
+        hipLaunchKernelGGL((cap_route_bwd2_kernel<C, 1>), dim3(BT + cx.nB), dim3(CM_NT), smem, st, X, Wp, bp, c, dc1, dS, dY, dlogit, N, HS, (int)r2, cx, lin, RouteJobs<false>{});
         GPTST_CHECK_LAUNCH();
         return GPTST_OK;
     }
     if (lin.dX != nullptr) {
         static size_t curL = 0;
         if (smem > curL) { (void)hipFuncSetAttribute((const void*)cap_route_bwd2_kernel<C, 0, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem); curL = smem; }
-        hipLaunchKernelGGL((cap_route_bwd2_kernel<C, 0, true>), dim3(BT), dim3(CM_NT), smem, st, X, Wp, bp, c, dc1, dS, dY, dlogit, N, HS, (int)r2, cx, lin);
+        hipLaunchKernelGGL((cap_route_bwd2_kernel<C, 0, true>), dim3(BT), dim3(CM_NT), smem, st, X, Wp, bp, c, dc1, dS, dY, dlogit, N, HS, (int)r2, cx, lin, RouteJobs<false>{});
         GPTST_CHECK_LAUNCH();
         return GPTST_OK;
     }
     static size_t cur = 0;
     if (smem > cur) { (void)hipFuncSetAttribute((const void*)cap_route_bwd2_kernel<C, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem); cur = smem; }
-    hipLaunchKernelGGL((cap_route_bwd2_kernel<C, 0>), dim3(BT), dim3(CM_NT), smem, st, X, Wp, bp, c, dc1, dS, dY, dlogit, N, HS, (int)r2, cx, lin);
+    hipLaunchKernelGGL((cap_route_bwd2_kernel<C, 0>), dim3(BT), dim3(CM_NT), smem, st, X, Wp, bp, c, dc1, dS, dY, dlogit, N, HS, (int)r2, cx, lin, RouteJobs<false>{});
     GPTST_CHECK_LAUNCH();
     return GPTST_OK;
 }
@@ -1164,6 +1212,40 @@ extern "C" int gptst_cap_cross_route_lin_bwd(const float* X, const float* Wp, co
 // (cap_rec_bwd2_kernel: defined above cap_route_bwd2_kernel, which runs the same body as its first ROLE)
 GPTST_INTERNAL int gptst_cap_rec_bwd_v1(const float* drec, const float* c, const float* v, float* dc1, float* dv, int BT, int N, int C,
                                     int HS, void* stream);
+
+// r05, late: gptst_cap_cross_route_lin_bwd + gptst_pool_jobs(njobs gradient-reduction jobs, kinds 1 / 2) — the jobs as role workgroups of the same launch where
+// the role form serves (see RouteJobs above), else as those two calls.  The jobs' inputs must be complete when this call is enqueued (earlier launches of the
+// stream), and nothing in this launch may read their outputs.
+GPTST_INTERNAL int gptst_pj_reduce_table(PJobs* t, int njobs, const int* kind, const void* const* emb, const void* const* x, const void* const* pool,
+                                         const void* const* out, const int* R, const int* K, const int* cols, const int* nsplit, const int* ldx,
+                                         int* npool, int* npb, int* neb);
+extern "C" int gptst_pool_jobs(int njobs, const int* kind, const void* const* emb, const void* const* x, const void* const* pool,
+                               const void* const* out, const int* R, const int* K, const int* cols, const int* nsplit, const int* ldx, void* stream);
+extern "C" int gptst_cap_cross_route_lin_bwd_jobs(const float* X, const float* Wp, const float* bp, const float* c, const float* dc1, const float* dv,
+                                                  const float* s, const float* Rt, const float* Ht, const float* dyn, const float* tmpl,
+                                                  const float* dPre, const float* out, int premul, float* dX, float* dWp, float* dbp, float* dlogit,
+                                                  float* ddyn, float* dS_ws, void* flags, int B, int T, int N, int C, int HS, int HT,
+                                                  int njobs, const int* jkind, const void* const* jemb, const void* const* jx, const void* const* jpool,
+                                                  const void* const* jout, const int* jR, const int* jK, const int* jcols, const int* jnsplit, const int* jldx,
+                                                  void* stream) {
+    if (!X || !Wp || !bp || !c || !dc1 || !dv || !s || !Rt || !Ht || !dyn || !tmpl || !dPre || !dX || !dWp || !dbp || !dlogit || !ddyn || B <= 0 ||
+        T <= 0 || (out && premul)) return GPTST_EARG;
+    if (njobs < 0 || (njobs && (!jkind || !jemb || !jx || !jpool || !jout || !jR || !jK || !jcols || !jnsplit))) return GPTST_EARG;
+    if (C != 64) return GPTST_ESHAPE;
+    const bool roles = dS_ws != nullptr && flags != nullptr && !g_cap_bwd_noroles;
+    const CrossBwdArgs cx{dv, s, Rt, Ht, dyn, tmpl, ddyn, T, HT, roles ? dS_ws : nullptr, roles ? (unsigned*)flags : nullptr, roles ? B * CX_SPLIT : 0};
+    const LinArgs lin{dPre, out, dX, dWp, dbp, premul};
+    if (njobs > 0 && roles) {
+        RouteJobs<true> jr;
+        if (gptst_pj_reduce_table(&jr.t, njobs, jkind, jemb, jx, jpool, jout, jR, jK, jcols, jnsplit, jldx, &jr.npool, &jr.npb, &jr.neb) == GPTST_OK) {
+            const int rc = launch_route_bwd2<64>(X, Wp, bp, c, dc1, nullptr, nullptr, dlogit, B * T, N, HS, (hipStream_t)stream, cx, lin, &jr);
+            if (rc != GPTST_ESHAPE) return rc;
+        }
+    }
+    const int rc = launch_route_bwd2<64>(X, Wp, bp, c, dc1, nullptr, nullptr, dlogit, B * T, N, HS, (hipStream_t)stream, cx, lin);
+    if (rc || njobs == 0) return rc;
+    return gptst_pool_jobs(njobs, jkind, jemb, jx, jpool, jout, jR, jK, jcols, jnsplit, jldx, stream);
+}
 
 extern "C" int gptst_cap_rec_bwd(const float* drec, const float* c, const float* v, float* dc1, float* dv, int BT, int N, int C, int HS,
                                  void* stream) {

@@ -17,10 +17,6 @@
 #define PG_ROWS 16     // rows per block of the VALU forward: the K pool rows a thread keeps in registers are re-read from L2 once per block
 
 // V = 4: float4 columns (cols % 4 == 0, rows 16-byte aligned);  V = 1: scalar columns (e.g. HS*N = 2070 for METR_LA)
-template <int V> __device__ __forceinline__ float4 ldv(const float* p) { return ld4(p); }
-template <> __device__ __forceinline__ float4 ldv<1>(const float* p) { return make_float4(*p, 0.f, 0.f, 0.f); }
-template <int V> __device__ __forceinline__ void stv(float* p, float4 v) { st4(p, v); }
-template <> __device__ __forceinline__ void stv<1>(float* p, float4 v) { *p = v.x; }
 
 // ---- job table ------------------------------------------------------------------------------------------------------------
 // One launch serves up to PJ_MAX independent problems ("jobs"), each with its OWN embedding, shapes and kind.  A pretraining step has
@@ -33,12 +29,6 @@ template <> __device__ __forceinline__ void stv<1>(float* p, float4 v) { *p = v.
 #ifndef PJ_OCC
 #define PJ_OCC 6       // r05: 76 VGPRs with PJ_UC = 4 (was 152 / 3 waves per SIMD): the forward table 32.8 -> 28.0 us, the reduction table unchanged at the
 #endif                 // ~4 TB/s a streaming read reaches on this chip (torch.sum: 3.7-4.9 TB/s), profiles/r05_pooljobs_occupancy.txt
-#ifndef PJ_UC
-#define PJ_UC 4
-#endif
-#ifndef PJ_NU
-#define PJ_NU 4
-#endif
 // (PJ_MAX, PJob, PJobs, pj_fwd_mfma: poolgen_dev.h — the cooperative mask launch of masksel.hip carries forward jobs too, r05)
 
 // out[r, :] = sum_k emb[r,k] pool[k, :].   blocks: (ceil(cols/V/256), ceil(R/rows)), rows <= PG_MAXROWS
@@ -99,138 +89,7 @@ __device__ __forceinline__ void pj_fwd(const PJob& a, int bx, int by, int rows, 
 // The reduction over rows happens inside the MFMA; the workgroup's 4 waves take 4 row chunks of the slab and fold through LDS:
 // ONE read-modify-write per output element by ONE workgroup (no atomics: the result does not depend on scheduling).
 // blocks: (ceil(cols / (16 V)), 1)
-template <int V>
-__device__ __forceinline__ void pj_bwd_pool(const PJob& a, int bx, float (*fold)[PG_MAXK][65]) {
-    constexpr int SLAB = 16 * V;
-    const float* __restrict__ emb = a.emb;
-    const float* __restrict__ dW = a.x;
-    float* __restrict__ dpool = a.out;
-    const int cols = a.cols, R = a.R, K = a.K, RR = R * a.nsplit;
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int j = lane & 15, kk = lane >> 4;
-    int nchunk = 4;
-    if (nchunk * 16 > RR) nchunk = (RR + 15) / 16;
-    int per = (RR + nchunk - 1) / nchunk;
-    per = (per + 3) & ~3;
-    const int r0 = wave < nchunk ? wave * per : RR, r1 = min(RR, r0 + per);       // an idle wave gets an empty row range
-    const int c = bx * SLAB + V * j;
-    const bool cok = c < cols;
-    f32x4 acc[V];
-#pragma unroll
-    for (int e = 0; e < V; ++e) acc[e] = (f32x4){0.f, 0.f, 0.f, 0.f};
-    // NU k-steps (4 rows each) per batch: all dW / emb loads of a batch are issued before the first MFMA (row and column are
-    // clamped instead of predicated; a row beyond the chunk contributes through a zero emb operand).
-    constexpr int NU = PJ_NU;
-    const int cl = cok ? c : 0;
-    for (int rb = r0; rb < r1; rb += 4 * NU) {
-        float av[NU];
-        float4 b[NU];
-#pragma unroll
-        for (int u = 0; u < NU; ++u) {
-            const int row = min(rb + 4 * u + kk, r1 - 1);
-            av[u] = emb[(size_t)(row % R) * K + min(j, K - 1)];
-            b[u] = ldv<V>(dW + (size_t)row * a.ldx + cl);
-        }
-        SB();
-#pragma unroll
-        for (int u = 0; u < NU; ++u) {
-            const float a_ = (rb + 4 * u + kk < r1 && j < K) ? av[u] : 0.f;
-            acc[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(a_, b[u].x, acc[0], 0, 0, 0);
-            if (V == 4) {
-                acc[V > 1 ? 1 : 0] = __builtin_amdgcn_mfma_f32_16x16x4f32(a_, b[u].y, acc[V > 1 ? 1 : 0], 0, 0, 0);
-                acc[V > 2 ? 2 : 0] = __builtin_amdgcn_mfma_f32_16x16x4f32(a_, b[u].z, acc[V > 2 ? 2 : 0], 0, 0, 0);
-                acc[V > 3 ? 3 : 0] = __builtin_amdgcn_mfma_f32_16x16x4f32(a_, b[u].w, acc[V > 3 ? 3 : 0], 0, 0, 0);
-            }
-        }
-    }
-#pragma unroll
-    for (int e = 0; e < V; ++e)
-#pragma unroll
-        for (int r = 0; r < 4; ++r) fold[wave][kk * 4 + r][V * j + e] = acc[e][r];      // D reg r: row (l>>4)*4 + r = k, col l&15 = j
-    __syncthreads();
-    for (int o = threadIdx.x; o < PG_MAXK * SLAB; o += 256) {
-        const int k = o / SLAB, cc = o % SLAB, col = bx * SLAB + cc;
-        if (k < K && col < cols) {
-            float* d = dpool + (size_t)k * cols + col;
-            *d += (fold[0][k][cc] + fold[1][k][cc]) + (fold[2][k][cc] + fold[3][k][cc]);      // this workgroup owns the element
-        }
-    }
-}
-
-// demb[r, k] += sum_split sum_c dW[split*R + r, c] * pool[k, c]   on fp32 MFMA 16x16x4:
-// D[i = row][j = k] += A[i][kk] B[kk][j] with A = dW[row0+i][c], B = pool[j][c]; lane (kk = l>>4, i = l&15) fetches
-// float4s at c + 4kk so one load pair feeds four MFMA steps (the usual k-permutation); the MFMA does the reduction over the
-// columns that a VALU version would have to do with cross-lane shuffles.  A wave owns (16-row tile, 256-column chunk); several
-// jobs (and chunks) add into one demb, so the final add is an atomic.   blocks: (ceil(R/16), ceil(chunks/4))
-// accumulate one 256-column chunk of one job into acc (D[i = row][j = k])
-template <int V>
-__device__ __forceinline__ void pj_emb_accum(const PJob& a, int bx, int chunk, f32x4& acc) {
-    constexpr int chunk_cols = 256;
-    const int lane = threadIdx.x & 63;
-    const int i = lane & 15, kk = lane >> 4;
-    const int R = a.R, K = a.K;
-    const int row = bx * 16 + i;
-    const float* __restrict__ w = a.x;
-    const float* __restrict__ pl = a.pool;
-    const int cc = a.cols, ns = a.nsplit, ldx = a.ldx;
-    const int cbeg = chunk * chunk_cols, cend = min(cc, cbeg + chunk_cols);
-    if (cbeg >= cc) return;
-    if (V == 4) {
-        // UC column steps (16 columns each) per batch, all loads issued before the MFMAs (clamped, not predicated)
-        constexpr int UC = PJ_UC;
-        const int rowc = min(row, R - 1), ic = min(i, K - 1);
-        const bool rok = row < R, kok = i < K;
-        for (int c0 = cbeg; c0 < cend; c0 += 16 * UC) {
-            float4 av[UC], b[UC];
-#pragma unroll
-            for (int u = 0; u < UC; ++u) {
-                const int c = min(c0 + 16 * u + 4 * kk, cc - 4);
-                av[u] = ld4(w + (size_t)rowc * ldx + c);
-                b[u] = ld4(pl + (size_t)ic * cc + c);
-            }
-            for (int s = 1; s < ns; ++s) {
-#pragma unroll
-                for (int u = 0; u < UC; ++u) {
-                    const int c = min(c0 + 16 * u + 4 * kk, cc - 4);
-                    av[u] = f4add(av[u], ld4(w + ((size_t)s * R + rowc) * ldx + c));
-                }
-            }
-            SB();
-#pragma unroll
-            for (int u = 0; u < UC; ++u) {
-                const bool ok = c0 + 16 * u + 4 * kk < cend;
-                const float4 a_ = (ok && rok) ? av[u] : f4zero();
-                const float4 b_ = (ok && kok) ? b[u] : f4zero();
-                acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a_.x, b_.x, acc, 0, 0, 0);
-                acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a_.y, b_.y, acc, 0, 0, 0);
-                acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a_.z, b_.z, acc, 0, 0, 0);
-                acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a_.w, b_.w, acc, 0, 0, 0);
-            }
-        }
-    } else {
-        for (int c = cbeg + kk; c < cend + kk; c += 4) {
-            float av = 0.f, b = 0.f;
-            if (c < cend) {
-                if (row < R) for (int s = 0; s < ns; ++s) av += w[((size_t)s * R + row) * ldx + c];
-                if (i < K) b = pl[(size_t)i * cc + c];
-            }
-            acc = __builtin_amdgcn_mfma_f32_16x16x4f32(av, b, acc, 0, 0, 0);
-        }
-    }
-}
-
-template <int V>
-__device__ __forceinline__ void pj_bwd_emb(const PJob& a, int bx, int by) {
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int i = lane & 15, kk = lane >> 4;
-    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
-    pj_emb_accum<V>(a, bx, by * 4 + wave, acc);
-#pragma unroll
-    for (int r = 0; r < 4; ++r) {
-        const int orow = bx * 16 + kk * 4 + r;      // D reg r: row (l>>4)*4 + r, col l&15
-        if (orow < a.R && i < a.K && (by * 4 + wave) * 256 < a.cols) atomicAdd(a.out + (size_t)orow * a.K + i, acc[r]);
-    }
-}
+// pj_bwd_pool<V>(a, bx, fold, tid), pj_emb_accum<V>(a, bx, chunk, acc, tid), pj_bwd_emb<V>(a, bx, by, tid): poolgen_dev.h
 
 // Deterministic form (gptst_set_deterministic), r05: ONE launch for every embedding gradient of the call.  The table holds the kind-2 jobs grouped
 // by their demb (a group = the jobs that add into one demb, in call order; blk0 / nbx of a job = first workgroup / number of 16-row tiles of its
@@ -255,7 +114,7 @@ __global__ __launch_bounds__(PJ_DET_T) void pool_emb_det_kernel(PJobs t) {
         const int nch = (a.cols + 255) / 256;
         for (int ch = 0; ch < nch; ++ch, ++chunk_id) {
             if ((chunk_id & (PJ_DET_T / 64 - 1)) != wave) continue;
-            if (v4) pj_emb_accum<4>(a, tile, ch, acc); else pj_emb_accum<1>(a, tile, ch, acc);
+            if (v4) pj_emb_accum<4>(a, tile, ch, acc, threadIdx.x); else pj_emb_accum<1>(a, tile, ch, acc, threadIdx.x);
         }
     }
 #pragma unroll
@@ -284,8 +143,8 @@ __global__ __launch_bounds__(256, PJ_OCC) void pool_jobs_kernel(PJobs t, int fwd
         else pj_fwd<1>(a, bx, by, fwd_rows, &fold[0][0][0]);
     }
     else if (a.kind == PJ_GRAM) pj_gram(a, rel, &fold[0][0][0], 256);
-    else if (a.kind == PJ_BWD_POOL) { if (v4) pj_bwd_pool<4>(a, bx, fold); else pj_bwd_pool<1>(a, bx, fold); }
-    else { if (v4) pj_bwd_emb<4>(a, bx, by); else pj_bwd_emb<1>(a, bx, by); }
+    else if (a.kind == PJ_BWD_POOL) { if (v4) pj_bwd_pool<4>(a, bx, fold, threadIdx.x); else pj_bwd_pool<1>(a, bx, fold, threadIdx.x); }
+    else { if (v4) pj_bwd_emb<4>(a, bx, by, threadIdx.x); else pj_bwd_emb<1>(a, bx, by, threadIdx.x); }
 }
 
 // Host side: fill one job and its block range; returns the number of blocks.
@@ -348,6 +207,32 @@ GPTST_INTERNAL int gptst_pj_embed_table(PJobs* t, int njobs, const int* kind, co
                 if (j.cols % 12 || pj_gram_rows(j.K, j.cols) <= 0) return GPTST_EARG;
                 j.blk0 = *ngw; *ngw += pj_blocks(j);
             }
+            t->j[t->n++] = j;
+        }
+    }
+    return GPTST_OK;
+}
+
+// Table of gradient-reduction jobs (kinds 1 and 2) for a backward launch that carries them as a role (cap_mfma.hip, gptst_cap_cross_route_lin_bwd_jobs): the kind-1
+// jobs first, each kind numbered in its own space of 256-thread blocks.  GPTST_ESHAPE: the caller runs gptst_pool_jobs instead (deterministic mode: the kind-2
+// jobs have their single-owner launch; another kind; too many jobs).
+GPTST_INTERNAL int gptst_pj_reduce_table(PJobs* t, int njobs, const int* kind, const void* const* emb, const void* const* x, const void* const* pool,
+                                         const void* const* out, const int* R, const int* K, const int* cols, const int* nsplit, const int* ldx,
+                                         int* npool, int* npb, int* neb) {
+    if (njobs > PJ_MAX || g_deterministic) return GPTST_ESHAPE;
+    t->n = 0;
+    *npool = *npb = *neb = 0;
+    for (int pass = 0; pass < 2; ++pass) {
+        for (int p = 0; p < njobs; ++p) {
+            if (kind[p] != PJ_BWD_POOL && kind[p] != PJ_BWD_EMB) return GPTST_ESHAPE;
+            if ((kind[p] == PJ_BWD_EMB) != (pass == 1)) continue;
+            PJob j{(const float*)emb[p], (const float*)x[p], (const float*)pool[p], (float*)out[p], R[p], K[p], cols[p], nsplit[p], 0, kind[p], 0, ldx ? ldx[p] : 0};
+            if (j.R <= 0 || j.K <= 0 || j.K > PG_MAXK || j.cols <= 0 || j.nsplit <= 0 || !j.out || !j.x) return GPTST_EARG;
+            if (kind[p] == PJ_BWD_POOL ? !j.emb : !j.pool) return GPTST_EARG;
+            if (j.ldx <= 0) j.ldx = j.cols;
+            if (j.ldx < j.cols) return GPTST_EARG;
+            if (pass == 0) { j.blk0 = *npb; *npb += pj_blocks(j); ++*npool; }
+            else { j.blk0 = *neb; *neb += pj_blocks(j); }
             t->j[t->n++] = j;
         }
     }

@@ -74,12 +74,39 @@ class Reductions:
     small launches per STHCN.  Nothing on the critical chain waits for these results; only the optimiser does."""
 
     def __init__(self):
-        self.jobs = ops.PoolJobs()
+        self.jobs = ops.PoolJobs()   # reductions whose inputs are complete when they are queued (their producer has been launched)
+        self.late = ops.PoolJobs()   # reductions over dA, which gram_bwd writes in _run(): never carried by an earlier launch
+        self.no_carry = False        # (deterministic steppers: one reduction launch, as the single-owner kind-2 launch groups by target)
         self.grams = []          # (A (L*N,Hm,T), dG (L*N,T,T), dA out)
         self.tf = []             # (params, grads, dout, rows, K)
         self.keep = []
         self.on_bucket = None    # callable(k): gradient bucket k is complete (k = 0: the decoder's) — called on the forked stream, right behind
         self.nbucket = 0         # the reductions that finish it, so a data-parallel step can enqueue that bucket's all-reduce under the rest of the backward
+
+    def take_carry(self, mb):
+        """Up to `mb` MB of the queued reductions for a backward launch that carries them as role workgroups (ops.cap_cross_route_lin_bwd jobs=): the
+        decoder's reductions under the encoder's routing backward.  None: nothing to carry / not in this step (data-parallel bucket overlap: the bucket's
+        reductions run where the bucket closes; node shards; deterministic mode)."""
+        if not CARRY_RED or self.no_carry or self.on_bucket is not None or CTX.NODE_REDUCE is not None or not self.jobs.jobs:
+            return None
+        take, rest, nb = [], [], 0.0
+        for j in self.jobs.jobs:
+            b = 4.0 * j[5] * j[7] * j[8] / 2 ** 20                # R * cols * nsplit floats
+            if j[0] in (ops.PoolJobs.BWD_POOL, ops.PoolJobs.BWD_EMB) and nb + b <= mb and len(take) < 100:
+                take.append(j); nb += b
+            else:
+                rest.append(j)
+        if not take:
+            return None
+        self.jobs.jobs = rest
+        c = ops.PoolJobs()
+        c.jobs = take
+        return c
+
+    def untake(self, carry):
+        if carry is not None and carry.jobs:
+            self.jobs.jobs = carry.jobs + self.jobs.jobs
+            carry.jobs = []
 
     def gram(self, A, dG, dA, N, nsG):
         """A (L*N,Hm,T), dG (L, nsG, N, T, T) partial graph gradients, dA (L*N,Hm,T) output"""
@@ -94,7 +121,7 @@ class Reductions:
         """A gradient bucket is complete (a data-parallel step, GPTST_DP_OVERLAP=1; no-op otherwise): its reductions run HERE, on the calling
         stream (as a side branch their ~1300 bandwidth-bound workgroups slowed the chain they ran under by more than they hid: 717 vs 752
         steps/s at one rank), and only the bucket's all-reduce — a few RCCL workgroups — is forked under the rest of the backward."""
-        if getattr(self, "bucket_inline", False) and self.on_bucket is not None and self.nbucket == 0 and (self.jobs.jobs or self.grams or self.tf):
+        if getattr(self, "bucket_inline", False) and self.on_bucket is not None and self.nbucket == 0 and (self.jobs.jobs or self.late.jobs or self.grams or self.tf):
             self._run(tidx)
             self.fork_side.wait_stream(torch.cuda.current_stream())
             with torch.cuda.stream(self.fork_side):
@@ -119,6 +146,7 @@ class Reductions:
                 dG = torch.as_strided(dG, (dG.shape[0] + dG2.shape[0],) + tuple(dG.shape[1:]), dG.stride())
                 dA = torch.as_strided(dA, (dA.shape[0] + dA2.shape[0],) + tuple(dA.shape[1:]), dA.stride())
             ops.gram_bwd(A, dG, out=dA, layers=A.shape[0] // N, nsplit=nsG)
+        self.jobs.jobs, self.late.jobs = self.jobs.jobs + self.late.jobs, []
         self.jobs.launch()
         tf, self.tf = self.tf, []
         ops.timefeat_jobs_bwd(tf, tidx)
@@ -225,6 +253,8 @@ def hypertem_core_bwd(saved, dout, dG_out, dims, chain=False, premul=False):
     return dx, (dWbt, ns, (dbias, nsb))
 
 
+CARRY_RED = os.environ.get("GPTST_CARRY_RED", "1") == "1"        # queued weight-gradient reductions as role workgroups of the routing backward (r05, late)
+CARRY_MB = float(os.environ.get("GPTST_CARRY_MB", "25"))        # at most this much of them per launch
 PAIR_UNDER_DP = os.environ.get("GPTST_PAIR_UNDER_DP", "1") == "1"    # the decoder-hyperTem1 / encoder-hyperTem4 pair also when the decoder's gradient bucket leaves early (r05)
 PAIR_BWD = os.environ.get("GPTST_PAIR_BWD", "1") == "1"        # two adjacent hyperTem layers' backward in one launch (r04)
 
@@ -363,9 +393,11 @@ def cap_core_bwd(p, g, pfx, saved, dout, dims, HS, HT, red, chain=False):
     gw, gb = g[pfx + "ln_p.weight"], g[pfx + "ln_p.bias"]
     if fused is None and FUSE_CROSS and CAP_LIN and C == 64 and CTX.NODE_REDUCE is None and Y is None:
         # r05: cross-time backward (role) + routing backward + the entry Linear's backward and the residual branch in ONE launch; dY never leaves LDS
+        carry = red.take_carry(CARRY_MB) if CROSS_ROLE else None      # r05: queued reductions of the layers already behind us ride in this launch
         lin = ops.cap_cross_route_lin_bwd(x.view(B, T, N, C), p[pfx + "ln_p.weight"], p[pfx + "ln_p.bias"], c, dc1, dv, s, Rt, Ht, dyn,
                                           p[pfx + "mask_template"], dout, None if chain else out, chain, B, T, HS, HT,
-                                          flags=_zeros(x, 4 * B) if CROSS_ROLE else None)
+                                          flags=_zeros(x, 4 * B) if CROSS_ROLE else None, jobs=carry)
+        red.untake(carry)                                              # (not launched: shape beyond the fused form)
         if lin is not None:
             dx, dWp, dbp, dlogit, ddyn = lin
             red.jobs.bwd_pool(_ones(dev, BT), dWp, gw.view(1, C * C))
@@ -577,6 +609,32 @@ def sthcn_bwd(p, g, pfx, tidx, sv, dout, dims, red, chain=False, premul_in=False
     d_te, d_teb, d_tes = _zeros(time_eb, *time_eb.shape), _zeros(teb, *teb.shape), _zeros(tes, *tes.shape)
     nsG = graph_grad_splits(dims)
     dG_all, dA_all = _grad_buffers(red, sv.get("slot"), N, T, Hm * T, dout, nsG)
+    # ---- gradient reductions of the generated parameters: queued as soon as a layer's partials have been launched (r05: the routing backward launches
+    # further down the chain carry them as role workgroups, red.take_carry), executed by red.flush() at the latest ----
+    J = red.jobs
+    CC, BT = C * C, B * T
+
+    def queue_ht(h, hp):
+        dWbt, ns, (dbias, nsb) = hp                              # (ns*BT, CC), possibly a column window of [dW | db] rows
+        J.bwd_pool(time_eb, dWbt, g[h + "weights_pool"].view(d, CC), nsplit=ns)
+        J.bwd_pool(time_eb, dbias, g[h + "bias_pool"], nsplit=nsb)
+        J.bwd_emb(dWbt, p[h + "weights_pool"].view(d, CC), d_te, nsplit=ns)
+        J.bwd_emb(dbias, p[h + "bias_pool"], d_te, nsplit=nsb)
+
+    def queue_cap(c, cp):
+        dWn, ns, (dbn, nsb), ddyn, dlogit = cp
+        dW2 = dWn if dWn.dim() == 2 else dWn.view(ns * N, CC)      # (ns*N, CC), possibly a column window of [dW | db] rows
+        J.bwd_pool(nes, dW2, g[c + "weights_spa"].view(d, CC), nsplit=ns)
+        J.bwd_pool(nes, dbn, g[c + "bias_spa"], nsplit=nsb)
+        J.bwd_emb(dW2, p[c + "weights_spa"].view(d, CC), dnes, nsplit=ns)
+        J.bwd_emb(dbn, p[c + "bias_spa"], dnes, nsplit=nsb)
+        dd2 = ddyn.view(B, HT * T * HS)
+        J.bwd_pool(tes, dd2, g[c + "t_adj"].view(ds, HT * T * HS))
+        J.bwd_emb(dd2, p[c + "t_adj"].view(ds, HT * T * HS), d_tes)
+        dl2 = dlogit.view(BT, HS * N)
+        J.bwd_pool(teb, dl2, g[c + "adj"].view(ds, HS * N))
+        J.bwd_emb(dl2, p[c + "adj"].view(ds, HS * N), d_teb)
+
     if isinstance(dout, PendingH1):                 # the STHCN above left its first layer to the pair launch with this one's last layer
         up = dout
         dd, _, hp4 = ht_pair_bwd(up.saved, sv["h4"], up.dd, up.dG, dG_all[3], dims, dWb1=up.dWb)
@@ -585,14 +643,19 @@ def sthcn_bwd(p, g, pfx, tidx, sv, dout, dims, red, chain=False, premul_in=False
             after_pending()
     else:
         dd, hp4 = hypertem_core_bwd(sv["h4"], dout, dG_all[3], dims, chain, True)
+    queue_ht(hts[3], hp4)
     dd, cp2 = cap_core_bwd(p, g, cps[1], sv["c2"], dd, dims, HS, HT, red, chain)
+    queue_cap(cps[1], cp2)
     pair = ht_pair_bwd(sv["h3"], sv["h2"], dd, dG_all[2], dG_all[1], dims) if chain and PAIR_BWD else None
     if pair is not None:                            # hyperTem3 + hyperTem2: nothing in between (GPTST.py:267-268) -> one launch on the slab
         dd, hp3, hp2 = pair
     else:
         dd, hp3 = hypertem_core_bwd(sv["h3"], dd, dG_all[2], dims, chain, True)
         dd, hp2 = hypertem_core_bwd(sv["h2"], dd, dG_all[1], dims, chain, True)
+    queue_ht(hts[2], hp3)
+    queue_ht(hts[1], hp2)
     dd, cp1 = cap_core_bwd(p, g, cps[0], sv["c1"], dd, dims, HS, HT, red, chain)
+    queue_cap(cps[0], cp1)
     if isinstance(sv["h1"], EncIn):                 # the encoder's first layer on the low-rank input form: no input gradient tensor
         assert chain
         e = sv["h1"]
@@ -619,31 +682,11 @@ def sthcn_bwd(p, g, pfx, tidx, sv, dout, dims, red, chain=False, premul_in=False
         dd = PendingH1(sv["h1"], dd, dG_all[0], dWb)
     else:
         dd, hp1 = hypertem_core_bwd(sv["h1"], dd, dG_all[0], dims, chain, premul_in)
-    # ---- gradient reductions of all generated parameters: queued, executed by red.flush() ----
-    J = red.jobs
-    CC, BT = C * C, B * T
-    for h, (dWbt, ns, (dbias, nsb)) in zip(hts, (hp1, hp2, hp3, hp4)):
-        dW2 = dWbt                                              # (ns*BT, CC), possibly a column window of [dW | db] rows
-        J.bwd_pool(time_eb, dW2, g[h + "weights_pool"].view(d, CC), nsplit=ns)
-        J.bwd_pool(time_eb, dbias, g[h + "bias_pool"], nsplit=nsb)
-        J.bwd_emb(dW2, p[h + "weights_pool"].view(d, CC), d_te, nsplit=ns)
-        J.bwd_emb(dbias, p[h + "bias_pool"], d_te, nsplit=nsb)
+    queue_ht(hts[0], hp1)                           # (a deferred hyperTem1: its partials are written by the pair launch that opens the STHCN below)
     red.gram(A_all.view(4 * N, Hm, T), dG_all, dA_all.view(4 * N, Hm, T), N, nsG)
-    for i, h in enumerate(hts):
-        J.bwd_pool(ne, dA_all[i], g[h + "adj"].view(d, Hm * T))
-        J.bwd_emb(dA_all[i], p[h + "adj"].view(d, Hm * T), dne)
-    for c, (dWn, ns, (dbn, nsb), ddyn, dlogit) in zip(cps, (cp1, cp2)):
-        dW2 = dWn if dWn.dim() == 2 else dWn.view(ns * N, CC)      # (ns*N, CC), possibly a column window of [dW | db] rows
-        J.bwd_pool(nes, dW2, g[c + "weights_spa"].view(d, CC), nsplit=ns)
-        J.bwd_pool(nes, dbn, g[c + "bias_spa"], nsplit=nsb)
-        J.bwd_emb(dW2, p[c + "weights_spa"].view(d, CC), dnes, nsplit=ns)
-        J.bwd_emb(dbn, p[c + "bias_spa"], dnes, nsplit=nsb)
-        dd2 = ddyn.view(B, HT * T * HS)
-        J.bwd_pool(tes, dd2, g[c + "t_adj"].view(ds, HT * T * HS))
-        J.bwd_emb(dd2, p[c + "t_adj"].view(ds, HT * T * HS), d_tes)
-        dl2 = dlogit.view(BT, HS * N)
-        J.bwd_pool(teb, dl2, g[c + "adj"].view(ds, HS * N))
-        J.bwd_emb(dl2, p[c + "adj"].view(ds, HS * N), d_teb)
+    for i, h in enumerate(hts):                                  # (dA_all is written by gram_bwd at flush time: the late table)
+        red.late.bwd_pool(ne, dA_all[i], g[h + "adj"].view(d, Hm * T))
+        red.late.bwd_emb(dA_all[i], p[h + "adj"].view(d, Hm * T), dne)
     red.timefeat(p, g, pfx + "time_feature1.", tidx, d_te)
     red.timefeat(p, g, pfx + "time_feature1_.", tidx, d_teb)
     red.timefeat(p, g, pfx + "time_feature2.", tidx, d_tes, spg=True)

@@ -155,6 +155,7 @@ class PretrainStep:
         # time embeddings + every generated parameter: 3 launches; r05: the STHCNs' forward jobs wait for the mask's launch (_part2_impl)
         gen = engine.gen_all(p, tidx, dims, guide=need_guide, defer=DEFER_GEN)
         red = engine.Reductions()
+        red.no_carry = self.deterministic
         self._dec_reduced = False
         if self.dp_overlap and self._dp_in_graph():
             red.on_bucket = self._bucket_ready

@@ -26,7 +26,7 @@ extern "C" {
 #pragma GCC visibility push(default)
 #endif
 
-#define GPTST_ABI_VERSION 13  /* 13 (r05, late): + gptst_mask_u24_fwd_jobs (forward generation jobs inside the cooperative mask launch); 12 (r05, late): + gptst_mask_cooperative (gptst_mask_*_u24 with 8192 < M <= 65536 cells and a workspace: ONE cooperative launch); 11 (r05): + gptst_cap_cross_route_lin_bwd, gptst_comm_available, gptst_handoff_reset, gptst_set_handoff_guard (gptst_clip_adam: stats_out[5] = expiries on record); - gptst_cap_rec_cross_route_bwd (three-role form, measured slower); 9, 10 (r04, late): + gptst_hypertem_bwd_pair, gptst_cap_rec_cross_route_bwd, gptst_mask_*_u24, gptst_pool_jobs_gram_rows, gptst_handoff_timeouts; gptst_fusion_gate_fwd/bwd */
+#define GPTST_ABI_VERSION 14  /* 14 (r05, late): + gptst_cap_cross_route_lin_bwd_jobs (gradient-reduction jobs as a role of the routing backward); 13 (r05, late): + gptst_mask_u24_fwd_jobs (forward generation jobs inside the cooperative mask launch); 12 (r05, late): + gptst_mask_cooperative (gptst_mask_*_u24 with 8192 < M <= 65536 cells and a workspace: ONE cooperative launch); 11 (r05): + gptst_cap_cross_route_lin_bwd, gptst_comm_available, gptst_handoff_reset, gptst_set_handoff_guard (gptst_clip_adam: stats_out[5] = expiries on record); - gptst_cap_rec_cross_route_bwd (three-role form, measured slower); 9, 10 (r04, late): + gptst_hypertem_bwd_pair, gptst_cap_rec_cross_route_bwd, gptst_mask_*_u24, gptst_pool_jobs_gram_rows, gptst_handoff_timeouts; gptst_fusion_gate_fwd/bwd */
 int gptst_abi_version(void);
 /* 1: bit-reproducible steps — the two reductions that end in float atomics by default (embedding gradients of gptst_pool_jobs kind 2,
  * weight gradients of gptst_timefeat_jobs) run as single-owner kernels with a fixed summation order (slower).  Everything else is
@@ -262,6 +262,18 @@ int gptst_cap_cross_route_lin_bwd(const float* X, const float* Wp, const float* 
                                   const float* s, const float* Rt, const float* Ht, const float* dyn, const float* tmpl,
                                   const float* dPre, const float* out, int premul, float* dX, float* dWp, float* dbp, float* dlogit,
                                   float* ddyn, float* dS_ws, void* flags, int B, int T, int N, int C, int HS, int HT, void* stream);
+/* r05, late — gptst_cap_cross_route_lin_bwd followed by gptst_pool_jobs(njobs, ...) with gradient-reduction jobs (kinds 1 and 2 only), in ONE launch where the
+ * role form serves (dS_ws and flags given, not the deterministic mode): the jobs run as further role workgroups behind the routing workgroups, on the CUs and the
+ * HBM bandwidth this launch leaves idle (384 routing workgroups on 256 CUs at ~2.3 TB/s).  The jobs' inputs must have been written by EARLIER launches of the
+ * stream and nothing in this launch reads their outputs (the steppers: the decoder's weight-gradient reductions under the encoder's routing backward).
+ * Otherwise exactly the two calls.  Same results either way (kind-2 outputs are float atomics as in gptst_pool_jobs). */
+int gptst_cap_cross_route_lin_bwd_jobs(const float* X, const float* Wp, const float* bp, const float* c, const float* dc1, const float* dv,
+                                       const float* s, const float* Rt, const float* Ht, const float* dyn, const float* tmpl,
+                                       const float* dPre, const float* out, int premul, float* dX, float* dWp, float* dbp, float* dlogit,
+                                       float* ddyn, float* dS_ws, void* flags, int B, int T, int N, int C, int HS, int HT,
+                                       int njobs, const int* jkind, const void* const* jemb, const void* const* jx, const void* const* jpool,
+                                       const void* const* jout, const int* jR, const int* jK, const int* jcols, const int* jnsplit, const int* jldx,
+                                       void* stream);
 
 /* ---- cap for node counts whose (b,t) capsule matrix does not fit LDS (cap_big.hip; BASELINE config 5: N = 4096, C = 128) ----
  * gptst_cap_fits_lds() == 0 -> the host composes the same algebra from these streaming kernels (ops.py: cap_route_fwd/bwd, cap_rec_*):
