@@ -1105,6 +1105,73 @@ def test_cap_route_lin_bwd_equals_route_bwd_plus_linear_bwd(B, N, HS, HT, mode):
             close(dbp2.sum(0), dbp1.sum(0).cpu(), tol=2e-6, what="route_lin dbp")
 
 
+@pytest.mark.parametrize("B,N,det", [(32, 170, 0), (3, 37, 0), (32, 170, 1)])
+def test_cap_route_lin_bwd_carries_reduction_jobs(B, N, det):
+    """gptst_cap_cross_route_lin_bwd_jobs (r05): a table of gradient-reduction jobs (gptst_pool_jobs kinds 1 / 2) rides in the routing backward's launch as
+    role workgroups.  The launch's own outputs are bit-identical to the plain call; the pool gradients (owned elements) are bit-identical to gptst_pool_jobs,
+    the embedding gradients (float atomics) agree to rounding.  det = 1 (gptst_set_deterministic): the same call runs its two launches instead."""
+    from gptst_amd import ops
+    dev = _dev()
+    g = torch.Generator().manual_seed(74)
+    C, T, HS, HT = 64, 12, 10, 16
+    s = rnd(B * T, HS, C, g=g).to(dev)
+    dyn = (rnd(B, HT, T * HS, g=g) * 0.3).to(dev)
+    tmpl = (torch.arange(1, T + 1) / 12.0).float().to(dev)
+    c = torch.softmax(rnd(B * T, HS, N, g=g), 1).to(dev).contiguous()
+    _, Ht, Rt = ops.cap_cross_fwd(s, dyn, tmpl, B, T, HS, HT)
+    X = rnd(B, T, N, C, g=g).to(dev)
+    Wp, bp = (rnd(C, C, g=g) * 0.1).to(dev), rnd(C, g=g).to(dev)
+    dc1, dv = rnd(B * T, HS, N, g=g).to(dev), rnd(B * T, HS, C, g=g).to(dev)
+    dout = rnd(B * T * N, C, g=g).to(dev)
+    d = 10
+    # reduction problems of the shapes a step queues: time-conditioned weights (B*T rows of C*C + C), node-conditioned weights in three row splits,
+    # a scalar-column matrix (HS * N = 1700 / 370), and one-row "sum the partials" jobs
+    te, ne = rnd(B * T, d, g=g).to(dev), rnd(N, d, g=g).to(dev)
+    dWb = rnd(B * T, C * C + C, g=g).to(dev)
+    dWn = rnd(3 * N, C * C + C, g=g).to(dev)
+    dl = rnd(B * T, HS * N, g=g).to(dev)
+    pool_w, pool_b, pool_l = rnd(d, C * C, g=g).to(dev), rnd(d, C, g=g).to(dev), rnd(d, HS * N, g=g).to(dev)
+    ones = torch.ones(B * T, 1, device=dev)
+
+    def table():
+        pj = ops.PoolJobs()
+        outs = [torch.zeros(d, C * C, device=dev), torch.zeros(d, C, device=dev), torch.zeros(d, C * C, device=dev), torch.zeros(d, HS * N, device=dev),
+                torch.zeros(1, C * C, device=dev), torch.zeros(B * T, d, device=dev), torch.zeros(N, d, device=dev)]
+        pj.bwd_pool(te, dWb[:, :C * C], outs[0])
+        pj.bwd_pool(te, dWb[:, C * C:], outs[1])
+        pj.bwd_pool(ne, dWn[:, :C * C], outs[2], nsplit=3)
+        pj.bwd_pool(te, dl, outs[3])
+        pj.bwd_pool(ones, dWb[:, :C * C], outs[4])
+        pj.bwd_emb(dWb[:, :C * C], pool_w, outs[5])
+        pj.bwd_emb(dWb[:, C * C:], pool_b, outs[5])
+        pj.bwd_emb(dl, pool_l, outs[5])
+        pj.bwd_emb(dWn[:, :C * C], pool_w, outs[6], nsplit=3)
+        return pj, outs
+
+    ref = ops.cap_cross_route_lin_bwd(X, Wp, bp, c, dc1, dv, s, Rt, Ht, dyn, tmpl, dout, None, True, B, T, HS, HT, flags=torch.zeros(4 * B, device=dev))
+    if ref is None:
+        pytest.skip("the one-launch routing backward does not serve this shape")
+    pj, ref_out = table()
+    pj.launch()
+    ops.set_deterministic(det)
+    try:
+        for rep in range(3):
+            pj, outs = table()
+            got = ops.cap_cross_route_lin_bwd(X, Wp, bp, c, dc1, dv, s, Rt, Ht, dyn, tmpl, dout, None, True, B, T, HS, HT,
+                                              flags=torch.zeros(4 * B, device=dev), jobs=pj)
+            assert got is not None and not pj.jobs
+            for a, b in zip(got, ref):
+                assert torch.equal(a, b), rep
+            for k, (a, b) in enumerate(zip(outs, ref_out)):
+                if k < 5:
+                    assert torch.equal(a, b), (rep, k)
+                else:
+                    close(a, b.cpu(), tol=2e-6, what="carried embedding gradient")
+    finally:
+        ops.set_deterministic(0)
+    assert _handoff_timeouts() == 0
+
+
 @pytest.mark.parametrize("B,N", [(32, 170), (3, 37), (9, 16)])
 def test_hypertem_bwd_pair_equals_two_layer_calls(B, N):
     """gptst_hypertem_bwd_pair (two adjacent hyperTem layers' backward on the slab, the lower layer's weight-gradient role fed by write-through
