@@ -1221,6 +1221,21 @@ GPTST_INTERNAL int gptst_pj_reduce_table(PJobs* t, int njobs, const int* kind, c
                                          int* npool, int* npb, int* neb);
 extern "C" int gptst_pool_jobs(int njobs, const int* kind, const void* const* emb, const void* const* x, const void* const* pool,
                                const void* const* out, const int* R, const int* K, const int* cols, const int* nsplit, const int* ldx, void* stream);
+// 1: gptst_cap_cross_route_lin_bwd at this shape runs the cross-time backward as a ROLE (dS_ws / flags given) — the form that also carries reduction jobs
+// (gptst_cap_cross_route_lin_bwd_jobs); 0: a caller with jobs to place keeps them for its reduction launch (the _jobs entry would run them as a launch of their own).
+extern "C" int gptst_cap_route_roles_ok(int B, int T, int N, int C, int HS, int HT) {
+    if (C != 64 || HS > 64 || HS <= 0 || B <= 0 || N <= 0 || T != 12 || g_cap_bwd_noroles) return 0;
+    const int NR = cm_rows(N), NP = cm_np(N), HSP = cm_hsp(HS), BT = B * T, nB = B * CX_SPLIT;
+    size_t r2 = (size_t)C * C, need = (size_t)2 * HSP * NP;
+    if (need > r2) r2 = need;
+    r2 = (r2 + 3) & ~(size_t)3;
+    const size_t smem = ((size_t)NR * Tile<64>::PITCH + r2 + (size_t)HSP * Tile<64>::PITCH + 2 * (size_t)NR + 4) * sizeof(float);
+    const int no = (12 / CX_SPLIT) * HS;
+    const size_t need_r = (size_t)(T * HS + 2 * HT + 2 * no) * Tile<64>::PITCH + (size_t)HT * T * HS;
+    if (smem > 80 * 1024 || BT + nB > 512 || need_r > (size_t)NR * Tile<64>::PITCH + r2 || (HT * T * HS) % 4 != 0) return 0;
+    return smem >= 2 * (4 * PG_MAXK * 65) * sizeof(float) ? 1 : 0;
+}
+
 extern "C" int gptst_cap_cross_route_lin_bwd_jobs(const float* X, const float* Wp, const float* bp, const float* c, const float* dc1, const float* dv,
                                                   const float* s, const float* Rt, const float* Ht, const float* dyn, const float* tmpl,
                                                   const float* dPre, const float* out, int premul, float* dX, float* dWp, float* dbp, float* dlogit,

@@ -10,7 +10,7 @@ import threading
 
 import torch
 
-from . import ops
+from . import _C, ops
 from .ops import (EPI_ADD_DPRE, EPI_ADD_PREMUL, EPI_LRELU, EPI_PREMUL, EPI_PLAIN, EPI_RES_LRELU, MODE_NODE, MODE_SHARED, MODE_TIME, PRO_DPRE, PRO_NONE)
 
 TF_NAMES = ("ln_day", "ln_week", "ln1", "ln2", "ln")
@@ -92,7 +92,7 @@ class Reductions:
         take, rest, nb = [], [], 0.0
         for j in self.jobs.jobs:
             b = 4.0 * j[5] * j[7] * j[8] / 2 ** 20                # R * cols * nsplit floats
-            if j[0] in (ops.PoolJobs.BWD_POOL, ops.PoolJobs.BWD_EMB) and nb + b <= mb and len(take) < 100:
+            if j[0] in (ops.PoolJobs.BWD_POOL, ops.PoolJobs.BWD_EMB) and nb + b <= mb and len(take) < 100 and (j[7] | j[9]) % 4 == 0:     # (float4-shaped jobs only)
                 take.append(j); nb += b
             else:
                 rest.append(j)
@@ -393,7 +393,8 @@ def cap_core_bwd(p, g, pfx, saved, dout, dims, HS, HT, red, chain=False):
     gw, gb = g[pfx + "ln_p.weight"], g[pfx + "ln_p.bias"]
     if fused is None and FUSE_CROSS and CAP_LIN and C == 64 and CTX.NODE_REDUCE is None and Y is None:
         # r05: cross-time backward (role) + routing backward + the entry Linear's backward and the residual branch in ONE launch; dY never leaves LDS
-        carry = red.take_carry(CARRY_MB) if CROSS_ROLE else None      # r05: queued reductions of the layers already behind us ride in this launch
+        # r05: queued reductions of the layers already behind us ride in this launch — where it has the role form (idle slots: B*T + 4B <= 512 workgroups)
+        carry = red.take_carry(CARRY_MB) if CROSS_ROLE and _C.lib().value("gptst_cap_route_roles_ok", B, T, N, C, HS, HT) == 1 else None
         lin = ops.cap_cross_route_lin_bwd(x.view(B, T, N, C), p[pfx + "ln_p.weight"], p[pfx + "ln_p.bias"], c, dc1, dv, s, Rt, Ht, dyn,
                                           p[pfx + "mask_template"], dout, None if chain else out, chain, B, T, HS, HT,
                                           flags=_zeros(x, 4 * B) if CROSS_ROLE else None, jobs=carry)

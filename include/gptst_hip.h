@@ -267,6 +267,8 @@ int gptst_cap_cross_route_lin_bwd(const float* X, const float* Wp, const float* 
  * HBM bandwidth this launch leaves idle (384 routing workgroups on 256 CUs at ~2.3 TB/s).  The jobs' inputs must have been written by EARLIER launches of the
  * stream and nothing in this launch reads their outputs (the steppers: the decoder's weight-gradient reductions under the encoder's routing backward).
  * Otherwise exactly the two calls.  Same results either way (kind-2 outputs are float atomics as in gptst_pool_jobs). */
+/* 1 when gptst_cap_cross_route_lin_bwd at this shape takes the role form that also carries jobs (every workgroup resident: B*T + 4 B <= 512, <= 80 KB of LDS) */
+int gptst_cap_route_roles_ok(int B, int T, int N, int C, int HS, int HT);
 int gptst_cap_cross_route_lin_bwd_jobs(const float* X, const float* Wp, const float* bp, const float* c, const float* dc1, const float* dv,
                                        const float* s, const float* Rt, const float* Ht, const float* dyn, const float* tmpl,
                                        const float* dPre, const float* out, int premul, float* dX, float* dWp, float* dbp, float* dlogit,
