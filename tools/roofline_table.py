@@ -4,7 +4,7 @@
 profiles/r05_pmc_calibration.txt), algorithmic FLOPs from bench.kernel_flops (SURVEY 8d formulas).  For every kernel of the median step: us per step,
 bytes, achieved TB/s on its ACTUAL traffic, time that traffic takes at the ~4.5 TB/s a streaming kernel reaches on this chip (tools/experiments/stream_rates.py),
 fp32-MFMA time at 157.3 TFLOP/s, and which of the two floors is the higher one.
-    python tools/roofline_table.py r05g > profiles/r05g_roofline_table.txt"""
+    python tools/roofline_table.py r05h > profiles/r05h_roofline_table.txt"""
 import json
 import os
 import re
@@ -14,12 +14,12 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 import bench  # noqa: E402
 
-tag = sys.argv[1] if len(sys.argv) > 1 else "r05g"
+tag = sys.argv[1] if len(sys.argv) > 1 else "r05h"
 STREAM_TBS, MFMA_TF = 4.5, 157.3
 d = dict(B=32, T=12, N=170, C=64, HS=10, R=3)
 pm = json.load(open(os.path.join(ROOT, "profiles", "pmc_traffic.json")))["kernels"]
 SYM2ENTRY = {
-    "void cap_route_bwd2_kernel<64, 1, true>": ("gptst_cap_cross_route_lin_bwd", ""), "void hypertem_bwd_pair_kernel<6>": ("gptst_hypertem_bwd_pair", ""),
+    "void cap_route_bwd2_kernel<64, 1, true": ("gptst_cap_cross_route_lin_bwd", ""), "void hypertem_bwd_pair_kernel<6>": ("gptst_hypertem_bwd_pair", ""),
     "void hypertem_chain_fwd_kernel<2>": ("gptst_hypertem_chain_fwd", "x2"), "void cap_route_fwd4_kernel<2>": ("gptst_cap_route_fwd", ""),
     "void applywg64_kernel<0, 1>": ("gptst_apply_wgrad", ""), "void applywg64_kernel<0, 2>": ("gptst_apply_wgrad", ""),
     "void apply64_kernel<0, 1>": ("gptst_apply", ""), "void apply64_kernel<0, 3>": ("gptst_apply", ""),
@@ -44,7 +44,7 @@ for nm, (n, us) in sorted(per.items(), key=lambda kv: -kv[1][1]):
     key = [k for k in pm if k.startswith(nm[:40]) and k.endswith(nm[-8:])]
     by = pm[key[0]]["hbm_bytes"] * n if key else 0.0
     sym = nm.rsplit(" [", 1)[0]
-    ent = SYM2ENTRY.get(sym)
+    ent = SYM2ENTRY.get(sym) or next((v for k, v in SYM2ENTRY.items() if sym.startswith(k[:40])), None)
     fl = bench.kernel_flops(ent[0], ent[1], d) * n if ent else 0.0
     t_h, t_m = by / (STREAM_TBS * 1e6), fl / (MFMA_TF * 1e6)
     tot_b += by; tot_t += t_h; tot_m += t_m
