@@ -752,6 +752,14 @@ def _fused_jobs(jobs, u24):
     if not u24 or jobs.post or any(j[0] not in (PoolJobs.FWD, PoolJobs.GRAM) for j in jobs.jobs):
         jobs.launch()
         return None
+    odd = [j for j in jobs.jobs if j[0] == PoolJobs.FWD and j[7] % 4]          # scalar-column forward jobs (HS * N = 2070 at METR_LA): a small launch of
+    if odd:                                                                      # their own, so that the rest still rides in the mask launch
+        rest = [j for j in jobs.jobs if not (j[0] == PoolJobs.FWD and j[7] % 4)]
+        jobs.jobs = odd
+        jobs.launch()
+        jobs.jobs = rest
+        if not rest:
+            return None
     js, jobs.jobs = jobs.jobs, []
     col = lambda i: [j[i] for j in js]      # noqa: E731
     return js, (len(js), _ints(col(0)), _ptrs0(col(1)), _ptrs0(col(3)), _ptrs0(col(4)), _ints(col(5)), _ints(col(6)), _ints(col(7)))
