@@ -731,7 +731,7 @@ static void apply128_geometry(const RowMap& rm, bool has_colsum, int& tpw, int& 
     // few, short groups (one rank's 512-node share of configs[4]: 384 groups x 32 tiles): tiles per wave halved until ~3 workgroups per CU exist
     // (r05: 8 -> 4 -> 2 keeps every wave of a workgroup busy; the 1024-workgroup rule of round 4 ended at one tile per wave, i.e. a 64 KB weight
     // staged per 8 tiles: 148 -> 152.5 steps/s on that share)
-    while (tpw > 1 && !(has_colsum && rm.G == 1) && (long)rm.G * ((ntiles + AP128_NW * tpw - 1) / (AP128_NW * tpw)) < g_apply128_minwg) tpw >>= 1;
+    while (tpw > 1 && !(has_colsum && rm.G == 1) && (long)rm.G * ((ntiles + AP128_NW * tpw - 1) / (AP128_NW * tpw)) < g_apply128_minwg) tpw = (tpw + 1) >> 1;
     if (g_apply_tpw > 0) tpw = g_apply_tpw;
     if (tpw < 1) tpw = 1;
     gy = (ntiles + AP128_NW * tpw - 1) / (AP128_NW * tpw);
