@@ -53,7 +53,7 @@ def kernel_flops(name, tag, d):
         return 2.0 * rows * C * C + (2 * R + 2) * 2.0 * B * T * HS * N * C
     if name in ("gptst_cap_route_bwd", "gptst_cap_cross_route_bwd"):
         return 2.0 * rows * C * C + 2 * 2.0 * B * T * HS * N * C
-    if name in ("gptst_cap_cross_route_lin_bwd", "gptst_cap_cross_route_lin_bwd_jobs"):   # (_jobs: + carried reduction jobs — bandwidth work, no FLOPs counted)
+    if name in ("gptst_cap_cross_route_lin_bwd", "gptst_cap_cross_route_lin_bwd_jobs", "gptst_cap_cross_route_lin_bwd_split"):   # (_jobs: + carried reduction jobs — bandwidth work, no FLOPs counted)
         # r05: + the entry Linear's backward: dX = dY Wp and dWp = dY^T X on top of the routing backward
         return 6.0 * rows * C * C + 2 * 2.0 * B * T * HS * N * C
     if name in ("gptst_apply_wgrad", "gptst_linear_bwd"):
@@ -70,7 +70,7 @@ KERNEL_SYMBOL = {
     "gptst_cap_route_fwd": "void cap_route_fwd", "gptst_cap_route_bwd": "void cap_route_bwd2_kernel<64",
     "gptst_hypertem_fwd": "hypertem_fwd_kernel", "gptst_hypertem_bwd": "hypertem_bwd_kernel", "gptst_wgrad": "void wgrad64_kernel",
     "gptst_hypertem_bwd_wgrad": "void hypertem_bwd_wgrad_kernel<", "gptst_cap_cross_route_bwd": "void cap_route_bwd2_kernel<64",
-    "gptst_cap_cross_route_lin_bwd": "void cap_route_bwd2_kernel<64", "gptst_cap_cross_route_lin_bwd_jobs": "void cap_route_bwd2_kernel<64", "gptst_hypertem_bwd_pair": "void hypertem_bwd_pair_kernel<", "gptst_hypertem_chain_fwd": "void hypertem_chain_fwd_kernel<",
+    "gptst_cap_cross_route_lin_bwd": "void cap_route_bwd2_kernel<64", "gptst_cap_cross_route_lin_bwd_jobs": "void cap_route_bwd2_kernel<64", "gptst_cap_cross_route_lin_bwd_split": "void cap_route_bwd2_kernel<64", "gptst_hypertem_bwd_pair": "void hypertem_bwd_pair_kernel<", "gptst_hypertem_chain_fwd": "void hypertem_chain_fwd_kernel<",
     "gptst_cap_cross_rec_fwd": "void cap_cross_rec_fwd_kernel<64>", "gptst_apply_wgrad": "void applywg64_kernel<0,", "gptst_linear_bwd": "void applywg64_kernel<1,",
     "gptst_apply": "void apply64_kernel<", "gptst_tmix": "void tmix_kernel<64", "gptst_tmix_dgraph": "void tmix_dgraph_kernel<64>",
     "gptst_cap_rec_bwd": "void cap_rec_bwd2_kernel<64>", "gptst_cap_cross_bwd": "void cap_cross_bwd_kernel<64>",
@@ -95,7 +95,7 @@ def kernel_source_hash():
 # dY and the saved X and writes dX (3A).  hyperTem is one launch per direction; a cap layer's 2A / 3A are spread over its launches: X read
 # by the routing kernels, the layer output written by the node-conditioned apply, dOut read by its backward, dX written by the entry-Linear backward.
 ALG_8D_A = {"gptst_hypertem_fwd": 2.0, "gptst_hypertem_bwd": 3.0, "gptst_hypertem_bwd_wgrad": 3.0, "gptst_hypertem_bwd_pair": 6.0, "gptst_cap_route_fwd": 1.0,
-            "gptst_cap_cross_route_bwd": 1.0, "gptst_cap_cross_route_lin_bwd": 2.0, "gptst_cap_cross_route_lin_bwd_jobs": 2.0, "gptst_cap_route_bwd": 1.0, "gptst_apply": 1.0, "gptst_apply_wgrad": 1.0, "gptst_linear_bwd": 1.0,
+            "gptst_cap_cross_route_bwd": 1.0, "gptst_cap_cross_route_lin_bwd": 2.0, "gptst_cap_cross_route_lin_bwd_jobs": 2.0, "gptst_cap_cross_route_lin_bwd_split": 2.0, "gptst_cap_route_bwd": 1.0, "gptst_apply": 1.0, "gptst_apply_wgrad": 1.0, "gptst_linear_bwd": 1.0,
             "gptst_cap_cross_rec_fwd": 0.0, "gptst_cap_rec_fwd": 0.0, "gptst_cap_rec_bwd": 0.0}
 
 

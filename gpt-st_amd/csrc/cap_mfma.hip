@@ -683,7 +683,7 @@ __global__ __launch_bounds__(CM_NT, 4) void cap_route_bwd2_kernel(const float* _
                                                                   const float* __restrict__ bp, const float* __restrict__ c,
                                                                   const float* __restrict__ dc1, const float* __restrict__ dS,
                                                                   float* __restrict__ dY, float* __restrict__ dlogit, int N, int HS,
-                                                                  int region2, CrossBwdArgs cx, LinArgs lin, RouteJobs<JOBS> jr) {
+                                                                  int region2, CrossBwdArgs cx, LinArgs lin, RouteJobs<JOBS> jr, int nfull, int nhr) {
     if constexpr (JOBS) {
         if ((int)blockIdx.x >= jr.first) {
             extern __shared__ __attribute__((aligned(16))) float jsmem[];
@@ -735,6 +735,7 @@ __global__ __launch_bounds__(CM_NT, 4) void cap_route_bwd2_kernel(const float* _
     unsigned* s_ok = reinterpret_cast<unsigned*>(qq + NR);
     GPTST_WG_BEGIN(); GPTST_STAMP(0);
     const int blk = (int)blockIdx.x;
+    int ru;                                              // routing work unit of this workgroup
     if (ROLES && blk < cx.nB) {                          // cross-time role: workgroup r = (sample r / CX_SPLIT, time steps of part r % CX_SPLIT)
         constexpr int TS = 12 / CX_SPLIT;
         cap_cross_bwd_prologue<C, true>(cx.dv, cx.s, cx.Rt, cx.Ht, cx.dyn, cx.tmpl, cx.ddyn, smem, nullptr, blk / CX_SPLIT,
@@ -742,10 +743,26 @@ __global__ __launch_bounds__(CM_NT, 4) void cap_route_bwd2_kernel(const float* _
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");            // every storing wave drains its write-through stores ...
         __syncthreads();
         if (tid == 0) { gptst_publish_fence(); __hip_atomic_store(cx.flags + blk, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }     // ... before the flag goes up
-        GPTST_STAMP(1); GPTST_WG_END();
-        return;
+        GPTST_STAMP(1);
+        if (blk >= nhr) { GPTST_WG_END(); return; }
+        // r06: the first nhr role workgroups go on with a node HALF (below) — a role is a 12-us latency chain that leaves the CU's matrix pipe idle, a half
+        // is what the CU lacks for an even load; with the halves behind the roles' slots instead, the last of them start when the roles END (measured:
+        // profiles/r06_node_halves.txt).  Their own role is done before they wait for anybody's flag.
+        ru = nfull + blk;
+        __syncthreads();
+    } else {
+        // r06 NODE HALVES: routing work unit ru < nfull is the whole (b,t) = ru; the units behind are the two node halves (tiles [0, th) / [th, ntiles)) of
+        // (b,t) = nfull + (ru - nfull) / 2 — see gptst_cap_split_units().  Everything below is per node tile, so a half needs no exchange with the other
+        // one: only its weight / bias gradient partial is a row of its own (row ru of dWp / dbp: B*T + nsplit rows).
+        const int r = ROLES ? blk - cx.nB : blk;
+        ru = r < nfull ? r : r + nhr;                  // (halves 0 .. nhr-1 ride behind the roles)
     }
-    const int bt = ROLES ? blk - cx.nB : blk;
+    int bt = ru, tlo = 0, thi = NR / 16;
+    if (ru >= nfull) {
+        const int k = ru - nfull, th = (NR / 16 + 1) >> 1;
+        bt = nfull + (k >> 1);
+        if (k & 1) tlo = th; else thi = th;
+    }
     const float* Xbt = X + (size_t)bt * N * C;
     const bool fold = !ROLES && cx.dv != nullptr;                  // dS out of the cross-time backward computed HERE (uniform)
     if constexpr (!ROLES) {
@@ -761,7 +778,7 @@ __global__ __launch_bounds__(CM_NT, 4) void cap_route_bwd2_kernel(const float* _
         // ---- Y = X Wp^T + bp, q = |Y|^2, g = squash factor: fused MFMA epilogue as in the forward ----
         const int j = lane & 15, kk = lane >> 4;
         float4 a[4];
-        cm_fetch_a16(a, Xbt, wave, N, j, kk);
+        cm_fetch_a16(a, Xbt, tlo + wave, N, j, kk);
         const float4 b4 = ld4(bp + 4 * j);
         load_w_lds<C, CM_NT>(Wl, Wp, 1, tid);
         if (!fold) for (int i = tid; i < HSP * P; i += CM_NT) Vs[i] = 0.f;
@@ -769,8 +786,8 @@ __global__ __launch_bounds__(CM_NT, 4) void cap_route_bwd2_kernel(const float* _
         GPTST_STAMP(2);
         float4 bv[4][4];
         cm_load_bfrag(bv, Wl, j, kk);
-        for (int tile = wave; tile < NR / 16; tile += CM_NW) {
-            if (tile != wave) cm_fetch_a16(a, Xbt, tile, N, j, kk);
+        for (int tile = tlo + wave; tile < thi; tile += CM_NW) {
+            if (tile != tlo + wave) cm_fetch_a16(a, Xbt, tile, N, j, kk);
             float4 y[4];
             cm_tile16(a, bv, b4, y);
 #pragma unroll
@@ -890,11 +907,10 @@ __global__ __launch_bounds__(CM_NT, 4) void cap_route_bwd2_kernel(const float* _
     GPTST_STAMP(4);
 
     const int j = lane & 15, kk = lane >> 4;
-    const int ntiles = (N + 15) / 16;
     float csum[C / 16];
 #pragma unroll
     for (int ct = 0; ct < C / 16; ++ct) csum[ct] = 0.f;
-    for (int nt = wave; nt < ntiles; nt += CM_NW) {
+    for (int nt = tlo + wave; nt < thi; nt += CM_NW) {
         const int n = nt * 16 + j;                          // node of this lane as MFMA column (type 2) / row (dP)
         const float gn = gq[n];
         // ---- (a) dc = dc1 + dS.P^T on this node tile, wsum[n] = sum_h c dc ----
@@ -992,7 +1008,7 @@ __global__ __launch_bounds__(CM_NT, 4) void cap_route_bwd2_kernel(const float* _
 #define CRL_LOAD_RES(nt_) _Pragma("unroll") for (int r = 0; r < 4; ++r) {                                                   \
             const size_t off_ = ((size_t)bt * N + min((nt_) * 16 + kk_ * 4 + r, N - 1)) * 64 + 4 * j_;                         \
             sv[r] = ld4(sgn_src + off_); rv[r] = ld4(lin.dPre + off_); }
-        CRL_LOAD_RES(wave_);                                      // first tile's residual operands: in flight across the barrier and the staging
+        CRL_LOAD_RES(tlo + wave_);                                // first tile's residual operands: in flight across the barrier and the staging
 #pragma unroll
         for (int ct = 0; ct < 4; ++ct) { csum[ct] += __shfl_xor(csum[ct], 16, 64); csum[ct] += __shfl_xor(csum[ct], 32, 64); }
         __syncthreads();
@@ -1006,11 +1022,11 @@ __global__ __launch_bounds__(CM_NT, 4) void cap_route_bwd2_kernel(const float* _
             float t = 0.f;
 #pragma unroll
             for (int w = 0; w < CM_NW; ++w) t += Vs[w * 64 + tid_];
-            lin.dbp[(size_t)bt * 64 + tid_] = t;
+            lin.dbp[(size_t)ru * 64 + tid_] = t;
         }
         GPTST_STAMP(6);
-        for (int nt = wave_; nt < ntiles; nt += CM_NW) {
-            if (nt != wave_) { CRL_LOAD_RES(nt); }
+        for (int nt = tlo + wave_; nt < thi; nt += CM_NW) {
+            if (nt != tlo + wave_) { CRL_LOAD_RES(nt); }
             SB();
             unsigned sgn = 0u;                                   // bit 4r+e: the sign operand of row r / channel 4j+e is positive
 #pragma unroll
@@ -1063,14 +1079,14 @@ __global__ __launch_bounds__(CM_NT, 4) void cap_route_bwd2_kernel(const float* _
             const float* xcol = Xbt + 16 * it0 + j_;
             const float* ycol = Ys + 16 * ot + j_;
             constexpr int UB = 11;                               // k-steps per batch of loads; the next batch is requested before this one's MFMAs
-            const int nsteps = NR / 4;
+            const int sbeg = 4 * tlo, nsteps = 4 * thi;              // k-steps (4 nodes each) of this unit's node tiles
             float b0[UB], b1[UB], n0[UB], n1[UB];
 #define CRL_LOADX(d0, d1, s0_) _Pragma("unroll") for (int u = 0; u < UB; ++u) {                          \
                 const int n_ = min(4 * ((s0_) + u) + kk_, N - 1);                                          \
                 d0[u] = xcol[(size_t)n_ * 64]; d1[u] = xcol[(size_t)n_ * 64 + 16]; }
-            CRL_LOADX(b0, b1, 0);
+            CRL_LOADX(b0, b1, sbeg);
 #pragma unroll 1
-            for (int s0 = 0; s0 < nsteps; s0 += UB) {
+            for (int s0 = sbeg; s0 < nsteps; s0 += UB) {
                 if (s0 + UB < nsteps) { CRL_LOADX(n0, n1, s0 + UB); }
                 float av[UB];
 #pragma unroll
@@ -1086,7 +1102,7 @@ __global__ __launch_bounds__(CM_NT, 4) void cap_route_bwd2_kernel(const float* _
                 for (int u = 0; u < UB; ++u) { b0[u] = n0[u]; b1[u] = n1[u]; }
             }
 #undef CRL_LOADX
-            float* dw = lin.dWp + (size_t)bt * 64 * 64;
+            float* dw = lin.dWp + (size_t)ru * 64 * 64;
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 const int o = 16 * ot + 4 * kk_ + r;             // D reg r: row o, col i
@@ -1099,13 +1115,16 @@ __global__ __launch_bounds__(CM_NT, 4) void cap_route_bwd2_kernel(const float* _
     GPTST_WG_END();
 }
 
+thread_local int g_cap_split_roles = 1;     // gptst_tune(26, 0): node halves never ride behind the cross-time roles
 thread_local int g_cap_bwd_noroles = 0;       // gptst_tune(23, 1): the cross-time backward as a replicated prologue (r03) also where the role form serves
 
 template <int C>
 static int launch_route_bwd2(const float* X, const float* Wp, const float* bp, const float* c, const float* dc1, const float* dS,
                              float* dY, float* dlogit, int BT, int N, int HS, hipStream_t st, CrossBwdArgs cx = CrossBwdArgs{nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, 0, 0, nullptr, nullptr, 0},
-                             LinArgs lin = LinArgs{nullptr, nullptr, nullptr, nullptr, nullptr, 0}, RouteJobs<true>* jobs = nullptr) {
+                             LinArgs lin = LinArgs{nullptr, nullptr, nullptr, nullptr, nullptr, 0}, RouteJobs<true>* jobs = nullptr, int nsplit = 0) {
     if (HS > 64) return GPTST_ESHAPE;
+    if (nsplit < 0 || nsplit > BT || (nsplit > 0 && (C != 64 || lin.dX == nullptr))) return GPTST_EARG;      // node halves: the folded C = 64 form only
+    const int nfull = BT - nsplit;                            // routing work units: nfull whole (b,t) + 2 nsplit node halves
     if (lin.dX != nullptr && C != 64) return GPTST_ESHAPE;      // the folded Linear backward: C = 64
     const int NR = cm_rows(N), NP = cm_np(N), HSP = cm_hsp(HS);
     size_t r2 = (size_t)C * C, need = (size_t)2 * HSP * NP;
@@ -1122,40 +1141,43 @@ static int launch_route_bwd2(const float* X, const float* Wp, const float* bp, c
         const size_t need_r = (size_t)(cx.T * HS + 2 * cx.HT + 2 * no) * Tile<C>::PITCH + (size_t)cx.HT * cx.T * HS;
         if (smem > 80 * 1024 || BT + cx.nB > 512 || cx.T != 12 || need_r > (size_t)NR * Tile<C>::PITCH + r2) cx.nB = 0;
     }
+    // halves carried by role workgroups (gptst_tune(26, 0): none): the launch then has nB + nfull + (2 nsplit - nhr) workgroups ahead of the jobs
+    const int nhr = (cx.nB > 0 && g_cap_split_roles) ? (2 * nsplit < cx.nB ? 2 * nsplit : cx.nB) : 0;
+    const int NU = BT + nsplit - nhr;                         // routing workgroups behind the roles
     if (jobs != nullptr && !(cx.nB > 0 && lin.dX != nullptr && smem >= 2 * (4 * PG_MAXK * 65) * sizeof(float))) return GPTST_ESHAPE;   // (the caller then runs the jobs on their own)
     if (jobs != nullptr) {
         static size_t curJ = 0;
         if (smem > curJ) { (void)hipFuncSetAttribute((const void*)cap_route_bwd2_kernel<C, 1, true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem); curJ = smem; }
-        jobs->first = BT + cx.nB;
+        jobs->first = NU + cx.nB;
         const int njw = ((jobs->npb + 1) >> 1) + ((jobs->neb + 1) >> 1);
-        hipLaunchKernelGGL((cap_route_bwd2_kernel<C, 1, true, true>), dim3(BT + cx.nB + njw), dim3(CM_NT), smem, st, X, Wp, bp, c, dc1, dS, dY, dlogit, N, HS, (int)r2, cx, lin, *jobs);
+        hipLaunchKernelGGL((cap_route_bwd2_kernel<C, 1, true, true>), dim3(NU + cx.nB + njw), dim3(CM_NT), smem, st, X, Wp, bp, c, dc1, dS, dY, dlogit, N, HS, (int)r2, cx, lin, *jobs, nfull, nhr);
         GPTST_CHECK_LAUNCH();
         return GPTST_OK;
     }
     if (cx.nB > 0 && lin.dX != nullptr) {
         static size_t curRL = 0;
         if (smem > curRL) { (void)hipFuncSetAttribute((const void*)cap_route_bwd2_kernel<C, 1, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem); curRL = smem; }
-        hipLaunchKernelGGL((cap_route_bwd2_kernel<C, 1, true>), dim3(BT + cx.nB), dim3(CM_NT), smem, st, X, Wp, bp, c, dc1, dS, dY, dlogit, N, HS, (int)r2, cx, lin, RouteJobs<false>{});
+        hipLaunchKernelGGL((cap_route_bwd2_kernel<C, 1, true>), dim3(NU + cx.nB), dim3(CM_NT), smem, st, X, Wp, bp, c, dc1, dS, dY, dlogit, N, HS, (int)r2, cx, lin, RouteJobs<false>{}, nfull, nhr);
         GPTST_CHECK_LAUNCH();
         return GPTST_OK;
     }
     if (cx.nB > 0) {
         static size_t curR = 0;
         if (smem > curR) { (void)hipFuncSetAttribute((const void*)cap_route_bwd2_kernel<C, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem); curR = smem; }
-        hipLaunchKernelGGL((cap_route_bwd2_kernel<C, 1>), dim3(BT + cx.nB), dim3(CM_NT), smem, st, X, Wp, bp, c, dc1, dS, dY, dlogit, N, HS, (int)r2, cx, lin, RouteJobs<false>{});
+        hipLaunchKernelGGL((cap_route_bwd2_kernel<C, 1>), dim3(BT + cx.nB), dim3(CM_NT), smem, st, X, Wp, bp, c, dc1, dS, dY, dlogit, N, HS, (int)r2, cx, lin, RouteJobs<false>{}, BT, 0);
         GPTST_CHECK_LAUNCH();
         return GPTST_OK;
     }
     if (lin.dX != nullptr) {
         static size_t curL = 0;
         if (smem > curL) { (void)hipFuncSetAttribute((const void*)cap_route_bwd2_kernel<C, 0, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem); curL = smem; }
-        hipLaunchKernelGGL((cap_route_bwd2_kernel<C, 0, true>), dim3(BT), dim3(CM_NT), smem, st, X, Wp, bp, c, dc1, dS, dY, dlogit, N, HS, (int)r2, cx, lin, RouteJobs<false>{});
+        hipLaunchKernelGGL((cap_route_bwd2_kernel<C, 0, true>), dim3(NU), dim3(CM_NT), smem, st, X, Wp, bp, c, dc1, dS, dY, dlogit, N, HS, (int)r2, cx, lin, RouteJobs<false>{}, nfull, nhr);
         GPTST_CHECK_LAUNCH();
         return GPTST_OK;
     }
     static size_t cur = 0;
     if (smem > cur) { (void)hipFuncSetAttribute((const void*)cap_route_bwd2_kernel<C, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem); cur = smem; }
-    hipLaunchKernelGGL((cap_route_bwd2_kernel<C, 0>), dim3(BT), dim3(CM_NT), smem, st, X, Wp, bp, c, dc1, dS, dY, dlogit, N, HS, (int)r2, cx, lin, RouteJobs<false>{});
+    hipLaunchKernelGGL((cap_route_bwd2_kernel<C, 0>), dim3(BT), dim3(CM_NT), smem, st, X, Wp, bp, c, dc1, dS, dY, dlogit, N, HS, (int)r2, cx, lin, RouteJobs<false>{}, BT, 0);
     GPTST_CHECK_LAUNCH();
     return GPTST_OK;
 }
@@ -1236,6 +1258,60 @@ extern "C" int gptst_cap_route_roles_ok(int B, int T, int N, int C, int HS, int 
     return smem >= 2 * (4 * PG_MAXK * 65) * sizeof(float) ? 1 : 0;
 }
 
+// r06 NODE HALVES (MEASURED AND NOT ADOPTED: off by default, profiles/r06_node_halves.txt).  B*T = 384 routing workgroups on 256 CUs at
+// two per CU: half the CUs run two (b,t), the other half one.  Everything in the routing backward is per node tile, so the LAST nsplit (b,t) can be cut into
+// two node halves of their own workgroup each: B*T - nsplit whole units + 2 nsplit halves — at B*T = 1.5 CUs every CU gets one whole unit and one half (the
+// first 4 B halves ride behind the cross-time role workgroups, so that all 512 workgroups are resident from the start).  The price: a half writes its own
+// dWp / dbp partial row (B*T + nsplit rows for the reduction).  What the stamps say: a HALF lasts 33-35 us next to a whole unit's 35-40 (a whole unit next to
+// another: 41) — the workgroup is a chain of dependent phases whose length hardly depends on its tile count, the launch stays at 43 us, and the carried
+// reduction jobs lose the slots the 12-us roles used to free (857 vs 887 steps/s).  The 384-on-256 quantisation is not what bounds this launch.
+thread_local int g_cap_split = 0;             // gptst_tune(25, v): 0 = off (default), -1 = by the CU count (below), v > 0 = that many (b,t) in halves
+static int cap_cu_count() {
+    static thread_local int dev_cached = -1, ncu = 0;
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess) return 0;
+    if (dev != dev_cached) {
+        if (hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) ncu = 0;
+        dev_cached = dev;
+    }
+    return ncu;
+}
+// number of (b,t) units — the last ones — that the C = 64 routing kernels of this device cut into node halves (0: none)
+extern "C" int gptst_cap_split_units(int BT, int N, int C, int HS) {
+    if (C != 64 || HS <= 0 || HS > 64 || N < 32 || BT <= 0) return 0;
+    if (g_cap_split >= 0) return g_cap_split < BT ? g_cap_split : BT;
+    const int ncu = cap_cu_count();
+    if (ncu <= 0 || BT <= ncu || 2 * BT > 3 * ncu) return 0;      // one unit per CU already / more than 1.5: the extra halves would only queue
+    return BT - ncu;
+}
+
+static int cap_cross_route_lin_bwd_any(const float* X, const float* Wp, const float* bp, const float* c, const float* dc1, const float* dv,
+                                       const float* s, const float* Rt, const float* Ht, const float* dyn, const float* tmpl,
+                                       const float* dPre, const float* out, int premul, float* dX, float* dWp, float* dbp, float* dlogit,
+                                       float* ddyn, float* dS_ws, void* flags, int B, int T, int N, int C, int HS, int HT, int nsplit,
+                                       int njobs, const int* jkind, const void* const* jemb, const void* const* jx, const void* const* jpool,
+                                       const void* const* jout, const int* jR, const int* jK, const int* jcols, const int* jnsplit, const int* jldx,
+                                       void* stream) {
+    if (!X || !Wp || !bp || !c || !dc1 || !dv || !s || !Rt || !Ht || !dyn || !tmpl || !dPre || !dX || !dWp || !dbp || !dlogit || !ddyn || B <= 0 ||
+        T <= 0 || (out && premul) || nsplit < 0 || nsplit > B * T) return GPTST_EARG;
+    if (njobs < 0 || (njobs && (!jkind || !jemb || !jx || !jpool || !jout || !jR || !jK || !jcols || !jnsplit))) return GPTST_EARG;
+    if (C != 64) return GPTST_ESHAPE;
+    if (nsplit > 0 && N < 32) return GPTST_EARG;               // a half needs a node tile of its own
+    const bool roles = dS_ws != nullptr && flags != nullptr && !g_cap_bwd_noroles;
+    const CrossBwdArgs cx{dv, s, Rt, Ht, dyn, tmpl, ddyn, T, HT, roles ? dS_ws : nullptr, roles ? (unsigned*)flags : nullptr, roles ? B * CX_SPLIT : 0};
+    const LinArgs lin{dPre, out, dX, dWp, dbp, premul};
+    if (njobs > 0 && roles) {
+        RouteJobs<true> jr;
+        if (gptst_pj_reduce_table(&jr.t, njobs, jkind, jemb, jx, jpool, jout, jR, jK, jcols, jnsplit, jldx, &jr.npool, &jr.npb, &jr.neb) == GPTST_OK) {
+            const int rc = launch_route_bwd2<64>(X, Wp, bp, c, dc1, nullptr, nullptr, dlogit, B * T, N, HS, (hipStream_t)stream, cx, lin, &jr, nsplit);
+            if (rc != GPTST_ESHAPE) return rc;
+        }
+    }
+    const int rc = launch_route_bwd2<64>(X, Wp, bp, c, dc1, nullptr, nullptr, dlogit, B * T, N, HS, (hipStream_t)stream, cx, lin, nullptr, nsplit);
+    if (rc || njobs == 0) return rc;
+    return gptst_pool_jobs(njobs, jkind, jemb, jx, jpool, jout, jR, jK, jcols, jnsplit, jldx, stream);
+}
+
 extern "C" int gptst_cap_cross_route_lin_bwd_jobs(const float* X, const float* Wp, const float* bp, const float* c, const float* dc1, const float* dv,
                                                   const float* s, const float* Rt, const float* Ht, const float* dyn, const float* tmpl,
                                                   const float* dPre, const float* out, int premul, float* dX, float* dWp, float* dbp, float* dlogit,
@@ -1243,23 +1319,20 @@ extern "C" int gptst_cap_cross_route_lin_bwd_jobs(const float* X, const float* W
                                                   int njobs, const int* jkind, const void* const* jemb, const void* const* jx, const void* const* jpool,
                                                   const void* const* jout, const int* jR, const int* jK, const int* jcols, const int* jnsplit, const int* jldx,
                                                   void* stream) {
-    if (!X || !Wp || !bp || !c || !dc1 || !dv || !s || !Rt || !Ht || !dyn || !tmpl || !dPre || !dX || !dWp || !dbp || !dlogit || !ddyn || B <= 0 ||
-        T <= 0 || (out && premul)) return GPTST_EARG;
-    if (njobs < 0 || (njobs && (!jkind || !jemb || !jx || !jpool || !jout || !jR || !jK || !jcols || !jnsplit))) return GPTST_EARG;
-    if (C != 64) return GPTST_ESHAPE;
-    const bool roles = dS_ws != nullptr && flags != nullptr && !g_cap_bwd_noroles;
-    const CrossBwdArgs cx{dv, s, Rt, Ht, dyn, tmpl, ddyn, T, HT, roles ? dS_ws : nullptr, roles ? (unsigned*)flags : nullptr, roles ? B * CX_SPLIT : 0};
-    const LinArgs lin{dPre, out, dX, dWp, dbp, premul};
-    if (njobs > 0 && roles) {
-        RouteJobs<true> jr;
-        if (gptst_pj_reduce_table(&jr.t, njobs, jkind, jemb, jx, jpool, jout, jR, jK, jcols, jnsplit, jldx, &jr.npool, &jr.npb, &jr.neb) == GPTST_OK) {
-            const int rc = launch_route_bwd2<64>(X, Wp, bp, c, dc1, nullptr, nullptr, dlogit, B * T, N, HS, (hipStream_t)stream, cx, lin, &jr);
-            if (rc != GPTST_ESHAPE) return rc;
-        }
-    }
-    const int rc = launch_route_bwd2<64>(X, Wp, bp, c, dc1, nullptr, nullptr, dlogit, B * T, N, HS, (hipStream_t)stream, cx, lin);
-    if (rc || njobs == 0) return rc;
-    return gptst_pool_jobs(njobs, jkind, jemb, jx, jpool, jout, jR, jK, jcols, jnsplit, jldx, stream);
+    return cap_cross_route_lin_bwd_any(X, Wp, bp, c, dc1, dv, s, Rt, Ht, dyn, tmpl, dPre, out, premul, dX, dWp, dbp, dlogit, ddyn, dS_ws, flags, B, T, N, C, HS,
+                                       HT, 0, njobs, jkind, jemb, jx, jpool, jout, jR, jK, jcols, jnsplit, jldx, stream);
+}
+
+// ... with the last nsplit (b,t) as node halves (gptst_cap_split_units): dWp (B*T + nsplit, C*C), dbp (B*T + nsplit, C) partial rows
+extern "C" int gptst_cap_cross_route_lin_bwd_split(const float* X, const float* Wp, const float* bp, const float* c, const float* dc1, const float* dv,
+                                                   const float* s, const float* Rt, const float* Ht, const float* dyn, const float* tmpl,
+                                                   const float* dPre, const float* out, int premul, float* dX, float* dWp, float* dbp, float* dlogit,
+                                                   float* ddyn, float* dS_ws, void* flags, int B, int T, int N, int C, int HS, int HT, int nsplit,
+                                                   int njobs, const int* jkind, const void* const* jemb, const void* const* jx, const void* const* jpool,
+                                                   const void* const* jout, const int* jR, const int* jK, const int* jcols, const int* jnsplit, const int* jldx,
+                                                   void* stream) {
+    return cap_cross_route_lin_bwd_any(X, Wp, bp, c, dc1, dv, s, Rt, Ht, dyn, tmpl, dPre, out, premul, dX, dWp, dbp, dlogit, ddyn, dS_ws, flags, B, T, N, C, HS,
+                                       HT, nsplit, njobs, jkind, jemb, jx, jpool, jout, jR, jK, jcols, jnsplit, jldx, stream);
 }
 
 extern "C" int gptst_cap_rec_bwd(const float* drec, const float* c, const float* v, float* dc1, float* dv, int BT, int N, int C, int HS,

@@ -315,10 +315,14 @@ extern thread_local int g_apply128_minwg;
 extern thread_local int g_tl_mfma;
 extern thread_local int g_cap_route_v2;
 extern thread_local int g_cap_bwd_noroles;
+extern thread_local int g_cap_split;
+extern thread_local int g_cap_split_roles;
 extern "C" int gptst_tune(int id, int value) {
     if (id == 15) g_tl_mfma = value;
     if (id == 20) g_cap_route_v2 = value;
     if (id == 23) g_cap_bwd_noroles = value;
+    if (id == 25) g_cap_split = value;
+    if (id == 26) g_cap_split_roles = value;
     if (id == 19) g_pg_sort = value;
     if (id == 1 && value > 0 && value <= PG_MAXROWS) g_pg_rows = value;
     if (id == 6 && value > 0) g_tl_nb = value;

@@ -401,8 +401,8 @@ def cap_core_bwd(p, g, pfx, saved, dout, dims, HS, HT, red, chain=False):
         red.untake(carry)                                              # (not launched: shape beyond the fused form)
         if lin is not None:
             dx, dWp, dbp, dlogit, ddyn = lin
-            red.jobs.bwd_pool(_ones(dev, BT), dWp, gw.view(1, C * C))
-            red.jobs.bwd_pool(_ones(dev, BT), dbp, gb.view(1, C))
+            red.jobs.bwd_pool(_ones(dev, dWp.shape[0]), dWp, gw.view(1, C * C))      # B*T (+ the node halves' rows, r06) partials
+            red.jobs.bwd_pool(_ones(dev, dbp.shape[0]), dbp, gb.view(1, C))
             return dx, (dWn, ns, (dbn, nsb), ddyn, dlogit)
     if fused is None and FUSE_CROSS and CTX.NODE_REDUCE is None and Y is None:
         fused = ops.cap_cross_route_bwd(x.view(B, T, N, C), p[pfx + "ln_p.weight"], p[pfx + "ln_p.bias"], c, dc1, dv, s, Rt, Ht, dyn,

@@ -112,7 +112,7 @@ class CapFn(torch.autograd.Function):
                                               flags=torch.zeros(4 * B, device=dev))
         if lin is not None:
             dx, dWp, dbp_part, dlogit, ddyn = lin
-            dlnp_w, dbp = dWp.view(BT, C, C).sum(0), dbp_part.sum(0, keepdim=True)
+            dlnp_w, dbp = dWp.view(-1, C, C).sum(0), dbp_part.sum(0, keepdim=True)      # B*T (+ node halves) partial rows
         else:
             dS, ddyn = ops.cap_cross_bwd(dv, s, Rt, Ht, dyn, tmpl, B, T, HS, HT)
             dY, dlogit = ops.cap_route_bwd(x, lnp_w, lnp_b, c, dc1, dS)

@@ -691,9 +691,11 @@ def cap_cross_route_bwd(X, Wp, bp, c, dc1, dv, s, Rt, Ht, dyn, tmpl, B, T, HS, H
     return dY, dlogit, ddyn
 
 
-def cap_cross_route_lin_bwd(X, Wp, bp, c, dc1, dv, s, Rt, Ht, dyn, tmpl, dPre, out, premul, B, T, HS, HT, flags=None, jobs=None):
-    """cap_cross_route_bwd + linear_bwd in one launch (r05) -> (dX (B*T*N, C), dWp (B*T, C*C), dbp (B*T, C), dlogit, ddyn), or None when the shape
+def cap_cross_route_lin_bwd(X, Wp, bp, c, dc1, dv, s, Rt, Ht, dyn, tmpl, dPre, out, premul, B, T, HS, HT, flags=None, jobs=None, nsplit=None):
+    """cap_cross_route_bwd + linear_bwd in one launch (r05) -> (dX (B*T*N, C), dWp (rows, C*C), dbp (rows, C), dlogit, ddyn), or None when the shape
     needs the separate launches.  dPre: the cap layer's output gradient (already dPre when out is None; premul: dX times lrelu'(X)).
+    rows = B*T + nsplit partial rows (r06: the last nsplit (b,t) run as two node halves with a partial row each; None = what the device's kernels want,
+    gptst_cap_split_units).
     jobs: a PoolJobs table of gradient reductions (bwd_pool / bwd_emb) whose inputs are complete — launched here, as role workgroups of this launch where
     that form serves (gptst_cap_cross_route_lin_bwd_jobs); left untouched when None is returned."""
     _chk(X, Wp, bp, c, dc1, dv, s, Rt, Ht, dyn, tmpl, dPre, out)
@@ -701,25 +703,24 @@ def cap_cross_route_lin_bwd(X, Wp, bp, c, dc1, dv, s, Rt, Ht, dyn, tmpl, dPre, o
     if C != 64 or FORCE_CAP_BIG:
         return None
     dev = X.device
+    if nsplit is None:
+        nsplit = _C.lib().value("gptst_cap_split_units", B * T, N, C, HS)
+    rows = B * T + nsplit
     dX = torch.empty(B * T * N, C, device=dev, dtype=torch.float32)
-    dWp = torch.empty(B * T, C * C, device=dev, dtype=torch.float32)
-    dbp = torch.empty(B * T, C, device=dev, dtype=torch.float32)
+    dWp = torch.empty(rows, C * C, device=dev, dtype=torch.float32)
+    dbp = torch.empty(rows, C, device=dev, dtype=torch.float32)
     dlogit = torch.empty_like(c)
     ddyn = torch.empty_like(dyn)
     try:
         dS_ws = torch.empty(B * T, HS, C, device=dev, dtype=torch.float32) if flags is not None else None
         js = jobs.jobs if jobs is not None and not jobs.post and all(j[0] in (PoolJobs.BWD_POOL, PoolJobs.BWD_EMB) for j in jobs.jobs) else []
+        col = lambda i: [j[i] for j in js]      # noqa: E731
+        _call("gptst_cap_cross_route_lin_bwd_split", _p(X), _p(Wp), _p(bp), _p(c), _p(dc1), _p(dv), _p(s), _p(Rt), _p(Ht), _p(dyn), _p(tmpl),
+              _p(dPre), _p(out), int(bool(premul)), _p(dX), _p(dWp), _p(dbp), _p(dlogit), _p(ddyn), _p(dS_ws), _p(flags), B, T, N, C, HS, HT, nsplit,
+              len(js), _ints(col(0)), _ptrs0(col(1)), _ptrs0(col(2)), _ptrs0(col(3)), _ptrs0(col(4)), _ints(col(5)), _ints(col(6)), _ints(col(7)),
+              _ints(col(8)), _ints(col(9)), nbytes=_nb(X, Wp, bp, c, dc1, dv, s, Rt, dPre, out, dX, dWp, dlogit))
         if js:
-            col = lambda i: [j[i] for j in js]      # noqa: E731
-            _call("gptst_cap_cross_route_lin_bwd_jobs", _p(X), _p(Wp), _p(bp), _p(c), _p(dc1), _p(dv), _p(s), _p(Rt), _p(Ht), _p(dyn), _p(tmpl),
-                  _p(dPre), _p(out), int(bool(premul)), _p(dX), _p(dWp), _p(dbp), _p(dlogit), _p(ddyn), _p(dS_ws), _p(flags), B, T, N, C, HS, HT,
-                  len(js), _ints(col(0)), _ptrs0(col(1)), _ptrs0(col(2)), _ptrs0(col(3)), _ptrs0(col(4)), _ints(col(5)), _ints(col(6)), _ints(col(7)),
-                  _ints(col(8)), _ints(col(9)), nbytes=_nb(X, Wp, bp, c, dc1, dv, s, Rt, dPre, out, dX, dWp, dlogit))
             jobs.jobs = []
-            return dX, dWp, dbp, dlogit, ddyn
-        _call("gptst_cap_cross_route_lin_bwd", _p(X), _p(Wp), _p(bp), _p(c), _p(dc1), _p(dv), _p(s), _p(Rt), _p(Ht), _p(dyn), _p(tmpl),
-              _p(dPre), _p(out), int(bool(premul)), _p(dX), _p(dWp), _p(dbp), _p(dlogit), _p(ddyn), _p(dS_ws), _p(flags), B, T, N, C, HS, HT,
-              nbytes=_nb(X, Wp, bp, c, dc1, dv, s, Rt, dPre, out, dX, dWp, dlogit))
     except _C.GptstError as e:
         if e.code != _C.ESHAPE:
             raise

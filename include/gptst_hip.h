@@ -26,7 +26,7 @@ extern "C" {
 #pragma GCC visibility push(default)
 #endif
 
-#define GPTST_ABI_VERSION 14  /* 14 (r05, late): + gptst_cap_cross_route_lin_bwd_jobs (gradient-reduction jobs as a role of the routing backward); 13 (r05, late): + gptst_mask_u24_fwd_jobs (forward generation jobs inside the cooperative mask launch); 12 (r05, late): + gptst_mask_cooperative (gptst_mask_*_u24 with 8192 < M <= 65536 cells and a workspace: ONE cooperative launch); 11 (r05): + gptst_cap_cross_route_lin_bwd, gptst_comm_available, gptst_handoff_reset, gptst_set_handoff_guard (gptst_clip_adam: stats_out[5] = expiries on record); - gptst_cap_rec_cross_route_bwd (three-role form, measured slower); 9, 10 (r04, late): + gptst_hypertem_bwd_pair, gptst_cap_rec_cross_route_bwd, gptst_mask_*_u24, gptst_pool_jobs_gram_rows, gptst_handoff_timeouts; gptst_fusion_gate_fwd/bwd */
+#define GPTST_ABI_VERSION 15  /* 15 (r06): + gptst_cap_split_units, gptst_cap_cross_route_lin_bwd_split (the last (b,t) units of the routing backward as two node halves: 384 units on 256 CUs -> one whole unit + one half per CU); 14 (r05, late): + gptst_cap_cross_route_lin_bwd_jobs (gradient-reduction jobs as a role of the routing backward); 13 (r05, late): + gptst_mask_u24_fwd_jobs (forward generation jobs inside the cooperative mask launch); 12 (r05, late): + gptst_mask_cooperative (gptst_mask_*_u24 with 8192 < M <= 65536 cells and a workspace: ONE cooperative launch); 11 (r05): + gptst_cap_cross_route_lin_bwd, gptst_comm_available, gptst_handoff_reset, gptst_set_handoff_guard (gptst_clip_adam: stats_out[5] = expiries on record); - gptst_cap_rec_cross_route_bwd (three-role form, measured slower); 9, 10 (r04, late): + gptst_hypertem_bwd_pair, gptst_cap_rec_cross_route_bwd, gptst_mask_*_u24, gptst_pool_jobs_gram_rows, gptst_handoff_timeouts; gptst_fusion_gate_fwd/bwd */
 int gptst_abi_version(void);
 /* 1: bit-reproducible steps — the two reductions that end in float atomics by default (embedding gradients of gptst_pool_jobs kind 2,
  * weight gradients of gptst_timefeat_jobs) run as single-owner kernels with a fixed summation order (slower).  Everything else is
@@ -276,6 +276,23 @@ int gptst_cap_cross_route_lin_bwd_jobs(const float* X, const float* Wp, const fl
                                        int njobs, const int* jkind, const void* const* jemb, const void* const* jx, const void* const* jpool,
                                        const void* const* jout, const int* jR, const int* jK, const int* jcols, const int* jnsplit, const int* jldx,
                                        void* stream);
+/* r06 NODE HALVES.  The (b,t)-grouped cap kernels run B*T = 384 workgroups on the 256 CUs of an MI355X at two per CU: half the CUs get two units, the rest
+ * one, and the launch lasts as long as the former (the reference has no such notion: GPTST.py:100-141 is a chain of whole-tensor einsums).  Every step of
+ * the routing backward is local to a 16-node tile, so the LAST nsplit (b,t) can be cut into two node halves with a workgroup each (B*T - nsplit whole
+ * units + 2 nsplit halves: at B*T = 1.5 x CUs one whole unit and one half per CU).
+ * MEASURED AND NOT ADOPTED (profiles/r06_node_halves.txt: a half lasts as long as a whole unit — the workgroup is a latency chain, not a throughput item):
+ * gptst_cap_split_units returns 0 unless a test / benchmark turns the policy on (gptst_tune(25, -1): B*T - CUs where CUs < B*T <= 1.5 CUs, C = 64, N >= 32) — what a caller passes to
+ * gptst_cap_cross_route_lin_bwd_split, which is gptst_cap_cross_route_lin_bwd_jobs (njobs may be 0) with dWp (B*T + nsplit, C*C) and dbp (B*T + nsplit, C):
+ * a half writes a partial row of its own (rows B*T - nsplit + 2k, + 2k + 1 are the halves of (b,t) = B*T - nsplit + k).  Any 0 <= nsplit <= B*T is valid;
+ * the results do not depend on it beyond the summation order of the caller's reduction over the partial rows. */
+int gptst_cap_split_units(int BT, int N, int C, int HS);
+int gptst_cap_cross_route_lin_bwd_split(const float* X, const float* Wp, const float* bp, const float* c, const float* dc1, const float* dv,
+                                        const float* s, const float* Rt, const float* Ht, const float* dyn, const float* tmpl,
+                                        const float* dPre, const float* out, int premul, float* dX, float* dWp, float* dbp, float* dlogit,
+                                        float* ddyn, float* dS_ws, void* flags, int B, int T, int N, int C, int HS, int HT, int nsplit,
+                                        int njobs, const int* jkind, const void* const* jemb, const void* const* jx, const void* const* jpool,
+                                        const void* const* jout, const int* jR, const int* jK, const int* jcols, const int* jnsplit, const int* jldx,
+                                        void* stream);
 
 /* ---- cap for node counts whose (b,t) capsule matrix does not fit LDS (cap_big.hip; BASELINE config 5: N = 4096, C = 128) ----
  * gptst_cap_fits_lds() == 0 -> the host composes the same algebra from these streaming kernels (ops.py: cap_route_fwd/bwd, cap_rec_*):

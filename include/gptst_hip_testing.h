@@ -14,7 +14,8 @@ extern "C" {
  * 6: workgroups of the loss-head kernels; 7 / 8: 1 = first-generation weight gradient / apply for C = 128; 10: 0 = VALU forward of the
  * pool jobs instead of the (bit-identical) MFMA one; 20: 1 = second-generation cap routing forward (cap_route_fwd2_kernel); 21: cap routing
  * forward variant (0 = cap_route_fwd4_kernel, 1 / 2 = cap_route_fwd3_kernel at <= 128 / <= 80 VGPRs); 23: 1 = cross-time backward as a replicated prologue of
- * cap_route_bwd2_kernel instead of a role.  The Python binding applies GPTST_TUNE="id=value,..." from the environment. */
+ * cap_route_bwd2_kernel instead of a role; 25: node halves of the routing backward (gptst_cap_split_units: 0 = off, the default; -1 = by the CU count; n = the
+ * last n (b,t)); 26: 0 = the halves never ride behind the cross-time role workgroups.  The Python binding applies GPTST_TUNE="id=value,..." from the environment. */
 int gptst_tune(int id, int value);
 /* mask selection: 1 = the multi-launch radix select for every size (a single-workgroup launch serves M <= 8192 cells otherwise);
  * 2 (gptst_mask_*_u24 only) = the one-workgroup lattice kernel for every size up to 65536 cells; either value also keeps the cooperative launch

@@ -1094,15 +1094,23 @@ def test_cap_route_lin_bwd_equals_route_bwd_plus_linear_bwd(B, N, HS, HT, mode):
     dY, dl1, ddyn1 = ref
     o_, pm = (out, False) if mode == "out" else (None, mode == "dpre_premul")
     dX1, dWp1, dbp1, ns = ops.linear_bwd(dY, X.view(-1, C), Wp, dout, o_, premul=pm)
-    for rep in range(2):
+    # r06: the last nsplit (b,t) as two node halves with a workgroup and a partial row each (None: what the device wants, 128 at B = 32 on 256 CUs)
+    for rep, nsp in enumerate((0, None, 5, B * T)):
         for flags in (torch.zeros(4 * B, device=dev), None):          # cross-time backward as a role / as a prologue
-            r = ops.cap_cross_route_lin_bwd(X, Wp, bp, c, dc1, dv, s, Rt, Ht, dyn, tmpl, dout, o_, pm, B, T, HS, HT, flags=flags)
+            r = ops.cap_cross_route_lin_bwd(X, Wp, bp, c, dc1, dv, s, Rt, Ht, dyn, tmpl, dout, o_, pm, B, T, HS, HT, flags=flags, nsplit=nsp)
             assert r is not None
             dX2, dWp2, dbp2, dl2, ddyn2 = r
+            assert nsp is None or dWp2.shape[0] == B * T + nsp
             assert torch.equal(dl2, dl1) and torch.equal(ddyn2, ddyn1)
             assert torch.equal(dX2, dX1), float((dX2 - dX1).abs().max())
             close(dWp2.sum(0), dWp1.sum(0).cpu(), tol=2e-6, what="route_lin dWp")
             close(dbp2.sum(0), dbp1.sum(0).cpu(), tol=2e-6, what="route_lin dbp")
+            if nsp:         # the two halves' rows add up to the whole unit's row of the unsplit call
+                k0 = B * T - nsp
+                close((dWp2[k0::2] + dWp2[k0 + 1::2]), whole[1][k0:].cpu(), tol=2e-6, what="node halves dWp rows")
+                assert torch.equal(dWp2[:k0], whole[1][:k0]) and torch.equal(dbp2[:k0], whole[2][:k0])
+            elif nsp == 0:
+                whole = r
 
 
 @pytest.mark.parametrize("B,N,det", [(32, 170, 0), (3, 37, 0), (32, 170, 1)])

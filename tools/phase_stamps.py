@@ -75,6 +75,8 @@ ph = (ctypes.c_longlong * (8 * 32))()
 wg = (ctypes.c_longlong * (2048 * 2))()
 assert getattr(dll, "gptst_stamps_" + unit)(ph, wg) == 0
 nwg = BT + (4 * B if name.endswith('roles') else 0)
+if len(sys.argv) > 2:            # launch geometry given (node halves, r06): workgroup count, printed in chunks of 64
+    nwg = int(sys.argv[2])
 if name == "ht_bwd_pair":
     nwg = 352 + 2 * BT
 ph = np.array(ph).reshape(8, 32); wg = np.array(wg).reshape(2048, 2)[:nwg]
@@ -86,6 +88,10 @@ for lo, hi in (((0, 352), (352, 352 + BT), (352 + BT, nwg)) if name == "ht_bwd_p
     if hi > lo and lo < nwg and hi <= nwg:
         w = wg[lo:hi]
         print("   workgroups %3d..%3d: end %.2f us (mean), duration %.2f us" % (lo, hi - 1, (w[:, 1].mean() - t0) * 0.01, (w[:, 1] - w[:, 0]).mean() * 0.01))
+if len(sys.argv) > 2:
+    for lo in range(0, nwg, 64):
+        w = wg[lo:min(lo + 64, nwg)]
+        print("   workgroups %3d..%3d: start %.2f end %.2f us (mean), duration %.2f us" % (lo, lo + len(w) - 1, (w[:, 0].mean() - t0) * 0.01, (w[:, 1].mean() - t0) * 0.01, (w[:, 1] - w[:, 0]).mean() * 0.01))
 for sl, b in enumerate((5, 100, 200, 300, 261, 383)):
     if b >= BT or ph[sl, 0] == 0:
         continue
