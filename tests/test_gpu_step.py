@@ -473,15 +473,29 @@ def test_weight_trajectory_is_as_close_to_fp64_as_the_fp32_oracle(parity):
     parity("traj_hip_vs_fp64", dh)
     parity("traj_hip_over_fp32oracle", dh / max(d32, 1e-12))
     assert moved > 50 * max(dh, d32), (moved, dh, d32)                 # the 12 steps moved the weights far more than the runs differ
-    # measured r04: fp32 oracle 4.9e-7, HIP 8.7e-7 (ratio 1.76) — and 1.55e-4 (ratio 317) before the optimiser took 1 - beta from the host:
-    # 1.f - 0.999f made every Adam step 6.4e-6 too long, which this test found and test_clip_adam_matches_torch (2e-6 of |p|) could not see
-    # r05: 8x (3x before).  Two VALID fp32 summation orders of one weight gradient sit at different multiples: with the entry Linear's backward folded
-    # into the routing backward (one dWp partial per (b,t) instead of 510 row splits; every other tensor of a step bit-identical,
-    # tools/experiments/lin_grad_diff.py) the run reads 6.4x (3.2e-6), without it 1.8x.  The mechanism: Adam normalises per element, so the 1e-7-of-max
-    # rounding of a weight gradient is a 10 % change of the update of its smallest elements; through ln_p -> cluster assignment -> KL target the
-    # guide classifier's pools then drift by 1e-4 of their norm over the 12 steps (GPTST_TRAJ_DEBUG=1 lists the tensors).  The fp32 oracle is ONE
-    # sample of that lottery; an optimiser or gradient defect shows as 100x and more (317x for the 1 - beta2 rounding below).
-    assert dh <= 8.0 * d32 + 1e-7, (dh, d32)                            # HIP is as close to the fp64 trajectory as the fp32 oracle
+    # The yardstick (no literal multiple): how far do VALID fp32 runs of these 12 steps land from the fp64 trajectory?  Adam normalises
+    # per element, so the 1e-7-of-max rounding of a weight gradient is a 10 % change of the update of its smallest elements, and one run is one draw of a
+    # lottery: the fp32 oracle itself reads 4.9e-7 on one host and 2.0e-5 on another (its reductions split by thread count).  The draws are taken HERE, from
+    # the oracle: its two associations of the cap algebra, the batch in other sample orders (every sum over the batch re-associated), and initial states one
+    # ulp apart — the size two fp32 implementations of one forward differ by.  The HIP run must not be further out than 1.5x the worst of them; an optimiser
+    # or gradient defect is (r04: 1.55e-4, 317x the oracle, when Adam formed 1 - beta2 in fp32) — GPTST_TRAJ_DEBUG=1 lists the tensors.
+    def o32(sd0, m5d=True, perm=None):
+        so = O.Stepper(sd0, args, synth.SCALER_MEAN, synth.SCALER_STD, materialize_5d=m5d)
+        for i in range(K):
+            s_, m_ = srcs[i], masks[i]
+            if perm is not None:
+                s_, m_ = s_[perm].contiguous(), m_.view(B, -1)[perm].reshape(m_.shape).contiguous()
+            so.step(s_, epochs[i], forced_mask=m_)
+        return float((cat(so.sd) - w64).norm() / w64.norm())
+    gen = torch.Generator().manual_seed(5)
+    draws = [d32, o32(sd, m5d=False)] + [o32(sd, perm=torch.tensor(p_)) for p_ in ([1, 0, 3, 2], [3, 2, 1, 0], [2, 3, 0, 1])]
+    for _ in range(5):
+        sdp = {k_: (torch.nextafter(v_, v_ + (torch.randint(0, 2, v_.shape, generator=gen) * 2 - 1).to(v_.dtype)) if v_.is_floating_point() else v_)
+               for k_, v_ in sd.items()}
+        draws.append(o32(sdp))
+    print("fp32 oracle draws (distance to the fp64 trajectory): %s; HIP %.2e" % (["%.2e" % v_ for v_ in draws], dh))
+    parity("traj_hip_over_worst_fp32_draw", dh / max(draws))
+    assert dh <= 1.5 * max(draws), (dh, draws)                          # HIP is as close to the fp64 trajectory as valid fp32 runs are
     # losses: the fp32 runs against fp64, step by step — the HIP run within twice the fp32 oracle's own deviation (+ 2e-6 floor)
     for i in range(K):
         e32 = abs(l32[i][0] - l64[i][0]) / abs(l64[i][0])
