@@ -26,9 +26,10 @@ extern "C" int gptst_handoff_timeouts(int* out) {
 GPTST_INTERNAL int gptst_handoff_clear_capmfma(unsigned to);
 GPTST_INTERNAL int gptst_handoff_clear_hypertem(unsigned to);
 GPTST_INTERNAL int gptst_handoff_clear_masksel(unsigned to);
+GPTST_INTERNAL int gptst_adam_skipped_clear(void);
 extern "C" int gptst_handoff_reset(void) {
     if (hipDeviceSynchronize() != hipSuccess) return -5;
-    return (gptst_handoff_clear_capmfma(0u) || gptst_handoff_clear_hypertem(0u) || gptst_handoff_clear_masksel(0u)) ? -5 : GPTST_OK;
+    return (gptst_handoff_clear_capmfma(0u) || gptst_handoff_clear_hypertem(0u) || gptst_handoff_clear_masksel(0u) || gptst_adam_skipped_clear()) ? -5 : GPTST_OK;
 }
 // (include/gptst_hip_testing.h)
 extern "C" int gptst_handoff_inject(int n) {

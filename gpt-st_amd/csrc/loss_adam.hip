@@ -134,6 +134,14 @@ __global__ __launch_bounds__(256) void gradnorm_kernel(const float* __restrict__
     }
 }
 
+// updates skipped by the guard below since the last gptst_handoff_reset(): goes out in stats_out[6], so that a host that enqueued SEVERAL steps before it
+// looked (bench loops, step groups that fell back to single steps) knows how many optimiser steps to take back
+__device__ unsigned g_adam_skipped = 0u;
+GPTST_INTERNAL int gptst_adam_skipped_clear(void) {
+    const unsigned z = 0u;
+    return hipMemcpyToSymbol(HIP_SYMBOL(g_adam_skipped), &z, sizeof(unsigned)) == hipSuccess ? 0 : 1;
+}
+
 // stats[3] on entry: squared-norm contributions that are not in g on this rank (node-sharded runs add the other ranks' node-local
 // parts there; otherwise 0); on exit (written by workgroup 0): the total squared gradient norm.
 __global__ __launch_bounds__(256) void adam_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m,
@@ -179,8 +187,13 @@ __global__ __launch_bounds__(256) void adam_kernel(float* __restrict__ p, const 
     // (stats[3] is rewritten only after every workgroup has read it: the caller's next kernel boundary orders that — here the
     // total goes to stats[4], which nobody reads inside this launch)
     if (blockIdx.x == 0 && threadIdx.x == 0) stats[4] = gsq;
-    if (stats_out != nullptr && blockIdx.x == 0 && threadIdx.x < 8)
-        stats_out[threadIdx.x] = threadIdx.x == 4 ? gsq : threadIdx.x == 5 ? (float)nlost : stats[threadIdx.x];
+    if (blockIdx.x == 0) {
+        __shared__ unsigned s_skipped;
+        if (threadIdx.x == 0) s_skipped = nlost != 0u ? (g_adam_skipped += 1u) : g_adam_skipped;      // (only workgroup 0 touches the word)
+        __syncthreads();
+        if (stats_out != nullptr && threadIdx.x < 8)
+            stats_out[threadIdx.x] = threadIdx.x == 4 ? gsq : threadIdx.x == 5 ? (float)nlost : threadIdx.x == 6 ? (float)s_skipped : stats[threadIdx.x];
+    }
 }
 
 extern "C" int gptst_mae_fwd(const float* out, const float* src, int lda, const float* mask, float sigma, float mu, float thresh,

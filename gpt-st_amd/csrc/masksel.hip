@@ -476,11 +476,12 @@ int g_ms_force_multi = 0;       // tests: 1 = take the multi-launch path for eve
 #ifndef MS_COOP_DEFAULT
 #define MS_COOP_DEFAULT 1
 #endif
-extern int g_ms_coop;
+extern thread_local int g_ms_coop;
 // 0 default; 1: multi-launch path for every size; 2 (u24): the one-workgroup lattice kernel up to 65536 cells; 3 (u24): the multi-launch path where
 // the cooperative launch (r05) would serve, sizes up to 8192 cells still on the one-workgroup kernel
 extern "C" int gptst_mask_force_multi(int on) { g_ms_force_multi = on; return GPTST_OK; }
 extern "C" int gptst_mask_cooperative(int on) { g_ms_coop = on < 0 ? MS_COOP_DEFAULT : (on != 0); return GPTST_OK; }
+extern "C" int gptst_mask_cooperative_state(void) { return g_ms_coop; }
 
 static int ms_random_impl(const float* noise, int M, int k, float* mask, void* ws, int ws_zeroed, void* stream, int u24) {
     if (!noise || !mask || !ws || M <= 0 || k < 0 || k > M) return GPTST_EARG;
@@ -791,7 +792,7 @@ __global__ __launch_bounds__(MU_T) void mu_mask_kernel(const int* __restrict__ l
 }
 
 // ======================================================================================================================
-// r05: the whole mask generation as ONE COOPERATIVE launch — ceil(M / 1024) <= 64 workgroups of 1024 threads, ONE CELL PER THREAD (its keys live in
+// r05: the whole mask generation as ONE COOPERATIVE launch — ceil(M / 1024) <= MC_MAXWG = 128 workgroups of 1024 threads (64 at the bench shape), ONE CELL PER THREAD (its keys live in
 // registers), a grid barrier where the multi-launch path has a kernel boundary.  The six launches of the adaptive phase are ~7.5 us each of launch
 // + two dependent memory round trips on 64 workgroups (45 us per step, three quarters of the chip idle); a barrier of 64 arrivals on one counter is
 // 2-3 us.  Phases: [class histogram] | A digit 1 | A digit 2 | (ties: per-workgroup counts) | mark A, R digit 1 | R digit 2 | (ties) | write.
@@ -799,7 +800,7 @@ __global__ __launch_bounds__(MU_T) void mu_mask_kernel(const int* __restrict__ l
 // bins merged into the global histogram with atomics; behind the barrier every workgroup reads the 4096 bins back (agent-scope loads) and finds
 // the threshold bin itself.  Same SET as the multi-launch path and the oracle: ties at rank k go to the lowest cell indices (per-workgroup counts
 // of threshold-equal cells + one more barrier, only when a tie straddles the rank).
-// All workgroups are resident by construction (<= 64 workgroups of 16 waves on 256 CUs); the barrier wait is bounded like every in-launch wait
+// All workgroups are resident by construction (<= 128 workgroups of 16 waves, at most half of what the device holds: mc_fits); the barrier wait is bounded like every in-launch wait
 // (gptst_wait_ge, 2 s): on expiry the outputs are NaN and the expiry is on record (gptst_handoff_timeouts; the optimiser's guard skips the step).
 // ws words (zeroed): [0, 16384) four histograms (selection s, digit d) | 16384 class counts (256) | 16768 barrier | 16769 bad | 16800 tie counts (2 x MC_MAXWG)
 // ======================================================================================================================
@@ -1018,21 +1019,26 @@ __global__ __launch_bounds__(MC_T) void mc_mask_jobs_kernel(McArgs g, unsigned n
     mc_mask_body<ADAPTIVE>(g, nmask);
 }
 
-// The grid barriers need every mask workgroup resident at once: workgroups the device can hold = CUs x occupancy of the kernel (queried once per kernel;
-// a partitioned or CU-masked device simply takes the multi-launch path)
+// The grid barriers need every mask workgroup resident at once: workgroups the device can hold = CUs x occupancy of the kernel (queried once per kernel
+// AND device; a partitioned or CU-masked device simply takes the multi-launch path).  The query knows nothing about what else is on the chip — a forked RCCL
+// all-reduce under the data-parallel bucket overlap, another process — so the launch is taken only with HALF the slots to spare: at most
+// MC_MAXWG = 128 mask workgroups against >= 256 slots on an MI355X.  (The job workgroups of mc_mask_jobs_kernel sit behind the mask workgroups in block
+// order and take no part in the barriers.)  A mask workgroup that is not resident after all ends in the bounded wait -> NaN -> the steppers' safe mode.
 template <typename K>
 static bool mc_fits(K kernel, int nwg) {
-    static int cap = -1;
-    if (cap < 0) {
-        int dev = 0, ncu = 0, per = 0;
-        if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess ||
+    static thread_local int cap = -1, cap_dev = -1;
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess) return false;
+    if (cap < 0 || dev != cap_dev) {
+        int ncu = 0, per = 0;
+        if (hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess ||
             hipOccupancyMaxActiveBlocksPerMultiprocessor(&per, (const void*)kernel, MC_T, 0) != hipSuccess) { ncu = 0; per = 0; }
-        cap = ncu * per;
+        cap = ncu * per; cap_dev = dev;
     }
-    return nwg <= cap;
+    return 2 * nwg <= cap;
 }
 
-int g_ms_coop = MS_COOP_DEFAULT;              // gptst_mask_cooperative(0): the multi-launch path instead of the cooperative launch (the steppers' fallback after a lost hand-off; A/B; tests)
+thread_local int g_ms_coop = MS_COOP_DEFAULT;              // (thread-local like the other launch-mode knobs: ranks emulated by threads) gptst_mask_cooperative(0): the multi-launch path instead of the cooperative launch (the steppers' fallback after a lost hand-off; A/B; tests)
 
 static int mu_prepare() {
     static int done = 0;

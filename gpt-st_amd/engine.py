@@ -53,9 +53,12 @@ class _Context(threading.local):
     """Per-thread execution context of a step (thread-local so that several shard steppers can run side by side in one process:
     tests emulate the ranks of a node-sharded run with threads).
       ARENA        ZeroArena of the running step (None -> plain torch.zeros)
-      NODE_REDUCE  node-sharded run: callable that completes a sum over nodes across the ranks, in place (None -> single shard)"""
+      NODE_REDUCE  node-sharded run: callable that completes a sum over nodes across the ranks, in place (None -> single shard)
+      NO_HANDOFFS  the step is enqueued without launches in which one workgroup waits for another (no_handoffs(): a stepper in safe mode) — per
+                   thread, so that one emulated rank in safe mode does not change the launches another thread is enqueuing"""
     ARENA = None
     NODE_REDUCE = None
+    NO_HANDOFFS = False
 
 
 CTX = _Context()
@@ -262,17 +265,25 @@ PAIR_BWD = os.environ.get("GPTST_PAIR_BWD", "1") == "1"        # two adjacent hy
 @contextlib.contextmanager
 def no_handoffs():
     """Enqueue (or capture) the step without launches in which one workgroup waits for another (the hyperTem backward pairs, the cross-time role
-    of the routing backward, the cooperative mask launch): what a stepper falls back to after a bounded wait expired (step.py::_enter_safe_mode)."""
-    global PAIR_BWD, CROSS_ROLE
+    of the routing backward, the cooperative mask launch): what a stepper falls back to after a bounded wait expired (step.py::_enter_safe_mode).
+    Everything it switches is per thread (CTX, the library's thread-local mask switch) and put back as it was found."""
     from . import _C
-    keep = (PAIR_BWD, CROSS_ROLE)
-    PAIR_BWD, CROSS_ROLE = False, 0
+    keep = (CTX.NO_HANDOFFS, _C.lib().value("gptst_mask_cooperative_state"))
+    CTX.NO_HANDOFFS = True
     _C.lib().call("gptst_mask_cooperative", 0)
     try:
         yield
     finally:
-        PAIR_BWD, CROSS_ROLE = keep
-        _C.lib().call("gptst_mask_cooperative", -1)
+        CTX.NO_HANDOFFS = keep[0]
+        _C.lib().call("gptst_mask_cooperative", keep[1])
+
+
+def pair_bwd_on():
+    return PAIR_BWD and not CTX.NO_HANDOFFS
+
+
+def cross_role():
+    return 0 if CTX.NO_HANDOFFS else CROSS_ROLE
 
 
 def _ht_pair_shape_ok(dims):
@@ -287,7 +298,7 @@ def _ht_pair_shape_ok(dims):
 
 
 def ht_pair_ok(saved1, saved0, dims):
-    return (PAIR_BWD and dims[3] == 64 and not isinstance(saved1, EncIn) and saved1[1] is not None and saved0[1] is not None
+    return (pair_bwd_on() and dims[3] == 64 and not isinstance(saved1, EncIn) and saved1[1] is not None and saved0[1] is not None
             and _ht_fused_bwd(dims) and _ht_pair_shape_ok(dims))
 
 
@@ -394,10 +405,10 @@ def cap_core_bwd(p, g, pfx, saved, dout, dims, HS, HT, red, chain=False):
     if fused is None and FUSE_CROSS and CAP_LIN and C == 64 and CTX.NODE_REDUCE is None and Y is None:
         # r05: cross-time backward (role) + routing backward + the entry Linear's backward and the residual branch in ONE launch; dY never leaves LDS
         # r05: queued reductions of the layers already behind us ride in this launch — where it has the role form (idle slots: B*T + 4B <= 512 workgroups)
-        carry = red.take_carry(CARRY_MB) if CROSS_ROLE and _C.lib().value("gptst_cap_route_roles_ok", B, T, N, C, HS, HT) == 1 else None
+        carry = red.take_carry(CARRY_MB) if cross_role() and _C.lib().value("gptst_cap_route_roles_ok", B, T, N, C, HS, HT) == 1 else None
         lin = ops.cap_cross_route_lin_bwd(x.view(B, T, N, C), p[pfx + "ln_p.weight"], p[pfx + "ln_p.bias"], c, dc1, dv, s, Rt, Ht, dyn,
                                           p[pfx + "mask_template"], dout, None if chain else out, chain, B, T, HS, HT,
-                                          flags=_zeros(x, 4 * B) if CROSS_ROLE else None, jobs=carry)
+                                          flags=_zeros(x, 4 * B) if cross_role() else None, jobs=carry)
         red.untake(carry)                                              # (not launched: shape beyond the fused form)
         if lin is not None:
             dx, dWp, dbp, dlogit, ddyn = lin
@@ -406,7 +417,7 @@ def cap_core_bwd(p, g, pfx, saved, dout, dims, HS, HT, red, chain=False):
             return dx, (dWn, ns, (dbn, nsb), ddyn, dlogit)
     if fused is None and FUSE_CROSS and CTX.NODE_REDUCE is None and Y is None:
         fused = ops.cap_cross_route_bwd(x.view(B, T, N, C), p[pfx + "ln_p.weight"], p[pfx + "ln_p.bias"], c, dc1, dv, s, Rt, Ht, dyn,
-                                        p[pfx + "mask_template"], B, T, HS, HT, flags=_zeros(x, 4 * B) if CROSS_ROLE else None)
+                                        p[pfx + "mask_template"], B, T, HS, HT, flags=_zeros(x, 4 * B) if cross_role() else None)
     if fused is not None:
         dY, dlogit, ddyn = fused
     else:
@@ -647,7 +658,7 @@ def sthcn_bwd(p, g, pfx, tidx, sv, dout, dims, red, chain=False, premul_in=False
     queue_ht(hts[3], hp4)
     dd, cp2 = cap_core_bwd(p, g, cps[1], sv["c2"], dd, dims, HS, HT, red, chain)
     queue_cap(cps[1], cp2)
-    pair = ht_pair_bwd(sv["h3"], sv["h2"], dd, dG_all[2], dG_all[1], dims) if chain and PAIR_BWD else None
+    pair = ht_pair_bwd(sv["h3"], sv["h2"], dd, dG_all[2], dG_all[1], dims) if chain and pair_bwd_on() else None
     if pair is not None:                            # hyperTem3 + hyperTem2: nothing in between (GPTST.py:267-268) -> one launch on the slab
         dd, hp3, hp2 = pair
     else:

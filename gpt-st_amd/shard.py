@@ -229,6 +229,10 @@ class ShardedPretrainStep(PretrainStep):
             else:
                 self.noise_a_g.copy_(noise_a.reshape(-1)); self.noise_r_g.copy_(noise_r.reshape(-1))
         self._host_prepare(phase, epoch, list_c)
+        #  what losses() needs to repeat this step after a lost hand-off: the base class's re-run calls step(src, epoch, list_c=...) — this one
+        self._g_last = None
+        self._last_call = (epoch, self._filled_list_c, self.rank_weight) if not inject else None
+        self._unseen.append(phase)
         if not self.shard_graph:
             self.inject_noise = inject
             self._sbody(phase)

@@ -76,6 +76,8 @@ class PretrainStep:
         # switch this stepper to the launches WITHOUT hand-offs (safe_mode: graphs re-captured) and re-run the skipped steps from the untouched weights
         self.safe_mode = False
         self.lost_steps = 0                  # steps re-run so far
+        self.lost_batches = 0                # ... and steps that were skipped with a later one and could not be repeated (their batches were gone)
+        self._unseen = []                    # phase of every step enqueued since the host last read the statistics
         self._last_call = None               # (epoch, list_c) of the last plain step()
         self._g_list_cs = None               # class orders of the last group
         self.arena = engine.ZeroArena(self.dev)
@@ -126,7 +128,9 @@ class PretrainStep:
         AND statistics, so the global kept-cell count the optimiser divides by does not see the padding either."""
         if self.rank_weight != 1.0:
             assert not self.use_graph, "a rank weight is baked into a captured graph: tail rounds use eager steppers"
-            sl.mul_(self.rank_weight)
+            lost = self.stats[5:6].clone()              # the hand-off expiry count rides in the statistics block: a padding rank's expiry must reach its
+            sl.mul_(self.rank_weight)                   # peers unscaled, or it alone skips the update and re-runs a step of collectives nobody joins
+            self.stats[5:6].copy_(lost)
         self.dp.allreduce_(sl)
 
     def _bucket_ready(self, k):
@@ -348,7 +352,8 @@ class PretrainStep:
         if forced_mask is not None:
             self.mask_buf.copy_(forced_mask.reshape(-1), non_blocking=True)
         self._host_prepare(phase, epoch, list_c)
-        self._last_call = (epoch, self._filled_list_c) if not inject and forced_mask is None else None
+        self._last_call = (epoch, self._filled_list_c, self.rank_weight) if not inject and forced_mask is None else None
+        self._unseen.append(phase)                      # steps enqueued since the host last looked at the statistics (losses())
         key = (phase, inject, forced_mask is not None)
         if not self.use_graph:
             self.inject_noise, self.force_mask = inject, forced_mask is not None
@@ -466,7 +471,7 @@ class PretrainStep:
             snaps = []                                  # every step's statistics (device copies, no sync): losses_group() returns K triples here too
             for j, src in enumerate(sources):
                 self.step(src, epoch, list_c=None if list_cs is None else list_cs[j])
-                snaps.append((self.stats_out.clone(), bool(self.tB and self.phase_kl)))
+                snaps.append((self.stats_out.clone(), bool(self.tB and self.phase_kl), src, self._filled_list_c, epoch))
             self._g_last = None
             self._g_fallback = snaps
             return
@@ -571,16 +576,24 @@ class PretrainStep:
         """[(loss, loss_flow, loss_s)] of the steps of the last step_group() — synchronises."""
         if self._g_last is None:
             if getattr(self, "_g_fallback", None):      # step_group() fell back to single steps: one triple per step, as the grouped path
-                out = []
-                for st, kl in self._g_fallback:
-                    st = st.cpu()
-                    lf = float(st[0] / max(float(st[1]), 1.0))
-                    ls = float(st[2]) * 0.1 if kl else 0.0
-                    out.append((lf + ls, lf, ls))
+                snaps, self._g_fallback = self._g_fallback, None
+                rows = [(st.cpu(), kl) for st, kl, _, _, _ in snaps]
+                out = [self._stats_row(st, kl) for st, kl in rows]
+                lost = [j for j, (st, _) in enumerate(rows) if float(st[5]) > 0]
+                del self._unseen[:]
+                if lost:                                # a hand-off expired in step j0: its update and every later one were skipped (ADVICE r05) —
+                    j0 = lost[0]                        # take them back and re-run them, as the grouped path does
+                    self._enter_safe_mode(len(snaps) - j0, sum(1 for _, kl, _, _, _ in snaps[j0:] if kl))
+                    for j in range(j0, len(snaps)):
+                        _, kl, src, lc, ep = snaps[j]
+                        self.step(src, ep, list_c=lc)
+                        out[j] = self._stats_row(self.stats_out.cpu(), kl)
+                    del self._unseen[:]
                 return out
             return [self.losses()]
         K, phase = self._g_last
         st = self._g_stats.cpu()
+        del self._unseen[:]
         rerun = {}
         if float(st[:, 5].max()) > 0:           # a hand-off expired in sub-step j0: its update and every later one were skipped
             j0 = int((st[:, 5] > 0).float().argmax())
@@ -589,6 +602,7 @@ class PretrainStep:
             for j, (src, lc) in enumerate(zip(srcs, lcs)):
                 self.step(src, epoch, list_c=lc)
                 rerun[j0 + j] = self._stats_row(self.stats_out.cpu(), phase == 1)
+            del self._unseen[:]
             self._g_last = (K, phase)            # (step() cleared it: the group's triples stay readable)
         out = []
         for j in range(K):
@@ -624,11 +638,25 @@ class PretrainStep:
         if self._g_last is not None:
             return self.losses_group()[-1]
         st = self.stats_out.cpu()
+        unseen, self._unseen = self._unseen, []
         if float(st[5]) > 0:                     # the update of this step was skipped (a hand-off expired): re-run it from the untouched weights
             if self._last_call is None:
                 raise RuntimeError("an in-launch hand-off expired in a step with injected mask inputs: call _enter_safe_mode() and repeat the step")
-            epoch, lc = self._last_call
-            self._enter_safe_mode(1, 1 if self.phase_kl else 0)
-            self.step(self.src, epoch, list_c=lc)
+            # The guard skips EVERY update while the record is up, and the host may have enqueued several steps since it last looked (bench loops): the
+            # device counts them (stats_out[6]).  All of them are taken back; only the last one can be repeated — the earlier batches are gone.
+            nskip = max(1, min(int(st[6]), len(unseen))) if unseen else 1
+            epoch, lc, weight = self._last_call
+            self._enter_safe_mode(nskip, sum(unseen[-nskip:]) if unseen else (1 if self.phase_kl else 0))
+            if nskip > 1:
+                import sys
+                self.lost_batches += nskip - 1
+                print("gpt-st_amd: %d step(s) enqueued before the last one were skipped with it and cannot be repeated (their batches are gone): "
+                      "the optimiser counters were taken back, the batches were not trained on" % (nskip - 1), file=sys.stderr)
+            keep_w, self.rank_weight = self.rank_weight, weight          # the same weighted step (a padding rank of a tail round re-runs as padding)
+            try:
+                self.step(self.src, epoch, list_c=lc)
+            finally:
+                self.rank_weight = keep_w
             st = self.stats_out.cpu()
+            del self._unseen[:]
         return self._stats_row(st, bool(self.tB and self.phase_kl))

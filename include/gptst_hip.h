@@ -26,7 +26,7 @@ extern "C" {
 #pragma GCC visibility push(default)
 #endif
 
-#define GPTST_ABI_VERSION 15  /* 15 (r06): + gptst_cap_split_units, gptst_cap_cross_route_lin_bwd_split (the last (b,t) units of the routing backward as two node halves: 384 units on 256 CUs -> one whole unit + one half per CU); 14 (r05, late): + gptst_cap_cross_route_lin_bwd_jobs (gradient-reduction jobs as a role of the routing backward); 13 (r05, late): + gptst_mask_u24_fwd_jobs (forward generation jobs inside the cooperative mask launch); 12 (r05, late): + gptst_mask_cooperative (gptst_mask_*_u24 with 8192 < M <= 65536 cells and a workspace: ONE cooperative launch); 11 (r05): + gptst_cap_cross_route_lin_bwd, gptst_comm_available, gptst_handoff_reset, gptst_set_handoff_guard (gptst_clip_adam: stats_out[5] = expiries on record); - gptst_cap_rec_cross_route_bwd (three-role form, measured slower); 9, 10 (r04, late): + gptst_hypertem_bwd_pair, gptst_cap_rec_cross_route_bwd, gptst_mask_*_u24, gptst_pool_jobs_gram_rows, gptst_handoff_timeouts; gptst_fusion_gate_fwd/bwd */
+#define GPTST_ABI_VERSION 15  /* 15 (r06): + gptst_cap_split_units, gptst_cap_cross_route_lin_bwd_split (the last (b,t) units of the routing backward as two node halves: 384 units on 256 CUs -> one whole unit + one half per CU; measured, opt-in), gptst_clip_adam: stats_out[6] = updates skipped since gptst_handoff_reset; + gptst_mask_cooperative_state (the switch is thread-local now); 14 (r05, late): + gptst_cap_cross_route_lin_bwd_jobs (gradient-reduction jobs as a role of the routing backward); 13 (r05, late): + gptst_mask_u24_fwd_jobs (forward generation jobs inside the cooperative mask launch); 12 (r05, late): + gptst_mask_cooperative (gptst_mask_*_u24 with 8192 < M <= 65536 cells and a workspace: ONE cooperative launch); 11 (r05): + gptst_cap_cross_route_lin_bwd, gptst_comm_available, gptst_handoff_reset, gptst_set_handoff_guard (gptst_clip_adam: stats_out[5] = expiries on record); - gptst_cap_rec_cross_route_bwd (three-role form, measured slower); 9, 10 (r04, late): + gptst_hypertem_bwd_pair, gptst_cap_rec_cross_route_bwd, gptst_mask_*_u24, gptst_pool_jobs_gram_rows, gptst_handoff_timeouts; gptst_fusion_gate_fwd/bwd */
 int gptst_abi_version(void);
 /* 1: bit-reproducible steps — the two reductions that end in float atomics by default (embedding gradients of gptst_pool_jobs kind 2,
  * weight gradients of gptst_timefeat_jobs) run as single-owner kernels with a fixed summation order (slower).  Everything else is
@@ -36,15 +36,18 @@ int gptst_set_deterministic(int on);
  * gptst_cap_cross_route_lin_bwd, the lower weight-gradient role of gptst_hypertem_bwd_pair, the grid barriers of the cooperative mask launch
  * (gptst_mask_*_u24): a consumer workgroup waits at most 2 s of wall clock for its producer and poisons its output with NaN on expiry).  0 in a healthy run; lets a NaN loss be told from numerical trouble.  Synchronises. */
 int gptst_handoff_timeouts(int* out);
-/* r05: while an expiry is on record gptst_clip_adam SKIPS its update (weights and moments untouched; the count goes out in stats_out[5]) — the
+/* r05: while an expiry is on record gptst_clip_adam SKIPS its update (weights and moments untouched; the count goes out in stats_out[5], and — r06 —
+ * the number of updates skipped since the last gptst_handoff_reset() in stats_out[6]: a caller that enqueued several steps before it looked knows how many to take back) — the
  * caller re-runs the step without in-launch hand-offs and then clears the record with gptst_handoff_reset() (synchronises).
  * gptst_set_handoff_guard(0) turns the skip off (process-wide). */
 int gptst_handoff_reset(void);
 /* r05: gptst_mask_random_u24 / gptst_mask_adaptive_u24 with a workspace and 8192 < M <= 131072 cells run as ONE launch of ceil(M / 1024) workgroups of
  * 1024 threads (a cell per thread, digit histograms in the workspace, grid barriers with the bounded wait above; every workgroup is resident: at most
- * 128 on 256 CUs; the launcher checks the device's capacity).  0: the multi-launch radix select instead (what a stepper falls back to after a lost hand-off); 1: on; < 0: the build's default
- * (on).  Process-wide.  Same masks bit for bit either way. */
+ * 128 on 256 CUs; the launcher takes this form only while the grid is at most HALF of what the device holds).  0: the multi-launch radix select instead (what a stepper falls back to after a lost hand-off); 1: on; < 0: the build's default
+ * (on).  Thread-local (r06), like the other launch-mode switches.  Same masks bit for bit either way.  gptst_mask_cooperative_state(): the calling thread's setting (0 / 1) —
+ * a scope that switches the form off restores what it found. */
 int gptst_mask_cooperative(int on);
+int gptst_mask_cooperative_state(void);
 int gptst_set_handoff_guard(int on);
 
 /* ---- embedding-conditioned parameter generation (poolgen.hip) -----------------------------------------

@@ -211,3 +211,36 @@ def test_sharded_step_in_one_hipgraph(kind, parity):
     err = float((pe - pg).norm() / pe.norm())
     parity("param_rel_l2_graph_vs_eager", err)
     assert err < 1e-3
+
+
+def test_sharded_step_recovers_from_a_lost_handoff():
+    """the node-sharded stepper runs the fused hand-off launches too; an expiry on record makes the optimiser skip, losses() takes the
+    step back and repeats it on the launches without hand-offs (the base class's recovery: the shard's step() now leaves what that needs)."""
+    from gptst_amd import _C
+    from gptst_amd.model import GPTST_Model
+    from gptst_amd.shard import DistNodeGroup, ShardedPretrainStep
+    N, B = 40, 2
+    args = _args(N)
+    sd = O.init_state_dict(args, 8)
+    srcs = [synth.make_batch(B, 12, N, 1, seed=80 + s).to(DEV) for s in range(3)]
+    orders = [synth.class_order(args.HS, 5 + s) for s in range(3)]
+    res = []
+    try:
+        for lose in (False, True):
+            m = GPTST_Model(args); m.load_state_dict(sd); m = m.to(DEV)
+            st = ShardedPretrainStep(m, args, N, DistNodeGroup(0, 1), synth.SCALER_MEAN, synth.SCALER_STD, batch_size=B, use_graph=True)
+            out = []
+            for i, (src, lc) in enumerate(zip(srcs, orders)):
+                if lose and i == 1:
+                    torch.cuda.synchronize()
+                    _C.lib().call("gptst_handoff_inject", 1)
+                st.step(src, 20, list_c=lc)
+                out.append(st.losses())
+            assert st.safe_mode == lose and st.lost_steps == (1 if lose else 0) and (st.tA, st.tB) == (3, 3)
+            res.append((out, m.flat.detach().clone()))
+    finally:
+        _C.lib().call("gptst_handoff_reset")
+    for a, b in zip(res[0][0], res[1][0]):
+        for x, y in zip(a, b):
+            assert abs(x - y) <= 2e-4 * max(abs(y), 1e-3), (res[0][0], res[1][0])
+    assert float((res[0][1] - res[1][1]).norm() / res[0][1].norm()) < 1e-3

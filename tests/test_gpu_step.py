@@ -392,6 +392,60 @@ def test_lost_handoff_skips_the_update_and_the_step_is_rerun():
     assert n.value == 0
 
 
+def test_lost_handoff_with_several_steps_enqueued_before_the_host_looks():
+    """the optimiser's guard skips EVERY update while an expiry is on record, and a caller may enqueue several step()s before one losses()
+    (bench loops) or run a group that fell back to single steps.  The device counts the skipped updates (stats_out[6]); losses() takes all of them
+    back (Adam's bias-correction counters, the Philox step key) and repeats the last one — the earlier batches are gone and are reported as such;
+    the fallen-back group keeps its sources and repeats every skipped step.  Both end bit-identical (deterministic mode) to runs that stepped on
+    exactly the batches that were applied."""
+    from gptst_amd import _C
+    from gptst_amd.model import GPTST_Model
+    from gptst_amd.step import PretrainStep
+    args = _args()
+    sd = O.init_state_dict(args, 2)
+    srcs = [synth.make_batch(4, 12, 20, 1, seed=930 + i).to(DEV) for i in range(9)]
+    orders = [synth.class_order(5, 60 + i) for i in range(9)]
+    lib = _C.lib()
+
+    def fresh(group_fails=False):
+        model = GPTST_Model(args); model.load_state_dict(sd); model = model.to(DEV)
+        st = PretrainStep(model, args, synth.SCALER_MEAN, synth.SCALER_STD, batch_size=4, use_graph=True, deterministic=True)
+        st._group_failed = group_fails
+        return model, st
+    try:
+        # (a) steps 0, 1 seen; the hand-off is lost in front of step 2; steps 2, 3, 4 enqueued, then ONE losses()
+        m0, s0 = fresh()
+        for i in (0, 1, 4):
+            s0.step(srcs[i], 5, list_c=orders[i]); l0 = s0.losses()
+        m1, s1 = fresh()
+        for i in (0, 1):
+            s1.step(srcs[i], 5, list_c=orders[i]); s1.losses()
+        torch.cuda.synchronize()
+        lib.call("gptst_handoff_inject", 1)
+        for i in (2, 3, 4):
+            s1.step(srcs[i], 5, list_c=orders[i])
+        l1 = s1.losses()
+        assert s1.safe_mode and s1.lost_steps == 3 and s1.lost_batches == 2 and (s1.tA, s1.tB) == (s0.tA, s0.tB) == (3, 3)
+        assert l1 == l0 and torch.equal(m1.flat, m0.flat) and torch.equal(s1.m, s0.m) and torch.equal(s1.v, s0.v)
+        # (b) a group that runs as single steps (capture refused): expiry in front of its third step -> steps 2, 3 repeated from the kept sources
+        m2, s2 = fresh(group_fails=True)
+        s2.step_group(srcs[5:9], 5, list_cs=orders[5:9]); l2 = s2.losses_group()
+        m3, s3 = fresh(group_fails=True)
+        s3.step_group(srcs[5:7], 5, list_cs=orders[5:7]); l3 = s3.losses_group()
+        torch.cuda.synchronize()
+        lib.call("gptst_handoff_inject", 1)
+        s3.step_group(srcs[5:9], 5, list_cs=orders[5:9])          # (its first two steps are skipped too: they repeat steps 5, 6 on top — compare with the same sequence)
+        l3b = s3.losses_group()
+        m4, s4 = fresh(group_fails=True)
+        s4.step_group(srcs[5:7], 5, list_cs=orders[5:7]); s4.losses_group()
+        s4.step_group(srcs[5:9], 5, list_cs=orders[5:9]); l4 = s4.losses_group()
+        assert s3.lost_steps == 4 and (s3.tA, s3.tB) == (s4.tA, s4.tB) == (6, 6)
+        assert l3b == l4 and torch.equal(m3.flat, m4.flat) and torch.equal(s3.m, s4.m)
+        assert len(l2) == 4
+    finally:
+        lib.call("gptst_handoff_reset")
+
+
 def test_step_group_falls_back_to_single_steps_when_the_capture_fails(monkeypatch):
     """A runtime that cannot record K steps in one graph (e.g. collectives) raises at capture time: the group then runs as K single steps —
     counters not advanced twice, later groups do not retry — and gives the results of K step() calls."""
