@@ -13,7 +13,7 @@ from collections import OrderedDict
 import torch
 import torch.nn as nn
 
-from . import engine, ops
+from . import engine, module_graph, ops
 
 
 # --------------------------------------------------------------------------------------------------------------------
@@ -129,6 +129,7 @@ class _PretrainFn(torch.autograd.Function):
         base = model.input_base_dim
         p = model.param_views()
         gflat = model._grad_buffer()
+        model._last_gflat = gflat                     # (optim.ClipAdam: the flat buffer behind the .grad views autograd is about to keep)
         g = model.views_of(gflat)
         d_out = d_out.contiguous().view(-1, base)
         d_dec2 = None if d_dec is None or not bool(d_dec.any()) else d_dec.contiguous().view(-1, C)
@@ -190,12 +191,25 @@ class GPTST_Model(nn.Module):
             flat[offs[k]:offs[k] + t.numel()].copy_(t.detach().reshape(-1))
             t.data = flat[offs[k]:offs[k] + t.numel()].view(t.shape)
         self.flat, self._offs = flat, offs
+        import weakref
+        GPTST_Model._OWNERS[flat.untyped_storage().data_ptr()] = weakref.ref(self)
         self.nA, self.nB = seg_end[0], seg_end[1] - seg_end[0]
         self._views = None
         # the parameter objects in module order, walked ONCE: named_parameters() traverses ~640 modules, and the eager path asked for it four times per
         # step (1.2 ms of the reference-style loop's 6.7 ms, tools/experiments/prof_module_path.py)
         self._named = list(named.items())
+        self._vmeta = None
         self._shapes = {k: (t.numel(), t.shape) for k, t in self._named}
+
+    _OWNERS = {}                                 # address of a flat parameter buffer -> weakref of its model (optim.ClipAdam finds the layout by it)
+
+    @staticmethod
+    def owner_of(param):
+        """the GPTST_Model whose flat buffer `param` is a view of (None: not one of ours)"""
+        base = param._base if param._base is not None else param
+        ref = GPTST_Model._OWNERS.get(base.untyped_storage().data_ptr())
+        m = ref() if ref is not None else None
+        return m if m is not None and m.flat.untyped_storage().data_ptr() == base.untyped_storage().data_ptr() else None
 
     def _apply(self, fn, *a, **k):               # .to(device) / .cuda(): re-establish the flat views afterwards
         super()._apply(fn, *a, **k)
@@ -214,7 +228,17 @@ class GPTST_Model(nn.Module):
         return torch.zeros_like(self.flat)
 
     def views_of(self, flat):
-        return {k: flat[o:o + self._shapes[k][0]].view(self._shapes[k][1]) for k, o in self._offs.items()}
+        """{key: view of `flat` with the parameter's shape} — one as_strided per tensor (a slice + a view were two dispatches each: 310 per backward)"""
+        if self._vmeta is None:
+            self._vmeta = []
+            for k, o in self._offs.items():
+                shp = tuple(self._shapes[k][1])
+                st, acc = [], 1
+                for d in reversed(shp):
+                    st.append(acc); acc *= d
+                self._vmeta.append((k, shp, tuple(reversed(st)), o))
+        a = torch.as_strided
+        return {k: a(flat, shp, st, o) for k, shp, st, o in self._vmeta}
 
     def param_views(self):
         k0, t0 = self._named[0]
@@ -280,6 +304,14 @@ class GPTST_Model(nn.Module):
         source = source.contiguous().float()
         B, T, N, _ = source.shape
         base = self.input_base_dim
+        # r06: the training loop's call — gradients on, nothing injected, static shape — replays the captured forward; its backward is a second graph
+        # (module_graph.py).  Anything else (no_grad, injected mask inputs, a forward while the previous one still waits for its backward) runs eagerly.
+        if module_graph.ENABLED and torch.is_grad_enabled() and self._inject is None and epoch is not None and self.hidden_dim == 64 \
+                and not torch.cuda.is_current_stream_capturing():
+            key = (tuple(source.shape), 0 if epoch <= self.change_epoch else 1, self.flat.data_ptr())
+            gp = module_graph.graphs_of(self, key)          # (kept outside the module: copy.deepcopy(model), BasicTrainer.py:180, must not meet a hipGraph)
+            if not gp.busy:
+                return gp.forward(source, epoch)
         p = self.param_views()
         with torch.no_grad():
             # the mask depends on the guide probabilities only through argmax (no gradient), so the guide classifier runs first — once: its

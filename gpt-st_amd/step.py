@@ -97,7 +97,11 @@ class PretrainStep:
         # is exchanged behind the chain (one 4.15 MB all-reduce behind everything before).  GPTST_DP_OVERLAP=0: the single all-reduce.
         # (the bucket's reductions stay on the chain's stream, only its all-reduce is forked: forking the reductions too cost 5 % at one rank)
         self.always_guide = os.environ.get("GPTST_ALWAYS_GUIDE", "0") == "1"      # run the guide classifier in the random-mask phase too (as the reference does)
-        self.dp_overlap = (os.environ.get("GPTST_DP_OVERLAP", "1") != "0" and dp is not None and getattr(dp, "capturable", False)
+        # r06: OFF by default.  Measured with one forced-DP rank (profiles/r06_dp_world1.txt): 854.9 steps/s with the overlap, 885.6 without, 891.1 without
+        # data parallelism — the early bucket needs its own reduction flush in the middle of the backward (gram_bwd + job table + time-feature launch:
+        # ~50 us) and keeps the reductions out of the routing backward's idle slots, i.e. it costs ~41 us per step on EVERY rank to hide part of a
+        # 4.15 MB all-reduce that takes about that long un-hidden on eight xGMI-connected GPUs.  GPTST_DP_OVERLAP=1 turns it on.
+        self.dp_overlap = (os.environ.get("GPTST_DP_OVERLAP", "0") != "0" and dp is not None and getattr(dp, "capturable", False)
                            and (self.W > 1 or os.environ.get("GPTST_FORCE_DP", "0") == "1"))
         self.dec_lo, self.dec_hi = self._decoder_bucket(model)
         self.rank_weight = 1.0                          # 0.0: this rank steps on padding (eager tail round of a data-parallel epoch, see _allreduce)
