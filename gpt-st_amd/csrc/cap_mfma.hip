@@ -480,13 +480,16 @@ __device__ __forceinline__ void cap_rec_bwd2_body(const float* __restrict__ drec
 #pragma unroll
     for (int u = 0; u < 4; ++u) cr[u] = cb[min(u * CM_NT + tid, ncn - 1)];
     vr = ld4(v + (size_t)bt * HS * C + 4 * (size_t)min(tid, nv - 1));
-    for (int i0 = 0; i0 < NR * LPR; i0 += 4 * CM_NT) {
-        float4 d4[4];
+#ifndef CRB_DREC_BATCH
+#define CRB_DREC_BATCH 6          // float4 loads per thread and round trip of the drec staging (N = 170, C = 64: 5.5 per thread -> ONE trip; 4: 892.0 -> 6: 894.4 steps/s, r06)
+#endif
+    for (int i0 = 0; i0 < NR * LPR; i0 += CRB_DREC_BATCH * CM_NT) {
+        float4 d4[CRB_DREC_BATCH];
 #pragma unroll
-        for (int u = 0; u < 4; ++u) d4[u] = ld4(drec + (size_t)bt * N * C + 4 * (size_t)min(i0 + u * CM_NT + tid, nD - 1));
+        for (int u = 0; u < CRB_DREC_BATCH; ++u) d4[u] = ld4(drec + (size_t)bt * N * C + 4 * (size_t)min(i0 + u * CM_NT + tid, nD - 1));
         SB();
 #pragma unroll
-        for (int u = 0; u < 4; ++u) {
+        for (int u = 0; u < CRB_DREC_BATCH; ++u) {
             const int i = i0 + u * CM_NT + tid;
             if (i < NR * LPR) st4(Ds + (i / LPR) * P + 4 * (i % LPR), i < nD ? d4[u] : f4zero());
         }
@@ -875,6 +878,7 @@ __global__ __launch_bounds__(CM_NT, 4) void cap_route_bwd2_kernel(const float* _
             *s_ok = got ? 1u : 0u;
         }
     };
+    // (r06: requesting c / dc1 ahead of the capsule GEMM — 8 more live registers across it — measured 889.1 vs 892.0 steps/s: not kept)
     for (int i0 = 0; i0 < HS * N; i0 += 4 * CM_NT) {             // c, dc1: batches of 4 + 4 loads per thread
         float cv[4], dv[4];
 #pragma unroll
