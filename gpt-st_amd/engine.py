@@ -723,6 +723,7 @@ def encin_ok(dims, base):
 
 
 GUIDEIN = os.environ.get("GPTST_GUIDEIN", "1") == "1"
+GUIDE_HEAD = os.environ.get("GPTST_GUIDE_HEAD", "1") == "1"     # r06: the classifier's forward as node vectors + ONE (b,t)-grouped pass (gptst_guide_head_fwd)
 
 
 def guide_fwd(p, source, tidx, dims, base, gen=None, lowrank_in=False):
@@ -734,6 +735,12 @@ def guide_fwd(p, source, tidx, dims, base, gen=None, lowrank_in=False):
         gen = gen_all(p, tidx, dims, which=(), guide=True)["guide"]
     t4m, Wspa, bspa, Wtem, btem = gen
     m = "encoder.MLP_RL."
+    if lowrank_in and GUIDEIN and GUIDE_HEAD and base == 1 and C == 64:
+        # r06: u_n / c_n, then ONE (b,t)-grouped pass for :22-:33, the softmax and the labels (bit-identical to the three launches below)
+        r = ops.guide_head_fwd(source, p[m + "ln1.weight"], p[m + "ln1.bias"], Wspa, bspa, Wtem, btem, p[m + "ln3.weight"], p[m + "ln3.bias"])
+        if r is not None:
+            h1, h2, prob, label = r
+            return prob, (t4m, ("lowrank", Wspa), (h1, h2, Wtem), h2, label)
     if lowrank_in and GUIDEIN and base == 1 and C in (64, 128):
         h1 = ops.guide_in_fwd(source, p[m + "ln1.weight"], p[m + "ln1.bias"], Wspa, bspa)                 # :22 + :24-27, elementwise
         s1 = ("lowrank", Wspa)

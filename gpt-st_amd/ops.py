@@ -351,6 +351,25 @@ def guide_in_fwd(source, w1, b1, Wn, bn):
     return h1
 
 
+def guide_head_fwd(source, w1, b1, Wn, bn, Wbt, bbt, W3, b3):
+    """MLP_RL's whole forward on the low-rank input form (base = 1, C = 64) in two launches -> h1, h2 (B*T*N, C), prob (B*T*N, J), label int32 —
+    or None when the shape needs the three launches (guide_in_fwd, apply, rowdot)."""
+    B, T, N, F = source.shape
+    C, J = Wn.shape[-1], W3.shape[0]
+    if C != 64 or J > 16:
+        return None
+    _chk(source, w1, b1, Wn, bn, Wbt, bbt, W3, b3)
+    dev = source.device
+    f = dict(device=dev, dtype=torch.float32)
+    uc = torch.empty(N, 2 * C, **f)
+    h1, h2 = torch.empty(B * T * N, C, **f), torch.empty(B * T * N, C, **f)
+    prob = torch.empty(B * T * N, J, **f)
+    label = torch.empty(B * T * N, device=dev, dtype=torch.int32)
+    _call("gptst_guide_head_fwd", _p(source), F, _p(w1), _p(b1), _p(Wn), _p(bn), _p(Wbt), _p(bbt), _p(W3), _p(b3), _p(uc), _p(h1), _p(h2), _p(prob),
+          _p(label), B * T, N, C, J, nbytes=_nb(Wbt, h1, h2, prob))
+    return h1, h2, prob, label
+
+
 def guide_in_bwd(dPre, source, w1, b1, Wn):
     """-> dWb (N, C*C + C) rows [dW_n | db_n], dinp (N, 2C) partials of d(ln1.weight | ln1.bias)."""
     B, T, N, F = source.shape

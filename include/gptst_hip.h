@@ -26,7 +26,7 @@ extern "C" {
 #pragma GCC visibility push(default)
 #endif
 
-#define GPTST_ABI_VERSION 15  /* 15 (r06): + gptst_cap_split_units, gptst_cap_cross_route_lin_bwd_split (the last (b,t) units of the routing backward as two node halves: 384 units on 256 CUs -> one whole unit + one half per CU; measured, opt-in), gptst_clip_adam: stats_out[6] = updates skipped since gptst_handoff_reset; + gptst_mask_cooperative_state (the switch is thread-local now); 14 (r05, late): + gptst_cap_cross_route_lin_bwd_jobs (gradient-reduction jobs as a role of the routing backward); 13 (r05, late): + gptst_mask_u24_fwd_jobs (forward generation jobs inside the cooperative mask launch); 12 (r05, late): + gptst_mask_cooperative (gptst_mask_*_u24 with 8192 < M <= 65536 cells and a workspace: ONE cooperative launch); 11 (r05): + gptst_cap_cross_route_lin_bwd, gptst_comm_available, gptst_handoff_reset, gptst_set_handoff_guard (gptst_clip_adam: stats_out[5] = expiries on record); - gptst_cap_rec_cross_route_bwd (three-role form, measured slower); 9, 10 (r04, late): + gptst_hypertem_bwd_pair, gptst_cap_rec_cross_route_bwd, gptst_mask_*_u24, gptst_pool_jobs_gram_rows, gptst_handoff_timeouts; gptst_fusion_gate_fwd/bwd */
+#define GPTST_ABI_VERSION 15  /* 15 (r06): + gptst_cap_split_units, gptst_cap_cross_route_lin_bwd_split (the last (b,t) units of the routing backward as two node halves: 384 units on 256 CUs -> one whole unit + one half per CU; measured, opt-in), gptst_clip_adam: stats_out[6] = updates skipped since gptst_handoff_reset; + gptst_mask_cooperative_state (the switch is thread-local now); + gptst_guide_head_fwd, gptst_guide_uc_floats (the guide classifier's forward in two launches); 14 (r05, late): + gptst_cap_cross_route_lin_bwd_jobs (gradient-reduction jobs as a role of the routing backward); 13 (r05, late): + gptst_mask_u24_fwd_jobs (forward generation jobs inside the cooperative mask launch); 12 (r05, late): + gptst_mask_cooperative (gptst_mask_*_u24 with 8192 < M <= 65536 cells and a workspace: ONE cooperative launch); 11 (r05): + gptst_cap_cross_route_lin_bwd, gptst_comm_available, gptst_handoff_reset, gptst_set_handoff_guard (gptst_clip_adam: stats_out[5] = expiries on record); - gptst_cap_rec_cross_route_bwd (three-role form, measured slower); 9, 10 (r04, late): + gptst_hypertem_bwd_pair, gptst_cap_rec_cross_route_bwd, gptst_mask_*_u24, gptst_pool_jobs_gram_rows, gptst_handoff_timeouts; gptst_fusion_gate_fwd/bwd */
 int gptst_abi_version(void);
 /* 1: bit-reproducible steps — the two reductions that end in float atomics by default (embedding gradients of gptst_pool_jobs kind 2,
  * weight gradients of gptst_timefeat_jobs) run as single-owner kernels with a fixed summation order (slower).  Everything else is
@@ -188,6 +188,15 @@ int gptst_guide_in_fwd(const float* src, int lda, const float* w1, const float* 
                        int C, void* stream);
 int gptst_guide_in_bwd(const float* dPre, const float* src, int lda, const float* w1, const float* b1, const float* Wn, float* dWb, float* dinp,
                        int BT, int N, int C, void* stream);
+/* r06: the classifier's whole forward (GPTST.py:21-34 + the softmax of :332 / :343 and the arg-max of :344-345) in two launches: the node vectors
+ * u_n, c_n (N workgroups), then ONE pass grouped by (b,t): h1 = LReLU(s u_n + c_n) built in registers, h2 = LReLU(h1 W_bt + b_bt), logits = h2 W3^T + b3,
+ * softmax, first-maximum label.  Replaces gptst_guide_in_fwd + gptst_apply(mode TIME, LReLU) + gptst_rowdot(softmax, label): same arithmetic in the
+ * same order (bit-identical h1, h2, prob, label), three activation-sized round trips less.  uc: gptst_guide_uc_floats(N, C) floats of scratch.
+ * Wbt (B*T, C, C) [in][out] / bbt (B*T, C): the time-conditioned parameters; W3 (J, C) / b3 (J): MLP_RL.ln3, J <= 16.  C = 64, else GPTST_ESHAPE. */
+int gptst_guide_uc_floats(int N, int C);
+int gptst_guide_head_fwd(const float* src, int lda, const float* w1, const float* b1, const float* Wn, const float* bn, const float* Wbt,
+                         const float* bbt, const float* W3, const float* b3, float* uc, float* h1, float* h2, float* prob, int* label,
+                         int BT, int N, int C, int J, void* stream);
 
 /* "dPre chain" convention of the backward kernels (r03): the gradient that travels down the layer chain may be handed over ALREADY multiplied
  * by the LeakyReLU derivative of the activation it belongs to (dPre = dOut * lrelu'(out)).  A consumer is told so by Y == NULL (it then

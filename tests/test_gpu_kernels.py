@@ -1420,3 +1420,28 @@ def test_guide_in_low_rank_pair_equals_lin_in_plus_node_layer(B, N, C):
     dh0 = torch.einsum("rno,nio->rni", dP, Wn.double())
     close(dinp[:, :C].sum(0), torch.einsum("rn,rni->i", s, dh0).cpu(), tol=5e-6, what="guide_in d ln1.weight")
     close(dinp[:, C:].sum(0), dh0.sum((0, 1)).cpu(), tol=5e-6, what="guide_in d ln1.bias")
+
+
+@pytest.mark.parametrize("B,N,HS", [(32, 170, 10), (2, 50, 5), (3, 37, 16), (2, 207, 10)])
+def test_guide_head_fwd_equals_the_three_launches(B, N, HS):
+    """r06: gptst_guide_head_fwd (node vectors + one (b,t)-grouped pass) == gptst_guide_in_fwd + gptst_apply(TIME, LReLU) + gptst_rowdot(softmax,
+    label): the same fmaf / MFMA chains in the same order -> h1, h2, prob and the labels are bit-identical."""
+    from gptst_amd import ops
+    dev = _dev()
+    g = torch.Generator().manual_seed(81)
+    C, T = 64, 12
+    src = rnd(B, T, N, 3, g=g).to(dev)
+    w1, b1 = rnd(C, 1, g=g).to(dev), rnd(C, g=g).to(dev)
+    Wn, bn = (rnd(N, C, C, g=g) * 0.2).to(dev), rnd(N, C, g=g).to(dev)
+    Wbt, bbt = (rnd(B * T, C, C, g=g) * 0.2).to(dev), rnd(B * T, C, g=g).to(dev)
+    W3, b3 = (rnd(HS, C, g=g) * 0.3).to(dev), rnd(HS, g=g).to(dev)
+    h1r = ops.guide_in_fwd(src, w1, b1, Wn, bn)
+    h2r = ops.apply(h1r, Wbt, ops.MODE_TIME, B * T, N, bias=bbt, epi=ops.EPI_LRELU)
+    pr, lr = ops.rowdot(h2r, W3, b3, softmax=True, want_label=True)
+    for _ in range(2):
+        r = ops.guide_head_fwd(src, w1, b1, Wn, bn, Wbt, bbt, W3, b3)
+        assert r is not None
+        h1, h2, prob, label = r
+        assert torch.equal(h1, h1r), float((h1 - h1r).abs().max())
+        assert torch.equal(h2, h2r), float((h2 - h2r).abs().max())
+        assert torch.equal(prob, pr) and torch.equal(label, lr)
