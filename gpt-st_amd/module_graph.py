@@ -12,7 +12,8 @@ in that loop, so the autograd node's forward and backward are captured ONCE per 
 Semantics kept: the returned tensors are fresh (clones of the graph's static outputs), parameter gradients are ordinary ``.grad`` tensors (views of
 a flat buffer, as in the eager path), KL-path parameters get ``None`` gradients when ``prob`` did not enter the loss, and every situation the
 static buffers cannot serve falls back to the eager node: gradients disabled, injected mask inputs, a second forward before the first one's
-backward, ``flow_decode`` entering the loss, accumulated ``.grad``s that alias the static buffer.  ``GPTST_MODULE_GRAPHS=0`` turns it off.
+backward (eager node); ``flow_decode`` entering the loss (the backward body enqueued eagerly with the extra term); accumulated ``.grad``s that alias
+the static buffer (detached from it first); a capture that fails (the model then stays on the eager node).  ``GPTST_MODULE_GRAPHS=0`` turns it off.
 """
 import os
 import random
@@ -28,13 +29,26 @@ ENABLED = os.environ.get("GPTST_MODULE_GRAPHS", "1") == "1"
 _CACHE = weakref.WeakKeyDictionary()        # model -> {(input shape, masking phase, flat buffer address): GraphedPretrain}
 
 
+class _Unavailable:
+    """placeholder of a (shape, phase) whose capture failed: the model keeps its eager node for it"""
+    busy = True
+
+
 def graphs_of(model, key):
     d = _CACHE.setdefault(model, {})
     gp = d.get(key)
     if gp is None:
         if len(d) >= 8:                         # (ragged last batches, re-flattened buffers: bounded)
             d.clear()
-        gp = d[key] = GraphedPretrain(model, key[0], key[1])
+        try:
+            gp = GraphedPretrain(model, key[0], key[1])
+        except Exception as e:                  # noqa: BLE001  (out of memory for the static buffers, a runtime that cannot capture, ...)
+            import sys
+            print("gpt-st_amd: capturing the module's forward failed (%s: %s) -> eager autograd node for input shape %s"
+                  % (type(e).__name__, str(e).splitlines()[0][:160] if str(e) else "", tuple(key[0])), file=sys.stderr)
+            torch.cuda.synchronize()
+            gp = _Unavailable()
+        d[key] = gp
     return gp
 
 
@@ -126,7 +140,7 @@ class GraphedPretrain:
         self.out, self.dec, self.prob, self.c1, self.mask = out.view(B, T, N, base), dec.view(B, T, N, C), prob.view(B, T, N, -1), c1, mask
         self.saved = (tidx, gen, sv_g, sv_e, sv_d, dec, prob)
 
-    def _bwd_body(self, has_kl):
+    def _bwd_body(self, has_kl, d_dec=None):
         m, base, dims = self.model, self.base, self.dims
         B, T, N, C = dims
         p, g = m.param_views(), self.g
@@ -140,6 +154,8 @@ class GraphedPretrain:
             wo = "decoder.dim_flow_out."
             dd = ops.lin_in(self.d_out, base, base, p[wo + "weight"], None, C, wlayout=1)            # backward of dim_flow_out (GPTST.py:455)
             ops.rowouter(self.d_out, base, base, dec, g[wo + "weight"], 1, asum=g[wo + "bias"])
+            if d_dec is not None:                                                                   # (eager only: flow_decode entered the loss)
+                dd = dd + d_dec
             if chain:                                                                               # dPre chain: times lrelu'(dec), dec = a LeakyReLU output
                 dd = dd * torch.where(dec > 0, 1.0, 0.01)
             engine.model_bwd(p, g, self.src, self.mask, tidx, sv_e, sv_d, dec, None, None, dims, base, m.scaler_zeros, red, dd=dd, chain=chain)
@@ -217,19 +233,22 @@ class GraphedPretrain:
 
     def backward(self, d_out, d_dec, d_prob):
         m = self.model
-        if d_dec is not None:
-            raise RuntimeError("gpt-st_amd: flow_decode entered the loss — the graphed backward does not carry its gradient (GPTST_MODULE_GRAPHS=0)")
-        has_kl = d_prob is not None and self.phase == 1
-        if d_prob is not None and self.phase == 0:
-            raise RuntimeError("gpt-st_amd: the guide probabilities entered the loss in the random-mask phase (GPTST_MODULE_GRAPHS=0)")
+        has_kl = d_prob is not None                      # (also in the random-mask phase, should a caller put the guide probabilities into its loss there)
         if d_out is None:
             self.d_out.zero_()
         else:
             self.d_out.copy_(d_out.reshape(self.M, self.base))
         if has_kl:
             self.d_prob.copy_(d_prob.reshape(self.M, self.HS))
-        if has_kl not in self.gb:
-            self._capture_bwd(has_kl)
+        if d_dec is None and has_kl not in self.gb:
+            try:
+                self._capture_bwd(has_kl)
+            except Exception as e:                       # noqa: BLE001  (the backward then runs eagerly on the same kernels)
+                import sys
+                print("gpt-st_amd: capturing the module's backward failed (%s: %s) -> enqueued eagerly"
+                      % (type(e).__name__, str(e).splitlines()[0][:160] if str(e) else ""), file=sys.stderr)
+                torch.cuda.synchronize()
+                self.gb[has_kl] = None
         # .grad tensors that still alias the static gradient buffer (a loop that accumulates, or zero_grad(set_to_none=False)) are detached from it
         # first: the replay rewrites that memory
         lo = self.gflat.data_ptr()
@@ -240,7 +259,11 @@ class GraphedPretrain:
                     if q.grad is not None and lo <= q.grad.data_ptr() < hi:
                         q.grad = q.grad.clone()
                 break
-        self.gb[has_kl].replay()
+        if d_dec is not None or self.gb.get(has_kl) is None:       # flow_decode entered the loss (or no graph): the same body, enqueued eagerly
+            with torch.no_grad():
+                self._bwd_body(has_kl, d_dec=None if d_dec is None else d_dec.reshape(self.M, -1).contiguous())
+        else:
+            self.gb[has_kl].replay()
         m._last_gflat = self.gflat
         g = m.views_of(self.gflat)                       # fresh view objects: autograd keeps them as .grad without a copy
         return tuple(g[k] if (sg == 0 or (sg == 1 and has_kl)) else None for k, sg in zip(m.param_keys, self._segs))

@@ -91,6 +91,20 @@ class ClipAdam(torch.optim.Optimizer):
         ops.clip_adam(mdl.flat, self._flat_grad(), self.m, self.v, mdl.nA, mdl.nB, self.hyper, self.stats, stats_out=self.stats_out)
         return loss
 
+    def state_dict(self):
+        """torch's dictionary + the flat moment buffers and step counts (the per-parameter `state` of torch.optim.Adam has no counterpart here)"""
+        d = super().state_dict()
+        d["gptst_flat"] = dict(exp_avg=self.m.clone(), exp_avg_sq=self.v.clone(), step=self.tA, step_kl=self.tB)
+        return d
+
+    def load_state_dict(self, state_dict):
+        state_dict = dict(state_dict)
+        flat = state_dict.pop("gptst_flat", None)
+        super().load_state_dict(state_dict)
+        if flat is not None:
+            self.m.copy_(flat["exp_avg"]); self.v.copy_(flat["exp_avg_sq"])
+            self.tA, self.tB = int(flat["step"]), int(flat["step_kl"])
+
     def grad_norm(self):
         """total gradient norm of the last step, before clipping (what clip_grad_norm_ returns) — synchronises"""
         return float(self.stats_out[4].sqrt())

@@ -121,6 +121,18 @@ def test_calling_patterns_the_static_buffers_cannot_serve_fall_back():
     gb = _grads(model)
     k0 = "encoder.STHCN_encode.cap1.ln_p.weight"
     assert float((gb[k0] - ga[k0]).abs().max()) > 0 and torch.isfinite(gb[k0]).all()
+    # flow_decode in the loss: the graphed forward's backward is enqueued eagerly with the extra term == the eager node with the same mask
+    model.zero_grad()
+    o = model(src, src, None, 2)
+    (_loss(o, src, args, 2)[0] + o[1].square().mean()).backward()
+    gd = _grads(model)
+    model.zero_grad()
+    model.set_mask_inputs(forced_mask=(1 - o[2]).float())
+    o2 = model(src, src, None, 2)
+    (_loss(o2, src, args, 2)[0] + o2[1].square().mean()).backward()
+    for k, g_ref in _grads(model).items():
+        if g_ref is not None:
+            assert float((gd[k] - g_ref).abs().max()) <= 1e-4 * max(float(g_ref.abs().max()), 1e-6), k
     copy.deepcopy(model)                                   # BasicTrainer.py:180 deep-copies the model: the graphs live outside it
     assert g_sum[k0] is not None
 
@@ -166,6 +178,10 @@ def test_clip_adam_optimizer_equals_clip_grad_norm_plus_torch_adam(parity):
         parity("clip_adam_vs_torch_step%d" % step, err)
         assert err < 2e-6, (step, err)
     assert (ob.tA, ob.tB) == (6, 3)
+    sd_o = ob.state_dict()
+    oc = ClipAdam(mb.parameters(), lr=1.0, max_grad_norm=0.0)
+    oc.load_state_dict(sd_o)
+    assert (oc.tA, oc.tB) == (6, 3) and torch.equal(oc.m, ob.m) and oc.param_groups[0]["lr"] == ob.param_groups[0]["lr"]
     never = [k for k, _ in mb.named_parameters() if k.startswith("decoder.time_feature1_.")]
     for k in never:
         assert torch.equal(dict(mb.named_parameters())[k].detach().cpu(), sd[k])
