@@ -171,3 +171,22 @@ def test_downstream_gate_has_no_cpu_path():
     from gptst_amd.fusion import fusion_gate
     with pytest.raises(RuntimeError):
         fusion_gate(torch.zeros(2, 3, 4, 64), torch.zeros(2, 3, 4, 3), Fusion(64), torch.nn.Linear(1, 64), 1)
+
+
+def test_parameters_are_served_from_the_cached_walk_and_owner_lookup():
+    """r06: GPTST_Model.parameters() / named_parameters() return the list of the last _flatten() (the reference loop asks every step), in the module
+    tree's order; owner_of() finds the model behind a parameter of its flat buffer (optim.ClipAdam needs the layout)."""
+    import torch.nn as nn
+    from gptst_amd.config import make_args
+    from gptst_amd.model import GPTST_Model
+    args = make_args("PEMS08", num_nodes=12, embed_dim=4, HS=3, HT=4)
+    m = GPTST_Model(args)
+    fast = list(m.named_parameters())
+    slow = list(nn.Module.named_parameters(m))
+    assert [k for k, _ in fast] == [k for k, _ in slow] and all(a is b for (_, a), (_, b) in zip(fast, slow))
+    assert [id(p) for p in m.parameters()] == [id(p) for _, p in slow]
+    assert [k for k, _ in m.named_parameters(prefix="x")] == ["x." + k for k, _ in slow]       # non-default calls take nn.Module's walk
+    assert GPTST_Model.owner_of(fast[3][1]) is m and GPTST_Model.owner_of(nn.Parameter(torch.zeros(3))) is None
+    m2 = GPTST_Model(args)
+    assert GPTST_Model.owner_of(next(m2.parameters())) is m2
+    assert len(m.state_dict()) == len(slow) + 4          # 4 mask_template buffers
