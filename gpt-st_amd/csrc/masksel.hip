@@ -806,7 +806,7 @@ __global__ __launch_bounds__(MU_T) void mu_mask_kernel(const int* __restrict__ l
 // ======================================================================================================================
 GPTST_HANDOFF_COUNTER(masksel)
 #define MC_T 1024
-#define MC_MAXWG 128     // 131072 cells (METR_LA / NYC_TAXI at B = 32 too)
+#define MC_MAXWG 256     // 262144 cells (METR_LA / NYC_TAXI at B = 32 too; r06: the global batch of FOUR data-parallel ranks at the bench shape — 255 workgroups, half the slots of an MI355X: mc_fits)
 static_assert(16800 + 2 * MC_MAXWG <= MS_WS_WORDS, "tie counts beyond the mask workspace");
 struct McShared {
     unsigned hist[MU_BINS];
