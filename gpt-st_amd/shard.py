@@ -233,6 +233,8 @@ class ShardedPretrainStep(PretrainStep):
         self._g_last = None
         self._last_call = (epoch, self._filled_list_c, self.rank_weight) if not inject else None
         self._unseen.append(phase)
+        if len(self._unseen) > 4096:
+            del self._unseen[:2048]
         if not self.shard_graph:
             self.inject_noise = inject
             self._sbody(phase)

@@ -358,6 +358,8 @@ class PretrainStep:
         self._host_prepare(phase, epoch, list_c)
         self._last_call = (epoch, self._filled_list_c, self.rank_weight) if not inject and forced_mask is None else None
         self._unseen.append(phase)                      # steps enqueued since the host last looked at the statistics (losses())
+        if len(self._unseen) > 4096:
+            del self._unseen[:2048]
         key = (phase, inject, forced_mask is not None)
         if not self.use_graph:
             self.inject_noise, self.force_mask = inject, forced_mask is not None
@@ -601,7 +603,15 @@ class PretrainStep:
         rerun = {}
         if float(st[:, 5].max()) > 0:           # a hand-off expired in sub-step j0: its update and every later one were skipped
             j0 = int((st[:, 5] > 0).float().argmax())
-            self._enter_safe_mode(K - j0, (K - j0) if phase == 1 else 0)
+            # (groups enqueued BEFORE this one without a look in between — bench loops — were skipped too if the expiry is older: the device's count of
+            #  skipped updates says how many; their batches are gone, their optimiser steps are taken back with this group's)
+            extra = max(0, int(st[K - 1, 6]) - (K - j0))
+            if extra:
+                import sys
+                self.lost_batches += extra
+                print("gpt-st_amd: %d step(s) of earlier groups were skipped too and cannot be repeated (their batches are gone): the optimiser counters "
+                      "were taken back, the batches were not trained on" % extra, file=sys.stderr)
+            self._enter_safe_mode(K - j0 + extra, (K - j0 + extra) if phase == 1 else 0)
             srcs, lcs, epoch = [t.clone() for t in self._g_src[j0:]], self._g_list_cs[j0:], self._g_epoch
             for j, (src, lc) in enumerate(zip(srcs, lcs)):
                 self.step(src, epoch, list_c=lc)

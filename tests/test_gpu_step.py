@@ -442,6 +442,20 @@ def test_lost_handoff_with_several_steps_enqueued_before_the_host_looks():
         assert s3.lost_steps == 4 and (s3.tA, s3.tB) == (s4.tA, s4.tB) == (6, 6)
         assert l3b == l4 and torch.equal(m3.flat, m4.flat) and torch.equal(s3.m, s4.m)
         assert len(l2) == 4
+        # (c) TWO graph-replayed groups enqueued before one look, the expiry in front of the first: all eight updates are skipped; the last group is repeated,
+        # the first group's four steps are taken back and reported lost -> the state of a run that stepped on the second group only
+        m5, s5 = fresh()
+        s5.step_group(srcs[1:5], 5, list_cs=orders[1:5]); s5.losses_group()          # (captures the group graph; four applied steps)
+        m6, s6 = fresh()
+        s6.step_group(srcs[1:5], 5, list_cs=orders[1:5]); s6.losses_group()
+        torch.cuda.synchronize()
+        lib.call("gptst_handoff_inject", 1)
+        s6.step_group(srcs[5:9], 5, list_cs=orders[5:9])
+        s6.step_group(srcs[0:4], 5, list_cs=orders[0:4])
+        l6 = s6.losses_group()
+        s5.step_group(srcs[0:4], 5, list_cs=orders[0:4]); l5 = s5.losses_group()
+        assert s6.lost_batches == 4 and s6.lost_steps == 8 and (s6.tA, s6.tB) == (s5.tA, s5.tB) == (8, 8)
+        assert l6 == l5 and torch.equal(m6.flat, m5.flat) and torch.equal(s6.m, s5.m)
     finally:
         lib.call("gptst_handoff_reset")
 
