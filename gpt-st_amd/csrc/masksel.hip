@@ -792,8 +792,8 @@ __global__ __launch_bounds__(MU_T) void mu_mask_kernel(const int* __restrict__ l
 }
 
 // ======================================================================================================================
-// r05: the whole mask generation as ONE COOPERATIVE launch — ceil(M / 1024) <= MC_MAXWG = 128 workgroups of 1024 threads (64 at the bench shape), ONE CELL PER THREAD (its keys live in
-// registers), a grid barrier where the multi-launch path has a kernel boundary.  The six launches of the adaptive phase are ~7.5 us each of launch
+// r05: the whole mask generation as ONE COOPERATIVE launch — <= MC_MAXWG = 128 workgroups of 1024 threads (64 at the bench shape), ONE CELL PER THREAD up to 131 072
+// cells (two or four beyond, r06; the keys live in registers), a grid barrier where the multi-launch path has a kernel boundary.  The six launches of the adaptive phase are ~7.5 us each of launch
 // + two dependent memory round trips on 64 workgroups (45 us per step, three quarters of the chip idle); a barrier of 64 arrivals on one counter is
 // 2-3 us.  Phases: [class histogram] | A digit 1 | A digit 2 | (ties: per-workgroup counts) | mark A, R digit 1 | R digit 2 | (ties) | write.
 // Histograms: per-workgroup in LDS (exact zeros — every ineligible cell — counted with a ballot, not with 1000 same-address atomics), non-empty
@@ -806,7 +806,10 @@ __global__ __launch_bounds__(MU_T) void mu_mask_kernel(const int* __restrict__ l
 // ======================================================================================================================
 GPTST_HANDOFF_COUNTER(masksel)
 #define MC_T 1024
-#define MC_MAXWG 256     // 262144 cells (METR_LA / NYC_TAXI at B = 32 too; r06: the global batch of FOUR data-parallel ranks at the bench shape — 255 workgroups, half the slots of an MI355X: mc_fits)
+#define MC_MAXWG 128     // workgroups of the mask role; 1 / 2 / 4 cells per thread: 131 072 / 262 144 / 524 288 cells (r06: the global batch of up to eight bench-shape ranks)
+#define MC_MAXM (4 * MC_T * MC_MAXWG)
+static inline int mc_cpt(int M) { return M <= MC_T * MC_MAXWG ? 1 : M <= 2 * MC_T * MC_MAXWG ? 2 : 4; }      // cells per thread
+static inline int mc_nwg(int M) { const int c = mc_cpt(M) * MC_T; return (M + c - 1) / c; }
 static_assert(16800 + 2 * MC_MAXWG <= MS_WS_WORDS, "tie counts beyond the mask workspace");
 struct McShared {
     unsigned hist[MU_BINS];
@@ -846,14 +849,18 @@ __device__ __forceinline__ unsigned mc_scan(unsigned loc, McShared& sh, unsigned
     return before;
 }
 
-// merge this workgroup's histogram of `dig` (only keys with match) into gh, zeros through a ballot
-__device__ __forceinline__ void mc_hist(unsigned bin, bool take, unsigned* __restrict__ gh, McShared& sh) {
+// merge this workgroup's histogram of `dig` (only keys with match) into gh, zeros through a ballot.  CPT cells per thread (r06).
+template <int CPT>
+__device__ __forceinline__ void mc_hist(const unsigned (&bin)[CPT], const bool (&take)[CPT], unsigned* __restrict__ gh, McShared& sh) {
     for (int b = threadIdx.x; b < MU_BINS; b += MC_T) sh.hist[b] = 0u;
     __syncthreads();
-    const bool z = take && bin == 0u;
-    const unsigned long long zb = __ballot(z);
-    if (take && bin != 0u) atomicAdd(&sh.hist[bin], 1u);
-    if ((threadIdx.x & 63) == 0 && zb) atomicAdd(&sh.hist[0], (unsigned)__popcll(zb));
+#pragma unroll
+    for (int u = 0; u < CPT; ++u) {
+        const bool z = take[u] && bin[u] == 0u;
+        const unsigned long long zb = __ballot(z);
+        if (take[u] && bin[u] != 0u) atomicAdd(&sh.hist[bin[u]], 1u);
+        if ((threadIdx.x & 63) == 0 && zb) atomicAdd(&sh.hist[0], (unsigned)__popcll(zb));
+    }
     __syncthreads();
     for (int b = threadIdx.x; b < MU_BINS; b += MC_T) { const unsigned v = sh.hist[b]; if (v) atomicAdd(gh + b, v); }
 }
@@ -876,27 +883,44 @@ __device__ __forceinline__ void mc_find(const unsigned* __restrict__ gh, unsigne
     __syncthreads();
 }
 
-// one selection of rank k over this grid's keys (key of this thread's cell; 0 = ineligible): -> this cell is masked.  `ph`: barrier phases used so far.
-__device__ __forceinline__ bool mc_select(unsigned key, bool valid, int k, unsigned* __restrict__ ws, int s, unsigned nwg, unsigned& ph, McShared& sh, bool& ok) {
-    if (k <= 0) return false;                                        // uniform over the grid
+// one selection of rank k over this grid's keys (keys of this thread's CPT consecutive cells; 0 = ineligible): -> m[u] = the cell is masked.
+// `ph`: barrier phases used so far.
+template <int CPT>
+__device__ __forceinline__ void mc_select(const unsigned (&key)[CPT], const bool (&valid)[CPT], int k, unsigned* __restrict__ ws, int s, unsigned nwg,
+                                          unsigned& ph, McShared& sh, bool& ok, bool (&m)[CPT]) {
+#pragma unroll
+    for (int u = 0; u < CPT; ++u) m[u] = false;
+    if (k <= 0) return;                                              // uniform over the grid
     unsigned* H0 = ws + (2 * s) * MU_BINS, *H1 = H0 + MU_BINS;
     unsigned* bar = ws + 16768;
-    mc_hist(key >> 12, valid, H0, sh);
+    unsigned bin[CPT];
+    bool take[CPT];
+#pragma unroll
+    for (int u = 0; u < CPT; ++u) { bin[u] = key[u] >> 12; take[u] = valid[u]; }
+    mc_hist<CPT>(bin, take, H0, sh);
     ok = mc_barrier(bar, nwg, ++ph, sh) && ok;
     mc_find(H0, (unsigned)k, sh);
     const unsigned d1 = sh.res[0], rem = sh.res[1];
     __syncthreads();
-    mc_hist(key & 0xFFFu, valid && (key >> 12) == d1, H1, sh);
+#pragma unroll
+    for (int u = 0; u < CPT; ++u) { take[u] = valid[u] && (key[u] >> 12) == d1; bin[u] = key[u] & 0xFFFu; }
+    mc_hist<CPT>(bin, take, H1, sh);
     ok = mc_barrier(bar, nwg, ++ph, sh) && ok;
     mc_find(H1, rem, sh);
     const unsigned thr = (d1 << 12) | sh.res[0], need = sh.res[1], cnt_eq = sh.res[2];
     __syncthreads();
-    bool m = valid && key > thr;
-    const bool eq = valid && key == thr;
-    if (need == cnt_eq) return m || eq;                              // uniform: no tie straddles the rank
-    // a tie straddles rank k: threshold-equal cells take the `need` slots in CELL-INDEX order = (workgroup, thread) order
+    bool eq[CPT];
+    unsigned neq = 0u;
+#pragma unroll
+    for (int u = 0; u < CPT; ++u) { m[u] = valid[u] && key[u] > thr; eq[u] = valid[u] && key[u] == thr; neq += eq[u] ? 1u : 0u; }
+    if (need == cnt_eq) {                                            // uniform: no tie straddles the rank
+#pragma unroll
+        for (int u = 0; u < CPT; ++u) m[u] = m[u] || eq[u];
+        return;
+    }
+    // a tie straddles rank k: threshold-equal cells take the `need` slots in CELL-INDEX order = (workgroup, thread, cell of the thread) order
     unsigned total;
-    const unsigned before = mc_scan(eq ? 1u : 0u, sh, total);
+    const unsigned before = mc_scan(neq, sh, total);
     unsigned* ec = ws + 16800 + MC_MAXWG * s;
     if (threadIdx.x == 0) __hip_atomic_store(ec + blockIdx.x, total, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     ok = mc_barrier(bar, nwg, ++ph, sh) && ok;
@@ -906,9 +930,11 @@ __device__ __forceinline__ bool mc_select(unsigned key, bool valid, int k, unsig
         sh.base_rank = b;
     }
     __syncthreads();
-    if (eq && sh.base_rank + before < need) m = true;
+    unsigned r = sh.base_rank + before;
+#pragma unroll
+    for (int u = 0; u < CPT; ++u)
+        if (eq[u]) { if (r < need) m[u] = true; ++r; }
     __syncthreads();
-    return m;
 }
 
 struct McArgs {
@@ -917,8 +943,11 @@ struct McArgs {
     float* m_ada; float* m_rnd; float* mask; unsigned* ws;
 };
 
-// the mask role: workgroups 0 .. nwg-1 of the launch (a cell per thread)
-template <bool ADAPTIVE>
+// the mask role: workgroups 0 .. nwg-1 of the launch.  CPT consecutive cells per thread: 1 up to 131 072 cells (the single-rank shapes and two
+// data-parallel ranks), 2 / 4 beyond — the global batch of up to EIGHT bench-shape ranks (522 240 cells) still runs on <= 128 workgroups, i.e. with the
+// barrier cost and the residency margin of the small grid (r06; the multi-launch select took 119 us there against ~34 for this launch at one rank,
+// gpurun_out/r06w8.txt)
+template <bool ADAPTIVE, int CPT>
 __device__ __forceinline__ void mc_mask_body(const McArgs& g, unsigned nwg) {
     const int* __restrict__ label = g.label; const int* __restrict__ list_c = g.list_c; const int* __restrict__ nums = g.nums;
     const float* __restrict__ noise_a = g.noise_a; const float* __restrict__ noise_r = g.noise_r;
@@ -926,23 +955,30 @@ __device__ __forceinline__ void mc_mask_body(const McArgs& g, unsigned nwg) {
     float* __restrict__ m_ada = g.m_ada; float* __restrict__ m_rnd = g.m_rnd; float* __restrict__ mask = g.mask;
     unsigned* __restrict__ ws = g.ws;
     __shared__ McShared sh;
-    const int t = threadIdx.x, i = blockIdx.x * MC_T + t;
-    const bool valid = i < M;
+    const int t = threadIdx.x, i0 = (blockIdx.x * MC_T + t) * CPT;
     unsigned ph = 0u, bad = 0u;
     bool ok = true;
     unsigned* bar = ws + 16768;
-    const int ic = valid ? i : M - 1;
-    const float na = noise_a[ic];
-    const float nr = ADAPTIVE ? noise_r[ic] : 0.f;
-    const int lab = ADAPTIVE ? (label[ic] & 255) : 0;
-    const unsigned ka24 = mu_key(na, bad), kr24 = ADAPTIVE ? mu_key(nr, bad) : 0u;        // (every value is checked, eligible or not)
+    bool valid[CPT], ma[CPT], mr[CPT];
+    unsigned ka24[CPT], kr24[CPT];
+    int lab[CPT];
+#pragma unroll
+    for (int u = 0; u < CPT; ++u) {
+        valid[u] = i0 + u < M;
+        const int ic = valid[u] ? i0 + u : M - 1;
+        const float na = noise_a[ic];
+        const float nr = ADAPTIVE ? noise_r[ic] : 0.f;
+        lab[u] = ADAPTIVE ? (label[ic] & 255) : 0;
+        ka24[u] = mu_key(na, bad); kr24[u] = ADAPTIVE ? mu_key(nr, bad) : 0u;              // (every value is checked, eligible or not)
+        ma[u] = false; mr[u] = false;
+    }
     if (bad) atomicOr(ws + 16769, 1u);
-    bool ma = false, mr = false;
     if constexpr (ADAPTIVE) {
         // class histogram (GPTST.py:344-345 bincount): LDS per workgroup, one global atomic per class and workgroup
         for (int h = t; h < 256; h += MC_T) sh.counts[h] = 0;
         __syncthreads();
-        if (valid) atomicAdd(&sh.counts[lab], 1);
+#pragma unroll
+        for (int u = 0; u < CPT; ++u) if (valid[u]) atomicAdd(&sh.counts[lab[u]], 1);
         __syncthreads();
         int* gc = reinterpret_cast<int*>(ws + 16384);
         for (int h = t; h < HS; h += MC_T) if (sh.counts[h]) atomicAdd(gc + h, sh.counts[h]);
@@ -964,37 +1000,47 @@ __device__ __forceinline__ void mc_mask_body(const McArgs& g, unsigned nwg) {
         }
         __syncthreads();
         const int ka = sh.cls.ka;
-        const bool da = valid && sh.cls.d[lab] != 0;
-        const unsigned keyA = (valid && sh.cls.f[lab]) ? ka24 : 0u;                        // :390
+        bool da[CPT];
+        unsigned keyA[CPT], keyR[CPT];
+#pragma unroll
+        for (int u = 0; u < CPT; ++u) {
+            da[u] = valid[u] && sh.cls.d[lab[u]] != 0;
+            keyA[u] = (valid[u] && sh.cls.f[lab[u]]) ? ka24[u] : 0u;                      // :390
+        }
         __syncthreads();
-        ma = mc_select(keyA, valid, ka, ws, 0, nwg, ph, sh, ok) || da;                     // :386-397
-        const unsigned keyR = ma ? 0u : kr24;                                              // :401
-        mr = mc_select(keyR, valid, nums[1], ws, 1, nwg, ph, sh, ok);                      // :399-413
+        mc_select<CPT>(keyA, valid, ka, ws, 0, nwg, ph, sh, ok, ma);                       // :386-397
+#pragma unroll
+        for (int u = 0; u < CPT; ++u) { ma[u] = ma[u] || da[u]; keyR[u] = ma[u] ? 0u : kr24[u]; }      // :401
+        mc_select<CPT>(keyR, valid, nums[1], ws, 1, nwg, ph, sh, ok, mr);                  // :399-413
     } else {
-        mr = mc_select(ka24, valid, k_const, ws, 0, nwg, ph, sh, ok);                      // :316-321
+        mc_select<CPT>(ka24, valid, k_const, ws, 0, nwg, ph, sh, ok, mr);                  // :316-321
     }
     // the lattice flag: every workgroup raised it before its first barrier; a launch without any barrier (k = 0 everywhere) reads what is there
     const bool poison = !ok || mc_ld(ws + 16769) != 0u;
     const float nan = __int_as_float(0x7fc00000);
-    if (!valid) return;
-    const float va = ma ? 0.f : 1.f, vr = mr ? 0.f : 1.f;
-    if (ADAPTIVE) {
-        if (m_ada) m_ada[i] = poison ? nan : va;
-        if (m_rnd) m_rnd[i] = poison ? nan : vr;
-        const float f = poison ? nan : va * vr;
-        for (int j = 0; j < base; ++j) mask[(size_t)i * base + j] = f;
-    } else {
-        mask[i] = poison ? nan : vr;
+#pragma unroll
+    for (int u = 0; u < CPT; ++u) {
+        if (!valid[u]) continue;
+        const int i = i0 + u;
+        const float va = ma[u] ? 0.f : 1.f, vr = mr[u] ? 0.f : 1.f;
+        if (ADAPTIVE) {
+            if (m_ada) m_ada[i] = poison ? nan : va;
+            if (m_rnd) m_rnd[i] = poison ? nan : vr;
+            const float f = poison ? nan : va * vr;
+            for (int j = 0; j < base; ++j) mask[(size_t)i * base + j] = f;
+        } else {
+            mask[i] = poison ? nan : vr;
+        }
     }
 }
 
-template <bool ADAPTIVE>
-__global__ __launch_bounds__(MC_T) void mc_mask_kernel(McArgs g) { mc_mask_body<ADAPTIVE>(g, gridDim.x); }
+template <bool ADAPTIVE, int CPT>
+__global__ __launch_bounds__(MC_T) void mc_mask_kernel(McArgs g) { mc_mask_body<ADAPTIVE, CPT>(g, gridDim.x); }
 
 // r05: the same launch also runs a table of forward generation jobs (poolgen_dev.h) on workgroups nmask, nmask+1, ..: each 256-thread quarter of a
 // workgroup takes one 256-thread job block.  The jobs do not depend on the mask nor the mask on them; the 64 mask workgroups are latency-bound
 // (five grid barriers) on 64 CUs, the jobs are write-bound on all of them.  The mask workgroups come FIRST in dispatch order: all resident at once.
-template <bool ADAPTIVE>
+template <bool ADAPTIVE, int CPT>
 __global__ __launch_bounds__(MC_T) void mc_mask_jobs_kernel(McArgs g, unsigned nmask, PJobs t, int nf, int nvb, int fwd_rows) {
     if (blockIdx.x >= nmask) {
         const int nfw = (nvb + MC_T / 256 - 1) / (MC_T / 256);              // workgroups of the forward jobs; behind them one workgroup per graph-job block
@@ -1016,7 +1062,7 @@ __global__ __launch_bounds__(MC_T) void mc_mask_jobs_kernel(McArgs g, unsigned n
         pj_fwd_mfma(a, rel % a.nbx, rel / a.nbx, fwd_rows, threadIdx.x & 255);
         return;
     }
-    mc_mask_body<ADAPTIVE>(g, nmask);
+    mc_mask_body<ADAPTIVE, CPT>(g, nmask);
 }
 
 // The grid barriers need every mask workgroup resident at once: workgroups the device can hold = CUs x occupancy of the kernel (queried once per kernel
@@ -1062,10 +1108,13 @@ extern "C" int gptst_mask_random_u24(const float* noise, int M, int k, float* ma
         GPTST_CHECK_LAUNCH();
         return GPTST_OK;
     }
-    if (g_ms_coop && g_ms_force_multi == 0 && ws && M <= MC_T * MC_MAXWG && mc_fits(mc_mask_kernel<false>, (M + MC_T - 1) / MC_T)) {   // r05: one cooperative launch, a cell per thread
+    if (g_ms_coop && g_ms_force_multi == 0 && ws && M <= MC_MAXM && mc_fits(mc_mask_kernel<false, 1>, mc_nwg(M))) {   // r05: one cooperative launch
         if (!ws_zeroed) hipLaunchKernelGGL(ms_zero_kernel, dim3(24), dim3(256), 0, (hipStream_t)stream, (unsigned*)ws, MS_WS_WORDS);
         const McArgs g{nullptr, nullptr, nullptr, noise, nullptr, 0, M, 0, 1, k, nullptr, nullptr, mask, (unsigned*)ws};
-        hipLaunchKernelGGL((mc_mask_kernel<false>), dim3((M + MC_T - 1) / MC_T), dim3(MC_T), 0, (hipStream_t)stream, g);
+        const int cpt = mc_cpt(M);
+        if (cpt == 1) hipLaunchKernelGGL((mc_mask_kernel<false, 1>), dim3(mc_nwg(M)), dim3(MC_T), 0, (hipStream_t)stream, g);
+        else if (cpt == 2) hipLaunchKernelGGL((mc_mask_kernel<false, 2>), dim3(mc_nwg(M)), dim3(MC_T), 0, (hipStream_t)stream, g);
+        else hipLaunchKernelGGL((mc_mask_kernel<false, 4>), dim3(mc_nwg(M)), dim3(MC_T), 0, (hipStream_t)stream, g);
         GPTST_CHECK_LAUNCH();
         return GPTST_OK;
     }
@@ -1083,10 +1132,13 @@ extern "C" int gptst_mask_adaptive_u24(const int* label, const int* counts, cons
         GPTST_CHECK_LAUNCH();
         return GPTST_OK;
     }
-    if (g_ms_coop && g_ms_force_multi == 0 && ws && M <= MC_T * MC_MAXWG && mc_fits(mc_mask_kernel<true>, (M + MC_T - 1) / MC_T)) {    // r05: one cooperative launch (the class histogram is taken inside)
+    if (g_ms_coop && g_ms_force_multi == 0 && ws && M <= MC_MAXM && mc_fits(mc_mask_kernel<true, 1>, mc_nwg(M))) {    // r05: one cooperative launch (the class histogram is taken inside)
         if (!ws_zeroed) hipLaunchKernelGGL(ms_zero_kernel, dim3(24), dim3(256), 0, (hipStream_t)stream, (unsigned*)ws, MS_WS_WORDS);
         const McArgs g{label, list_c, nums, noise_a, noise_r, ada_all, M, HS, base, 0, m_ada, m_rnd, mask, (unsigned*)ws};
-        hipLaunchKernelGGL((mc_mask_kernel<true>), dim3((M + MC_T - 1) / MC_T), dim3(MC_T), 0, (hipStream_t)stream, g);
+        const int cpt = mc_cpt(M);
+        if (cpt == 1) hipLaunchKernelGGL((mc_mask_kernel<true, 1>), dim3(mc_nwg(M)), dim3(MC_T), 0, (hipStream_t)stream, g);
+        else if (cpt == 2) hipLaunchKernelGGL((mc_mask_kernel<true, 2>), dim3(mc_nwg(M)), dim3(MC_T), 0, (hipStream_t)stream, g);
+        else hipLaunchKernelGGL((mc_mask_kernel<true, 4>), dim3(mc_nwg(M)), dim3(MC_T), 0, (hipStream_t)stream, g);
         GPTST_CHECK_LAUNCH();
         return GPTST_OK;
     }
@@ -1111,19 +1163,22 @@ extern "C" int gptst_mask_u24_fwd_jobs(int adaptive, const int* label, const int
                  : (!noise_a || !mask || M <= 0 || k < 0 || k > M)) return GPTST_EARG;
     PJobs t;
     int nf = 0, nvb = 0, ngw = 0;
-    const bool coop = g_ms_coop && g_ms_force_multi == 0 && ws && M > MSS_MAXM && M <= MC_T * MC_MAXWG &&
-                      (adaptive ? mc_fits(mc_mask_jobs_kernel<true>, (M + MC_T - 1) / MC_T) : mc_fits(mc_mask_jobs_kernel<false>, (M + MC_T - 1) / MC_T));
+    const bool coop = g_ms_coop && g_ms_force_multi == 0 && ws && M > MSS_MAXM && M <= MC_MAXM &&
+                      (adaptive ? mc_fits(mc_mask_jobs_kernel<true, 1>, mc_nwg(M)) : mc_fits(mc_mask_jobs_kernel<false, 1>, mc_nwg(M)));
     if (coop && njobs > 0 && gptst_pj_embed_table(&t, njobs, kind, emb, pool, out, R, K, cols, &nf, &nvb, &ngw) == GPTST_OK) {
         if (!ws_zeroed) hipLaunchKernelGGL(ms_zero_kernel, dim3(24), dim3(256), 0, (hipStream_t)stream, (unsigned*)ws, MS_WS_WORDS);
-        const unsigned nmask = (unsigned)((M + MC_T - 1) / MC_T);
+        const unsigned nmask = (unsigned)mc_nwg(M);
+        const int cpt = mc_cpt(M);
         const dim3 grid(nmask + (unsigned)((nvb + MC_T / 256 - 1) / (MC_T / 256)) + (unsigned)ngw);
+#define MC_JOBS_LAUNCH(AD, CP) hipLaunchKernelGGL((mc_mask_jobs_kernel<AD, CP>), grid, dim3(MC_T), 0, (hipStream_t)stream, g, nmask, t, nf, nvb, PG_MFMA_ROWS)
         if (adaptive) {
             const McArgs g{label, list_c, nums, noise_a, noise_r, ada_all, M, HS, base, 0, m_ada, m_rnd, mask, (unsigned*)ws};
-            hipLaunchKernelGGL((mc_mask_jobs_kernel<true>), grid, dim3(MC_T), 0, (hipStream_t)stream, g, nmask, t, nf, nvb, PG_MFMA_ROWS);
+            if (cpt == 1) MC_JOBS_LAUNCH(true, 1); else if (cpt == 2) MC_JOBS_LAUNCH(true, 2); else MC_JOBS_LAUNCH(true, 4);
         } else {
             const McArgs g{nullptr, nullptr, nullptr, noise_a, nullptr, 0, M, 0, 1, k, nullptr, nullptr, mask, (unsigned*)ws};
-            hipLaunchKernelGGL((mc_mask_jobs_kernel<false>), grid, dim3(MC_T), 0, (hipStream_t)stream, g, nmask, t, nf, nvb, PG_MFMA_ROWS);
+            if (cpt == 1) MC_JOBS_LAUNCH(false, 1); else if (cpt == 2) MC_JOBS_LAUNCH(false, 2); else MC_JOBS_LAUNCH(false, 4);
         }
+#undef MC_JOBS_LAUNCH
         GPTST_CHECK_LAUNCH();
         return GPTST_OK;
     }

@@ -13,7 +13,7 @@ class FakeDP:
     def __init__(self, world): self.world, self.rank = world, 0
     def allreduce_(self, buf): return buf
     def gather_labels(self, local, out=None):
-        for r in range(self.world): out[r * local.numel():(r + 1) * local.numel()].copy_(local)
+        out.view(self.world, -1).copy_(local.view(1, -1).expand(self.world, -1))      # ONE launch, as the real all-gather is (W copies cost 45 us at W = 8)
         return out
     def rows_of(self, flat_global, per_rank): return flat_global[:per_rank]
     def barrier(self): pass
