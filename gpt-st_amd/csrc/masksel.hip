@@ -806,9 +806,9 @@ __global__ __launch_bounds__(MU_T) void mu_mask_kernel(const int* __restrict__ l
 // ======================================================================================================================
 GPTST_HANDOFF_COUNTER(masksel)
 #define MC_T 1024
-#define MC_MAXWG 128     // workgroups of the mask role; 1 / 2 / 4 cells per thread: 131 072 / 262 144 / 524 288 cells (r06: the global batch of up to eight bench-shape ranks)
-#define MC_MAXM (4 * MC_T * MC_MAXWG)
-static inline int mc_cpt(int M) { return M <= MC_T * MC_MAXWG ? 1 : M <= 2 * MC_T * MC_MAXWG ? 2 : 4; }      // cells per thread
+#define MC_MAXWG 128     // workgroups of the mask role; 1 / 2 / 4 / 8 cells per thread: 131 072 / 262 144 / 524 288 / 1 048 576 cells (r06: the global batch of eight ranks at the PEMS08, METR_LA and NYC_TAXI shapes)
+#define MC_MAXM (8 * MC_T * MC_MAXWG)
+static inline int mc_cpt(int M) { return M <= MC_T * MC_MAXWG ? 1 : M <= 2 * MC_T * MC_MAXWG ? 2 : M <= 4 * MC_T * MC_MAXWG ? 4 : 8; }      // cells per thread
 static inline int mc_nwg(int M) { const int c = mc_cpt(M) * MC_T; return (M + c - 1) / c; }
 static_assert(16800 + 2 * MC_MAXWG <= MS_WS_WORDS, "tie counts beyond the mask workspace");
 struct McShared {
@@ -944,7 +944,7 @@ struct McArgs {
 };
 
 // the mask role: workgroups 0 .. nwg-1 of the launch.  CPT consecutive cells per thread: 1 up to 131 072 cells (the single-rank shapes and two
-// data-parallel ranks), 2 / 4 beyond — the global batch of up to EIGHT bench-shape ranks (522 240 cells) still runs on <= 128 workgroups, i.e. with the
+// data-parallel ranks), 2 / 4 / 8 beyond — the global batch of up to EIGHT ranks (522 240 cells at the bench shape, 817 152 at NYC_TAXI's) still runs on <= 128 workgroups, i.e. with the
 // barrier cost and the residency margin of the small grid (r06; the multi-launch select took 119 us there against ~34 for this launch at one rank,
 // gpurun_out/r06w8.txt)
 template <bool ADAPTIVE, int CPT>
@@ -1070,18 +1070,36 @@ __global__ __launch_bounds__(MC_T) void mc_mask_jobs_kernel(McArgs g, unsigned n
 // all-reduce under the data-parallel bucket overlap, another process — so the launch is taken only with HALF the slots to spare: at most
 // MC_MAXWG = 128 mask workgroups against >= 256 slots on an MI355X.  (The job workgroups of mc_mask_jobs_kernel sit behind the mask workgroups in block
 // order and take no part in the barriers.)  A mask workgroup that is not resident after all ends in the bounded wait -> NaN -> the steppers' safe mode.
-template <typename K>
-static bool mc_fits(K kernel, int nwg) {
-    static thread_local int cap = -1, cap_dev = -1;
+static bool mc_fits_ptr(const void* kernel, int nwg) {
+    // (capacity cached per kernel AND device: the instantiations share one function type, so a per-type static would mix them up)
+    struct Ent { const void* k; int dev, cap; };
+    static thread_local Ent tab[16];
+    static thread_local int ntab = 0;
     int dev = 0;
     if (hipGetDevice(&dev) != hipSuccess) return false;
-    if (cap < 0 || dev != cap_dev) {
+    int cap = -1;
+    for (int i = 0; i < ntab; ++i) if (tab[i].k == kernel && tab[i].dev == dev) cap = tab[i].cap;
+    if (cap < 0) {
         int ncu = 0, per = 0;
         if (hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess ||
-            hipOccupancyMaxActiveBlocksPerMultiprocessor(&per, (const void*)kernel, MC_T, 0) != hipSuccess) { ncu = 0; per = 0; }
-        cap = ncu * per; cap_dev = dev;
+            hipOccupancyMaxActiveBlocksPerMultiprocessor(&per, kernel, MC_T, 0) != hipSuccess) { ncu = 0; per = 0; }
+        cap = ncu * per;
+        if (ntab < 16) tab[ntab++] = Ent{kernel, dev, cap};
     }
     return 2 * nwg <= cap;
+}
+// ... of the instantiation that M cells would launch
+template <bool ADAPTIVE, bool JOBS>
+static bool mc_fits(int M) {
+    const int nwg = mc_nwg(M);
+#define MC_PTR(CP) (JOBS ? (const void*)mc_mask_jobs_kernel<ADAPTIVE, CP> : (const void*)mc_mask_kernel<ADAPTIVE, CP>)
+    switch (mc_cpt(M)) {
+        case 1: return mc_fits_ptr(MC_PTR(1), nwg);
+        case 2: return mc_fits_ptr(MC_PTR(2), nwg);
+        case 4: return mc_fits_ptr(MC_PTR(4), nwg);
+        default: return mc_fits_ptr(MC_PTR(8), nwg);
+    }
+#undef MC_PTR
 }
 
 thread_local int g_ms_coop = MS_COOP_DEFAULT;              // (thread-local like the other launch-mode knobs: ranks emulated by threads) gptst_mask_cooperative(0): the multi-launch path instead of the cooperative launch (the steppers' fallback after a lost hand-off; A/B; tests)
@@ -1108,13 +1126,14 @@ extern "C" int gptst_mask_random_u24(const float* noise, int M, int k, float* ma
         GPTST_CHECK_LAUNCH();
         return GPTST_OK;
     }
-    if (g_ms_coop && g_ms_force_multi == 0 && ws && M <= MC_MAXM && mc_fits(mc_mask_kernel<false, 1>, mc_nwg(M))) {   // r05: one cooperative launch
+    if (g_ms_coop && g_ms_force_multi == 0 && ws && M <= MC_MAXM && mc_fits<false, false>(M)) {   // r05: one cooperative launch
         if (!ws_zeroed) hipLaunchKernelGGL(ms_zero_kernel, dim3(24), dim3(256), 0, (hipStream_t)stream, (unsigned*)ws, MS_WS_WORDS);
         const McArgs g{nullptr, nullptr, nullptr, noise, nullptr, 0, M, 0, 1, k, nullptr, nullptr, mask, (unsigned*)ws};
         const int cpt = mc_cpt(M);
         if (cpt == 1) hipLaunchKernelGGL((mc_mask_kernel<false, 1>), dim3(mc_nwg(M)), dim3(MC_T), 0, (hipStream_t)stream, g);
         else if (cpt == 2) hipLaunchKernelGGL((mc_mask_kernel<false, 2>), dim3(mc_nwg(M)), dim3(MC_T), 0, (hipStream_t)stream, g);
-        else hipLaunchKernelGGL((mc_mask_kernel<false, 4>), dim3(mc_nwg(M)), dim3(MC_T), 0, (hipStream_t)stream, g);
+        else if (cpt == 4) hipLaunchKernelGGL((mc_mask_kernel<false, 4>), dim3(mc_nwg(M)), dim3(MC_T), 0, (hipStream_t)stream, g);
+        else hipLaunchKernelGGL((mc_mask_kernel<false, 8>), dim3(mc_nwg(M)), dim3(MC_T), 0, (hipStream_t)stream, g);
         GPTST_CHECK_LAUNCH();
         return GPTST_OK;
     }
@@ -1132,13 +1151,14 @@ extern "C" int gptst_mask_adaptive_u24(const int* label, const int* counts, cons
         GPTST_CHECK_LAUNCH();
         return GPTST_OK;
     }
-    if (g_ms_coop && g_ms_force_multi == 0 && ws && M <= MC_MAXM && mc_fits(mc_mask_kernel<true, 1>, mc_nwg(M))) {    // r05: one cooperative launch (the class histogram is taken inside)
+    if (g_ms_coop && g_ms_force_multi == 0 && ws && M <= MC_MAXM && mc_fits<true, false>(M)) {    // r05: one cooperative launch (the class histogram is taken inside)
         if (!ws_zeroed) hipLaunchKernelGGL(ms_zero_kernel, dim3(24), dim3(256), 0, (hipStream_t)stream, (unsigned*)ws, MS_WS_WORDS);
         const McArgs g{label, list_c, nums, noise_a, noise_r, ada_all, M, HS, base, 0, m_ada, m_rnd, mask, (unsigned*)ws};
         const int cpt = mc_cpt(M);
         if (cpt == 1) hipLaunchKernelGGL((mc_mask_kernel<true, 1>), dim3(mc_nwg(M)), dim3(MC_T), 0, (hipStream_t)stream, g);
         else if (cpt == 2) hipLaunchKernelGGL((mc_mask_kernel<true, 2>), dim3(mc_nwg(M)), dim3(MC_T), 0, (hipStream_t)stream, g);
-        else hipLaunchKernelGGL((mc_mask_kernel<true, 4>), dim3(mc_nwg(M)), dim3(MC_T), 0, (hipStream_t)stream, g);
+        else if (cpt == 4) hipLaunchKernelGGL((mc_mask_kernel<true, 4>), dim3(mc_nwg(M)), dim3(MC_T), 0, (hipStream_t)stream, g);
+        else hipLaunchKernelGGL((mc_mask_kernel<true, 8>), dim3(mc_nwg(M)), dim3(MC_T), 0, (hipStream_t)stream, g);
         GPTST_CHECK_LAUNCH();
         return GPTST_OK;
     }
@@ -1164,7 +1184,7 @@ extern "C" int gptst_mask_u24_fwd_jobs(int adaptive, const int* label, const int
     PJobs t;
     int nf = 0, nvb = 0, ngw = 0;
     const bool coop = g_ms_coop && g_ms_force_multi == 0 && ws && M > MSS_MAXM && M <= MC_MAXM &&
-                      (adaptive ? mc_fits(mc_mask_jobs_kernel<true, 1>, mc_nwg(M)) : mc_fits(mc_mask_jobs_kernel<false, 1>, mc_nwg(M)));
+                      (adaptive ? mc_fits<true, true>(M) : mc_fits<false, true>(M));
     if (coop && njobs > 0 && gptst_pj_embed_table(&t, njobs, kind, emb, pool, out, R, K, cols, &nf, &nvb, &ngw) == GPTST_OK) {
         if (!ws_zeroed) hipLaunchKernelGGL(ms_zero_kernel, dim3(24), dim3(256), 0, (hipStream_t)stream, (unsigned*)ws, MS_WS_WORDS);
         const unsigned nmask = (unsigned)mc_nwg(M);
@@ -1173,10 +1193,10 @@ extern "C" int gptst_mask_u24_fwd_jobs(int adaptive, const int* label, const int
 #define MC_JOBS_LAUNCH(AD, CP) hipLaunchKernelGGL((mc_mask_jobs_kernel<AD, CP>), grid, dim3(MC_T), 0, (hipStream_t)stream, g, nmask, t, nf, nvb, PG_MFMA_ROWS)
         if (adaptive) {
             const McArgs g{label, list_c, nums, noise_a, noise_r, ada_all, M, HS, base, 0, m_ada, m_rnd, mask, (unsigned*)ws};
-            if (cpt == 1) MC_JOBS_LAUNCH(true, 1); else if (cpt == 2) MC_JOBS_LAUNCH(true, 2); else MC_JOBS_LAUNCH(true, 4);
+            if (cpt == 1) MC_JOBS_LAUNCH(true, 1); else if (cpt == 2) MC_JOBS_LAUNCH(true, 2); else if (cpt == 4) MC_JOBS_LAUNCH(true, 4); else MC_JOBS_LAUNCH(true, 8);
         } else {
             const McArgs g{nullptr, nullptr, nullptr, noise_a, nullptr, 0, M, 0, 1, k, nullptr, nullptr, mask, (unsigned*)ws};
-            if (cpt == 1) MC_JOBS_LAUNCH(false, 1); else if (cpt == 2) MC_JOBS_LAUNCH(false, 2); else MC_JOBS_LAUNCH(false, 4);
+            if (cpt == 1) MC_JOBS_LAUNCH(false, 1); else if (cpt == 2) MC_JOBS_LAUNCH(false, 2); else if (cpt == 4) MC_JOBS_LAUNCH(false, 4); else MC_JOBS_LAUNCH(false, 8);
         }
 #undef MC_JOBS_LAUNCH
         GPTST_CHECK_LAUNCH();

@@ -41,8 +41,8 @@ int gptst_handoff_timeouts(int* out);
  * caller re-runs the step without in-launch hand-offs and then clears the record with gptst_handoff_reset() (synchronises).
  * gptst_set_handoff_guard(0) turns the skip off (process-wide). */
 int gptst_handoff_reset(void);
-/* r05: gptst_mask_random_u24 / gptst_mask_adaptive_u24 with a workspace and 8192 < M <= 524288 cells run as ONE launch of at most 128 workgroups of
- * 1024 threads (one cell per thread up to 131072 cells, two / four beyond — r06: the global batch of up to eight bench-shape data-parallel ranks; digit histograms in the workspace, grid barriers with the bounded wait above; every workgroup is resident: at most
+/* r05: gptst_mask_random_u24 / gptst_mask_adaptive_u24 with a workspace and 8192 < M <= 1048576 cells run as ONE launch of at most 128 workgroups of
+ * 1024 threads (one cell per thread up to 131072 cells, two / four / eight beyond — r06: the global batch of up to eight bench-shape data-parallel ranks; digit histograms in the workspace, grid barriers with the bounded wait above; every workgroup is resident: at most
  * 128 on 256 CUs; the launcher takes this form only while the grid is at most HALF of what the device holds).  0: the multi-launch radix select instead (what a stepper falls back to after a lost hand-off); 1: on; < 0: the build's default
  * (on).  Thread-local (r06), like the other launch-mode switches.  Same masks bit for bit either way.  gptst_mask_cooperative_state(): the calling thread's setting (0 / 1) —
  * a scope that switches the form off restores what it found. */
@@ -383,7 +383,7 @@ int gptst_mask_adaptive_u24(const int* label, const int* counts, const int* list
 /* r05 — gptst_pool_jobs with njobs generation jobs (kind[j] 0: out_j (R_j, cols_j) = emb_j (R_j, K_j) @ pool_j (K_j, cols_j), or 3: the temporal graphs of
  * gptst_pool_jobs; kind NULL: all 0; no gradient kinds) followed by gptst_mask_random_u24
  * (adaptive == 0: noise_a is the noise, k the number of cells to drop) or gptst_mask_adaptive_u24 (adaptive != 0; k unused) — in ONE launch when the mask
- * takes the cooperative form (gptst_mask_cooperative, 8192 < M <= 524288, ws given) and every forward job has cols % 4 == 0: the (at most 128) mask workgroups are
+ * takes the cooperative form (gptst_mask_cooperative, 8192 < M <= 1048576, ws given) and every forward job has cols % 4 == 0: the (at most 128) mask workgroups are
  * latency-bound on as many CUs, the jobs are write-bound on all of them, and neither depends on the other (the steppers: the generated parameters of the
  * two STHCNs next to the mask that the guide's output selects).  Otherwise exactly those two calls.  Same results bit for bit either way. */
 int gptst_mask_u24_fwd_jobs(int adaptive, const int* label, const int* counts, const int* list_c, const int* nums, const float* noise_a,

@@ -1284,7 +1284,8 @@ def test_step_begin_draws_philox_noise():
     assert float((noise2.cpu() == u).float().mean()) < 1e-3
 
 
-@pytest.mark.parametrize("W", [2, 8, 32, 64])   # 32 / 64: 261 120 / 522 240 cells = the global batch of four / eight bench-shape ranks (two / four cells per thread of the cooperative launch, r06)
+@pytest.mark.parametrize("W", [2, 8, 32, 64, 100])   # 32 / 64 / 100: 261 120 / 522 240 / 816 000 cells = the global batch of four / eight bench-shape ranks / eight NYC_TAXI-shape
+                                                      # ranks (two / four / eight cells per thread of the cooperative launch, r06)
 def test_mask_generation_over_a_global_batch(W):
     """Data parallel with global masks: every rank selects over world x B*T*N cells — more selection workgroups than the single-rank 64
     (one per 1024 cells, up to 512); bit-exact against the oracle for both phases."""
